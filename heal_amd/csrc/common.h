@@ -1,0 +1,76 @@
+// Shared host/device helpers for libheal_amd (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define HEAL_WAVE 64
+
+namespace heal {
+
+// thread-local last error text, exposed through heal_last_error()
+char* err_buf();
+int set_error(const char* fmt, ...);
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bump allocator over the caller-provided workspace.
+struct Arena {
+    char* base; size_t cap; size_t off;
+    Arena(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+    template <typename T> T* take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T));
+        T* r = (T*)(base + off);
+        off += bytes;
+        return r;
+    }
+    bool ok() const { return off <= cap && (base != nullptr || off == 0); }
+};
+
+#define HEAL_HIP(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return heal::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                   __FILE__, __LINE__);                                     \
+    } while (0)
+
+#define HEAL_REQUIRE(cond, ...)                       \
+    do {                                              \
+        if (!(cond)) return heal::set_error(__VA_ARGS__); \
+    } while (0)
+
+#define HEAL_LAUNCH_CHECK() HEAL_HIP(hipGetLastError())
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+}  // namespace heal

@@ -1,0 +1,181 @@
+// K2 -- fused pillar feature net (PillarVFE + PFNLayer) and scatter to the dense BEV canvas.
+//
+// Reference arithmetic: opencood/models/sub_modules/pillar_vfe.py:105-155 (feature decoration and
+// padding mask), :31-53 (Linear(10->64, no bias) -> eval BatchNorm1d(eps 1e-3) -> ReLU -> max over
+// the P rows INCLUDING the zeroed padding rows), opencood/models/sub_modules/point_pillar_scatter.py:
+// 19-76 (canvas[:, z + y*nx + x] = pillar, one zero canvas per agent).
+//
+// MI355X formulation
+//   k_pfn     one 64-lane wave per pillar, lane = output channel.  The P x 10 decorated features
+//             are staged in LDS and read back as broadcasts, each lane runs the 10-term dot product
+//             for its channel, BN scale/shift, ReLU and the running max.  The pillar's canvas cell
+//             is recorded in an index map (cell -> pillar id).
+//   k_canvas  one pass over the WHOLE canvas: each thread owns 4 consecutive x cells, reads their
+//             pillar ids once and streams 16-B stores for every channel (zeros where the cell is
+//             empty).  The 67 MB/agent canvas is therefore written exactly once -- no memset pass
+//             followed by a scatter pass -- which is what the HBM roofline of this operator allows.
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+constexpr int PFN_C = 64;
+constexpr int PFN_FROW = 12;  // 10 features padded to 12 floats (16-B aligned rows)
+
+struct PfnGeom {
+    float vx, vy, vz, xo, yo, zo;
+    int n_agents, ny, nx;
+};
+
+__global__ __launch_bounds__(256) void k_pfn(const float4* __restrict__ voxels, int P,
+                                            const int4* __restrict__ coords,
+                                            const int* __restrict__ num_points, int n_voxels,
+                                            const int* __restrict__ n_voxels_dev,
+                                            const float* __restrict__ weight /*[64][10]*/,
+                                            const float* __restrict__ bn_scale,
+                                            const float* __restrict__ bn_shift, PfnGeom g,
+                                            float* __restrict__ pillar_feat /*[M][64]*/,
+                                            int* __restrict__ cell_map /*[n_agents][ny*nx]*/) {
+    __shared__ __attribute__((aligned(16))) float sfeat[4][64][PFN_FROW];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    int M = n_voxels;
+    if (n_voxels_dev != nullptr) M = min(M, *n_voxels_dev);
+
+    float w[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) w[k] = weight[l * 10 + k];
+    const float sc = bn_scale[l], sh = bn_shift[l];
+    const float pad_val = fmaxf(sh, 0.f);  // a zeroed row gives 0*W -> BN -> ReLU = relu(shift)
+
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        const int4 cd = coords[m];  // (b, z, y, x)
+        const int np = num_points[m];
+        float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < P) pt = voxels[(size_t)m * P + l];
+        // mean over the COUNT of the sum over all P rows (pillar_vfe.py:118-121)
+        const float fn = (float)np;
+        const float mx = wave_sum(pt.x) / fn;
+        const float my = wave_sum(pt.y) / fn;
+        const float mz = wave_sum(pt.z) / fn;
+        if (l < P) {
+            const bool live = l < np;
+            const float cxm = (float)cd.w * g.vx + g.xo;
+            const float cym = (float)cd.z * g.vy + g.yo;
+            const float czm = (float)cd.y * g.vz + g.zo;
+            float f[PFN_FROW];
+            f[0] = pt.x; f[1] = pt.y; f[2] = pt.z; f[3] = pt.w;
+            f[4] = pt.x - mx; f[5] = pt.y - my; f[6] = pt.z - mz;
+            f[7] = pt.x - cxm; f[8] = pt.y - cym; f[9] = pt.z - czm;
+            f[10] = 0.f; f[11] = 0.f;
+            float4* dst = reinterpret_cast<float4*>(&sfeat[wave][l][0]);
+            const float k = live ? 1.f : 0.f;  // features *= mask (pillar_vfe.py:145-149)
+            dst[0] = make_float4(f[0] * k, f[1] * k, f[2] * k, f[3] * k);
+            dst[1] = make_float4(f[4] * k, f[5] * k, f[6] * k, f[7] * k);
+            dst[2] = make_float4(f[8] * k, f[9] * k, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float best = (np < P) ? pad_val : 0.f;  // ReLU output is >= 0, so 0 is the identity of max
+        const int live_n = min(np, P);
+        for (int p = 0; p < live_n; ++p) {
+            const float4* src = reinterpret_cast<const float4*>(&sfeat[wave][p][0]);
+            const float4 a = src[0], b = src[1], c = src[2];
+            float acc = a.x * w[0];
+            acc = fmaf(a.y, w[1], acc); acc = fmaf(a.z, w[2], acc); acc = fmaf(a.w, w[3], acc);
+            acc = fmaf(b.x, w[4], acc); acc = fmaf(b.y, w[5], acc); acc = fmaf(b.z, w[6], acc);
+            acc = fmaf(b.w, w[7], acc); acc = fmaf(c.x, w[8], acc); acc = fmaf(c.y, w[9], acc);
+            const float y = fmaf(acc, sc, sh);
+            best = fmaxf(best, y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        pillar_feat[(size_t)m * PFN_C + l] = best;
+        if (l == 0) {
+            const int idx = cd.y + cd.z * g.nx + cd.w;  // z + y*nx + x (point_pillar_scatter.py:58)
+            if (cd.x >= 0 && cd.x < g.n_agents && idx >= 0 && idx < g.ny * g.nx)
+                atomicMax(&cell_map[(size_t)cd.x * g.ny * g.nx + idx], m);
+        }
+    }
+}
+
+// canvas[b][c][cell] = cell_map[b][cell] >= 0 ? pillar_feat[id][c] : 0, 4 cells per thread
+template <int CG /*channels per block*/>
+__global__ __launch_bounds__(256) void k_canvas(const int4* __restrict__ cell_map4,
+                                               const float* __restrict__ pillar_feat, int cells4,
+                                               int channels, float4* __restrict__ canvas4) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= cells4) return;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CG;
+    const int4 id = cell_map4[(size_t)b * cells4 + t];
+    float4* out = canvas4 + ((size_t)b * channels + c0) * cells4 + t;
+    if ((id.x & id.y & id.z & id.w) < 0) {  // all four empty (ids are -1)
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < CG; ++c) out[(size_t)c * cells4] = z;
+        return;
+    }
+#pragma unroll 4
+    for (int c = 0; c < CG; ++c) {
+        float4 v;
+        v.x = id.x >= 0 ? pillar_feat[(size_t)id.x * channels + c0 + c] : 0.f;
+        v.y = id.y >= 0 ? pillar_feat[(size_t)id.y * channels + c0 + c] : 0.f;
+        v.z = id.z >= 0 ? pillar_feat[(size_t)id.z * channels + c0 + c] : 0.f;
+        v.w = id.w >= 0 ? pillar_feat[(size_t)id.w * channels + c0 + c] : 0.f;
+        out[(size_t)c * cells4] = v;
+    }
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+// Shared with the BEV pool (K4): stream a dense [n,C,cells] canvas from a cell->row index map.
+int heal_canvas_from_map(const int* cell_map, const float* rows, int n_agents, int channels,
+                         int cells, float* canvas, hipStream_t s) {
+    HEAL_REQUIRE(cells % 4 == 0 && channels % 16 == 0, "canvas: cells %% 4 and channels %% 16 required");
+    const int cells4 = cells / 4;
+    dim3 grid(ceil_div(cells4, 256), channels / 16, n_agents);
+    k_canvas<16><<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), rows, cells4, channels,
+                                      reinterpret_cast<float4*>(canvas));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t heal_pfn_scatter_workspace(int n_voxels, int n_agents, int ny, int nx, int channels) {
+    size_t b = align_up((size_t)n_agents * ny * nx * sizeof(int));
+    b += align_up((size_t)(n_voxels < 1 ? 1 : n_voxels) * channels * sizeof(float));
+    return b + 256;
+}
+
+extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points,
+                                int n_voxels, const int32_t* n_voxels_dev, int max_points,
+                                const float* weight, const float* bn_scale, const float* bn_shift,
+                                int channels, float vx, float vy, float vz, float x_offset,
+                                float y_offset, float z_offset, int n_agents, int ny, int nx,
+                                float* canvas, float* pillar_feat, void* ws, size_t ws_bytes,
+                                void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(channels == PFN_C, "pfn_scatter: channels must be 64 (got %d)", channels);
+    HEAL_REQUIRE(max_points >= 1 && max_points <= 64, "pfn_scatter: max_points must be in [1,64]");
+    HEAL_REQUIRE(n_agents >= 1 && ny >= 1 && nx >= 1 && (nx * ny) % 4 == 0, "pfn_scatter: bad grid");
+    HEAL_REQUIRE(n_voxels >= 0, "pfn_scatter: negative n_voxels");
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "pfn_scatter: workspace must be 256-B aligned");
+    Arena a(ws, ws_bytes);
+    int* cell_map = a.take<int>((size_t)n_agents * ny * nx);
+    float* pf = pillar_feat;
+    if (pf == nullptr) pf = a.take<float>((size_t)(n_voxels < 1 ? 1 : n_voxels) * channels);
+    HEAL_REQUIRE(a.ok(), "pfn_scatter: workspace too small (%zu < %zu)", ws_bytes, a.off);
+
+    HEAL_HIP(hipMemsetAsync(cell_map, 0xFF, (size_t)n_agents * ny * nx * sizeof(int), s));
+    if (n_voxels > 0) {
+        PfnGeom g{vx, vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx};
+        const int blocks = min(ceil_div(n_voxels, 4), 256 * 8);
+        const float4* v4 = reinterpret_cast<const float4*>(voxels);
+        const int4* c4 = reinterpret_cast<const int4*>(coords);
+        k_pfn<<<blocks, 256, 0, s>>>(v4, max_points, c4, num_points, n_voxels, n_voxels_dev, weight,
+                                     bn_scale, bn_shift, g, pf, cell_map);
+        HEAL_LAUNCH_CHECK();
+    }
+    return heal_canvas_from_map(cell_map, pf, n_agents, channels, ny * nx, canvas, s);
+}

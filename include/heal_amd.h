@@ -1,0 +1,148 @@
+/*
+ * heal_amd.h -- C ABI of libheal_amd.so: the MI355X (gfx950) kernels of HEAL's per-frame
+ * perception hot path.
+ *
+ * The reference (yifanlu0227/HEAL) is pure Python; it has no FFI of its own.  Each entry point
+ * below replaces the arithmetic of one reference function (cited as file:line, paths relative to
+ * the reference root) and is what a ctypes stub on the reference side would bind.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous;
+ *   - `ws` is caller-owned device scratch of at least heal_*_workspace(...) bytes, 256-B aligned;
+ *   - return value: 0 on success, non-zero on error; heal_last_error() gives the message
+ *     (thread-local).  No call allocates, frees or synchronises.
+ *   - all floating point is fp32 unless stated, indices int32, layouts are C-contiguous.
+ */
+#ifndef HEAL_AMD_H
+#define HEAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEAL_AMD_ABI_VERSION 1
+
+int heal_abi_version(void);
+const char* heal_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  hard voxelisation (first-come, input-order semantics of spconv's point->voxel generator).
+ * Replaces: opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:62-85 (preprocess ->
+ *           spconv VoxelGeneratorV2.generate / Point2VoxelCPU3d.point_to_voxel) and the batch-index
+ *           prepend of collate_batch_list (:110-147).
+ *   points      [n_points,4] f32 (x,y,z,intensity)
+ *   range       host, 6 floats (xmin,ymin,zmin,xmax,ymax,zmax); voxel_size host, 3 floats
+ *   voxels      [cap,max_points,4] f32, rows [0,M) written (zero padded); cap = min(n_points,max_voxels)
+ *   coords      [cap,4] i32 (batch_idx,z,y,x), rows [0,M)
+ *   num_points  [cap] i32
+ *   n_voxels    [1] i32  <- M
+ * -----------------------------------------------------------------------------------------------*/
+size_t heal_voxelize_workspace(int n_points, int max_voxels);
+int heal_voxelize(const float* points, int n_points,
+                  const float* range_host, const float* voxel_size_host,
+                  int max_points, int max_voxels, int batch_idx,
+                  float* voxels, int32_t* coords, int32_t* num_points, int32_t* n_voxels,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  fused pillar feature net + scatter to the dense BEV canvas.
+ * Replaces: opencood/models/sub_modules/pillar_vfe.py:105-155 (PillarVFE.forward),
+ *           :31-53 (PFNLayer.forward, single last layer, use_norm, eval-mode BatchNorm1d),
+ *           opencood/models/sub_modules/point_pillar_scatter.py:19-76 (PointPillarScatter.forward).
+ *   voxels [M,P,4], coords [M,4] (b,z,y,x), num_points [M]
+ *   n_voxels_dev: optional device int; when non-NULL the kernels use min(*n_voxels_dev, M) pillars
+ *   weight [C,10] (nn.Linear weight), bn_scale[C] = gamma/sqrt(var+eps), bn_shift[C] = beta-mean*scale
+ *   canvas [n_agents,C,ny,nx] f32 -- every element is written (zeros where no pillar)
+ *   pillar_feat (optional, may be NULL) [M,C] f32 gets the PFN output (pillar_vfe.py:153)
+ *   C must be 64, P <= 64.
+ * -----------------------------------------------------------------------------------------------*/
+size_t heal_pfn_scatter_workspace(int n_voxels, int n_agents, int ny, int nx, int channels);
+int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points,
+                     int n_voxels, const int32_t* n_voxels_dev, int max_points,
+                     const float* weight, const float* bn_scale, const float* bn_shift, int channels,
+                     float vx, float vy, float vz, float x_offset, float y_offset, float z_offset,
+                     int n_agents, int ny, int nx,
+                     float* canvas, float* pillar_feat,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  warp to ego + occupancy-softmax weighted fusion over agents (one pyramid level, one scene).
+ * Replaces: opencood/models/fuse_modules/pyramid_fuse.py:17-63 (weighted_fuse) including
+ *           warp_affine_simple (opencood/models/sub_modules/torch_transformation_utils.py:323-332:
+ *           F.affine_grid + F.grid_sample bilinear / zeros / align_corners=False), the score
+ *           construction sigmoid(occ)+1e-4 (pyramid_fuse.py:145) and the eval-mode camera crop
+ *           mask (pyramid_fuse.py:147-162).
+ *   feats  [n_agents,C,H,W]; occ [n_agents,1,H,W] (logits of single_head_i)
+ *   affine_host: host, n_agents*6 doubles = rows of affine_matrix[b][0, a] (2x3) from
+ *                normalize_pairwise_tfm (opencood/utils/transformation_utils.py:68-92)
+ *   grid_f64: non-zero -> sampling grid computed in fp64 then rounded to fp32 (the reference's
+ *             behaviour when pairwise_t_matrix is float64), zero -> fp32 throughout
+ *   crop_host: host, n_agents*4 ints (h0,h1,w0,w1) rectangle where the camera score is KEPT
+ *              (outside -> score 0); h1<=h0 means "no mask" (lidar agent); may be NULL
+ *   out    [C,H,W]
+ * -----------------------------------------------------------------------------------------------*/
+int heal_warp_fuse(const float* feats, const float* occ, int n_agents, int channels, int H, int W,
+                   const double* affine_host, int grid_f64, const int32_t* crop_host,
+                   float* out, void* stream);
+
+/* Same operator split for agent-sharded execution: warp ONE agent's features and score
+ * into the ego frame (rank-local, before the all-gather) ...                                      */
+int heal_warp_agent(const float* feat, const float* occ, int channels, int H, int W,
+                    const double* affine_host, int grid_f64, const int32_t* crop_host,
+                    float* feat_ego, float* score_ego, void* stream);
+/* ... and fuse already-warped stacks (after the all-gather): -inf mask, softmax over agents, sum. */
+int heal_fuse_warped(const float* feats_ego, const float* scores_ego, int n_agents, int channels,
+                     int H, int W, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8  box decode + filters + rotated NMS.
+ * Replaces: opencood/data_utils/post_processor/voxel_postprocessor.py:245-405 (post_process),
+ *           :407-453 (delta_to_boxes3d), opencood/utils/box_utils.py:152-204 (boxes_to_corners_3d),
+ *           :278-316 (project_box3d), :840-890 (remove_large_pred_bbx, remove_bbx_abnormal_z),
+ *           :693-738 (nms_rotated, shapely IoU via common_utils.py:230-270),
+ *           :384-421 (mask_boxes_outside_range_numpy).
+ *   cls [A,H,W], reg [7A,H,W], dir [num_bins*A,H,W] (may be NULL), anchors [H,W,A,7] f32 (x,y,z,h,w,l,yaw)
+ *   tfm_host: host 16 floats row-major 4x4 (ego <- cav), order 'hwl'
+ *   gt_range_host: host 6 floats
+ *   out_corners [max_out,8,3] f32, out_scores [max_out] f32, out_count [1] i32 (<= max_out, max_out>=nms_top)
+ * -----------------------------------------------------------------------------------------------*/
+size_t heal_decode_nms_workspace(int anchors_total, int nms_top);
+int heal_decode_nms(const float* cls, const float* reg, const float* dir, const float* anchors,
+                    int H, int W, int anchor_num, int num_bins,
+                    float score_thr, float dir_offset, float nms_thr, int nms_top,
+                    const float* tfm_host, const float* gt_range_host,
+                    float* out_corners, float* out_scores, int32_t* out_count, int max_out,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* Pairwise rotated IoU of convex quads given as 4 (x,y) fp32 corners; fp64 geometry, fp32 result.
+ * Same arithmetic as the NMS above (common_utils.py:230-251 compute_iou).  a [n,4,2], b [m,4,2],
+ * iou [n,m].                                                                                       */
+int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  Lift-Splat frustum -> BEV pooling, fused with the depth softmax and the outer product.
+ * Replaces: opencood/models/heter_encoders.py:125-147 (get_geometry), :161-217 (voxel_pooling),
+ *           opencood/utils/camera_utils.py:220-236 (QuickCumsum.forward) and the
+ *           softmax(depth) (x) feat outer product of lss_submodule.py:129-134.
+ *   depth_logit [n_agents*n_cams,D,fH,fW]; feat [n_agents*n_cams,C,fH,fW]
+ *   frustum [D,fH,fW,3] f32 (create_frustum, heter_encoders.py:110-123)
+ *   cam_host: host, per (agent,cam) 27 floats: combine = rots @ inv(intrins) (9), inv(post_rots) (9),
+ *             post_trans (3), trans (3), pad (3)   -- the small matrix algebra stays on the host
+ *   dx,bx host 3 floats each, nx host 3 ints (gen_dx_bx, camera_utils.py:129-134)
+ *   out [n_agents, C*nz, ny, nx] f32, every element written
+ * -----------------------------------------------------------------------------------------------*/
+size_t heal_bev_pool_workspace(int n_agents, int n_cams, int D, int fH, int fW, int channels,
+                               int nx, int ny, int nz);
+int heal_bev_pool(const float* depth_logit, const float* feat, const float* frustum,
+                  const float* cam_host, int n_agents, int n_cams, int D, int fH, int fW, int channels,
+                  const float* dx_host, const float* bx_host, const int32_t* nx_host,
+                  float* out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEAL_AMD_H */

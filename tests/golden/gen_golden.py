@@ -1,0 +1,260 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference (build container only).
+
+    python -m tests.golden.gen_golden [name ...]
+
+Each fixture stores inputs and the reference's outputs only.  Model weights are never stored:
+they are a closed-form function of (state_dict key, index) -- tests/golden/detfill.py -- applied to
+the reference modules here and to this repo's modules / oracle at test time.
+"""
+import copy
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from heal_amd import synth
+from oracle import cref
+from tests.golden import ref_import as R
+from tests.golden.detfill import fill_module
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+YAML_DIR = "/root/reference/opencood/hypes_yaml/opv2v"
+SMALL_RANGE = [-25.6, -25.6, -3, 25.6, 25.6, 1]
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  " + ", ".join(
+        f"{k}{tuple(np.asarray(v).shape)}" for k, v in arrays.items()))
+
+
+def replace_ranges(d, new_range):
+    """inference.py:54-73 style recursive override of every *_range key."""
+    for k, v in list(d.items()):
+        if isinstance(v, dict):
+            replace_ranges(v, new_range)
+        elif k in ("cav_lidar_range", "lidar_range", "gt_range"):
+            d[k] = list(new_range)
+
+
+def small_lidar_inputs(seeds, lidar_range=SMALL_RANGE, voxel_size=(0.4, 0.4, 4), max_points=32,
+                       n_points=9000):
+    """Voxelised (oracle voxeliser) synthetic frames, collated like collate_batch_list."""
+    vf, vc, vn = [], [], []
+    for b, seed in enumerate(seeds):
+        pts = synth.lidar_frame(seed)
+        near = (np.abs(pts[:, 0]) < lidar_range[3] + 2) & (np.abs(pts[:, 1]) < lidar_range[4] + 2)
+        pts = pts[near][:n_points]
+        v, c, n = cref.voxelize(pts, lidar_range, voxel_size, max_points, 70000, batch_idx=b)
+        vf.append(v); vc.append(c); vn.append(n)
+    return np.concatenate(vf), np.concatenate(vc), np.concatenate(vn)
+
+
+def load_hypes(rel):
+    yu = R.ref("opencood.hypes_yaml.yaml_utils")
+    return yu.load_yaml(os.path.join(YAML_DIR, rel))
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_pointpillar_encoder():
+    he = R.ref("opencood.models.heter_encoders")
+    hy = load_hypes("LiDAROnly/lidar_pyramid.yaml")
+    args = copy.deepcopy(hy["model"]["args"]["m1"]["encoder_args"])
+    args["lidar_range"] = list(SMALL_RANGE)
+    enc = fill_module(he.PointPillar(args)).eval()
+    vf, vc, vn = small_lidar_inputs([11, 12])
+    data = {"inputs_m1": {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+                          "voxel_num_points": torch.from_numpy(vn)}}
+    with torch.no_grad():
+        bd = {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+              "voxel_num_points": torch.from_numpy(vn)}
+        pillar = enc.pillar_vfe(dict(bd))["pillar_features"].numpy()
+        canvas = enc(data, "m1").numpy()
+    save("pointpillar_encoder", voxel_features=vf, voxel_coords=vc, voxel_num_points=vn,
+         lidar_range=np.array(SMALL_RANGE), voxel_size=np.array(args["voxel_size"]),
+         pillar_features=pillar, spatial_features=canvas)
+
+
+def gen_warp_fuse():
+    tu = R.ref("opencood.utils.transformation_utils")
+    tt = R.ref("opencood.models.sub_modules.torch_transformation_utils")
+    pf = R.ref("opencood.models.fuse_modules.pyramid_fuse")
+    rng = np.random.default_rng(5)
+    out = {}
+    for tag, (n, C, H, W, dtype) in {"sq": (3, 8, 32, 32, np.float64), "rect": (2, 4, 24, 40, np.float64),
+                                     "f32": (3, 8, 32, 32, np.float32)}.items():
+        Hm, Wm = 0.8 * H * 2, 0.8 * W * 2  # metres covered by the map
+        poses = synth.agent_poses(17 + n, n, r_min=4.0, r_max=0.3 * min(Hm, Wm))
+        pw = synth.pairwise_t_matrix(poses, 5)[None].astype(dtype)  # [1,L,L,4,4]
+        x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+        score = rng.uniform(0.05, 1.0, (n, 1, H, W)).astype(np.float32)
+        score[:, :, : H // 4, : W // 3] = 0.0          # zero regions -> -inf -> all-masked pixels
+        score[1, :, H // 2:, :] = 0.0
+        aff = tu.normalize_pairwise_tfm(torch.from_numpy(pw.copy()), Hm, Wm, 1)
+        record_len = torch.tensor([n])
+        with torch.no_grad():
+            fused = pf.weighted_fuse(torch.from_numpy(x), torch.from_numpy(score), record_len, aff, False)
+            warped = tt.warp_affine_simple(torch.from_numpy(x), aff[0, 0, :n], (H, W))
+            wscore = tt.warp_affine_simple(torch.from_numpy(score), aff[0, 0, :n], (H, W))
+        out.update({f"{tag}_x": x, f"{tag}_score": score, f"{tag}_pairwise": pw[0],
+                    f"{tag}_HW_m": np.array([Hm, Wm]), f"{tag}_affine": aff.numpy()[0],
+                    f"{tag}_warped": warped.numpy(), f"{tag}_wscore": wscore.numpy(),
+                    f"{tag}_fused": fused.numpy()[0]})
+    save("warp_fuse", **out)
+
+
+def _post_params(hy):
+    p = copy.deepcopy(hy["postprocess"])
+    return p
+
+
+def gen_decode():
+    vp = R.ref("opencood.data_utils.post_processor.voxel_postprocessor")
+    bu = R.ref("opencood.utils.box_utils")
+    cu = R.ref("opencood.utils.common_utils")
+    yu = R.ref("opencood.hypes_yaml.yaml_utils")
+    hy = load_hypes("LiDAROnly/lidar_pyramid.yaml")
+    replace_ranges(hy, SMALL_RANGE)
+    hy = yu.load_general_params(hy)
+    post = vp.VoxelPostprocessor(hy["postprocess"], train=False)
+    anchors = post.generate_anchor_box()  # [64,64,2,7] f64
+    H, W, A = anchors.shape[:3]
+    rng = np.random.default_rng(9)
+    out = {"anchors": anchors, "gt_range": np.array(SMALL_RANGE)}
+    for tag, tfm in {"id": np.eye(4, dtype=np.float32),
+                     "tf": synth.x_to_world([3.0, -2.0, 0.1, 0.0, 25.0, 0.0]).astype(np.float32)}.items():
+        cls = (rng.standard_normal((1, A, H, W)) * 1.6 - 3.2).astype(np.float32)
+        # cluster some strong, overlapping detections so NMS has work to do
+        for _ in range(25):
+            h0, w0 = rng.integers(2, H - 2), rng.integers(2, W - 2)
+            cls[0, :, h0 - 1:h0 + 2, w0 - 1:w0 + 2] += rng.uniform(2.0, 6.0)
+        reg = (rng.standard_normal((1, 7 * A, H, W)) * 0.25).astype(np.float32)
+        dirp = rng.standard_normal((1, 2 * A, H, W)).astype(np.float32)
+        data_dict = {"ego": {"transformation_matrix": torch.from_numpy(tfm),
+                             "anchor_box": torch.from_numpy(anchors)}}
+        output_dict = {"ego": {"cls_preds": torch.from_numpy(cls), "reg_preds": torch.from_numpy(reg),
+                               "dir_preds": torch.from_numpy(dirp)}}
+        with torch.no_grad():
+            boxes3d = post.delta_to_boxes3d(torch.from_numpy(reg), torch.from_numpy(anchors)).numpy()
+            pred, score = post.post_process(data_dict, output_dict)
+        out.update({f"{tag}_tfm": tfm, f"{tag}_cls": cls, f"{tag}_reg": reg, f"{tag}_dir": dirp,
+                    f"{tag}_boxes3d": boxes3d[0], f"{tag}_pred": pred.numpy(), f"{tag}_score": score.numpy()})
+    # component functions
+    boxes = np.concatenate([rng.uniform(-20, 20, (40, 2)), rng.uniform(-2.5, 0, (40, 1)),
+                            rng.uniform(1.2, 2.0, (40, 1)), rng.uniform(1.4, 2.2, (40, 1)),
+                            rng.uniform(3.0, 5.0, (40, 1)), rng.uniform(-4, 4, (40, 1))], 1).astype(np.float32)
+    corners = bu.boxes_to_corners_3d(torch.from_numpy(boxes), "hwl")
+    tfm = torch.from_numpy(out["tf_tfm"])
+    proj = bu.project_box3d(corners, tfm)
+    lp = cu.limit_period(torch.from_numpy(boxes[:, 6]) - 0.7853, 0, np.pi)
+    lp2 = cu.limit_period(torch.from_numpy(boxes[:, 6]), 0.5, 2 * np.pi)
+    sc = rng.uniform(0.2, 1.0, 40).astype(np.float32)
+    sc[5] = sc[6]  # a score tie
+    keep = bu.nms_rotated(proj, torch.from_numpy(sc), 0.15)
+    out.update({"cmp_boxes": boxes, "cmp_corners": corners.numpy(), "cmp_proj": proj.numpy(),
+                "cmp_limit0": lp.numpy(), "cmp_limit1": lp2.numpy(), "cmp_scores": sc, "cmp_keep": keep,
+                "cmp_large": bu.remove_large_pred_bbx(proj).numpy(),
+                "cmp_absz": bu.remove_bbx_abnormal_z(proj).numpy()})
+    save("decode", **out)
+
+
+def _collab_small_args(hy):
+    args = copy.deepcopy(hy["model"]["args"])
+    replace_ranges(args, SMALL_RANGE)
+    return args
+
+
+def gen_collab_small():
+    m = R.ref("opencood.models.heter_pyramid_collab")
+    hy = load_hypes("LiDAROnly/lidar_pyramid.yaml")
+    model = fill_module(m.HeterPyramidCollab(_collab_small_args(hy))).eval()
+    out = {}
+    for tag, seeds in {"a2": [21, 22], "a3": [31, 32, 33]}.items():
+        n = len(seeds)
+        vf, vc, vn = small_lidar_inputs(seeds, n_points=7000)
+        poses = synth.agent_poses(40 + n, n, r_min=4.0, r_max=14.0)
+        pw = synth.pairwise_t_matrix(poses, 5)[None]  # float64, as the dataset produces
+        data = {"inputs_m1": {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+                              "voxel_num_points": torch.from_numpy(vn)},
+                "agent_modality_list": ["m1"] * n, "record_len": torch.tensor([n]),
+                "pairwise_t_matrix": torch.from_numpy(pw.copy())}
+        with torch.no_grad():
+            o = model(data)
+        out.update({f"{tag}_voxel_features": vf, f"{tag}_voxel_coords": vc, f"{tag}_voxel_num_points": vn,
+                    f"{tag}_pairwise": pw, f"{tag}_cls": o["cls_preds"].numpy(), f"{tag}_reg": o["reg_preds"].numpy(),
+                    f"{tag}_dir": o["dir_preds"].numpy()})
+        for i, occ in enumerate(o["occ_single_list"]):
+            out[f"{tag}_occ{i}"] = occ.numpy()
+    save("collab_small", **out)
+
+
+def gen_single_late_small():
+    out = {}
+    vf, vc, vn = small_lidar_inputs([51], n_points=7000)
+    data = {"inputs_m1": {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+                          "voxel_num_points": torch.from_numpy(vn)}}
+    out.update(voxel_features=vf, voxel_coords=vc, voxel_num_points=vn)
+    ms = R.ref("opencood.models.heter_pyramid_single")
+    hy = load_hypes("MoreModality/HEAL/stage2/m1_single_pyramid.yaml") if os.path.exists(
+        os.path.join(YAML_DIR, "MoreModality/HEAL/stage2/m1_single_pyramid.yaml")) else None
+    if hy is not None:
+        model = fill_module(ms.HeterPyramidSingle(_collab_small_args(hy))).eval()
+        with torch.no_grad():
+            o = model(dict(data))
+        out.update(single_cls=o["cls_preds"].numpy(), single_reg=o["reg_preds"].numpy(),
+                   single_dir=o["dir_preds"].numpy(),
+                   **{f"single_occ{i}": t.numpy() for i, t in enumerate(o["occ_single_list"])})
+    ml = R.ref("opencood.models.heter_model_late")
+    hy = load_hypes("Single/m1_pointpillar_pretrain.yaml")
+    model = fill_module(ml.HeterModelLate(_collab_small_args(hy))).eval()
+    with torch.no_grad():
+        o = model(dict(data))
+    out.update(late_cls=o["cls_preds"].numpy(), late_reg=o["reg_preds"].numpy(), late_dir=o["dir_preds"].numpy())
+    save("single_late_small", **out)
+
+
+def gen_lss():
+    he = R.ref("opencood.models.heter_encoders")
+    cu = R.ref("opencood.utils.camera_utils")
+    grid_conf = {"xbound": [-12.8, 12.8, 0.4], "ybound": [-12.8, 12.8, 0.4], "zbound": [-10, 10, 20.0],
+                 "ddiscr": [2, 26, 8], "mode": "LID"}
+    data_aug_conf = {"final_dim": [48, 64]}
+    dx, bx, nx = cu.gen_dx_bx(grid_conf["xbound"], grid_conf["ybound"], grid_conf["zbound"])
+    ns = SimpleNamespace(grid_conf=grid_conf, data_aug_conf=data_aug_conf, downsample=8, dx=dx, bx=bx, nx=nx,
+                         use_quickcumsum=True)
+    ns.frustum = he.LiftSplatShoot.create_frustum(ns)
+    D, fH, fW, _ = ns.frustum.shape
+    B, N, C = 2, 4, 16
+    rng = np.random.default_rng(3)
+    rig = synth.camera_rig(0, N, 48, 64)
+    cam = {k: np.tile(v[None], (B,) + (1,) * v.ndim).astype(np.float32) for k, v in rig.items()}
+    # a non-trivial post augmentation on agent 1
+    cam["post_rots"][1, :, 0, 0] = 0.9; cam["post_rots"][1, :, 1, 1] = 0.9
+    cam["post_trans"][1, :, 0] = 2.0; cam["post_trans"][1, :, 1] = -1.0
+    tens = {k: torch.from_numpy(v) for k, v in cam.items()}
+    with torch.no_grad():
+        geom = he.LiftSplatShoot.get_geometry(ns, tens["rots"], tens["trans"], tens["intrins"],
+                                              tens["post_rots"], tens["post_trans"])
+        depth_logit = rng.standard_normal((B * N, D, fH, fW)).astype(np.float32)
+        feat = rng.standard_normal((B * N, C, fH, fW)).astype(np.float32)
+        depth = torch.from_numpy(depth_logit).softmax(dim=1)
+        new_x = depth.unsqueeze(1) * torch.from_numpy(feat).unsqueeze(2)       # lss_submodule.py:133-134
+        x = new_x.view(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)           # heter_encoders.py:156-157
+        pooled = he.LiftSplatShoot.voxel_pooling(ns, geom, x)
+    save("lss", frustum=ns.frustum.numpy(), dx=dx.numpy(), bx=bx.numpy(), nx=nx.numpy(),
+         depth_bins=np.asarray(cu.depth_discretization(*grid_conf["ddiscr"], grid_conf["mode"])),
+         geom=geom.numpy(), depth_logit=depth_logit, feat=feat, pooled=pooled.numpy(),
+         **{f"cam_{k}": v for k, v in cam.items()})
+
+
+GENS = {"pointpillar_encoder": gen_pointpillar_encoder, "warp_fuse": gen_warp_fuse, "decode": gen_decode,
+        "collab_small": gen_collab_small, "single_late_small": gen_single_late_small, "lss": gen_lss}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GENS)
+    for nme in names:
+        GENS[nme]()
