@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/s of HEAL's per-frame perception hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scene5|pair|single]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one synthetic OPV2V-shaped scene through the whole path with its inputs (device point
+clouds, anchors) already resident in HBM: voxelise (K1) -> PFN+scatter (K2) -> BEV backbones ->
+pyramid stages -> warp + occupancy-softmax fusion (K5) -> deblocks / shrink / heads -> decode +
+rotated NMS (K8) -> host sees the boxes.  N = 1: everything on one GPU.  N > 1: the agents of the
+scene are sharded one per rank with a single all-gather of ego-frame maps (heal_amd/dist.py);
+`value` = scenes completed per second by the whole job.
+
+Rank 0 prints ONE JSON line (metric/roofline/cpu_baseline as the contract in DESIGN.md describes).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3   # fp32 matrix/vector peak, same guide
+
+WORKLOADS = {
+    # name: (n_agents, description)
+    "scene5": (5, "5-agent OPV2V scene, 5x PointPillars(m1) + PyramidFusion, range +-102.4 m, 64-line LiDAR "
+                  "(the camera agents m2/m4 of OPV2V-H are LiDAR agents here until the LSS encoder row lands)"),
+    "pair": (2, "2-agent OPV2V scene, PointPillars + PyramidFusion (BASELINE config 3)"),
+    "single": (1, "single-agent PointPillars + pyramid backbone (BASELINE config 2)"),
+}
+
+
+def k2_algorithmic_bytes(n_points_per_voxel_rows, n_voxels, ny, nx, channels=64):
+    """16*M*P + 20*M + 4*C*ny*nx bytes per agent."""
+    return 16 * n_voxels * n_points_per_voxel_rows + 20 * n_voxels + 4 * channels * ny * nx
+
+
+def dense_flops(model, sample_input_fn):
+    """FLOPs of the dense conv/linear part of one scene, counted by torch's flop counter."""
+    try:
+        from torch.utils.flop_counter import FlopCounterMode
+        with FlopCounterMode(display=False) as fc:
+            sample_input_fn()
+        return float(fc.get_total_flops())
+    except Exception:
+        return None
+
+
+def cpu_baseline(hypes, scene_points, pairwise, n_agents):
+    """The oracle (CPU port of the reference algorithm) timed on this box's host cores, on a bounded
+    sample: ONE scene of the same workload.  Reported, never the thing measured above."""
+    from heal_amd.opencood.tools.train_utils import create_model
+    from heal_amd.pipeline import fill_deterministic
+    from oracle import cref, model_ref
+    from oracle import oracle_np as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = fill_deterministic(create_model(hypes), 0).state_dict()
+    args = hypes["model"]["args"]
+    r = args["lidar_range"]
+    t0 = time.perf_counter()
+    vs, cs, ns = [], [], []
+    for b, p in enumerate(scene_points):
+        v, c, n = cref.voxelize(p, r, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    out = model_ref.heter_pyramid_collab_m1(sd, args, np.concatenate(vs), np.concatenate(cs), np.concatenate(ns),
+                                            n_agents, pairwise)
+    anchors = O.generate_anchor_box(r, 0.4, 0.4, int(round((r[3] - r[0]) / 0.4)), int(round((r[4] - r[1]) / 0.4)),
+                                    3.9, 1.6, 1.56, [0, 90])
+    out["cls_preds"] = out["cls_preds"] - 4.0  # same head bias as the GPU pipeline
+    O.post_process(out["cls_preds"], out["reg_preds"], out["dir_preds"], anchors, 0.2, 0.7853, 2, 0.15,
+                   np.eye(4, dtype=np.float32), r)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"1 scene of the same workload ({n_agents} agents) through oracle/ "
+                      f"(C voxeliser + numpy PFN/warp/fuse + torch-CPU fp32 convs + C rotated NMS), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="scene5", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from heal_amd import configs, ops
+    from heal_amd.dist import ShardedCollab, owned_agents
+    from heal_amd.pipeline import Scene, ScenePipeline
+
+    n_agents, desc = WORKLOADS[a.workload]
+    hypes = configs.lidar_pyramid(max_cav=max(5, n_agents))
+    pipe = ScenePipeline(hypes, dev, seed=0)
+    scene = Scene(n_agents, seed=4, device=dev)
+    batch = {"ego": {"transformation_matrix": pipe.tfm, "anchor_box": pipe.anchor_box}}
+
+    if world == 1:
+        def step():
+            return pipe.step(scene)
+    else:
+        sharded = ShardedCollab(pipe.model, rank, world)
+        mine = owned_agents(n_agents, rank, world)
+        local_pts = {"m1": [scene.points[k] for k in mine]}
+        inp = scene.model_input()
+
+        def step():
+            out = sharded.forward(inp, n_agents, local_pts)
+            if rank == 0:
+                return pipe.post.post_process(batch, {"ego": out})
+            return None, None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ops.TIMING = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timing = ops.timing_summary()
+    ops.TIMING = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        nx = ny = 512
+        # K2 roofline: algorithmic bytes of the operator / its measured duration (HIP events)
+        with torch.no_grad():
+            m_per_agent = []
+            for p in scene.points:
+                _, _, nn_ = ops.voxelize(p, hypes["model"]["args"]["lidar_range"], [0.4, 0.4, 4], 32, 70000)
+                m_per_agent.append(int(nn_.shape[0]))
+        roof = None
+        if "pfn_scatter" in timing:
+            calls, mean_ms = timing["pfn_scatter"]
+            # one launch of the operator = one agent (the no-sync points path calls K2 per agent)
+            bytes_per_launch = float(np.mean([k2_algorithmic_bytes(32, m, ny, nx) for m in m_per_agent]))
+            achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+            roof = {"kernel": "K2 heal_pfn_scatter (memset + k_pfn + k_canvas)", "bound": "hbm",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": bytes_per_launch, "launch_ms": round(mean_ms, 5), "launches": calls}
+        kernels = {k: {"calls": c, "mean_ms": round(ms, 5)} for k, (c, ms) in sorted(timing.items())}
+        line = {
+            "metric": "scenes/sec (5-agent OPV2V-H, PointPillars+PyramidFusion)",
+            "value": round(a.steps / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {desc}", "agents": n_agents,
+                       "pillars_per_agent": m_per_agent, "points_per_agent": [int(p.shape[0]) for p in scene.points],
+                       "parallelism": "1 GPU" if world == 1 else f"agent-sharded over {world} ranks, 1 all-gather",
+                       "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
+            "roofline": roof, "op_timing_ms": kernels,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(hypes, [p.cpu().numpy() for p in scene.points], scene.pairwise,
+                                                n_agents)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""ctypes binding of libheal_amd.so -- the C ABI declared in include/heal_amd.h.
+
+This is the only place the package touches the native library.  There is NO fallback: if the
+library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libheal_amd.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "heal_amd.h")
+
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "heal_abi_version": (c_int, []),
+    "heal_last_error": (ctypes.c_char_p, []),
+    "heal_voxelize_workspace": (c_size_t, [c_int, c_int]),
+    "heal_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_pfn_scatter_workspace": (c_size_t, [c_int] * 5),
+    "heal_pfn_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_int,
+                                 c_float, c_float, c_float, c_float, c_float, c_float,
+                                 c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p]),
+    "heal_warp_agent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "heal_fuse_warped": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "heal_decode_nms_workspace": (c_size_t, [c_int, c_int]),
+    "heal_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_float, c_float, c_float, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "heal_quad_iou": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+}
+
+
+class HealAmdError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Function names declared in include/heal_amd.h."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(heal_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load libheal_amd.so (raises if it has not been built: python -m heal_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HealAmdError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m heal_amd.build`); heal_amd has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            if not hasattr(L, name):
+                continue  # declared but not built yet -> surfaces in call() / the symbol test
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise HealAmdError with heal_last_error() on failure."""
+    L = lib()
+    if not hasattr(L, name):
+        raise HealAmdError(f"libheal_amd.so does not export {name}")
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise HealAmdError(f"{name} failed: {L.heal_last_error().decode(errors='replace')}")
+
+
+def query(name, *args):
+    """Call a size_t-returning workspace query."""
+    L = lib()
+    if not hasattr(L, name):
+        raise HealAmdError(f"libheal_amd.so does not export {name}")
+    return int(getattr(L, name)(*args))

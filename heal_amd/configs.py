@@ -1,0 +1,119 @@
+"""Hypes dictionaries for the BASELINE configurations, built in code with the reference's key names
+(what `yaml_utils.load_yaml` returns for opencood/hypes_yaml/opv2v/LiDAROnly/lidar_pyramid.yaml,
+MoreModality/HEAL/stage2/m1_single_pyramid.yaml, Single/m1_pointpillar_pretrain.yaml and
+MoreModality/HEAL/final_infer/m1m2m3m4.yaml, inference-relevant sections only).
+`dump_yaml` writes them out as a config.yaml that both loaders parse.
+"""
+import copy
+
+import yaml
+
+from heal_amd.opencood.hypes_yaml.yaml_utils import load_general_params
+
+FULL_RANGE = [-102.4, -102.4, -3, 102.4, 102.4, 1]
+ANCHOR_YAW = [0, 90]
+DIR_ARGS = {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": ANCHOR_YAW}
+
+
+def _pointpillar_modality(lidar_range, aligner="identity"):
+    aligner_args = {"core_method": "identity"} if aligner == "identity" else {
+        "core_method": "convnext", "spatial_align": False, "args": {"num_of_blocks": 3, "dim": 64}}
+    return {
+        "core_method": "point_pillar",
+        "sensor_type": "lidar",
+        "encoder_args": {
+            "voxel_size": [0.4, 0.4, 4],
+            "lidar_range": list(lidar_range),
+            "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+            "point_pillar_scatter": {"num_features": 64},
+        },
+        "backbone_args": {"layer_nums": [3], "layer_strides": [2], "num_filters": [64]},
+        "aligner_args": aligner_args,
+    }
+
+
+def _fusion_backbone():
+    return {"resnext": True, "layer_nums": [3, 5, 8], "layer_strides": [1, 2, 2], "num_filters": [64, 128, 256],
+            "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128], "anchor_number": 2}
+
+
+def _shrink_header():
+    return {"kernal_size": [3], "stride": [1], "padding": [1], "dim": [256], "input_dim": 384}
+
+
+def _common(lidar_range, max_cav):
+    r = list(lidar_range)
+    return {
+        "yaml_parser": "load_general_params",
+        "train_params": {"batch_size": 1, "max_cav": max_cav},
+        "cav_lidar_range": r,
+        "preprocess": {
+            "core_method": "SpVoxelPreprocessor",
+            "args": {"voxel_size": [0.4, 0.4, 4], "max_points_per_voxel": 32, "max_voxel_train": 32000,
+                     "max_voxel_test": 70000},
+            "cav_lidar_range": r,
+        },
+        "postprocess": {
+            "core_method": "VoxelPostprocessor",
+            "gt_range": r,
+            "anchor_args": {"cav_lidar_range": r, "l": 3.9, "w": 1.6, "h": 1.56, "r": list(ANCHOR_YAW),
+                            "feature_stride": 2, "num": 2},
+            "target_args": {"pos_threshold": 0.6, "neg_threshold": 0.45, "score_threshold": 0.2},
+            "order": "hwl",
+            "max_num": 150,
+            "nms_thresh": 0.15,
+            "dir_args": copy.deepcopy(DIR_ARGS),
+        },
+    }
+
+
+def lidar_pyramid(lidar_range=FULL_RANGE, max_cav=5):
+    """PointPillars + PyramidFusion collaborative model (BASELINE configs 3 and the LiDAR part of 4)."""
+    h = _common(lidar_range, max_cav)
+    h["name"] = "heal_amd_opv2v_lidar_pyramid"
+    h["model"] = {"core_method": "heter_pyramid_collab", "args": {
+        "lidar_range": list(lidar_range), "supervise_single": True,
+        "m1": _pointpillar_modality(lidar_range, "identity"),
+        "fusion_backbone": _fusion_backbone(), "shrink_header": _shrink_header(),
+        "in_head": 256, "anchor_number": 2, "dir_args": copy.deepcopy(DIR_ARGS)}}
+    return load_general_params(h)
+
+
+def m1_single_pyramid(lidar_range=FULL_RANGE):
+    """Single-agent PointPillars through the pyramid backbone (BASELINE configs 1/2)."""
+    h = _common(lidar_range, 1)
+    h["name"] = "heal_amd_opv2v_m1_single_pyramid"
+    h["model"] = {"core_method": "heter_pyramid_single", "args": {
+        "ego_modality": "m1", "lidar_range": list(lidar_range), "fix_encoder": False,
+        "m1": _pointpillar_modality(lidar_range, "convnext"),
+        "fusion_backbone": _fusion_backbone(), "shrink_header": _shrink_header(),
+        "in_head": 256, "anchor_number": 2, "dir_args": copy.deepcopy(DIR_ARGS)}}
+    return load_general_params(h)
+
+
+def m1_late(lidar_range=FULL_RANGE):
+    """Single-agent PointPillars detector of the late-fusion / pre-training recipe (configs 1/2)."""
+    h = _common(lidar_range, 1)
+    h["name"] = "heal_amd_opv2v_m1_pointpillar_late"
+    m1 = _pointpillar_modality(lidar_range, "identity")
+    m1["layers_args"] = {"layer_nums": [3, 5, 8], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                         "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]}
+    m1["shrink_header"] = _shrink_header()
+    m1["head_args"] = {"in_head": 256}
+    h["model"] = {"core_method": "heter_model_late", "args": {
+        "ego_modality": "m1", "lidar_range": list(lidar_range), "m1": m1, "anchor_number": 2,
+        "dir_args": copy.deepcopy(DIR_ARGS)}}
+    return load_general_params(h)
+
+
+def dump_yaml(hypes, path):
+    def plain(o):
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        if hasattr(o, "tolist"):
+            return o.tolist()
+        return o
+    with open(path, "w") as f:
+        yaml.safe_dump(plain(hypes), f, sort_keys=False)

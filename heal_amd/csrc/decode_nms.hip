@@ -1,0 +1,403 @@
+// K8 -- anchor box decode, score / size / z filters, rotated NMS and range mask, all on device.
+//
+// Reference arithmetic:
+//   opencood/data_utils/post_processor/voxel_postprocessor.py:245-405 (post_process),
+//   :407-453 (delta_to_boxes3d); opencood/utils/common_utils.py:104-113 (limit_period), :139-161
+//   (rotate_points_along_z); opencood/utils/box_utils.py:152-204 (boxes_to_corners_3d 'hwl'),
+//   :278-316 (project_box3d), :840-890 (size / z filters), :693-738 (nms_rotated: top-1000 by
+//   score, greedy, suppress iou > thr), :384-421 (mask_boxes_outside_range_numpy);
+//   IoU = shapely Polygon(corners[0:4,:2]) intersection/union in fp64 -> fp32
+//   (opencood/utils/common_utils.py:230-270).
+// The reference moves the candidates to the host and runs O(K^2) Python->GEOS calls.  Here:
+//   k_decode_key   one thread per anchor: sigmoid, decode, filters -> sort key (score bits) or 0
+//   radix sort     stable, ascending; the descending top-k are read from the tail (ties: larger
+//                  anchor index first == stable argsort reversed)
+//   k_nms_prepare  re-decode the top-k (cheaper than storing 96 B for each of 131 072 anchors)
+//   k_nms_mask     64x64 tiles of the upper-triangular suppression bit matrix; fp64 convex clip
+//   k_nms_reduce   one wave: per 64-row block resolve the diagonal tile serially with lane reads,
+//                  then OR the surviving rows into the removed set; ordered compaction of output
+#include <string.h>
+#include "prims.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+struct DecodeParams {
+    int H, W, A, num_bins;
+    float score_thr, dir_offset, period, two_pi;
+    float tfm[16];
+    float gt_range[6];
+    uint32_t key_base;  // keys are bits(score) - key_base (>= 1 for candidates)
+};
+
+struct Box3D {
+    float c[8][3];
+    float score;
+    bool pass;
+};
+
+__device__ __forceinline__ float limit_period_f(float val, float offset, float period) {
+    return val - floorf(val / period + offset) * period;
+}
+
+// Full per-anchor pipeline up to (and including) the size / z filters.
+__device__ __forceinline__ void decode_anchor(const float* __restrict__ cls, const float* __restrict__ reg,
+                                              const float* __restrict__ dir,
+                                              const float* __restrict__ anchors, const DecodeParams& p,
+                                              int j, bool want_corners, Box3D& o) {
+    const int HW = p.H * p.W;
+    const int a = j % p.A;
+    const int hw = j / p.A;
+    const float logit = cls[(size_t)a * HW + hw];
+    const float prob = 1.f / (1.f + expf(-logit));
+    o.score = prob;
+    o.pass = false;
+    if (!(prob > p.score_thr)) return;
+    float d[7], an[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        d[k] = reg[(size_t)(a * 7 + k) * HW + hw];
+        an[k] = anchors[(size_t)j * 7 + k];
+    }
+    const float ad = sqrtf(an[4] * an[4] + an[5] * an[5]);
+    const float x = d[0] * ad + an[0];
+    const float y = d[1] * ad + an[1];
+    const float z = d[2] * an[3] + an[2];
+    const float bh = expf(d[3]) * an[3];
+    const float bw = expf(d[4]) * an[4];
+    const float bl = expf(d[5]) * an[5];
+    float yaw = d[6] + an[6];
+    if (dir != nullptr) {
+        int label = 0;
+        float best = dir[(size_t)(a * p.num_bins) * HW + hw];
+        for (int b = 1; b < p.num_bins; ++b) {
+            const float v = dir[(size_t)(a * p.num_bins + b) * HW + hw];
+            if (v > best) { best = v; label = b; }
+        }
+        const float dir_rot = limit_period_f(yaw - p.dir_offset, 0.f, p.period);
+        yaw = dir_rot + p.dir_offset + p.period * (float)label;
+        yaw = limit_period_f(yaw, 0.5f, p.two_pi);
+    }
+    // corners: dims (l, w, h) * template / 2, rotate about z, translate, project
+    const float cosa = cosf(yaw), sina = sinf(yaw);
+    const float sx[8] = {1, 1, -1, -1, 1, 1, -1, -1};
+    const float sy[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+    const float sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float px = bl * (sx[k] / 2.f), py = bw * (sy[k] / 2.f), pz = bh * (sz[k] / 2.f);
+        // [px py pz] @ [[cos, sin, 0], [-sin, cos, 0], [0, 0, 1]]
+        const float rx = (px * cosa + py * (-sina)) + pz * 0.f;
+        const float ry = (px * sina + py * cosa) + pz * 0.f;
+        const float rz = (px * 0.f + py * 0.f) + pz * 1.f;
+        const float cx = rx + x, cy = ry + y, cz = rz + z;
+        const float qx = ((p.tfm[0] * cx + p.tfm[1] * cy) + p.tfm[2] * cz) + p.tfm[3];
+        const float qy = ((p.tfm[4] * cx + p.tfm[5] * cy) + p.tfm[6] * cz) + p.tfm[7];
+        const float qz = ((p.tfm[8] * cx + p.tfm[9] * cy) + p.tfm[10] * cz) + p.tfm[11];
+        if (want_corners) { o.c[k][0] = qx; o.c[k][1] = qy; o.c[k][2] = qz; }
+        xmin = fminf(xmin, qx); xmax = fmaxf(xmax, qx);
+        ymin = fminf(ymin, qy); ymax = fmaxf(ymax, qy);
+        zmin = fminf(zmin, qz); zmax = fmaxf(zmax, qz);
+    }
+    const float x_len = xmax - xmin, y_len = ymax - ymin;
+    // remove_large_pred_bbx: x_len<=6 & y_len<=6 & bool(z_len), where the reference derives z_len
+    // from the y column (box_utils.py:862-867); remove_bbx_abnormal_z: z in [-3, 1]
+    o.pass = (x_len <= 6.f) && (y_len <= 6.f) && (y_len != 0.f) && (zmin >= -3.f) && (zmax <= 1.f);
+}
+
+__global__ __launch_bounds__(256) void k_decode_key(const float* __restrict__ cls,
+                                                   const float* __restrict__ reg,
+                                                   const float* __restrict__ dir,
+                                                   const float* __restrict__ anchors, DecodeParams p,
+                                                   int n, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, int* __restrict__ n_cand) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    bool cand = false;
+    if (j < n) {
+        Box3D b;
+        decode_anchor(cls, reg, dir, anchors, p, j, false, b);
+        cand = b.pass;
+        keys[j] = cand ? (__float_as_uint(b.score) - p.key_base) : 0u;
+        vals[j] = (uint32_t)j;
+    }
+    const unsigned long long m = __ballot(cand);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_cand, __popcll(m));
+}
+
+// ---- fp64 convex quad IoU (same operation order as oracle/oracle_ref.c) ---------------------------
+__device__ __forceinline__ double poly_area(const double* p, int n) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        a += p[2 * i] * p[2 * j + 1] - p[2 * j] * p[2 * i + 1];
+    }
+    return 0.5 * a;
+}
+
+__device__ __forceinline__ int clip_edge(const double* subj, int ns, double ax, double ay, double bx,
+                                         double by, double* out) {
+    int no = 0;
+    const double ex = bx - ax, ey = by - ay;
+    for (int i = 0; i < ns; ++i) {
+        const int j = (i + 1 == ns) ? 0 : i + 1;
+        const double px = subj[2 * i], py = subj[2 * i + 1];
+        const double qx = subj[2 * j], qy = subj[2 * j + 1];
+        const double dp = ex * (py - ay) - ey * (px - ax);
+        const double dq = ex * (qy - ay) - ey * (qx - ax);
+        const bool pin = dp >= 0.0, qin = dq >= 0.0;
+        if (pin) { out[2 * no] = px; out[2 * no + 1] = py; ++no; }
+        if (pin != qin) {
+            const double t = dp / (dp - dq);
+            out[2 * no] = px + t * (qx - px);
+            out[2 * no + 1] = py + t * (qy - py);
+            ++no;
+        }
+    }
+    return no;
+}
+
+__device__ __forceinline__ void make_ccw(double* q, double& area) {
+    area = poly_area(q, 4);
+    if (area < 0.0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double tx = q[2 * i], ty = q[2 * i + 1];
+            q[2 * i] = q[2 * (3 - i)]; q[2 * i + 1] = q[2 * (3 - i) + 1];
+            q[2 * (3 - i)] = tx; q[2 * (3 - i) + 1] = ty;
+        }
+        area = -area;
+    }
+}
+
+__device__ float quad_iou(const float* qa, const float* qb) {
+    double a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (double)qa[i]; b[i] = (double)qb[i]; }
+    double sa, sb;
+    make_ccw(a, sa);
+    make_ccw(b, sb);
+    double buf0[32], buf1[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf0[i] = a[i];
+    int n = 4;
+    double* cur = buf0;
+    double* nxt = buf1;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const int f = (e + 1) & 3;
+        n = clip_edge(cur, n, b[2 * e], b[2 * e + 1], b[2 * f], b[2 * f + 1], nxt);
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    double inter = (n >= 3) ? poly_area(cur, n) : 0.0;
+    if (inter < 0.0) inter = 0.0;
+    const double uni = sa + sb - inter;
+    return (float)(inter / uni);
+}
+
+// ---- top-k re-decode --------------------------------------------------------------------------------
+struct NmsBufs {
+    float* corners;   // [top][8][3]
+    float* scores;    // [top]
+    float* quads;     // [top][4][2]
+    int* inrange;     // [top]
+    unsigned long long* mask;  // [top][words]
+    int* n_cand;
+};
+
+__global__ __launch_bounds__(64) void k_nms_prepare(const float* __restrict__ cls, const float* __restrict__ reg,
+                                                   const float* __restrict__ dir,
+                                                   const float* __restrict__ anchors, DecodeParams p, int n,
+                                                   const uint32_t* __restrict__ svals, int top, NmsBufs nb) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    const int K = min(*nb.n_cand, top);
+    if (r >= K) return;
+    const int j = (int)svals[n - 1 - r];
+    Box3D b;
+    decode_anchor(cls, reg, dir, anchors, p, j, true, b);
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            nb.corners[((size_t)r * 8 + k) * 3 + ax] = b.c[k][ax];
+            inside = inside && (b.c[k][ax] >= p.gt_range[ax]) && (b.c[k][ax] <= p.gt_range[3 + ax]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nb.quads[(size_t)r * 8 + 2 * k] = b.c[k][0];
+        nb.quads[(size_t)r * 8 + 2 * k + 1] = b.c[k][1];
+    }
+    nb.scores[r] = b.score;
+    nb.inrange[r] = inside ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_nms_mask(NmsBufs nb, int top, int words, float thr) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int K = min(*nb.n_cand, top);
+    if (bi * 64 >= K || bj * 64 >= K) return;
+    __shared__ float cq[64][8];
+    const int cj = bj * 64 + threadIdx.x;
+    if (cj < K) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cq[threadIdx.x][k] = nb.quads[(size_t)cj * 8 + k];
+    }
+    __syncthreads();
+    const int i = bi * 64 + threadIdx.x;
+    if (i >= K) return;
+    float q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = nb.quads[(size_t)i * 8 + k];
+    unsigned long long bits = 0ull;
+    const int jn = min(64, K - bj * 64);
+    for (int t = (bi == bj) ? (int)threadIdx.x + 1 : 0; t < jn; ++t) {
+        const float v = quad_iou(q, cq[t]);
+        if (v > thr) bits |= 1ull << t;
+    }
+    nb.mask[(size_t)i * words + bj] = bits;
+}
+
+__global__ __launch_bounds__(64) void k_nms_reduce(NmsBufs nb, int top, int words,
+                                                  float* __restrict__ out_corners,
+                                                  float* __restrict__ out_scores, int* __restrict__ out_count,
+                                                  int max_out) {
+    __shared__ unsigned long long keep_bits[64];
+    const int l = threadIdx.x;
+    const int K = min(*nb.n_cand, top);
+    const int W = (K + 63) / 64;
+    unsigned long long removed = 0ull;  // lane l holds word l of the removed set
+    for (int blk = 0; blk < W; ++blk) {
+        const int r = blk * 64 + l;
+        const unsigned long long diag = (r < K) ? nb.mask[(size_t)r * words + blk] : 0ull;
+        unsigned long long rem = __shfl(removed, blk, 64);
+        unsigned long long alive = 0ull;
+        const int cnt = min(64, K - blk * 64);
+        for (int i = 0; i < cnt; ++i) {
+            const unsigned long long di = __shfl(diag, i, 64);
+            if (!((rem >> i) & 1ull)) {
+                alive |= 1ull << i;
+                rem |= di;
+            }
+        }
+        if (l == 0) keep_bits[blk] = alive;
+        // OR the surviving rows into the removed words of the blocks still to come
+        unsigned long long a = alive;
+        while (a) {
+            const int i = __ffsll((long long)a) - 1;
+            a &= a - 1;
+            if (l > blk && l < W) removed |= nb.mask[(size_t)(blk * 64 + i) * words + l];
+        }
+    }
+    __syncthreads();
+    // ordered compaction: kept (pick order) and inside gt_range
+    int base = 0;
+    for (int blk = 0; blk < W; ++blk) {
+        const int r = blk * 64 + l;
+        const bool kept = (r < K) && ((keep_bits[blk] >> l) & 1ull) && nb.inrange[r];
+        const unsigned long long m = __ballot(kept);
+        const int pos = base + __popcll(m & lanemask_lt());
+        if (kept && pos < max_out) {
+            for (int k = 0; k < 24; ++k) out_corners[(size_t)pos * 24 + k] = nb.corners[(size_t)r * 24 + k];
+            out_scores[pos] = nb.scores[r];
+        }
+        base += __popcll(m);
+    }
+    if (l == 0) *out_count = min(base, max_out);
+}
+
+__global__ __launch_bounds__(256) void k_quad_iou(const float* __restrict__ a, int n,
+                                                 const float* __restrict__ b, int m, float* __restrict__ iou) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * m) return;
+    const int i = t / m, j = t - i * m;
+    float qa[8], qb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { qa[k] = a[(size_t)i * 8 + k]; qb[k] = b[(size_t)j * 8 + k]; }
+    iou[t] = quad_iou(qa, qb);
+}
+
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+struct DecWs {
+    uint32_t *keys[2], *vals[2];
+    int* scratch;
+    NmsBufs nb;
+};
+
+static bool carve(Arena& a, int n, int top, DecWs& w) {
+    for (int k = 0; k < 2; ++k) { w.keys[k] = a.take<uint32_t>(n); w.vals[k] = a.take<uint32_t>(n); }
+    w.scratch = a.take<int>(sort_scratch_words(n));
+    const int words = ceil_div(top, 64);
+    w.nb.corners = a.take<float>((size_t)top * 24);
+    w.nb.scores = a.take<float>(top);
+    w.nb.quads = a.take<float>((size_t)top * 8);
+    w.nb.inrange = a.take<int>(top);
+    w.nb.mask = a.take<unsigned long long>((size_t)top * words);
+    w.nb.n_cand = a.take<int>(64);
+    return a.ok();
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" size_t heal_decode_nms_workspace(int anchors_total, int nms_top) {
+    Arena a(nullptr, 0);
+    DecWs w;
+    carve(a, anchors_total < 1 ? 1 : anchors_total, nms_top < 1 ? 1 : nms_top, w);
+    return a.off + 256;
+}
+
+extern "C" int heal_decode_nms(const float* cls, const float* reg, const float* dir, const float* anchors,
+                               int H, int W, int anchor_num, int num_bins, float score_thr,
+                               float dir_offset, float nms_thr, int nms_top, const float* tfm_host,
+                               const float* gt_range_host, float* out_corners, float* out_scores,
+                               int32_t* out_count, int max_out, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(H >= 1 && W >= 1 && anchor_num >= 1, "decode_nms: bad shape");
+    HEAL_REQUIRE(nms_top >= 1 && nms_top <= 4096, "decode_nms: nms_top must be in [1,4096]");
+    HEAL_REQUIRE(dir == nullptr || num_bins >= 1, "decode_nms: num_bins must be >= 1");
+    HEAL_REQUIRE(max_out >= 1, "decode_nms: max_out must be >= 1");
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "decode_nms: workspace must be 256-B aligned");
+    const int n = H * W * anchor_num;
+    Arena a(ws, ws_bytes);
+    DecWs w;
+    HEAL_REQUIRE(carve(a, n, nms_top, w), "decode_nms: workspace too small (%zu < %zu)", ws_bytes, a.off);
+
+    DecodeParams p;
+    p.H = H; p.W = W; p.A = anchor_num; p.num_bins = num_bins;
+    p.score_thr = score_thr; p.dir_offset = dir_offset;
+    p.period = (float)(2.0 * 3.141592653589793 / (double)(num_bins > 0 ? num_bins : 1));
+    p.two_pi = (float)(2.0 * 3.141592653589793);
+    for (int k = 0; k < 16; ++k) p.tfm[k] = tfm_host[k];
+    for (int k = 0; k < 6; ++k) p.gt_range[k] = gt_range_host[k];
+    // candidates have sigmoid score in (thr, 1]; key = bits(score) - key_base >= 1
+    uint32_t key_base = 0, max_key;
+    if (score_thr > 0.f) { key_base = f2u(score_thr); max_key = f2u(1.0f) - key_base; }
+    else { key_base = 0; max_key = f2u(1.0f); }
+    // scores are > thr so bits(score) > key_base for thr > 0; for thr <= 0 a zero score (logit -inf)
+    // would collide with the "not a candidate" key 0 -- shift by one in that case
+    if (score_thr <= 0.f) { key_base = 0xFFFFFFFFu; max_key += 1; }  // bits - (-1) = bits + 1
+    p.key_base = key_base;
+    int key_bits = 1;
+    while (key_bits < 32 && (1u << key_bits) <= max_key) ++key_bits;
+
+    HEAL_HIP(hipMemsetAsync(w.nb.n_cand, 0, sizeof(int), s));
+    k_decode_key<<<ceil_div(n, 256), 256, 0, s>>>(cls, reg, dir, anchors, p, n, w.keys[0], w.vals[0], w.nb.n_cand);
+    int res = 0;
+    if (radix_sort_pairs(w.keys, w.vals, n, key_bits, &res, w.scratch, s)) return 1;
+    const int words = ceil_div(nms_top, 64);
+    k_nms_prepare<<<ceil_div(nms_top, 64), 64, 0, s>>>(cls, reg, dir, anchors, p, n, w.vals[res], nms_top, w.nb);
+    k_nms_mask<<<dim3(words, words), 64, 0, s>>>(w.nb, nms_top, words, nms_thr);
+    k_nms_reduce<<<1, 64, 0, s>>>(w.nb, nms_top, words, out_corners, out_scores, out_count, max_out);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void* stream) {
+    if (n <= 0 || m <= 0) return 0;
+    k_quad_iou<<<ceil_div(n * m, 256), 256, 0, (hipStream_t)stream>>>(a, n, b, m, iou);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,269 @@
+// K5 -- warp every agent's BEV features and occupancy score into the ego frame and fuse them with a
+// per-pixel softmax over agents.
+//
+// Reference arithmetic (one pyramid level, one scene):
+//   opencood/models/fuse_modules/pyramid_fuse.py:17-63   weighted_fuse
+//   opencood/models/fuse_modules/pyramid_fuse.py:145-162 score = sigmoid(occ) + 1e-4, eval-mode
+//                                                         camera crop mask
+//   opencood/models/sub_modules/torch_transformation_utils.py:323-332  warp_affine_simple =
+//       F.affine_grid(M, size, align_corners=False) (+ `.to(src)`) and
+//       F.grid_sample(bilinear, zeros padding, align_corners=False)
+// The reference runs ~8 ATen kernels per level, each streaming the whole agent stack
+// (warp features, warp scores, compare, masked_fill, softmax, isnan/where, multiply, sum) and
+// materialises the warped stack.  Here one kernel reads each source tap once and writes the fused
+// map once: bytes moved = the operator's compulsory traffic.
+//
+// Sampling arithmetic follows PyTorch operation for operation: base grid = linspace(-1,1,W)*(W-1)/W
+// in the dtype of the affine matrix (float64 when pairwise_t_matrix comes from numpy), grid =
+// base @ M^T, rounded to fp32, unnormalise ((g+1)*size-1)/2, floor, corner weights as products of
+// fp32 differences, taps outside the image contribute zero.
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+constexpr int WF_MAXA = 8;     // agents handled per launch (max_cav is 5..8 in the reference configs)
+constexpr int WF_TW = 32, WF_TH = 8;  // pixel tile per 256-thread block
+
+struct WarpParams {
+    double m[WF_MAXA][6];   // rows of affine_matrix[b][0, a]: m00 m01 m02 m10 m11 m12
+    int crop[WF_MAXA][4];   // (h0,h1,w0,w1) window where the score is kept; h1<=h0: keep everything
+    int n_agents, C, H, W;
+    int grid_f64;
+};
+
+struct Taps {
+    int off;       // y0*W + x0 (may point outside; guarded by `ok`)
+    float w[4];    // nw, ne, sw, se
+    unsigned ok;   // bit k set: tap k lies inside the image
+};
+
+template <typename T>
+__device__ __forceinline__ T base_coord(int j, int n) {
+    // torch.linspace(-1, 1, n) * (n - 1) / n, element j
+    if (n <= 1) return (T)0;
+    const T step = (T)2 / (T)(n - 1);
+    const T v = (j < n / 2) ? (T)-1 + step * (T)j : (T)1 - step * (T)(n - 1 - j);
+    return v * (T)(n - 1) / (T)n;
+}
+
+template <typename T>
+__device__ __forceinline__ void grid_point(const double* m, int h, int w, int H, int W, float& gx, float& gy) {
+    const T xs = base_coord<T>(w, W), ys = base_coord<T>(h, H);
+    gx = (float)(((T)m[0] * xs + (T)m[1] * ys) + (T)m[2]);
+    gy = (float)(((T)m[3] * xs + (T)m[4] * ys) + (T)m[5]);
+}
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
+    const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+    const float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float x1 = x0 + 1.f, y1 = y0 + 1.f;
+    Taps t;
+    t.w[0] = (x1 - ix) * (y1 - iy);
+    t.w[1] = (ix - x0) * (y1 - iy);
+    t.w[2] = (x1 - ix) * (iy - y0);
+    t.w[3] = (ix - x0) * (iy - y0);
+    const bool xin0 = x0 >= 0.f && x0 <= (float)(W - 1);
+    const bool xin1 = x1 >= 0.f && x1 <= (float)(W - 1);
+    const bool yin0 = y0 >= 0.f && y0 <= (float)(H - 1);
+    const bool yin1 = y1 >= 0.f && y1 <= (float)(H - 1);
+    t.ok = (unsigned)(xin0 && yin0) | ((unsigned)(xin1 && yin0) << 1) | ((unsigned)(xin0 && yin1) << 2) |
+           ((unsigned)(xin1 && yin1) << 3);
+    // offsets are only dereferenced for taps with their bit set; keep the int conversion defined
+    const float xc = fminf(fmaxf(x0, -2.f), (float)W), yc = fminf(fmaxf(y0, -2.f), (float)H);
+    t.off = (int)yc * W + (int)xc;
+    return t;
+}
+
+__device__ __forceinline__ float score_at(const float* __restrict__ occ, int idx, int W, const int* crop) {
+    // sigmoid(occ) + 1e-4, zero outside the camera crop window (pyramid_fuse.py:145-162)
+    if (crop[1] > crop[0]) {
+        const int h = idx / W, w = idx - h * W;
+        if (h < crop[0] || h >= crop[1] || w < crop[2] || w >= crop[3]) return 0.f;
+    }
+    return 1.f / (1.f + expf(-occ[idx])) + 1e-4f;
+}
+
+__device__ __forceinline__ float sample(const float* __restrict__ src, const Taps& t, int W) {
+    // nw, ne, sw, se accumulated in that order (taps outside contribute exactly zero)
+    float acc = 0.f;
+    if (t.ok & 1u) acc = src[t.off] * t.w[0];
+    if (t.ok & 2u) acc += src[t.off + 1] * t.w[1];
+    if (t.ok & 4u) acc += src[t.off + W] * t.w[2];
+    if (t.ok & 8u) acc += src[t.off + W + 1] * t.w[3];
+    return acc;
+}
+
+__device__ __forceinline__ float sample_score(const float* __restrict__ occ, const Taps& t, int W, const int* crop) {
+    float acc = 0.f;
+    if (t.ok & 1u) acc = score_at(occ, t.off, W, crop) * t.w[0];
+    if (t.ok & 2u) acc += score_at(occ, t.off + 1, W, crop) * t.w[1];
+    if (t.ok & 4u) acc += score_at(occ, t.off + W, W, crop) * t.w[2];
+    if (t.ok & 8u) acc += score_at(occ, t.off + W + 1, W, crop) * t.w[3];
+    return acc;
+}
+
+// softmax over agents of the warped scores with the reference's masking rules:
+// score == 0 -> -inf; all agents masked -> NaN -> 0 (pyramid_fuse.py:51-58)
+__device__ __forceinline__ void agent_softmax(float* s, int n) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < WF_MAXA; ++a)
+        if (a < n) { if (s[a] == 0.f) s[a] = -INFINITY; mx = fmaxf(mx, s[a]); }
+    if (mx == -INFINITY) {
+#pragma unroll
+        for (int a = 0; a < WF_MAXA; ++a) s[a] = 0.f;
+        return;
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int a = 0; a < WF_MAXA; ++a)
+        if (a < n) { s[a] = expf(s[a] - mx); den += s[a]; }
+#pragma unroll
+    for (int a = 0; a < WF_MAXA; ++a)
+        if (a < n) s[a] = s[a] / den;
+}
+
+// ---- fused: warp all agents + softmax + weighted sum -------------------------------------------
+template <int CCH>
+__global__ __launch_bounds__(256) void k_warp_fuse(const float* __restrict__ feats,
+                                                  const float* __restrict__ occ, WarpParams p,
+                                                  float* __restrict__ out) {
+    const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
+    const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
+    if (w >= p.W || h >= p.H) return;
+    const int HW = p.H * p.W;
+    Taps taps[WF_MAXA];
+    float prob[WF_MAXA];
+#pragma unroll
+    for (int a = 0; a < WF_MAXA; ++a) {
+        prob[a] = 0.f;
+        if (a < p.n_agents) {
+            float gx, gy;
+            if (p.grid_f64) grid_point<double>(p.m[a], h, w, p.H, p.W, gx, gy);
+            else grid_point<float>(p.m[a], h, w, p.H, p.W, gx, gy);
+            taps[a] = make_taps(gx, gy, p.H, p.W);
+            prob[a] = sample_score(occ + (size_t)a * HW, taps[a], p.W, p.crop[a]);
+        }
+    }
+    agent_softmax(prob, p.n_agents);
+    const int c0 = blockIdx.z * CCH;
+    const int pix = h * p.W + w;
+#pragma unroll 2
+    for (int c = c0; c < c0 + CCH && c < p.C; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < WF_MAXA; ++a) {
+            if (a < p.n_agents && prob[a] != 0.f) {
+                const float v = sample(feats + ((size_t)a * p.C + c) * HW, taps[a], p.W);
+                acc += v * prob[a];
+            }
+        }
+        out[(size_t)c * HW + pix] = acc;
+    }
+}
+
+// ---- split form for agent-sharded execution ------------------------------------------------------
+template <int CCH>
+__global__ __launch_bounds__(256) void k_warp_agent(const float* __restrict__ feat,
+                                                   const float* __restrict__ occ, WarpParams p,
+                                                   float* __restrict__ feat_ego,
+                                                   float* __restrict__ score_ego) {
+    const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
+    const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
+    if (w >= p.W || h >= p.H) return;
+    const int HW = p.H * p.W;
+    float gx, gy;
+    if (p.grid_f64) grid_point<double>(p.m[0], h, w, p.H, p.W, gx, gy);
+    else grid_point<float>(p.m[0], h, w, p.H, p.W, gx, gy);
+    const Taps t = make_taps(gx, gy, p.H, p.W);
+    const int pix = h * p.W + w;
+    if (blockIdx.z == 0 && score_ego != nullptr) score_ego[pix] = sample_score(occ, t, p.W, p.crop[0]);
+    const int c0 = blockIdx.z * CCH;
+#pragma unroll 4
+    for (int c = c0; c < c0 + CCH && c < p.C; ++c)
+        feat_ego[(size_t)c * HW + pix] = sample(feat + (size_t)c * HW, t, p.W);
+}
+
+__global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ feats,
+                                                    const float4* __restrict__ scores, int n, int C,
+                                                    int HW4, float4* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW4) return;
+    float px[WF_MAXA], py[WF_MAXA], pz[WF_MAXA], pw[WF_MAXA];
+#pragma unroll
+    for (int a = 0; a < WF_MAXA; ++a) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a < n) s = scores[(size_t)a * HW4 + i];
+        px[a] = s.x; py[a] = s.y; pz[a] = s.z; pw[a] = s.w;
+    }
+    agent_softmax(px, n); agent_softmax(py, n); agent_softmax(pz, n); agent_softmax(pw, n);
+    const int c0 = blockIdx.y * 16;
+    for (int c = c0; c < c0 + 16 && c < C; ++c) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < WF_MAXA; ++a) {
+            if (a < n) {
+                const float4 v = feats[((size_t)a * C + c) * HW4 + i];
+                acc.x += v.x * px[a]; acc.y += v.y * py[a]; acc.z += v.z * pz[a]; acc.w += v.w * pw[a];
+            }
+        }
+        out[(size_t)c * HW4 + i] = acc;
+    }
+}
+
+static int fill_params(WarpParams& p, int n_agents, int C, int H, int W, const double* affine_host,
+                       int grid_f64, const int32_t* crop_host) {
+    HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "warp_fuse: n_agents must be in [1,%d] (got %d)",
+                 WF_MAXA, n_agents);
+    HEAL_REQUIRE(C >= 1 && H >= 1 && W >= 1, "warp_fuse: bad shape");
+    HEAL_REQUIRE(affine_host != nullptr, "warp_fuse: affine is NULL");
+    p.n_agents = n_agents; p.C = C; p.H = H; p.W = W; p.grid_f64 = grid_f64;
+    for (int a = 0; a < WF_MAXA; ++a) {
+        for (int k = 0; k < 6; ++k) p.m[a][k] = a < n_agents ? affine_host[a * 6 + k] : 0.0;
+        for (int k = 0; k < 4; ++k) p.crop[a][k] = (a < n_agents && crop_host) ? crop_host[a * 4 + k] : 0;
+    }
+    return 0;
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents, int channels, int H,
+                              int W, const double* affine_host, int grid_f64, const int32_t* crop_host,
+                              float* out, void* stream) {
+    WarpParams p;
+    if (fill_params(p, n_agents, channels, H, W, affine_host, grid_f64, crop_host)) return 1;
+    constexpr int CCH = 16;
+    dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, CCH));
+    k_warp_fuse<CCH><<<grid, 256, 0, (hipStream_t)stream>>>(feats, occ, p, out);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_warp_agent(const float* feat, const float* occ, int channels, int H, int W,
+                               const double* affine_host, int grid_f64, const int32_t* crop_host,
+                               float* feat_ego, float* score_ego, void* stream) {
+    WarpParams p;
+    if (fill_params(p, 1, channels, H, W, affine_host, grid_f64, crop_host)) return 1;
+    constexpr int CCH = 16;
+    dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, CCH));
+    k_warp_agent<CCH><<<grid, 256, 0, (hipStream_t)stream>>>(feat, occ, p, feat_ego, score_ego);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_fuse_warped(const float* feats_ego, const float* scores_ego, int n_agents,
+                                int channels, int H, int W, float* out, void* stream) {
+    HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "fuse_warped: n_agents must be in [1,%d]", WF_MAXA);
+    HEAL_REQUIRE((H * W) % 4 == 0, "fuse_warped: H*W must be a multiple of 4");
+    const int HW4 = H * W / 4;
+    dim3 grid(ceil_div(HW4, 256), ceil_div(channels, 16));
+    k_fuse_warped<<<grid, 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(feats_ego), reinterpret_cast<const float4*>(scores_ego), n_agents,
+        channels, HW4, reinterpret_cast<float4*>(out));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,77 @@
+"""PyramidFusion (reference: opencood/models/fuse_modules/pyramid_fuse.py:65-168) on top of the
+fused warp + occupancy-softmax kernel K5 (heal_warp_fuse)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from heal_amd import ops
+from heal_amd.opencood.models.sub_modules.bev_blocks import (Bottleneck, ResNetBEVBackbone, ResNetModified)
+
+
+def crop_window(H, W, ratio_h, ratio_w):
+    """pyramid_fuse.py:151-158: centre window of a camera agent's map whose score is kept."""
+    crop_H = H / ratio_h - 4
+    crop_W = W / ratio_w - 4
+    return (int(H // 2 - crop_H // 2), int(H // 2 + crop_H // 2),
+            int(W // 2 - crop_W // 2), int(W // 2 + crop_W // 2))
+
+
+def weighted_fuse(x, occ, record_len, affine_matrix, grid_f64=True, crops=None):
+    """pyramid_fuse.py:17-63 with the score construction folded in.
+
+    x [sum(n),C,H,W]; occ [sum(n),1,H,W] occupancy LOGITS; record_len: list of ints;
+    affine_matrix: host numpy [B,L,L,2,3]; crops: per-agent (h0,h1,w0,w1) or None."""
+    out = []
+    start = 0
+    for b, n in enumerate(record_len):
+        rows = affine_matrix[b][0, :n]
+        crop = None
+        if crops is not None:
+            crop = [crops[start + a] if crops[start + a] is not None else (0, 0, 0, 0) for a in range(n)]
+        out.append(ops.warp_fuse(x[start:start + n], occ[start:start + n], rows, grid_f64, crop))
+        start += n
+    return torch.stack(out)
+
+
+class PyramidFusion(ResNetBEVBackbone):
+    def __init__(self, model_cfg, input_channels=64):
+        super().__init__(model_cfg, input_channels)
+        if model_cfg["resnext"]:
+            # ResNeXt stages: 32 groups, width 4 per group, Bottleneck with expansion 1
+            self.resnet = ResNetModified(Bottleneck, model_cfg["layer_nums"], model_cfg["layer_strides"],
+                                         model_cfg["num_filters"], inplanes=model_cfg.get("inplanes", 64),
+                                         groups=32, width_per_group=4, expansion=1)
+        self.align_corners = model_cfg.get("align_corners", False)
+        if self.align_corners:
+            raise NotImplementedError("align_corners=True fusion is not used by any HEAL config")
+        for i in range(self.num_levels):
+            setattr(self, f"single_head_{i}", nn.Conv2d(model_cfg["num_filters"][i], 1, kernel_size=1))
+
+    def forward_single(self, spatial_features):
+        feature_list = self.get_multiscale_feature(spatial_features)
+        occ_map_list = [getattr(self, f"single_head_{i}")(feature_list[i]) for i in range(self.num_levels)]
+        return self.decode_multiscale_feature(feature_list), occ_map_list
+
+    def forward_collab(self, spatial_features, record_len, affine_matrix, agent_modality_list=None,
+                       cam_crop_info=None, grid_f64=True):
+        """affine_matrix: host numpy [B,L,L,2,3] (normalize_pairwise_tfm of the host pairwise matrix);
+        record_len: list of ints."""
+        feature_list = self.get_multiscale_feature(spatial_features)
+        use_crop = bool(cam_crop_info) and not self.training
+        fused_feature_list, occ_map_list = [], []
+        for i in range(self.num_levels):
+            occ_map = getattr(self, f"single_head_{i}")(feature_list[i])
+            occ_map_list.append(occ_map)
+            crops = None
+            if use_crop:
+                _, _, H, W = occ_map.shape
+                crops = []
+                for mod in agent_modality_list:
+                    if mod in cam_crop_info:
+                        crops.append(crop_window(H, W, cam_crop_info[mod][f"crop_ratio_H_{mod}"],
+                                                 cam_crop_info[mod][f"crop_ratio_W_{mod}"]))
+                    else:
+                        crops.append(None)
+            fused_feature_list.append(weighted_fuse(feature_list[i], occ_map, record_len, affine_matrix,
+                                                    grid_f64, crops))
+        return self.decode_multiscale_feature(fused_feature_list), occ_map_list

@@ -1,0 +1,112 @@
+"""HeterPyramidCollab -- HEAL's collaborative model (reference: opencood/models/
+heter_pyramid_collab.py:21-209).  Same constructor `args`, same forward(data_dict) keys, same
+state_dict key names; encoders, fusion and scatter run on the gfx950 kernels of libheal_amd.
+"""
+from collections import Counter, OrderedDict
+
+import torch
+import torch.nn as nn
+
+from heal_amd.opencood.models._heter_common import center_crop, find_encoder, modality_names, record_len_to_list
+from heal_amd.opencood.models.fuse_modules.pyramid_fuse import PyramidFusion
+from heal_amd.opencood.models.sub_modules.bev_blocks import (AlignNet, DownsampleConv, NaiveCompressor,
+                                                             ResNetBEVBackbone)
+from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
+
+
+class HeterPyramidCollab(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.modality_name_list = modality_names(args)
+        self.cav_range = args["lidar_range"]
+        self.sensor_type_dict = OrderedDict()
+        self.cam_crop_info = {}
+        for m in self.modality_name_list:
+            setting = args[m]
+            sensor = setting["sensor_type"]
+            self.sensor_type_dict[m] = sensor
+            setattr(self, f"encoder_{m}", find_encoder(setting["core_method"])(setting["encoder_args"]))
+            setattr(self, f"depth_supervision_{m}", bool(setting["encoder_args"].get("depth_supervision", False)))
+            setattr(self, f"backbone_{m}", ResNetBEVBackbone(setting["backbone_args"]))
+            setattr(self, f"aligner_{m}", AlignNet(setting["aligner_args"]))
+            if sensor == "camera":
+                gc = setting["camera_mask_args"]["grid_conf"]
+                setattr(self, f"crop_ratio_W_{m}", self.cav_range[3] / gc["xbound"][1])
+                setattr(self, f"crop_ratio_H_{m}", self.cav_range[4] / gc["ybound"][1])
+                setattr(self, f"xdist_{m}", gc["xbound"][1] - gc["xbound"][0])
+                setattr(self, f"ydist_{m}", gc["ybound"][1] - gc["ybound"][0])
+                self.cam_crop_info[m] = {f"crop_ratio_W_{m}": getattr(self, f"crop_ratio_W_{m}"),
+                                         f"crop_ratio_H_{m}": getattr(self, f"crop_ratio_H_{m}")}
+        self.H = self.cav_range[4] - self.cav_range[1]
+        self.W = self.cav_range[3] - self.cav_range[0]
+        self.fake_voxel_size = 1
+        self.pyramid_backbone = PyramidFusion(args["fusion_backbone"])
+        self.shrink_flag = "shrink_header" in args
+        if self.shrink_flag:
+            self.shrink_conv = DownsampleConv(args["shrink_header"])
+        self.cls_head = nn.Conv2d(args["in_head"], args["anchor_number"], kernel_size=1)
+        self.reg_head = nn.Conv2d(args["in_head"], 7 * args["anchor_number"], kernel_size=1)
+        self.dir_head = nn.Conv2d(args["in_head"], args["dir_args"]["num_bins"] * args["anchor_number"],
+                                  kernel_size=1)
+        self.compress = "compressor" in args
+        if self.compress:
+            self.compressor = NaiveCompressor(args["compressor"]["input_dim"], args["compressor"]["compress_ratio"])
+        self.model_train_init()
+
+    def model_train_init(self):
+        if self.compress:
+            self.eval()
+            for p in self.parameters():
+                p.requires_grad_(False)
+            self.compressor.train()
+            for p in self.compressor.parameters():
+                p.requires_grad_(True)
+
+    def encode_modality(self, data_dict, m):
+        """encoder -> light backbone -> aligner (-> camera pad) for all agents of modality m."""
+        feature = getattr(self, f"encoder_{m}")(data_dict, m)
+        feature = getattr(self, f"backbone_{m}")({"spatial_features": feature})["spatial_features_2d"]
+        feature = getattr(self, f"aligner_{m}")(feature)
+        if self.sensor_type_dict[m] == "camera":
+            _, _, H, W = feature.shape
+            feature = center_crop(feature, int(H * getattr(self, f"crop_ratio_H_{m}")),
+                                  int(W * getattr(self, f"crop_ratio_W_{m}")))
+        return feature
+
+    def heads(self, fused_feature):
+        if self.shrink_flag:
+            fused_feature = self.shrink_conv(fused_feature)
+        return self.cls_head(fused_feature), self.reg_head(fused_feature), self.dir_head(fused_feature)
+
+    def forward(self, data_dict):
+        output_dict = {"pyramid": "collab"}
+        agent_modality_list = data_dict["agent_modality_list"]
+        pairwise, grid_f64 = pairwise_to_host(data_dict["pairwise_t_matrix"])
+        affine_matrix = normalize_pairwise_tfm(pairwise, self.H, self.W, self.fake_voxel_size)
+        record_len = record_len_to_list(data_dict["record_len"])
+        counts = Counter(agent_modality_list)
+        feats = {}
+        for m in self.modality_name_list:
+            if m not in counts:
+                continue
+            feats[m] = self.encode_modality(data_dict, m)
+            if self.sensor_type_dict[m] == "camera" and getattr(self, f"depth_supervision_{m}"):
+                output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
+        if len(feats) == 1 and len(counts) == 1:
+            heter_feature_2d = next(iter(feats.values()))  # already in scene order
+        else:
+            cursor = {m: 0 for m in self.modality_name_list}
+            parts = []
+            for m in agent_modality_list:
+                parts.append(feats[m][cursor[m]])
+                cursor[m] += 1
+            heter_feature_2d = torch.stack(parts)
+        if self.compress:
+            heter_feature_2d = self.compressor(heter_feature_2d)
+        fused, occ_outputs = self.pyramid_backbone.forward_collab(
+            heter_feature_2d, record_len, affine_matrix, agent_modality_list, self.cam_crop_info, grid_f64)
+        cls_preds, reg_preds, dir_preds = self.heads(fused)
+        output_dict.update({"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds,
+                            "occ_single_list": occ_outputs})
+        return output_dict

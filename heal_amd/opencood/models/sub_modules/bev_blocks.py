@@ -1,0 +1,386 @@
+"""Dense 2-D BEV building blocks: ResNet / ResNeXt layers, deblocks, shrink head, ConvNeXt aligner,
+channel compressor.
+
+Parameter names and shapes follow the reference so its checkpoints load unchanged
+(SURVEY 8b): opencood/models/sub_modules/resblock.py:18-219, base_bev_backbone_resnet.py:12-142,
+downsample_conv.py:7-49, feature_alignnet.py:12-39, feature_alignnet_modules.py:12-31,299-361,
+naive_compress.py:5-31.
+
+Inference design (eval mode): every Conv+BatchNorm pair is folded into one convolution with bias
+(cached, re-folded when a parameter changes), ReLU and the residual add run in place -- one pass
+over each BEV map instead of three.  The convolutions themselves are library GEMM/conv calls
+(MIOpen through torch) in fp32; they are the MFMA-bound part of the path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _versions(*tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
+class _FoldCache:
+    """Folded (weight, bias) of a conv followed by an eval-mode BatchNorm, cached per module pair."""
+
+    def __init__(self):
+        self.key = None
+        self.value = None
+
+    def get(self, conv, bn, transposed=False):
+        tensors = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = _versions(*tensors)
+        if key != self.key:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+                if transposed:  # ConvTranspose2d weight is [Cin, Cout/groups, k, k]
+                    w = conv.weight * scale.view(1, -1, 1, 1)
+                else:
+                    w = conv.weight * scale.view(-1, 1, 1, 1)
+                b = shift if conv.bias is None else shift + conv.bias * scale
+                self.value = (w.contiguous(), b.contiguous())
+            self.key = key
+        return self.value
+
+
+def _require_eval(module):
+    if module.training and torch.is_grad_enabled():
+        raise NotImplementedError(
+            "heal_amd implements the inference hot path; the training/backward path is listed as "
+            "'next' (SURVEY 8f).  Call model.eval() and run under torch.no_grad().")
+
+
+class ConvBN(nn.Module):
+    """conv (no bias) + BatchNorm2d (+ ReLU) with reference-compatible child names given by the
+    owner; this helper only provides the folded forward."""
+
+    @staticmethod
+    def run(x, conv, bn, cache, relu, residual=None):
+        w, b = cache.get(conv, bn)
+        y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if residual is not None:
+            y.add_(residual)
+        if relu:
+            y.relu_()
+        return y
+
+
+def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, groups=groups,
+                     bias=False, dilation=dilation)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """resblock.py:18-64."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self._c1, self._c2, self._cd = _FoldCache(), _FoldCache(), _FoldCache()
+
+    def forward(self, x):
+        _require_eval(self)
+        identity = x
+        if self.downsample is not None:
+            identity = ConvBN.run(x, self.downsample[0], self.downsample[1], self._cd, relu=False)
+        out = ConvBN.run(x, self.conv1, self.bn1, self._c1, relu=True)
+        return ConvBN.run(out, self.conv2, self.bn2, self._c2, relu=True, residual=identity)
+
+
+class Bottleneck(nn.Module):
+    """resblock.py:67-122.  PyramidFusion uses it with expansion 1 (pyramid_fuse.py:72)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None, expansion=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        exp = self.expansion if expansion is None else expansion
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = conv1x1(inplanes, width)
+        self.bn1 = norm_layer(width)
+        self.conv2 = conv3x3(width, width, stride, groups, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = conv1x1(width, planes * exp)
+        self.bn3 = norm_layer(planes * exp)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self._c1, self._c2, self._c3, self._cd = _FoldCache(), _FoldCache(), _FoldCache(), _FoldCache()
+
+    def forward(self, x):
+        _require_eval(self)
+        identity = x
+        if self.downsample is not None:
+            identity = ConvBN.run(x, self.downsample[0], self.downsample[1], self._cd, relu=False)
+        out = ConvBN.run(x, self.conv1, self.bn1, self._c1, relu=True)
+        out = ConvBN.run(out, self.conv2, self.bn2, self._c2, relu=True)
+        return ConvBN.run(out, self.conv3, self.bn3, self._c3, relu=True, residual=identity)
+
+
+class ResNetModified(nn.Module):
+    """resblock.py:125-219: `layer{i}` = one stage of `layers[i]` blocks with stride layer_strides[i]."""
+
+    def __init__(self, block, layers, layer_strides, num_filters, groups=1, width_per_group=64, inplanes=64,
+                 expansion=None):
+        super().__init__()
+        self.inplanes = inplanes
+        self.groups = groups
+        self.base_width = width_per_group
+        self.layernum = len(num_filters)
+        self._exp = block.expansion if expansion is None else expansion
+        for i in range(self.layernum):
+            setattr(self, f"layer{i}", self._make_layer(block, num_filters[i], layers[i], layer_strides[i]))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, block, planes, blocks, stride):
+        exp = self._exp
+        kw = {"expansion": exp} if block is Bottleneck else {}
+        downsample = None
+        if stride != 1 or self.inplanes != planes * exp:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * exp, stride), nn.BatchNorm2d(planes * exp))
+        layers = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, 1, None, **kw)]
+        self.inplanes = planes * exp
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width, **kw))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        feats = []
+        for i in range(self.layernum):
+            x = getattr(self, f"layer{i}")(x)
+            feats.append(x)
+        return feats
+
+
+class _Deblock(nn.Sequential):
+    """ConvTranspose2d(k=s, stride=s) | Conv2d + BatchNorm2d(eps 1e-3) + ReLU, folded at inference
+    (base_bev_backbone_resnet.py:49-74)."""
+
+    def __init__(self, conv, bn):
+        super().__init__(conv, bn, nn.ReLU())
+        self._cache = _FoldCache()
+
+    def forward(self, x):
+        _require_eval(self)
+        conv, bn = self[0], self[1]
+        if isinstance(conv, nn.ConvTranspose2d):
+            w, b = self._cache.get(conv, bn, transposed=True)
+            y = F.conv_transpose2d(x, w, b, conv.stride, conv.padding, conv.output_padding, conv.groups)
+        else:
+            w, b = self._cache.get(conv, bn)
+            y = F.conv2d(x, w, b, conv.stride, conv.padding)
+        return y.relu_()
+
+
+class ResNetBEVBackbone(nn.Module):
+    """base_bev_backbone_resnet.py:12-142."""
+
+    def __init__(self, model_cfg, input_channels=64):
+        super().__init__()
+        self.model_cfg = model_cfg
+        if "layer_nums" in model_cfg:
+            layer_nums = model_cfg["layer_nums"]
+            layer_strides = model_cfg["layer_strides"]
+            num_filters = model_cfg["num_filters"]
+            assert len(layer_nums) == len(layer_strides) == len(num_filters)
+        else:
+            layer_nums = layer_strides = num_filters = []
+        if "upsample_strides" in model_cfg:
+            assert len(model_cfg["upsample_strides"]) == len(model_cfg["num_upsample_filter"])
+            num_upsample_filters = model_cfg["num_upsample_filter"]
+            upsample_strides = model_cfg["upsample_strides"]
+        else:
+            upsample_strides = num_upsample_filters = []
+        self.resnet = ResNetModified(BasicBlock, layer_nums, layer_strides, num_filters,
+                                     inplanes=model_cfg.get("inplanes", 64))
+        self.num_levels = len(layer_nums)
+        self.deblocks = nn.ModuleList()
+        for idx in range(self.num_levels):
+            if len(upsample_strides) > 0:
+                stride = upsample_strides[idx]
+                if stride >= 1:
+                    conv = nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride,
+                                              bias=False)
+                else:
+                    stride = int(np.round(1 / stride))
+                    conv = nn.Conv2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride, bias=False)
+                self.deblocks.append(_Deblock(conv, nn.BatchNorm2d(num_upsample_filters[idx], eps=1e-3, momentum=0.01)))
+        c_in = sum(num_upsample_filters)
+        if len(upsample_strides) > self.num_levels:
+            self.deblocks.append(_Deblock(
+                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
+                nn.BatchNorm2d(c_in, eps=1e-3, momentum=0.01)))
+        self.num_bev_features = c_in
+
+    def get_multiscale_feature(self, spatial_features):
+        return self.resnet(spatial_features)
+
+    def decode_multiscale_feature(self, x):
+        ups = []
+        for i in range(self.num_levels):
+            ups.append(self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i])
+        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        if len(self.deblocks) > self.num_levels:
+            x = self.deblocks[-1](x)
+        return x
+
+    def get_layer_i_feature(self, spatial_features, layer_i):
+        return getattr(self.resnet, f"layer{layer_i}")(spatial_features)
+
+    def forward(self, data_dict):
+        x = self.resnet(data_dict["spatial_features"])
+        data_dict["spatial_features_2d"] = self.decode_multiscale_feature(x)
+        return data_dict
+
+
+class DoubleConv(nn.Module):
+    """downsample_conv.py:7-27: conv(k,s,p)+ReLU, conv3x3+ReLU, both with bias, no BN."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1),
+            nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        c0, c1 = self.double_conv[0], self.double_conv[2]
+        x = F.conv2d(x, c0.weight, c0.bias, c0.stride, c0.padding).relu_()
+        return F.conv2d(x, c1.weight, c1.bias, c1.stride, c1.padding).relu_()
+
+
+class DownsampleConv(nn.Module):
+    """downsample_conv.py:30-49 (config keys incl. the reference's spelling 'kernal_size')."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        input_dim = config["input_dim"]
+        for ksize, dim, stride, padding in zip(config["kernal_size"], config["dim"], config["stride"],
+                                               config["padding"]):
+            self.layers.append(DoubleConv(input_dim, dim, kernel_size=ksize, stride=stride, padding=padding))
+            input_dim = dim
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class LayerNorm(nn.Module):
+    """feature_alignnet_modules.py:12-31."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.data_format = data_format
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        if self.data_format == "channels_last":
+            return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        u = x.mean(1, keepdim=True)
+        s = (x - u).pow(2).mean(1, keepdim=True)
+        x = (x - u) / torch.sqrt(s + self.eps)
+        return self.weight[:, None, None] * x + self.bias[:, None, None]
+
+
+class ConvNeXtBlock(nn.Module):
+    """feature_alignnet_modules.py:299-344 (deform=False, drop_path=0)."""
+
+    def __init__(self, dim, layer_scale_init_value=1e-6, kernel_size=7):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, kernel_size=kernel_size, padding=kernel_size // 2, groups=dim)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) \
+            if layer_scale_init_value > 0 else None
+
+    def forward(self, x):
+        inp = x
+        x = self.dwconv(x).permute(0, 2, 3, 1)
+        x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
+        if self.gamma is not None:
+            x = self.gamma * x
+        return inp + x.permute(0, 3, 1, 2)
+
+
+class ConvNeXt(nn.Module):
+    """feature_alignnet_modules.py:346-361."""
+
+    def __init__(self, args):
+        super().__init__()
+        if args.get("deform", False):
+            raise NotImplementedError("deformable ConvNeXt aligner is out of scope (needs mmcv)")
+        self.model = nn.Sequential(*[ConvNeXtBlock(args["dim"], kernel_size=args.get("kernel_size", 7))
+                                     for _ in range(args["num_of_blocks"])])
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class AlignNet(nn.Module):
+    """feature_alignnet.py:12-39; the HEAL configs use 'identity' and 'convnext'."""
+
+    def __init__(self, args):
+        super().__init__()
+        name = args["core_method"]
+        if name == "identity":
+            self.channel_align = nn.Identity()
+        elif name == "convnext":
+            self.channel_align = ConvNeXt(args["args"])
+        else:
+            raise NotImplementedError(f"aligner '{name}' is outside the hot-path scope (SURVEY 2, row 6)")
+        if args.get("spatial_align", False):
+            raise NotImplementedError
+
+    def forward(self, x):
+        return self.channel_align(x)
+
+
+class NaiveCompressor(nn.Module):
+    """naive_compress.py:5-31."""
+
+    def __init__(self, input_dim, compress_raito):
+        super().__init__()
+        mid = input_dim // compress_raito
+        self.encoder = nn.Sequential(nn.Conv2d(input_dim, mid, 3, 1, 1), nn.BatchNorm2d(mid, eps=1e-3, momentum=0.01),
+                                     nn.ReLU())
+        self.decoder = nn.Sequential(nn.Conv2d(mid, input_dim, 3, 1, 1),
+                                     nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01), nn.ReLU(),
+                                     nn.Conv2d(input_dim, input_dim, 3, 1, 1),
+                                     nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01), nn.ReLU())
+        self._c = [_FoldCache() for _ in range(3)]
+
+    def forward(self, x):
+        _require_eval(self)
+        x = ConvBN.run(x, self.encoder[0], self.encoder[1], self._c[0], relu=True)
+        x = ConvBN.run(x, self.decoder[0], self.decoder[1], self._c[1], relu=True)
+        return ConvBN.run(x, self.decoder[3], self.decoder[4], self._c[2], relu=True)

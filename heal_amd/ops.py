@@ -1,0 +1,239 @@
+"""Tensor-level wrappers over the C ABI (include/heal_amd.h).
+
+torch is used for device memory and the current HIP stream only; all arithmetic happens in
+libheal_amd.so.  Every function requires CUDA(HIP) tensors and raises otherwise -- there is no CPU
+path in the product.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+
+_WS = {}
+
+# Optional per-operator timing with HIP events on the launch stream (bench.py turns it on):
+# TIMING = {} enables it; every wrapper then appends (start_event, end_event) under its name.
+TIMING = None
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            self.e1.record(torch.cuda.current_stream())
+            TIMING.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
+def timing_summary():
+    """name -> (calls, mean milliseconds); call after torch.cuda.synchronize()."""
+    out = {}
+    for name, evs in (TIMING or {}).items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _capi.HealAmdError(f"{name} must be a CUDA/HIP tensor (heal_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise _capi.HealAmdError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _workspace(key, nbytes, device):
+    """Grow-only per-(op, device) scratch buffer (256-B aligned by the caching allocator)."""
+    k = (key, device.index)
+    buf = _WS.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _WS[k] = buf
+    return buf
+
+
+def _host_array(values, ctype):
+    arr = (ctype * len(values))(*values)
+    return arr
+
+
+# ------------------------------------------------------------------------------------------------
+def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=0, sync=True):
+    """K1.  points [N,4] f32 cuda -> (voxels [M,P,4], coords [M,4] (b,z,y,x) i32, num_points [M] i32).
+
+    With sync=True (the SpVoxelPreprocessor contract: exact-size outputs) the voxel count is read
+    back and the outputs are sliced; with sync=False the full-capacity buffers and the device
+    counter are returned: (voxels, coords, num_points, n_voxels_dev)."""
+    points = _need(points, torch.float32, "points")
+    if points.dim() != 2 or points.shape[1] != 4:
+        raise _capi.HealAmdError("points must be [N,4]")
+    n = int(points.shape[0])
+    cap = max(1, min(n, int(max_voxels)))
+    dev = points.device
+    voxels = torch.empty((cap, max_points, 4), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nbytes = _capi.query("heal_voxelize_workspace", n, int(max_voxels))
+    ws = _workspace("voxelize", nbytes, dev)
+    rng = _host_array([float(v) for v in lidar_range], ctypes.c_float)
+    vs = _host_array([float(v) for v in voxel_size], ctypes.c_float)
+    with _Timed("voxelize"):
+        _capi.call("heal_voxelize", _ptr(points), n, rng, vs, int(max_points), int(max_voxels), int(batch_idx),
+                   _ptr(voxels), _ptr(coords), _ptr(num), _ptr(count), _ptr(ws), ws.numel(), _stream())
+    if not sync:
+        return voxels, coords, num, count
+    m = int(count.item())
+    return voxels[:m], coords[:m], num[:m]
+
+
+def pfn_scatter(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_size, lidar_range,
+                n_agents, ny, nx, n_voxels_dev=None, return_pillars=False, out=None):
+    """K2.  -> canvas [n_agents,64,ny,nx] (and pillar features [M,64] when asked)."""
+    voxels = _need(voxels, torch.float32, "voxels")
+    coords = _need(coords, torch.int32, "coords")
+    num_points = _need(num_points, torch.int32, "num_points")
+    weight = _need(weight, torch.float32, "weight")
+    bn_scale = _need(bn_scale, torch.float32, "bn_scale")
+    bn_shift = _need(bn_shift, torch.float32, "bn_shift")
+    M, P = int(voxels.shape[0]), int(voxels.shape[1])
+    C = int(weight.shape[0])
+    if weight.shape[1] != 10 or voxels.shape[2] != 4 or coords.shape[1] != 4:
+        raise _capi.HealAmdError("pfn_scatter: expected voxels [M,P,4], coords [M,4], weight [C,10]")
+    dev = voxels.device
+    if out is None:
+        canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev)
+    else:
+        canvas = out
+        if (tuple(canvas.shape) != (n_agents, C, ny, nx) or canvas.dtype != torch.float32
+                or not canvas.is_contiguous() or not canvas.is_cuda):
+            raise _capi.HealAmdError("pfn_scatter: `out` must be a contiguous f32 cuda [n_agents,C,ny,nx]")
+    pillars = torch.empty((max(M, 1), C), dtype=torch.float32, device=dev)
+    nbytes = _capi.query("heal_pfn_scatter_workspace", M, n_agents, ny, nx, C)
+    ws = _workspace("pfn_scatter", nbytes, dev)
+    vx, vy, vz = (float(v) for v in voxel_size)
+    xo = vx / 2 + lidar_range[0]
+    yo = vy / 2 + lidar_range[1]
+    zo = vz / 2 + lidar_range[2]
+    with _Timed("pfn_scatter"):
+        _capi.call("heal_pfn_scatter", _ptr(voxels), _ptr(coords), _ptr(num_points), M, _ptr(n_voxels_dev), P,
+                   _ptr(weight), _ptr(bn_scale), _ptr(bn_shift), C, vx, vy, vz, xo, yo, zo,
+                   int(n_agents), int(ny), int(nx), _ptr(canvas), _ptr(pillars), _ptr(ws), ws.numel(), _stream())
+    if return_pillars:
+        return canvas, pillars[:M]
+    return canvas
+
+
+def _affine_host(affine_rows):
+    a = np.ascontiguousarray(np.asarray(affine_rows, dtype=np.float64).reshape(-1, 6))
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _crop_host(crop, n):
+    if crop is None:
+        return None, ctypes.c_void_p(0)
+    c = np.ascontiguousarray(np.asarray(crop, dtype=np.int32).reshape(n, 4))
+    return c, c.ctypes.data_as(ctypes.c_void_p)
+
+
+def warp_fuse(feats, occ, affine_rows, grid_f64=True, crop=None):
+    """K5 fused.  feats [n,C,H,W], occ [n,1,H,W] logits, affine_rows [n,2,3] (host) -> [C,H,W]."""
+    feats = _need(feats, torch.float32, "feats")
+    occ = _need(occ, torch.float32, "occ")
+    n, C, H, W = (int(v) for v in feats.shape)
+    out = torch.empty((C, H, W), dtype=torch.float32, device=feats.device)
+    a, ap = _affine_host(affine_rows)
+    c, cp = _crop_host(crop, n)
+    with _Timed(f"warp_fuse_c{C}"):
+        _capi.call("heal_warp_fuse", _ptr(feats), _ptr(occ), n, C, H, W, ap, int(bool(grid_f64)), cp,
+                   _ptr(out), _stream())
+    return out
+
+
+def warp_agent(feat, occ, affine_row, grid_f64=True, crop=None):
+    """K5 split, rank-local half: feat [C,H,W], occ [1,H,W] -> (feat_ego [C,H,W], score_ego [1,H,W])."""
+    feat = _need(feat, torch.float32, "feat")
+    occ = _need(occ, torch.float32, "occ")
+    C, H, W = (int(v) for v in feat.shape[-3:])
+    feat_ego = torch.empty((C, H, W), dtype=torch.float32, device=feat.device)
+    score_ego = torch.empty((1, H, W), dtype=torch.float32, device=feat.device)
+    a, ap = _affine_host(affine_row)
+    c, cp = _crop_host(crop, 1)
+    _capi.call("heal_warp_agent", _ptr(feat), _ptr(occ), C, H, W, ap, int(bool(grid_f64)), cp,
+               _ptr(feat_ego), _ptr(score_ego), _stream())
+    return feat_ego, score_ego
+
+
+def fuse_warped(feats_ego, scores_ego):
+    """K5 split, post-all-gather half: [n,C,H,W], [n,1,H,W] -> [C,H,W]."""
+    feats_ego = _need(feats_ego, torch.float32, "feats_ego")
+    scores_ego = _need(scores_ego, torch.float32, "scores_ego")
+    n, C, H, W = (int(v) for v in feats_ego.shape)
+    out = torch.empty((C, H, W), dtype=torch.float32, device=feats_ego.device)
+    _capi.call("heal_fuse_warped", _ptr(feats_ego), _ptr(scores_ego), n, C, H, W, _ptr(out), _stream())
+    return out
+
+
+def decode_nms(cls, reg, dirp, anchors, score_thr, dir_offset, num_bins, nms_thr, tfm, gt_range,
+               nms_top=1000, sync=True):
+    """K8.  cls [1,A,H,W], reg [1,7A,H,W], dirp [1,bins*A,H,W] or None, anchors [H,W,A,7] f32 cuda.
+    -> (corners [K,8,3], scores [K]) or (None, None) when nothing survives (sync=True), or the
+    full-capacity buffers plus the device count (sync=False)."""
+    cls = _need(cls, torch.float32, "cls_preds")
+    reg = _need(reg, torch.float32, "reg_preds")
+    anchors = _need(anchors, torch.float32, "anchors")
+    if dirp is not None:
+        dirp = _need(dirp, torch.float32, "dir_preds")
+    if cls.dim() == 4:
+        if cls.shape[0] != 1:
+            raise _capi.HealAmdError("decode_nms: batch size must be 1 (voxel_postprocessor.py:314)")
+        cls, reg = cls[0], reg[0]
+        dirp = dirp[0] if dirp is not None else None
+    A, H, W = (int(v) for v in cls.shape)
+    dev = cls.device
+    out_c = torch.empty((nms_top, 8, 3), dtype=torch.float32, device=dev)
+    out_s = torch.empty((nms_top,), dtype=torch.float32, device=dev)
+    out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nbytes = _capi.query("heal_decode_nms_workspace", A * H * W, int(nms_top))
+    ws = _workspace("decode_nms", nbytes, dev)
+    t = _host_array([float(v) for v in np.asarray(tfm, dtype=np.float32).reshape(-1)], ctypes.c_float)
+    g = _host_array([float(v) for v in gt_range], ctypes.c_float)
+    with _Timed("decode_nms"):
+        _capi.call("heal_decode_nms", _ptr(cls), _ptr(reg), _ptr(dirp), _ptr(anchors), H, W, A, int(num_bins),
+                   float(score_thr), float(dir_offset), float(nms_thr), int(nms_top), t, g,
+                   _ptr(out_c), _ptr(out_s), _ptr(out_n), int(nms_top), _ptr(ws), ws.numel(), _stream())
+    if not sync:
+        return out_c, out_s, out_n
+    k = int(out_n.item())
+    if k == 0:
+        return None, None
+    return out_c[:k], out_s[:k]
+
+
+def quad_iou(a, b):
+    """Pairwise rotated IoU of quads a [n,4,2], b [m,4,2] (f32 cuda) -> [n,m]."""
+    a = _need(a, torch.float32, "a")
+    b = _need(b, torch.float32, "b")
+    n, m = int(a.shape[0]), int(b.shape[0])
+    out = torch.empty((n, m), dtype=torch.float32, device=a.device)
+    _capi.call("heal_quad_iou", _ptr(a), n, _ptr(b), m, _ptr(out), _stream())
+    return out

@@ -1,0 +1,77 @@
+"""One-scene perception pipeline on one GPU: device point clouds -> voxelise (K1) -> model forward
+(K2, dense BEV convs, K5) -> decode + rotated NMS (K8).  This is what `tools/inference.py`'s loop
+body does per frame (to_device, model(batch['ego']), dataset.post_process), minus disk
+I/O: inputs are already resident in HBM.
+"""
+import numpy as np
+import torch
+
+from heal_amd import synth
+from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+from heal_amd.opencood.tools.train_utils import create_model
+
+
+def fill_deterministic(module, seed=0):
+    """Random-init weights of the named architecture (there are no checkpoints on the box); BN
+    statistics are kept non-trivial so that folding is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if not t.dtype.is_floating_point:
+                continue
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "running_var":
+                t.copy_(0.7 + 0.6 * torch.rand(t.shape, generator=g))
+            elif leaf == "running_mean":
+                t.copy_(0.1 * torch.randn(t.shape, generator=g))
+            elif t.dim() == 1 and leaf == "weight":
+                t.copy_(1.0 + 0.1 * torch.randn(t.shape, generator=g))
+            elif leaf in ("bias", "gamma"):
+                t.copy_(0.05 * torch.randn(t.shape, generator=g))
+            elif t.dim() >= 2:
+                fan_in = int(np.prod(t.shape[1:]))
+                t.copy_(torch.randn(t.shape, generator=g) * (1.6 / fan_in) ** 0.5)
+    return module
+
+
+class Scene:
+    """Synthetic OPV2V-shaped scene resident on one device."""
+
+    def __init__(self, n_agents, seed, device, max_cav=None, modalities=None):
+        self.n_agents = n_agents
+        self.modalities = modalities or ["m1"] * n_agents
+        self.points = [torch.from_numpy(synth.lidar_frame(seed * 1000 + k)).to(device) for k in range(n_agents)]
+        self.poses = synth.agent_poses(seed, n_agents)
+        L = max_cav or max(n_agents, 5)
+        self.pairwise = synth.pairwise_t_matrix(self.poses, L)[None]  # [1,L,L,4,4] float64 (host metadata)
+        self.record_len = [n_agents]
+
+    def model_input(self):
+        return {"inputs_m1": {"points": self.points}, "agent_modality_list": list(self.modalities),
+                "record_len": self.record_len, "pairwise_t_matrix": self.pairwise}
+
+
+class ScenePipeline:
+    def __init__(self, hypes, device, seed=0):
+        self.hypes = hypes
+        self.device = torch.device(device)
+        self.model = fill_deterministic(create_model(hypes), seed).to(self.device).eval()
+        # keep candidate counts realistic with random weights: bias the classification head down
+        with torch.no_grad():
+            for name, p in self.model.named_parameters():
+                if name.startswith("cls_head") and name.endswith("bias"):
+                    p.fill_(-4.0)
+        self.post = VoxelPostprocessor(hypes["postprocess"], train=False)
+        self.anchor_box = torch.from_numpy(self.post.generate_anchor_box()).to(self.device)
+        self.tfm = torch.eye(4)
+
+    @torch.no_grad()
+    def forward(self, scene):
+        return self.model(scene.model_input())
+
+    @torch.no_grad()
+    def step(self, scene):
+        """One scene end to end; returns (pred_box3d [K,8,3] | None, scores | None)."""
+        out = self.model(scene.model_input())
+        batch = {"ego": {"transformation_matrix": self.tfm, "anchor_box": self.anchor_box}}
+        return self.post.post_process(batch, {"ego": out})

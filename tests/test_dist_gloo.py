@@ -1,0 +1,75 @@
+"""The N>1 path's exchange step on CPU: world_size-2 gloo processes run the same ownership /
+pack / all-gather / unpack code the GPU ranks run (heal_amd/dist.py); the result must equal the
+single-process stacking in scene agent order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from heal_amd import dist as hd
+
+SHAPES = [(4, 8, 8), (6, 4, 4), (8, 2, 2)]
+
+
+def _agent_maps(a):
+    g = torch.Generator().manual_seed(100 + a)
+    feats = [torch.randn((c, h, w), generator=g) for c, h, w in SHAPES]
+    scores = [torch.rand((1, h, w), generator=g) for c, h, w in SHAPES]
+    return feats, scores
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, n_agents, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = hd.owned_agents(n_agents, rank, world)
+    lf = [torch.stack([_agent_maps(a)[0][l] for a in mine]) if mine else torch.zeros((0,) + SHAPES[l])
+          for l in range(len(SHAPES))]
+    ls = [torch.stack([_agent_maps(a)[1][l] for a in mine]) if mine else torch.zeros((0, 1) + SHAPES[l][1:])
+          for l in range(len(SHAPES))]
+    buf = hd.pack_levels(lf, ls, hd.slots_per_rank(n_agents, world))
+    gathered = hd.all_gather_packed(buf, world)
+    levels = hd.unpack_levels(gathered, SHAPES, n_agents, world)
+    if rank == 0:
+        torch.save([(f.clone(), s.clone()) for f, s in levels], tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_agents", [5, 2, 1])
+def test_all_gather_of_packed_maps_world2(tmp_path, n_agents):
+    world = 2
+    out = str(tmp_path / "levels.pt")
+    mp.spawn(_worker, args=(world, n_agents, _free_port(), out), nprocs=world, join=True)
+    levels = torch.load(out)
+    for l, (f, s) in enumerate(levels):
+        want_f = torch.stack([_agent_maps(a)[0][l] for a in range(n_agents)])
+        want_s = torch.stack([_agent_maps(a)[1][l] for a in range(n_agents)])
+        assert torch.equal(f, want_f) and torch.equal(s, want_s)
+
+
+def test_ownership_and_padding_rules():
+    assert hd.owned_agents(5, 0, 2) == [0, 2, 4] and hd.owned_agents(5, 1, 2) == [1, 3]
+    assert hd.owned_agents(5, 7, 8) == [] and hd.owned_agents(5, 0, 8) == [0]
+    assert hd.slots_per_rank(5, 2) == 3 and hd.slots_per_rank(5, 8) == 1 and hd.slots_per_rank(5, 4) == 2
+    # padding slots are all-zero: score 0 -> masked out by the fusion kernel
+    lf = [torch.ones((1,) + s) for s in SHAPES]
+    ls = [torch.ones((1, 1) + s[1:]) for s in SHAPES]
+    buf = hd.pack_levels(lf, ls, 3)
+    assert buf.shape[0] == 3 and float(buf[1:].abs().sum()) == 0.0 and float(buf[0].min()) == 1.0
+    # single-process gather is the identity
+    g = hd.all_gather_packed(buf, 1)
+    lv = hd.unpack_levels(g, SHAPES, 1, 1)
+    assert all(torch.equal(f, torch.ones((1,) + s)) for (f, _), s in zip(lv, SHAPES))

@@ -1,0 +1,269 @@
+"""Parity of the gfx950 kernels (through the C ABI) against the oracle and the reference's golden
+vectors.  Needs a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from oracle import oracle_np as O
+from tests.golden.detfill import det_values
+
+pytestmark = pytest.mark.gpu
+
+PP_RANGE = [-102.4, -102.4, -3, 102.4, 102.4, 1]
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def check_voxelize(pts, lidar_range, voxel_size, P, max_voxels):
+    from heal_amd import ops
+    v, c, n = ops.voxelize(dev(pts), lidar_range, voxel_size, P, max_voxels, batch_idx=3)
+    ov, oc, on = cref.voxelize(pts, lidar_range, voxel_size, P, max_voxels, batch_idx=3)
+    assert v.shape[0] == ov.shape[0], (v.shape, ov.shape)
+    np.testing.assert_array_equal(c.cpu().numpy(), oc)
+    np.testing.assert_array_equal(n.cpu().numpy(), on)
+    # bit-exact copy of the points (compare as raw bits so that NaN payloads count too)
+    np.testing.assert_array_equal(v.cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    return ov.shape[0]
+
+
+# ---------------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("seed", [1000, 1001])
+def test_voxelize_pointpillars_full_frame(seed):
+    from heal_amd import synth
+    pts = synth.lidar_frame(seed)
+    m = check_voxelize(pts, PP_RANGE, [0.4, 0.4, 4], 32, 70000)
+    assert m > 3000
+
+
+def test_voxelize_second_grid_and_voxel_cap():
+    from heal_amd import synth
+    pts = synth.lidar_frame(1002)
+    check_voxelize(pts, PP_RANGE, [0.1, 0.1, 0.1], 5, 70000)      # 41 x 2048 x 2048 cells: hash path
+    check_voxelize(pts, PP_RANGE, [0.1, 0.1, 0.1], 5, 3000)       # max_voxels cap reached
+    check_voxelize(pts, PP_RANGE, [0.4, 0.4, 4], 3, 100)          # both caps
+
+
+def test_voxelize_edge_cases():
+    rng = np.random.default_rng(0)
+    R = [-4.0, -4.0, -3.0, 4.0, 4.0, 1.0]
+    V = [0.4, 0.4, 4.0]
+    # every point outside
+    pts = rng.uniform(5, 9, (257, 4)).astype(np.float32)
+    assert check_voxelize(pts, R, V, 8, 100) == 0
+    # exactly on the boundaries (lower inclusive, upper exclusive), negative zero, duplicates, NaN
+    pts = np.array([[-4.0, -4.0, -3.0, 0.1], [4.0, 0.0, 0.0, 0.2], [0.0, 4.0, 0.0, 0.3], [0.0, 0.0, 1.0, 0.4],
+                    [-0.0, -0.0, -0.0, 0.5], [0.0, 0.0, 0.0, 0.6], [3.9999998, 3.9999998, 0.9999999, 0.7],
+                    [np.nan, 0.0, 0.0, 0.8], [0.0, np.inf, 0.0, 0.9], [0.4, 0.8, 0.0, 1.0],
+                    [0.4, 0.8, 0.0, 1.0], [0.39999998, 0.8000001, 0.0, 1.1]], np.float32)
+    assert check_voxelize(pts, R, V, 8, 100) > 0
+    # many points in a single voxel (> max_points) and a single point
+    pts = np.concatenate([rng.uniform(0.0, 0.39, (500, 4)), rng.uniform(-3.9, 3.9, (300, 4))]).astype(np.float32)
+    check_voxelize(pts, R, V, 8, 100)
+    check_voxelize(pts[:1], R, V, 8, 100)
+    # ragged sizes around the tile boundaries of the scan / sort
+    for n in (63, 64, 65, 2047, 2048, 2049, 4097):
+        check_voxelize(rng.uniform(-4.5, 4.5, (n, 4)).astype(np.float32), R, V, 4, 50)
+
+
+def test_voxelize_round_trip_property():
+    """Size-independent properties at full size: every in-range point lands in exactly the voxel of
+    its cell, no voxel is empty, slots keep input order."""
+    from heal_amd import ops, synth
+    pts = synth.lidar_frame(1003)
+    v, c, n = ops.voxelize(dev(pts), PP_RANGE, [0.4, 0.4, 4], 32, 70000)
+    v, c, n = v.cpu().numpy(), c.cpu().numpy(), n.cpu().numpy()
+    assert n.min() >= 1 and n.max() <= 32
+    cells = c[:, 1].astype(np.int64) * 512 * 512 + c[:, 2] * 512 + c[:, 3]
+    assert len(np.unique(cells)) == len(cells)
+    fx = np.floor((pts[:, 0] - np.float32(-102.4)) / np.float32(0.4))
+    fy = np.floor((pts[:, 1] - np.float32(-102.4)) / np.float32(0.4))
+    fz = np.floor((pts[:, 2] - np.float32(-3)) / np.float32(4))
+    inr = (fx >= 0) & (fx < 512) & (fy >= 0) & (fy < 512) & (fz >= 0) & (fz < 1)
+    pcell = (fz[inr] * 512 * 512 + fy[inr] * 512 + fx[inr]).astype(np.int64)
+    ucell, cnt = np.unique(pcell, return_counts=True)
+    assert np.array_equal(np.sort(cells), ucell)
+    assert n.sum() == np.minimum(cnt, 32).sum()
+    mask = np.arange(32)[None, :] < n[:, None]
+    assert np.all(v[~mask] == 0)
+
+
+# ---------------------------------------------------------------------------------------------- K2
+def pfn_params():
+    pre = "pillar_vfe.pfn_layers.0."
+    w = det_values(pre + "linear.weight", (64, 10), "weight")
+    g = det_values(pre + "norm.weight", (64,), "bn_weight")
+    b = det_values(pre + "norm.bias", (64,), "bn_bias")
+    mu = det_values(pre + "norm.running_mean", (64,), "running_mean")
+    var = det_values(pre + "norm.running_var", (64,), "running_var")
+    scale = (g / np.sqrt(var + np.float32(1e-3))).astype(np.float32)
+    shift = (b - mu * scale).astype(np.float32)
+    return dict(weight=w, bn_gamma=g, bn_beta=b, bn_mean=mu, bn_var=var), w, scale, shift
+
+
+def test_pfn_scatter_matches_reference_golden(golden):
+    from heal_amd import ops
+    g = golden("pointpillar_encoder")
+    _, w, scale, shift = pfn_params()
+    canvas, pillars = ops.pfn_scatter(dev(g["voxel_features"]), dev(g["voxel_coords"], torch.int32),
+                                      dev(g["voxel_num_points"], torch.int32), dev(w), dev(scale), dev(shift),
+                                      g["voxel_size"].tolist(), g["lidar_range"].tolist(), 2, 128, 128,
+                                      return_pillars=True)
+    np.testing.assert_allclose(pillars.cpu().numpy(), g["pillar_features"], rtol=1e-3, atol=1e-5)
+    c = canvas.cpu().numpy()
+    np.testing.assert_allclose(c, g["spatial_features"], rtol=1e-3, atol=1e-5)
+    assert np.array_equal(c != 0, g["spatial_features"] != 0)
+
+
+def test_pfn_scatter_full_size_vs_oracle():
+    from heal_amd import ops, synth
+    params, w, scale, shift = pfn_params()
+    vs, cs, ns = [], [], []
+    for b, seed in enumerate((1000, 1001)):
+        v, c, n = cref.voxelize(synth.lidar_frame(seed), PP_RANGE, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    v, c, n = np.concatenate(vs), np.concatenate(cs), np.concatenate(ns)
+    canvas = ops.pfn_scatter(dev(v), dev(c), dev(n), dev(w), dev(scale), dev(shift), [0.4, 0.4, 4], PP_RANGE,
+                             2, 512, 512).cpu().numpy()
+    ref, _ = O.pfn_scatter(v, c, n, voxel_size=[0.4, 0.4, 4], lidar_range=PP_RANGE, n_agents=2, ny=512, nx=512,
+                           **params)
+    np.testing.assert_allclose(canvas, ref, rtol=1e-3, atol=1e-5)
+    assert np.array_equal(canvas != 0, ref != 0)
+    # every pillar occupies exactly one canvas cell (some channels may be exactly 0 after ReLU)
+    occupied = (canvas != 0).any(axis=1).sum()
+    assert occupied <= len(n) and occupied >= 0.99 * len(n)
+
+
+# ---------------------------------------------------------------------------------------------- K5
+@pytest.mark.parametrize("tag", ["sq", "rect", "f32"])
+def test_warp_fuse_matches_reference_golden(golden, tag):
+    from heal_amd import ops
+    g = golden("warp_fuse")
+    x, score = g[f"{tag}_x"], g[f"{tag}_score"]
+    n = x.shape[0]
+    rows = g[f"{tag}_affine"][0, :n]
+    f64 = rows.dtype == np.float64
+    # the kernel builds the score from occupancy logits; feed logit(score - 1e-4) ... except that the
+    # fixture also contains exact zeros, which a sigmoid cannot produce -> use the split API whose
+    # second half takes scores directly, and the fused kernel on a zero-free variant below
+    feats_ego, scores_ego = [], []
+    for a in range(n):
+        fe, _ = ops.warp_agent(dev(x[a]), dev(np.zeros_like(score[a])), rows[a], grid_f64=f64)
+        se, _ = ops.warp_agent(dev(score[a]), dev(np.zeros_like(score[a])), rows[a], grid_f64=f64)
+        feats_ego.append(fe); scores_ego.append(se)
+    fe = torch.stack(feats_ego); se = torch.stack(scores_ego)
+    np.testing.assert_allclose(fe.cpu().numpy(), g[f"{tag}_warped"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(se.cpu().numpy(), g[f"{tag}_wscore"], rtol=1e-4, atol=2e-5)
+    assert np.array_equal(se.cpu().numpy() == 0, g[f"{tag}_wscore"] == 0)
+    fused = ops.fuse_warped(fe, se)
+    np.testing.assert_allclose(fused.cpu().numpy(), g[f"{tag}_fused"], rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,C,H,W,f64", [(3, 64, 64, 64, True), (5, 128, 128, 128, True), (2, 16, 24, 40, False),
+                                         (1, 8, 32, 32, True), (8, 8, 16, 16, True)])
+def test_warp_fuse_fused_vs_oracle(n, C, H, W, f64):
+    from heal_amd import ops, synth
+    rng = np.random.default_rng(n * 100 + C)
+    x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+    occ = (rng.standard_normal((n, 1, H, W)) * 2).astype(np.float32)
+    Hm, Wm = 0.8 * H, 0.8 * W
+    poses = synth.agent_poses(7 + n, n, r_min=2.0, r_max=0.3 * min(Hm, Wm))
+    pw = synth.pairwise_t_matrix(poses, 8)[None].astype(np.float64 if f64 else np.float32)
+    rows = O.normalize_pairwise_tfm(pw, Hm, Wm, 1)[0][0, :n]
+    mods = ["m1"] * n
+    crop_info = {}
+    crops = None
+    if n >= 3:  # make agent 1 a camera agent with a crop window
+        mods[1] = "m2"
+        crop_info = {"m2": {"crop_ratio_H_m2": 2.0, "crop_ratio_W_m2": 2.0}}
+        from heal_amd.opencood.models.fuse_modules.pyramid_fuse import crop_window
+        crops = [crop_window(H, W, 2.0, 2.0) if m == "m2" else (0, 0, 0, 0) for m in mods]
+    out = ops.warp_fuse(dev(x), dev(occ), rows, grid_f64=f64, crop=crops).cpu().numpy()
+    score = O.occ_to_score(occ, O.camera_crop_mask(n, H, W, mods, crop_info))
+    ref = O.weighted_fuse(x, score, rows)
+    np.testing.assert_allclose(out, ref, rtol=1e-3, atol=2e-5)
+    # split form == fused form
+    fe, se = zip(*[ops.warp_agent(dev(x[a]), dev(occ[a]), rows[a], grid_f64=f64,
+                                  crop=None if crops is None else [crops[a]]) for a in range(n)])
+    out2 = ops.fuse_warped(torch.stack(fe), torch.stack(se)).cpu().numpy()
+    np.testing.assert_allclose(out2, out, rtol=1e-5, atol=1e-6)
+
+
+def test_warp_fuse_identity_is_exact():
+    """Linearity / idempotence property: one agent, identity transform -> output == input."""
+    from heal_amd import ops
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 64, 256, 256)).astype(np.float32)
+    occ = rng.standard_normal((1, 1, 256, 256)).astype(np.float32)
+    rows = np.array([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]])
+    out = ops.warp_fuse(dev(x), dev(occ), rows, grid_f64=True).cpu().numpy()
+    np.testing.assert_allclose(out, x[0], rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- K8
+def test_quad_iou_bit_exact_vs_oracle(golden):
+    from heal_amd import ops
+    g = golden("decode")
+    q = np.ascontiguousarray(g["cmp_proj"][:, :4, :2])
+    rng = np.random.default_rng(2)
+    extra = q[rng.integers(0, len(q), 64)] + rng.normal(0, 0.5, (64, 1, 2)).astype(np.float32)
+    allq = np.concatenate([q, extra.astype(np.float32), np.zeros((1, 4, 2), np.float32), q[:3][:, ::-1]])
+    got = ops.quad_iou(dev(allq), dev(allq)).cpu().numpy()
+    want = cref.quad_iou(allq, allq)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))  # bit exact incl. NaN
+
+
+@pytest.mark.parametrize("tag", ["id", "tf"])
+def test_decode_nms_matches_reference_golden(golden, tag):
+    from heal_amd import ops
+    g = golden("decode")
+    anchors = dev(g["anchors"].astype(np.float32))
+    pred, score = ops.decode_nms(dev(g[f"{tag}_cls"]), dev(g[f"{tag}_reg"]), dev(g[f"{tag}_dir"]), anchors,
+                                 0.2, 0.7853, 2, 0.15, g[f"{tag}_tfm"], g["gt_range"].tolist())
+    assert pred.shape == g[f"{tag}_pred"].shape
+    np.testing.assert_allclose(score.cpu().numpy(), g[f"{tag}_score"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pred.cpu().numpy(), g[f"{tag}_pred"], rtol=1e-3, atol=1e-3)
+
+
+def test_decode_nms_full_size_vs_oracle():
+    """131 072 anchors (256x256x2), many candidates, more than nms_top survivors of the filters."""
+    from heal_amd import ops
+    rng = np.random.default_rng(4)
+    H = W = 256
+    anchors = O.generate_anchor_box(PP_RANGE, 0.4, 0.4, 512, 512, 3.9, 1.6, 1.56, [0, 90])
+    cls = (rng.standard_normal((1, 2, H, W)) * 1.5 - 2.5).astype(np.float32)
+    reg = (rng.standard_normal((1, 14, H, W)) * 0.2).astype(np.float32)
+    dirp = rng.standard_normal((1, 4, H, W)).astype(np.float32)
+    tfm = np.eye(4, dtype=np.float32)
+    pred, score = ops.decode_nms(dev(cls), dev(reg), dev(dirp), dev(anchors.astype(np.float32)), 0.2, 0.7853, 2,
+                                 0.15, tfm, PP_RANGE)
+    rp, rs = O.post_process(cls, reg, dirp, anchors, 0.2, 0.7853, 2, 0.15, tfm, PP_RANGE)
+    assert pred.shape == rp.shape
+    np.testing.assert_allclose(score.cpu().numpy(), rs, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pred.cpu().numpy(), rp, rtol=1e-3, atol=1e-3)
+    # idempotence: NMS survivors do not suppress each other
+    q = pred[:, :4, :2].contiguous()
+    iou = ops.quad_iou(q, q).cpu().numpy()
+    np.fill_diagonal(iou, 0)
+    assert not (iou > 0.15).any()
+
+
+def test_decode_nms_nothing_above_threshold():
+    from heal_amd import ops
+    anchors = O.generate_anchor_box([-25.6, -25.6, -3, 25.6, 25.6, 1], 0.4, 0.4, 128, 128, 3.9, 1.6, 1.56, [0, 90])
+    cls = np.full((1, 2, 64, 64), -9.0, np.float32)
+    reg = np.zeros((1, 14, 64, 64), np.float32)
+    pred, score = ops.decode_nms(dev(cls), dev(reg), None, dev(anchors.astype(np.float32)), 0.2, 0.7853, 2, 0.15,
+                                 np.eye(4, dtype=np.float32), [-25.6, -25.6, -3, 25.6, 25.6, 1])
+    assert pred is None and score is None
+
+
+def test_ops_reject_cpu_tensors():
+    from heal_amd import _capi, ops
+    with pytest.raises(_capi.HealAmdError):
+        ops.voxelize(torch.zeros(10, 4), PP_RANGE, [0.4, 0.4, 4], 32, 100)
