@@ -59,6 +59,10 @@ def lib():
             raise HealAmdError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -m heal_amd.build`); heal_amd has no CPU fallback")
+        # torch ships its own libamdhip64; it must be the HIP runtime of the process, so make sure it
+        # is loaded before libheal_amd.so pulls in a second copy from /opt/rocm (two runtimes in one
+        # process do not share devices, streams or allocations).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             if not hasattr(L, name):

@@ -56,14 +56,32 @@ class ScenePipeline:
         self.hypes = hypes
         self.device = torch.device(device)
         self.model = fill_deterministic(create_model(hypes), seed).to(self.device).eval()
-        # keep candidate counts realistic with random weights: bias the classification head down
-        with torch.no_grad():
-            for name, p in self.model.named_parameters():
-                if name.startswith("cls_head") and name.endswith("bias"):
-                    p.fill_(-4.0)
         self.post = VoxelPostprocessor(hypes["postprocess"], train=False)
         self.anchor_box = torch.from_numpy(self.post.generate_anchor_box()).to(self.device)
         self.tfm = torch.eye(4)
+
+    @torch.no_grad()
+    def calibrate_cls_bias(self, scene, target_candidates=600):
+        """Random-init heads put an arbitrary fraction of the 131 072 anchors above the 0.2 score
+        threshold.  Shift the classification bias (a parameter like any other) so that about
+        `target_candidates` anchors pass -- a busy but realistic frame for decode + NMS."""
+        out = self.model(scene.model_input())
+        # keep regressed boxes near their anchors (std 0.15), otherwise exp(delta) sizes fail the
+        # reference's size / z filters and nothing reaches the NMS
+        std = float(out["reg_preds"].std())
+        if std > 0:
+            for name, p in self.model.named_parameters():
+                if name.startswith("reg_head"):
+                    p.mul_(0.15 / std)
+        logits = out["cls_preds"].flatten()
+        k = min(max(int(target_candidates), 1), logits.numel() - 1)
+        kth = torch.topk(logits, k).values[-1]
+        thr = self.hypes["postprocess"]["target_args"]["score_threshold"]
+        shift = float(np.log(thr / (1.0 - thr))) - float(kth)
+        for name, p in self.model.named_parameters():
+            if name.startswith("cls_head") and name.endswith("bias"):
+                p.add_(shift)
+        return shift
 
     @torch.no_grad()
     def forward(self, scene):
