@@ -30,11 +30,13 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.m
 FP32_PEAK_TFLOPS = 157.3   # fp32 matrix/vector peak, same guide
 
 WORKLOADS = {
-    # name: (n_agents, description)
-    "scene5": (5, "5-agent OPV2V scene, 5x PointPillars(m1) + PyramidFusion, range +-102.4 m, 64-line LiDAR "
-                  "(the camera agents m2/m4 of OPV2V-H are LiDAR agents here until the LSS encoder row lands)"),
-    "pair": (2, "2-agent OPV2V scene, PointPillars + PyramidFusion (BASELINE config 3)"),
-    "single": (1, "single-agent PointPillars + pyramid backbone (BASELINE config 2)"),
+    # name: (agent modalities in scene order, description)
+    "scene5": (["m1", "m1", "m1", "m2", "m4"],
+               "5-agent OPV2V-H scene (BASELINE config 4): 3x PointPillars LiDAR (m1) + Lift-Splat camera agents "
+               "m2 (EfficientNet-b0, 4x384x512) and m4 (ResNet101 stem, 4x336x448), PyramidFusion, range +-102.4 m"),
+    "scene5_lidar": (["m1"] * 5, "5-agent OPV2V scene, 5x PointPillars(m1) + PyramidFusion, range +-102.4 m"),
+    "pair": (["m1", "m1"], "2-agent OPV2V scene, PointPillars + PyramidFusion (BASELINE config 3)"),
+    "single": (["m1"], "single-agent PointPillars through the collaborative model (BASELINE config 2)"),
 }
 
 
@@ -112,10 +114,13 @@ def main():
     from heal_amd.dist import ShardedCollab, owned_agents
     from heal_amd.pipeline import Scene, ScenePipeline
 
-    n_agents, desc = WORKLOADS[a.workload]
-    hypes = configs.lidar_pyramid(max_cav=max(5, n_agents))
+    mods, desc = WORKLOADS[a.workload]
+    n_agents = len(mods)
+    lidar_only = all(m == "m1" for m in mods)
+    hypes = configs.lidar_pyramid(max_cav=max(5, n_agents)) if lidar_only else \
+        configs.heal_heter(tuple(sorted(set(mods))), max_cav=max(5, n_agents))
     pipe = ScenePipeline(hypes, dev, seed=0)
-    scene = Scene(n_agents, seed=4, device=dev)
+    scene = Scene(n_agents, seed=4, device=dev, modalities=mods)
     cls_shift = pipe.calibrate_cls_bias(scene)
     batch = {"ego": {"transformation_matrix": pipe.tfm, "anchor_box": pipe.anchor_box}}
 
@@ -125,11 +130,11 @@ def main():
     else:
         sharded = ShardedCollab(pipe.model, rank, world)
         mine = owned_agents(n_agents, rank, world)
-        local_pts = {"m1": [scene.points[k] for k in mine]}
+        local_inputs = scene.inputs_for(mine)
         inp = scene.model_input()
 
         def step():
-            out = sharded.forward(inp, n_agents, local_pts)
+            out = sharded.forward(inp, n_agents, local_inputs)
             if rank == 0:
                 return pipe.post.post_process(batch, {"ego": out})
             return None, None
@@ -162,8 +167,9 @@ def main():
         # K2 roofline: algorithmic bytes of the operator / its measured duration (HIP events)
         with torch.no_grad():
             m_per_agent = []
-            for p in scene.points:
-                _, _, nn_ = ops.voxelize(p, hypes["model"]["args"]["lidar_range"], [0.4, 0.4, 4], 32, 70000)
+            for k in sorted(scene.points):
+                _, _, nn_ = ops.voxelize(scene.points[k], hypes["model"]["args"]["lidar_range"], [0.4, 0.4, 4], 32,
+                                         70000)
                 m_per_agent.append(int(nn_.shape[0]))
         roof = None
         if "pfn_scatter" in timing:
@@ -182,14 +188,22 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {desc}", "agents": n_agents,
-                       "pillars_per_agent": m_per_agent, "points_per_agent": [int(p.shape[0]) for p in scene.points],
+                       "pillars_per_agent": m_per_agent, "modalities": mods,
+                       "points_per_agent": [int(scene.points[k].shape[0]) for k in sorted(scene.points)],
                        "parallelism": "1 GPU" if world == 1 else f"agent-sharded over {world} ranks, 1 all-gather",
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "op_timing_ms": kernels,
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(hypes, [p.cpu().numpy() for p in scene.points], scene.pairwise,
-                                                n_agents, cls_shift)
+            # the CPU port covers the LiDAR (PointPillars) agents; for the heterogeneous workload the
+            # sample is the same scene with every agent treated as a LiDAR agent (stated in `sample`)
+            lidar_hypes = hypes if lidar_only else configs.lidar_pyramid(max_cav=max(5, n_agents))
+            lidar_scene = scene if lidar_only else Scene(n_agents, seed=4, device="cpu")
+            line["cpu_baseline"] = cpu_baseline(lidar_hypes,
+                                                [lidar_scene.points[k].cpu().numpy() for k in sorted(lidar_scene.points)],
+                                                scene.pairwise, n_agents, cls_shift)
+            if not lidar_only:
+                line["cpu_baseline"]["sample"] += " [all 5 agents as PointPillars LiDAR agents: the CPU port has no camera trunk]"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

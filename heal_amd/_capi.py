@@ -37,6 +37,9 @@ _SIGNATURES = {
                                 c_float, c_float, c_float, c_int, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "heal_quad_iou": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "heal_bev_pool_workspace": (c_size_t, [c_int] * 9),
+    "heal_bev_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 

@@ -106,6 +106,47 @@ def m1_late(lidar_range=FULL_RANGE):
     return load_general_params(h)
 
 
+def _camera_modality(lidar_range, final_dim, encoder):
+    grid_conf = {"xbound": [-51.2, 51.2, 0.4], "ybound": [-51.2, 51.2, 0.4], "zbound": [-10, 10, 20.0],
+                 "ddiscr": [2, 50, 48], "mode": "LID"}
+    data_aug_conf = {"resize_lim": [0.65, 0.7] if encoder == "EfficientNet" else [0.56, 0.61],
+                     "final_dim": list(final_dim), "rot_lim": [-3.6, 3.6], "H": 600, "W": 800, "rand_flip": False,
+                     "bot_pct_lim": [0.0, 0.05], "cams": ["camera0", "camera1", "camera2", "camera3"], "Ncams": 4}
+    return {
+        "core_method": "lift_splat_shoot",
+        "sensor_type": "camera",
+        "encoder_args": {"anchor_number": 2, "grid_conf": grid_conf, "data_aug_conf": data_aug_conf,
+                         "img_downsample": 8, "img_features": 128, "use_depth_gt": False,
+                         "depth_supervision": True, "camera_encoder": encoder},
+        "camera_mask_args": {"cav_lidar_range": list(lidar_range), "grid_conf": copy.deepcopy(grid_conf)},
+        "backbone_args": {"layer_nums": [3], "layer_strides": [2], "num_filters": [64], "inplanes": 128},
+        "aligner_args": {"core_method": "convnext", "spatial_align": False,
+                         "args": {"num_of_blocks": 3, "dim": 64}},
+    }
+
+
+def heal_heter(modalities=("m1", "m2", "m4"), lidar_range=FULL_RANGE, max_cav=5):
+    """HEAL final-infer collaborative model with several modalities (m1 PointPillars LiDAR,
+    m2 Lift-Splat EfficientNet 384x512, m4 Lift-Splat Resnet101 336x448; m3 SECOND when built) --
+    MoreModality/HEAL/final_infer/m1m2m3m4.yaml, BASELINE config 4."""
+    h = _common(lidar_range, max_cav)
+    h["name"] = "heal_amd_opv2v_" + "".join(modalities)
+    args = {"ego_modality": "m1", "lidar_range": list(lidar_range), "supervise_single": True}
+    for m in modalities:
+        if m == "m1":
+            args[m] = _pointpillar_modality(lidar_range, "identity")
+        elif m == "m2":
+            args[m] = _camera_modality(lidar_range, (384, 512), "EfficientNet")
+        elif m == "m4":
+            args[m] = _camera_modality(lidar_range, (336, 448), "Resnet101")
+        else:
+            raise NotImplementedError(f"modality {m}")
+    args.update({"fusion_backbone": _fusion_backbone(), "shrink_header": _shrink_header(), "in_head": 256,
+                 "anchor_number": 2, "dir_args": copy.deepcopy(DIR_ARGS)})
+    h["model"] = {"core_method": "heter_pyramid_collab", "args": args}
+    return load_general_params(h)
+
+
 def dump_yaml(hypes, path):
     def plain(o):
         if isinstance(o, dict):

@@ -1,0 +1,257 @@
+// K4 -- Lift-Splat frustum -> BEV pooling, fused with the depth softmax and the depth (x) feature
+// outer product.
+//
+// Reference arithmetic: opencood/models/heter_encoders.py:125-147 (get_geometry), :161-217
+// (voxel_pooling: `.long()` truncation, bounds filter, rank, argsort, cumsum trick, scatter into a
+// zero [B,C,Z,Y,X] tensor, Z folded into channels), opencood/utils/camera_utils.py:220-236
+// (QuickCumsum.forward) and opencood/models/sub_modules/lss_submodule.py:129-134
+// (softmax(depth)[:,None] * feat[:,:,None], a 302 MB/agent tensor the reference materialises).
+//
+// MI355X formulation -- the 302 MB lifted tensor is never formed:
+//   k_lss_keys       one thread per camera pixel: softmax over the D depth bins in registers, frustum
+//                    geometry in fp32 (same operation order as the reference), cell key per point
+//   radix sort       stable sort of (cell key, point index): points of a cell become contiguous, in
+//                    point-index order (so every per-cell sum has a fixed, deterministic order)
+//   k_lss_segments   segment heads / tails of the sorted keys
+//   k_lss_transpose  features to pixel-major [BN, fH*fW, C] so that one point reads C contiguous floats
+//   k_lss_reduce     one wave per BEV cell, lanes over channels: sum p_d * f over the cell's points
+//                    (sequential fp32, more accurate than the reference's cumsum difference), emit a
+//                    compact row and the cell->row map
+//   k_canvas         (shared with K2) one streaming pass writes the whole [B, C*nz, ny, nx] output
+#include "prims.h"
+#include "../../include/heal_amd.h"
+
+int heal_canvas_from_map(const int* cell_map, const float* rows, int n_agents, int channels, int cells,
+                         float* canvas, hipStream_t s);
+
+namespace heal {
+
+struct LssGeom {
+    float dx[3], lo[3];  // lo = bx - dx/2
+    int nx[3];
+    int n_agents, n_cams, D, fH, fW, C;
+};
+
+struct CamMats {          // 27 floats per (agent, cam), see heal_amd.h
+    float combine[9];     // rots @ inv(intrins)
+    float inv_post_rot[9];
+    float post_trans[3];
+    float trans[3];
+    float pad[3];
+};
+
+__global__ __launch_bounds__(256) void k_lss_keys(const float* __restrict__ depth_logit,
+                                                 const float* __restrict__ frustum,
+                                                 const CamMats* __restrict__ cams, LssGeom g,
+                                                 uint32_t invalid_key, uint32_t* __restrict__ keys,
+                                                 uint32_t* __restrict__ vals, float* __restrict__ probs) {
+    const int HW = g.fH * g.fW;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int total = g.n_agents * g.n_cams * HW;
+    if (t >= total) return;
+    const int bn = t / HW, pix = t - bn * HW;
+    const int b = bn / g.n_cams;
+    const float* lg = depth_logit + (size_t)bn * g.D * HW + pix;
+    // softmax over depth (lss_submodule.py:130): max, exp, normalise
+    float mx = -INFINITY;
+    for (int d = 0; d < g.D; ++d) mx = fmaxf(mx, lg[(size_t)d * HW]);
+    float den = 0.f;
+    for (int d = 0; d < g.D; ++d) den += expf(lg[(size_t)d * HW] - mx);
+    const CamMats cm = cams[bn];
+    const int cells_per_agent = g.nx[0] * g.nx[1] * g.nx[2];
+    for (int d = 0; d < g.D; ++d) {
+        const size_t idx = ((size_t)bn * g.D + d) * HW + pix;
+        probs[idx] = expf(lg[(size_t)d * HW] - mx) / den;
+        // get_geometry: undo post transform, lift by depth, camera -> ego
+        const float* fr = frustum + ((size_t)d * HW + pix) * 3;
+        const float p0 = fr[0] - cm.post_trans[0], p1 = fr[1] - cm.post_trans[1], p2 = fr[2] - cm.post_trans[2];
+        const float* A = cm.inv_post_rot;
+        const float q0 = (A[0] * p0 + A[1] * p1) + A[2] * p2;
+        const float q1 = (A[3] * p0 + A[4] * p1) + A[5] * p2;
+        const float q2 = (A[6] * p0 + A[7] * p1) + A[8] * p2;
+        const float u0 = q0 * q2, u1 = q1 * q2, u2 = q2;
+        const float* M = cm.combine;
+        const float ex = ((M[0] * u0 + M[1] * u1) + M[2] * u2) + cm.trans[0];
+        const float ey = ((M[3] * u0 + M[4] * u1) + M[5] * u2) + cm.trans[1];
+        const float ez = ((M[6] * u0 + M[7] * u1) + M[8] * u2) + cm.trans[2];
+        // voxel_pooling: ((geom - (bx - dx/2)) / dx).long()  -- truncation toward zero
+        const float fx = (ex - g.lo[0]) / g.dx[0];
+        const float fy = (ey - g.lo[1]) / g.dx[1];
+        const float fz = (ez - g.lo[2]) / g.dx[2];
+        uint32_t key = invalid_key;
+        // compare in float first so that huge / NaN values never reach the int conversion
+        if (fx > -1.f && fx < (float)g.nx[0] && fy > -1.f && fy < (float)g.nx[1] && fz > -1.f &&
+            fz < (float)g.nx[2]) {
+            const int ix = (int)fx, iy = (int)fy, iz = (int)fz;  // trunc: (-1,0) -> 0 like .long()
+            if (ix >= 0 && ix < g.nx[0] && iy >= 0 && iy < g.nx[1] && iz >= 0 && iz < g.nx[2])
+                key = (uint32_t)(b * cells_per_agent + (iz * g.nx[1] + iy) * g.nx[0] + ix);
+        }
+        keys[idx] = key;
+        vals[idx] = (uint32_t)idx;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lss_segments(const uint32_t* __restrict__ skeys, int n,
+                                                     uint32_t invalid_key, int* __restrict__ seg_start,
+                                                     int* __restrict__ seg_end) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t k = skeys[j];
+    if (k >= invalid_key) return;
+    if (j == 0 || skeys[j - 1] != k) seg_start[k] = j;
+    if (j == n - 1 || skeys[j + 1] != k) seg_end[k] = j + 1;
+}
+
+// [BN, C, HW] -> [BN, HW, C] through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void k_lss_transpose(const float* __restrict__ in, int C, int HW,
+                                                      float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int bn = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? in[((size_t)bn * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < C) out[((size_t)bn * HW + p) * C + c] = tile[tx][r];
+    }
+}
+
+template <int CPL /*channels per lane*/>
+__global__ __launch_bounds__(256) void k_lss_reduce(const uint32_t* __restrict__ svals,
+                                                   const int* __restrict__ seg_start,
+                                                   const int* __restrict__ seg_end,
+                                                   const float* __restrict__ probs,
+                                                   const float* __restrict__ featT, LssGeom g, int n_cells,
+                                                   int* __restrict__ row_counter, float* __restrict__ rows,
+                                                   int* __restrict__ cell_map) {
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const int l = threadIdx.x & 63;
+    const int lo = seg_start[cell], hi = seg_end[cell];
+    if (hi <= lo) {
+        if (l == 0) cell_map[cell] = -1;
+        return;
+    }
+    const int HW = g.fH * g.fW, DHW = g.D * HW;
+    float acc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
+    for (int j = lo; j < hi; ++j) {
+        const uint32_t idx = svals[j];
+        const int bn = idx / DHW;
+        const int pix = (idx - bn * DHW) % HW;
+        const float p = probs[idx];
+        const float* f = featT + ((size_t)bn * HW + pix) * g.C;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = l + 64 * k;
+            if (c < g.C) acc[k] += p * f[c];  // product then add, like the reference's lifted tensor sum
+        }
+    }
+    int row = 0;
+    if (l == 0) {
+        row = atomicAdd(row_counter, 1);
+        cell_map[cell] = row;
+    }
+    row = __shfl(row, 0, 64);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = l + 64 * k;
+        if (c < g.C) rows[(size_t)row * g.C + c] = acc[k];
+    }
+}
+
+struct LssWs {
+    uint32_t *keys[2], *vals[2];
+    float *probs, *featT, *rows;
+    int *seg_start, *seg_end, *cell_map, *row_counter, *scratch;
+};
+
+static bool carve(Arena& a, int n_agents, int n_cams, int D, int HW, int C, int cells_total, LssWs& w) {
+    const size_t np = (size_t)n_agents * n_cams * D * HW;
+    for (int k = 0; k < 2; ++k) { w.keys[k] = a.take<uint32_t>(np); w.vals[k] = a.take<uint32_t>(np); }
+    w.probs = a.take<float>(np);
+    w.featT = a.take<float>((size_t)n_agents * n_cams * HW * C);
+    const size_t max_rows = (size_t)cells_total < np ? (size_t)cells_total : np;
+    w.rows = a.take<float>((max_rows + 1) * C);
+    // seg_start | seg_end contiguous: one memset clears both
+    w.seg_start = a.take<int>(cells_total);
+    w.seg_end = a.take<int>(cells_total);
+    w.cell_map = a.take<int>(cells_total);
+    w.row_counter = a.take<int>(64);
+    w.scratch = a.take<int>(sort_scratch_words((int64_t)np));
+    return a.ok();
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" size_t heal_bev_pool_workspace(int n_agents, int n_cams, int D, int fH, int fW, int channels,
+                                          int nx, int ny, int nz) {
+    Arena a(nullptr, 0);
+    LssWs w;
+    carve(a, n_agents, n_cams, D, fH * fW, channels, n_agents * nx * ny * nz, w);
+    return a.off + 256;
+}
+
+extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const float* frustum,
+                             const float* cam_mats, int n_agents, int n_cams, int D, int fH, int fW,
+                             int channels, const float* dx_host, const float* bx_host,
+                             const int32_t* nx_host, float* out, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n_agents >= 1 && n_cams >= 1 && D >= 1 && fH >= 1 && fW >= 1, "bev_pool: bad shape");
+    HEAL_REQUIRE(channels >= 16 && channels <= 256 && channels % 16 == 0,
+                 "bev_pool: channels must be a multiple of 16 in [16,256] (got %d)", channels);
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "bev_pool: workspace must be 256-B aligned");
+    LssGeom g;
+    for (int k = 0; k < 3; ++k) {
+        g.dx[k] = dx_host[k];
+        g.lo[k] = bx_host[k] - dx_host[k] / 2.f;  // (self.bx - self.dx/2.) in fp32
+        g.nx[k] = nx_host[k];
+        HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool: empty grid");
+    }
+    g.n_agents = n_agents; g.n_cams = n_cams; g.D = D; g.fH = fH; g.fW = fW; g.C = channels;
+    const int HW = fH * fW;
+    const int cells_per_agent = g.nx[0] * g.nx[1] * g.nx[2];
+    HEAL_REQUIRE((g.nx[0] * g.nx[1]) % 4 == 0, "bev_pool: nx*ny must be a multiple of 4");
+    const int64_t cells_total64 = (int64_t)cells_per_agent * n_agents;
+    const int64_t np64 = (int64_t)n_agents * n_cams * D * HW;
+    HEAL_REQUIRE(cells_total64 < (1ll << 30) && np64 < (1ll << 31), "bev_pool: problem too large");
+    const int cells_total = (int)cells_total64, np = (int)np64;
+    Arena a(ws, ws_bytes);
+    LssWs w;
+    HEAL_REQUIRE(carve(a, n_agents, n_cams, D, HW, channels, cells_total, w),
+                 "bev_pool: workspace too small (%zu < %zu)", ws_bytes, a.off);
+
+    HEAL_HIP(hipMemsetAsync(w.seg_start, 0, (size_t)((char*)w.cell_map - (char*)w.seg_start), s));
+    HEAL_HIP(hipMemsetAsync(w.row_counter, 0, sizeof(int), s));
+    const uint32_t invalid_key = (uint32_t)cells_total;
+    k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 256), 256, 0, s>>>(
+        depth_logit, frustum, reinterpret_cast<const CamMats*>(cam_mats), g,
+                                                                     invalid_key, w.keys[0], w.vals[0], w.probs);
+    k_lss_transpose<<<dim3(ceil_div(HW, 32), ceil_div(channels, 32), n_agents * n_cams), 256, 0, s>>>(
+        feat, channels, HW, w.featT);
+    int key_bits = 1;
+    while ((1u << key_bits) <= invalid_key) ++key_bits;
+    int res = 0;
+    if (radix_sort_pairs(w.keys, w.vals, np, key_bits, &res, w.scratch, s)) return 1;
+    k_lss_segments<<<ceil_div(np, 256), 256, 0, s>>>(w.keys[res], np, invalid_key, w.seg_start, w.seg_end);
+    const int rblocks = ceil_div(cells_total, 4);
+    if (channels <= 64)
+        k_lss_reduce<1><<<rblocks, 256, 0, s>>>(w.vals[res], w.seg_start, w.seg_end, w.probs, w.featT, g,
+                                                cells_total, w.row_counter, w.rows, w.cell_map);
+    else if (channels <= 128)
+        k_lss_reduce<2><<<rblocks, 256, 0, s>>>(w.vals[res], w.seg_start, w.seg_end, w.probs, w.featT, g,
+                                                cells_total, w.row_counter, w.rows, w.cell_map);
+    else
+        k_lss_reduce<4><<<rblocks, 256, 0, s>>>(w.vals[res], w.seg_start, w.seg_end, w.probs, w.featT, g,
+                                                cells_total, w.row_counter, w.rows, w.cell_map);
+    HEAL_LAUNCH_CHECK();
+    // out [B, C*nz, ny, nx] viewed as B*nz maps of [C, ny*nx]
+    return heal_canvas_from_map(w.cell_map, w.rows, n_agents * g.nx[2], channels, g.nx[0] * g.nx[1], out, s);
+}

@@ -78,9 +78,10 @@ class ShardedCollab:
         self.world = world
 
     @torch.no_grad()
-    def forward(self, scene_input, n_agents, local_points_by_modality):
-        """local_points_by_modality: {'m1': [points of the agents this rank owns, in scene order]}.
-        Returns the model output dict on rank 0, None elsewhere."""
+    def forward(self, scene_input, n_agents, local_inputs):
+        """local_inputs: {'inputs_mX': ...} for the agents this rank owns, in scene order (the
+        reference's collated layout, restricted to the local agents).  Returns the model output dict
+        on rank 0, None elsewhere."""
         from heal_amd import ops
         from heal_amd.opencood.models.fuse_modules.pyramid_fuse import crop_window
         from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
@@ -95,9 +96,8 @@ class ShardedCollab:
         if mine:
             feats = {}
             for mod in m.modality_name_list:
-                pts = local_points_by_modality.get(mod)
-                if pts:
-                    feats[mod] = m.encode_modality({f"inputs_{mod}": {"points": pts}}, mod)
+                if f"inputs_{mod}" in local_inputs:
+                    feats[mod] = m.encode_modality(local_inputs, mod)
             cursor = {k: 0 for k in feats}
             parts = []
             for a in mine:

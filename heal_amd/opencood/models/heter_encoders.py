@@ -76,3 +76,88 @@ class PointPillar(nn.Module):
         weight = self.pillar_vfe.pfn_layers[0].linear.weight.detach()
         return ops.pfn_scatter(voxels, coords, num, weight, scale, shift, self.voxel_size, self.lidar_range,
                                n_agents, self.scatter.ny, self.scatter.nx)
+
+
+class LiftSplatShoot(nn.Module):
+    """Camera agents: image trunk -> (depth logits, image features) -> fused lift + BEV pool (K4).
+
+    Reference: heter_encoders.py:83-241.  Differences by design: no hard-coded `.to("cuda")` in
+    __init__ (the frustum is a buffer-like tensor that follows the module's device lazily), and the
+    [BN,C,D,fH,fW] lifted tensor is never materialised."""
+
+    def __init__(self, args):
+        super().__init__()
+        from heal_amd.opencood.models.sub_modules.lss_submodule import CamEncode, CamEncode_Resnet101
+        from heal_amd.opencood.utils.camera_utils import depth_discretization, gen_dx_bx
+        self.grid_conf = args["grid_conf"]
+        self.data_aug_conf = args["data_aug_conf"]
+        dx, bx, nx = gen_dx_bx(self.grid_conf["xbound"], self.grid_conf["ybound"], self.grid_conf["zbound"])
+        self.dx_host = [float(v) for v in dx]
+        self.bx_host = [float(v) for v in bx]
+        self.nx_host = [int(v) for v in nx]
+        self.depth_supervision = args["depth_supervision"]
+        self.downsample = args["img_downsample"]
+        self.camC = args["img_features"]
+        self._frustum_cpu = self.create_frustum(depth_discretization)
+        self._frustum_dev = {}
+        self.D = self._frustum_cpu.shape[0]
+        self.camera_encoder_type = args["camera_encoder"]
+        enc = {"EfficientNet": CamEncode, "Resnet101": CamEncode_Resnet101}[self.camera_encoder_type]
+        self.camencode = enc(self.D, self.camC, self.downsample, self.grid_conf["ddiscr"], self.grid_conf["mode"],
+                             args["use_depth_gt"], args["depth_supervision"])
+        self.depth_items = None
+
+    def create_frustum(self, depth_discretization):
+        """heter_encoders.py:110-123 -> [D, fH, fW, 3] (u, v, depth)."""
+        ogfH, ogfW = self.data_aug_conf["final_dim"]
+        fH, fW = ogfH // self.downsample, ogfW // self.downsample
+        ds = torch.tensor(depth_discretization(*self.grid_conf["ddiscr"], self.grid_conf["mode"]),
+                          dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+        D = ds.shape[0]
+        xs = torch.linspace(0, ogfW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+        ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+        return torch.stack((xs, ys, ds), -1).contiguous()
+
+    def frustum(self, device):
+        key = str(device)
+        if key not in self._frustum_dev:
+            self._frustum_dev[key] = self._frustum_cpu.to(device)
+        return self._frustum_dev[key]
+
+    @staticmethod
+    def camera_matrices(rots, trans, intrins, post_rots, post_trans):
+        """The 3x3 algebra of get_geometry (heter_encoders.py:137-146) as device ops:
+        [B,N,...] -> [B*N, 27] = combine | inv(post_rots) | post_trans | trans | 0."""
+        B, N = trans.shape[:2]
+        combine = rots.matmul(torch.inverse(intrins)).reshape(B * N, 9)
+        ipr = torch.inverse(post_rots).reshape(B * N, 9)
+        pad = torch.zeros((B * N, 3), dtype=torch.float32, device=trans.device)
+        return torch.cat([combine.float(), ipr.float(), post_trans.reshape(B * N, 3).float(),
+                          trans.reshape(B * N, 3).float(), pad], dim=1).contiguous()
+
+    def pool(self, depth_logit, x_img, cam_mats, B, N):
+        return ops.bev_pool(depth_logit, x_img, self.frustum(x_img.device), cam_mats, B, N, self.dx_host,
+                            self.bx_host, self.nx_host)
+
+    def forward(self, data_dict, modality_name):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
+        inp = data_dict[f"inputs_{modality_name}"]
+        x = inp["imgs"]
+        B, N, C, imH, imW = x.shape
+        items, depth_logit, x_img = self.camencode(x.view(B * N, C, imH, imW))
+        if self.depth_supervision:
+            self.depth_items = items
+        cam = self.camera_matrices(inp["rots"], inp["trans"], inp["intrins"], inp["post_rots"], inp["post_trans"])
+        return self.pool(depth_logit.contiguous(), x_img.contiguous(), cam, B, N)
+
+
+class LiftSplatShootVoxel(LiftSplatShoot):
+    """heter_encoders.py:244-301: max over the z bins instead of folding them into channels."""
+
+    def pool(self, depth_logit, x_img, cam_mats, B, N):
+        out = super().pool(depth_logit, x_img, cam_mats, B, N)
+        nz = self.nx_host[2]
+        if nz == 1:
+            return out
+        return out.view(B, nz, self.camC, out.shape[2], out.shape[3]).max(dim=1)[0]

@@ -1,0 +1,231 @@
+"""Camera feature extractors of the Lift-Splat encoder (reference: opencood/models/sub_modules/
+lss_submodule.py:17-233): `Up`, `CamEncode` (EfficientNet-b0 trunk), `CamEncode_Resnet101`.
+
+The reference takes the two trunks from third-party packages that are not in its tree
+(efficientnet_pytorch==0.7.0, torchvision); they are restated here from the packages' published
+architecture with the same parameter names, so that HEAL checkpoints (`encoder_m2.camencode.trunk.*`,
+`encoder_m4.camencode.layer1.*`) load.  PARITY UNPINNED for the trunks: the build pins the
+path from the (depth_logit, image feature) boundary onward (K4).  Unlike the reference, the modules
+return the depth logits and the C-channel image features and never form the [BN,C,D,fH,fW] lifted
+tensor -- the outer product is fused into heal_bev_pool.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from heal_amd.opencood.models.sub_modules.bev_blocks import Bottleneck, ConvBN, _FoldCache, _require_eval
+
+
+class Up(nn.Module):
+    """lss_submodule.py:17-36: bilinear x2 (align_corners=True), concat, 2 x [3x3 conv + BN + ReLU]."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=scale_factor, mode="bilinear", align_corners=True)
+        self.conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True))
+        self._c = [_FoldCache(), _FoldCache()]
+
+    def forward(self, x1, x2):
+        _require_eval(self)
+        x = torch.cat([x2, self.up(x1)], dim=1)
+        x = ConvBN.run(x, self.conv[0], self.conv[1], self._c[0], relu=True)
+        return ConvBN.run(x, self.conv[3], self.conv[4], self._c[1], relu=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# EfficientNet-b0 (efficientnet_pytorch 0.7.0 layout: static "same" padding computed for a 224 px
+# image at construction, BN eps 1e-3, swish, squeeze-excite ratio 0.25 of the block INPUT filters)
+# ------------------------------------------------------------------------------------------------
+_B0_BLOCKS = [  # repeats, kernel, stride, expand, in, out
+    (1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+    (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+
+
+class _SamePadConv2d(nn.Conv2d):
+    """Conv2dStaticSamePadding: TF-style SAME padding fixed at construction for `image_size`."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride=1, groups=1, bias=False, image_size=224):
+        super().__init__(in_ch, out_ch, kernel_size, stride=stride, padding=0, groups=groups, bias=bias)
+        ih = iw = image_size
+        kh = kw = kernel_size
+        sh = sw = stride
+        oh, ow = math.ceil(ih / sh), math.ceil(iw / sw)
+        pad_h = max((oh - 1) * sh + (kh - 1) + 1 - ih, 0)
+        pad_w = max((ow - 1) * sw + (kw - 1) + 1 - iw, 0)
+        self.same_pad = (pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2)
+        self.static_padding = nn.ZeroPad2d(self.same_pad) if (pad_h > 0 or pad_w > 0) else nn.Identity()
+
+
+def _conv_bn(x, conv, bn, cache, act):
+    w, b = cache.get(conv, bn)
+    if any(conv.same_pad):
+        x = F.pad(x, conv.same_pad)
+    y = F.conv2d(x, w, b, conv.stride, 0, 1, conv.groups)
+    return F.silu(y, inplace=True) if act else y
+
+
+class _MBConv(nn.Module):
+    def __init__(self, kernel, stride, expand, inp, oup, image_size):
+        super().__init__()
+        self.expand = expand
+        self.id_skip = stride == 1 and inp == oup
+        mid = inp * expand
+        if expand != 1:
+            self._expand_conv = _SamePadConv2d(inp, mid, 1, image_size=image_size)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=0.01, eps=1e-3)
+        self._depthwise_conv = _SamePadConv2d(mid, mid, kernel, stride=stride, groups=mid, image_size=image_size)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=0.01, eps=1e-3)
+        sq = max(1, int(inp * 0.25))
+        out_size = math.ceil(image_size / stride)
+        self._se_reduce = _SamePadConv2d(mid, sq, 1, bias=True, image_size=1)
+        self._se_expand = _SamePadConv2d(sq, mid, 1, bias=True, image_size=1)
+        self._project_conv = _SamePadConv2d(mid, oup, 1, image_size=out_size)
+        self._bn2 = nn.BatchNorm2d(oup, momentum=0.01, eps=1e-3)
+        self._c = [_FoldCache(), _FoldCache(), _FoldCache()]
+
+    def forward(self, x):
+        inp = x
+        if self.expand != 1:
+            x = _conv_bn(x, self._expand_conv, self._bn0, self._c[0], act=True)
+        x = _conv_bn(x, self._depthwise_conv, self._bn1, self._c[1], act=True)
+        s = F.adaptive_avg_pool2d(x, 1)
+        s = F.conv2d(F.silu(F.conv2d(s, self._se_reduce.weight, self._se_reduce.bias)), self._se_expand.weight,
+                     self._se_expand.bias)
+        x = torch.sigmoid(s) * x
+        x = _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False)
+        return x + inp if self.id_skip else x
+
+
+class EfficientNetB0(nn.Module):
+    def __init__(self, image_size=224):
+        super().__init__()
+        self._conv_stem = _SamePadConv2d(3, 32, 3, stride=2, image_size=image_size)
+        self._bn0 = nn.BatchNorm2d(32, momentum=0.01, eps=1e-3)
+        size = math.ceil(image_size / 2)
+        blocks = []
+        for rep, k, s, e, i, o in _B0_BLOCKS:
+            for r in range(rep):
+                blocks.append(_MBConv(k, s if r == 0 else 1, e, i if r == 0 else o, o, size))
+                if r == 0:
+                    size = math.ceil(size / s)
+        self._blocks = nn.ModuleList(blocks)
+        self._conv_head = _SamePadConv2d(320, 1280, 1, image_size=size)  # present for checkpoint parity, unused
+        self._bn1 = nn.BatchNorm2d(1280, momentum=0.01, eps=1e-3)
+        self._fc = nn.Linear(1280, 1000)
+        self._c0 = _FoldCache()
+
+    def endpoints(self, x):
+        """lss_submodule.py:87-107: feature maps just before every spatial reduction, plus the last."""
+        out = {}
+        x = _conv_bn(x, self._conv_stem, self._bn0, self._c0, act=True)
+        prev = x
+        for block in self._blocks:
+            x = block(x)
+            if prev.size(2) > x.size(2):
+                out[f"reduction_{len(out) + 1}"] = prev
+            prev = x
+        out[f"reduction_{len(out) + 1}"] = x
+        return out
+
+
+def _bin_depths_lid_ud(depth_map, mode, depth_min, depth_max, num_bins):
+    """camera_utils.py:137-185 with target=False (inference): -> (indices int64, valid mask)."""
+    if mode == "UD":
+        bin_size = (depth_max - depth_min) / num_bins
+        indices = (depth_map - depth_min) / bin_size
+    elif mode == "LID":
+        bin_size = 2 * (depth_max - depth_min) / (num_bins * (1 + num_bins))
+        indices = -0.5 + 0.5 * torch.sqrt(1 + 8 * (depth_map - depth_min) / bin_size)
+    else:
+        raise NotImplementedError(mode)
+    mask = (indices < 0) | (indices >= num_bins) | (~torch.isfinite(indices))
+    indices = indices.clone()
+    indices[indices < 0] = 0
+    indices[indices >= num_bins] = num_bins - 1
+    indices[~torch.isfinite(indices)] = num_bins - 1
+    return indices.type(torch.int64), ~mask
+
+
+class _CamEncodeBase(nn.Module):
+    def _init_common(self, D, C, downsample, ddiscr, mode, use_gt_depth, depth_supervision):
+        self.D, self.C, self.downsample = D, C, downsample
+        self.d_min, self.d_max, self.num_bins = ddiscr[0], ddiscr[1], ddiscr[2]
+        self.mode = mode
+        self.use_gt_depth = use_gt_depth
+        self.depth_supervision = depth_supervision
+        if use_gt_depth:
+            raise NotImplementedError("use_gt_depth is a training-time ablation outside the hot path")
+
+    def gt_depth_indices(self, x):
+        """lss_submodule.py:66-85 (eval): bin the 4th image channel and sub-sample to the feature grid."""
+        d = x[:, 3, :, :].clamp_max(self.d_max)
+        idx, _ = _bin_depths_lid_ud(d, self.mode, self.d_min, self.d_max, self.num_bins)
+        s = self.downsample
+        return idx[:, s // 2::s, s // 2::s]
+
+    def heads(self, features, x):
+        x_img = self.image_head(features)
+        depth_logit = self.depth_head(features)
+        items = None
+        if self.depth_supervision:
+            items = (depth_logit, self.gt_depth_indices(x) if x.shape[1] > 3 else None)
+        return items, depth_logit, x_img
+
+
+class CamEncode(_CamEncodeBase):
+    """lss_submodule.py:39-138 with the EfficientNet-b0 trunk."""
+
+    def __init__(self, D, C, downsample, ddiscr, mode, use_gt_depth=False, depth_supervision=True):
+        super().__init__()
+        self._init_common(D, C, downsample, ddiscr, mode, use_gt_depth, depth_supervision)
+        self.trunk = EfficientNetB0()
+        self.up1 = Up(320 + 112, 512)
+        if downsample == 8:
+            self.up2 = Up(512 + 40, 512)
+        self.depth_head = nn.Conv2d(512, self.D, kernel_size=1, padding=0)
+        self.image_head = nn.Conv2d(512, self.C, kernel_size=1, padding=0)
+
+    def forward(self, x):
+        """x [BN, 3|4, H, W] -> (depth_items | None, depth_logit [BN,D,fH,fW], x_img [BN,C,fH,fW])."""
+        ep = self.trunk.endpoints(x[:, :3, :, :])
+        f = self.up1(ep["reduction_5"], ep["reduction_4"])
+        if self.downsample == 8:
+            f = self.up2(f, ep["reduction_3"])
+        return self.heads(f, x)
+
+
+class CamEncode_Resnet101(_CamEncodeBase):
+    """lss_submodule.py:140-233: torchvision resnet101 stem + layer1 + layer2 (/8, 512 channels)."""
+
+    def __init__(self, D, C, downsample, ddiscr, mode, use_gt_depth=False, depth_supervision=True):
+        super().__init__()
+        self._init_common(D, C, downsample, ddiscr, mode, use_gt_depth, depth_supervision)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU()
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 64, 3, 1)
+        self.layer2 = self._make_layer(256, 128, 4, 2)
+        self.layer3 = nn.Identity()
+        self.depth_head = nn.Conv2d(512, self.D, kernel_size=1, padding=0)
+        self.image_head = nn.Conv2d(512, self.C, kernel_size=1, padding=0)
+        self._c = _FoldCache()
+
+    @staticmethod
+    def _make_layer(inplanes, planes, blocks, stride):
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(inplanes, planes, stride, down, expansion=4)]
+        layers += [Bottleneck(planes * 4, planes, expansion=4) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        _require_eval(self)
+        f = ConvBN.run(x[:, :3, :, :], self.conv1, self.bn1, self._c, relu=True)
+        f = self.layer2(self.layer1(self.maxpool(f)))
+        return self.heads(f, x)

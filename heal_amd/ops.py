@@ -237,3 +237,31 @@ def quad_iou(a, b):
     out = torch.empty((n, m), dtype=torch.float32, device=a.device)
     _capi.call("heal_quad_iou", _ptr(a), n, _ptr(b), m, _ptr(out), _stream())
     return out
+
+
+def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
+    """K4.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum [D,fH,fW,3]
+    (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,
+    trans 3, pad 3); dx,bx host float[3], nx host int[3] -> [n_agents, C*nz, ny, nx]."""
+    depth_logit = _need(depth_logit, torch.float32, "depth_logit")
+    feat = _need(feat, torch.float32, "feat")
+    frustum = _need(frustum, torch.float32, "frustum")
+    BN, D, fH, fW = (int(v) for v in depth_logit.shape)
+    C = int(feat.shape[1])
+    if BN != n_agents * n_cams or tuple(feat.shape) != (BN, C, fH, fW) or tuple(frustum.shape) != (D, fH, fW, 3):
+        raise _capi.HealAmdError("bev_pool: inconsistent shapes")
+    cam_mats = _need(cam_mats, torch.float32, "cam_mats")
+    if tuple(cam_mats.shape) != (BN, 27):
+        raise _capi.HealAmdError("bev_pool: cam_mats must be [n_agents*n_cams, 27]")
+    nxi = [int(v) for v in nx]
+    dev = feat.device
+    out = torch.empty((n_agents, C * nxi[2], nxi[1], nxi[0]), dtype=torch.float32, device=dev)
+    nbytes = _capi.query("heal_bev_pool_workspace", n_agents, n_cams, D, fH, fW, C, nxi[0], nxi[1], nxi[2])
+    ws = _workspace("bev_pool", nbytes, dev)
+    with _Timed("bev_pool"):
+        _capi.call("heal_bev_pool", _ptr(depth_logit), _ptr(feat), _ptr(frustum),
+                   _ptr(cam_mats), n_agents, n_cams, D, fH, fW, C,
+                   _host_array([float(v) for v in dx], ctypes.c_float),
+                   _host_array([float(v) for v in bx], ctypes.c_float),
+                   _host_array(nxi, ctypes.c_int32), _ptr(out), _ptr(ws), ws.numel(), _stream())
+    return out

@@ -35,20 +35,50 @@ def fill_deterministic(module, seed=0):
 
 
 class Scene:
-    """Synthetic OPV2V-shaped scene resident on one device."""
+    """Synthetic OPV2V-shaped scene resident on one device.  `modalities[k]` names agent k's sensor
+    suite: LiDAR agents ('m1', 'm3') get a 64-line sweep, camera agents ('m2', 'm4') get four
+    normalised images and a camera rig."""
+
+    CAMERA_DIMS = {"m2": (384, 512), "m4": (336, 448)}
 
     def __init__(self, n_agents, seed, device, max_cav=None, modalities=None):
         self.n_agents = n_agents
-        self.modalities = modalities or ["m1"] * n_agents
-        self.points = [torch.from_numpy(synth.lidar_frame(seed * 1000 + k)).to(device) for k in range(n_agents)]
+        self.device = torch.device(device)
+        self.modalities = list(modalities) if modalities else ["m1"] * n_agents
+        assert len(self.modalities) == n_agents
+        self.points, self.cameras = {}, {}
+        for k, mod in enumerate(self.modalities):
+            if mod in self.CAMERA_DIMS:
+                H, W = self.CAMERA_DIMS[mod]
+                g = torch.Generator().manual_seed(seed * 1000 + k)
+                rig = synth.camera_rig(seed * 1000 + k, 4, H, W)
+                cam = {name: torch.from_numpy(v).to(self.device) for name, v in rig.items()}
+                cam["imgs"] = torch.randn((4, 3, H, W), generator=g).to(self.device)
+                self.cameras[k] = cam
+            else:
+                self.points[k] = torch.from_numpy(synth.lidar_frame(seed * 1000 + k)).to(self.device)
         self.poses = synth.agent_poses(seed, n_agents)
         L = max_cav or max(n_agents, 5)
         self.pairwise = synth.pairwise_t_matrix(self.poses, L)[None]  # [1,L,L,4,4] float64 (host metadata)
         self.record_len = [n_agents]
 
+    def inputs_for(self, agents):
+        """`inputs_mX` dictionaries (the reference's collated layout) for a subset of agents, in order."""
+        out = {}
+        for mod in sorted(set(self.modalities[a] for a in agents)):
+            mine = [a for a in agents if self.modalities[a] == mod]
+            if mod in self.CAMERA_DIMS:
+                keys = ("imgs", "rots", "trans", "intrins", "post_rots", "post_trans")
+                out[f"inputs_{mod}"] = {k: torch.stack([self.cameras[a][k] for a in mine]) for k in keys}
+            else:
+                out[f"inputs_{mod}"] = {"points": [self.points[a] for a in mine]}
+        return out
+
     def model_input(self):
-        return {"inputs_m1": {"points": self.points}, "agent_modality_list": list(self.modalities),
-                "record_len": self.record_len, "pairwise_t_matrix": self.pairwise}
+        d = self.inputs_for(list(range(self.n_agents)))
+        d.update({"agent_modality_list": list(self.modalities), "record_len": self.record_len,
+                  "pairwise_t_matrix": self.pairwise})
+        return d
 
 
 class ScenePipeline:

@@ -123,6 +123,26 @@ int heal_decode_nms(const float* cls, const float* reg, const float* dir, const 
  * iou [n,m].                                                                                       */
 int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K4  Lift-Splat frustum -> BEV pooling, fused with the depth softmax and the outer product.
+ * Replaces: opencood/models/heter_encoders.py:125-147 (get_geometry), :161-217 (voxel_pooling),
+ *           opencood/utils/camera_utils.py:220-236 (QuickCumsum.forward) and the
+ *           softmax(depth) (x) feat outer product of lss_submodule.py:129-134.
+ *   depth_logit [n_agents*n_cams,D,fH,fW]; feat [n_agents*n_cams,C,fH,fW]
+ *   frustum [D,fH,fW,3] f32 (create_frustum, heter_encoders.py:110-123)
+ *   cam_mats [n_agents*n_cams,27] f32 DEVICE: combine = rots @ inv(intrins) (9), inv(post_rots) (9),
+ *             post_trans (3), trans (3), pad (3)   -- the 3x3 algebra is a handful of tiny device ops
+ *             upstream, so no host round trip is needed in the middle of the forward pass
+ *   dx,bx host 3 floats each, nx host 3 ints (gen_dx_bx, camera_utils.py:129-134)
+ *   out [n_agents, C*nz, ny, nx] f32, every element written
+ * -----------------------------------------------------------------------------------------------*/
+size_t heal_bev_pool_workspace(int n_agents, int n_cams, int D, int fH, int fW, int channels,
+                               int nx, int ny, int nz);
+int heal_bev_pool(const float* depth_logit, const float* feat, const float* frustum,
+                  const float* cam_mats, int n_agents, int n_cams, int D, int fH, int fW, int channels,
+                  const float* dx_host, const float* bx_host, const int32_t* nx_host,
+                  float* out, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -267,3 +267,54 @@ def test_ops_reject_cpu_tensors():
     from heal_amd import _capi, ops
     with pytest.raises(_capi.HealAmdError):
         ops.voxelize(torch.zeros(10, 4), PP_RANGE, [0.4, 0.4, 4], 32, 100)
+
+
+# ---------------------------------------------------------------------------------------------- K4
+def _cam_mats(cam):
+    from heal_amd.opencood.models.heter_encoders import LiftSplatShoot
+    t = {k: dev(v) for k, v in cam.items()}
+    return LiftSplatShoot.camera_matrices(t["rots"], t["trans"], t["intrins"], t["post_rots"], t["post_trans"])
+
+
+def _pool_close(got, want, rtol=1e-3, atol=1e-4, max_bad_cells=2e-3):
+    """Per-cell sums must agree; a point that sits within one ulp of a cell edge may fall on the other
+    side of it in a different fp32 evaluation of the same geometry, so a tiny fraction of cells is
+    allowed to differ -- and then the TOTAL must still be conserved."""
+    bad = ~np.isclose(got, want, rtol=rtol, atol=atol)
+    bad_cells = bad.any(axis=1).mean()
+    assert bad_cells <= max_bad_cells, f"{bad_cells:.2e} of the BEV cells differ"
+    np.testing.assert_allclose(got.sum(axis=(2, 3)), want.sum(axis=(2, 3)), rtol=2e-3, atol=1e-2)
+
+
+def test_bev_pool_matches_reference_golden(golden):
+    from heal_amd import ops
+    g = golden("lss")
+    cam = {k[4:]: g[k] for k in g.files if k.startswith("cam_")}
+    B, N = cam["trans"].shape[:2]
+    out = ops.bev_pool(dev(g["depth_logit"]), dev(g["feat"]), dev(g["frustum"]), _cam_mats(cam), B, N,
+                       g["dx"].tolist(), g["bx"].tolist(), g["nx"].tolist()).cpu().numpy()
+    assert out.shape == g["pooled"].shape
+    _pool_close(out, g["pooled"])
+
+
+@pytest.mark.parametrize("n_agents,C,final_dim", [(2, 128, (384, 512)), (1, 128, (336, 448)), (1, 16, (64, 96))])
+def test_bev_pool_full_size_vs_oracle(n_agents, C, final_dim):
+    from heal_amd import ops, synth
+    rng = np.random.default_rng(C + n_agents)
+    fH, fW = final_dim[0] // 8, final_dim[1] // 8
+    D, N = 48, 4
+    frustum = O.create_frustum(list(final_dim), 8, [2, 50, 48], "LID")
+    dx, bx, nx = O.gen_dx_bx([-51.2, 51.2, 0.4], [-51.2, 51.2, 0.4], [-10, 10, 20.0])
+    rig = synth.camera_rig(0, N, final_dim[0], final_dim[1])
+    cam = {k: np.tile(v[None], (n_agents,) + (1,) * v.ndim).astype(np.float32) for k, v in rig.items()}
+    depth_logit = rng.standard_normal((n_agents * N, D, fH, fW)).astype(np.float32)
+    feat = rng.standard_normal((n_agents * N, C, fH, fW)).astype(np.float32)
+    out = ops.bev_pool(dev(depth_logit), dev(feat), dev(frustum), _cam_mats(cam), n_agents, N, dx.tolist(),
+                       bx.tolist(), nx.tolist()).cpu().numpy()
+    geom = O.lss_geometry(frustum, cam["rots"], cam["trans"], cam["intrins"], cam["post_rots"], cam["post_trans"])
+    lifted = O.lift(depth_logit, feat)
+    x = lifted.reshape(n_agents, N, C, D, fH, fW).transpose(0, 1, 3, 4, 5, 2)
+    ref = O.bev_pool(geom, x, dx, bx, nx)
+    assert out.shape == ref.shape == (n_agents, C, 256, 256)
+    _pool_close(out, ref)
+    assert (out != 0).any(axis=1).sum() > 1000
