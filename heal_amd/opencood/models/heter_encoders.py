@@ -78,6 +78,49 @@ class PointPillar(nn.Module):
                                n_agents, self.scatter.ny, self.scatter.nx)
 
 
+class SECOND(nn.Module):
+    """voxels -> MeanVFE -> VoxelBackBone8x (sparse conv, K3) -> HeightCompression -> [n,128,256,256].
+    Reference: heter_encoders.py:52-81.  Also accepts raw device point clouds ('points')."""
+
+    def __init__(self, args):
+        super().__init__()
+        from heal_amd.opencood.models.sub_modules.height_compression import HeightCompression
+        from heal_amd.opencood.models.sub_modules.mean_vfe import MeanVFE
+        from heal_amd.opencood.models.sub_modules.sparse_backbone_3d import VoxelBackBone8x
+        lidar_range = np.array(args["lidar_range"])
+        grid_size = np.round((lidar_range[3:6] - lidar_range[:3]) / np.array(args["voxel_size"])).astype(np.int64)
+        self.lidar_range = [float(v) for v in args["lidar_range"]]
+        self.voxel_size = [float(v) for v in args["voxel_size"]]
+        self.max_points = int(args.get("max_points_per_voxel", 5))
+        self.max_voxels = int(args.get("max_voxels", 70000))
+        self.vfe = MeanVFE(args["mean_vfe"], args["mean_vfe"]["num_point_features"])
+        self.spconv_block = VoxelBackBone8x(args["spconv"], input_channels=args["spconv"]["num_features_in"],
+                                            grid_size=grid_size)
+        self.map_to_bev = HeightCompression(args["map2bev"])
+
+    def forward(self, data_dict, modality_name):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
+        inp = data_dict[f"inputs_{modality_name}"]
+        if "points" in inp:
+            vs, cs, ns = [], [], []
+            for b, pts in enumerate(inp["points"]):
+                v, c, n = ops.voxelize(pts, self.lidar_range, self.voxel_size, self.max_points, self.max_voxels,
+                                       batch_idx=b, sync=True)
+                vs.append(v); cs.append(c); ns.append(n)
+            voxels, coords, num = torch.cat(vs), torch.cat(cs), torch.cat(ns)
+            batch_size = len(inp["points"])
+        else:
+            voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
+            batch_size = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
+        batch_dict = {"voxel_features": voxels, "voxel_coords": coords, "voxel_num_points": num,
+                      "batch_size": batch_size}
+        batch_dict = self.vfe(batch_dict)
+        batch_dict = self.spconv_block(batch_dict)
+        batch_dict = self.map_to_bev(batch_dict)
+        return batch_dict["spatial_features"]
+
+
 class LiftSplatShoot(nn.Module):
     """Camera agents: image trunk -> (depth logits, image features) -> fused lift + BEV pool (K4).
 

@@ -1,0 +1,114 @@
+"""VoxelBackBone8x -- the SECOND sparse 3-D backbone (reference: opencood/models/sub_modules/
+sparse_backbone_3d.py:33-152) on the gfx950 gather-GEMM kernel K3 (heal_sp_conv).
+
+Parameter names follow the reference (`conv_input.0.weight`, `conv_input.1.*`, `conv2.0.0.weight`, ...).
+Convolution weights are stored in spconv 1.2.1 layout [kz,ky,kx,Cin,Cout] (the layout of the authors'
+checkpoints, README "spconv 1.2.1"); spconv 2.x checkpoints ([Cout,kz,ky,kx,Cin]) are permuted on load.
+"""
+import torch
+import torch.nn as nn
+
+
+class SparseConvParam(nn.Module):
+    """Weight container of one SubMConv3d / SparseConv3d (bias=False)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, subm=False, indice_key=None):
+        super().__init__()
+        k = (kernel_size,) * 3 if isinstance(kernel_size, int) else tuple(kernel_size)
+        s = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        p = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = k, s, p
+        self.subm = subm
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(*k, in_channels, out_channels))
+        nn.init.kaiming_uniform_(self.weight.view(-1, in_channels, out_channels), a=5 ** 0.5)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "weight"
+        w = state_dict.get(key)
+        if w is not None and tuple(w.shape) != tuple(self.weight.shape) and w.dim() == 5 and \
+                tuple(w.permute(1, 2, 3, 4, 0).shape) == tuple(self.weight.shape):
+            state_dict[key] = w.permute(1, 2, 3, 4, 0).contiguous()  # spconv 2.x -> 1.x layout
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def flat_weight(self):
+        K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        return self.weight.detach().reshape(K, self.in_channels, self.out_channels).contiguous()
+
+
+class _Block(nn.Sequential):
+    """SparseSequential(conv, BatchNorm1d(eps 1e-3), ReLU) -- sparse_backbone_3d.py:11-30."""
+
+    def __init__(self, conv, channels):
+        super().__init__(conv, nn.BatchNorm1d(channels, eps=1e-3, momentum=0.01), nn.ReLU())
+        self._key = None
+        self._fold = None
+
+    def bn(self):
+        bn = self[1]
+        key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        if key != self._key:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                self._fold = (scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+            self._key = key
+        return self._fold
+
+    def run(self, x, nbr_cache):
+        """x: heal_amd.ops.SparseTensor -> SparseTensor."""
+        from heal_amd.ops import SparseTensor
+        conv = self[0]
+        scale, shift = self.bn()
+        if conv.subm:
+            nbr = nbr_cache.get(conv.indice_key)
+            if nbr is None:
+                nbr = x.neighbors(x.indices, x.spatial_shape, conv.kernel_size, (1, 1, 1),
+                                  tuple(k // 2 for k in conv.kernel_size))
+                nbr_cache[conv.indice_key] = nbr
+            feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True)
+            y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size)
+            y._table = x._table
+            return y
+        out_idx, out_shape = x.out_sites(conv.kernel_size, conv.stride, conv.padding)
+        nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding)
+        feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True)
+        return SparseTensor(feats, out_idx, out_shape, x.batch_size)
+
+
+def _block(cin, cout, k, key, stride=1, padding=0, conv_type="subm"):
+    conv = SparseConvParam(cin, cout, k, stride, padding, subm=(conv_type == "subm"), indice_key=key)
+    return _Block(conv, cout)
+
+
+class VoxelBackBone8x(nn.Module):
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        gs = [int(v) for v in grid_size]
+        self.sparse_shape = [gs[2] + 1, gs[1], gs[0]]  # grid_size[::-1] + [1, 0, 0]
+        self.conv_input = _block(input_channels, 16, 3, "subm1", padding=1)
+        self.conv1 = nn.Sequential(_block(16, 16, 3, "subm1", padding=1))
+        self.conv2 = nn.Sequential(_block(16, 32, 3, "spconv2", stride=2, padding=1, conv_type="spconv"),
+                                   _block(32, 32, 3, "subm2", padding=1), _block(32, 32, 3, "subm2", padding=1))
+        self.conv3 = nn.Sequential(_block(32, 64, 3, "spconv3", stride=2, padding=1, conv_type="spconv"),
+                                   _block(64, 64, 3, "subm3", padding=1), _block(64, 64, 3, "subm3", padding=1))
+        self.conv4 = nn.Sequential(_block(64, 64, 3, "spconv4", stride=2, padding=(0, 1, 1), conv_type="spconv"),
+                                   _block(64, 64, 3, "subm4", padding=1), _block(64, 64, 3, "subm4", padding=1))
+        self.num_point_features = model_cfg.get("num_features_out", 128)
+        self.conv_out = _block(64, self.num_point_features, (3, 1, 1), "spconv_down2", stride=(2, 1, 1), padding=0,
+                               conv_type="spconv")
+        self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
+
+    def forward(self, batch_dict):
+        from heal_amd.ops import SparseTensor
+        x = SparseTensor.from_unsorted(batch_dict["voxel_features"], batch_dict["voxel_coords"].int().contiguous(),
+                                       self.sparse_shape, int(batch_dict["batch_size"]))
+        cache = {}
+        x = self.conv_input.run(x, cache)
+        for stage in (self.conv1, self.conv2, self.conv3, self.conv4):
+            for blk in stage:
+                x = blk.run(x, cache)
+        out = self.conv_out.run(x, cache)
+        batch_dict.update({"encoded_spconv_tensor": out, "encoded_spconv_tensor_stride": 8})
+        return batch_dict

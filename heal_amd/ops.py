@@ -265,3 +265,106 @@ def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx)
                    _host_array([float(v) for v in bx], ctypes.c_float),
                    _host_array(nxi, ctypes.c_int32), _ptr(out), _ptr(ws), ws.numel(), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def _i3(v):
+    return _host_array([int(x) for x in v], ctypes.c_int32)
+
+
+def mean_vfe(voxels, num_points):
+    """MeanVFE: voxels [M,P,F], num_points [M] -> [M,F]."""
+    voxels = _need(voxels, torch.float32, "voxels")
+    num_points = _need(num_points, torch.int32, "num_points")
+    M, P, F = (int(v) for v in voxels.shape)
+    out = torch.empty((M, F), dtype=torch.float32, device=voxels.device)
+    _capi.call("heal_mean_vfe", _ptr(voxels), _ptr(num_points), M, P, F, _ptr(out), _stream())
+    return out
+
+
+class SparseTensor:
+    """features [n,C] f32 + indices [n,4] i32 (b,z,y,x) sorted by linear coordinate + shape (D,H,W)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(v) for v in spatial_shape]
+        self.batch_size = int(batch_size)
+        self._table = None
+
+    @property
+    def n(self):
+        return int(self.indices.shape[0])
+
+    @staticmethod
+    def from_unsorted(features, indices, spatial_shape, batch_size):
+        """Sort the sites by linear coordinate (K3 keeps them sorted for coherent tiles)."""
+        features = _need(features, torch.float32, "features")
+        indices = _need(indices, torch.int32, "indices")
+        n = int(indices.shape[0])
+        dev = indices.device
+        sorted_idx = torch.empty_like(indices)
+        perm = torch.empty((n,), dtype=torch.int32, device=dev)
+        ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
+        _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
+                   _ptr(perm), _ptr(ws), ws.numel(), _stream())
+        return SparseTensor(features.index_select(0, perm.long()), sorted_idx, spatial_shape, batch_size)
+
+    def table(self):
+        if self._table is None:
+            cap = _capi.query("heal_sp_table_capacity", self.n)
+            dev = self.indices.device
+            keys = torch.empty((cap,), dtype=torch.int32, device=dev)
+            vals = torch.empty((cap,), dtype=torch.int32, device=dev)
+            _capi.call("heal_sp_hash_build", _ptr(self.indices), self.n, _i3(self.spatial_shape), self.batch_size,
+                       _ptr(keys), _ptr(vals), cap, _stream())
+            self._table = (keys, vals, cap)
+        return self._table
+
+    def neighbors(self, out_indices, out_shape, ksize, stride, padding):
+        keys, vals, cap = self.table()
+        n_out = int(out_indices.shape[0])
+        K = int(ksize[0] * ksize[1] * ksize[2])
+        nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.indices.device)
+        _capi.call("heal_sp_neighbors", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
+                   _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(keys), _ptr(vals), cap,
+                   _ptr(nbr), _stream())
+        return nbr
+
+    def out_sites(self, ksize, stride, padding):
+        """Active output sites of a strided conv: (indices [n_out,4] sorted, out_shape)."""
+        out_shape = [(self.spatial_shape[d] + 2 * padding[d] - ksize[d]) // stride[d] + 1 for d in range(3)]
+        K = int(ksize[0] * ksize[1] * ksize[2])
+        dev = self.indices.device
+        cells = self.batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+        out_cap = max(1, min(self.n * min(K, 8), cells))
+        out_idx = torch.empty((out_cap, 4), dtype=torch.int32, device=dev)
+        n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ws = _workspace("sp_out_sites", _capi.query("heal_sp_out_sites_workspace", self.n, K), dev)
+        _capi.call("heal_sp_out_sites", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
+                   _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
+                   _ptr(ws), ws.numel(), _stream())
+        return out_idx[:int(n_out.item())], out_shape
+
+    def conv(self, nbr, weight, bn_scale, bn_shift, relu=True):
+        """Gather-GEMM: weight [K,Cin,Cout]; returns features [n_out,Cout]."""
+        weight = _need(weight, torch.float32, "weight")
+        K, cin, cout = (int(v) for v in weight.shape)
+        n_out = int(nbr.shape[0])
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=nbr.device)
+        with _Timed(f"sp_conv_{cin}_{cout}"):
+            _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight),
+                       _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
+                       int(bool(relu)), _ptr(out), _stream())
+        return out
+
+    def dense(self):
+        """-> [B, C*D, H, W] with channel = c*D + z (height_compression.py:21-23)."""
+        C = int(self.features.shape[1])
+        D, H, W = self.spatial_shape
+        dev = self.indices.device
+        out = torch.empty((self.batch_size, C * D, H, W), dtype=torch.float32, device=dev)
+        ws = _workspace("sp_to_bev", _capi.query("heal_sp_to_bev_workspace", self.batch_size, D, H, W), dev)
+        _capi.call("heal_sp_to_bev", _ptr(self.features), _ptr(self.indices), self.n, C, _i3(self.spatial_shape),
+                   self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _stream())
+        return out

@@ -383,3 +383,80 @@ def lift(depth_logit, feat):
     e = np.exp(d)
     p = (e / e.sum(axis=1, keepdims=True)).astype(F32)
     return p[:, None] * np.asarray(feat, F32)[:, :, None]
+
+
+# --------------------------------------------------------------------------------------------------
+# K3: MeanVFE + sparse 3-D convolution (spconv semantics)             [unpinned]
+# The arithmetic lives in the third-party spconv (not vendored, not installed): PARITY UNPINNED.
+# Restated as a DENSE conv3d on the densified grid, masked by spconv's active-site rules:
+#   submanifold: outputs only at the input's active sites;
+#   strided:     an output site is active iff some active input lies in its receptive field.
+# Only practical on small grids -- which is what the tests use.
+# --------------------------------------------------------------------------------------------------
+def mean_vfe(voxels, num_points):
+    """mean_vfe.py:13-31: sum over all P rows / clamp_min(num, 1)."""
+    v = np.asarray(voxels, F32)
+    n = np.maximum(np.asarray(num_points).astype(F32), F32(1.0))
+    return (v.sum(axis=1, dtype=F32) / n[:, None]).astype(F32)
+
+
+def densify(features, indices, shape, batch):
+    import torch
+    C = features.shape[1]
+    D, H, W = shape
+    dense = torch.zeros((batch, C, D, H, W), dtype=torch.float32)
+    mask = torch.zeros((batch, 1, D, H, W), dtype=torch.float32)
+    idx = torch.as_tensor(np.asarray(indices)).long()
+    dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = torch.as_tensor(np.asarray(features, F32))
+    mask[idx[:, 0], 0, idx[:, 1], idx[:, 2], idx[:, 3]] = 1.0
+    return dense, mask
+
+
+def sparse_conv_dense(dense, mask, weight, ksize, stride, padding, subm, bn_gamma, bn_beta, bn_mean, bn_var,
+                      eps=1e-3):
+    """One SparseSequential(conv, BatchNorm1d, ReLU) block (sparse_backbone_3d.py:11-30) on dense
+    tensors.  weight [kz,ky,kx,Cin,Cout] (spconv 1.2.1 layout).  Returns (dense_out, mask_out)."""
+    import torch
+    import torch.nn.functional as Fn
+    w = torch.as_tensor(np.asarray(weight, F32)).permute(4, 3, 0, 1, 2).contiguous()
+    if subm:
+        pad = tuple(k // 2 for k in ksize)
+        y = Fn.conv3d(dense, w, None, 1, pad)
+        mask_out = mask
+    else:
+        y = Fn.conv3d(dense, w, None, tuple(stride), tuple(padding))
+        ones = torch.ones((1, 1) + tuple(ksize))
+        mask_out = (Fn.conv3d(mask, ones, None, tuple(stride), tuple(padding)) > 0).float()
+    g = torch.as_tensor(np.asarray(bn_gamma, F32)).view(1, -1, 1, 1, 1)
+    b = torch.as_tensor(np.asarray(bn_beta, F32)).view(1, -1, 1, 1, 1)
+    mu = torch.as_tensor(np.asarray(bn_mean, F32)).view(1, -1, 1, 1, 1)
+    var = torch.as_tensor(np.asarray(bn_var, F32)).view(1, -1, 1, 1, 1)
+    y = torch.relu((y - mu) / torch.sqrt(var + eps) * g + b)
+    return y * mask_out, mask_out  # BN + ReLU act on the active rows only; inactive cells stay zero
+
+
+SECOND_LAYERS = [  # (state_dict prefix, ksize, stride, padding, subm)  sparse_backbone_3d.py:48-91
+    ("conv_input", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv1.0", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv2.0", (3, 3, 3), (2, 2, 2), (1, 1, 1), False), ("conv2.1", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv2.2", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv3.0", (3, 3, 3), (2, 2, 2), (1, 1, 1), False), ("conv3.1", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv3.2", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv4.0", (3, 3, 3), (2, 2, 2), (0, 1, 1), False), ("conv4.1", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv4.2", (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("conv_out", (3, 1, 1), (2, 1, 1), (0, 0, 0), False),
+]
+
+
+def second_backbone(sd, prefix, vfe_features, indices, sparse_shape, batch):
+    """VoxelBackBone8x.forward + HeightCompression (sparse_backbone_3d.py:114-130,
+    height_compression.py:10-26) -> dense [B, C*D, H, W] numpy."""
+    dense, mask = densify(vfe_features, indices, sparse_shape, batch)
+    for name, k, s, p, subm in SECOND_LAYERS:
+        cp = f"{prefix}{name}.0." if name in ("conv_input", "conv_out") else f"{prefix}{name}.0."
+        bp = f"{prefix}{name}.1."
+        dense, mask = sparse_conv_dense(dense, mask, np.asarray(sd[cp + "weight"]), k, s, p, subm,
+                                        np.asarray(sd[bp + "weight"]), np.asarray(sd[bp + "bias"]),
+                                        np.asarray(sd[bp + "running_mean"]), np.asarray(sd[bp + "running_var"]))
+    B, C, D, H, W = dense.shape
+    return dense.reshape(B, C * D, H, W).numpy()

@@ -318,3 +318,99 @@ def test_bev_pool_full_size_vs_oracle(n_agents, C, final_dim):
     assert out.shape == ref.shape == (n_agents, C, 256, 256)
     _pool_close(out, ref)
     assert (out != 0).any(axis=1).sum() > 1000
+
+
+# ---------------------------------------------------------------------------------------------- K3
+def _random_sites(rng, n, shape, batch):
+    D, H, W = shape
+    lin = rng.choice(batch * D * H * W, size=n, replace=False)
+    b, r = np.divmod(lin, D * H * W)
+    z, r = np.divmod(r, H * W)
+    y, x = np.divmod(r, W)
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+def _dense_from(st):
+    C = st.features.shape[1]
+    D, H, W = st.spatial_shape
+    return st.dense().cpu().numpy().reshape(st.batch_size, C, D, H, W)
+
+
+def test_mean_vfe_vs_oracle():
+    from heal_amd import ops
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((5000, 5, 4)).astype(np.float32)
+    n = rng.integers(0, 6, 5000).astype(np.int32)
+    v *= (np.arange(5)[None, :, None] < n[:, None, None])
+    got = ops.mean_vfe(dev(v), dev(n)).cpu().numpy()
+    np.testing.assert_allclose(got, O.mean_vfe(v, n), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("cin,cout,ksize,stride,padding,subm", [
+    (4, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True), (16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), False),
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True), (64, 64, (3, 3, 3), (2, 2, 2), (0, 1, 1), False),
+    (64, 64, (3, 1, 1), (2, 1, 1), (0, 0, 0), False), (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), False)])
+def test_sparse_conv_layer_vs_dense_oracle(cin, cout, ksize, stride, padding, subm):
+    from heal_amd import ops
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape, batch = (11, 24, 20), 2
+    idx = _random_sites(rng, 1500, shape, batch)
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    K = int(np.prod(ksize))
+    w = (rng.standard_normal(tuple(ksize) + (cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    g = rng.uniform(0.8, 1.2, cout).astype(np.float32); b = rng.normal(0, 0.1, cout).astype(np.float32)
+    mu = rng.normal(0, 0.1, cout).astype(np.float32); var = rng.uniform(0.7, 1.3, cout).astype(np.float32)
+    scale = (g / np.sqrt(var + np.float32(1e-3))).astype(np.float32); shift = (b - mu * scale).astype(np.float32)
+    x = ops.SparseTensor.from_unsorted(dev(feats), dev(idx), shape, batch)
+    # sites come back sorted by linear coordinate
+    xi = x.indices.cpu().numpy().astype(np.int64)
+    lin = ((xi[:, 0] * shape[0] + xi[:, 1]) * shape[1] + xi[:, 2]) * shape[2] + xi[:, 3]
+    assert np.all(np.diff(lin) > 0)
+    if subm:
+        nbr = x.neighbors(x.indices, shape, ksize, (1, 1, 1), tuple(k // 2 for k in ksize))
+        out = ops.SparseTensor(x.conv(nbr, dev(w.reshape(K, cin, cout)), dev(scale), dev(shift)), x.indices, shape, batch)
+    else:
+        oi, oshape = x.out_sites(ksize, stride, padding)
+        nbr = x.neighbors(oi, oshape, ksize, stride, padding)
+        out = ops.SparseTensor(x.conv(nbr, dev(w.reshape(K, cin, cout)), dev(scale), dev(shift)), oi, oshape, batch)
+    dense, mask = O.densify(feats, idx, shape, batch)
+    ref, rmask = O.sparse_conv_dense(dense, mask, w, ksize, stride, padding, subm, g, b, mu, var)
+    got = _dense_from(out)
+    assert got.shape == tuple(ref.shape)
+    # active-site set is an index computation: exact
+    om = np.zeros(rmask.shape, bool)
+    oidx = out.indices.cpu().numpy()
+    om[oidx[:, 0], 0, oidx[:, 1], oidx[:, 2], oidx[:, 3]] = True
+    assert np.array_equal(om, rmask.numpy() > 0)
+    np.testing.assert_allclose(got, ref.numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_second_encoder_vs_dense_oracle():
+    """The whole VoxelBackBone8x + HeightCompression on a reduced grid against the dense restatement."""
+    from heal_amd.opencood.models.heter_encoders import SECOND
+    from tests.golden.detfill import fill_module
+    from heal_amd import synth
+    rng_range = [-6.4, -6.4, -3, 6.4, 6.4, 1]  # 128 x 128 x 40 voxels of 0.1 m -> sparse shape [41,128,128]
+    args = {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": rng_range, "mean_vfe": {"num_point_features": 4},
+            "spconv": {"num_features_in": 4, "num_features_out": 64}, "map2bev": {"feature_num": 128}}
+    enc = fill_module(SECOND(args)).cuda().eval()
+    pts = synth.lidar_frame(5)
+    pts = pts[(np.abs(pts[:, 0]) < 7) & (np.abs(pts[:, 1]) < 7)]
+    vs, cs, ns = [], [], []
+    for b in range(2):
+        v, c, n = cref.voxelize(pts[b::2], rng_range, [0.1, 0.1, 0.1], 5, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    v, c, n = np.concatenate(vs), np.concatenate(cs), np.concatenate(ns)
+    assert len(n) > 2000
+    with torch.no_grad():
+        got = enc({"inputs_m3": {"voxel_features": dev(v), "voxel_coords": dev(c), "voxel_num_points": dev(n)}},
+                  "m3").cpu().numpy()
+    sd = {k: t.cpu().numpy() for k, t in enc.state_dict().items()}
+    ref = O.second_backbone(sd, "spconv_block.", O.mean_vfe(v, n), c, [41, 128, 128], 2)
+    assert got.shape == ref.shape == (2, 128, 16, 16)
+    assert np.array_equal(got != 0, ref != 0) or np.mean((got != 0) != (ref != 0)) < 1e-3
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4)
+    # the device point-cloud path gives the same result as the voxel path
+    with torch.no_grad():
+        got2 = enc({"inputs_m3": {"points": [dev(pts[0::2]), dev(pts[1::2])]}}, "m3").cpu().numpy()
+    np.testing.assert_array_equal(got2, got)
