@@ -55,6 +55,8 @@ _SIGNATURES = {
     "heal_sp_to_bev_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "heal_sp_to_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
+    "heal_agent_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                     c_int, c_void_p, c_void_p]),
 }
 
 

@@ -125,7 +125,21 @@ def _camera_modality(lidar_range, final_dim, encoder):
     }
 
 
-def heal_heter(modalities=("m1", "m2", "m4"), lidar_range=FULL_RANGE, max_cav=5):
+def _second_modality(lidar_range):
+    return {
+        "core_method": "second",
+        "sensor_type": "lidar",
+        "encoder_args": {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": list(lidar_range),
+                         "mean_vfe": {"num_point_features": 4},
+                         "spconv": {"num_features_in": 4, "num_features_out": 64},
+                         "map2bev": {"feature_num": 128}},
+        "backbone_args": {"layer_nums": [3], "layer_strides": [1], "num_filters": [64], "inplanes": 128},
+        "aligner_args": {"core_method": "convnext", "spatial_align": False,
+                         "args": {"num_of_blocks": 3, "dim": 64}},
+    }
+
+
+def heal_heter(modalities=("m1", "m2", "m3", "m4"), lidar_range=FULL_RANGE, max_cav=5):
     """HEAL final-infer collaborative model with several modalities (m1 PointPillars LiDAR,
     m2 Lift-Splat EfficientNet 384x512, m4 Lift-Splat Resnet101 336x448; m3 SECOND when built) --
     MoreModality/HEAL/final_infer/m1m2m3m4.yaml, BASELINE config 4."""
@@ -137,6 +151,8 @@ def heal_heter(modalities=("m1", "m2", "m4"), lidar_range=FULL_RANGE, max_cav=5)
             args[m] = _pointpillar_modality(lidar_range, "identity")
         elif m == "m2":
             args[m] = _camera_modality(lidar_range, (384, 512), "EfficientNet")
+        elif m == "m3":
+            args[m] = _second_modality(lidar_range)
         elif m == "m4":
             args[m] = _camera_modality(lidar_range, (336, 448), "Resnet101")
         else:
@@ -144,6 +160,49 @@ def heal_heter(modalities=("m1", "m2", "m4"), lidar_range=FULL_RANGE, max_cav=5)
     args.update({"fusion_backbone": _fusion_backbone(), "shrink_header": _shrink_header(), "in_head": 256,
                  "anchor_number": 2, "dir_args": copy.deepcopy(DIR_ARGS)})
     h["model"] = {"core_method": "heter_pyramid_collab", "args": args}
+    return load_general_params(h)
+
+
+def _v2xvit_args():
+    return {"transformer": {"encoder": {
+        "num_blocks": 1, "depth": 3, "use_roi_mask": True, "use_RTE": False, "RTE_ratio": 0,
+        "cav_att_config": {"dim": 256, "use_hetero": True, "use_RTE": False, "RTE_ratio": 0, "heads": 8,
+                           "dim_head": 32, "dropout": 0.3},
+        "pwindow_att_config": {"dim": 256, "heads": [16, 8, 4], "dim_head": [16, 32, 64], "dropout": 0.3,
+                               "window_size": [4, 8, 16], "relative_pos_embedding": True,
+                               "fusion_method": "split_attn"},
+        "feed_forward": {"mlp_dim": 256, "dropout": 0.3},
+        "sttf": {"voxel_size": [0.4, 0.4, 4], "downsample_rate": 4}}}}
+
+
+def _baseline_modality(base, strides, inplanes=None):
+    m = {k: v for k, v in base.items() if k in ("core_method", "sensor_type", "encoder_args", "camera_mask_args")}
+    m["backbone_args"] = {"layer_nums": [3, 5, 8], "layer_strides": list(strides), "num_filters": [64, 128, 256],
+                          "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]}
+    if inplanes:
+        m["backbone_args"]["inplanes"] = inplanes
+    m["shrink_header"] = {"kernal_size": [3], "stride": [2], "padding": [1], "dim": [256], "input_dim": 384}
+    return m
+
+
+def lidar_baseline(fusion_method="v2xvit", lidar_range=FULL_RANGE, max_cav=5, modality="m1"):
+    """HeterModelBaseline (LiDAROnly/lidar_v2xvit.yaml; BASELINE config 5 with modality='m3'):
+    encoder -> plain BEV backbone -> shrinker -> single-scale fusion (v2xvit | att | max) -> heads."""
+    h = _common(lidar_range, max_cav)
+    h["name"] = f"heal_amd_opv2v_{modality}_{fusion_method}"
+    if modality == "m1":
+        mod = _baseline_modality(_pointpillar_modality(lidar_range), (2, 2, 2))
+    elif modality == "m3":
+        mod = _baseline_modality(_second_modality(lidar_range), (1, 2, 2), inplanes=128)
+    else:
+        raise NotImplementedError(modality)
+    args = {"ego_modality": modality, "lidar_range": list(lidar_range), modality: mod, "fusion_method": fusion_method,
+            "in_head": 256, "anchor_number": 2, "dir_args": copy.deepcopy(DIR_ARGS)}
+    if fusion_method == "v2xvit":
+        args["v2xvit"] = _v2xvit_args()
+    elif fusion_method == "att":
+        args["att"] = {"feat_dim": 256}
+    h["model"] = {"core_method": "heter_model_baseline", "args": args}
     return load_general_params(h)
 
 

@@ -1,0 +1,101 @@
+// K6 -- per-pixel multi-head attention over the agents of a scene.
+//
+// Reference arithmetic: opencood/models/sub_modules/hmsa.py:110-151 (HGTCavAttention.forward: per
+// BEV pixel an L x L attention between agents, per head, keys of padded agents masked to -inf) with
+// the heterogeneous relation matrices folded into the projections by the host (they are constant
+// per (type_i, type_j) and HEAL always runs with a single agent type, hmsa.py:118-125), and
+// opencood/models/fuse_modules/fusion_in_one.py:14-45,126-151 (AttFusion: softmax(X X^T/sqrt(C)) X per
+// pixel, one head, q = k = v).
+//
+// The reference materialises [B,M,H,W,L,L] score tensors and [B,M,H,W,L,L,C_head] messages through
+// einsum; here one 64-lane wave owns one pixel: lane = (head, channel quad), q/k/v rows are read as
+// coalesced 16 B/lane loads, the L x L scores are reduced across the lanes of a head with xor
+// shuffles, softmax and the weighted sum stay in registers.  HBM traffic = read q,k,v once, write
+// the output once.
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+constexpr int AA_MAXL = 8;
+
+template <int LANES_PER_HEAD, int L>
+__global__ __launch_bounds__(256) void k_agent_attn(const float4* __restrict__ q, const float4* __restrict__ k,
+                                                   const float4* __restrict__ v,
+                                                   const int* __restrict__ key_mask /*[L] or null*/,
+                                                   int n_pix, float scale, int out_rows,
+                                                   float4* __restrict__ out) {
+    // tensors are [n_pix][L][C] with C = 256 = 64 lanes x 4 channels
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= n_pix) return;
+    const int l = threadIdx.x & 63;
+    float4 kk[L], vv[L];
+    bool valid[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        kk[j] = k[((size_t)pix * L + j) * 64 + l];
+        vv[j] = v[((size_t)pix * L + j) * 64 + l];
+        valid[j] = key_mask == nullptr || key_mask[j] != 0;
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        if (i >= out_rows) break;
+        const float4 qi = q[((size_t)pix * L + i) * 64 + l];
+        float s[L];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float d = qi.x * kk[j].x + qi.y * kk[j].y + qi.z * kk[j].z + qi.w * kk[j].w;
+#pragma unroll
+            for (int o = LANES_PER_HEAD / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            s[j] = valid[j] ? d * scale : -INFINITY;
+            mx = fmaxf(mx, s[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const float p = s[j] / den;
+            acc.x += p * vv[j].x; acc.y += p * vv[j].y; acc.z += p * vv[j].z; acc.w += p * vv[j].w;
+        }
+        out[((size_t)pix * out_rows + i) * 64 + l] = acc;
+    }
+}
+
+template <int LPH>
+static int launch_l(int L, const float* q, const float* k, const float* v, const int* mask, int n_pix, float scale,
+                    int out_rows, float* out, hipStream_t s) {
+    const int blocks = ceil_div(n_pix, 4);
+    const float4 *q4 = (const float4*)q, *k4 = (const float4*)k, *v4 = (const float4*)v;
+    float4* o4 = (float4*)out;
+#define HEAL_AA(LL) case LL: k_agent_attn<LPH, LL><<<blocks, 256, 0, s>>>(q4, k4, v4, mask, n_pix, scale, out_rows, o4); break;
+    switch (L) {
+        HEAL_AA(1) HEAL_AA(2) HEAL_AA(3) HEAL_AA(4) HEAL_AA(5) HEAL_AA(6) HEAL_AA(7) HEAL_AA(8)
+        default: return set_error("agent_attention: L must be in [1,%d]", AA_MAXL);
+    }
+#undef HEAL_AA
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" int heal_agent_attention(const float* q, const float* k, const float* v, const int32_t* key_mask,
+                                    int n_pix, int n_agents, int channels, int heads, float scale, int out_rows,
+                                    float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(channels == 256, "agent_attention: channels must be 256 (got %d)", channels);
+    HEAL_REQUIRE(out_rows >= 1 && out_rows <= n_agents, "agent_attention: out_rows must be in [1,n_agents]");
+    if (n_pix <= 0) return 0;
+    switch (heads) {
+        case 1: return launch_l<64>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
+        case 4: return launch_l<16>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
+        case 8: return launch_l<8>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
+        case 16: return launch_l<4>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
+        default: return set_error("agent_attention: heads must be 1, 4, 8 or 16 (got %d)", heads);
+    }
+}

@@ -1,0 +1,103 @@
+"""BaseBEVBackbone -- OpenPCDet-style plain BEV backbone (reference: opencood/models/sub_modules/
+base_bev_backbone.py:6-156).  Same Sequential layout (ZeroPad2d, Conv2d, BN, ReLU, [Conv2d, BN, ReLU]*k)
+so that checkpoint keys `blocks.{i}.{1,2,4,5,...}` match; Conv+BN pairs are folded at inference."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from heal_amd.opencood.models.sub_modules.bev_blocks import _Deblock, _FoldCache, _require_eval
+
+
+class _PlainStage(nn.Sequential):
+    def __init__(self, layers):
+        super().__init__(*layers)
+        self._caches = {}
+
+    def forward(self, x):
+        _require_eval(self)
+        mods = list(self)
+        i = 0
+        pad = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.ZeroPad2d):
+                pad = m.padding[0]
+                i += 1
+                continue
+            if isinstance(m, nn.Conv2d):
+                bn = mods[i + 1]
+                cache = self._caches.setdefault(i, _FoldCache())
+                w, b = cache.get(m, bn)
+                padding = pad if pad else m.padding
+                x = F.conv2d(x, w, b, m.stride, padding).relu_()
+                pad = 0
+                i += 3
+                continue
+            i += 1
+        return x
+
+
+class BaseBEVBackbone(nn.Module):
+    def __init__(self, model_cfg, input_channels):
+        super().__init__()
+        self.model_cfg = model_cfg
+        if "layer_nums" in model_cfg:
+            layer_nums, layer_strides, num_filters = (model_cfg["layer_nums"], model_cfg["layer_strides"],
+                                                      model_cfg["num_filters"])
+            assert len(layer_nums) == len(layer_strides) == len(num_filters)
+        else:
+            layer_nums = layer_strides = num_filters = []
+        if "upsample_strides" in model_cfg:
+            assert len(model_cfg["upsample_strides"]) == len(model_cfg["num_upsample_filter"])
+            num_upsample_filters, upsample_strides = model_cfg["num_upsample_filter"], model_cfg["upsample_strides"]
+        else:
+            upsample_strides = num_upsample_filters = []
+        self.num_levels = len(layer_nums)
+        c_in_list = [input_channels, *num_filters[:-1]]
+        self.blocks = nn.ModuleList()
+        self.deblocks = nn.ModuleList()
+        for idx in range(self.num_levels):
+            layers = [nn.ZeroPad2d(1),
+                      nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0,
+                                bias=False),
+                      nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()]
+            for _ in range(layer_nums[idx]):
+                layers += [nn.Conv2d(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
+                           nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()]
+            self.blocks.append(_PlainStage(layers))
+            if len(upsample_strides) > 0:
+                stride = upsample_strides[idx]
+                if stride >= 1:
+                    conv = nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride,
+                                              bias=False)
+                else:
+                    stride = int(np.round(1 / stride))
+                    conv = nn.Conv2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride, bias=False)
+                self.deblocks.append(_Deblock(conv, nn.BatchNorm2d(num_upsample_filters[idx], eps=1e-3, momentum=0.01)))
+        c_in = sum(num_upsample_filters)
+        if len(upsample_strides) > self.num_levels:
+            self.deblocks.append(_Deblock(
+                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
+                nn.BatchNorm2d(c_in, eps=1e-3, momentum=0.01)))
+        self.num_bev_features = c_in
+
+    def get_multiscale_feature(self, spatial_features):
+        feats = []
+        x = spatial_features
+        for blk in self.blocks:
+            x = blk(x)
+            feats.append(x)
+        return feats
+
+    def decode_multiscale_feature(self, x):
+        ups = [self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i] for i in range(self.num_levels)]
+        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        if len(self.deblocks) > self.num_levels:
+            x = self.deblocks[-1](x)
+        return x
+
+    def forward(self, data_dict):
+        data_dict["spatial_features_2d"] = self.decode_multiscale_feature(
+            self.get_multiscale_feature(data_dict["spatial_features"]))
+        return data_dict

@@ -368,3 +368,19 @@ class SparseTensor:
         _capi.call("heal_sp_to_bev", _ptr(self.features), _ptr(self.indices), self.n, C, _i3(self.spatial_shape),
                    self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _stream())
         return out
+
+
+# ------------------------------------------------------------------------------------------------ K6
+def agent_attention(q, k, v, heads, scale, key_mask=None, out_rows=None):
+    """K6.  q,k,v [n_pix, L, 256] f32 cuda -> [n_pix, out_rows, 256] (softmax over the L agents per
+    pixel and head; key_mask [L] int32 cuda marks real agents)."""
+    q = _need(q, torch.float32, "q"); k = _need(k, torch.float32, "k"); v = _need(v, torch.float32, "v")
+    n_pix, L, C = (int(x) for x in q.shape)
+    rows = L if out_rows is None else int(out_rows)
+    out = torch.empty((n_pix, rows, C), dtype=torch.float32, device=q.device)
+    if key_mask is not None:
+        key_mask = _need(key_mask, torch.int32, "key_mask")
+    with _Timed(f"agent_attention_h{heads}"):
+        _capi.call("heal_agent_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(key_mask), n_pix, L, C, int(heads),
+                   float(scale), rows, _ptr(out), _stream())
+    return out

@@ -184,6 +184,19 @@ size_t heal_sp_to_bev_workspace(int batch, int D, int H, int W);
 int heal_sp_to_bev(const float* features, const int32_t* indices, int n, int channels,
                    const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K6  per-pixel multi-head attention over agents.
+ * Replaces: opencood/models/sub_modules/hmsa.py:110-151 (HGTCavAttention attention core, relation
+ *           matrices folded into the projections by the caller) and
+ *           opencood/models/fuse_modules/fusion_in_one.py:14-45,126-151 (AttFusion, heads = 1, q=k=v).
+ *   q,k,v [n_pix, n_agents, 256] f32 (pixel-major); key_mask [n_agents] i32 DEVICE or NULL (0 = padded
+ *   agent, masked to -inf as a key); out [n_pix, out_rows, 256]: rows 0..out_rows-1 of the result
+ *   (out_rows = 1 keeps only the ego row, out_rows = n_agents keeps all).
+ * -----------------------------------------------------------------------------------------------*/
+int heal_agent_attention(const float* q, const float* k, const float* v, const int32_t* key_mask, int n_pix,
+                         int n_agents, int channels, int heads, float scale, int out_rows, float* out,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

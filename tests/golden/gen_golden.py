@@ -251,8 +251,56 @@ def gen_lss():
          **{f"cam_{k}": v for k, v in cam.items()})
 
 
+def gen_fusion_small():
+    fio = R.ref("opencood.models.fuse_modules.fusion_in_one")
+    tu = R.ref("opencood.utils.transformation_utils")
+    hy = load_hypes("LiDAROnly/lidar_v2xvit.yaml")
+    rng = np.random.default_rng(13)
+    n, C, H, W = 3, 256, 32, 32
+    x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+    Hm = Wm = 51.2
+    poses = synth.agent_poses(23, n, r_min=4.0, r_max=12.0)
+    pw = synth.pairwise_t_matrix(poses, 5)[None]
+    aff = tu.normalize_pairwise_tfm(torch.from_numpy(pw.copy()), Hm, Wm, 1)
+    rl = torch.tensor([n])
+    out = {"x": x, "pairwise": pw, "HW_m": np.array([Hm, Wm])}
+    with torch.no_grad():
+        out["max"] = fio.MaxFusion()(torch.from_numpy(x), rl, aff).numpy()
+        out["att"] = fio.AttFusion(C)(torch.from_numpy(x), rl, aff).numpy()
+        v = fill_module(fio.V2XViTFusion(copy.deepcopy(hy["model"]["args"]["v2xvit"]))).eval()
+        out["v2xvit"] = v(torch.from_numpy(x), rl, aff.float()).numpy()
+    save("fusion_small", **out)
+
+
+def gen_baseline_small():
+    m = R.ref("opencood.models.heter_model_baseline")
+    hy = load_hypes("LiDAROnly/lidar_v2xvit.yaml")
+    out = {}
+    for method in ("v2xvit", "att", "max"):
+        args = _collab_small_args(hy)
+        args["fusion_method"] = method
+        if method == "att":
+            args["att"] = {"feat_dim": 256}
+        model = fill_module(m.HeterModelBaseline(args)).eval()
+        n = 2
+        vf, vc, vn = small_lidar_inputs([61, 62], n_points=7000)
+        poses = synth.agent_poses(70, n, r_min=4.0, r_max=12.0)
+        pw = synth.pairwise_t_matrix(poses, 5)[None].astype(np.float32)  # V2XViT fusion needs a float32 grid
+        data = {"inputs_m1": {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+                              "voxel_num_points": torch.from_numpy(vn)},
+                "agent_modality_list": ["m1"] * n, "record_len": torch.tensor([n]),
+                "pairwise_t_matrix": torch.from_numpy(pw.copy())}
+        with torch.no_grad():
+            o = model(data)
+        out.update({"voxel_features": vf, "voxel_coords": vc, "voxel_num_points": vn, "pairwise": pw,
+                    f"{method}_cls": o["cls_preds"].numpy(), f"{method}_reg": o["reg_preds"].numpy(),
+                    f"{method}_dir": o["dir_preds"].numpy()})
+    save("baseline_small", **out)
+
+
 GENS = {"pointpillar_encoder": gen_pointpillar_encoder, "warp_fuse": gen_warp_fuse, "decode": gen_decode,
-        "collab_small": gen_collab_small, "single_late_small": gen_single_late_small, "lss": gen_lss}
+        "collab_small": gen_collab_small, "single_late_small": gen_single_late_small, "lss": gen_lss,
+        "fusion_small": gen_fusion_small, "baseline_small": gen_baseline_small}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENS)

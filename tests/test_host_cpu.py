@@ -52,7 +52,7 @@ def test_state_dict_keys_match_reference():
     from heal_amd.opencood.tools.train_utils import create_model
     keys = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
     for name, hy in (("collab", configs.lidar_pyramid()), ("single", configs.m1_single_pyramid()),
-                     ("late", configs.m1_late())):
+                     ("late", configs.m1_late()), ("baseline_v2xvit", configs.lidar_baseline("v2xvit"))):
         sd = create_model(hy).state_dict()
         assert {k: list(v.shape) for k, v in sd.items()} == keys[name], name
 
