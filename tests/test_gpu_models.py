@@ -81,10 +81,14 @@ def test_points_fast_path_equals_voxel_input(golden):
     pts = pts[near][:9000]
     v, c, n = cref.voxelize(pts, SMALL_RANGE, [0.4, 0.4, 4], 32, 70000, batch_idx=0)
     with torch.no_grad():
-        a = model({"inputs_m1": {"voxel_features": dev(v), "voxel_coords": dev(c), "voxel_num_points": dev(n)}})
-        b = model({"inputs_m1": {"points": [dev(pts)]}})
+        in_a = {"inputs_m1": {"voxel_features": dev(v), "voxel_coords": dev(c), "voxel_num_points": dev(n)}}
+        in_b = {"inputs_m1": {"points": [dev(pts)]}}
+        # the encoder (K1 + K2, our kernels) is bit-identical on both routes ...
+        assert torch.equal(model.encoder_m1(in_a, "m1"), model.encoder_m1(in_b, "m1"))
+        a, b = model(in_a), model(in_b)
+    # ... the dense tail goes through MIOpen, which may pick another algorithm on a later call
     for key in ("cls_preds", "reg_preds", "dir_preds"):
-        assert torch.equal(a[key], b[key])
+        np.testing.assert_allclose(a[key].cpu().numpy(), b[key].cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_post_process_end_to_end(golden):
