@@ -57,6 +57,9 @@ _SIGNATURES = {
                                c_void_p]),
     "heal_agent_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                      c_int, c_void_p, c_void_p]),
+    "heal_grouped_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_void_p]),
+    "heal_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 

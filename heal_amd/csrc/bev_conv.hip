@@ -1,0 +1,123 @@
+// K7 helpers for the dense BEV stacks -- the parts of the ResNeXt pyramid where a vendor convolution is
+// far from the roofline:
+//
+//  * heal_grouped_conv3x3: the 32-group 3x3 convolutions of the ResNeXt bottlenecks
+//    (opencood/models/sub_modules/resblock.py:90-98 via pyramid_fuse.py:71-79: groups 32, 4/8/16 channels
+//    per group) with the folded BatchNorm bias and ReLU as epilogue.  With 4..16 channels per group there
+//    is no GEMM worth a matrix core: it is an HBM-bound stencil (read the map once, write it once).  A
+//    block owns a 32x8 output tile of one (image, group): the input patch (with halo) goes through LDS,
+//    every thread keeps all output channels of its pixel in registers, weights are block-uniform.
+//  * heal_bias_act: y = act(x + bias[c] (+ residual)) in one pass, in place -- replaces the separate
+//    bias-add / residual-add / ReLU kernels that follow a library convolution.
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+template <int CG, int STRIDE>
+__global__ __launch_bounds__(256) void k_grouped_conv3x3(const float* __restrict__ x,
+                                                        const float* __restrict__ w /*[C][CG][3][3]*/,
+                                                        const float* __restrict__ bias /*[C] or null*/,
+                                                        int C, int H, int W, int Ho, int Wo, int relu,
+                                                        float* __restrict__ y) {
+    constexpr int TW = 32, TH = 8;
+    constexpr int IW = (TW - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3;
+    constexpr int CCH = 4;  // input channels staged per pass (keeps LDS small -> several blocks per CU)
+    __shared__ float tile[CCH][IH][IW + 1];
+    __shared__ float sw[CG * CG * 9];
+    const int G = C / CG;
+    const int n = blockIdx.z / G, g = blockIdx.z - n * G;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+    const float* xin = x + ((size_t)n * C + (size_t)g * CG) * H * W;
+    for (int e = threadIdx.x; e < CG * CG * 9; e += 256) sw[e] = w[(size_t)g * CG * CG * 9 + e];
+    const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    float acc[CG];
+#pragma unroll
+    for (int co = 0; co < CG; ++co) acc[co] = bias ? bias[g * CG + co] : 0.f;
+    for (int c0 = 0; c0 < CG; c0 += CCH) {
+        __syncthreads();  // previous pass finished reading the tile (and sw is complete on the first pass)
+        for (int e = threadIdx.x; e < CCH * IH * IW; e += 256) {
+            const int c = e / (IH * IW), r = (e / IW) % IH, col = e % IW;
+            const int iy = iy0 + r, ix = ix0 + col;
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xin[((size_t)(c0 + c) * H + iy) * W + ix];
+            tile[c][r][col] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CCH; ++cc) {
+            float v[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] = tile[cc][ty * STRIDE + k / 3][tx * STRIDE + k % 3];
+#pragma unroll
+            for (int co = 0; co < CG; ++co) {
+                const float* wk = &sw[(co * CG + c0 + cc) * 9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[co] = fmaf(v[k], wk[k], acc[co]);
+            }
+        }
+    }
+    if (ox < Wo && oy < Ho) {
+        float* yo = y + ((size_t)n * C + (size_t)g * CG) * Ho * Wo + (size_t)oy * Wo + ox;
+#pragma unroll
+        for (int co = 0; co < CG; ++co) {
+            const float r = relu ? fmaxf(acc[co], 0.f) : acc[co];
+            yo[(size_t)co * Ho * Wo] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bias_act(float4* __restrict__ x, const float* __restrict__ bias,
+                                                 const float4* __restrict__ res, int C, int HW4, long long total4,
+                                                 int relu) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < total4; i += stride) {
+        const int c = (int)((i / HW4) % C);
+        const float b = bias ? bias[c] : 0.f;
+        float4 v = x[i];
+        v.x += b; v.y += b; v.z += b; v.w += b;
+        if (res) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        x[i] = v;
+    }
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" int heal_grouped_conv3x3(const float* x, const float* weight, const float* bias, int n, int channels,
+                                    int groups, int H, int W, int stride, int relu, float* y, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n >= 1 && channels >= 1 && groups >= 1 && channels % groups == 0, "grouped_conv3x3: bad channels");
+    HEAL_REQUIRE(stride == 1 || stride == 2, "grouped_conv3x3: stride must be 1 or 2");
+    const int cg = channels / groups;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    HEAL_REQUIRE((long long)n * groups <= 65535, "grouped_conv3x3: n*groups exceeds the grid limit");
+    dim3 grid(ceil_div(Wo, 32), ceil_div(Ho, 8), n * groups);
+#define HEAL_GC(CG, ST)                                                                                    \
+    if (cg == CG && stride == ST) {                                                                        \
+        k_grouped_conv3x3<CG, ST><<<grid, 256, 0, s>>>(x, weight, bias, channels, H, W, Ho, Wo, relu, y);   \
+        HEAL_LAUNCH_CHECK();                                                                               \
+        return 0;                                                                                          \
+    }
+    HEAL_GC(4, 1) HEAL_GC(4, 2) HEAL_GC(8, 1) HEAL_GC(8, 2) HEAL_GC(16, 1) HEAL_GC(16, 2)
+#undef HEAL_GC
+    return set_error("grouped_conv3x3: %d channels per group is not instantiated (4, 8, 16)", cg);
+}
+
+extern "C" int heal_bias_act(float* x, const float* bias, const float* residual, int n, int channels, int HW,
+                             int relu, void* stream) {
+    HEAL_REQUIRE(HW % 4 == 0, "bias_act: H*W must be a multiple of 4");
+    const long long total4 = (long long)n * channels * (HW / 4);
+    if (total4 <= 0) return 0;
+    const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    k_bias_act<<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(x), bias,
+                                                        reinterpret_cast<const float4*>(residual), channels, HW / 4,
+                                                        total4, relu);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

@@ -45,6 +45,23 @@ class _FoldCache:
         return self.value
 
 
+def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, residual=None):
+    """conv2d + per-channel bias (+ residual) (+ ReLU).  The ResNeXt 32-group 3x3 convolutions run on the
+    hand-written stencil kernel (heal_grouped_conv3x3); everything else is a library convolution WITHOUT
+    bias followed by ONE fused in-place pass (heal_bias_act) instead of separate bias / add / ReLU kernels."""
+    from heal_amd import ops
+    st = stride if isinstance(stride, int) else stride[0]
+    pd = padding if isinstance(padding, int) else padding[0]
+    dl = dilation if isinstance(dilation, int) else dilation[0]
+    if (groups > 1 and w.shape[2:] == (3, 3) and pd == 1 and dl == 1 and st in (1, 2) and residual is None
+            and w.shape[1] in (4, 8, 16) and w.shape[0] == x.shape[1]):
+        return ops.grouped_conv3x3(x, w, b, groups, st, relu)
+    y = F.conv2d(x, w, None, stride, padding, dilation, groups)
+    if b is None and residual is None and not relu:
+        return y
+    return ops.bias_act_(y, b, residual, relu)
+
+
 def _require_eval(module):
     if module.training and torch.is_grad_enabled():
         raise NotImplementedError(
@@ -59,12 +76,7 @@ class ConvBN(nn.Module):
     @staticmethod
     def run(x, conv, bn, cache, relu, residual=None):
         w, b = cache.get(conv, bn)
-        y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
-        if residual is not None:
-            y.add_(residual)
-        if relu:
-            y.relu_()
-        return y
+        return conv_bias_act(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups, relu, residual)
 
 
 def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
@@ -183,13 +195,13 @@ class _Deblock(nn.Sequential):
     def forward(self, x):
         _require_eval(self)
         conv, bn = self[0], self[1]
+        from heal_amd import ops
         if isinstance(conv, nn.ConvTranspose2d):
             w, b = self._cache.get(conv, bn, transposed=True)
-            y = F.conv_transpose2d(x, w, b, conv.stride, conv.padding, conv.output_padding, conv.groups)
-        else:
-            w, b = self._cache.get(conv, bn)
-            y = F.conv2d(x, w, b, conv.stride, conv.padding)
-        return y.relu_()
+            y = F.conv_transpose2d(x, w, None, conv.stride, conv.padding, conv.output_padding, conv.groups)
+            return ops.bias_act_(y, b, None, True)
+        w, b = self._cache.get(conv, bn)
+        return conv_bias_act(x, w, b, conv.stride, conv.padding, 1, 1, True)
 
 
 class ResNetBEVBackbone(nn.Module):
@@ -266,8 +278,8 @@ class DoubleConv(nn.Module):
 
     def forward(self, x):
         c0, c1 = self.double_conv[0], self.double_conv[2]
-        x = F.conv2d(x, c0.weight, c0.bias, c0.stride, c0.padding).relu_()
-        return F.conv2d(x, c1.weight, c1.bias, c1.stride, c1.padding).relu_()
+        x = conv_bias_act(x, c0.weight, c0.bias, c0.stride, c0.padding, 1, 1, True)
+        return conv_bias_act(x, c1.weight, c1.bias, c1.stride, c1.padding, 1, 1, True)
 
 
 class DownsampleConv(nn.Module):

@@ -384,3 +384,28 @@ def agent_attention(q, k, v, heads, scale, key_mask=None, out_rows=None):
         _capi.call("heal_agent_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(key_mask), n_pix, L, C, int(heads),
                    float(scale), rows, _ptr(out), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ K7
+def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
+    """32-group 3x3 conv (padding 1) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3]."""
+    x = _need(x, torch.float32, "x")
+    weight = _need(weight, torch.float32, "weight")
+    n, C, H, W = (int(v) for v in x.shape)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    y = torch.empty((n, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    with _Timed(f"grouped_conv3x3_c{C}"):
+        _capi.call("heal_grouped_conv3x3", _ptr(x), _ptr(weight), _ptr(bias), n, C, int(groups), H, W, int(stride),
+                   int(bool(relu)), _ptr(y), _stream())
+    return y
+
+
+def bias_act_(x, bias=None, residual=None, relu=True):
+    """In place: x = act(x + bias[c] + residual).  x [n,C,H,W] contiguous f32 cuda."""
+    x = _need(x, torch.float32, "x")
+    n, C = int(x.shape[0]), int(x.shape[1])
+    HW = int(x.shape[2] * x.shape[3])
+    if residual is not None:
+        residual = _need(residual, torch.float32, "residual")
+    _capi.call("heal_bias_act", _ptr(x), _ptr(bias), _ptr(residual), n, C, HW, int(bool(relu)), _stream())
+    return x

@@ -197,6 +197,20 @@ int heal_agent_attention(const float* q, const float* k, const float* v, const i
                          int n_agents, int channels, int heads, float scale, int out_rows, float* out,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K7 helpers for the dense BEV stacks.
+ * heal_grouped_conv3x3 replaces the 32-group 3x3 convolutions of the ResNeXt bottlenecks
+ *   (opencood/models/sub_modules/resblock.py:90-98,110-112: conv2 + bn2 + relu, BatchNorm folded into
+ *   weight/bias by the caller); x [n,C,H,W], weight [C, C/groups, 3, 3], bias [C] or NULL, padding 1,
+ *   stride 1|2 -> y [n,C,Ho,Wo].
+ * heal_bias_act: x = act(x + bias[c] + residual) in place (resblock.py:57-62,113-120: bn (folded),
+ *   `out += identity`, relu); residual may be NULL, bias may be NULL.
+ * -----------------------------------------------------------------------------------------------*/
+int heal_grouped_conv3x3(const float* x, const float* weight, const float* bias, int n, int channels, int groups,
+                         int H, int W, int stride, int relu, float* y, void* stream);
+int heal_bias_act(float* x, const float* bias, const float* residual, int n, int channels, int HW, int relu,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -414,3 +414,34 @@ def test_second_encoder_vs_dense_oracle():
     with torch.no_grad():
         got2 = enc({"inputs_m3": {"points": [dev(pts[0::2]), dev(pts[1::2])]}}, "m3").cpu().numpy()
     np.testing.assert_array_equal(got2, got)
+
+
+# ---------------------------------------------------------------------------------------------- K7
+@pytest.mark.parametrize("C,stride,H,W", [(128, 1, 64, 96), (256, 2, 64, 64), (512, 1, 32, 32), (512, 2, 34, 30),
+                                          (128, 2, 37, 41)])
+def test_grouped_conv3x3_vs_torch(C, stride, H, W):
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(C + stride)
+    x = torch.randn((2, C, H, W), generator=g).cuda()
+    w = (torch.randn((C, C // 32, 3, 3), generator=g) * 0.2).cuda()
+    b = torch.randn((C,), generator=g).cuda()
+    got = ops.grouped_conv3x3(x, w, b, 32, stride, relu=True)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride, 1, 1, 32)).float()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    got2 = ops.grouped_conv3x3(x, w, None, 32, stride, relu=False)
+    ref2 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, 1, 1, 32).float()
+    np.testing.assert_allclose(got2.cpu().numpy(), ref2.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_bias_act_vs_torch():
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((3, 20, 12, 8), generator=g).cuda()
+    r = torch.randn((3, 20, 12, 8), generator=g).cuda()
+    b = torch.randn((20,), generator=g).cuda()
+    for bias, res, relu in ((b, r, True), (b, None, True), (None, r, False), (b, None, False)):
+        y = x.clone()
+        ops.bias_act_(y, bias, res, relu)
+        ref = x + (bias.view(1, -1, 1, 1) if bias is not None else 0) + (res if res is not None else 0)
+        ref = torch.relu(ref) if relu else ref
+        np.testing.assert_array_equal(y.cpu().numpy(), ref.cpu().numpy())
