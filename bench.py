@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="scene5", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying "
+                    "the captured HIP graph of the step")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,9 +126,21 @@ def main():
     cls_shift = pipe.calibrate_cls_bias(scene)
     batch = {"ego": {"transformation_matrix": pipe.tfm, "anchor_box": pipe.anchor_box}}
 
+    use_graph = False
     if world == 1:
         def step():
             return pipe.step(scene)
+        if not a.eager:
+            try:
+                pipe.capture(scene)
+                use_graph = True
+
+                def step():  # noqa: F811
+                    return pipe.replay()
+            except Exception as e:  # a path with a host round trip (e.g. SECOND's site counts) cannot be captured
+                print(f"[bench] HIP graph capture unavailable for this workload ({type(e).__name__}: {e}); "
+                      "running eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
     else:
         sharded = ShardedCollab(pipe.model, rank, world)
         mine = owned_agents(n_agents, rank, world)
@@ -148,12 +162,20 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    ops.TIMING = {}
+    if not use_graph:
+        ops.TIMING = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
     fence()
     dt = time.perf_counter() - t0
+    if use_graph:
+        # per-operator HIP-event timing needs host-side launches: an instrumented eager pass over the
+        # same K steps, right after the timed graph replays (events cannot be recorded inside a graph)
+        ops.TIMING = {}
+        for _ in range(a.steps):
+            pipe.step(scene)
+        torch.cuda.synchronize()
     timing = ops.timing_summary()
     ops.TIMING = None
     if world > 1:
@@ -191,6 +213,7 @@ def main():
                        "pillars_per_agent": m_per_agent, "modalities": mods,
                        "points_per_agent": [int(scene.points[k].shape[0]) for k in sorted(scene.points)],
                        "parallelism": "1 GPU" if world == 1 else f"agent-sharded over {world} ranks, 1 all-gather",
+                       "launch": "hipGraph replay of the whole step" if use_graph else "eager launches",
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "op_timing_ms": kernels,
         }

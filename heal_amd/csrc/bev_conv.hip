@@ -24,20 +24,20 @@ __global__ __launch_bounds__(256) void k_grouped_conv3x3(const float* __restrict
     constexpr int IW = (TW - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3;
     constexpr int CCH = 4;  // input channels staged per pass (keeps LDS small -> several blocks per CU)
     __shared__ float tile[CCH][IH][IW + 1];
-    __shared__ float sw[CG * CG * 9];
     const int G = C / CG;
     const int n = blockIdx.z / G, g = blockIdx.z - n * G;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
     const float* xin = x + ((size_t)n * C + (size_t)g * CG) * H * W;
-    for (int e = threadIdx.x; e < CG * CG * 9; e += 256) sw[e] = w[(size_t)g * CG * CG * 9 + e];
+    // weights of this group: block-uniform addresses -> scalar loads, operands come from SGPRs
+    const float* __restrict__ wg = w + (size_t)g * CG * CG * 9;
     const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
     const int ox = ox0 + tx, oy = oy0 + ty;
     float acc[CG];
 #pragma unroll
     for (int co = 0; co < CG; ++co) acc[co] = bias ? bias[g * CG + co] : 0.f;
     for (int c0 = 0; c0 < CG; c0 += CCH) {
-        __syncthreads();  // previous pass finished reading the tile (and sw is complete on the first pass)
+        __syncthreads();  // previous pass finished reading the tile
         for (int e = threadIdx.x; e < CCH * IH * IW; e += 256) {
             const int c = e / (IH * IW), r = (e / IW) % IH, col = e % IW;
             const int iy = iy0 + r, ix = ix0 + col;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_grouped_conv3x3(const float* __restrict
             for (int k = 0; k < 9; ++k) v[k] = tile[cc][ty * STRIDE + k / 3][tx * STRIDE + k % 3];
 #pragma unroll
             for (int co = 0; co < CG; ++co) {
-                const float* wk = &sw[(co * CG + c0 + cc) * 9];
+                const float* wk = wg + (co * CG + c0 + cc) * 9;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) acc[co] = fmaf(v[k], wk[k], acc[co]);
             }
