@@ -112,6 +112,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if os.environ.get("HEAL_MIOPEN_BENCHMARK", "0") == "1":
+        torch.backends.cudnn.benchmark = True  # MIOpen find mode: time the applicable solvers once per shape
     from heal_amd import configs, ops
     from heal_amd.dist import ShardedCollab, owned_agents
     from heal_amd.pipeline import Scene, ScenePipeline
