@@ -1,0 +1,59 @@
+"""Agent-sharded execution (heal_amd/dist.py) end to end on ONE GPU: two ranks share cuda:0 and exchange
+through gloo (RCCL refuses two ranks on one device), everything else -- ownership, rank-local warp,
+pack, all-gather, unpack, fusion tail -- is the code the multi-GPU bench runs.  The result must match
+the single-process model."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mods, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from heal_amd import configs
+    from heal_amd.dist import ShardedCollab, owned_agents
+    from heal_amd.pipeline import Scene, ScenePipeline
+    small = [-25.6, -25.6, -3, 25.6, 25.6, 1]
+    hypes = configs.lidar_pyramid(small)
+    pipe = ScenePipeline(hypes, "cuda:0", seed=5)
+    scene = Scene(len(mods), seed=6, device="cuda:0", modalities=mods)
+    scene.points = {k: p[(p[:, 0].abs() < 28) & (p[:, 1].abs() < 28)][:6000].contiguous()
+                    for k, p in scene.points.items()}
+    from heal_amd import synth
+    scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
+    sharded = ShardedCollab(pipe.model, rank, world)
+    mine = owned_agents(len(mods), rank, world)
+    with torch.no_grad():
+        out = sharded.forward(scene.model_input(), len(mods), scene.inputs_for(mine))
+        if rank == 0:
+            ref = pipe.model(scene.model_input())
+            torch.save({k: (out[k].cpu(), ref[k].cpu()) for k in ("cls_preds", "reg_preds", "dir_preds")}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_agents", [3, 2])
+def test_sharded_forward_equals_single_process(tmp_path, n_agents):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "o.pt")
+    mp.spawn(_worker, args=(2, _free_port(), ["m1"] * n_agents, out), nprocs=2, join=True)
+    res = torch.load(out)
+    for k, (got, ref) in res.items():
+        err = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+        assert err < 1e-4, (k, err)
