@@ -238,20 +238,34 @@ __global__ __launch_bounds__(64) void k_nms_mask(NmsBufs nb, int top, int words,
     const int K = min(*nb.n_cand, top);
     if (bi * 64 >= K || bj * 64 >= K) return;
     __shared__ float cq[64][8];
+    __shared__ float cbb[64][4];  // axis-aligned bounds (xmin, xmax, ymin, ymax) of the column quads
     const int cj = bj * 64 + threadIdx.x;
     if (cj < K) {
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cq[threadIdx.x][k] = nb.quads[(size_t)cj * 8 + k];
+        for (int k = 0; k < 4; ++k) {
+            const float px = nb.quads[(size_t)cj * 8 + 2 * k], py = nb.quads[(size_t)cj * 8 + 2 * k + 1];
+            cq[threadIdx.x][2 * k] = px; cq[threadIdx.x][2 * k + 1] = py;
+            x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
+        }
+        cbb[threadIdx.x][0] = x0; cbb[threadIdx.x][1] = x1; cbb[threadIdx.x][2] = y0; cbb[threadIdx.x][3] = y1;
     }
     __syncthreads();
     const int i = bi * 64 + threadIdx.x;
     if (i >= K) return;
     float q[8];
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) q[k] = nb.quads[(size_t)i * 8 + k];
+    for (int k = 0; k < 4; ++k) {
+        q[2 * k] = nb.quads[(size_t)i * 8 + 2 * k]; q[2 * k + 1] = nb.quads[(size_t)i * 8 + 2 * k + 1];
+        x0 = fminf(x0, q[2 * k]); x1 = fmaxf(x1, q[2 * k]); y0 = fminf(y0, q[2 * k + 1]); y1 = fmaxf(y1, q[2 * k + 1]);
+    }
     unsigned long long bits = 0ull;
     const int jn = min(64, K - bj * 64);
     for (int t = (bi == bj) ? (int)threadIdx.x + 1 : 0; t < jn; ++t) {
+        // strictly separated bounding boxes => empty intersection => IoU is 0 (or NaN for a degenerate
+        // pair): never above the threshold, exactly as the full clip would conclude
+        if (cbb[t][0] > x1 || cbb[t][1] < x0 || cbb[t][2] > y1 || cbb[t][3] < y0) continue;
         const float v = quad_iou(q, cq[t]);
         if (v > thr) bits |= 1ull << t;
     }
