@@ -140,16 +140,50 @@ __global__ __launch_bounds__(256) void k_lss_reduce(const uint32_t* __restrict__
     float acc[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
-    for (int j = lo; j < hi; ++j) {
-        const uint32_t idx = svals[j];
-        const int bn = idx / DHW;
-        const int pix = (idx - bn * DHW) % HW;
-        const float p = probs[idx];
-        const float* f = featT + ((size_t)bn * HW + pix) * g.C;
+    // 64 points at a time: lane j fetches point j's index, probability and feature-row offset (coalesced /
+    // independent), then the rows are streamed 4 at a time so that several 512 B row reads are in flight.
+    // The additions stay in point order, so the sum is deterministic.
+    for (int base = lo; base < hi; base += 64) {
+        const int cnt = min(64, hi - base);
+        float my_p = 0.f;
+        int my_off = 0;
+        if (l < cnt) {
+            const uint32_t idx = svals[base + l];
+            const int bn = idx / DHW;
+            const int pix = (idx - bn * DHW) % HW;
+            my_p = probs[idx];
+            my_off = (bn * HW + pix) * g.C;
+        }
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+            float p[4];
+            const float* f[4];
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const int c = l + 64 * k;
-            if (c < g.C) acc[k] += p * f[c];  // product then add, like the reference's lifted tensor sum
+            for (int u = 0; u < 4; ++u) {
+                p[u] = __shfl(my_p, j + u, 64);
+                f[u] = featT + __shfl(my_off, j + u, 64);
+            }
+            float v[4][CPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = l + 64 * k;
+                    v[u][k] = c < g.C ? f[u][c] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) acc[k] += p[u] * v[u][k];
+        }
+        for (; j < cnt; ++j) {
+            const float p = __shfl(my_p, j, 64);
+            const float* f = featT + __shfl(my_off, j, 64);
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c = l + 64 * k;
+                if (c < g.C) acc[k] += p * f[c];
+            }
         }
     }
     int row = 0;

@@ -14,6 +14,7 @@
 //             pillar ids once and streams 16-B stores for every channel (zeros where the cell is
 //             empty).  The 67 MB/agent canvas is therefore written exactly once -- no memset pass
 //             followed by a scatter pass -- which is what the HBM roofline of this operator allows.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/heal_amd.h"
 
@@ -47,11 +48,25 @@ __global__ __launch_bounds__(256) void k_pfn(const float4* __restrict__ voxels, 
     const float sc = bn_scale[l], sh = bn_shift[l];
     const float pad_val = fmaxf(sh, 0.f);  // a zeroed row gives 0*W -> BN -> ReLU = relu(shift)
 
-    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
-        const int4 cd = coords[m];  // (b, z, y, x)
-        const int np = num_points[m];
-        float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l < P) pt = voxels[(size_t)m * P + l];
+    const int stride = gridDim.x * 4;
+    int m = blockIdx.x * 4 + wave;
+    int4 cd_n = make_int4(0, 0, 0, 0);
+    int np_n = 0;
+    float4 pt_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
+        cd_n = coords[m]; np_n = num_points[m];
+        if (l < P) pt_n = voxels[(size_t)m * P + l];
+    }
+    for (; m < M; m += stride) {
+        const int4 cd = cd_n;  // (b, z, y, x)
+        const int np = np_n;
+        const float4 pt = pt_n;
+        // prefetch the next pillar of this wave while this one is being reduced
+        const int mn = m + stride;
+        if (mn < M) {
+            cd_n = coords[mn]; np_n = num_points[mn];
+            pt_n = (l < P) ? voxels[(size_t)mn * P + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         // mean over the COUNT of the sum over all P rows (pillar_vfe.py:118-121)
         const float fn = (float)np;
         const float mx = wave_sum(pt.x) / fn;
@@ -98,8 +113,14 @@ __global__ __launch_bounds__(256) void k_pfn(const float4* __restrict__ voxels, 
     }
 }
 
+using vf4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void st_nt(float4* p, float4 v) {
+    vf4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(p));
+}
+
 // canvas[b][c][cell] = cell_map[b][cell] >= 0 ? pillar_feat[id][c] : 0, 4 cells per thread
-template <int CG /*channels per block*/>
+template <int CG /*channels per block*/, bool NT>
 __global__ __launch_bounds__(256) void k_canvas(const int4* __restrict__ cell_map4,
                                                const float* __restrict__ pillar_feat, int cells4,
                                                int channels, float4* __restrict__ canvas4) {
@@ -112,7 +133,10 @@ __global__ __launch_bounds__(256) void k_canvas(const int4* __restrict__ cell_ma
     if ((id.x & id.y & id.z & id.w) < 0) {  // all four empty (ids are -1)
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < CG; ++c) out[(size_t)c * cells4] = z;
+        for (int c = 0; c < CG; ++c) {
+            if (NT) st_nt(&out[(size_t)c * cells4], z);
+            else out[(size_t)c * cells4] = z;
+        }
         return;
     }
 #pragma unroll 4
@@ -122,7 +146,8 @@ __global__ __launch_bounds__(256) void k_canvas(const int4* __restrict__ cell_ma
         v.y = id.y >= 0 ? pillar_feat[(size_t)id.y * channels + c0 + c] : 0.f;
         v.z = id.z >= 0 ? pillar_feat[(size_t)id.z * channels + c0 + c] : 0.f;
         v.w = id.w >= 0 ? pillar_feat[(size_t)id.w * channels + c0 + c] : 0.f;
-        out[(size_t)c * cells4] = v;
+        if (NT) st_nt(&out[(size_t)c * cells4], v);
+        else out[(size_t)c * cells4] = v;
     }
 }
 
@@ -136,8 +161,13 @@ int heal_canvas_from_map(const int* cell_map, const float* rows, int n_agents, i
     HEAL_REQUIRE(cells % 4 == 0 && channels % 16 == 0, "canvas: cells %% 4 and channels %% 16 required");
     const int cells4 = cells / 4;
     dim3 grid(ceil_div(cells4, 256), channels / 16, n_agents);
-    k_canvas<16><<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), rows, cells4, channels,
-                                      reinterpret_cast<float4*>(canvas));
+    static const int nt = []() { const char* e = getenv("HEAL_CANVAS_NT"); return e ? atoi(e) : 0; }();
+    if (nt)
+        k_canvas<16, true><<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), rows, cells4, channels,
+                                                reinterpret_cast<float4*>(canvas));
+    else
+        k_canvas<16, false><<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), rows, cells4, channels,
+                                                 reinterpret_cast<float4*>(canvas));
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -170,7 +200,8 @@ extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, cons
     HEAL_HIP(hipMemsetAsync(cell_map, 0xFF, (size_t)n_agents * ny * nx * sizeof(int), s));
     if (n_voxels > 0) {
         PfnGeom g{vx, vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx};
-        const int blocks = min(ceil_div(n_voxels, 4), 256 * 8);
+        // ~4 pillars per wave (software-prefetched): fewer, longer-lived waves than one per pillar
+        const int blocks = min(ceil_div(n_voxels, 16), 256 * 8);
         const float4* v4 = reinterpret_cast<const float4*>(voxels);
         const int4* c4 = reinterpret_cast<const int4*>(coords);
         k_pfn<<<blocks, 256, 0, s>>>(v4, max_points, c4, num_points, n_voxels, n_voxels_dev, weight,

@@ -126,6 +126,9 @@ __device__ __forceinline__ void agent_softmax(float* s, int n) {
 }
 
 // ---- fused: warp all agents + softmax + weighted sum -------------------------------------------
+// Per agent the four taps become (offset, weight) pairs with the softmax probability and the
+// "inside the image" test folded into the weight (outside taps: weight 0, offset clamped to 0), so the
+// channel loop is branch-free: 4 channels x n_agents x 4 taps independent loads are in flight per thread.
 template <int CCH>
 __global__ __launch_bounds__(256) void k_warp_fuse(const float* __restrict__ feats,
                                                   const float* __restrict__ occ, WarpParams p,
@@ -134,33 +137,59 @@ __global__ __launch_bounds__(256) void k_warp_fuse(const float* __restrict__ fea
     const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
     if (w >= p.W || h >= p.H) return;
     const int HW = p.H * p.W;
-    Taps taps[WF_MAXA];
+    int off[WF_MAXA][4];
+    float wt[WF_MAXA][4];
     float prob[WF_MAXA];
 #pragma unroll
     for (int a = 0; a < WF_MAXA; ++a) {
         prob[a] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { off[a][k] = 0; wt[a][k] = 0.f; }
         if (a < p.n_agents) {
             float gx, gy;
             if (p.grid_f64) grid_point<double>(p.m[a], h, w, p.H, p.W, gx, gy);
             else grid_point<float>(p.m[a], h, w, p.H, p.W, gx, gy);
-            taps[a] = make_taps(gx, gy, p.H, p.W);
-            prob[a] = sample_score(occ + (size_t)a * HW, taps[a], p.W, p.crop[a]);
+            const Taps t = make_taps(gx, gy, p.H, p.W);
+            prob[a] = sample_score(occ + (size_t)a * HW, t, p.W, p.crop[a]);
+            const int o4[4] = {t.off, t.off + 1, t.off + p.W, t.off + p.W + 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = (t.ok >> k) & 1u;
+                off[a][k] = ok ? o4[k] : 0;
+                wt[a][k] = ok ? t.w[k] : 0.f;
+            }
         }
     }
     agent_softmax(prob, p.n_agents);
+#pragma unroll
+    for (int a = 0; a < WF_MAXA; ++a) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wt[a][k] *= prob[a];
+    }
     const int c0 = blockIdx.z * CCH;
     const int pix = h * p.W + w;
-#pragma unroll 2
-    for (int c = c0; c < c0 + CCH && c < p.C; ++c) {
-        float acc = 0.f;
+    for (int c = c0; c < c0 + CCH && c < p.C; c += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < WF_MAXA; ++a) {
-            if (a < p.n_agents && prob[a] != 0.f) {
-                const float v = sample(feats + ((size_t)a * p.C + c) * HW, taps[a], p.W);
-                acc += v * prob[a];
+            if (a < p.n_agents) {
+                const float* base = feats + ((size_t)a * p.C + c) * HW;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c + u < p.C) {
+                        const float* src = base + (size_t)u * HW;
+                        float v = src[off[a][0]] * wt[a][0];
+                        v += src[off[a][1]] * wt[a][1];
+                        v += src[off[a][2]] * wt[a][2];
+                        v += src[off[a][3]] * wt[a][3];
+                        acc[u] += v;
+                    }
+                }
             }
         }
-        out[(size_t)c * HW + pix] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c + u < p.C) out[(size_t)(c + u) * HW + pix] = acc[u];
     }
 }
 
@@ -236,7 +265,8 @@ extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents
                               float* out, void* stream) {
     WarpParams p;
     if (fill_params(p, n_agents, channels, H, W, affine_host, grid_f64, crop_host)) return 1;
-    constexpr int CCH = 16;
+    // 8 channels per block: even the 64x64 level then launches >= 2048 blocks
+    constexpr int CCH = 8;
     dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, CCH));
     k_warp_fuse<CCH><<<grid, 256, 0, (hipStream_t)stream>>>(feats, occ, p, out);
     HEAL_LAUNCH_CHECK();
