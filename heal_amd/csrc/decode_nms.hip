@@ -272,18 +272,30 @@ __global__ __launch_bounds__(64) void k_nms_mask(NmsBufs nb, int top, int words,
     nb.mask[(size_t)i * words + bj] = bits;
 }
 
-__global__ __launch_bounds__(64) void k_nms_reduce(NmsBufs nb, int top, int words,
-                                                  float* __restrict__ out_corners,
-                                                  float* __restrict__ out_scores, int* __restrict__ out_count,
-                                                  int max_out) {
+// Greedy pass.  The suppression matrix of the top-k (<= 1024 x 16 words = 128 KB) is first copied into
+// LDS by the whole block (coalesced), then wave 0 walks it: per 64-row block the diagonal tile is resolved
+// serially with lane reads, and the surviving rows are OR-ed into the removed set with 64 independent,
+// predicated LDS reads (no data-dependent trip count).
+__global__ __launch_bounds__(256) void k_nms_reduce(NmsBufs nb, int top, int words,
+                                                   float* __restrict__ out_corners,
+                                                   float* __restrict__ out_scores, int* __restrict__ out_count,
+                                                   int max_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long smask[];  // [K][W]
     __shared__ unsigned long long keep_bits[64];
-    const int l = threadIdx.x;
     const int K = min(*nb.n_cand, top);
     const int W = (K + 63) / 64;
+    // upper-triangular tiles only were written (k_nms_mask): copy those, zero the rest
+    for (int e = threadIdx.x; e < K * W; e += 256) {
+        const int r = e / W, c = e - r * W;
+        smask[e] = (c >= r / 64) ? nb.mask[(size_t)r * words + c] : 0ull;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int l = threadIdx.x;
     unsigned long long removed = 0ull;  // lane l holds word l of the removed set
     for (int blk = 0; blk < W; ++blk) {
         const int r = blk * 64 + l;
-        const unsigned long long diag = (r < K) ? nb.mask[(size_t)r * words + blk] : 0ull;
+        const unsigned long long diag = (r < K) ? smask[(size_t)r * W + blk] : 0ull;
         unsigned long long rem = __shfl(removed, blk, 64);
         unsigned long long alive = 0ull;
         const int cnt = min(64, K - blk * 64);
@@ -295,15 +307,17 @@ __global__ __launch_bounds__(64) void k_nms_reduce(NmsBufs nb, int top, int word
             }
         }
         if (l == 0) keep_bits[blk] = alive;
-        // OR the surviving rows into the removed words of the blocks still to come
-        unsigned long long a = alive;
-        while (a) {
-            const int i = __ffsll((long long)a) - 1;
-            a &= a - 1;
-            if (l > blk && l < W) removed |= nb.mask[(size_t)(blk * 64 + i) * words + l];
+        if (l > blk && l < W) {
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) {
+                const int rr = blk * 64 + i;
+                const unsigned long long m = (rr < K) ? smask[(size_t)rr * W + l] : 0ull;
+                removed |= ((alive >> i) & 1ull) ? m : 0ull;
+            }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     // ordered compaction: kept (pick order) and inside gt_range
     int base = 0;
     for (int blk = 0; blk < W; ++blk) {
@@ -370,7 +384,7 @@ extern "C" int heal_decode_nms(const float* cls, const float* reg, const float* 
                                int32_t* out_count, int max_out, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(H >= 1 && W >= 1 && anchor_num >= 1, "decode_nms: bad shape");
-    HEAL_REQUIRE(nms_top >= 1 && nms_top <= 4096, "decode_nms: nms_top must be in [1,4096]");
+    HEAL_REQUIRE(nms_top >= 1 && nms_top <= 1088, "decode_nms: nms_top must be in [1,1088]");
     HEAL_REQUIRE(dir == nullptr || num_bins >= 1, "decode_nms: num_bins must be >= 1");
     HEAL_REQUIRE(max_out >= 1, "decode_nms: max_out must be >= 1");
     HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "decode_nms: workspace must be 256-B aligned");
@@ -404,7 +418,15 @@ extern "C" int heal_decode_nms(const float* cls, const float* reg, const float* 
     const int words = ceil_div(nms_top, 64);
     k_nms_prepare<<<ceil_div(nms_top, 64), 64, 0, s>>>(cls, reg, dir, anchors, p, n, w.vals[res], nms_top, w.nb);
     k_nms_mask<<<dim3(words, words), 64, 0, s>>>(w.nb, nms_top, words, nms_thr);
-    k_nms_reduce<<<1, 64, 0, s>>>(w.nb, nms_top, words, out_corners, out_scores, out_count, max_out);
+    const size_t reduce_lds = (size_t)words * 64 * words * sizeof(unsigned long long);
+    HEAL_REQUIRE(reduce_lds <= 150 * 1024, "decode_nms: nms_top=%d needs %zu B of LDS (limit 150 KB; use <= 1088)",
+                 nms_top, reduce_lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HEAL_HIP(hipFuncSetAttribute((const void*)k_nms_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    k_nms_reduce<<<1, 256, reduce_lds, s>>>(w.nb, nms_top, words, out_corners, out_scores, out_count, max_out);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -129,9 +129,8 @@ __device__ __forceinline__ void agent_softmax(float* s, int n) {
 // Per agent the four taps become (offset, weight) pairs with the softmax probability and the
 // "inside the image" test folded into the weight (outside taps: weight 0, offset clamped to 0), so the
 // channel loop is branch-free: 4 channels x n_agents x 4 taps independent loads are in flight per thread.
-template <int CCH>
-__global__ __launch_bounds__(256) void k_warp_fuse(const float* __restrict__ feats,
-                                                  const float* __restrict__ occ, WarpParams p,
+__global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ feats,
+                                                     const float* __restrict__ occ, WarpParams p, int CCH,
                                                   float* __restrict__ out) {
     const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
     const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
@@ -168,14 +167,15 @@ __global__ __launch_bounds__(256) void k_warp_fuse(const float* __restrict__ fea
     }
     const int c0 = blockIdx.z * CCH;
     const int pix = h * p.W + w;
-    for (int c = c0; c < c0 + CCH && c < p.C; c += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 2;  // channels in flight per thread (register budget: 4 waves per SIMD)
+    for (int c = c0; c < c0 + CCH && c < p.C; c += U) {
+        float acc[U] = {0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < WF_MAXA; ++a) {
             if (a < p.n_agents) {
                 const float* base = feats + ((size_t)a * p.C + c) * HW;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     if (c + u < p.C) {
                         const float* src = base + (size_t)u * HW;
                         float v = src[off[a][0]] * wt[a][0];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_warp_fuse(const float* __restrict__ fea
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u)
             if (c + u < p.C) out[(size_t)(c + u) * HW + pix] = acc[u];
     }
 }
@@ -265,10 +265,15 @@ extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents
                               float* out, void* stream) {
     WarpParams p;
     if (fill_params(p, n_agents, channels, H, W, affine_host, grid_f64, crop_host)) return 1;
-    // 8 channels per block: even the 64x64 level then launches >= 2048 blocks
-    constexpr int CCH = 8;
-    dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, CCH));
-    k_warp_fuse<CCH><<<grid, 256, 0, (hipStream_t)stream>>>(feats, occ, p, out);
+    // channels per block: the per-pixel prologue (grid, taps, scores, softmax) is recomputed by every
+    // channel block, so use as few channel blocks as still give ~1024 workgroups
+    const int tiles = ceil_div(W, WF_TW) * ceil_div(H, WF_TH);
+    int cch = (int)(((long long)channels * tiles + 1023) / 1024);
+    cch = (cch + 3) / 4 * 4;
+    if (cch < 4) cch = 4;
+    if (cch > channels) cch = (channels + 3) / 4 * 4;
+    dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, cch));
+    k_warp_fuse<<<grid, 256, 0, (hipStream_t)stream>>>(feats, occ, p, cch, out);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
