@@ -40,26 +40,41 @@ struct CamMats {          // 27 floats per (agent, cam), see heal_amd.h
     float pad[3];
 };
 
+// 64 pixels x 4 depth groups per block: the depth softmax is reduced across the 4 groups through LDS, so
+// the (small) pixel count of a camera rig still fills the chip and every logit is read by one thread only.
 __global__ __launch_bounds__(256) void k_lss_keys(const float* __restrict__ depth_logit,
                                                  const float* __restrict__ frustum,
                                                  const CamMats* __restrict__ cams, LssGeom g,
                                                  uint32_t invalid_key, uint32_t* __restrict__ keys,
                                                  uint32_t* __restrict__ vals, float* __restrict__ probs) {
+    constexpr int DG = 4;
+    __shared__ float red[DG][64];
     const int HW = g.fH * g.fW;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int px = threadIdx.x & 63, dg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + px;
     const int total = g.n_agents * g.n_cams * HW;
-    if (t >= total) return;
-    const int bn = t / HW, pix = t - bn * HW;
+    const bool live = t < total;
+    const int bn = live ? t / HW : 0, pix = live ? t - bn * HW : 0;
     const int b = bn / g.n_cams;
+    const int dper = (g.D + DG - 1) / DG;
+    const int d0 = dg * dper, d1 = min(d0 + dper, g.D);
     const float* lg = depth_logit + (size_t)bn * g.D * HW + pix;
     // softmax over depth (lss_submodule.py:130): max, exp, normalise
     float mx = -INFINITY;
-    for (int d = 0; d < g.D; ++d) mx = fmaxf(mx, lg[(size_t)d * HW]);
-    float den = 0.f;
-    for (int d = 0; d < g.D; ++d) den += expf(lg[(size_t)d * HW] - mx);
+    if (live) for (int d = d0; d < d1; ++d) mx = fmaxf(mx, lg[(size_t)d * HW]);
+    red[dg][px] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][px], red[1][px]), fmaxf(red[2][px], red[3][px]));
+    __syncthreads();
+    float part = 0.f;
+    if (live) for (int d = d0; d < d1; ++d) part += expf(lg[(size_t)d * HW] - mx);
+    red[dg][px] = part;
+    __syncthreads();
+    const float den = ((red[0][px] + red[1][px]) + red[2][px]) + red[3][px];
+    if (!live) return;
     const CamMats cm = cams[bn];
     const int cells_per_agent = g.nx[0] * g.nx[1] * g.nx[2];
-    for (int d = 0; d < g.D; ++d) {
+    for (int d = d0; d < d1; ++d) {
         const size_t idx = ((size_t)bn * g.D + d) * HW + pix;
         probs[idx] = expf(lg[(size_t)d * HW] - mx) / den;
         // get_geometry: undo post transform, lift by depth, camera -> ego
@@ -120,88 +135,149 @@ __global__ __launch_bounds__(256) void k_lss_transpose(const float* __restrict__
     }
 }
 
+// Segmented reduction over the sorted point list, balanced by construction: a wave owns a TILE of 128
+// consecutive sorted points, whatever cells they belong to (a near-range cell can hold thousands of
+// points, a far one a handful -- one wave per cell left most of the chip idle behind a few huge cells).
+// Runs (points of one cell) that lie entirely inside the tile are finished here; a run that crosses a
+// tile boundary leaves a partial row (slot 0: the run began in an earlier tile, slot 1: it begins here and
+// continues), and k_lss_combine adds the partials of such a cell in tile order.  Additions happen in a fixed
+// order, so the result is deterministic.
+constexpr int LSS_TILE = 128;
+
 template <int CPL /*channels per lane*/>
-__global__ __launch_bounds__(256) void k_lss_reduce(const uint32_t* __restrict__ svals,
-                                                   const int* __restrict__ seg_start,
-                                                   const int* __restrict__ seg_end,
-                                                   const float* __restrict__ probs,
-                                                   const float* __restrict__ featT, LssGeom g, int n_cells,
-                                                   int* __restrict__ row_counter, float* __restrict__ rows,
-                                                   int* __restrict__ cell_map) {
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= n_cells) return;
+__global__ __launch_bounds__(256) void k_lss_reduce_tiles(const uint32_t* __restrict__ skeys,
+                                                         const uint32_t* __restrict__ svals,
+                                                         const int* __restrict__ seg_start,
+                                                         const int* __restrict__ seg_end,
+                                                         const float* __restrict__ probs,
+                                                         const float* __restrict__ featT, LssGeom g, int np,
+                                                         uint32_t invalid_key, int* __restrict__ row_counter,
+                                                         float* __restrict__ rows, int* __restrict__ cell_map,
+                                                         float* __restrict__ partial /*[ntiles][2][C]*/) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int t_begin = tile * LSS_TILE;
+    if (t_begin >= np) return;
+    const int t_end = min(t_begin + LSS_TILE, np);
     const int l = threadIdx.x & 63;
-    const int lo = seg_start[cell], hi = seg_end[cell];
-    if (hi <= lo) {
-        if (l == 0) cell_map[cell] = -1;
-        return;
-    }
     const int HW = g.fH * g.fW, DHW = g.D * HW;
     float acc[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
-    // 64 points at a time: lane j fetches point j's index, probability and feature-row offset (coalesced /
-    // independent), then the rows are streamed 4 at a time so that several 512 B row reads are in flight.
-    // The additions stay in point order, so the sum is deterministic.
-    for (int base = lo; base < hi; base += 64) {
-        const int cnt = min(64, hi - base);
-        float my_p = 0.f;
-        int my_off = 0;
-        if (l < cnt) {
-            const uint32_t idx = svals[base + l];
-            const int bn = idx / DHW;
-            const int pix = (idx - bn * DHW) % HW;
-            my_p = probs[idx];
-            my_off = (bn * HW + pix) * g.C;
-        }
-        int j = 0;
-        for (; j + 4 <= cnt; j += 4) {
-            float p[4];
-            const float* f[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                p[u] = __shfl(my_p, j + u, 64);
-                f[u] = featT + __shfl(my_off, j + u, 64);
-            }
-            float v[4][CPL];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int c = l + 64 * k;
-                    v[u][k] = c < g.C ? f[u][c] : 0.f;
-                }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) acc[k] += p[u] * v[u][k];
-        }
-        for (; j < cnt; ++j) {
-            const float p = __shfl(my_p, j, 64);
-            const float* f = featT + __shfl(my_off, j, 64);
+    uint32_t cur = invalid_key;  // no open run
+
+    auto flush = [&](uint32_t cell) {
+        const int s = seg_start[cell], e = seg_end[cell];
+        if (s >= t_begin && e <= t_end) {  // run complete inside this tile
+            int row = 0;
+            if (l == 0) { row = atomicAdd(row_counter, 1); cell_map[cell] = row; }
+            row = __shfl(row, 0, 64);
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const int c = l + 64 * k;
-                if (c < g.C) acc[k] += p * f[c];
+                if (c < g.C) rows[(size_t)row * g.C + c] = acc[k];
+            }
+        } else {
+            const int slot = (s < t_begin) ? 0 : 1;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c = l + 64 * k;
+                if (c < g.C) partial[((size_t)tile * 2 + slot) * g.C + c] = acc[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
+    };
+
+    for (int base = t_begin; base < t_end; base += 64) {
+        const int cnt = min(64, t_end - base);
+        uint32_t my_key = invalid_key;
+        float my_p = 0.f;
+        int my_off = 0;
+        if (l < cnt) {
+            my_key = skeys[base + l];
+            if (my_key < invalid_key) {
+                const uint32_t idx = svals[base + l];
+                const int bn = idx / DHW;
+                const int pix = (idx - bn * DHW) % HW;
+                my_p = probs[idx];
+                my_off = (bn * HW + pix) * g.C;
+            }
+        }
+        for (int j = 0; j < cnt; j += 4) {
+            uint32_t key[4];
+            float p[4];
+            float v[4][CPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = min(j + u, cnt - 1);
+                key[u] = (j + u < cnt) ? __shfl(my_key, jj, 64) : invalid_key;
+                p[u] = __shfl(my_p, jj, 64);
+                const float* f = featT + __shfl(my_off, jj, 64);
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = l + 64 * k;
+                    v[u][k] = (c < g.C && key[u] < invalid_key) ? f[c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (key[u] >= invalid_key) continue;  // dropped points sort last: nothing valid follows
+                if (key[u] != cur) {
+                    if (cur != invalid_key) flush(cur);
+                    cur = key[u];
+                }
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) acc[k] += p[u] * v[u][k];
             }
         }
     }
-    int row = 0;
-    if (l == 0) {
-        row = atomicAdd(row_counter, 1);
-        cell_map[cell] = row;
+    if (cur != invalid_key) flush(cur);
+}
+
+// One wave per BEV cell: empty -> map = -1; a cell whose points span several tiles -> add its partial rows
+// in tile order; cells finished inside one tile were already written by k_lss_reduce_tiles.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_lss_combine(const int* __restrict__ seg_start,
+                                                    const int* __restrict__ seg_end,
+                                                    const float* __restrict__ partial, int C, int n_cells,
+                                                    int* __restrict__ row_counter, float* __restrict__ rows,
+                                                    int* __restrict__ cell_map) {
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const int l = threadIdx.x & 63;
+    const int s = seg_start[cell], e = seg_end[cell];
+    if (e <= s) {
+        if (l == 0) cell_map[cell] = -1;
+        return;
     }
+    const int t0 = s / LSS_TILE, t1 = (e - 1) / LSS_TILE;
+    if (t0 == t1) return;
+    float acc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = l + 64 * k;
+        acc[k] = c < C ? partial[((size_t)t0 * 2 + 1) * C + c] : 0.f;
+    }
+    for (int t = t0 + 1; t <= t1; ++t) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = l + 64 * k;
+            if (c < C) acc[k] += partial[((size_t)t * 2 + 0) * C + c];
+        }
+    }
+    int row = 0;
+    if (l == 0) { row = atomicAdd(row_counter, 1); cell_map[cell] = row; }
     row = __shfl(row, 0, 64);
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int c = l + 64 * k;
-        if (c < g.C) rows[(size_t)row * g.C + c] = acc[k];
+        if (c < C) rows[(size_t)row * C + c] = acc[k];
     }
 }
 
 struct LssWs {
     uint32_t *keys[2], *vals[2];
-    float *probs, *featT, *rows;
+    float *probs, *featT, *rows, *partial;
     int *seg_start, *seg_end, *cell_map, *row_counter, *scratch;
 };
 
@@ -212,6 +288,7 @@ static bool carve(Arena& a, int n_agents, int n_cams, int D, int HW, int C, int 
     w.featT = a.take<float>((size_t)n_agents * n_cams * HW * C);
     const size_t max_rows = (size_t)cells_total < np ? (size_t)cells_total : np;
     w.rows = a.take<float>((max_rows + 1) * C);
+    w.partial = a.take<float>((size_t)(np / LSS_TILE + 2) * 2 * C);
     // seg_start | seg_end contiguous: one memset clears both
     w.seg_start = a.take<int>(cells_total);
     w.seg_end = a.take<int>(cells_total);
@@ -265,7 +342,7 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     HEAL_HIP(hipMemsetAsync(w.seg_start, 0, (size_t)((char*)w.cell_map - (char*)w.seg_start), s));
     HEAL_HIP(hipMemsetAsync(w.row_counter, 0, sizeof(int), s));
     const uint32_t invalid_key = (uint32_t)cells_total;
-    k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 256), 256, 0, s>>>(
+    k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 64), 256, 0, s>>>(
         depth_logit, frustum, reinterpret_cast<const CamMats*>(cam_mats), g,
                                                                      invalid_key, w.keys[0], w.vals[0], w.probs);
     k_lss_transpose<<<dim3(ceil_div(HW, 32), ceil_div(channels, 32), n_agents * n_cams), 256, 0, s>>>(
@@ -275,16 +352,18 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     int res = 0;
     if (radix_sort_pairs(w.keys, w.vals, np, key_bits, &res, w.scratch, s)) return 1;
     k_lss_segments<<<ceil_div(np, 256), 256, 0, s>>>(w.keys[res], np, invalid_key, w.seg_start, w.seg_end);
-    const int rblocks = ceil_div(cells_total, 4);
-    if (channels <= 64)
-        k_lss_reduce<1><<<rblocks, 256, 0, s>>>(w.vals[res], w.seg_start, w.seg_end, w.probs, w.featT, g,
-                                                cells_total, w.row_counter, w.rows, w.cell_map);
-    else if (channels <= 128)
-        k_lss_reduce<2><<<rblocks, 256, 0, s>>>(w.vals[res], w.seg_start, w.seg_end, w.probs, w.featT, g,
-                                                cells_total, w.row_counter, w.rows, w.cell_map);
-    else
-        k_lss_reduce<4><<<rblocks, 256, 0, s>>>(w.vals[res], w.seg_start, w.seg_end, w.probs, w.featT, g,
-                                                cells_total, w.row_counter, w.rows, w.cell_map);
+    const int tblocks = ceil_div(ceil_div(np, LSS_TILE), 4);
+    const int cblocks = ceil_div(cells_total, 4);
+#define HEAL_LSS_REDUCE(CPL)                                                                                   \
+    k_lss_reduce_tiles<CPL><<<tblocks, 256, 0, s>>>(w.keys[res], w.vals[res], w.seg_start, w.seg_end, w.probs,  \
+                                                    w.featT, g, np, invalid_key, w.row_counter, w.rows,        \
+                                                    w.cell_map, w.partial);                                    \
+    k_lss_combine<CPL><<<cblocks, 256, 0, s>>>(w.seg_start, w.seg_end, w.partial, channels, cells_total,        \
+                                               w.row_counter, w.rows, w.cell_map)
+    if (channels <= 64) { HEAL_LSS_REDUCE(1); }
+    else if (channels <= 128) { HEAL_LSS_REDUCE(2); }
+    else { HEAL_LSS_REDUCE(4); }
+#undef HEAL_LSS_REDUCE
     HEAL_LAUNCH_CHECK();
     // out [B, C*nz, ny, nx] viewed as B*nz maps of [C, ny*nx]
     return heal_canvas_from_map(w.cell_map, w.rows, n_agents * g.nx[2], channels, g.nx[0] * g.nx[1], out, s);

@@ -129,22 +129,25 @@ __device__ __forceinline__ void agent_softmax(float* s, int n) {
 // Per agent the four taps become (offset, weight) pairs with the softmax probability and the
 // "inside the image" test folded into the weight (outside taps: weight 0, offset clamped to 0), so the
 // channel loop is branch-free: 4 channels x n_agents x 4 taps independent loads are in flight per thread.
+template <int NA>
 __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ feats,
                                                      const float* __restrict__ occ, WarpParams p, int CCH,
-                                                  float* __restrict__ out) {
+                                                     float* __restrict__ out) {
     const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
     const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
     if (w >= p.W || h >= p.H) return;
     const int HW = p.H * p.W;
-    int off[WF_MAXA][4];
-    float wt[WF_MAXA][4];
+    int off[NA][4];
+    float wt[NA][4];
     float prob[WF_MAXA];
 #pragma unroll
-    for (int a = 0; a < WF_MAXA; ++a) {
+    for (int a = NA; a < WF_MAXA; ++a) prob[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
         prob[a] = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { off[a][k] = 0; wt[a][k] = 0.f; }
-        if (a < p.n_agents) {
+        {
             float gx, gy;
             if (p.grid_f64) grid_point<double>(p.m[a], h, w, p.H, p.W, gx, gy);
             else grid_point<float>(p.m[a], h, w, p.H, p.W, gx, gy);
@@ -159,20 +162,22 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
             }
         }
     }
-    agent_softmax(prob, p.n_agents);
+    agent_softmax(prob, NA);
 #pragma unroll
-    for (int a = 0; a < WF_MAXA; ++a) {
+    for (int a = 0; a < NA; ++a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) wt[a][k] *= prob[a];
     }
     const int c0 = blockIdx.z * CCH;
     const int pix = h * p.W + w;
-    constexpr int U = 2;  // channels in flight per thread (register budget: 4 waves per SIMD)
+    constexpr int U = NA <= 4 ? 4 : (NA <= 6 ? 2 : 1);  // channels in flight per thread (register budget: 4 waves per SIMD)
     for (int c = c0; c < c0 + CCH && c < p.C; c += U) {
-        float acc[U] = {0.f, 0.f};
+        float acc[U];
 #pragma unroll
-        for (int a = 0; a < WF_MAXA; ++a) {
-            if (a < p.n_agents) {
+        for (int u = 0; u < U; ++u) acc[u] = 0.f;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            {
                 const float* base = feats + ((size_t)a * p.C + c) * HW;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -273,7 +278,12 @@ extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents
     if (cch < 4) cch = 4;
     if (cch > channels) cch = (channels + 3) / 4 * 4;
     dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, cch));
-    k_warp_fuse<<<grid, 256, 0, (hipStream_t)stream>>>(feats, occ, p, cch, out);
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_agents) {
+#define HEAL_WF(N) case N: k_warp_fuse<N><<<grid, 256, 0, st>>>(feats, occ, p, cch, out); break;
+        HEAL_WF(1) HEAL_WF(2) HEAL_WF(3) HEAL_WF(4) HEAL_WF(5) HEAL_WF(6) HEAL_WF(7) HEAL_WF(8)
+#undef HEAL_WF
+    }
     HEAL_LAUNCH_CHECK();
     return 0;
 }
