@@ -136,9 +136,33 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
         self._c1, self._c2, self._c3, self._cd = _FoldCache(), _FoldCache(), _FoldCache(), _FoldCache()
+        self._fused_key = None
+        self._fused = None
+
+    def _fused_params(self):
+        """Folded weights of the three convolutions in the layout heal_resnext_bottleneck wants."""
+        from heal_amd import ops
+        w1, b1 = self._c1.get(self.conv1, self.bn1)
+        w2, b2 = self._c2.get(self.conv2, self.bn2)
+        w3, b3 = self._c3.get(self.conv3, self.bn3)
+        key = (self._c1.key, self._c2.key, self._c3.key)
+        if key != self._fused_key:
+            self._fused = (ops.mfma_a_fragments(w1.reshape(w1.shape[0], w1.shape[1])), b1, w2, b2,
+                           ops.mfma_a_fragments(w3.reshape(w3.shape[0], w3.shape[1])), b3)
+            self._fused_key = key
+        return self._fused
+
+    def _fusable(self, x):
+        c = self.conv1.in_channels
+        return (x.is_cuda and self.downsample is None and self.stride == 1 and self.conv2.groups == 32
+                and self.conv3.out_channels == c and self.conv1.out_channels == 2 * c and c in (64, 128, 256)
+                and self.conv2.dilation == (1, 1))
 
     def forward(self, x):
         _require_eval(self)
+        if self._fusable(x):
+            from heal_amd import ops
+            return ops.resnext_bottleneck(x.contiguous(), *self._fused_params())
         identity = x
         if self.downsample is not None:
             identity = ConvBN.run(x, self.downsample[0], self.downsample[1], self._cd, relu=False)

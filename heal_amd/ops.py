@@ -409,3 +409,21 @@ def bias_act_(x, bias=None, residual=None, relu=True):
         residual = _need(residual, torch.float32, "residual")
     _capi.call("heal_bias_act", _ptr(x), _ptr(bias), _ptr(residual), n, C, HW, int(bool(relu)), _stream())
     return x
+
+
+def mfma_a_fragments(wm):
+    """[M,K] matrix -> MFMA 16x16x4 A-fragment order [M/16, K/4, 64]: frag[mt][ks][lane] =
+    wm[mt*16 + (lane & 15)][ks*4 + (lane >> 4)]."""
+    M, K = wm.shape
+    return wm.reshape(M // 16, 16, K // 4, 4).permute(0, 2, 3, 1).reshape(M // 16, K // 4, 64).contiguous()
+
+
+def resnext_bottleneck(x, w1_frag, b1, w2, b2, w3_frag, b3):
+    """Fused stride-1 ResNeXt bottleneck (K7b).  x [n,C,H,W] -> y [n,C,H,W]."""
+    x = _need(x, torch.float32, "x")
+    n, C, H, W = (int(v) for v in x.shape)
+    y = torch.empty_like(x)
+    with _Timed(f"resnext_bottleneck_c{C}"):
+        _capi.call("heal_resnext_bottleneck", _ptr(x), _ptr(w1_frag), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3_frag),
+                   _ptr(b3), n, C, H, W, _ptr(y), _stream())
+    return y

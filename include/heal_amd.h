@@ -211,6 +211,16 @@ int heal_grouped_conv3x3(const float* x, const float* weight, const float* bias,
 int heal_bias_act(float* x, const float* bias, const float* residual, int n, int channels, int HW, int relu,
                   void* stream);
 
+/* heal_resnext_bottleneck: one fused kernel for a stride-1 ResNeXt bottleneck without downsample
+ *   (opencood/models/sub_modules/resblock.py:100-122; 32 groups, width = 2*C, expansion 1):
+ *   y = relu(conv3(relu(gconv2(relu(conv1(x)+b1))+b2))+b3+x), BatchNorms folded by the caller.
+ *   x,y [n,C,H,W] (C = 64|128|256); w2 [2C, 2C/32, 3, 3]; b1,b2 [2C]; b3 [C];
+ *   w1_frag / w3_frag: the 1x1 weights W1 [2C,C], W3 [C,2C] re-laid in MFMA A-fragment order
+ *   frag[mt][ks][lane] = Wm[mt*16 + (lane & 15)][ks*4 + (lane >> 4)].                                */
+int heal_resnext_bottleneck(const float* x, const float* w1_frag, const float* b1, const float* w2,
+                            const float* b2, const float* w3_frag, const float* b3, int n, int channels, int H,
+                            int W, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

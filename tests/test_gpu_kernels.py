@@ -445,3 +445,22 @@ def test_bias_act_vs_torch():
         ref = x + (bias.view(1, -1, 1, 1) if bias is not None else 0) + (res if res is not None else 0)
         ref = torch.relu(ref) if relu else ref
         np.testing.assert_array_equal(y.cpu().numpy(), ref.cpu().numpy())
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 32, 48), (128, 24, 24), (256, 16, 16), (64, 13, 21), (256, 7, 10), (128, 9, 8)])
+def test_fused_resnext_bottleneck_vs_torch(C, H, W):
+    """K7b against the block it fuses, evaluated in fp64 by torch (resblock.py:100-122 with folded BN)."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn((2, C, H, W), generator=g).cuda()
+    w1 = (torch.randn((2 * C, C), generator=g) / C ** 0.5).cuda(); b1 = (torch.randn((2 * C,), generator=g) * 0.1).cuda()
+    w2 = (torch.randn((2 * C, 2 * C // 32, 3, 3), generator=g) / (9 * 2 * C / 32) ** 0.5).cuda()
+    b2 = (torch.randn((2 * C,), generator=g) * 0.1).cuda()
+    w3 = (torch.randn((C, 2 * C), generator=g) / (2 * C) ** 0.5).cuda(); b3 = (torch.randn((C,), generator=g) * 0.1).cuda()
+    got = ops.resnext_bottleneck(x, ops.mfma_a_fragments(w1), b1, w2, b2, ops.mfma_a_fragments(w3), b3)
+    F = torch.nn.functional
+    xd = x.double()
+    t = torch.relu(F.conv2d(xd, w1.double().view(2 * C, C, 1, 1), b1.double()))
+    t = torch.relu(F.conv2d(t, w2.double(), b2.double(), 1, 1, 1, 32))
+    ref = torch.relu(F.conv2d(t, w3.double().view(C, 2 * C, 1, 1), b3.double()) + xd).float()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-5)
