@@ -113,29 +113,33 @@ __global__ __launch_bounds__(256) void k_bottleneck(const float* __restrict__ x,
         }
         __syncthreads();
         // ---- phase 2: grouped 3x3 over the chunk's 64 channels -> t2[64][P0] ------------------------------
-        for (int item = threadIdx.x; item < (C::WC / C::COB) * C::P0; item += 256) {
-            const int ob = item / C::P0, p = item - ob * C::P0;
-            const int py = p / TW, px = p - py * TW;
+        // output-channel blocks are dealt to waves (wave-uniform -> the 3x3 weights come through scalar
+        // loads), lanes run over the tile's pixels
+        for (int obi = wave; obi < C::WC / C::COB; obi += 4) {
+            const int ob = __builtin_amdgcn_readfirstlane(obi);
             const int co0 = ob * C::COB;                 // first output channel (within the chunk)
             const int g0 = (co0 / C::CG) * C::CG;        // first channel of its group (within the chunk)
             const int wch = chunk * C::WC + co0;         // global width channel of co0
-            float acc[C::COB];
+            const float* __restrict__ wblk = w2 + (size_t)wch * C::CG * 9;
+            for (int p = l; p < C::P0; p += 64) {
+                const int py = p / TW, px = p - py * TW;
+                float acc[C::COB];
 #pragma unroll
-            for (int co = 0; co < C::COB; ++co) acc[co] = b2[wch + co];
+                for (int co = 0; co < C::COB; ++co) acc[co] = b2[wch + co];
 #pragma unroll
-            for (int ci = 0; ci < C::CG; ++ci) {
-                float v[9];
+                for (int ci = 0; ci < C::CG; ++ci) {
+                    float v[9];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) v[k] = st1[(g0 + ci) * C::XROW + (py + k / 3) * C::PW + px + k % 3];
+                    for (int k = 0; k < 9; ++k) v[k] = st1[(g0 + ci) * C::XROW + (py + k / 3) * C::PW + px + k % 3];
 #pragma unroll
-                for (int co = 0; co < C::COB; ++co) {
-                    const float* wk = w2 + ((size_t)(wch + co) * C::CG + ci) * 9;
+                    for (int co = 0; co < C::COB; ++co) {
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) acc[co] = fmaf(v[k], wk[k], acc[co]);
+                        for (int k = 0; k < 9; ++k) acc[co] = fmaf(v[k], wblk[(co * C::CG + ci) * 9 + k], acc[co]);
+                    }
                 }
-            }
 #pragma unroll
-            for (int co = 0; co < C::COB; ++co) st2[(co0 + co) * C::T2ROW + p] = fmaxf(acc[co], 0.f);
+                for (int co = 0; co < C::COB; ++co) st2[(co0 + co) * C::T2ROW + p] = fmaxf(acc[co], 0.f);
+            }
         }
         __syncthreads();
         // ---- phase 3: acc3 += W3[:, chunk] x t2 --------------------------------------------------------------
