@@ -153,6 +153,11 @@ class Bottleneck(nn.Module):
         return self._fused
 
     def _fusable(self, x):
+        # The fused kernel (heal_resnext_bottleneck) is correct but, at one workgroup per CU, still slower
+        # than the un-fused sequence ("K7b"): opt-in until it wins.
+        import os
+        if os.environ.get("HEAL_FUSED_BOTTLENECK", "0") != "1":
+            return False
         c = self.conv1.in_channels
         return (x.is_cuda and self.downsample is None and self.stride == 1 and self.conv2.groups == 32
                 and self.conv3.out_channels == c and self.conv1.out_channels == 2 * c and c in (64, 128, 256)
