@@ -143,6 +143,8 @@ class ScenePipeline:
                                   dir_args["num_bins"], self.post.params["nms_thresh"],
                                   np.eye(4, dtype=np.float32), self.post.params["gt_range"], sync=False)
 
+        # warm up on the SAME stream the capture will use: MIOpen keeps its solver choices per handle
+        # (= per stream), and a first convolution on a fresh stream triggers a minute-long search
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -151,7 +153,7 @@ class ScenePipeline:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=side):
             self._static_out = body()
         self._graph = graph
         return graph
