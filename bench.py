@@ -118,6 +118,10 @@ def main():
     from heal_amd.dist import ShardedCollab, owned_agents
     from heal_amd.pipeline import Scene, ScenePipeline
 
+    # everything runs on one non-default stream, so that an optional HIP-graph capture of the step reuses the
+    # stream (and MIOpen state) of the eager warm-up
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
     mods, desc = WORKLOADS[a.workload]
     n_agents = len(mods)
     lidar_only = all(m == "m1" for m in mods)

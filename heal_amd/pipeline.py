@@ -143,17 +143,17 @@ class ScenePipeline:
                                   dir_args["num_bins"], self.post.params["nms_thresh"],
                                   np.eye(4, dtype=np.float32), self.post.params["gt_range"], sync=False)
 
-        # warm up on the SAME stream the capture will use: MIOpen keeps its solver choices per handle
-        # (= per stream), and a first convolution on a fresh stream triggers a minute-long search
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                body()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
+        # Capture on the stream the caller already runs on (it must be a non-default stream): MIOpen keeps
+        # its solver choices per stream, and the first convolutions on a fresh stream trigger a search that
+        # takes minutes for the ~100 convolution shapes of the heterogeneous model.
+        cur = torch.cuda.current_stream(self.device)
+        if cur == torch.cuda.default_stream(self.device):
+            raise RuntimeError("capture() must be called under a non-default stream (torch.cuda.stream(s))")
+        for _ in range(warmup):
+            body()
+        cur.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        with torch.cuda.graph(graph, stream=cur):
             self._static_out = body()
         self._graph = graph
         return graph
