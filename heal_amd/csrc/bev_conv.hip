@@ -85,9 +85,39 @@ __global__ __launch_bounds__(256) void k_bias_act(float4* __restrict__ x, const 
     }
 }
 
+// x2 bilinear up-sampling with align_corners=True (nn.Upsample in the Lift-Splat `Up` block,
+// lss_submodule.py:21-22), same operation order as ATen's upsample_bilinear2d: src = dst*(in-1)/(out-1),
+// out = h0*(w0*a + w1*b) + h1*(w0*c + w1*d).
+__global__ __launch_bounds__(256) void k_upsample2x(const float* __restrict__ x, int H, int W, long long total,
+                                                   float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int Wo = 2 * W, Ho = 2 * H;
+    const int ox = (int)(i % Wo);
+    const int oy = (int)((i / Wo) % Ho);
+    const long long nc = i / ((long long)Wo * Ho);
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float fy = sh * (float)oy, fx = sw * (float)ox;
+    const int y1 = (int)fy, x1 = (int)fx;
+    const int yp = y1 < H - 1 ? 1 : 0, xp = x1 < W - 1 ? 1 : 0;
+    const float ly = fy - (float)y1, lx = fx - (float)x1;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = x + nc * (long long)H * W + (long long)y1 * W + x1;
+    y[i] = hy * (hx * p[0] + lx * p[xp]) + ly * (hx * p[yp * W] + lx * p[yp * W + xp]);
+}
+
 }  // namespace heal
 
 using namespace heal;
+
+extern "C" int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream) {
+    const long long total = (long long)n * channels * (2 * H) * (2 * W);
+    if (total <= 0) return 0;
+    k_upsample2x<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, H, W, total, y);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int heal_grouped_conv3x3(const float* x, const float* weight, const float* bias, int n, int channels,
                                     int groups, int H, int W, int stride, int relu, float* y, void* stream) {

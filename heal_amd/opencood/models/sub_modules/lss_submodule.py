@@ -33,7 +33,9 @@ class Up(nn.Module):
 
     def forward(self, x1, x2):
         _require_eval(self)
-        x = torch.cat([x2, self.up(x1)], dim=1)
+        from heal_amd import ops
+        up = ops.upsample2x_bilinear(x1) if (x1.is_cuda and self.up.scale_factor == 2) else self.up(x1)
+        x = torch.cat([x2, up], dim=1)
         x = ConvBN.run(x, self.conv[0], self.conv[1], self._c[0], relu=True)
         return ConvBN.run(x, self.conv[3], self.conv[4], self._c[1], relu=True)
 

@@ -427,3 +427,12 @@ def resnext_bottleneck(x, w1_frag, b1, w2, b2, w3_frag, b3):
         _capi.call("heal_resnext_bottleneck", _ptr(x), _ptr(w1_frag), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3_frag),
                    _ptr(b3), n, C, H, W, _ptr(y), _stream())
     return y
+
+
+def upsample2x_bilinear(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True).  x [n,C,H,W] -> [n,C,2H,2W]."""
+    x = _need(x, torch.float32, "x")
+    n, C, H, W = (int(v) for v in x.shape)
+    y = torch.empty((n, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    _capi.call("heal_upsample2x_bilinear", _ptr(x), n, C, H, W, _ptr(y), _stream())
+    return y

@@ -221,6 +221,10 @@ int heal_resnext_bottleneck(const float* x, const float* w1_frag, const float* b
                             const float* b2, const float* w3_frag, const float* b3, int n, int channels, int H,
                             int W, float* y, void* stream);
 
+/* heal_upsample2x_bilinear: nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) of the
+ *   Lift-Splat `Up` block (opencood/models/sub_modules/lss_submodule.py:21-22,33); x [n,C,H,W] -> y [n,C,2H,2W] */
+int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -464,3 +464,12 @@ def test_fused_resnext_bottleneck_vs_torch(C, H, W):
     t = torch.relu(F.conv2d(t, w2.double(), b2.double(), 1, 1, 1, 32))
     ref = torch.relu(F.conv2d(t, w3.double().view(C, 2 * C, 1, 1), b3.double()) + xd).float()
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_upsample2x_bilinear_vs_torch():
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for shape in ((2, 5, 12, 16), (1, 3, 1, 7), (4, 8, 24, 32)):
+        x = torch.randn(shape, generator=g).cuda()
+        ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        np.testing.assert_allclose(ops.upsample2x_bilinear(x).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
