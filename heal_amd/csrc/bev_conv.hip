@@ -107,9 +107,62 @@ __global__ __launch_bounds__(256) void k_upsample2x(const float* __restrict__ x,
     y[i] = hy * (hx * p[0] + lx * p[xp]) + ly * (hx * p[yp * W] + lx * p[yp * W + xp]);
 }
 
+// Depthwise k x k convolution (k = 3 | 5, stride 1 | 2) with explicit top/left padding (TF-style "same"
+// padding is asymmetric), folded-BN bias and optional SiLU: the MBConv depthwise stage of the
+// EfficientNet-b0 camera trunk (lss_submodule.py:93-105 via efficientnet_pytorch's MBConvBlock).  The
+// vendor library falls back to a naive reference kernel for these shapes.
+template <int K, int STRIDE>
+__global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, int C, int H, int W, int Ho,
+                                                  int Wo, int pad_t, int pad_l, int act, float* __restrict__ y) {
+    constexpr int TW = 32, TH = 8;
+    constexpr int IW = (TW - 1) * STRIDE + K, IH = (TH - 1) * STRIDE + K;
+    __shared__ float tile[IH][IW + 1];
+    const int nc = blockIdx.z;          // n * C + c
+    const int c = nc % C;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int ix0 = ox0 * STRIDE - pad_l, iy0 = oy0 * STRIDE - pad_t;
+    const float* xin = x + (size_t)nc * H * W;
+    for (int e = threadIdx.x; e < IH * IW; e += 256) {
+        const int r = e / IW, col = e - r * IW;
+        const int iy = iy0 + r, ix = ix0 + col;
+        tile[r][col] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xin[(size_t)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox >= Wo || oy >= Ho) return;
+    const float* __restrict__ wk = w + (size_t)c * K * K;  // block-uniform -> scalar loads
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc = fmaf(tile[ty * STRIDE + ky][tx * STRIDE + kx], wk[ky * K + kx], acc);
+    if (act == 1) acc = fmaxf(acc, 0.f);
+    else if (act == 2) acc = acc / (1.f + expf(-acc));  // SiLU
+    y[(size_t)nc * Ho * Wo + (size_t)oy * Wo + ox] = acc;
+}
+
 }  // namespace heal
 
 using namespace heal;
+
+extern "C" int heal_depthwise_conv(const float* x, const float* weight, const float* bias, int n, int channels,
+                                   int H, int W, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                   int act, float* y, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n >= 1 && channels >= 1 && (long long)n * channels <= 65535, "depthwise_conv: n*channels too large");
+    dim3 grid(ceil_div(Wo, 32), ceil_div(Ho, 8), n * channels);
+#define HEAL_DW(KK, ST)                                                                                       \
+    if (ksize == KK && stride == ST) {                                                                        \
+        k_depthwise<KK, ST><<<grid, 256, 0, s>>>(x, weight, bias, channels, H, W, Ho, Wo, pad_t, pad_l, act, y); \
+        HEAL_LAUNCH_CHECK();                                                                                  \
+        return 0;                                                                                             \
+    }
+    HEAL_DW(3, 1) HEAL_DW(3, 2) HEAL_DW(5, 1) HEAL_DW(5, 2)
+#undef HEAL_DW
+    return set_error("depthwise_conv: kernel %d stride %d is not instantiated", ksize, stride);
+}
 
 extern "C" int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream) {
     const long long total = (long long)n * channels * (2 * H) * (2 * W);

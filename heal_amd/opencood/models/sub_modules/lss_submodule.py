@@ -66,6 +66,10 @@ class _SamePadConv2d(nn.Conv2d):
 
 def _conv_bn(x, conv, bn, cache, act):
     w, b = cache.get(conv, bn)
+    if (x.is_cuda and conv.groups == conv.in_channels == conv.out_channels and conv.kernel_size[0] in (3, 5)
+            and conv.stride[0] in (1, 2) and x.shape[0] * conv.in_channels <= 65535):
+        from heal_amd import ops
+        return ops.depthwise_conv(x.contiguous(), w, b, conv.stride[0], conv.same_pad, "silu" if act else "none")
     if any(conv.same_pad):
         x = F.pad(x, conv.same_pad)
     y = F.conv2d(x, w, b, conv.stride, 0, 1, conv.groups)

@@ -436,3 +436,18 @@ def upsample2x_bilinear(x):
     y = torch.empty((n, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     _capi.call("heal_upsample2x_bilinear", _ptr(x), n, C, H, W, _ptr(y), _stream())
     return y
+
+
+def depthwise_conv(x, weight, bias, stride, pad, act="none"):
+    """Depthwise k x k conv; pad = (left, right, top, bottom) zero padding; act in none|relu|silu."""
+    x = _need(x, torch.float32, "x")
+    weight = _need(weight, torch.float32, "weight")
+    n, C, H, W = (int(v) for v in x.shape)
+    k = int(weight.shape[-1])
+    pl, pr, pt, pb = (int(v) for v in pad)
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    y = torch.empty((n, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _capi.call("heal_depthwise_conv", _ptr(x), _ptr(weight), _ptr(bias), n, C, H, W, k, int(stride), pt, pl, Ho, Wo,
+               {"none": 0, "relu": 1, "silu": 2}[act], _ptr(y), _stream())
+    return y

@@ -473,3 +473,16 @@ def test_upsample2x_bilinear_vs_torch():
         x = torch.randn(shape, generator=g).cuda()
         ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
         np.testing.assert_allclose(ops.upsample2x_bilinear(x).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(3, 1, (1, 1, 1, 1)), (3, 2, (0, 1, 0, 1)), (5, 1, (2, 2, 2, 2)), (5, 2, (1, 2, 1, 2))])
+def test_depthwise_conv_vs_torch(k, stride, pad):
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    x = torch.randn((3, 48, 24, 37), generator=g).cuda()
+    w = torch.randn((48, 1, k, k), generator=g).cuda() * 0.3
+    b = torch.randn((48,), generator=g).cuda()
+    F = torch.nn.functional
+    ref = F.silu(F.conv2d(F.pad(x, pad).double(), w.double(), b.double(), stride, 0, 1, 48)).float()
+    got = ops.depthwise_conv(x, w, b, stride, pad, "silu")
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
