@@ -37,6 +37,8 @@ WORKLOADS = {
     "scene5_lidar": (["m1"] * 5, "5-agent OPV2V scene, 5x PointPillars(m1) + PyramidFusion, range +-102.4 m"),
     "pair": (["m1", "m1"], "2-agent OPV2V scene, PointPillars + PyramidFusion (BASELINE config 3)"),
     "single": (["m1"], "single-agent PointPillars through the collaborative model (BASELINE config 2)"),
+    "scene8_second_v2xvit": (["m3"] * 8, "8-agent synthetic scene, SECOND (sparse conv) encoders + plain BEV backbone + "
+                                         "V2X-ViT fusion, heter_model_baseline (BASELINE config 5)"),
 }
 
 
@@ -125,8 +127,15 @@ def main():
     mods, desc = WORKLOADS[a.workload]
     n_agents = len(mods)
     lidar_only = all(m == "m1" for m in mods)
-    hypes = configs.lidar_pyramid(max_cav=max(5, n_agents)) if lidar_only else \
-        configs.heal_heter(tuple(sorted(set(mods))), max_cav=max(5, n_agents))
+    baseline_model = a.workload == "scene8_second_v2xvit"
+    if baseline_model:
+        if world > 1:
+            raise SystemExit("the agent-sharded path is implemented for the pyramid-fusion model (scene5*, pair)")
+        hypes = configs.lidar_baseline("v2xvit", max_cav=n_agents, modality="m3")
+    elif lidar_only:
+        hypes = configs.lidar_pyramid(max_cav=max(5, n_agents))
+    else:
+        hypes = configs.heal_heter(tuple(sorted(set(mods))), max_cav=max(5, n_agents))
     pipe = ScenePipeline(hypes, dev, seed=0)
     scene = Scene(n_agents, seed=4, device=dev, modalities=mods)
     cls_shift = pipe.calibrate_cls_bias(scene)
@@ -196,8 +205,8 @@ def main():
         with torch.no_grad():
             m_per_agent = []
             for k in sorted(scene.points):
-                _, _, nn_ = ops.voxelize(scene.points[k], hypes["model"]["args"]["lidar_range"], [0.4, 0.4, 4], 32,
-                                         70000)
+                vs_, pp_ = ([0.1, 0.1, 0.1], 5) if baseline_model else ([0.4, 0.4, 4], 32)
+                _, _, nn_ = ops.voxelize(scene.points[k], hypes["model"]["args"]["lidar_range"], vs_, pp_, 70000)
                 m_per_agent.append(int(nn_.shape[0]))
         roof = None
         if "pfn_scatter" in timing:
@@ -223,7 +232,7 @@ def main():
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "op_timing_ms": kernels,
         }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not baseline_model:
             # the CPU port covers the LiDAR (PointPillars) agents; for the heterogeneous workload the
             # sample is the same scene with every agent treated as a LiDAR agent (stated in `sample`)
             lidar_hypes = hypes if lidar_only else configs.lidar_pyramid(max_cav=max(5, n_agents))

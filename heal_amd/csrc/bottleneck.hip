@@ -14,7 +14,6 @@
 //            registers across the width chunks)
 //   epilogue bias + residual (x is still in LDS) + ReLU, store.
 // Weight matrices arrive pre-arranged in MFMA A-fragment order (one coalesced 256 B load per fragment).
-#include <stdlib.h>
 #include "common.h"
 #include "../../include/heal_amd.h"
 
@@ -43,7 +42,7 @@ struct BnCfg {
     static constexpr size_t LDS_FLOATS = (size_t)CIN * XROW + (size_t)WC * XROW + (size_t)WC * T2ROW;
 };
 
-template <int CIN, int TW, int TH, int SKIP = 0>
+template <int CIN, int TW, int TH>
 __global__ __launch_bounds__(256) void k_bottleneck(const float* __restrict__ x,
                                                    const float* __restrict__ w1f, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2,
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256) void k_bottleneck(const float* __restrict__ x,
 
     for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
         // ---- phase 1: t1[chunk rows][halo pixels] = relu(W1 x + b1), wave w owns 16 of the 64 rows -------
-        if (!(SKIP & 1)) {
+        {
             const int mt = chunk * 4 + wave;  // m-tile in units of 16 width channels
             float a[C::KS1];
 #pragma unroll
@@ -116,7 +115,6 @@ __global__ __launch_bounds__(256) void k_bottleneck(const float* __restrict__ x,
         // ---- phase 2: grouped 3x3 over the chunk's 64 channels -> t2[64][P0] ------------------------------
         // output-channel blocks are dealt to waves (wave-uniform -> the 3x3 weights come through scalar
         // loads), lanes run over the tile's pixels
-        if (!(SKIP & 2))
         for (int obi = wave; obi < C::WC / C::COB; obi += 4) {
             const int ob = __builtin_amdgcn_readfirstlane(obi);
             const int co0 = ob * C::COB;                 // first output channel (within the chunk)
@@ -145,7 +143,6 @@ __global__ __launch_bounds__(256) void k_bottleneck(const float* __restrict__ x,
         }
         __syncthreads();
         // ---- phase 3: acc3 += W3[:, chunk] x t2 --------------------------------------------------------------
-        if (!(SKIP & 4))
 #pragma unroll
         for (int mi = 0; mi < C::MT3W; ++mi) {
             const int mt = wave * C::MT3W + mi;
@@ -198,16 +195,6 @@ static int launch_bottleneck(const float* x, const float* w1f, const float* b1, 
         attr_set = true;
     }
     dim3 grid(ceil_div(W, TW), ceil_div(H, TH), n);
-    static const int skip = []() { const char* e = getenv("HEAL_BN_SKIP"); return e ? atoi(e) : 0; }();
-    if (skip) {  // timing experiments only (results are wrong): bit0 phase 1, bit1 phase 2, bit2 phase 3
-        static bool a2 = false;
-#define HEAL_BN_SK(SK) case SK: if (!a2) hipFuncSetAttribute((const void*)k_bottleneck<CIN, TW, TH, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-        k_bottleneck<CIN, TW, TH, SK><<<grid, 256, lds_bytes, s>>>(x, w1f, b1, w2, b2, w3f, b3, H, W, y); break;
-        switch (skip) { HEAL_BN_SK(1) HEAL_BN_SK(2) HEAL_BN_SK(4) HEAL_BN_SK(7) HEAL_BN_SK(6) HEAL_BN_SK(3) HEAL_BN_SK(5) }
-#undef HEAL_BN_SK
-        HEAL_LAUNCH_CHECK();
-        return 0;
-    }
     k_bottleneck<CIN, TW, TH><<<grid, 256, lds_bytes, s>>>(x, w1f, b1, w2, b2, w3f, b3, H, W, y);
     HEAL_LAUNCH_CHECK();
     return 0;

@@ -58,7 +58,7 @@ class Scene:
             else:
                 self.points[k] = torch.from_numpy(synth.lidar_frame(seed * 1000 + k)).to(self.device)
         self.poses = synth.agent_poses(seed, n_agents)
-        L = max_cav or max(n_agents, 5)
+        L = max(max_cav or 5, n_agents)
         self.pairwise = synth.pairwise_t_matrix(self.poses, L)[None]  # [1,L,L,4,4] float64 (host metadata)
         self.record_len = [n_agents]
 
