@@ -70,18 +70,23 @@ def all_gather_packed(buf, world):
 
 
 class ShardedCollab:
-    """HeterPyramidCollab forward split at the fusion boundary, one scene, `world` ranks."""
+    """HeterPyramidCollab forward split at the fusion boundary, one scene, `world` ranks.
+
+    The work of a rank is three stages: `local` (encode own agents, pyramid stages, occupancy heads, warp
+    into the ego frame, pack), the all-gather, and -- on rank 0 -- `tail` (fusion, deblocks, shrink head,
+    detection heads).  `local` and `tail` contain no collective and no host round trip, so each can be
+    captured once into a HIP graph and replayed (`capture`); the collective stays an ordinary stream op
+    between the two replays."""
 
     def __init__(self, model, rank, world):
         self.model = model
         self.rank = rank
         self.world = world
+        self._g_local = self._g_tail = None
 
+    # ---- stage 1: everything a rank can do alone ---------------------------------------------------------
     @torch.no_grad()
-    def forward(self, scene_input, n_agents, local_inputs):
-        """local_inputs: {'inputs_mX': ...} for the agents this rank owns, in scene order (the
-        reference's collated layout, restricted to the local agents).  Returns the model output dict
-        on rank 0, None elsewhere."""
+    def local(self, scene_input, n_agents, local_inputs):
         from heal_amd import ops
         from heal_amd.opencood.models.fuse_modules.pyramid_fuse import crop_window
         from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
@@ -92,7 +97,7 @@ class ShardedCollab:
         mods = scene_input["agent_modality_list"]
         pb = m.pyramid_backbone
         n_slots = slots_per_rank(n_agents, self.world)
-        level_feats, level_scores, shapes = [], [], None
+        level_feats, level_scores = [], []
         if mine:
             feats = {}
             for mod in m.modality_name_list:
@@ -120,23 +125,77 @@ class ShardedCollab:
                     fe_all.append(fe); se_all.append(se)
                 level_feats.append(torch.stack(fe_all))
                 level_scores.append(torch.stack(se_all))
-            shapes = [tuple(f.shape[1:]) for f in level_feats]
-        # every rank needs the level shapes to size its (possibly empty) contribution
-        shapes = self._level_shapes() if shapes is None else shapes
-        if not mine:
+        else:
             dev = next(m.parameters()).device
+            shapes = self._level_shapes()
             level_feats = [torch.zeros((0,) + s, device=dev) for s in shapes]
             level_scores = [torch.zeros((0, 1) + s[1:], device=dev) for s in shapes]
-        buf = pack_levels(level_feats, level_scores, n_slots)
-        gathered = all_gather_packed(buf, self.world)
-        if self.rank != 0:
-            return None
+        return pack_levels(level_feats, level_scores, n_slots)
+
+    # ---- stage 3 (rank 0): fusion and the fixed tail -------------------------------------------------------
+    @torch.no_grad()
+    def tail(self, gathered, n_agents):
+        from heal_amd import ops
+        m = self.model
+        pb = m.pyramid_backbone
         fused = []
-        for feats_ego, scores_ego in unpack_levels(gathered, shapes, n_agents, self.world):
+        for feats_ego, scores_ego in unpack_levels(gathered, self._level_shapes(), n_agents, self.world):
             fused.append(ops.fuse_warped(feats_ego, scores_ego).unsqueeze(0))
         y = pb.decode_multiscale_feature(fused)
         cls_preds, reg_preds, dir_preds = m.heads(y)
         return {"pyramid": "collab", "cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
+
+    @torch.no_grad()
+    def forward(self, scene_input, n_agents, local_inputs):
+        """local_inputs: {'inputs_mX': ...} for the agents this rank owns, in scene order (the
+        reference's collated layout, restricted to the local agents).  Returns the model output dict
+        on rank 0, None elsewhere."""
+        buf = self.local(scene_input, n_agents, local_inputs)
+        gathered = all_gather_packed(buf, self.world)
+        if self.rank != 0:
+            return None
+        return self.tail(gathered, n_agents)
+
+    # ---- HIP-graph replay of the two collective-free stages -------------------------------------------------
+    @torch.no_grad()
+    def capture(self, scene_input, n_agents, local_inputs, post_fn=None, warmup=2):
+        """Capture `local` (every rank) and `tail` (+ optional post_fn(out) on rank 0) on the CURRENT
+        non-default stream.  Afterwards `replay()` runs: graph(local) -> all-gather -> graph(tail)."""
+        dev = next(self.model.parameters()).device
+        cur = torch.cuda.current_stream(dev)
+        if cur == torch.cuda.default_stream(dev):
+            raise RuntimeError("capture() must be called under a non-default stream")
+        for _ in range(warmup):
+            out = self.forward(scene_input, n_agents, local_inputs)
+            if post_fn is not None and self.rank == 0:
+                post_fn(out)
+        cur.synchronize()
+        self._g_local = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_local, stream=cur):
+            self._static_buf = self.local(scene_input, n_agents, local_inputs)
+        self._static_gathered = all_gather_packed(self._static_buf, self.world)
+        if self.world > 1:
+            # all_gather_packed allocates its output: keep ONE static output and gather into it on replay
+            self._static_gathered = self._static_gathered.clone()
+        if self.rank == 0:
+            cur.synchronize()
+            self._g_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_tail, stream=cur):
+                out = self.tail(self._static_gathered, n_agents)
+                self._static_post = post_fn(out) if post_fn is not None else out
+        self._n_agents = n_agents
+
+    def replay(self):
+        self._g_local.replay()
+        if self.world > 1:
+            n_slots, per_slot = self._static_buf.shape
+            dist.all_gather_into_tensor(self._static_gathered.view(self.world * n_slots, per_slot), self._static_buf)
+        else:
+            self._static_gathered.copy_(self._static_buf.unsqueeze(0))
+        if self.rank != 0:
+            return None
+        self._g_tail.replay()
+        return self._static_post
 
     def _level_shapes(self):
         m = self.model

@@ -39,11 +39,19 @@ def _worker(rank, world, port, mods, out_path):
     scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
     sharded = ShardedCollab(pipe.model, rank, world)
     mine = owned_agents(len(mods), rank, world)
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
     with torch.no_grad():
         out = sharded.forward(scene.model_input(), len(mods), scene.inputs_for(mine))
+        # the same through graph(local) -> all-gather -> graph(tail)
+        sharded.capture(scene.model_input(), len(mods), scene.inputs_for(mine))
+        rep = sharded.replay()
+        rep = sharded.replay()
+        torch.cuda.synchronize()
         if rank == 0:
             ref = pipe.model(scene.model_input())
-            torch.save({k: (out[k].cpu(), ref[k].cpu()) for k in ("cls_preds", "reg_preds", "dir_preds")}, out_path)
+            torch.save({k: (out[k].cpu(), ref[k].cpu(), rep[k].cpu()) for k in ("cls_preds", "reg_preds", "dir_preds")},
+                       out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,6 +62,8 @@ def test_sharded_forward_equals_single_process(tmp_path, n_agents):
     out = str(tmp_path / "o.pt")
     mp.spawn(_worker, args=(2, _free_port(), ["m1"] * n_agents, out), nprocs=2, join=True)
     res = torch.load(out)
-    for k, (got, ref) in res.items():
+    for k, (got, ref, rep) in res.items():
         err = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
         assert err < 1e-4, (k, err)
+        err = float((rep - ref).abs().max() / (ref.abs().max() + 1e-12))
+        assert err < 1e-4, ("graph replay", k, err)
