@@ -107,12 +107,19 @@ def main():
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HEAL_DIST_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box (ranks share cuda:0);
+    # the real launch is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("HEAL_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if os.environ.get("HEAL_MIOPEN_BENCHMARK", "0") == "1":
         torch.backends.cudnn.benchmark = True  # MIOpen find mode: time the applicable solvers once per shape
@@ -167,6 +174,7 @@ def main():
             if rank == 0:
                 return pipe.post.post_process(batch, {"ego": out})
             return None, None
+        eager_step = step
 
         if not a.eager:
             # graph(local stage) -> RCCL all-gather -> graph(fusion tail + decode/NMS on rank 0)
@@ -178,17 +186,13 @@ def main():
                                       pipe.post.params["target_args"]["score_threshold"], dir_args["dir_offset"],
                                       dir_args["num_bins"], pipe.post.params["nms_thresh"],
                                       np.eye(4, dtype=np.float32), pipe.post.params["gt_range"], sync=False)
-            ok = torch.ones(1, device=dev)
-            try:
-                sharded.capture(inp, n_agents, local_inputs, post_fn)
-            except Exception as e:
+            if sharded.capture(inp, n_agents, local_inputs, post_fn):
+                use_graph = True
+            elif sharded._capture_error is not None:
+                e = sharded._capture_error
                 print(f"[bench] rank {rank}: HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly",
                       file=sys.stderr)
-                ok.zero_()
-                torch.cuda.synchronize()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must take the same path
-            if float(ok.item()) > 0:
-                use_graph = True
+            if use_graph:
 
                 def step():  # noqa: F811
                     res_ = sharded.replay()
@@ -214,12 +218,15 @@ def main():
         res = step()
     fence()
     dt = time.perf_counter() - t0
-    if use_graph and world == 1:
+    if use_graph:
         # per-operator HIP-event timing needs host-side launches: an instrumented eager pass over the
         # same K steps, right after the timed graph replays (events cannot be recorded inside a graph)
         ops.TIMING = {}
         for _ in range(a.steps):
-            pipe.step(scene)
+            if world == 1:
+                pipe.step(scene)
+            else:
+                eager_step()
         torch.cuda.synchronize()
     timing = ops.timing_summary()
     ops.TIMING = None

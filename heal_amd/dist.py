@@ -157,10 +157,20 @@ class ShardedCollab:
         return self.tail(gathered, n_agents)
 
     # ---- HIP-graph replay of the two collective-free stages -------------------------------------------------
+    def _agree(self, ok, dev):
+        """True only if every rank says True (ranks must take the same path through the collectives)."""
+        if self.world == 1:
+            return ok
+        t = torch.full((1,), 1.0 if ok else 0.0, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0)
+
     @torch.no_grad()
     def capture(self, scene_input, n_agents, local_inputs, post_fn=None, warmup=2):
         """Capture `local` (every rank) and `tail` (+ optional post_fn(out) on rank 0) on the CURRENT
-        non-default stream.  Afterwards `replay()` runs: graph(local) -> all-gather -> graph(tail)."""
+        non-default stream.  Afterwards `replay()` runs: graph(local) -> all-gather -> graph(tail).
+        Returns False (on every rank, agreed through an all-reduce so the collective sequences stay
+        aligned) if any rank could not capture; the caller then keeps using `forward`."""
         dev = next(self.model.parameters()).device
         cur = torch.cuda.current_stream(dev)
         if cur == torch.cuda.default_stream(dev):
@@ -170,20 +180,39 @@ class ShardedCollab:
             if post_fn is not None and self.rank == 0:
                 post_fn(out)
         cur.synchronize()
-        self._g_local = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_local, stream=cur):
-            self._static_buf = self.local(scene_input, n_agents, local_inputs)
-        self._static_gathered = all_gather_packed(self._static_buf, self.world)
-        if self.world > 1:
-            # all_gather_packed allocates its output: keep ONE static output and gather into it on replay
-            self._static_gathered = self._static_gathered.clone()
+        self._capture_error = None
+        ok = True
+        try:
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the process-group watchdog thread may query events while we capture
+            with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
+                self._static_buf = self.local(scene_input, n_agents, local_inputs)
+            self._g_local = g
+        except Exception as e:  # noqa: BLE001 - reported by the caller, path falls back to eager
+            self._capture_error = e
+            ok = False
+            torch.cuda.synchronize()
+        if not self._agree(ok, dev):
+            self._g_local = None
+            return False
+        self._static_gathered = all_gather_packed(self._static_buf, self.world).clone()
+        ok = True
         if self.rank == 0:
             cur.synchronize()
-            self._g_tail = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_tail, stream=cur):
-                out = self.tail(self._static_gathered, n_agents)
-                self._static_post = post_fn(out) if post_fn is not None else out
-        self._n_agents = n_agents
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
+                    out = self.tail(self._static_gathered, n_agents)
+                    self._static_post = post_fn(out) if post_fn is not None else out
+                self._g_tail = g
+            except Exception as e:  # noqa: BLE001
+                self._capture_error = e
+                ok = False
+                torch.cuda.synchronize()
+        if not self._agree(ok, dev):
+            self._g_local = self._g_tail = None
+            return False
+        return True
 
     def replay(self):
         self._g_local.replay()
