@@ -265,7 +265,8 @@ def main():
                        "pillars_per_agent": m_per_agent, "modalities": mods,
                        "points_per_agent": [int(scene.points[k].shape[0]) for k in sorted(scene.points)],
                        "parallelism": "1 GPU" if world == 1 else f"agent-sharded over {world} ranks, 1 all-gather",
-                       "launch": "hipGraph replay of the whole step" if use_graph else "eager launches",
+                       "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if world == 1
+                                  else "hipGraph(local stage) -> all-gather -> hipGraph(fusion tail + decode/NMS)"),
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "op_timing_ms": kernels,
         }

@@ -1,0 +1,56 @@
+"""Aggregate rocprofv3 --pmc counter_collection CSVs into a per-kernel table (mean per dispatch).
+
+usage: python scripts/pmc_summary.py OUT.txt DIR_FETCH DIR_WRITE [--json K2.json]
+Each DIR is the -d directory of one `rocprofv3 --pmc <COUNTER> --output-format csv` pass (counters are collected
+in separate passes: FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950, MI355X_MICROARCH.md PMC table)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def load(d):
+    acc = defaultdict(lambda: [0, 0.0])
+    name = None
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                k = row["Kernel_Name"]
+                name = row["Counter_Name"]
+                acc[k][0] += 1
+                acc[k][1] += float(row["Counter_Value"])
+    return name, {k: (n, s / n) for k, (n, s) in acc.items()}
+
+
+def main():
+    out, d_fetch, d_write = sys.argv[1:4]
+    _, fetch = load(d_fetch)
+    _, write = load(d_write)
+    keys = sorted(k for k in set(fetch) | set(write) if "heal::" in k)
+    lines = ["# mean per dispatch, counter units are KB (rocprofv3 FETCH_SIZE / WRITE_SIZE), separate passes",
+             "# gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> x2 for 16 B/lane streams",
+             f"{'kernel':<78}{'dispatches':>11}{'FETCH_KB':>12}{'WRITE_KB':>12}"]
+    for k in keys:
+        n = fetch.get(k, write.get(k))[0]
+        lines.append(f"{k[:76]:<78}{n:>11}{fetch.get(k, (0, 0.0))[1]:>12.1f}{write.get(k, (0, 0.0))[1]:>12.1f}")
+    open(out, "w").write("\n".join(lines) + "\n")
+    if "--json" in sys.argv:
+        # K2 = memset + k_pfn + k_canvas per agent launch; FETCH x2 (wide coalesced reads), WRITE as reported
+        tot = 0.0
+        parts = {}
+        for k in keys:
+            if "k_pfn" in k or "k_canvas" in k:
+                b = (2.0 * fetch.get(k, (0, 0.0))[1] + write.get(k, (0, 0.0))[1]) * 1024.0
+                parts[k.split("(")[0]] = b
+                tot += b
+        json.dump({"k2_traffic_bytes_per_launch": tot, "parts": parts,
+                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = 2*FETCH_SIZE"
+                             " + WRITE_SIZE (KB->B), k_pfn + k_canvas per agent (the 2.6 us hipMemsetAsync of the "
+                             "cell->pillar map is not a kernel dispatch and is not counted)"},
+                  open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
