@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void k_grouped_conv3x3(const float* __restrict
     constexpr int CCH = 4;  // input channels staged per pass (keeps LDS small -> several blocks per CU)
     __shared__ float tile[CCH][IH][IW + 1];
     const int G = C / CG;
-    const int n = blockIdx.z / G, g = blockIdx.z - n * G;
-    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const Block3 bk = xcd_block();  // neighbouring tiles (shared halo rows / 128-B lines) on one XCD's L2
+    const int n = bk.z / G, g = bk.z - n * G;
+    const int ox0 = bk.x * TW, oy0 = bk.y * TH;
     const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
     const float* xin = x + ((size_t)n * C + (size_t)g * CG) * H * W;
     // weights of this group: block-uniform addresses -> scalar loads, operands come from SGPRs
@@ -118,9 +119,10 @@ __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ x, 
     constexpr int TW = 32, TH = 8;
     constexpr int IW = (TW - 1) * STRIDE + K, IH = (TH - 1) * STRIDE + K;
     __shared__ float tile[IH][IW + 1];
-    const int nc = blockIdx.z;          // n * C + c
+    const Block3 bk = xcd_block();
+    const int nc = bk.z;          // n * C + c
     const int c = nc % C;
-    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int ox0 = bk.x * TW, oy0 = bk.y * TH;
     const int ix0 = ox0 * STRIDE - pad_l, iy0 = oy0 * STRIDE - pad_t;
     const float* xin = x + (size_t)nc * H * W;
     for (int e = threadIdx.x; e < IH * IW; e += 256) {

@@ -133,8 +133,9 @@ template <int NA>
 __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ feats,
                                                      const float* __restrict__ occ, WarpParams p, int CCH,
                                                      float* __restrict__ out) {
-    const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
-    const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
+    const Block3 bk = xcd_block();  // rotated bilinear footprints of neighbouring tiles overlap: keep them on one L2
+    const int w = bk.x * WF_TW + (threadIdx.x & (WF_TW - 1));
+    const int h = bk.y * WF_TH + (threadIdx.x / WF_TW);
     if (w >= p.W || h >= p.H) return;
     const int HW = p.H * p.W;
     int off[NA][4];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) wt[a][k] *= prob[a];
     }
-    const int c0 = blockIdx.z * CCH;
+    const int c0 = bk.z * CCH;
     const int pix = h * p.W + w;
     constexpr int U = NA <= 4 ? 4 : (NA <= 6 ? 2 : 1);  // channels in flight per thread (register budget: 4 waves per SIMD)
     for (int c = c0; c < c0 + CCH && c < p.C; c += U) {
@@ -204,8 +205,9 @@ __global__ __launch_bounds__(256) void k_warp_agent(const float* __restrict__ fe
                                                    const float* __restrict__ occ, WarpParams p,
                                                    float* __restrict__ feat_ego,
                                                    float* __restrict__ score_ego) {
-    const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
-    const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
+    const Block3 bk = xcd_block();
+    const int w = bk.x * WF_TW + (threadIdx.x & (WF_TW - 1));
+    const int h = bk.y * WF_TH + (threadIdx.x / WF_TW);
     if (w >= p.W || h >= p.H) return;
     const int HW = p.H * p.W;
     float gx, gy;
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(256) void k_warp_agent(const float* __restrict__ fe
     else grid_point<float>(p.m[0], h, w, p.H, p.W, gx, gy);
     const Taps t = make_taps(gx, gy, p.H, p.W);
     const int pix = h * p.W + w;
-    if (blockIdx.z == 0 && score_ego != nullptr) score_ego[pix] = sample_score(occ, t, p.W, p.crop[0]);
-    const int c0 = blockIdx.z * CCH;
+    if (bk.z == 0 && score_ego != nullptr) score_ego[pix] = sample_score(occ, t, p.W, p.crop[0]);
+    const int c0 = bk.z * CCH;
 #pragma unroll 4
     for (int c = c0; c < c0 + CCH && c < p.C; ++c)
         feat_ego[(size_t)c * HW + pix] = sample(feat + (size_t)c * HW, t, p.W);

@@ -239,6 +239,38 @@ def quad_iou(a, b):
     return out
 
 
+_BEV_MODES = {"overlap": 0, "iou": 1, "iou_normal": 2}
+
+
+def boxes_bev_matrix(boxes_a, boxes_b, mode="iou"):
+    """pcdet BEV box ops: boxes [n,7] / [m,7] f32 cuda (x, y, z, dx, dy, dz, heading) -> [n,m] overlap area
+    ('overlap'), rotated IoU ('iou') or axis-aligned IoU ('iou_normal')."""
+    a = _need(boxes_a, torch.float32, "boxes_a")
+    b = _need(boxes_b, torch.float32, "boxes_b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 7 or b.shape[1] != 7:
+        raise _capi.HealAmdError("boxes_bev_matrix: boxes must be [n,7]")
+    n, m = int(a.shape[0]), int(b.shape[0])
+    out = torch.zeros((n, m), dtype=torch.float32, device=a.device)
+    _capi.call("heal_boxes_bev_matrix", _ptr(a), n, _ptr(b), m, _BEV_MODES[mode], _ptr(out), _stream())
+    return out
+
+
+def nms_bev(boxes_sorted, thresh, rotated=True):
+    """Greedy pcdet NMS over boxes [n,7] already in descending-score order -> (keep [n] i64, count [1] i32), both on
+    the device; keep[:count] are the surviving indices in ascending order."""
+    b = _need(boxes_sorted, torch.float32, "boxes_sorted")
+    if b.dim() != 2 or b.shape[1] != 7:
+        raise _capi.HealAmdError("nms_bev: boxes must be [n,7]")
+    n = int(b.shape[0])
+    keep = torch.empty((n,), dtype=torch.int64, device=b.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    need = _capi.query("heal_nms_bev_workspace", n)
+    ws = _workspace("nms_bev", need, b.device)
+    _capi.call("heal_nms_bev", _ptr(b), n, float(thresh), int(bool(rotated)), _ptr(ws), need, _ptr(keep), _ptr(count),
+               _stream())
+    return keep, count
+
+
 def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
     """K4.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum [D,fH,fW,3]
     (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,

@@ -232,6 +232,24 @@ int heal_depthwise_conv(const float* x, const float* weight, const float* bias, 
                         int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y,
                         void* stream);
 
+/* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
+ * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265
+ * (boxes_overlap_kernel, boxes_iou_bev_kernel), :267-375 (nms_kernel, nms_normal_kernel) and the host mask walk of
+ * iou3d_nms.cpp:74-125,128-188, i.e. the `iou3d_nms_cuda` module bound by iou3d_nms_utils.py:32-46,109-181,252-289.
+ * Boxes are rows [x, y, z, dx, dy, dz, heading] f32.  pcdet semantics: fp32, corner test inflated by 1e-2,
+ * points sorted by polar angle around their centroid.
+ *
+ * heal_boxes_bev_matrix: out[n,m] = overlap area (mode 0: boxes_overlap_bev_gpu), rotated IoU (mode 1:
+ *   boxes_iou_bev_gpu) or axis-aligned IoU (mode 2: iou_normal).
+ * heal_nms_bev: greedy NMS over boxes ALREADY sorted by descending score (the caller's `boxes[order]`,
+ *   iou3d_nms_utils.py:262-270); rotated != 0 -> nms_gpu, 0 -> nms_normal_gpu.  keep [n] i64 (indices into the
+ *   sorted boxes, ascending) and *num_keep stay on the device: no mask copy to the host, no per-call allocation. */
+int heal_boxes_bev_matrix(const float* boxes_a, int n, const float* boxes_b, int m, int mode, float* out,
+                          void* stream);
+size_t heal_nms_bev_workspace(int n);
+int heal_nms_bev(const float* boxes_sorted, int n, float thresh, int rotated, void* workspace,
+                 size_t workspace_bytes, long long* keep, int* num_keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

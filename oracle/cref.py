@@ -29,6 +29,9 @@ def lib():
         _lib.oracle_voxelize.restype = ctypes.c_int
         _lib.oracle_quad_iou.restype = ctypes.c_float
         _lib.oracle_nms_rotated.restype = ctypes.c_int
+        _lib.oracle_pcdet_overlap.restype = ctypes.c_float
+        _lib.oracle_pcdet_iou_bev.restype = ctypes.c_float
+        _lib.oracle_pcdet_nms.restype = ctypes.c_int
     return _lib
 
 
@@ -73,3 +76,59 @@ def nms_rotated(quads, order, thr):
     k = lib().oracle_nms_rotated(_p(q, ctypes.c_float), _p(o, ctypes.c_int32), int(o.shape[0]),
                                  ctypes.c_float(thr), _p(keep, ctypes.c_int32))
     return keep[:k].copy()
+
+
+# ---- pcdet rotated BEV IoU / NMS -------------------------------------------------------------
+REF_LIB = os.path.join(HERE, "_ref", "libpcdet_iou_ref.so")
+_ref = None
+
+
+def build_ref(reference_root="/root/reference"):
+    """Compile the reference's own iou3d_cpu.cpp where it lies (oracle/Makefile.ref).  Returns the .so path, or
+    None when the reference tree is absent (GPU box: the prebuilt file travels with the snapshot)."""
+    if not os.path.isdir(reference_root):
+        return REF_LIB if os.path.exists(REF_LIB) else None
+    r = subprocess.run(["make", "-f", os.path.join("oracle", "Makefile.ref"), f"REF={reference_root}"],
+                       cwd=os.path.dirname(HERE), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("reference build failed:\n" + r.stdout + r.stderr)
+    return REF_LIB
+
+
+def ref_lib():
+    """ctypes handle of oracle/_ref/libpcdet_iou_ref.so (None if it was never built)."""
+    global _ref
+    if _ref is None and os.path.exists(REF_LIB):
+        import torch  # noqa: F401  (the reference routine takes at::Tensor: libtorch must be loaded first)
+        _ref = ctypes.CDLL(REF_LIB)
+        _ref.ref_boxes_iou_bev_cpu.restype = ctypes.c_int
+    return _ref
+
+
+def ref_boxes_iou_bev_cpu(boxes_a, boxes_b):
+    """The reference's boxes_iou_bev_cpu (iou3d_cpu.cpp:233-252) on [N,7] / [M,7] f32 -> [N,M] f32."""
+    a = np.ascontiguousarray(boxes_a, np.float32)
+    b = np.ascontiguousarray(boxes_b, np.float32)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    ref_lib().ref_boxes_iou_bev_cpu(_p(a, ctypes.c_float), a.shape[0], _p(b, ctypes.c_float), b.shape[0],
+                                    _p(out, ctypes.c_float))
+    return out
+
+
+def pcdet_matrix(boxes_a, boxes_b, mode):
+    """mode 'overlap' | 'iou' | 'iou_normal' -> [N,M] f32 (oracle restatement)."""
+    a = np.ascontiguousarray(boxes_a, np.float32)
+    b = np.ascontiguousarray(boxes_b, np.float32)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib().oracle_pcdet_matrix(_p(a, ctypes.c_float), a.shape[0], _p(b, ctypes.c_float), b.shape[0],
+                              {"overlap": 0, "iou": 1, "iou_normal": 2}[mode], _p(out, ctypes.c_float))
+    return out
+
+
+def pcdet_nms(boxes_sorted, thr, rotated=True):
+    """Greedy NMS over boxes already in descending-score order -> kept indices (int64)."""
+    b = np.ascontiguousarray(boxes_sorted, np.float32)
+    keep = np.zeros((b.shape[0],), np.int64)
+    k = lib().oracle_pcdet_nms(_p(b, ctypes.c_float), b.shape[0], ctypes.c_float(thr), int(bool(rotated)),
+                               _p(keep, ctypes.c_int64))
+    return keep[:k]

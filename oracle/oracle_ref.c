@@ -168,3 +168,138 @@ int oracle_nms_rotated(const float* quads, const int32_t* order, int k, float th
     free(dead);
     return nkeep;
 }
+
+/* =====================================================================================================
+ * pcdet rotated BEV IoU / NMS.  fp32 throughout, MARGIN-inflated corner test, centroid
+ * angle sort -- the arithmetic of opencood/pcdet_utils/iou3d_nms/src/iou3d_cpu.cpp:38-230 (CPU twin of
+ * iou3d_nms_kernel.cu:35-234), restated with precomputed polar angles (same comparisons, same swaps).
+ * PINNED: tests compare this bit for bit with oracle/_ref/libpcdet_iou_ref.so, which is the reference's
+ * own iou3d_cpu.cpp compiled where it lies (oracle/Makefile.ref).
+ * Boxes are [x, y, z, dx, dy, dz, heading].
+ * ===================================================================================================== */
+#define PC_EPS 1e-8f
+#define PC_MARGIN 1e-2f
+
+typedef struct { float x, y; } pc_pt;
+
+static float pc_cross3(pc_pt p1, pc_pt p2, pc_pt p0) { /* iou3d_cpu.cpp:63-65 */
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+static void pc_corners(const float* box, pc_pt* c /*[5]*/) { /* iou3d_cpu.cpp:134-165, 119-123 */
+    const float hx = box[3] / 2, hy = box[4] / 2;
+    const float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
+    const float cs = cosf(box[6]), sn = sinf(box[6]);
+    const float px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
+    for (int k = 0; k < 4; ++k) {
+        c[k].x = (px[k] - box[0]) * cs + (py[k] - box[1]) * (-sn) + box[0];
+        c[k].y = (px[k] - box[0]) * sn + (py[k] - box[1]) * cs + box[1];
+    }
+    c[4] = c[0];
+}
+
+static int pc_inside(const float* box, pc_pt p) { /* iou3d_cpu.cpp:76-87 */
+    const float cs = cosf(-box[6]), sn = sinf(-box[6]);
+    const float rx = (p.x - box[0]) * cs + (p.y - box[1]) * (-sn);
+    const float ry = (p.x - box[0]) * sn + (p.y - box[1]) * cs;
+    return fabsf(rx) < box[3] / 2 + PC_MARGIN && fabsf(ry) < box[4] / 2 + PC_MARGIN;
+}
+
+/* segment p0->p1 against q0->q1; iou3d_cpu.cpp:89-117 */
+static int pc_segment_hit(pc_pt p1, pc_pt p0, pc_pt q1, pc_pt q0, pc_pt* ans) {
+    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+        return 0;
+    const float s1 = pc_cross3(q0, p1, p0), s2 = pc_cross3(p1, q1, p0);
+    const float s3 = pc_cross3(p0, q1, q0), s4 = pc_cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    const float s5 = pc_cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > PC_EPS) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+float oracle_pcdet_overlap(const float* box_a, const float* box_b) { /* iou3d_cpu.cpp:129-221 */
+    pc_pt ca[5], cb[5], pts[24];
+    pc_corners(box_a, ca);
+    pc_corners(box_b, cb);
+    int cnt = 0;
+    float sx = 0.f, sy = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (pc_segment_hit(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+                sx = sx + pts[cnt].x; sy = sy + pts[cnt].y; ++cnt;
+            }
+    for (int k = 0; k < 4; ++k) {
+        if (pc_inside(box_a, cb[k])) { sx = sx + cb[k].x; sy = sy + cb[k].y; pts[cnt++] = cb[k]; }
+        if (pc_inside(box_b, ca[k])) { sx = sx + ca[k].x; sy = sy + ca[k].y; pts[cnt++] = ca[k]; }
+    }
+    sx /= cnt; sy /= cnt; /* cnt == 0 -> NaN centre, no sort, no area: overlap 0 (as the reference) */
+    float ang[24];
+    for (int k = 0; k < cnt; ++k) ang[k] = atan2f(pts[k].y - sy, pts[k].x - sx);
+    for (int j = 0; j < cnt - 1; ++j)           /* bubble sort, swap when angle[i] > angle[i+1] (:201-210) */
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                pc_pt t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+                float u = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = u;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y;
+        const float bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+        area += ax * by - ay * bx;
+    }
+    return fabsf(area) / 2.0f;
+}
+
+float oracle_pcdet_iou_bev(const float* a, const float* b) { /* iou3d_cpu.cpp:223-230 */
+    const float sa = a[3] * a[4], sb = b[3] * b[4];
+    const float so = oracle_pcdet_overlap(a, b);
+    return so / fmaxf(sa + sb - so, PC_EPS);
+}
+
+float oracle_pcdet_iou_normal(const float* a, const float* b) { /* iou3d_nms_kernel.cu:314-325 (axis-aligned) */
+    const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+    const float inter = w * h;
+    return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, PC_EPS);
+}
+
+/* mode 0: overlap area, 1: rotated IoU, 2: axis-aligned IoU.  out[n*m] */
+void oracle_pcdet_matrix(const float* a, int n, const float* b, int m, int mode, float* out) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            const float* pa = a + 7 * (size_t)i; const float* pb = b + 7 * (size_t)j;
+            out[(size_t)i * m + j] = mode == 0 ? oracle_pcdet_overlap(pa, pb)
+                                   : mode == 1 ? oracle_pcdet_iou_bev(pa, pb) : oracle_pcdet_iou_normal(pa, pb);
+        }
+}
+
+/* greedy NMS over boxes ALREADY in descending-score order: box i survives unless an earlier survivor j has
+ * IoU(j, i) > thr (row = the earlier box: iou3d_nms_kernel.cu:293-307; host pass iou3d_nms.cpp:109-122).
+ * rotated != 0 -> iou_bev, else iou_normal.  Returns the number kept, indices in keep[]. */
+int oracle_pcdet_nms(const float* boxes, int n, float thr, int rotated, int64_t* keep) {
+    char* dead = (char*)calloc((size_t)n + 1, 1);
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[k++] = i;
+        for (int j = i + 1; j < n; ++j) {
+            if (dead[j]) continue;
+            const float v = rotated ? oracle_pcdet_iou_bev(boxes + 7 * (size_t)i, boxes + 7 * (size_t)j)
+                                    : oracle_pcdet_iou_normal(boxes + 7 * (size_t)i, boxes + 7 * (size_t)j);
+            if (v > thr) dead[j] = 1;
+        }
+    }
+    free(dead);
+    return k;
+}

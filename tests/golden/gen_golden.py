@@ -302,6 +302,36 @@ GENS = {"pointpillar_encoder": gen_pointpillar_encoder, "warp_fuse": gen_warp_fu
         "collab_small": gen_collab_small, "single_late_small": gen_single_late_small, "lss": gen_lss,
         "fusion_small": gen_fusion_small, "baseline_small": gen_baseline_small}
 
+def pcdet_boxes(rng, n, spread):
+    b = np.zeros((n, 7), np.float32)
+    b[:, 0:2] = rng.uniform(-spread, spread, (n, 2))
+    b[:, 2] = rng.uniform(-1, 1, n)
+    b[:, 3] = rng.uniform(0.5, 5, n)
+    b[:, 4] = rng.uniform(0.5, 3, n)
+    b[:, 5] = rng.uniform(1, 2, n)
+    b[:, 6] = rng.uniform(-4, 4, n)
+    return b
+
+
+def gen_pcdet_iou():
+    """Outputs of the reference's OWN boxes_iou_bev_cpu (iou3d_cpu.cpp), called through oracle/_ref (the file
+    compiled where it lies, oracle/Makefile.ref)."""
+    from oracle import cref
+    assert cref.build_ref() and cref.ref_lib() is not None
+    rng = np.random.default_rng(77)
+    a, b = pcdet_boxes(rng, 160, 7.0), pcdet_boxes(rng, 120, 7.0)
+    # hand-made edge cases: identical, half-shifted, touching, contained, 90 deg, far away, degenerate
+    edge = np.array([[0, 0, 0, 4, 2, 1, 0], [0, 0, 0, 4, 2, 1, 0], [2, 0, 0, 4, 2, 1, 0], [4, 0, 0, 4, 2, 1, 0],
+                     [0, 0, 0, 1, 1, 1, 0.3], [0, 0, 0, 4, 2, 1, np.pi / 2], [100, 100, 0, 4, 2, 1, 1],
+                     [0, 0, 0, 0, 0, 1, 0], [0, 0, 0, 4, 2, 1, np.pi], [0.005, 0.005, 0, 4, 2, 1, 1e-4],
+                     [1, 0.5, 0, 4, 2, 1.5, np.pi / 4]], np.float32)
+    save("pcdet_iou", boxes_a=a, boxes_b=b, iou_ab=cref.ref_boxes_iou_bev_cpu(a, b), edge=edge,
+         iou_edge=cref.ref_boxes_iou_bev_cpu(edge, edge))
+
+
+GENS["pcdet_iou"] = gen_pcdet_iou
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENS)
     for nme in names:
