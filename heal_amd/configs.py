@@ -206,6 +206,33 @@ def lidar_baseline(fusion_method="v2xvit", lidar_range=FULL_RANGE, max_cav=5, mo
     return load_general_params(h)
 
 
+def oldstyle_pointpillar(fusion_method=None, lidar_range=FULL_RANGE, max_cav=5, compression=0):
+    """Old-style YAML (v2xsim2/visualization.yaml `model` block): core_method point_pillar, or
+    point_pillar_baseline when a fusion_method (max | att | v2xvit) is given.  Uses the `processed_lidar` key."""
+    h = _common(lidar_range, max_cav)
+    args = {"voxel_size": [0.4, 0.4, 4], "lidar_range": list(lidar_range), "anchor_number": 2, "max_cav": max_cav,
+            "backbone_fix": False,
+            "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+            "point_pillar_scatter": {"num_features": 64},
+            "base_bev_backbone": {"layer_nums": [3, 5, 8], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                                  "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]},
+            "shrink_header": {"kernal_size": [3], "stride": [1], "padding": [1], "dim": [256], "input_dim": 384},
+            "dir_args": copy.deepcopy(DIR_ARGS)}
+    core = "point_pillar"
+    if fusion_method is not None:
+        core = "point_pillar_baseline"
+        args["fusion_method"] = fusion_method
+        if fusion_method == "att":
+            args["att"] = {"feat_dim": 256}
+        elif fusion_method == "v2xvit":
+            args["v2xvit"] = _v2xvit_args()
+        if compression:
+            args["compression"] = compression
+    h["name"] = f"heal_amd_{core}"
+    h["model"] = {"core_method": core, "args": args}
+    return load_general_params(h)
+
+
 def dump_yaml(hypes, path):
     def plain(o):
         if isinstance(o, dict):

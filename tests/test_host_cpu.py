@@ -55,6 +55,12 @@ def test_state_dict_keys_match_reference():
                      ("late", configs.m1_late()), ("baseline_v2xvit", configs.lidar_baseline("v2xvit"))):
         sd = create_model(hy).state_dict()
         assert {k: list(v.shape) for k, v in sd.items()} == keys[name], name
+    # old-style models
+    for name, hy in (("point_pillar", configs.oldstyle_pointpillar()),
+                     ("point_pillar_baseline_max", configs.oldstyle_pointpillar("max", compression=4)),
+                     ("point_pillar_baseline_att", configs.oldstyle_pointpillar("att", compression=4))):
+        sd = create_model(hy).state_dict()
+        assert {k: list(v.shape) for k, v in sd.items()} == keys[name], name
 
 
 def test_yaml_loader_round_trip(tmp_path):
