@@ -234,3 +234,31 @@ def test_synth_scene_is_deterministic():
     pw = synth.pairwise_t_matrix(synth.agent_poses(1, 3), 5)
     assert pw.shape == (5, 5, 4, 4) and pw.dtype == np.float64
     np.testing.assert_allclose(pw[0, 1] @ pw[1, 0], np.eye(4), atol=1e-9)
+
+
+def test_oracle_sparse_conv_known_answers():
+    """spconv is absent (parity unpinned): the oracle's active-site rules are pinned by hand-made cases.
+    Submanifold: outputs only at input sites, neighbours that are inactive contribute nothing.
+    Regular (strided): an output site is active iff any input lies in its receptive field."""
+    import torch
+    from oracle import oracle_np as O
+    feats = np.array([[1.0, 2.0], [10.0, 20.0]], np.float32)          # two sites, C_in = 2
+    idx = np.array([[0, 1, 1, 1], [0, 1, 1, 2]], np.int64)            # (b, z, y, x): x-neighbours
+    dense, mask = O.densify(feats, idx, (4, 4, 4), 1)
+    w = np.zeros((3, 3, 3, 2, 1), np.float32)
+    w[1, 1, 1] = [[1.0], [1.0]]                                       # centre tap: sum of channels
+    w[1, 1, 2] = [[0.5], [0.0]]                                       # +x neighbour: half of channel 0
+    one, zero = np.ones(1, np.float32), np.zeros(1, np.float32)
+    y, m = O.sparse_conv_dense(dense, mask, w, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, one, zero, zero, one - 1e-3)
+    assert m.sum() == 2 and torch.equal(m, mask)                      # same active set
+    np.testing.assert_allclose(float(y[0, 0, 1, 1, 1]), 3.0 + 0.5 * 10.0, rtol=1e-6)   # centre + right neighbour
+    np.testing.assert_allclose(float(y[0, 0, 1, 1, 2]), 30.0, rtol=1e-6)               # right neighbour is inactive
+    assert float(y.abs().sum()) == pytest.approx(38.0, rel=1e-6)      # nothing leaks to inactive cells
+    # strided 3x3x3, stride 2, padding 1: output cell o covers inputs 2o-1 .. 2o+1 per axis
+    y2, m2 = O.sparse_conv_dense(dense, mask, np.ones((3, 3, 3, 2, 1), np.float32), (3, 3, 3), (2, 2, 2), (1, 1, 1),
+                                 False, one, zero, zero, one - 1e-3)
+    act = {tuple(int(v) for v in t) for t in torch.nonzero(m2[0, 0])}
+    # input (1,1,1) -> outputs with each coord in {0,1}; input (1,1,2) -> z,y in {0,1}, x in {1}
+    assert act == {(z, y_, x) for z in (0, 1) for y_ in (0, 1) for x in (0, 1)}
+    np.testing.assert_allclose(float(y2[0, 0, 0, 0, 0]), 3.0, rtol=1e-6)     # sees only the first site
+    np.testing.assert_allclose(float(y2[0, 0, 0, 0, 1]), 33.0, rtol=1e-6)    # sees both
