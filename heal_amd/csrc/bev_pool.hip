@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_lss_transpose(const float* __restrict__
 // tile boundary leaves a partial row (slot 0: the run began in an earlier tile, slot 1: it begins here and
 // continues), and k_lss_combine adds the partials of such a cell in tile order.  Additions happen in a fixed
 // order, so the result is deterministic.
-constexpr int LSS_TILE = 128;
+constexpr int LSS_TILE = 32;  // points per wave: small tiles = many waves in flight (the reduce is latency-bound)
 
 template <int CPL /*channels per lane*/>
 __global__ __launch_bounds__(256) void k_lss_reduce_tiles(const uint32_t* __restrict__ skeys,
@@ -234,31 +234,33 @@ __global__ __launch_bounds__(256) void k_lss_reduce_tiles(const uint32_t* __rest
     if (cur != invalid_key) flush(cur);
 }
 
-// One wave per BEV cell: empty -> map = -1; a cell whose points span several tiles -> add its partial rows
-// in tile order; cells finished inside one tile were already written by k_lss_reduce_tiles.
+// One wave per TILE: a cell whose run starts in this tile and continues past its end is finished here by adding
+// the partial rows of the following tiles in tile order (cells finished inside one tile were already written by
+// k_lss_reduce_tiles; empty cells keep the -1 of the cell_map memset).
 template <int CPL>
-__global__ __launch_bounds__(256) void k_lss_combine(const int* __restrict__ seg_start,
+__global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict__ skeys,
+                                                    const int* __restrict__ seg_start,
                                                     const int* __restrict__ seg_end,
-                                                    const float* __restrict__ partial, int C, int n_cells,
-                                                    int* __restrict__ row_counter, float* __restrict__ rows,
-                                                    int* __restrict__ cell_map) {
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= n_cells) return;
-    const int l = threadIdx.x & 63;
+                                                    const float* __restrict__ partial, int C, int np,
+                                                    uint32_t invalid_key, int* __restrict__ row_counter,
+                                                    float* __restrict__ rows, int* __restrict__ cell_map) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int t_begin = tile * LSS_TILE;
+    if (t_begin >= np) return;
+    const int t_end = min(t_begin + LSS_TILE, np);
+    const uint32_t cell = skeys[t_end - 1];
+    if (cell >= invalid_key) return;
     const int s = seg_start[cell], e = seg_end[cell];
-    if (e <= s) {
-        if (l == 0) cell_map[cell] = -1;
-        return;
-    }
-    const int t0 = s / LSS_TILE, t1 = (e - 1) / LSS_TILE;
-    if (t0 == t1) return;
+    if (e <= t_end || s < t_begin) return;  // ends here, or this tile is not the head of the run
+    const int l = threadIdx.x & 63;
+    const int t1 = (e - 1) / LSS_TILE;
     float acc[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int c = l + 64 * k;
-        acc[k] = c < C ? partial[((size_t)t0 * 2 + 1) * C + c] : 0.f;
+        acc[k] = c < C ? partial[((size_t)tile * 2 + 1) * C + c] : 0.f;
     }
-    for (int t = t0 + 1; t <= t1; ++t) {
+    for (int t = tile + 1; t <= t1; ++t) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const int c = l + 64 * k;
@@ -339,7 +341,7 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     HEAL_REQUIRE(carve(a, n_agents, n_cams, D, HW, channels, cells_total, w),
                  "bev_pool: workspace too small (%zu < %zu)", ws_bytes, a.off);
 
-    HEAL_HIP(hipMemsetAsync(w.seg_start, 0, (size_t)((char*)w.cell_map - (char*)w.seg_start), s));
+    HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
     HEAL_HIP(hipMemsetAsync(w.row_counter, 0, sizeof(int), s));
     const uint32_t invalid_key = (uint32_t)cells_total;
     k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 64), 256, 0, s>>>(
@@ -353,13 +355,12 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     if (radix_sort_pairs(w.keys, w.vals, np, key_bits, &res, w.scratch, s)) return 1;
     k_lss_segments<<<ceil_div(np, 256), 256, 0, s>>>(w.keys[res], np, invalid_key, w.seg_start, w.seg_end);
     const int tblocks = ceil_div(ceil_div(np, LSS_TILE), 4);
-    const int cblocks = ceil_div(cells_total, 4);
 #define HEAL_LSS_REDUCE(CPL)                                                                                   \
     k_lss_reduce_tiles<CPL><<<tblocks, 256, 0, s>>>(w.keys[res], w.vals[res], w.seg_start, w.seg_end, w.probs,  \
                                                     w.featT, g, np, invalid_key, w.row_counter, w.rows,        \
                                                     w.cell_map, w.partial);                                    \
-    k_lss_combine<CPL><<<cblocks, 256, 0, s>>>(w.seg_start, w.seg_end, w.partial, channels, cells_total,        \
-                                               w.row_counter, w.rows, w.cell_map)
+    k_lss_combine<CPL><<<tblocks, 256, 0, s>>>(w.keys[res], w.seg_start, w.seg_end, w.partial, channels, np,    \
+                                               invalid_key, w.row_counter, w.rows, w.cell_map)
     if (channels <= 64) { HEAL_LSS_REDUCE(1); }
     else if (channels <= 128) { HEAL_LSS_REDUCE(2); }
     else { HEAL_LSS_REDUCE(4); }

@@ -232,44 +232,58 @@ __global__ __launch_bounds__(64) void k_nms_prepare(const float* __restrict__ cl
     nb.inrange[r] = inside ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_nms_mask(NmsBufs nb, int top, int words, float thr) {
+// One 64x64 tile per block, 8 waves: wave w tests every row of the tile against columns [8w, 8w+8), so the serial
+// chain of fp64 clips per lane is 8 long instead of 64 (the kernel is latency-bound: ~136 tiles for 1000 boxes).
+constexpr int NMS_SPLIT = 8, NMS_COLS = 64 / NMS_SPLIT;
+__global__ __launch_bounds__(64 * NMS_SPLIT) void k_nms_mask(NmsBufs nb, int top, int words, float thr) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
     const int K = min(*nb.n_cand, top);
     if (bi * 64 >= K || bj * 64 >= K) return;
     __shared__ float cq[64][8];
     __shared__ float cbb[64][4];  // axis-aligned bounds (xmin, xmax, ymin, ymax) of the column quads
-    const int cj = bj * 64 + threadIdx.x;
-    if (cj < K) {
+    __shared__ unsigned char part[64][NMS_SPLIT];
+    const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+    const int cj = bj * 64 + lane;
+    if (chunk == 0 && cj < K) {
         float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float px = nb.quads[(size_t)cj * 8 + 2 * k], py = nb.quads[(size_t)cj * 8 + 2 * k + 1];
-            cq[threadIdx.x][2 * k] = px; cq[threadIdx.x][2 * k + 1] = py;
+            cq[lane][2 * k] = px; cq[lane][2 * k + 1] = py;
             x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
         }
-        cbb[threadIdx.x][0] = x0; cbb[threadIdx.x][1] = x1; cbb[threadIdx.x][2] = y0; cbb[threadIdx.x][3] = y1;
+        cbb[lane][0] = x0; cbb[lane][1] = x1; cbb[lane][2] = y0; cbb[lane][3] = y1;
     }
     __syncthreads();
-    const int i = bi * 64 + threadIdx.x;
-    if (i >= K) return;
-    float q[8];
-    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    const int i = bi * 64 + lane;
+    unsigned bits = 0u;
+    if (i < K) {
+        float q[8];
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        q[2 * k] = nb.quads[(size_t)i * 8 + 2 * k]; q[2 * k + 1] = nb.quads[(size_t)i * 8 + 2 * k + 1];
-        x0 = fminf(x0, q[2 * k]); x1 = fmaxf(x1, q[2 * k]); y0 = fminf(y0, q[2 * k + 1]); y1 = fmaxf(y1, q[2 * k + 1]);
+        for (int k = 0; k < 4; ++k) {
+            q[2 * k] = nb.quads[(size_t)i * 8 + 2 * k]; q[2 * k + 1] = nb.quads[(size_t)i * 8 + 2 * k + 1];
+            x0 = fminf(x0, q[2 * k]); x1 = fmaxf(x1, q[2 * k]); y0 = fminf(y0, q[2 * k + 1]); y1 = fmaxf(y1, q[2 * k + 1]);
+        }
+        const int jn = min(64, K - bj * 64);
+        for (int t = chunk * NMS_COLS; t < chunk * NMS_COLS + NMS_COLS && t < jn; ++t) {
+            if (bi == bj && t <= lane) continue;
+            // strictly separated bounding boxes => empty intersection => IoU is 0 (or NaN for a degenerate
+            // pair): never above the threshold, exactly as the full clip would conclude
+            if (cbb[t][0] > x1 || cbb[t][1] < x0 || cbb[t][2] > y1 || cbb[t][3] < y0) continue;
+            const float v = quad_iou(q, cq[t]);
+            if (v > thr) bits |= 1u << (t - chunk * NMS_COLS);
+        }
     }
-    unsigned long long bits = 0ull;
-    const int jn = min(64, K - bj * 64);
-    for (int t = (bi == bj) ? (int)threadIdx.x + 1 : 0; t < jn; ++t) {
-        // strictly separated bounding boxes => empty intersection => IoU is 0 (or NaN for a degenerate
-        // pair): never above the threshold, exactly as the full clip would conclude
-        if (cbb[t][0] > x1 || cbb[t][1] < x0 || cbb[t][2] > y1 || cbb[t][3] < y0) continue;
-        const float v = quad_iou(q, cq[t]);
-        if (v > thr) bits |= 1ull << t;
+    part[lane][chunk] = (unsigned char)bits;
+    __syncthreads();
+    if (chunk == 0 && i < K) {
+        unsigned long long w = 0ull;
+#pragma unroll
+        for (int c = 0; c < NMS_SPLIT; ++c) w |= (unsigned long long)part[lane][c] << (c * NMS_COLS);
+        nb.mask[(size_t)i * words + bj] = w;
     }
-    nb.mask[(size_t)i * words + bj] = bits;
 }
 
 // Greedy pass.  The suppression matrix of the top-k (<= 1024 x 16 words = 128 KB) is first copied into
@@ -417,7 +431,7 @@ extern "C" int heal_decode_nms(const float* cls, const float* reg, const float* 
     if (radix_sort_pairs(w.keys, w.vals, n, key_bits, &res, w.scratch, s)) return 1;
     const int words = ceil_div(nms_top, 64);
     k_nms_prepare<<<ceil_div(nms_top, 64), 64, 0, s>>>(cls, reg, dir, anchors, p, n, w.vals[res], nms_top, w.nb);
-    k_nms_mask<<<dim3(words, words), 64, 0, s>>>(w.nb, nms_top, words, nms_thr);
+    k_nms_mask<<<dim3(words, words), 64 * NMS_SPLIT, 0, s>>>(w.nb, nms_top, words, nms_thr);
     const size_t reduce_lds = (size_t)words * 64 * words * sizeof(unsigned long long);
     HEAL_REQUIRE(reduce_lds <= 150 * 1024, "decode_nms: nms_top=%d needs %zu B of LDS (limit 150 KB; use <= 1088)",
                  nms_top, reduce_lds);
