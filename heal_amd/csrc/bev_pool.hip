@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_lss_reduce_tiles(const uint32_t* __rest
                                                          const int* __restrict__ seg_end,
                                                          const float* __restrict__ probs,
                                                          const float* __restrict__ featT, LssGeom g, int np,
-                                                         uint32_t invalid_key, int* __restrict__ row_counter,
+                                                         uint32_t invalid_key,
                                                          float* __restrict__ rows, int* __restrict__ cell_map,
                                                          float* __restrict__ partial /*[ntiles][2][C]*/) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256) void k_lss_reduce_tiles(const uint32_t* __rest
     auto flush = [&](uint32_t cell) {
         const int s = seg_start[cell], e = seg_end[cell];
         if (s >= t_begin && e <= t_end) {  // run complete inside this tile
-            int row = 0;
-            if (l == 0) { row = atomicAdd(row_counter, 1); cell_map[cell] = row; }
-            row = __shfl(row, 0, 64);
+            // row = cell: the compact-row counter this replaces was ~9 k same-address atomics (~15 ns each,
+            // serialised at the L2) and alone cost more than the whole reduction
+            if (l == 0) cell_map[cell] = (int)cell;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const int c = l + 64 * k;
-                if (c < g.C) rows[(size_t)row * g.C + c] = acc[k];
+                if (c < g.C) rows[(size_t)cell * g.C + c] = acc[k];
             }
         } else {
             const int slot = (s < t_begin) ? 0 : 1;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
                                                     const int* __restrict__ seg_start,
                                                     const int* __restrict__ seg_end,
                                                     const float* __restrict__ partial, int C, int np,
-                                                    uint32_t invalid_key, int* __restrict__ row_counter,
+                                                    uint32_t invalid_key,
                                                     float* __restrict__ rows, int* __restrict__ cell_map) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int t_begin = tile * LSS_TILE;
@@ -260,27 +260,33 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
         const int c = l + 64 * k;
         acc[k] = c < C ? partial[((size_t)tile * 2 + 1) * C + c] : 0.f;
     }
-    for (int t = tile + 1; t <= t1; ++t) {
+    // a near-camera cell can span hundreds of tiles: 8 partial rows in flight per step, added in tile order
+    for (int t = tile + 1; t <= t1; t += 8) {
+        float v[8][CPL];
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const int c = l + 64 * k;
-            if (c < C) acc[k] += partial[((size_t)t * 2 + 0) * C + c];
-        }
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c = l + 64 * k;
+                v[u][k] = (c < C && t + u <= t1) ? partial[((size_t)(t + u) * 2 + 0) * C + c] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) acc[k] += v[u][k];
     }
-    int row = 0;
-    if (l == 0) { row = atomicAdd(row_counter, 1); cell_map[cell] = row; }
-    row = __shfl(row, 0, 64);
+    if (l == 0) cell_map[cell] = (int)cell;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int c = l + 64 * k;
-        if (c < C) rows[(size_t)row * C + c] = acc[k];
+        if (c < C) rows[(size_t)cell * C + c] = acc[k];
     }
 }
 
 struct LssWs {
     uint32_t *keys[2], *vals[2];
     float *probs, *featT, *rows, *partial;
-    int *seg_start, *seg_end, *cell_map, *row_counter, *scratch;
+    int *seg_start, *seg_end, *cell_map, *scratch;
 };
 
 static bool carve(Arena& a, int n_agents, int n_cams, int D, int HW, int C, int cells_total, LssWs& w) {
@@ -288,14 +294,12 @@ static bool carve(Arena& a, int n_agents, int n_cams, int D, int HW, int C, int 
     for (int k = 0; k < 2; ++k) { w.keys[k] = a.take<uint32_t>(np); w.vals[k] = a.take<uint32_t>(np); }
     w.probs = a.take<float>(np);
     w.featT = a.take<float>((size_t)n_agents * n_cams * HW * C);
-    const size_t max_rows = (size_t)cells_total < np ? (size_t)cells_total : np;
-    w.rows = a.take<float>((max_rows + 1) * C);
+    w.rows = a.take<float>(((size_t)cells_total + 1) * C);  // row of a cell = its index (only non-empty rows are touched)
     w.partial = a.take<float>((size_t)(np / LSS_TILE + 2) * 2 * C);
     // seg_start | seg_end contiguous: one memset clears both
     w.seg_start = a.take<int>(cells_total);
     w.seg_end = a.take<int>(cells_total);
     w.cell_map = a.take<int>(cells_total);
-    w.row_counter = a.take<int>(64);
     w.scratch = a.take<int>(sort_scratch_words((int64_t)np));
     return a.ok();
 }
@@ -342,7 +346,6 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
                  "bev_pool: workspace too small (%zu < %zu)", ws_bytes, a.off);
 
     HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
-    HEAL_HIP(hipMemsetAsync(w.row_counter, 0, sizeof(int), s));
     const uint32_t invalid_key = (uint32_t)cells_total;
     k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 64), 256, 0, s>>>(
         depth_logit, frustum, reinterpret_cast<const CamMats*>(cam_mats), g,
@@ -357,10 +360,10 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     const int tblocks = ceil_div(ceil_div(np, LSS_TILE), 4);
 #define HEAL_LSS_REDUCE(CPL)                                                                                   \
     k_lss_reduce_tiles<CPL><<<tblocks, 256, 0, s>>>(w.keys[res], w.vals[res], w.seg_start, w.seg_end, w.probs,  \
-                                                    w.featT, g, np, invalid_key, w.row_counter, w.rows,        \
+                                                    w.featT, g, np, invalid_key, w.rows,        \
                                                     w.cell_map, w.partial);                                    \
     k_lss_combine<CPL><<<tblocks, 256, 0, s>>>(w.keys[res], w.seg_start, w.seg_end, w.partial, channels, np,    \
-                                               invalid_key, w.row_counter, w.rows, w.cell_map)
+                                               invalid_key, w.rows, w.cell_map)
     if (channels <= 64) { HEAL_LSS_REDUCE(1); }
     else if (channels <= 128) { HEAL_LSS_REDUCE(2); }
     else { HEAL_LSS_REDUCE(4); }
