@@ -1,0 +1,140 @@
+// Pointwise (1x1, stride 1) convolution with the epilogue fused: y = act(W x + b (+ residual)), NCHW fp32.
+// Replaces the `conv1x1 -> BatchNorm -> (+identity) -> ReLU` sequences of the ResNeXt bottlenecks
+// (opencood/models/sub_modules/resblock.py:95-121) that the library path runs as a Tensile GEMM plus a separate
+// bias/residual/ReLU pass over the output.
+//
+// Per image this is the GEMM  Y[Cout, HW] = W[Cout, Cin] · X[Cin, HW]  with X and Y already in the layout MFMA
+// wants for B and D (pixels = columns), so nothing is transposed:
+//   * block = 4 waves, output tile BM channels x 128 pixels; wave w owns BM/4 rows (BM/64 m-tiles) x 8 n-tiles,
+//     accumulators in registers (v_mfma_f32_16x16x4_f32; fp32 in, fp32 accumulate);
+//   * B (activations): 32-channel x 128-pixel chunks staged through LDS with 512-B coalesced rows (16 B/lane),
+//     double-buffered against the MFMA loop; row stride 144 floats -> the four k-rows of a fragment read fall in
+//     disjoint bank groups (conflict-free ds_read_b32);
+//   * A (weights): pre-laid on the host in fragment order frag[mt][ks][lane] (ops.mfma_a_fragments), so a wave's
+//     A operand is ONE coalesced 256-B load per (m-tile, k-step) straight from L2 -- no LDS, no shuffles;
+//   * epilogue in registers: + bias[co] (+ residual) -> ReLU | SiLU -> store (64-B segments per 16-pixel run);
+//   * XCD-contiguous block order with the Cout-chunk index fastest: the (<=4) blocks that re-read one pixel tile
+//     for different output-channel chunks share an L2.
+// Roofline: HBM-bound for Cin,Cout <= 128 (ridge 20 FLOP/B in fp32), MFMA-bound above; §6 of DESIGN.md.
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int C1_BN = 128;          // pixels per block
+constexpr int C1_KC = 32;           // input channels per LDS chunk
+constexpr int C1_LD = C1_BN + 16;   // LDS row stride (floats): 144 % 64 == 16 -> k-rows 0..3 hit banks 0-15,16-31,...
+
+template <int BM>
+__global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ wfrag,
+                                                const float* __restrict__ bias, const float* __restrict__ res,
+                                                int Cin, int Cout, int HW, int act, float* __restrict__ y) {
+    constexpr int MT = BM / 64;     // m-tiles per wave
+    __shared__ __attribute__((aligned(16))) float sB[2][C1_KC][C1_LD];
+    const Block3 bk = xcd_block();  // x: Cout chunk, y: pixel tile, z: image
+    const int m0 = bk.x * BM, p0 = bk.y * C1_BN, n = bk.z;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int lk = l >> 4, ln = l & 15;
+    const float* __restrict__ xin = x + (size_t)n * Cin * HW;
+    const int ksteps = Cin / 4;     // k-steps of 4 channels over the whole K
+    const int nchunks = Cin / C1_KC;
+    // staging assignment: thread t -> channels t/32 + 8*i, pixels (t%32)*4 .. +3
+    const int sp = (threadIdx.x & 31) * 4, sc = threadIdx.x >> 5;
+    const bool pix_ok = p0 + sp < HW;  // HW % 4 == 0 (checked by the host): a float4 is all-in or all-out
+
+    f32x4 acc[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 stage[4];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = c * C1_KC + sc + 8 * i;
+            stage[i] = pix_ok ? *reinterpret_cast<const float4*>(xin + (size_t)ch * HW + p0 + sp)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sB[buf][sc + 8 * i][sp]) = stage[i];
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);  // in flight during the MFMA loop
+        float a[MT][C1_KC / 4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mtg = (m0 >> 4) + wave * MT + mt;  // global m-tile
+#pragma unroll
+            for (int ks = 0; ks < C1_KC / 4; ++ks)
+                a[mt][ks] = wfrag[((size_t)mtg * ksteps + c * (C1_KC / 4) + ks) * 64 + l];
+        }
+#pragma unroll
+        for (int ks = 0; ks < C1_KC / 4; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const float b = sB[buf][ks * 4 + lk][nt * 16 + ln];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][ks], b, acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row = lk*4 + r][col = ln] of tile (mt, nt)
+    float* __restrict__ yout = y + (size_t)n * Cout * HW;
+    const float* __restrict__ rin = res ? res + (size_t)n * Cout * HW : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + (wave * MT + mt) * 16 + lk * 4 + r;
+            const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const int p = p0 + nt * 16 + ln;
+                if (p >= HW) continue;
+                float v = acc[mt][nt][r] + bv;
+                const size_t o = (size_t)co * HW + p;
+                if (rin) v += rin[o];
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = v / (1.f + expf(-v));
+                yout[o] = v;
+            }
+        }
+    }
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
+                            int cin, int cout, int HW, int act, float* y, void* stream) {
+    HEAL_REQUIRE(n >= 1 && HW >= 1, "conv1x1: bad shape");
+    HEAL_REQUIRE(cin % C1_KC == 0, "conv1x1: Cin must be a multiple of %d (got %d)", C1_KC, cin);
+    HEAL_REQUIRE(cout % 64 == 0, "conv1x1: Cout must be a multiple of 64 (got %d)", cout);
+    HEAL_REQUIRE(HW % 4 == 0, "conv1x1: H*W must be a multiple of 4 (got %d)", HW);
+    HEAL_REQUIRE(act >= 0 && act <= 2, "conv1x1: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
+    HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ptiles = ceil_div(HW, C1_BN);
+    if (cout % 128 == 0) {
+        k_conv1x1<128><<<dim3(cout / 128, ptiles, n), 256, 0, s>>>(x, weight_frag, bias, residual, cin, cout, HW, act, y);
+    } else {
+        k_conv1x1<64><<<dim3(cout / 64, ptiles, n), 256, 0, s>>>(x, weight_frag, bias, residual, cin, cout, HW, act, y);
+    }
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

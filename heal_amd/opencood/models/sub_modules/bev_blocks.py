@@ -45,6 +45,10 @@ class _FoldCache:
         return self.value
 
 
+import os
+_CONV1X1 = os.environ.get("HEAL_CONV1X1", "1") == "1"  # hand-written pointwise conv with fused epilogue (K7c)
+
+
 def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, residual=None):
     """conv2d + per-channel bias (+ residual) (+ ReLU).  The ResNeXt 32-group 3x3 convolutions run on the
     hand-written stencil kernel (heal_grouped_conv3x3); everything else is a library convolution WITHOUT
@@ -56,6 +60,9 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
     if (groups > 1 and w.shape[2:] == (3, 3) and pd == 1 and dl == 1 and st in (1, 2) and residual is None
             and w.shape[1] in (4, 8, 16) and w.shape[0] == x.shape[1]):
         return ops.grouped_conv3x3(x, w, b, groups, st, relu)
+    if (_CONV1X1 and groups == 1 and w.shape[2:] == (1, 1) and st == 1 and pd == 0
+            and ops.conv1x1_supported(int(w.shape[1]), int(w.shape[0]), int(x.shape[2] * x.shape[3]))):
+        return ops.conv1x1(x, w, b, residual, 1 if relu else 0)
     y = F.conv2d(x, w, None, stride, padding, dilation, groups)
     if b is None and residual is None and not relu:
         return y

@@ -450,6 +450,45 @@ def mfma_a_fragments(wm):
     return wm.reshape(M // 16, 16, K // 4, 4).permute(0, 2, 3, 1).reshape(M // 16, K // 4, 64).contiguous()
 
 
+_FRAG_CACHE = {}
+
+
+def conv1x1_fragments(w):
+    """Cached MFMA A-fragment layout of a [Cout,Cin,1,1] (or [Cout,Cin]) weight, keyed by storage + version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _FRAG_CACHE.get(key)
+    if hit is None:
+        if len(_FRAG_CACHE) > 512:
+            _FRAG_CACHE.clear()
+        hit = (mfma_a_fragments(w.detach().reshape(w.shape[0], w.shape[1])), w)  # keep w alive: the key is its address
+        _FRAG_CACHE[key] = hit
+    return hit[0]
+
+
+def conv1x1_supported(cin, cout, hw):
+    return cin % 32 == 0 and cout % 64 == 0 and hw % 4 == 0
+
+
+def conv1x1(x, w, bias=None, residual=None, act=0):
+    """Pointwise convolution with fused epilogue: act(W x + bias (+ residual)); act 0 none | 1 ReLU | 2 SiLU.
+    x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1]."""
+    x = _need(x, torch.float32, "x")
+    n, cin, H, W = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    if int(w.shape[1]) != cin or not conv1x1_supported(cin, cout, H * W):
+        raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HW={H * W}")
+    frag = conv1x1_fragments(w)
+    y = torch.empty((n, cout, H, W), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _need(residual, torch.float32, "residual")
+        if tuple(residual.shape) != tuple(y.shape):
+            raise _capi.HealAmdError("conv1x1: residual shape mismatch")
+    with _Timed(f"conv1x1_{cin}_{cout}"):
+        _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
+                   _ptr(residual) if residual is not None else None, n, cin, cout, H * W, int(act), _ptr(y), _stream())
+    return y
+
+
 def resnext_bottleneck(x, w1_frag, b1, w2, b2, w3_frag, b3):
     """Fused stride-1 ResNeXt bottleneck (K7b).  x [n,C,H,W] -> y [n,C,H,W]."""
     x = _need(x, torch.float32, "x")

@@ -486,3 +486,38 @@ def test_depthwise_conv_vs_torch(k, stride, pad):
     ref = F.silu(F.conv2d(F.pad(x, pad).double(), w.double(), b.double(), stride, 0, 1, 48)).float()
     got = ops.depthwise_conv(x, w, b, stride, pad, "silu")
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,act,with_res,with_bias", [
+    (2, 64, 128, 32, 32, 1, False, True), (1, 128, 64, 16, 24, 1, True, True), (3, 256, 512, 8, 8, 0, False, False),
+    (1, 512, 256, 12, 16, 1, True, True), (2, 32, 64, 6, 10, 2, False, True), (1, 64, 192, 50, 2, 0, True, False)])
+def test_conv1x1_fused_vs_torch(n, cin, cout, H, W, act, with_res, with_bias):
+    """K7c: y = act(W x + b (+ res)).  fp32 MFMA accumulates in a different order than the library GEMM:
+    1e-4 relative to the output scale (the north-star tolerance for features is 1e-3)."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda() if with_bias else None
+    r = torch.randn((n, cout, H, W), generator=g).cuda() if with_res else None
+    got = ops.conv1x1(x, w, b, r, act)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double())
+    if r is not None:
+        ref = ref + r.double()
+    ref = torch.relu(ref) if act == 1 else torch.nn.functional.silu(ref) if act == 2 else ref
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    # the fragment cache must notice an in-place weight update
+    w.mul_(2.0)
+    got2 = ops.conv1x1(x, w, None, None, 0)
+    ref2 = torch.nn.functional.conv2d(x.double(), w.double())
+    assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-4
+
+
+def test_conv1x1_rejects_unsupported_shapes():
+    from heal_amd import _capi, ops
+    x = torch.randn((1, 48, 8, 8)).cuda()
+    with pytest.raises(_capi.HealAmdError):
+        ops.conv1x1(x, torch.randn((64, 48, 1, 1)).cuda())
+    with pytest.raises(_capi.HealAmdError):
+        ops.conv1x1(torch.randn((1, 64, 8, 8)).cuda(), torch.randn((24, 64, 1, 1)).cuda())
