@@ -16,6 +16,7 @@
 //   * XCD-contiguous block order with the Cout-chunk index fastest: the (<=4) blocks that re-read one pixel tile
 //     for different output-channel chunks share an L2.
 // Roofline: HBM-bound for Cin,Cout <= 128 (ridge 20 FLOP/B in fp32), MFMA-bound above; §6 of DESIGN.md.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/heal_amd.h"
 
@@ -23,73 +24,96 @@ namespace heal {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int C1_BN = 128;          // pixels per block
-constexpr int C1_KC = 32;           // input channels per LDS chunk
-constexpr int C1_LD = C1_BN + 16;   // LDS row stride (floats): 144 % 64 == 16 -> k-rows 0..3 hit banks 0-15,16-31,...
-
-template <int BM>
+template <int BM, int BN, int KC>
 __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 int Cin, int Cout, int HW, int act, float* __restrict__ y) {
-    constexpr int MT = BM / 64;     // m-tiles per wave
-    __shared__ __attribute__((aligned(16))) float sB[2][C1_KC][C1_LD];
+    constexpr int MT = BM / 64;      // m-tiles per wave
+    constexpr int NT = BN / 16;      // n-tiles per wave
+    constexpr int LD = BN + 16;      // LDS row stride (floats): LD % 64 == 16 -> k-rows 0..3 hit banks 0-15,16-31,...
+    constexpr int KS = KC / 4;       // k-steps per chunk
+    constexpr int TPR = BN / 4;      // staging: threads per row (one float4 each)
+    constexpr int RPP = 256 / TPR;   // rows per pass
+    constexpr int NPASS = KC / RPP;  // float4 loads per thread per chunk
+    static_assert(NPASS >= 1 && KC % RPP == 0, "bad staging shape");
+    __shared__ __attribute__((aligned(16))) float sB[2][KC][LD];
     const Block3 bk = xcd_block();  // x: Cout chunk, y: pixel tile, z: image
-    const int m0 = bk.x * BM, p0 = bk.y * C1_BN, n = bk.z;
+    const int m0 = bk.x * BM, p0 = bk.y * BN, n = bk.z;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
     const float* __restrict__ xin = x + (size_t)n * Cin * HW;
     const int ksteps = Cin / 4;     // k-steps of 4 channels over the whole K
-    const int nchunks = Cin / C1_KC;
-    // staging assignment: thread t -> channels t/32 + 8*i, pixels (t%32)*4 .. +3
-    const int sp = (threadIdx.x & 31) * 4, sc = threadIdx.x >> 5;
+    const int nchunks = Cin / KC;
+    const int sp = (threadIdx.x % TPR) * 4, sc = threadIdx.x / TPR;
     const bool pix_ok = p0 + sp < HW;  // HW % 4 == 0 (checked by the host): a float4 is all-in or all-out
 
-    f32x4 acc[MT][8];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 stage[4];
+    float4 stage[NPASS];
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = c * C1_KC + sc + 8 * i;
+        for (int i = 0; i < NPASS; ++i) {
+            const int ch = c * KC + sc + RPP * i;
             stage[i] = pix_ok ? *reinterpret_cast<const float4*>(xin + (size_t)ch * HW + p0 + sp)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sB[buf][sc + 8 * i][sp]) = stage[i];
+        for (int i = 0; i < NPASS; ++i) *reinterpret_cast<float4*>(&sB[buf][sc + RPP * i][sp]) = stage[i];
     };
 
+    // A fragments of one chunk: MT x KS coalesced 256-B loads per wave (weights stay L2-resident)
+    float a_cur[MT][KS], a_nxt[MT][KS];
+    auto load_a = [&](int c, float (&a)[MT][KS]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mtg = (m0 >> 4) + wave * MT + mt;  // global m-tile
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[mt][ks] = wfrag[((size_t)mtg * ksteps + c * KS + ks) * 64 + l];
+        }
+    };
+
+    load_a(0, a_cur);
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);  // in flight during the MFMA loop
-        float a[MT][C1_KC / 4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int mtg = (m0 >> 4) + wave * MT + mt;  // global m-tile
-#pragma unroll
-            for (int ks = 0; ks < C1_KC / 4; ++ks)
-                a[mt][ks] = wfrag[((size_t)mtg * ksteps + c * (C1_KC / 4) + ks) * 64 + l];
+        // Software pipeline: the NEXT chunk's A fragments and B rows are requested before this chunk's MFMAs, which
+        // depend on nothing outstanding (vmcnt is in-order: a load the MFMAs needed behind the HBM-latency B loads
+        // would stall the matrix pipe for the whole round trip).
+        if (c + 1 < nchunks) {
+            load_a(c + 1, a_nxt);
+            load_chunk(c + 1);
         }
+        // B fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run (register double buffer)
+        float bfr[2][NT];
 #pragma unroll
-        for (int ks = 0; ks < C1_KC / 4; ++ks) {
+        for (int nt = 0; nt < NT; ++nt) bfr[0][nt] = sB[buf][lk][nt * 16 + ln];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float b = sB[buf][ks * 4 + lk][nt * 16 + ln];
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bfr[(ks + 1) & 1][nt] = sB[buf][(ks + 1) * 4 + lk][nt * 16 + ln];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this k-step's MFMAs (the scheduler sinks it)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][ks], b, acc[mt][nt], 0, 0, 0);
-            }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][ks], bfr[ks & 1][nt], acc[mt][nt], 0, 0, 0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a_cur[mt][ks] = a_nxt[mt][ks];
     }
 
     // epilogue: D[row = lk*4 + r][col = ln] of tile (mt, nt)
@@ -102,7 +126,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             const int co = m0 + (wave * MT + mt) * 16 + lk * 4 + r;
             const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 const int p = p0 + nt * 16 + ln;
                 if (p >= HW) continue;
                 float v = acc[mt][nt][r] + bv;
@@ -123,18 +147,33 @@ using namespace heal;
 extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
                             int cin, int cout, int HW, int act, float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && HW >= 1, "conv1x1: bad shape");
-    HEAL_REQUIRE(cin % C1_KC == 0, "conv1x1: Cin must be a multiple of %d (got %d)", C1_KC, cin);
+    HEAL_REQUIRE(cin % 32 == 0, "conv1x1: Cin must be a multiple of 32 (got %d)", cin);
     HEAL_REQUIRE(cout % 64 == 0, "conv1x1: Cout must be a multiple of 64 (got %d)", cout);
     HEAL_REQUIRE(HW % 4 == 0, "conv1x1: H*W must be a multiple of 4 (got %d)", HW);
     HEAL_REQUIRE(act >= 0 && act <= 2, "conv1x1: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
     HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int ptiles = ceil_div(HW, C1_BN);
-    if (cout % 128 == 0) {
-        k_conv1x1<128><<<dim3(cout / 128, ptiles, n), 256, 0, s>>>(x, weight_frag, bias, residual, cin, cout, HW, act, y);
-    } else {
-        k_conv1x1<64><<<dim3(cout / 64, ptiles, n), 256, 0, s>>>(x, weight_frag, bias, residual, cin, cout, HW, act, y);
+    // Tile choice (BM, BN, KC).  Measured on MI355X at the PyramidFusion shapes (scripts/conv1x1_bench.py --sweep): the
+    // smallest tile wins everywhere (64 channels x 64 pixels: 48 VGPR + 16 AGPR, 20 KB LDS -> 8 waves/SIMD); the kernel
+    // is latency-bound between chunks and more resident blocks hide it better than a fatter tile's operand reuse.
+    // HEAL_C1_CFG="bm,bn,kc" overrides for tuning.
+    int bm = 64, bn = 64, kc = 32;
+    if (const char* e = getenv("HEAL_C1_CFG")) {
+        int a_ = 0, b_ = 0, c_ = 0;
+        if (sscanf(e, "%d,%d,%d", &a_, &b_, &c_) == 3) { bm = a_; bn = b_; kc = c_; }
     }
+    HEAL_REQUIRE(cout % bm == 0, "conv1x1: Cout %d not a multiple of the tile height %d", cout, bm);
+#define HEAL_C1(BM_, BN_, KC_)                                                                                   \
+    if (bm == BM_ && bn == BN_ && kc == KC_) {                                                                   \
+        k_conv1x1<BM_, BN_, KC_><<<dim3(cout / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                         \
+            x, weight_frag, bias, residual, cin, cout, HW, act, y);                                              \
+        launched = true;                                                                                         \
+    }
+    bool launched = false;
+    HEAL_C1(128, 128, 32) HEAL_C1(64, 128, 32) HEAL_C1(128, 64, 32) HEAL_C1(64, 64, 32)
+    HEAL_C1(128, 128, 16) HEAL_C1(64, 128, 16) HEAL_C1(128, 64, 16) HEAL_C1(64, 64, 16)
+#undef HEAL_C1
+    HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d)", bm, bn, kc);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -29,6 +29,17 @@ def main():
         b = torch.randn((cout,), device="cuda")
         r = torch.randn((n, cout, hw, hw), device="cuda") if res else None
         t_new = timeit(lambda: ops.conv1x1(x, w, b, r, 1))
+        if "--sweep" in sys.argv:
+            best = []
+            for bm in (128, 64):
+                for bn in (128, 64):
+                    for kc in (32, 16):
+                        if cout % bm:
+                            continue
+                        os.environ["HEAL_C1_CFG"] = f"{bm},{bn},{kc}"
+                        best.append((timeit(lambda: ops.conv1x1(x, w, b, r, 1), 10), bm, bn, kc))
+            os.environ.pop("HEAL_C1_CFG")
+            print("    sweep:", " ".join(f"({bm},{bn},{kc}):{t:.0f}" for t, bm, bn, kc in sorted(best)), flush=True)
         t_lib = timeit(lambda: ops.bias_act_(F.conv2d(x, w), b, r, True))
         flops = 2.0 * n * cin * cout * hw * hw
         byts = 4.0 * n * hw * hw * (cin + cout * (2 if res else 1))
