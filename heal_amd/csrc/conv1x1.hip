@@ -27,7 +27,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <int BM, int BN, int KC>
 __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
-                                                int Cin, int Cout, int HW, int act, float* __restrict__ y) {
+                                                const float* __restrict__ in_scale, int Cin, int Kpad, int Cout,
+                                                int HW, int act, float* __restrict__ y) {
     constexpr int MT = BM / 64;      // m-tiles per wave
     constexpr int NT = BN / 16;      // n-tiles per wave
     constexpr int LD = BN + 16;      // LDS row stride (floats): LD % 64 == 16 -> k-rows 0..3 hit banks 0-15,16-31,...
@@ -42,8 +43,9 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
     const float* __restrict__ xin = x + (size_t)n * Cin * HW;
-    const int ksteps = Cin / 4;     // k-steps of 4 channels over the whole K
-    const int nchunks = Cin / KC;
+    const int ksteps = Kpad / 4;    // k-steps of 4 channels over the (zero-padded) K of the fragment layout
+    const int nchunks = Kpad / KC;
+    const float* __restrict__ scl = in_scale ? in_scale + (size_t)n * Cin : nullptr;
     const int sp = (threadIdx.x % TPR) * 4, sc = threadIdx.x / TPR;
     const bool pix_ok = p0 + sp < HW;  // HW % 4 == 0 (checked by the host): a float4 is all-in or all-out
 
@@ -58,8 +60,13 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int ch = c * KC + sc + RPP * i;
-            stage[i] = pix_ok ? *reinterpret_cast<const float4*>(xin + (size_t)ch * HW + p0 + sp)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix_ok && ch < Cin) {
+                float4 v = *reinterpret_cast<const float4*>(xin + (size_t)ch * HW + p0 + sp);
+                if (scl) { const float g = scl[ch]; v.x *= g; v.y *= g; v.z *= g; v.w *= g; }
+                stage[i] = v;
+            } else {
+                stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto store_chunk = [&](int buf) {
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = m0 + (wave * MT + mt) * 16 + lk * 4 + r;
+            if (co >= Cout) continue;
             const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -144,11 +152,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
 
 using namespace heal;
 
-extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
-                            int cin, int cout, int HW, int act, float* y, void* stream) {
-    HEAL_REQUIRE(n >= 1 && HW >= 1, "conv1x1: bad shape");
-    HEAL_REQUIRE(cin % 32 == 0, "conv1x1: Cin must be a multiple of 32 (got %d)", cin);
-    HEAL_REQUIRE(cout % 64 == 0, "conv1x1: Cout must be a multiple of 64 (got %d)", cout);
+extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
+                            const float* in_scale, int n, int cin, int cout, int HW, int act, float* y,
+                            void* stream) {
+    HEAL_REQUIRE(n >= 1 && HW >= 1 && cin >= 1 && cout >= 1, "conv1x1: bad shape");
+    const int kpad = (cin + 31) / 32 * 32, mpad = (cout + 63) / 64 * 64;  // dims of the zero-padded fragment layout
     HEAL_REQUIRE(HW % 4 == 0, "conv1x1: H*W must be a multiple of 4 (got %d)", HW);
     HEAL_REQUIRE(act >= 0 && act <= 2, "conv1x1: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
     HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
@@ -162,11 +170,11 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
         int a_ = 0, b_ = 0, c_ = 0;
         if (sscanf(e, "%d,%d,%d", &a_, &b_, &c_) == 3) { bm = a_; bn = b_; kc = c_; }
     }
-    HEAL_REQUIRE(cout % bm == 0, "conv1x1: Cout %d not a multiple of the tile height %d", cout, bm);
+    HEAL_REQUIRE(mpad % bm == 0, "conv1x1: padded Cout %d not a multiple of the tile height %d", mpad, bm);
 #define HEAL_C1(BM_, BN_, KC_)                                                                                   \
     if (bm == BM_ && bn == BN_ && kc == KC_) {                                                                   \
-        k_conv1x1<BM_, BN_, KC_><<<dim3(cout / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                         \
-            x, weight_frag, bias, residual, cin, cout, HW, act, y);                                              \
+        k_conv1x1<BM_, BN_, KC_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                         \
+            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, act, y);                              \
         launched = true;                                                                                         \
     }
     bool launched = false;

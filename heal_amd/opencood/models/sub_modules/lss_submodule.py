@@ -64,8 +64,17 @@ class _SamePadConv2d(nn.Conv2d):
         self.static_padding = nn.ZeroPad2d(self.same_pad) if (pad_h > 0 or pad_w > 0) else nn.Identity()
 
 
-def _conv_bn(x, conv, bn, cache, act):
+def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None):
+    """conv + folded BatchNorm (+ SiLU).  Pointwise convolutions run on heal_conv1x1 with the squeeze-excite gate
+    (in_scale, per image and input channel), the bias, the skip connection and the activation fused."""
     w, b = cache.get(conv, bn)
+    if (x.is_cuda and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
+            and not any(conv.same_pad)):
+        from heal_amd import ops
+        if ops.conv1x1_supported(conv.in_channels, conv.out_channels, int(x.shape[2] * x.shape[3])):
+            return ops.conv1x1(x, w, b, residual, 2 if act else 0, in_scale)
+    if in_scale is not None:
+        x = in_scale * x
     if (x.is_cuda and conv.groups == conv.in_channels == conv.out_channels and conv.kernel_size[0] in (3, 5)
             and conv.stride[0] in (1, 2) and x.shape[0] * conv.in_channels <= 65535):
         from heal_amd import ops
@@ -73,7 +82,8 @@ def _conv_bn(x, conv, bn, cache, act):
     if any(conv.same_pad):
         x = F.pad(x, conv.same_pad)
     y = F.conv2d(x, w, b, conv.stride, 0, 1, conv.groups)
-    return F.silu(y, inplace=True) if act else y
+    y = F.silu(y, inplace=True) if act else y
+    return y + residual if residual is not None else y
 
 
 class _MBConv(nn.Module):
@@ -103,9 +113,9 @@ class _MBConv(nn.Module):
         s = F.adaptive_avg_pool2d(x, 1)
         s = F.conv2d(F.silu(F.conv2d(s, self._se_reduce.weight, self._se_reduce.bias)), self._se_expand.weight,
                      self._se_expand.bias)
-        x = torch.sigmoid(s) * x
-        x = _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False)
-        return x + inp if self.id_skip else x
+        # lss_submodule.py trunk (efficientnet_pytorch MBConvBlock): x = sigmoid(s) * x; project; (+ skip)
+        return _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False, in_scale=torch.sigmoid(s),
+                        residual=inp if self.id_skip else None)
 
 
 class EfficientNetB0(nn.Module):

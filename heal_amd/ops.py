@@ -454,28 +454,34 @@ _FRAG_CACHE = {}
 
 
 def conv1x1_fragments(w):
-    """Cached MFMA A-fragment layout of a [Cout,Cin,1,1] (or [Cout,Cin]) weight, keyed by storage + version."""
+    """Cached MFMA A-fragment layout of a [Cout,Cin,1,1] (or [Cout,Cin]) weight, zero-padded to [ceil64(Cout),
+    ceil32(Cin)], keyed by storage + version."""
     key = (w.data_ptr(), w._version, tuple(w.shape))
     hit = _FRAG_CACHE.get(key)
     if hit is None:
-        if len(_FRAG_CACHE) > 512:
+        if len(_FRAG_CACHE) > 1024:
             _FRAG_CACHE.clear()
-        hit = (mfma_a_fragments(w.detach().reshape(w.shape[0], w.shape[1])), w)  # keep w alive: the key is its address
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        mpad, kpad = (cout + 63) // 64 * 64, (cin + 31) // 32 * 32
+        wm = w.detach().reshape(cout, cin)
+        if (mpad, kpad) != (cout, cin):
+            wm = torch.nn.functional.pad(wm, (0, kpad - cin, 0, mpad - cout))
+        hit = (mfma_a_fragments(wm), w)  # keep w alive: the key is its address
         _FRAG_CACHE[key] = hit
     return hit[0]
 
 
 def conv1x1_supported(cin, cout, hw):
-    return cin % 32 == 0 and cout % 64 == 0 and hw % 4 == 0
+    return hw % 4 == 0 and hw >= 64
 
 
-def conv1x1(x, w, bias=None, residual=None, act=0):
-    """Pointwise convolution with fused epilogue: act(W x + bias (+ residual)); act 0 none | 1 ReLU | 2 SiLU.
-    x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1]."""
+def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None):
+    """Pointwise convolution with fused prologue / epilogue: act(W (in_scale . x) + bias (+ residual));
+    act 0 none | 1 ReLU | 2 SiLU.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin] (any trailing 1-dims)."""
     x = _need(x, torch.float32, "x")
     n, cin, H, W = (int(v) for v in x.shape)
     cout = int(w.shape[0])
-    if int(w.shape[1]) != cin or not conv1x1_supported(cin, cout, H * W):
+    if int(w.shape[1]) != cin or (H * W) % 4 != 0:
         raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HW={H * W}")
     frag = conv1x1_fragments(w)
     y = torch.empty((n, cout, H, W), dtype=torch.float32, device=x.device)
@@ -483,9 +489,12 @@ def conv1x1(x, w, bias=None, residual=None, act=0):
         residual = _need(residual, torch.float32, "residual")
         if tuple(residual.shape) != tuple(y.shape):
             raise _capi.HealAmdError("conv1x1: residual shape mismatch")
+    if in_scale is not None:
+        in_scale = _need(in_scale.reshape(n, cin), torch.float32, "in_scale")
     with _Timed(f"conv1x1_{cin}_{cout}"):
         _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
-                   _ptr(residual) if residual is not None else None, n, cin, cout, H * W, int(act), _ptr(y), _stream())
+                   _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
+                   n, cin, cout, H * W, int(act), _ptr(y), _stream())
     return y
 
 

@@ -232,13 +232,17 @@ int heal_depthwise_conv(const float* x, const float* weight, const float* bias, 
                         int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y,
                         void* stream);
 
-/* heal_conv1x1: pointwise convolution with fused epilogue, y = act(W x + bias (+ residual)); the conv1x1 + BatchNorm
- *   (+ identity) + ReLU sequences of the ResNeXt bottleneck (opencood/models/sub_modules/resblock.py:95-121) with the
- *   BatchNorm folded into W / bias by the caller.  x [n,Cin,H,W], y/residual [n,Cout,H,W] f32 NCHW; Cin % 32 == 0,
- *   Cout % 64 == 0, H*W % 4 == 0; weight_frag = W [Cout,Cin] in MFMA A-fragment order
- *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)]; act 0 none | 1 ReLU | 2 SiLU.            */
-int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
-                 int cin, int cout, int HW, int act, float* y, void* stream);
+/* heal_conv1x1: pointwise convolution with fused prologue/epilogue,
+ *     y = act(W (in_scale . x) + bias (+ residual)),
+ *   i.e. the conv1x1 + BatchNorm (+ identity) + ReLU sequences of the ResNeXt bottleneck
+ *   (opencood/models/sub_modules/resblock.py:95-121) and the expand / squeeze-excite-scale + project (+ skip) stages of
+ *   the EfficientNet MBConv blocks of the Lift-Splat trunk (lss_submodule.py:93-105), BatchNorm folded into W / bias by
+ *   the caller.  x [n,Cin,H,W], y/residual [n,Cout,H,W] f32 NCHW, H*W % 4 == 0; in_scale [n,Cin] or NULL (per-image,
+ *   per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU.
+ *   weight_frag = W zero-padded to [Mpad = ceil64(Cout), Kpad = ceil32(Cin)] in MFMA A-fragment order
+ *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)], mt < Mpad/16, ks < Kpad/4.                */
+int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
+                 const float* in_scale, int n, int cin, int cout, int HW, int act, float* y, void* stream);
 
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265

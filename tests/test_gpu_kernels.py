@@ -514,10 +514,29 @@ def test_conv1x1_fused_vs_torch(n, cin, cout, H, W, act, with_res, with_bias):
     assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,H,W", [(2, 48, 24, 8, 8), (4, 96, 16, 12, 16), (1, 16, 96, 24, 32), (3, 240, 40, 6, 8),
+                                            (1, 256, 2, 16, 16), (2, 3, 5, 4, 4)])
+def test_conv1x1_padded_shapes_gate_and_skip(n, cin, cout, H, W):
+    """EfficientNet MBConv project stage: y = W (sigmoid(s) . x) + b (+ skip), channel counts that are not multiples
+    of the 64 x 32 tile (zero-padded fragments, guarded rows)."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(cin + 1000 * cout)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    gate = torch.sigmoid(torch.randn((n, cin, 1, 1), generator=g)).cuda()
+    skip = torch.randn((n, cout, H, W), generator=g).cuda()
+    got = ops.conv1x1(x, w, b, skip, 0, in_scale=gate)
+    ref = torch.nn.functional.conv2d((gate * x).double(), w.double(), b.double()) + skip.double()
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+    got = ops.conv1x1(x, w, b, None, 2)
+    ref = torch.nn.functional.silu(torch.nn.functional.conv2d(x.double(), w.double(), b.double()))
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
 def test_conv1x1_rejects_unsupported_shapes():
     from heal_amd import _capi, ops
-    x = torch.randn((1, 48, 8, 8)).cuda()
-    with pytest.raises(_capi.HealAmdError):
-        ops.conv1x1(x, torch.randn((64, 48, 1, 1)).cuda())
-    with pytest.raises(_capi.HealAmdError):
-        ops.conv1x1(torch.randn((1, 64, 8, 8)).cuda(), torch.randn((24, 64, 1, 1)).cuda())
+    with pytest.raises(_capi.HealAmdError):  # H*W must be a multiple of 4 (16-byte rows)
+        ops.conv1x1(torch.randn((1, 64, 3, 5)).cuda(), torch.randn((64, 64, 1, 1)).cuda())
+    with pytest.raises(_capi.HealAmdError):  # Cin mismatch
+        ops.conv1x1(torch.randn((1, 64, 8, 8)).cuda(), torch.randn((24, 32, 1, 1)).cuda())
