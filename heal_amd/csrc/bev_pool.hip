@@ -283,6 +283,43 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
     }
 }
 
+// One thread per camera: the 3x3 algebra of get_geometry (closed-form adjugate inverses, fp32) in ONE launch instead
+// of ~90 tiny elementwise kernels per camera modality.
+__device__ __forceinline__ void inv3x3(const float* m, float* o) {
+    const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const float A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
+    const float D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
+    const float G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
+    const float det = a * A + b * D + c * G;
+    o[0] = A / det; o[1] = B / det; o[2] = C / det;
+    o[3] = D / det; o[4] = E / det; o[5] = F / det;
+    o[6] = G / det; o[7] = H / det; o[8] = I / det;
+}
+
+__global__ __launch_bounds__(64) void k_camera_matrices(const float* __restrict__ rots, const float* __restrict__ trans,
+                                                       const float* __restrict__ intrins,
+                                                       const float* __restrict__ post_rots,
+                                                       const float* __restrict__ post_trans, int n,
+                                                       float* __restrict__ out /*[n,27]*/) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n) return;
+    float ii[9], R[9], K[9], P[9], ip[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R[k] = rots[t * 9 + k]; K[k] = intrins[t * 9 + k]; P[k] = post_rots[t * 9 + k]; }
+    inv3x3(K, ii);
+    inv3x3(P, ip);
+    float* o = out + (size_t)t * 27;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)  // combine = rots @ inv(intrins), summed left to right like a matmul row
+            o[r * 3 + c] = (R[r * 3 + 0] * ii[0 * 3 + c] + R[r * 3 + 1] * ii[1 * 3 + c]) + R[r * 3 + 2] * ii[2 * 3 + c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[9 + k] = ip[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[18 + k] = post_trans[t * 3 + k]; o[21 + k] = trans[t * 3 + k]; o[24 + k] = 0.f; }
+}
+
 struct LssWs {
     uint32_t *keys[2], *vals[2];
     float *probs, *featT, *rows, *partial;
@@ -307,6 +344,16 @@ static bool carve(Arena& a, int n_agents, int n_cams, int D, int HW, int C, int 
 }  // namespace heal
 
 using namespace heal;
+
+extern "C" int heal_camera_matrices(const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                                    const float* post_trans, int n_cameras, float* cam_mats, void* stream) {
+    HEAL_REQUIRE(n_cameras >= 1, "camera_matrices: no cameras");
+    HEAL_REQUIRE(rots && trans && intrins && post_rots && post_trans && cam_mats, "camera_matrices: null pointer");
+    k_camera_matrices<<<ceil_div(n_cameras, 64), 64, 0, (hipStream_t)stream>>>(rots, trans, intrins, post_rots, post_trans,
+                                                                            n_cameras, cam_mats);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" size_t heal_bev_pool_workspace(int n_agents, int n_cams, int D, int fH, int fW, int channels,
                                           int nx, int ny, int nz) {

@@ -168,29 +168,10 @@ class LiftSplatShoot(nn.Module):
         return self._frustum_dev[key]
 
     @staticmethod
-    def _inv3x3(m):
-        """Closed-form inverse of [...,3,3] matrices (adjugate / determinant) from elementwise device ops:
-        no LAPACK call, no host synchronisation, capturable in a HIP graph."""
-        a, b, c = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
-        d, e, f = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
-        g, h, i = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
-        A, B, C = e * i - f * h, c * h - b * i, b * f - c * e
-        D, E, F_ = f * g - d * i, a * i - c * g, c * d - a * f
-        G, H, I = d * h - e * g, b * g - a * h, a * e - b * d
-        det = a * A + b * D + c * G
-        adj = torch.stack([torch.stack([A, B, C], -1), torch.stack([D, E, F_], -1), torch.stack([G, H, I], -1)], -2)
-        return adj / det[..., None, None]
-
-    @staticmethod
     def camera_matrices(rots, trans, intrins, post_rots, post_trans):
-        """The 3x3 algebra of get_geometry (heter_encoders.py:137-146) as device ops:
-        [B,N,...] -> [B*N, 27] = combine | inv(post_rots) | post_trans | trans | 0."""
-        B, N = trans.shape[:2]
-        combine = rots.matmul(LiftSplatShoot._inv3x3(intrins)).reshape(B * N, 9)
-        ipr = LiftSplatShoot._inv3x3(post_rots).reshape(B * N, 9)
-        pad = torch.zeros((B * N, 3), dtype=torch.float32, device=trans.device)
-        return torch.cat([combine.float(), ipr.float(), post_trans.reshape(B * N, 3).float(),
-                          trans.reshape(B * N, 3).float(), pad], dim=1).contiguous()
+        """The 3x3 algebra of get_geometry (heter_encoders.py:137-146) on the device, one launch
+        (heal_camera_matrices): [B,N,...] -> [B*N, 27] = rots @ inv(intrins) | inv(post_rots) | post_trans | trans | 0."""
+        return ops.camera_matrices(rots, trans, intrins, post_rots, post_trans)
 
     def pool(self, depth_logit, x_img, cam_mats, B, N):
         return ops.bev_pool(depth_logit, x_img, self.frustum(x_img.device), cam_mats, B, N, self.dx_host,

@@ -271,6 +271,21 @@ def nms_bev(boxes_sorted, thresh, rotated=True):
     return keep, count
 
 
+def camera_matrices(rots, trans, intrins, post_rots, post_trans):
+    """[B,N,3,3] / [B,N,3] device tensors -> cam_mats [B*N,27] f32 (rots @ inv(intrins) | inv(post_rots) | post_trans |
+    trans | 0): the 3x3 algebra of get_geometry in one launch."""
+    f = lambda t, name: _need(t.float() if t.dtype != torch.float32 else t, torch.float32, name)
+    rots, trans, intrins = f(rots, "rots"), f(trans, "trans"), f(intrins, "intrins")
+    post_rots, post_trans = f(post_rots, "post_rots"), f(post_trans, "post_trans")
+    n = int(trans.numel() // 3)
+    if rots.numel() != 9 * n or intrins.numel() != 9 * n or post_rots.numel() != 9 * n or post_trans.numel() != 3 * n:
+        raise _capi.HealAmdError("camera_matrices: inconsistent shapes")
+    out = torch.empty((n, 27), dtype=torch.float32, device=trans.device)
+    _capi.call("heal_camera_matrices", _ptr(rots), _ptr(trans), _ptr(intrins), _ptr(post_rots), _ptr(post_trans), n,
+               _ptr(out), _stream())
+    return out
+
+
 def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
     """K4.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum [D,fH,fW,3]
     (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,

@@ -136,6 +136,11 @@ int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void
  *   dx,bx host 3 floats each, nx host 3 ints (gen_dx_bx, camera_utils.py:129-134)
  *   out [n_agents, C*nz, ny, nx] f32, every element written
  * -----------------------------------------------------------------------------------------------*/
+/* heal_camera_matrices: the per-camera 3x3 algebra of get_geometry (heter_encoders.py:137-146): fills the `cam_mats`
+ *   rows consumed by heal_bev_pool from rots/intrins/post_rots [n,3,3] and trans/post_trans [n,3] (all f32 device),
+ *   inverses in closed form (adjugate / determinant) -- one launch, no host round trip.                          */
+int heal_camera_matrices(const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                         const float* post_trans, int n_cameras, float* cam_mats, void* stream);
 size_t heal_bev_pool_workspace(int n_agents, int n_cams, int D, int fH, int fW, int channels,
                                int nx, int ny, int nz);
 int heal_bev_pool(const float* depth_logit, const float* feat, const float* frustum,
