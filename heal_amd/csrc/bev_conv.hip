@@ -166,6 +166,46 @@ extern "C" int heal_depthwise_conv(const float* x, const float* weight, const fl
     return set_error("depthwise_conv: kernel %d stride %d is not instantiated", ksize, stride);
 }
 
+namespace heal {
+// Squeeze-excite gate of an MBConv block in one launch: gate[n][c] = sigmoid(W2 silu(W1 m[n] + b1) + b2)[c] with m the
+// spatial mean [n,C], W1 [S,C], W2 [C,S] (S <= 64).  One block per image; replaces conv / SiLU / conv / sigmoid
+// launches on 1x1 maps.
+__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                const float* __restrict__ b2, int C, int S,
+                                                float* __restrict__ gate) {
+    __shared__ float hid[64];
+    const int n = blockIdx.x;
+    const float* m = mean + (size_t)n * C;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int j = wave; j < S; j += 4) {  // one wave per hidden unit: coalesced row of W1, tree reduction
+        float acc = 0.f;
+        for (int c = l; c < C; c += 64) acc = fmaf(w1[(size_t)j * C + c], m[c], acc);
+        acc = wave_sum(acc);
+        if (l == 0) {
+            const float v = acc + b1[j];
+            hid[j] = v / (1.f + expf(-v));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = b2[c];
+        for (int j = 0; j < S; ++j) acc = fmaf(w2[(size_t)c * S + j], hid[j], acc);
+        gate[(size_t)n * C + c] = 1.f / (1.f + expf(-acc));
+    }
+}
+}  // namespace heal
+
+extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand,
+                            const float* b_expand, int n, int channels, int squeezed, float* gate, void* stream) {
+    HEAL_REQUIRE(n >= 1 && channels >= 1 && squeezed >= 1 && squeezed <= 64, "se_gate: squeezed channels must be in [1,64]");
+    HEAL_REQUIRE(mean && w_reduce && b_reduce && w_expand && b_expand && gate, "se_gate: null pointer");
+    heal::k_se_gate<<<n, 256, 0, (hipStream_t)stream>>>(mean, w_reduce, b_reduce, w_expand, b_expand, channels, squeezed,
+                                                      gate);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream) {
     const long long total = (long long)n * channels * (2 * H) * (2 * W);
     if (total <= 0) return 0;

@@ -40,3 +40,25 @@ def record_len_to_list(record_len):
     if isinstance(record_len, torch.Tensor):
         return [int(v) for v in record_len.detach().cpu().tolist()]
     return [int(v) for v in record_len]
+
+
+def detection_heads(x, cls_head, reg_head, dir_head):
+    """cls / reg / dir 1x1 heads (heter_pyramid_collab.py:102-107,198-200) as ONE pointwise convolution over the
+    concatenated output channels (the input map is read once instead of three times); returns the three channel
+    slices.  The concatenated weight is cached per parameter version."""
+    from heal_amd import ops
+    heads = (cls_head, reg_head, dir_head)
+    if not (x.is_cuda and ops.conv1x1_supported(x.shape[1], 1, int(x.shape[2] * x.shape[3]))
+            and all(h.kernel_size == (1, 1) and h.stride == (1, 1) for h in heads)):
+        return cls_head(x), reg_head(x), dir_head(x)
+    key = tuple((h.weight.data_ptr(), h.weight._version, h.bias.data_ptr(), h.bias._version) for h in heads)
+    hit = cls_head.__dict__.get("_heal_fused_heads")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            w = torch.cat([h.weight for h in heads], 0).contiguous()
+            b = torch.cat([h.bias for h in heads], 0).contiguous()
+        hit = (key, w, b)
+        cls_head.__dict__["_heal_fused_heads"] = hit  # plain attribute: not a parameter, not in the state_dict
+    y = ops.conv1x1(x, hit[1], hit[2], None, 0)
+    c0, c1 = cls_head.out_channels, cls_head.out_channels + reg_head.out_channels
+    return y[:, :c0], y[:, c0:c1], y[:, c1:]

@@ -6,7 +6,7 @@ from collections import Counter, OrderedDict
 import torch
 import torch.nn as nn
 
-from heal_amd.opencood.models._heter_common import center_crop, find_encoder, modality_names
+from heal_amd.opencood.models._heter_common import detection_heads, center_crop, find_encoder, modality_names
 from heal_amd.opencood.models.fuse_modules.fusion_in_one import AttFusion, MaxFusion, V2XViTFusion
 from heal_amd.opencood.models.sub_modules.base_bev_backbone import BaseBEVBackbone
 from heal_amd.opencood.models.sub_modules.bev_blocks import DownsampleConv, NaiveCompressor
@@ -106,6 +106,6 @@ class HeterModelBaseline(nn.Module):
         fused = self.fusion_net(x, record_len, affine_matrix)
         if self.shrink_flag:
             fused = self.shrink_conv(fused)
-        output_dict.update({"cls_preds": self.cls_head(fused), "reg_preds": self.reg_head(fused),
-                            "dir_preds": self.dir_head(fused)})
+        cls_preds, reg_preds, dir_preds = detection_heads(fused, self.cls_head, self.reg_head, self.dir_head)
+        output_dict.update({"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds})
         return output_dict

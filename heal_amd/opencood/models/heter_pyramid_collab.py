@@ -7,7 +7,7 @@ from collections import Counter, OrderedDict
 import torch
 import torch.nn as nn
 
-from heal_amd.opencood.models._heter_common import center_crop, find_encoder, modality_names, record_len_to_list
+from heal_amd.opencood.models._heter_common import detection_heads, center_crop, find_encoder, modality_names, record_len_to_list
 from heal_amd.opencood.models.fuse_modules.pyramid_fuse import PyramidFusion
 from heal_amd.opencood.models.sub_modules.bev_blocks import (AlignNet, DownsampleConv, NaiveCompressor,
                                                              ResNetBEVBackbone)
@@ -77,7 +77,7 @@ class HeterPyramidCollab(nn.Module):
     def heads(self, fused_feature):
         if self.shrink_flag:
             fused_feature = self.shrink_conv(fused_feature)
-        return self.cls_head(fused_feature), self.reg_head(fused_feature), self.dir_head(fused_feature)
+        return detection_heads(fused_feature, self.cls_head, self.reg_head, self.dir_head)
 
     def forward(self, data_dict):
         output_dict = {"pyramid": "collab"}

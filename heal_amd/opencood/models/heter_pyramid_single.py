@@ -5,7 +5,7 @@ from collections import OrderedDict
 
 import torch.nn as nn
 
-from heal_amd.opencood.models._heter_common import center_crop, find_encoder, modality_names
+from heal_amd.opencood.models._heter_common import detection_heads, center_crop, find_encoder, modality_names
 from heal_amd.opencood.models.fuse_modules.pyramid_fuse import PyramidFusion
 from heal_amd.opencood.models.sub_modules.bev_blocks import AlignNet, DownsampleConv, ResNetBEVBackbone
 
@@ -64,6 +64,7 @@ class HeterPyramidSingle(nn.Module):
         feature, occ_map_list = self.pyramid_backbone.forward_single(feature)
         if self.shrink_flag:
             feature = self.shrink_conv(feature)
-        output_dict.update({"cls_preds": self.cls_head(feature), "reg_preds": self.reg_head(feature),
-                            "dir_preds": self.dir_head(feature), "occ_single_list": occ_map_list})
+        cls_preds, reg_preds, dir_preds = detection_heads(feature, self.cls_head, self.reg_head, self.dir_head)
+        output_dict.update({"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds,
+                            "occ_single_list": occ_map_list})
         return output_dict

@@ -110,11 +110,11 @@ class _MBConv(nn.Module):
         if self.expand != 1:
             x = _conv_bn(x, self._expand_conv, self._bn0, self._c[0], act=True)
         x = _conv_bn(x, self._depthwise_conv, self._bn1, self._c[1], act=True)
-        s = F.adaptive_avg_pool2d(x, 1)
-        s = F.conv2d(F.silu(F.conv2d(s, self._se_reduce.weight, self._se_reduce.bias)), self._se_expand.weight,
-                     self._se_expand.bias)
-        # lss_submodule.py trunk (efficientnet_pytorch MBConvBlock): x = sigmoid(s) * x; project; (+ skip)
-        return _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False, in_scale=torch.sigmoid(s),
+        # efficientnet_pytorch MBConvBlock: s = expand(silu(reduce(avgpool(x)))); x = sigmoid(s) * x; project; (+ skip)
+        from heal_amd import ops
+        gate = ops.se_gate(x.mean((2, 3)), self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight,
+                           self._se_expand.bias)
+        return _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False, in_scale=gate[:, :, None, None],
                         residual=inp if self.id_skip else None)
 
 

@@ -540,3 +540,16 @@ def test_conv1x1_rejects_unsupported_shapes():
         ops.conv1x1(torch.randn((1, 64, 3, 5)).cuda(), torch.randn((64, 64, 1, 1)).cuda())
     with pytest.raises(_capi.HealAmdError):  # Cin mismatch
         ops.conv1x1(torch.randn((1, 64, 8, 8)).cuda(), torch.randn((24, 32, 1, 1)).cuda())
+
+
+def test_se_gate_vs_torch():
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for n, C, S in ((4, 96, 4), (2, 1152, 48), (1, 32, 8), (3, 240, 10)):
+        m = torch.randn((n, C, 1, 1), generator=g).cuda()
+        w1 = (torch.randn((S, C, 1, 1), generator=g) / C ** 0.5).cuda(); b1 = torch.randn((S,), generator=g).cuda()
+        w2 = (torch.randn((C, S, 1, 1), generator=g) / S ** 0.5).cuda(); b2 = torch.randn((C,), generator=g).cuda()
+        ref = torch.sigmoid(torch.nn.functional.conv2d(torch.nn.functional.silu(
+            torch.nn.functional.conv2d(m.double(), w1.double(), b1.double())), w2.double(), b2.double()))
+        got = ops.se_gate(m, w1, b1, w2, b2)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.float().reshape(n, C).cpu().numpy(), rtol=1e-5, atol=1e-6)
