@@ -123,28 +123,44 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             for (int ks = 0; ks < KS; ++ks) a_cur[mt][ks] = a_nxt[mt][ks];
     }
 
-    // epilogue: D[row = lk*4 + r][col = ln] of tile (mt, nt)
+    // Epilogue.  MFMA leaves D[row = lk*4 + r][col = ln] per (mt, nt): written directly, a store instruction covers 4 rows
+    // x 64 B.  Instead each wave transposes its 16 x BN tile through its own LDS slice (the B buffers are free after the
+    // last barrier) and streams float4 rows: BN*4-byte contiguous segments for the stores and the residual loads.
+    constexpr int LDO = BN + 4;                       // 68 | 132 floats: (lk*4*LDO + ln) % 64 distinct -> conflict-free
+    static_assert(4 * 16 * LDO <= 2 * KC * LD, "epilogue tile does not fit the B buffers");
+    float* so = &sB[0][0][0] + wave * (16 * LDO);
     float* __restrict__ yout = y + (size_t)n * Cout * HW;
     const float* __restrict__ rin = res ? res + (size_t)n * Cout * HW : nullptr;
+    constexpr int F4_PER_ROW = BN / 4, ITERS = 16 * F4_PER_ROW / 64;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = m0 + (wave * MT + mt) * 16 + lk * 4 + r;
-            if (co >= Cout) continue;
-            const float bv = bias ? bias[co] : 0.f;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int p = p0 + nt * 16 + ln;
-                if (p >= HW) continue;
-                float v = acc[mt][nt][r] + bv;
-                const size_t o = (size_t)co * HW + p;
-                if (rin) v += rin[o];
-                if (act == 1) v = fmaxf(v, 0.f);
-                else if (act == 2) v = v / (1.f + expf(-v));
-                yout[o] = v;
+            for (int r = 0; r < 4; ++r) so[(lk * 4 + r) * LDO + nt * 16 + ln] = acc[mt][nt][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int idx = i * 64 + l, row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
+            const int co = m0 + (wave * MT + mt) * 16 + row, p = p0 + c4 * 4;
+            if (co >= Cout || p >= HW) continue;
+            float4 v = *reinterpret_cast<const float4*>(&so[row * LDO + c4 * 4]);
+            const float bv = bias ? bias[co] : 0.f;
+            const size_t o = (size_t)co * HW + p;
+            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            if (rin) {
+                const float4 q = *reinterpret_cast<const float4*>(rin + o);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
             }
+            if (act == 1) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (act == 2) {
+                v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
+                v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+            }
+            *reinterpret_cast<float4*>(yout + o) = v;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -179,7 +195,6 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
     }
     bool launched = false;
     HEAL_C1(128, 128, 32) HEAL_C1(64, 128, 32) HEAL_C1(128, 64, 32) HEAL_C1(64, 64, 32)
-    HEAL_C1(128, 128, 16) HEAL_C1(64, 128, 16) HEAL_C1(128, 64, 16) HEAL_C1(64, 64, 16)
 #undef HEAL_C1
     HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d)", bm, bn, kc);
     HEAL_LAUNCH_CHECK();
