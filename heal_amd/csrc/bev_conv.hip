@@ -168,65 +168,43 @@ extern "C" int heal_depthwise_conv(const float* x, const float* weight, const fl
 
 namespace heal {
 // Squeeze-excite gate of an MBConv block in one launch: gate[n][c] = sigmoid(W2 silu(W1 m[n] + b1) + b2)[c] with m the
-// spatial mean [n,C], W1 [S,C], W2 [C,S] (S <= 64).  One block per image; replaces conv / SiLU / conv / sigmoid
-// launches on 1x1 maps.
-__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ mean, const float* __restrict__ w1,
-                                                const float* __restrict__ b1, const float* __restrict__ w2,
-                                                const float* __restrict__ b2, int C, int S,
-                                                float* __restrict__ gate) {
-    // grid (ceil(C/256), n): every block recomputes the S hidden units (S*C MACs, all loads independent and coalesced:
-    // thread t owns channels t, t+256, ... and keeps S partial sums), then gates its own 256-channel slice.
-    __shared__ float part[4][64];
+// spatial mean [n,C], W1 [S,C], W2 given TRANSPOSED [S,C] (S <= 64).  One 16-wave block per image; replaces the conv /
+// SiLU / conv / sigmoid launches on 1x1 maps.  Kept deliberately small in code size: a fully unrolled variant was 5x
+// faster in isolation and 5x SLOWER inside the pipeline (cold instruction fetch between hundreds of other kernels).
+__global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                 const float* __restrict__ b2, int C, int S,
+                                                 float* __restrict__ gate) {
     __shared__ float hid[64];
-    const int n = blockIdx.y;
+    const int n = blockIdx.x;
     const float* m = mean + (size_t)n * C;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    float acc[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) acc[j] = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float mc = m[c];
-        // branch-free on purpose: a uniform `if (j < S)` around each load makes the compiler wait out every load
-        // before the next branch (measured 70 us); clamped rows keep all 64 loads independent and in flight
-#pragma unroll
-        for (int j = 0; j < 64; ++j) acc[j] = fmaf(w1[(size_t)min(j, S - 1) * C + c], mc, acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (j < S) {  // uniform
-            const float v = wave_sum(acc[j]);
-            if (l == 0) part[wave][j] = v;
+    for (int j = wave; j < S; j += 16) {  // one wave per hidden unit: coalesced row of W1, tree reduction
+        const float* wr = w1 + (size_t)j * C;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int c = l; c < C; c += 64) acc = fmaf(wr[c], m[c], acc);
+        acc = wave_sum(acc);
+        if (l == 0) {
+            const float v = acc + b1[j];
+            hid[j] = v / (1.f + expf(-v));
         }
     }
     __syncthreads();
-    if (threadIdx.x < S) {
-        const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]
-                        + b1[threadIdx.x];
-        hid[threadIdx.x] = v / (1.f + expf(-v));
-    }
-    __syncthreads();
-    // expand: wave w owns channels c0 + 64w .. +63; per channel the S products sit on lanes 0..S-1 (one coalesced row of
-    // W2 per step, independent loads) and are tree-reduced; lane i keeps channel i's sum
-    const int c0 = blockIdx.x * 256 + wave * 64;
-    const float hj = l < S ? hid[l] : 0.f;
-    float mine = 0.f;
+    for (int c = threadIdx.x; c < C; c += 1024) {  // thread per channel: column c of W2^T, coalesced across threads
+        float g = b2[c];
 #pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-        const int c = c0 + i;
-        const float v = (c < C && l < S) ? w2[(size_t)c * S + l] * hj : 0.f;
-        const float t = wave_sum(v);
-        if (l == i) mine = t;
+        for (int j = 0; j < S; ++j) g = fmaf(w2t[(size_t)j * C + c], hid[j], g);
+        gate[(size_t)n * C + c] = 1.f / (1.f + expf(-g));
     }
-    const int c = c0 + l;
-    if (c < C) gate[(size_t)n * C + c] = 1.f / (1.f + expf(-(mine + b2[c])));
 }
 }  // namespace heal
 
-extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand,
+extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
                             const float* b_expand, int n, int channels, int squeezed, float* gate, void* stream) {
     HEAL_REQUIRE(n >= 1 && channels >= 1 && squeezed >= 1 && squeezed <= 64, "se_gate: squeezed channels must be in [1,64]");
-    HEAL_REQUIRE(mean && w_reduce && b_reduce && w_expand && b_expand && gate, "se_gate: null pointer");
-    heal::k_se_gate<<<dim3(ceil_div(channels, 256), n), 256, 0, (hipStream_t)stream>>>(mean, w_reduce, b_reduce, w_expand, b_expand, channels, squeezed,
+    HEAL_REQUIRE(mean && w_reduce && b_reduce && w_expand_t && b_expand && gate, "se_gate: null pointer");
+    heal::k_se_gate<<<n, 1024, 0, (hipStream_t)stream>>>(mean, w_reduce, b_reduce, w_expand_t, b_expand, channels, squeezed,
                                                       gate);
     HEAL_LAUNCH_CHECK();
     return 0;

@@ -513,14 +513,25 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None):
     return y
 
 
+_SE_T_CACHE = {}
+
+
 def se_gate(mean, w_reduce, b_reduce, w_expand, b_expand):
     """Squeeze-excite gate: mean [n,C] (any trailing 1-dims), w_reduce [S,C,1,1], w_expand [C,S,1,1] -> gate [n,C]."""
     n, C = int(mean.shape[0]), int(mean.shape[1])
     S = int(w_reduce.shape[0])
     mean = _need(mean.reshape(n, C), torch.float32, "mean")
+    w_expand = _need(w_expand, torch.float32, "w_expand")
+    key = (w_expand.data_ptr(), w_expand._version)
+    hit = _SE_T_CACHE.get(key)
+    if hit is None:
+        if len(_SE_T_CACHE) > 256:
+            _SE_T_CACHE.clear()
+        hit = (w_expand.detach().reshape(C, S).t().contiguous(), w_expand)  # [S,C]; keep the source alive (key = address)
+        _SE_T_CACHE[key] = hit
     gate = torch.empty((n, C), dtype=torch.float32, device=mean.device)
     _capi.call("heal_se_gate", _ptr(mean), _ptr(_need(w_reduce, torch.float32, "w_reduce")),
-               _ptr(_need(b_reduce, torch.float32, "b_reduce")), _ptr(_need(w_expand, torch.float32, "w_expand")),
+               _ptr(_need(b_reduce, torch.float32, "b_reduce")), _ptr(hit[0]),
                _ptr(_need(b_expand, torch.float32, "b_expand")), n, C, S, _ptr(gate), _stream())
     return gate
 

@@ -239,8 +239,9 @@ int heal_depthwise_conv(const float* x, const float* weight, const float* bias, 
 
 /* heal_se_gate: squeeze-excite gate of the EfficientNet MBConv block (efficientnet_pytorch MBConvBlock as called from
  *   lss_submodule.py:93-105): gate [n,C] = sigmoid(W_expand silu(W_reduce mean + b_reduce) + b_expand) from the spatial
- *   mean [n,C]; W_reduce [S,C], W_expand [C,S], S <= 64.  Feeds heal_conv1x1's in_scale.                         */
-int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand,
+ *   mean [n,C]; W_reduce [S,C]; w_expand_t = W_expand^T laid out [S,C] (coalesced columns); S <= 64.
+ *   Feeds heal_conv1x1's in_scale.                                                                               */
+int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
                  const float* b_expand, int n, int channels, int squeezed, float* gate, void* stream);
 
 /* heal_conv1x1: pointwise convolution with fused prologue/epilogue,
