@@ -24,11 +24,13 @@ namespace heal {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int BM, int BN, int KC>
+template <int BM, int BN, int KC, int STRIDE>
 __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 const float* __restrict__ in_scale, int Cin, int Kpad, int Cout,
-                                                int HW, int act, float* __restrict__ y) {
+                                                int HW, int Wo, int in_W, int in_HW, int act,
+                                                float* __restrict__ y) {
+    // HW / Wo: OUTPUT pixels per image / per row; in_W / in_HW: input row width / pixels per image.  STRIDE 1: in == out.
     constexpr int MT = BM / 64;      // m-tiles per wave
     constexpr int NT = BN / 16;      // n-tiles per wave
     constexpr int LD = BN + 16;      // LDS row stride (floats): LD % 64 == 16 -> k-rows 0..3 hit banks 0-15,16-31,...
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
     const int m0 = bk.x * BM, p0 = bk.y * BN, n = bk.z;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
-    const float* __restrict__ xin = x + (size_t)n * Cin * HW;
+    const float* __restrict__ xin = x + (size_t)n * Cin * in_HW;
     const int ksteps = Kpad / 4;    // k-steps of 4 channels over the (zero-padded) K of the fragment layout
     const int nchunks = Kpad / KC;
     const float* __restrict__ scl = in_scale ? in_scale + (size_t)n * Cin : nullptr;
@@ -61,7 +63,14 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
         for (int i = 0; i < NPASS; ++i) {
             const int ch = c * KC + sc + RPP * i;
             if (pix_ok && ch < Cin) {
-                float4 v = *reinterpret_cast<const float4*>(xin + (size_t)ch * HW + p0 + sp);
+                float4 v;
+                if constexpr (STRIDE == 1) {
+                    v = *reinterpret_cast<const float4*>(xin + (size_t)ch * HW + p0 + sp);
+                } else {  // 4 consecutive output pixels of one row (Wo % 4 == 0) -> every STRIDE-th input pixel
+                    const int p = p0 + sp, oy = p / Wo, ox = p - oy * Wo;
+                    const float* src = xin + (size_t)ch * in_HW + (size_t)(oy * STRIDE) * in_W + ox * STRIDE;
+                    v = make_float4(src[0], src[STRIDE], src[2 * STRIDE], src[3 * STRIDE]);
+                }
                 if (scl) { const float g = scl[ch]; v.x *= g; v.y *= g; v.z *= g; v.w *= g; }
                 stage[i] = v;
             } else {
@@ -169,34 +178,38 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
 using namespace heal;
 
 extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
-                            const float* in_scale, int n, int cin, int cout, int HW, int act, float* y,
-                            void* stream) {
-    HEAL_REQUIRE(n >= 1 && HW >= 1 && cin >= 1 && cout >= 1, "conv1x1: bad shape");
+                            const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
+                            float* y, void* stream) {
+    HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv1x1: bad shape");
+    HEAL_REQUIRE(stride == 1 || stride == 2, "conv1x1: stride must be 1 or 2 (got %d)", stride);
     const int kpad = (cin + 31) / 32 * 32, mpad = (cout + 63) / 64 * 64;  // dims of the zero-padded fragment layout
-    HEAL_REQUIRE(HW % 4 == 0, "conv1x1: H*W must be a multiple of 4 (got %d)", HW);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, HW = Ho * Wo;
+    if (stride == 1) HEAL_REQUIRE(HW % 4 == 0, "conv1x1: H*W must be a multiple of 4 (got %d)", HW);
+    else HEAL_REQUIRE(Wo % 4 == 0, "conv1x1: output width must be a multiple of 4 for stride 2 (got %d)", Wo);
     HEAL_REQUIRE(act >= 0 && act <= 2, "conv1x1: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
     HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
     hipStream_t s = (hipStream_t)stream;
     // Tile choice (BM, BN, KC).  Measured on MI355X at the PyramidFusion shapes (scripts/conv1x1_bench.py --sweep): the
     // smallest tile wins everywhere (64 channels x 64 pixels: 48 VGPR + 16 AGPR, 20 KB LDS -> 8 waves/SIMD); the kernel
     // is latency-bound between chunks and more resident blocks hide it better than a fatter tile's operand reuse.
-    // HEAL_C1_CFG="bm,bn,kc" overrides for tuning.
+    // HEAL_C1_CFG="bm,bn,kc" overrides for tuning (stride 1).
     int bm = 64, bn = 64, kc = 32;
     if (const char* e = getenv("HEAL_C1_CFG")) {
         int a_ = 0, b_ = 0, c_ = 0;
-        if (sscanf(e, "%d,%d,%d", &a_, &b_, &c_) == 3) { bm = a_; bn = b_; kc = c_; }
+        if (stride == 1 && sscanf(e, "%d,%d,%d", &a_, &b_, &c_) == 3) { bm = a_; bn = b_; kc = c_; }
     }
     HEAL_REQUIRE(mpad % bm == 0, "conv1x1: padded Cout %d not a multiple of the tile height %d", mpad, bm);
-#define HEAL_C1(BM_, BN_, KC_)                                                                                   \
-    if (bm == BM_ && bn == BN_ && kc == KC_) {                                                                   \
-        k_conv1x1<BM_, BN_, KC_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                         \
-            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, act, y);                              \
+#define HEAL_C1(BM_, BN_, KC_, ST_)                                                                              \
+    if (bm == BM_ && bn == BN_ && kc == KC_ && stride == ST_) {                                                  \
+        k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                    \
+            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, y);                \
         launched = true;                                                                                         \
     }
     bool launched = false;
-    HEAL_C1(128, 128, 32) HEAL_C1(64, 128, 32) HEAL_C1(128, 64, 32) HEAL_C1(64, 64, 32)
+    HEAL_C1(64, 64, 32, 1) HEAL_C1(64, 64, 32, 2)
+    HEAL_C1(128, 128, 32, 1) HEAL_C1(64, 128, 32, 1) HEAL_C1(128, 64, 32, 1)
 #undef HEAL_C1
-    HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d)", bm, bn, kc);
+    HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d) stride %d", bm, bn, kc, stride);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

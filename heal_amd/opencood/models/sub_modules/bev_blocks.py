@@ -60,9 +60,10 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
     if (groups > 1 and w.shape[2:] == (3, 3) and pd == 1 and dl == 1 and st in (1, 2) and residual is None
             and w.shape[1] in (4, 8, 16) and w.shape[0] == x.shape[1]):
         return ops.grouped_conv3x3(x, w, b, groups, st, relu)
-    if (_CONV1X1 and groups == 1 and w.shape[2:] == (1, 1) and st == 1 and pd == 0
-            and ops.conv1x1_supported(int(w.shape[1]), int(w.shape[0]), int(x.shape[2] * x.shape[3]))):
-        return ops.conv1x1(x, w, b, residual, 1 if relu else 0)
+    if _CONV1X1 and groups == 1 and w.shape[2:] == (1, 1) and st in (1, 2) and pd == 0:
+        Ho, Wo = (int(x.shape[2]) - 1) // st + 1, (int(x.shape[3]) - 1) // st + 1
+        if ops.conv1x1_supported(int(w.shape[1]), int(w.shape[0]), Ho * Wo, st, Wo):
+            return ops.conv1x1(x, w, b, residual, 1 if relu else 0, stride=st)
     y = F.conv2d(x, w, None, stride, padding, dilation, groups)
     if b is None and residual is None and not relu:
         return y

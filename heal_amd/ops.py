@@ -486,30 +486,36 @@ def conv1x1_fragments(w):
     return hit[0]
 
 
-def conv1x1_supported(cin, cout, hw):
-    return hw % 4 == 0 and hw >= 64
+def conv1x1_supported(cin, cout, hw, stride=1, out_w=None):
+    """Shapes heal_conv1x1 takes: 16-byte pixel rows (stride 1: Ho*Wo % 4 == 0; stride 2: Wo % 4 == 0) and maps large
+    enough to fill a few tiles."""
+    if stride == 1:
+        return hw % 4 == 0 and hw >= 64
+    return stride == 2 and out_w is not None and out_w % 4 == 0 and hw >= 64
 
 
-def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None):
+def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1):
     """Pointwise convolution with fused prologue / epilogue: act(W (in_scale . x) + bias (+ residual));
-    act 0 none | 1 ReLU | 2 SiLU.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin] (any trailing 1-dims)."""
+    act 0 none | 1 ReLU | 2 SiLU; stride 1 | 2.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin]."""
     x = _need(x, torch.float32, "x")
     n, cin, H, W = (int(v) for v in x.shape)
     cout = int(w.shape[0])
-    if int(w.shape[1]) != cin or (H * W) % 4 != 0:
-        raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HW={H * W}")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    hard_ok = stride in (1, 2) and ((Ho * Wo) % 4 == 0 if stride == 1 else Wo % 4 == 0)
+    if int(w.shape[1]) != cin or not hard_ok:
+        raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HxW={H}x{W} stride={stride}")
     frag = conv1x1_fragments(w)
-    y = torch.empty((n, cout, H, W), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
         if tuple(residual.shape) != tuple(y.shape):
             raise _capi.HealAmdError("conv1x1: residual shape mismatch")
     if in_scale is not None:
         in_scale = _need(in_scale.reshape(n, cin), torch.float32, "in_scale")
-    with _Timed(f"conv1x1_{cin}_{cout}"):
+    with _Timed(f"conv1x1_{cin}_{cout}" + ("_s2" if stride == 2 else "")):
         _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
                    _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
-                   n, cin, cout, H * W, int(act), _ptr(y), _stream())
+                   n, cin, cout, H, W, int(stride), int(act), _ptr(y), _stream())
     return y
 
 

@@ -249,12 +249,14 @@ int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce
  *   i.e. the conv1x1 + BatchNorm (+ identity) + ReLU sequences of the ResNeXt bottleneck
  *   (opencood/models/sub_modules/resblock.py:95-121) and the expand / squeeze-excite-scale + project (+ skip) stages of
  *   the EfficientNet MBConv blocks of the Lift-Splat trunk (lss_submodule.py:93-105), BatchNorm folded into W / bias by
- *   the caller.  x [n,Cin,H,W], y/residual [n,Cout,H,W] f32 NCHW, H*W % 4 == 0; in_scale [n,Cin] or NULL (per-image,
- *   per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU.
+ *   the caller.  x [n,Cin,H,W] f32 NCHW; stride 1 | 2 (the 1x1 stride-2 `downsample` of resblock.py:160-165: every
+ *   second pixel); y/residual [n,Cout,Ho,Wo], Ho = (H-1)/stride+1; Ho*Wo % 4 == 0 (stride 1) or Wo % 4 == 0 (stride 2);
+ *   in_scale [n,Cin] or NULL (per-image, per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU.
  *   weight_frag = W zero-padded to [Mpad = ceil64(Cout), Kpad = ceil32(Cin)] in MFMA A-fragment order
  *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)], mt < Mpad/16, ks < Kpad/4.                */
 int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
-                 const float* in_scale, int n, int cin, int cout, int HW, int act, float* y, void* stream);
+                 const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act, float* y,
+                 void* stream);
 
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265

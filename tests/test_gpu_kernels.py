@@ -534,6 +534,20 @@ def test_conv1x1_padded_shapes_gate_and_skip(n, cin, cout, H, W):
     assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,H,W", [(2, 64, 128, 32, 32), (1, 128, 256, 16, 24), (3, 64, 64, 9, 16)])
+def test_conv1x1_stride2_vs_torch(n, cin, cout, H, W):
+    """the 1x1 stride-2 `downsample` convolution of the residual blocks (resblock.py:160-165)"""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    got = ops.conv1x1(x, w, b, None, 0, stride=2)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2)
+    assert got.shape == ref.shape
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
 def test_conv1x1_rejects_unsupported_shapes():
     from heal_amd import _capi, ops
     with pytest.raises(_capi.HealAmdError):  # H*W must be a multiple of 4 (16-byte rows)
