@@ -248,12 +248,25 @@ def main():
         roof = None
         if "pfn_scatter" in timing:
             calls, mean_ms = timing["pfn_scatter"]
-            # one launch of the operator = one agent (the no-sync points path calls K2 per agent)
-            bytes_per_launch = float(np.mean([k2_algorithmic_bytes(32, m, ny, nx) for m in m_per_agent]))
+            # one launch of the operator = the collated LiDAR agents this rank encodes (reference: one PillarVFE +
+            # PointPillarScatter call per modality batch); algorithmic bytes = sum over those agents
+            lidar_ids = [i for i, m in enumerate(mods) if m == "m1"]
+            if world > 1:
+                lidar_ids = [i for i in lidar_ids if i in owned_agents(n_agents, 0, world)]
+            order = sorted(scene.points)
+            m_launch = [m_per_agent[order.index(i)] for i in lidar_ids if i in order]
+            bytes_per_launch = float(sum(k2_algorithmic_bytes(32, m, ny, nx) for m in m_launch))
             achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
-            roof = {"kernel": "K2 heal_pfn_scatter (memset + k_pfn + k_canvas)", "bound": "hbm",
+            traffic = None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_k2_traffic.json")
+            if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 PMC passes (scripts/profile_round.sh)
+                tj = json.load(open(tpath))
+                if int(tj.get("agents_per_launch", -1)) == len(m_launch):
+                    traffic = float(tj["k2_traffic_bytes_per_launch"])
+            roof = {"kernel": f"K2 heal_pfn_scatter, {len(m_launch)} collated LiDAR agents per launch "
+                              "(map memset + k_pfn + k_canvas)", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": bytes_per_launch, "launch_ms": round(mean_ms, 5), "launches": calls}
         kernels = {k: {"calls": c, "mean_ms": round(ms, 5)} for k, (c, ms) in sorted(timing.items())}
         line = {

@@ -200,9 +200,10 @@ extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, cons
     HEAL_HIP(hipMemsetAsync(cell_map, 0xFF, (size_t)n_agents * ny * nx * sizeof(int), s));
     if (n_voxels > 0) {
         PfnGeom g{vx, vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx};
-        // one pillar per wave up to 8192 waves, beyond that a (software-prefetched) grid-stride loop;
-        // measured: fewer, longer-lived waves are slower (the per-pillar work is ~5 points on average)
-        const int blocks = min(ceil_div(n_voxels, 4), 256 * 8);
+        // one pillar per wave up to 32768 waves (a collated 3-agent launch is ~33 k pillars), beyond that a
+        // (software-prefetched) grid-stride loop; measured: fewer, longer-lived waves are slower (the per-pillar
+        // work is ~5 points on average)
+        const int blocks = min(ceil_div(n_voxels, 4), 256 * 32);
         const float4* v4 = reinterpret_cast<const float4*>(voxels);
         const int4* c4 = reinterpret_cast<const int4*>(coords);
         k_pfn<<<blocks, 256, 0, s>>>(v4, max_points, c4, num_points, n_voxels, n_voxels_dev, weight,

@@ -83,10 +83,11 @@ __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ p
                                                    const int* __restrict__ slot_of,
                                                    const uint32_t* __restrict__ tmin,
                                                    const int* __restrict__ vid_excl, int cap,
-                                                   int batch_idx, uint32_t* __restrict__ tvid,
-                                                   int* __restrict__ coords) {
+                                                   int batch_idx, const int* __restrict__ row_offset,
+                                                   uint32_t* __restrict__ tvid, int* __restrict__ coords) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const int base = row_offset ? *row_offset : 0;  // rows of earlier agents in a shared (collated) buffer
     const int s = slot_of[i];
     if (s < 0 || tmin[s] != (uint32_t)i) return;
     const int vid = vid_excl[i];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ p
     if (vid < cap) {
         int cx, cy, cz;
         point_cell(pts[i], g, cx, cy, cz);
-        reinterpret_cast<int4*>(coords)[vid] = make_int4(batch_idx, cz, cy, cx);
+        reinterpret_cast<int4*>(coords)[base + vid] = make_int4(batch_idx, cz, cy, cx);
     }
 }
 
@@ -132,9 +133,15 @@ __global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pt
                                                   const int* __restrict__ count,
                                                   const int* __restrict__ total_voxels, int cap, int P,
                                                   float4* __restrict__ voxels, int* __restrict__ num_points,
-                                                  int* __restrict__ n_voxels_out) {
+                                                  int* __restrict__ n_voxels_out,
+                                                  const int* __restrict__ row_offset,
+                                                  int* __restrict__ row_offset_next) {
     const int M = min(*total_voxels, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_voxels_out = M;
+    const int base = row_offset ? *row_offset : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *n_voxels_out = M;
+        if (row_offset_next) *row_offset_next = base + M;
+    }
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= M) return;
     const int l = threadIdx.x & 63;
@@ -143,9 +150,9 @@ __global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pt
     for (int p = l; p < P; p += 64) {
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < c) val = pts[svals[st + p]];
-        voxels[(size_t)v * P + p] = val;
+        voxels[(size_t)(base + v) * P + p] = val;
     }
-    if (l == 0) num_points[v] = c;
+    if (l == 0) num_points[base + v] = c;
 }
 
 static int key_bits_for(int cap) {
@@ -203,12 +210,17 @@ extern "C" size_t heal_voxelize_workspace(int n_points, int max_voxels) {
 extern "C" int heal_voxelize(const float* points, int n_points, const float* range_host,
                              const float* voxel_size_host, int max_points, int max_voxels,
                              int batch_idx, float* voxels, int32_t* coords, int32_t* num_points,
-                             int32_t* n_voxels, void* ws, size_t ws_bytes, void* stream) {
+                             int32_t* n_voxels, const int32_t* row_offset, int32_t* row_offset_next, void* ws,
+                             size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(n_points >= 0 && max_points >= 1 && max_voxels >= 1, "voxelize: bad sizes");
     HEAL_REQUIRE(n_voxels != nullptr, "voxelize: n_voxels is NULL");
     if (n_points == 0) {
         HEAL_HIP(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
+        if (row_offset_next) {
+            if (row_offset) HEAL_HIP(hipMemcpyAsync(row_offset_next, row_offset, sizeof(int), hipMemcpyDeviceToDevice, s));
+            else HEAL_HIP(hipMemsetAsync(row_offset_next, 0, sizeof(int), s));
+        }
         return 0;
     }
     VoxGrid g;
@@ -237,7 +249,7 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
     k_vox_insert<<<nb, 256, 0, s>>>(pts, n_points, g, w.tkey, w.tmin, w.tcap - 1, w.slot_of);
     k_vox_flag<<<nb, 256, 0, s>>>(w.slot_of, w.tmin, n_points, w.flag);
     if (scan_exclusive(w.flag, w.flag, n_points, w.total, w.scratch, s)) return 1;
-    k_vox_assign<<<nb, 256, 0, s>>>(pts, n_points, g, w.slot_of, w.tmin, w.flag, cap, batch_idx,
+    k_vox_assign<<<nb, 256, 0, s>>>(pts, n_points, g, w.slot_of, w.tmin, w.flag, cap, batch_idx, row_offset,
                                     w.tvid, coords);
     k_vox_keys<<<nb, 256, 0, s>>>(w.slot_of, w.tvid, n_points, cap, w.keys[0], w.vals[0], w.count);
     int res = 0;
@@ -245,7 +257,7 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
     k_vox_heads<<<nb, 256, 0, s>>>(w.keys[res], n_points, cap, w.seg_start);
     k_vox_write<<<ceil_div(cap, 4), 256, 0, s>>>(pts, w.vals[res], w.seg_start, w.count, w.total, cap,
                                                  max_points, reinterpret_cast<float4*>(voxels),
-                                                 num_points, n_voxels);
+                                                 num_points, n_voxels, row_offset, row_offset_next);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

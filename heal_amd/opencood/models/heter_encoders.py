@@ -45,19 +45,17 @@ class PointPillar(nn.Module):
         return self._fold
 
     def encode_points(self, point_list):
-        """Raw device point clouds -> canvas, one K1 + K2 pair per agent and NO host round trip:
-        the voxel count stays on the device (K2 reads it) and every agent writes its own canvas slab."""
+        """Raw device point clouds -> canvas with NO host round trip: K1 per agent into collated buffers (the running
+        row offset stays on the device), then ONE K2 launch over all agents of the modality -- the reference's collated
+        PillarVFE + PointPillarScatter call (heter_encoders.py:46-49), 3x67 MB written by one streaming kernel."""
         scale, shift = self._bn()
         weight = self.pillar_vfe.pfn_layers[0].linear.weight.detach()
         ny, nx = self.scatter.ny, self.scatter.nx
-        canvas = torch.empty((len(point_list), weight.shape[0], ny, nx), dtype=torch.float32,
-                             device=point_list[0].device)
-        for b, pts in enumerate(point_list):
-            v, c, n, count = ops.voxelize(pts, self.lidar_range, self.voxel_size, self.max_points,
-                                          self.max_voxels, batch_idx=0, sync=False)
-            ops.pfn_scatter(v, c, n, weight, scale, shift, self.voxel_size, self.lidar_range, 1, ny, nx,
-                            n_voxels_dev=count, out=canvas[b:b + 1])
-        return canvas
+        v, c, n, offsets = ops.voxelize_collated(point_list, self.lidar_range, self.voxel_size, self.max_points,
+                                                 self.max_voxels)
+        k = len(point_list)
+        return ops.pfn_scatter(v, c, n, weight, scale, shift, self.voxel_size, self.lidar_range, k, ny, nx,
+                               n_voxels_dev=offsets[k:k + 1])
 
     def forward(self, data_dict, modality_name):
         if self.training and torch.is_grad_enabled():

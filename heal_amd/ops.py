@@ -99,11 +99,41 @@ def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=
     vs = _host_array([float(v) for v in voxel_size], ctypes.c_float)
     with _Timed("voxelize"):
         _capi.call("heal_voxelize", _ptr(points), n, rng, vs, int(max_points), int(max_voxels), int(batch_idx),
-                   _ptr(voxels), _ptr(coords), _ptr(num), _ptr(count), _ptr(ws), ws.numel(), _stream())
+                   _ptr(voxels), _ptr(coords), _ptr(num), _ptr(count), None, None, _ptr(ws), ws.numel(), _stream())
     if not sync:
         return voxels, coords, num, count
     m = int(count.item())
     return voxels[:m], coords[:m], num[:m]
+
+
+def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxels):
+    """K1 for every agent of a modality into ONE set of collated buffers (collate_batch_list,
+    sp_voxel_preprocessor.py:110-147) without a host round trip: agent b's rows follow agent b-1's, the running row
+    offset lives on the device.  -> (voxels [cap,P,4], coords [cap,4] (b,z,y,x), num_points [cap], offsets [n+1] i32
+    device; offsets[b+1]-offsets[b] = voxels of agent b, offsets[n] = total); rows beyond the total are unspecified."""
+    pts = [_need(p, torch.float32, "points") for p in point_list]
+    for p in pts:
+        if p.dim() != 2 or p.shape[1] != 4:
+            raise _capi.HealAmdError("points must be [N,4]")
+    dev = pts[0].device
+    caps = [max(1, min(int(p.shape[0]), int(max_voxels))) for p in pts]
+    cap = sum(caps)
+    voxels = torch.empty((cap, max_points, 4), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    offsets = torch.zeros((len(pts) + 1,), dtype=torch.int32, device=dev)
+    counts = torch.zeros((len(pts),), dtype=torch.int32, device=dev)
+    rng = _host_array([float(v) for v in lidar_range], ctypes.c_float)
+    vs = _host_array([float(v) for v in voxel_size], ctypes.c_float)
+    for b, p in enumerate(pts):
+        n = int(p.shape[0])
+        nbytes = _capi.query("heal_voxelize_workspace", n, int(max_voxels))
+        ws = _workspace("voxelize", nbytes, dev)
+        with _Timed("voxelize"):
+            _capi.call("heal_voxelize", _ptr(p), n, rng, vs, int(max_points), int(max_voxels), b, _ptr(voxels),
+                       _ptr(coords), _ptr(num), _ptr(counts[b:b + 1]), _ptr(offsets[b:b + 1]),
+                       _ptr(offsets[b + 1:b + 2]), _ptr(ws), ws.numel(), _stream())
+    return voxels, coords, num, offsets
 
 
 def pfn_scatter(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_size, lidar_range,

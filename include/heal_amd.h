@@ -40,12 +40,16 @@ const char* heal_last_error(void);
  *   coords      [cap,4] i32 (batch_idx,z,y,x), rows [0,M)
  *   num_points  [cap] i32
  *   n_voxels    [1] i32  <- M
+ *   row_offset / row_offset_next  device i32 or NULL: collate_batch_list without a host round trip -- this agent's
+ *               rows go to [*row_offset, *row_offset + M) of voxels/coords/num_points (buffers shared by the agents
+ *               of a modality) and *row_offset_next <- *row_offset + M feeds the next agent's call.
  * -----------------------------------------------------------------------------------------------*/
 size_t heal_voxelize_workspace(int n_points, int max_voxels);
 int heal_voxelize(const float* points, int n_points,
                   const float* range_host, const float* voxel_size_host,
                   int max_points, int max_voxels, int batch_idx,
                   float* voxels, int32_t* coords, int32_t* num_points, int32_t* n_voxels,
+                  const int32_t* row_offset, int32_t* row_offset_next,
                   void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

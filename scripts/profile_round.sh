@@ -15,7 +15,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- 
     python bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- \
     python bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2> $OUT/pmc_write.err
-python scripts/pmc_summary.py $OUT/pmc_heal_kernels.txt $OUT/pmc_fetch $OUT/pmc_write --json $OUT/pmc_k2_traffic.json
+python scripts/pmc_summary.py $OUT/pmc_heal_kernels.txt $OUT/pmc_fetch $OUT/pmc_write --json $OUT/pmc_k2_traffic.json --agents 3
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_scene5.csv \;
 rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write   # keep the merge-back small
 ls -la $OUT

@@ -567,3 +567,19 @@ def test_se_gate_vs_torch():
             torch.nn.functional.conv2d(m.double(), w1.double(), b1.double())), w2.double(), b2.double()))
         got = ops.se_gate(m, w1, b1, w2, b2)
         np.testing.assert_allclose(got.cpu().numpy(), ref.float().reshape(n, C).cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_voxelize_collated_equals_per_agent():
+    """collate_batch_list on the device: per-agent K1 calls writing into shared buffers at a device-side row offset."""
+    from heal_amd import ops, synth
+    pts = [torch.from_numpy(synth.lidar_frame(300 + k)).cuda()[: 20000 + 5000 * k].contiguous() for k in range(3)]
+    pts.append(torch.zeros((0, 4)).cuda())  # an agent with no points
+    R = [-102.4, -102.4, -3, 102.4, 102.4, 1]
+    v, c, n, off = ops.voxelize_collated(pts, R, [0.4, 0.4, 4], 32, 70000)
+    off = off.cpu().numpy()
+    assert off[0] == 0 and off[-1] == off[-2]
+    for b, p in enumerate(pts[:3]):
+        vb, cb, nb = ops.voxelize(p, R, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
+        lo, hi = int(off[b]), int(off[b + 1])
+        assert hi - lo == vb.shape[0]
+        assert torch.equal(v[lo:hi], vb) and torch.equal(c[lo:hi], cb) and torch.equal(n[lo:hi], nb)
