@@ -8,7 +8,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libheal_amd.so")
+LIB_PATH = os.environ.get("HEAL_AMD_LIB") or os.path.join(HERE, "lib", "libheal_amd.so")  # env: A/B a rebuilt library
 HEADER = os.path.join(os.path.dirname(HERE), "include", "heal_amd.h")
 
 _lib = None
