@@ -291,6 +291,42 @@ extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const floa
     return 0;
 }
 
+namespace heal {
+// LayerNorm over the CHANNEL axis of an NCHW map (ConvNeXt block, feature_alignnet_modules.py:12-31,318-321: the
+// reference permutes to NHWC and calls F.layer_norm).  One thread per pixel: consecutive threads read consecutive pixels
+// of a channel plane (coalesced), two passes over the C planes (mean, then biased variance), eps inside the sqrt.
+__global__ __launch_bounds__(256) void k_layernorm_nchw(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int C, int HW, float eps,
+                                                       float* __restrict__ y) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* xi = x + (size_t)blockIdx.y * C * HW + p;
+    float* yo = y + (size_t)blockIdx.y * C * HW + p;
+    float mean = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) mean += xi[(size_t)c * HW];
+    mean /= (float)C;
+    float var = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const float d = xi[(size_t)c * HW] - mean;
+        var = fmaf(d, d, var);
+    }
+    const float inv = 1.f / sqrtf(var / (float)C + eps);
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) yo[(size_t)c * HW] = (xi[(size_t)c * HW] - mean) * inv * gamma[c] + beta[c];
+}
+}  // namespace heal
+
+extern "C" int heal_layernorm_nchw(const float* x, const float* gamma, const float* beta, int n, int channels, int HW,
+                                   float eps, float* y, void* stream) {
+    HEAL_REQUIRE(n >= 1 && channels >= 1 && HW >= 1 && n <= 65535, "layernorm_nchw: bad shape");
+    HEAL_REQUIRE(x && gamma && beta && y, "layernorm_nchw: null pointer");
+    heal::k_layernorm_nchw<<<dim3(ceil_div(HW, 256), n), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, channels, HW, eps, y);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream) {
     const long long total = (long long)n * channels * (2 * H) * (2 * W);
     if (total <= 0) return 0;

@@ -166,6 +166,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             } else if (act == 2) {
                 v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
                 v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+            } else if (act == 3) {  // exact GELU: 0.5 x (1 + erf(x / sqrt(2)))
+                v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752f));
+                v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752f));
+                v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752f));
+                v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
             }
             *reinterpret_cast<float4*>(yout + o) = v;
         }
@@ -186,7 +191,7 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, HW = Ho * Wo;
     if (stride == 1) HEAL_REQUIRE(HW % 4 == 0, "conv1x1: H*W must be a multiple of 4 (got %d)", HW);
     else HEAL_REQUIRE(Wo % 4 == 0, "conv1x1: output width must be a multiple of 4 for stride 2 (got %d)", Wo);
-    HEAL_REQUIRE(act >= 0 && act <= 2, "conv1x1: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
+    HEAL_REQUIRE(act >= 0 && act <= 3, "conv1x1: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (GELU)");
     HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
     hipStream_t s = (hipStream_t)stream;
     // Tile choice (BM, BN, KC).  Measured on MI355X at the PyramidFusion shapes (scripts/conv1x1_bench.py --sweep): the

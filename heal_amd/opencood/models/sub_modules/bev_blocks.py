@@ -372,9 +372,31 @@ class ConvNeXtBlock(nn.Module):
         self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) \
             if layer_scale_init_value > 0 else None
 
+    def _folded_pw2(self):
+        """pwconv2 with the layer scale folded in: gamma * (W2 h + b2) = (gamma . W2) h + gamma . b2 (cached)."""
+        t = [self.pwconv2.weight, self.pwconv2.bias] + ([self.gamma] if self.gamma is not None else [])
+        key = _versions(*t)
+        if getattr(self, "_pw2_key", None) != key:
+            with torch.no_grad():
+                w, b = self.pwconv2.weight, self.pwconv2.bias
+                if self.gamma is not None:
+                    w, b = w * self.gamma[:, None], b * self.gamma
+                self._pw2 = (w.contiguous()[:, :, None, None], b.contiguous())
+            self._pw2_key = key
+        return self._pw2
+
     def forward(self, x):
+        from heal_amd import ops
         inp = x
-        x = self.dwconv(x).permute(0, 2, 3, 1)
+        x = self.dwconv(x)
+        if x.is_cuda and ops.conv1x1_supported(x.shape[1], 4 * x.shape[1], int(x.shape[2] * x.shape[3])):
+            # NCHW all the way: channel LayerNorm in one pass, the two Linear layers as pointwise convolutions with
+            # GELU / (layer scale + residual) fused -- 3 launches instead of permute, LN, 2 GEMMs, GELU, scale, add
+            xn = ops.layernorm_nchw(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            h = ops.conv1x1(xn, self.pwconv1.weight[:, :, None, None], self.pwconv1.bias, None, 3)
+            w2, b2 = self._folded_pw2()
+            return ops.conv1x1(h, w2, b2, inp, 0)
+        x = x.permute(0, 2, 3, 1)
         x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
         if self.gamma is not None:
             x = self.gamma * x

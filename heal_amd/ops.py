@@ -549,6 +549,16 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1):
     return y
 
 
+def layernorm_nchw(x, gamma, beta, eps):
+    """LayerNorm over the channel axis of x [n,C,H,W] (biased variance, eps inside the sqrt)."""
+    x = _need(x, torch.float32, "x")
+    n, C, H, W = (int(v) for v in x.shape)
+    y = torch.empty_like(x)
+    _capi.call("heal_layernorm_nchw", _ptr(x), _ptr(_need(gamma, torch.float32, "gamma")),
+               _ptr(_need(beta, torch.float32, "beta")), n, C, H * W, float(eps), _ptr(y), _stream())
+    return y
+
+
 _SE_T_CACHE = {}
 
 

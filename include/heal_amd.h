@@ -241,6 +241,12 @@ int heal_depthwise_conv(const float* x, const float* weight, const float* bias, 
                         int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y,
                         void* stream);
 
+/* heal_layernorm_nchw: LayerNorm over the channel axis of an NCHW map, y = (x - mean_c) / sqrt(var_c + eps) * gamma + beta
+ *   (biased variance) -- the `norm` of the ConvNeXt aligner block (feature_alignnet_modules.py:12-31,318-321), which the
+ *   reference evaluates as permute -> F.layer_norm -> ... -> permute.  x,y [n,C,H,W].                               */
+int heal_layernorm_nchw(const float* x, const float* gamma, const float* beta, int n, int channels, int HW, float eps,
+                        float* y, void* stream);
+
 /* heal_se_gate: squeeze-excite gate of the EfficientNet MBConv block (efficientnet_pytorch MBConvBlock as called from
  *   lss_submodule.py:93-105): gate [n,C] = sigmoid(W_expand silu(W_reduce mean + b_reduce) + b_expand) from the spatial
  *   mean [n,C]; W_reduce [S,C]; w_expand_t = W_expand^T laid out [S,C] (coalesced columns); S <= 64.
@@ -255,7 +261,7 @@ int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce
  *   the EfficientNet MBConv blocks of the Lift-Splat trunk (lss_submodule.py:93-105), BatchNorm folded into W / bias by
  *   the caller.  x [n,Cin,H,W] f32 NCHW; stride 1 | 2 (the 1x1 stride-2 `downsample` of resblock.py:160-165: every
  *   second pixel); y/residual [n,Cout,Ho,Wo], Ho = (H-1)/stride+1; Ho*Wo % 4 == 0 (stride 1) or Wo % 4 == 0 (stride 2);
- *   in_scale [n,Cin] or NULL (per-image, per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU.
+ *   in_scale [n,Cin] or NULL (per-image, per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU | 3 GELU (erf).
  *   weight_frag = W zero-padded to [Mpad = ceil64(Cout), Kpad = ceil32(Cin)] in MFMA A-fragment order
  *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)], mt < Mpad/16, ks < Kpad/4.                */
 int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,

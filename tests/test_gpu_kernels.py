@@ -583,3 +583,24 @@ def test_voxelize_collated_equals_per_agent():
         lo, hi = int(off[b]), int(off[b + 1])
         assert hi - lo == vb.shape[0]
         assert torch.equal(v[lo:hi], vb) and torch.equal(c[lo:hi], cb) and torch.equal(n[lo:hi], nb)
+
+
+def test_convnext_block_nchw_path_vs_reference_formula():
+    """ConvNeXtBlock (feature_alignnet_modules.py:299-344): dwconv -> permute -> LayerNorm -> Linear -> GELU -> Linear
+    -> gamma -> permute -> + input, evaluated by the reference formula in fp64 against the fused NCHW path."""
+    from heal_amd.opencood.models.sub_modules.bev_blocks import ConvNeXtBlock
+    from tests.golden.detfill import fill_module
+    torch.manual_seed(0)
+    blk = fill_module(ConvNeXtBlock(64, layer_scale_init_value=1e-6)).cuda().eval()
+    with torch.no_grad():
+        blk.gamma.copy_(torch.linspace(0.5, 1.5, 64))  # the 1e-6 init would hide the branch in the residual
+        x = torch.randn((2, 64, 32, 48)).cuda()
+        got = blk(x)
+        d = blk.double()
+        xd = x.double()
+        t = d.dwconv(xd).permute(0, 2, 3, 1)
+        t = torch.nn.functional.layer_norm(t, (64,), d.norm.weight, d.norm.bias, d.norm.eps)
+        t = d.pwconv2(torch.nn.functional.gelu(d.pwconv1(t)))
+        ref = xd + (d.gamma * t).permute(0, 3, 1, 2)
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
