@@ -242,7 +242,7 @@ extern "C" int heal_depthwise_conv(const float* x, const float* weight, const fl
         HEAL_LAUNCH_CHECK();                                                                                  \
         return 0;                                                                                             \
     }
-    HEAL_DW(3, 1) HEAL_DW(3, 2) HEAL_DW(5, 1) HEAL_DW(5, 2)
+    HEAL_DW(3, 1) HEAL_DW(3, 2) HEAL_DW(5, 1) HEAL_DW(5, 2) HEAL_DW(7, 1)
 #undef HEAL_DW
     return set_error("depthwise_conv: kernel %d stride %d is not instantiated", ksize, stride);
 }

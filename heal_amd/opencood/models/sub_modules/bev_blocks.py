@@ -388,7 +388,11 @@ class ConvNeXtBlock(nn.Module):
     def forward(self, x):
         from heal_amd import ops
         inp = x
-        x = self.dwconv(x)
+        k = self.dwconv.kernel_size[0]
+        if x.is_cuda and k == 7 and int(x.shape[0] * x.shape[1]) <= 65535:
+            x = ops.depthwise_conv(x, self.dwconv.weight, self.dwconv.bias, 1, (3, 3, 3, 3), "none")
+        else:
+            x = self.dwconv(x)
         if x.is_cuda and ops.conv1x1_supported(x.shape[1], 4 * x.shape[1], int(x.shape[2] * x.shape[3])):
             # NCHW all the way: channel LayerNorm in one pass, the two Linear layers as pointwise convolutions with
             # GELU / (layer scale + residual) fused -- 3 launches instead of permute, LN, 2 GEMMs, GELU, scale, add

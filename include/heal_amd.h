@@ -234,7 +234,8 @@ int heal_resnext_bottleneck(const float* x, const float* w1_frag, const float* b
  *   Lift-Splat `Up` block (opencood/models/sub_modules/lss_submodule.py:21-22,33); x [n,C,H,W] -> y [n,C,2H,2W] */
 int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream);
 
-/* heal_depthwise_conv: depthwise k x k (k = 3|5, stride 1|2) with explicit top/left zero padding, bias and
+/* heal_depthwise_conv: depthwise k x k (k = 3|5 at stride 1|2, k = 7 at stride 1: the ConvNeXt aligner's dwconv,
+ *   feature_alignnet_modules.py:314) with explicit top/left zero padding, bias and
  *   activation (0 none, 1 ReLU, 2 SiLU): the MBConv depthwise stage of the EfficientNet-b0 trunk
  *   (lss_submodule.py:93-105); x [n,C,H,W], weight [C,1,k,k] -> y [n,C,Ho,Wo]                              */
 int heal_depthwise_conv(const float* x, const float* weight, const float* bias, int n, int channels, int H, int W,
