@@ -164,7 +164,8 @@ def main():
                       "running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
     else:
-        sharded = ShardedCollab(pipe.model, rank, world)
+        wire = torch.float16 if os.environ.get("HEAL_WIRE", "fp32") == "fp16" else None  # opt-in half-size exchange
+        sharded = ShardedCollab(pipe.model, rank, world, wire_dtype=wire)
         mine = owned_agents(n_agents, rank, world)
         local_inputs = scene.inputs_for(mine)
         inp = scene.model_input()
@@ -277,7 +278,8 @@ def main():
             "config": {"workload": f"{a.workload}: {desc}", "agents": n_agents,
                        "pillars_per_agent": m_per_agent, "modalities": mods,
                        "points_per_agent": [int(scene.points[k].shape[0]) for k in sorted(scene.points)],
-                       "parallelism": "1 GPU" if world == 1 else f"agent-sharded over {world} ranks, 1 all-gather",
+                       "parallelism": "1 GPU" if world == 1 else (f"agent-sharded over {world} ranks, 1 all-gather"
+                                                                   + (" (fp16 wire)" if os.environ.get("HEAL_WIRE") == "fp16" else "")),
                        "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if world == 1
                                   else "hipGraph(local stage) -> all-gather -> hipGraph(fusion tail + decode/NMS)"),
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mods, out_path):
+def _worker(rank, world, port, mods, out_path, wire=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -37,7 +37,7 @@ def _worker(rank, world, port, mods, out_path):
                     for k, p in scene.points.items()}
     from heal_amd import synth
     scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
-    sharded = ShardedCollab(pipe.model, rank, world)
+    sharded = ShardedCollab(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None)
     mine = owned_agents(len(mods), rank, world)
     work = torch.cuda.Stream()
     torch.cuda.set_stream(work)
@@ -67,3 +67,17 @@ def test_sharded_forward_equals_single_process(tmp_path, n_agents):
         assert err < 1e-4, (k, err)
         err = float((rep - ref).abs().max() / (ref.abs().max() + 1e-12))
         assert err < 1e-4, ("graph replay", k, err)
+
+
+def test_sharded_forward_fp16_wire_stays_inside_the_parity_budget(tmp_path):
+    """half-size exchange buffer.  fp16 rounding of the shared maps (~5e-4 relative) must keep the head
+    outputs within the 1e-3 north-star tolerance of the fp32 single-process result."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "o16.pt")
+    mp.spawn(_worker, args=(2, _free_port(), ["m1"] * 3, out, "float16"), nprocs=2, join=True)
+    res = torch.load(out)
+    worst = 0.0
+    for k, (got, ref, rep) in res.items():
+        worst = max(worst, float((got - ref).abs().max() / (ref.abs().max() + 1e-12)),
+                    float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)))
+    assert 0.0 < worst < 1e-3, worst  # > 0: the fp16 path really ran
