@@ -160,14 +160,26 @@ int heal_canvas_from_map(const int* cell_map, const float* rows, int n_agents, i
                          int cells, float* canvas, hipStream_t s) {
     HEAL_REQUIRE(cells % 4 == 0 && channels % 16 == 0, "canvas: cells %% 4 and channels %% 16 required");
     const int cells4 = cells / 4;
-    dim3 grid(ceil_div(cells4, 256), channels / 16, n_agents);
+    // channels per block: measured on the 201 MB collated canvas (scripts/k2_bench.py): 1: 77 us, 2: 72, 4: 75, 8: 79,
+    // 16: 86, 32: 98, 64: 93 -> many small blocks win (more stores in flight); HEAL_CANVAS_CG overrides for tuning
+    static const int cg = []() { const char* e = getenv("HEAL_CANVAS_CG"); return e ? atoi(e) : 4; }();
     static const int nt = []() { const char* e = getenv("HEAL_CANVAS_NT"); return e ? atoi(e) : 0; }();
-    if (nt)
-        k_canvas<16, true><<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), rows, cells4, channels,
-                                                reinterpret_cast<float4*>(canvas));
-    else
-        k_canvas<16, false><<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), rows, cells4, channels,
-                                                 reinterpret_cast<float4*>(canvas));
+    const int4* map4 = reinterpret_cast<const int4*>(cell_map);
+    float4* out4 = reinterpret_cast<float4*>(canvas);
+#define HEAL_CV(CG_)                                                                                         \
+    if (cg == CG_ && channels % CG_ == 0) {                                                                  \
+        dim3 grid(ceil_div(cells4, 256), channels / CG_, n_agents);                                          \
+        if (nt) k_canvas<CG_, true><<<grid, 256, 0, s>>>(map4, rows, cells4, channels, out4);                \
+        else k_canvas<CG_, false><<<grid, 256, 0, s>>>(map4, rows, cells4, channels, out4);                  \
+        HEAL_LAUNCH_CHECK();                                                                                 \
+        return 0;                                                                                            \
+    }
+    HEAL_CV(1) HEAL_CV(2) HEAL_CV(4) HEAL_CV(8) HEAL_CV(32) HEAL_CV(64)
+    // 16 (or a channel count the choice does not divide)
+#undef HEAL_CV
+    dim3 grid(ceil_div(cells4, 256), channels / 16, n_agents);
+    if (nt) k_canvas<16, true><<<grid, 256, 0, s>>>(map4, rows, cells4, channels, out4);
+    else k_canvas<16, false><<<grid, 256, 0, s>>>(map4, rows, cells4, channels, out4);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
