@@ -20,6 +20,7 @@
 //     v_mfma_f32_16x16x4_f32 accumulates; taps that have no neighbour anywhere in the block are
 //     skipped.  BatchNorm scale/shift and ReLU are the epilogue.  fp32 in, fp32 accumulate: the
 //     result is a fixed-order fmaf chain per output (deterministic, no atomics).
+#include <stdlib.h>
 #include "prims.h"
 #include "../../include/heal_amd.h"
 
@@ -182,8 +183,19 @@ __global__ __launch_bounds__(256) void k_sp_keys_to_idx(const uint32_t* __restri
 // ---- gather-GEMM on the fp32 matrix cores -----------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_sp_conv(const float* __restrict__ feat_in,
+// 32 output sites (two 16-row MFMA tiles) per block, the K taps SPLIT over the block's 4 waves.
+//   * the kernel is gather-latency-bound (per tap: neighbour ids -> row gather -> LDS -> MFMA, a serial chain); with
+//     split-K each wave walks a quarter of the chain on its own LDS slice, no barrier until the final reduction, and a
+//     layer with 15 k active sites is ~470 blocks x 4 independent waves instead of 235 blocks that serialise 27 taps
+//     behind four block barriers each (64->64 layer: 144 -> see DESIGN.md);
+//   * taps with no neighbour among the 32 sites are skipped (wave-uniform ballot);
+//   * A (gathered neighbour rows): coalesced row loads into the wave's LDS slice (64/CIN rows per instruction for
+//     narrow layers), fragments read back conflict-free (row stride CIN+4 floats);
+//   * B (the tap's [CIN,COUT] weight slice): read straight from the reference layout in fragment order -- lane (k, n)
+//     reads W[tap][4kc + k][16nb + n], four 64-B runs per load, L2-resident -- no LDS staging, no re-layout;
+//   * fixed summation order (wave w: taps w, w+4, ...; then ((w0 + w1) + w2) + w3): deterministic.
+template <int CIN, int COUT, int NW /*waves per block = tap split*/>
+__global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ feat_in,
                                                 const int* __restrict__ nbr, int n_out, int K,
                                                 const float* __restrict__ weight /*[K][CIN][COUT]*/,
                                                 const float* __restrict__ scale,
@@ -192,67 +204,95 @@ __global__ __launch_bounds__(256) void k_sp_conv(const float* __restrict__ feat_
     constexpr int KC = (CIN + 3) / 4;        // k-steps of 4 input channels
     constexpr int CINP = KC * 4;             // input channels padded to a multiple of 4
     constexpr int NC = COUT / 16;            // 16-wide output-channel blocks
-    constexpr int ASTR = CINP + 2;           // LDS row strides chosen for conflict-free fragment reads
-    constexpr int WSTR = COUT + 16;
-    __shared__ float sW[CINP * WSTR];
-    __shared__ float sA[4][16 * ASTR];
-    __shared__ int sAny;
+    constexpr int ASTR = CINP + 4;           // LDS row stride: (m*ASTR + k) mod 64 distinct for m < 16, k < 4
+    constexpr int MS = 32;                   // sites per block
+    constexpr int LPR = CINP < 64 ? CINP : 64;  // lanes per gathered row
+    constexpr int RPI = 64 / LPR;            // rows per gather instruction
+    constexpr int ACCF = 2 * NC * 4;         // accumulator floats per lane
+    constexpr int SA = MS * ASTR;            // gather slice per wave
+    constexpr int SMEM = (NW * SA > NW * 64 * ACCF) ? NW * SA : NW * 64 * ACCF;
+    __shared__ float smem[SMEM];
 
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int site0 = blockIdx.x * 64 + wave * 16;
-    f32x4 acc[NC];
+    const int lk = l >> 4, ln = l & 15;
+    const int site0 = blockIdx.x * MS;
+    float* sA = smem + wave * SA;
+    f32x4 acc[2][NC];
 #pragma unroll
-    for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int grow = l / LPR, gch = l - grow * LPR;  // gather role of this lane
 
-    for (int tap = 0; tap < K; ++tap) {
-        // which of this wave's 16 rows have a neighbour through this tap?
+    for (int tap = wave; tap < K; tap += NW) {
         int src = -1;
-        if (l < 16 && site0 + l < n_out) src = nbr[(size_t)(site0 + l) * K + tap];
+        if (l < MS && site0 + l < n_out) src = nbr[(size_t)(site0 + l) * K + tap];
         const unsigned long long have = __ballot(src >= 0);
-        if (threadIdx.x == 0) sAny = 0;
-        __syncthreads();
-        if (l == 0 && have) sAny = 1;  // benign race: every writer stores 1
-        __syncthreads();
-        if (!sAny) continue;  // block-uniform: nobody in the 64 sites uses this tap
-        // stage the weight slab of this tap (coalesced) ...
-        for (int e = threadIdx.x; e < CINP * COUT; e += 256) {
-            const int ci = e / COUT, co = e - ci * COUT;
-            sW[ci * WSTR + co] = ci < CIN ? weight[((size_t)tap * CIN + ci) * COUT + co] : 0.f;
+        if (!have) continue;  // wave-uniform: none of the 32 sites has a neighbour through this tap
+        // B fragments of this tap (independent loads, in flight during the gather)
+        float bfr[KC][NC];
+        const float* wt = weight + (size_t)tap * CIN * COUT;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int ci = kc * 4 + lk;
+#pragma unroll
+            for (int n = 0; n < NC; ++n) bfr[kc][n] = ci < CIN ? wt[(size_t)ci * COUT + n * 16 + ln] : 0.f;
         }
-        // ... and the wave's gathered input rows (zero rows where there is no neighbour)
-#pragma unroll 4
-        for (int r = 0; r < 16; ++r) {
+        // gather the neighbour rows (zero rows where there is none)
+#pragma unroll
+        for (int r0 = 0; r0 < MS; r0 += RPI) {
+            const int r = r0 + grow;
             const int j = __shfl(src, r, 64);
-            if (l < CINP) sA[wave][r * ASTR + l] = (j >= 0 && l < CIN) ? feat_in[(size_t)j * CIN + l] : 0.f;
+            float v = 0.f;
+            if (j >= 0 && gch < CIN) v = feat_in[(size_t)j * CIN + gch];
+            if (gch < CINP) sA[r * ASTR + gch] = v;
         }
-        __syncthreads();
-        if (have) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool lo = (have & 0xFFFFull) != 0, hi = (have >> 16) != 0;  // skip an all-zero 16-row tile
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const float a = sA[wave][(l & 15) * ASTR + kc * 4 + (l >> 4)];
+        for (int kc = 0; kc < KC; ++kc) {
+            const float a0 = sA[ln * ASTR + kc * 4 + lk];
+            const float a1 = sA[(16 + ln) * ASTR + kc * 4 + lk];
 #pragma unroll
-                for (int n = 0; n < NC; ++n) {
-                    const float b = sW[(kc * 4 + (l >> 4)) * WSTR + n * 16 + (l & 15)];
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
-                }
+            for (int n = 0; n < NC; ++n) {
+                if (lo) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bfr[kc][n], acc[0][n], 0, 0, 0);
+                if (hi) acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bfr[kc][n], acc[1][n], 0, 0, 0);
             }
         }
-        __syncthreads();  // before the next tap overwrites sW / sA
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // before this wave's next tap overwrites its slice
     }
-    // epilogue: BatchNorm1d (eval) + ReLU on the active sites; C/D layout: col = l&15, row = (l>>4)*4 + reg
+    // reduce the 4 partial accumulators in a fixed order through LDS (the gather slices are free now)
+    __syncthreads();
+    float* part = smem + ((size_t)wave * 64 + l) * ACCF;
 #pragma unroll
-    for (int n = 0; n < NC; ++n) {
-        const int co = n * 16 + (l & 15);
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(m * NC + n) * 4 + r] = acc[m][n][r];
+    __syncthreads();
+    // epilogue: wave w finishes the output-channel blocks n = w, w+4, ...; BatchNorm1d (eval) + ReLU on the active
+    // sites; C/D layout: col = l&15, row = (l>>4)*4 + reg
+    for (int n = wave; n < NC; n += NW) {
+        const int co = n * 16 + ln;
         const float sc = scale[co], sh = shift[co];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int site = site0 + (l >> 4) * 4 + r;
-            if (site < n_out) {
-                float v = fmaf(acc[n][r], sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
-                feat_out[(size_t)site * COUT + co] = v;
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (m * NC + n) * 4 + r;
+                float sum = smem[(size_t)l * ACCF + e];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sum += smem[((size_t)w * 64 + l) * ACCF + e];
+                const int site = site0 + m * 16 + lk * 4 + r;
+                if (site < n_out) {
+                    float v = fmaf(sum, sc, sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                    feat_out[(size_t)site * COUT + co] = v;
+                }
             }
-        }
     }
 }
 
@@ -447,11 +487,16 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
                             int relu, float* feat_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n_out <= 0) return 0;
-    const int blocks = ceil_div(n_out, 64);
+    const int blocks = ceil_div(n_out, 32);
+    static const int nw = []() { const char* e = getenv("HEAL_SP_NW"); return e ? atoi(e) : 4; }();  // tuning: 4 | 8
 #define HEAL_SP_CASE(CI, CO)                                                                              \
     if (c_in == CI && c_out == CO) {                                                                      \
-        k_sp_conv<CI, CO><<<blocks, 256, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight, bn_scale,    \
-                                                 bn_shift, relu, feat_out);                               \
+        if (nw == 8)                                                                                      \
+            k_sp_conv<CI, CO, 8><<<blocks, 512, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight,       \
+                                                        bn_scale, bn_shift, relu, feat_out);              \
+        else                                                                                              \
+            k_sp_conv<CI, CO, 4><<<blocks, 256, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight,       \
+                                                        bn_scale, bn_shift, relu, feat_out);              \
         HEAL_LAUNCH_CHECK();                                                                              \
         return 0;                                                                                         \
     }
