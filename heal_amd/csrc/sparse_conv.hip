@@ -194,7 +194,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 //   * B (the tap's [CIN,COUT] weight slice): read straight from the reference layout in fragment order -- lane (k, n)
 //     reads W[tap][4kc + k][16nb + n], four 64-B runs per load, L2-resident -- no LDS staging, no re-layout;
 //   * fixed summation order (wave w: taps w, w+4, ...; then ((w0 + w1) + w2) + w3): deterministic.
-template <int CIN, int COUT, int NW /*waves per block = tap split*/>
+template <int CIN, int COUT, int NW /*waves per block = tap split*/, int MT /*16-row tiles per block*/>
 __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ feat_in,
                                                 const int* __restrict__ nbr, int n_out, int K,
                                                 const float* __restrict__ weight /*[K][CIN][COUT]*/,
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
     constexpr int CINP = KC * 4;             // input channels padded to a multiple of 4
     constexpr int NC = COUT / 16;            // 16-wide output-channel blocks
     constexpr int ASTR = CINP + 4;           // LDS row stride: (m*ASTR + k) mod 64 distinct for m < 16, k < 4
-    constexpr int MS = 32;                   // sites per block
+    constexpr int MS = 16 * MT;              // sites per block
     constexpr int LPR = CINP < 64 ? CINP : 64;  // lanes per gathered row
     constexpr int RPI = 64 / LPR;            // rows per gather instruction
-    constexpr int ACCF = 2 * NC * 4;         // accumulator floats per lane
+    constexpr int ACCF = MT * NC * 4;        // accumulator floats per lane
     constexpr int SA = MS * ASTR;            // gather slice per wave
     constexpr int SMEM = (NW * SA > NW * 64 * ACCF) ? NW * SA : NW * 64 * ACCF;
     __shared__ float smem[SMEM];
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
     const int lk = l >> 4, ln = l & 15;
     const int site0 = blockIdx.x * MS;
     float* sA = smem + wave * SA;
-    f32x4 acc[2][NC];
+    f32x4 acc[MT][NC];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NC; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int grow = l / LPR, gch = l - grow * LPR;  // gather role of this lane
@@ -249,16 +249,19 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool lo = (have & 0xFFFFull) != 0, hi = (have >> 16) != 0;  // skip an all-zero 16-row tile
+        bool live[MT];  // skip an all-zero 16-row tile
+#pragma unroll
+        for (int m = 0; m < MT; ++m) live[m] = ((have >> (16 * m)) & 0xFFFFull) != 0;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            const float a0 = sA[ln * ASTR + kc * 4 + lk];
-            const float a1 = sA[(16 + ln) * ASTR + kc * 4 + lk];
+            float a[MT];
 #pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                if (lo) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bfr[kc][n], acc[0][n], 0, 0, 0);
-                if (hi) acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bfr[kc][n], acc[1][n], 0, 0, 0);
-            }
+            for (int m = 0; m < MT; ++m) a[m] = sA[(16 * m + ln) * ASTR + kc * 4 + lk];
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if (live[m]) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bfr[kc][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();  // before this wave's next tap overwrites its slice
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
     __syncthreads();
     float* part = smem + ((size_t)wave * 64 + l) * ACCF;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NC; ++n)
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
         const int co = n * 16 + ln;
         const float sc = scale[co], sh = shift[co];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int e = (m * NC + n) * 4 + r;
@@ -487,16 +490,13 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
                             int relu, float* feat_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n_out <= 0) return 0;
+    // Block shape sweep on MI355X (SECOND encoder, 43 k voxels, 64->64 layers): 32 sites x 4 tap-waves 97 us;
+    // 16 sites x 4: 190 (weight fragments re-read twice as often); 64 sites x 4: 140 (occupancy 2); 32 sites x 8: 106.
     const int blocks = ceil_div(n_out, 32);
-    static const int nw = []() { const char* e = getenv("HEAL_SP_NW"); return e ? atoi(e) : 4; }();  // tuning: 4 | 8
 #define HEAL_SP_CASE(CI, CO)                                                                              \
     if (c_in == CI && c_out == CO) {                                                                      \
-        if (nw == 8)                                                                                      \
-            k_sp_conv<CI, CO, 8><<<blocks, 512, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight,       \
-                                                        bn_scale, bn_shift, relu, feat_out);              \
-        else                                                                                              \
-            k_sp_conv<CI, CO, 4><<<blocks, 256, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight,       \
-                                                        bn_scale, bn_shift, relu, feat_out);              \
+        k_sp_conv<CI, CO, 4, 2><<<blocks, 256, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight,        \
+                                                       bn_scale, bn_shift, relu, feat_out);               \
         HEAL_LAUNCH_CHECK();                                                                              \
         return 0;                                                                                         \
     }
