@@ -40,21 +40,22 @@ _SIGNATURES = {
     "heal_bev_pool_workspace": (c_size_t, [c_int] * 9),
     "heal_bev_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "heal_mean_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "heal_mean_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_sort_workspace": (c_size_t, [c_int]),
-    "heal_sp_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_sp_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                   c_void_p]),
     "heal_sp_table_capacity": (c_size_t, [c_int]),
-    "heal_sp_hash_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_sp_hash_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "heal_sp_neighbors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                  c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "heal_sp_out_sites_workspace": (c_size_t, [c_int, c_int]),
     "heal_sp_out_sites": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                  c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "heal_sp_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                             c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p]),
     "heal_sp_to_bev_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "heal_sp_to_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
-                               c_void_p]),
+                               c_void_p, c_void_p]),
     "heal_agent_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                      c_int, c_void_p, c_void_p]),
     "heal_grouped_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -52,11 +52,18 @@ __device__ __forceinline__ int sp_lookup(const uint32_t* __restrict__ tkey, cons
     }
 }
 
+// Row counts may live on the device (n_dev != NULL): the host then passes the CAPACITY of the buffers and every kernel
+// clamps to min(*n_dev, capacity) -- no host round trip between the layers, the whole encoder is graph-capturable.
+__device__ __forceinline__ int live_rows(const int* __restrict__ n_dev, int cap) {
+    return n_dev ? min(*n_dev, cap) : cap;
+}
+
 // ---- MeanVFE ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mean_vfe(const float* __restrict__ voxels,
-                                                 const int* __restrict__ num, int M, int P, int F,
-                                                 float* __restrict__ out) {
+                                                 const int* __restrict__ num, int M_cap, int P, int F,
+                                                 const int* __restrict__ n_dev, float* __restrict__ out) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    const int M = live_rows(n_dev, M_cap);
     if (t >= M * F) return;
     const int m = t / F, f = t - m * F;
     float s = 0.f;
@@ -66,30 +73,34 @@ __global__ __launch_bounds__(256) void k_mean_vfe(const float* __restrict__ voxe
 }
 
 // ---- keys / hash -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sp_keys(const int4* __restrict__ idx, int n, SpShape s,
-                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_sp_keys(const int4* __restrict__ idx, int cap, const int* __restrict__ n_dev,
+                                                SpShape s, uint32_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= cap) return;
+    vals[i] = (uint32_t)i;
+    if (i >= live_rows(n_dev, cap)) { keys[i] = SP_EMPTY; return; }  // padding rows sort last (stable: they come last)
     const int4 c = idx[i];  // (b, z, y, x)
     keys[i] = sp_key(s, c.x, c.y, c.z, c.w);
-    vals[i] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void k_sp_apply_perm(const int4* __restrict__ idx,
-                                                      const uint32_t* __restrict__ perm, int n,
+                                                      const uint32_t* __restrict__ perm, int cap,
+                                                      const int* __restrict__ n_dev,
                                                       int4* __restrict__ idx_sorted, int* __restrict__ perm_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_rows(n_dev, cap)) return;
     const uint32_t j = perm[i];
     idx_sorted[i] = idx[j];
     perm_out[i] = (int)j;
 }
 
-__global__ __launch_bounds__(256) void k_sp_hash_insert(const int4* __restrict__ idx, int n, SpShape s,
+__global__ __launch_bounds__(256) void k_sp_hash_insert(const int4* __restrict__ idx, int cap,
+                                                       const int* __restrict__ n_dev, SpShape s,
                                                        uint32_t* __restrict__ tkey, int* __restrict__ tval,
                                                        uint32_t mask) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_rows(n_dev, cap)) return;
     const int4 c = idx[i];
     const uint32_t key = sp_key(s, c.x, c.y, c.z, c.w);
     uint32_t slot = sp_hash(key) & mask;
@@ -108,13 +119,14 @@ struct SpConvGeom {
 
 // neighbour table: nbr[o][tap] = input row feeding output o through tap (kz,ky,kx), or -1.
 // input coordinate = o*s - p + tap   (cross-correlation, taps enumerated (kz,ky,kx) row-major)
-__global__ __launch_bounds__(256) void k_sp_nbr(const int4* __restrict__ out_idx, int n_out, SpConvGeom g,
+__global__ __launch_bounds__(256) void k_sp_nbr(const int4* __restrict__ out_idx, int out_cap,
+                                               const int* __restrict__ n_dev, SpConvGeom g,
                                                const uint32_t* __restrict__ tkey,
                                                const int* __restrict__ tval, uint32_t mask,
                                                int* __restrict__ nbr) {
     const int K = g.k[0] * g.k[1] * g.k[2];
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)n_out * K) return;
+    if (t >= (long long)live_rows(n_dev, out_cap) * K) return;
     const int o = (int)(t / K), tap = (int)(t - (long long)o * K);
     const int kz = tap / (g.k[1] * g.k[2]), ky = (tap / g.k[2]) % g.k[1], kx = tap % g.k[2];
     const int4 c = out_idx[o];
@@ -128,11 +140,12 @@ __global__ __launch_bounds__(256) void k_sp_nbr(const int4* __restrict__ out_idx
 }
 
 // strided conv: every (input site, tap) proposes the output cell it contributes to
-__global__ __launch_bounds__(256) void k_sp_candidates(const int4* __restrict__ in_idx, int n_in, SpConvGeom g,
+__global__ __launch_bounds__(256) void k_sp_candidates(const int4* __restrict__ in_idx, int in_cap,
+                                                      const int* __restrict__ n_dev, SpConvGeom g,
                                                       uint32_t* __restrict__ okey, uint32_t omask) {
     const int K = g.k[0] * g.k[1] * g.k[2];
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)n_in * K) return;
+    if (t >= (long long)live_rows(n_dev, in_cap) * K) return;
     const int i = (int)(t / K), tap = (int)(t - (long long)i * K);
     const int kz = tap / (g.k[1] * g.k[2]), ky = (tap / g.k[2]) % g.k[1], kx = tap % g.k[2];
     const int4 c = in_idx[i];
@@ -196,11 +209,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 //   * fixed summation order (wave w: taps w, w+4, ...; then ((w0 + w1) + w2) + w3): deterministic.
 template <int CIN, int COUT, int NW /*waves per block = tap split*/, int MT /*16-row tiles per block*/>
 __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ feat_in,
-                                                const int* __restrict__ nbr, int n_out, int K,
+                                                const int* __restrict__ nbr, int out_cap,
+                                                const int* __restrict__ n_dev, int K,
                                                 const float* __restrict__ weight /*[K][CIN][COUT]*/,
                                                 const float* __restrict__ scale,
                                                 const float* __restrict__ shift, int relu,
                                                 float* __restrict__ feat_out /*[n_out][COUT]*/) {
+    const int n_out = live_rows(n_dev, out_cap);
+    if ((int)blockIdx.x * 16 * MT >= n_out) return;  // blocks beyond the live rows (capacity-sized grid)
     constexpr int KC = (CIN + 3) / 4;        // k-steps of 4 input channels
     constexpr int CINP = KC * 4;             // input channels padded to a multiple of 4
     constexpr int NC = COUT / 16;            // 16-wide output-channel blocks
@@ -300,10 +316,11 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
 }
 
 // ---- sparse -> dense BEV ([B, C*D, H, W], channel = c*D + z : height_compression.py:21-23) ------------
-__global__ __launch_bounds__(256) void k_sp_fill_map(const int4* __restrict__ idx, int n, SpShape s,
+__global__ __launch_bounds__(256) void k_sp_fill_map(const int4* __restrict__ idx, int cap,
+                                                    const int* __restrict__ n_dev, SpShape s,
                                                     int* __restrict__ cell_map /*[B][D][H*W]*/) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_rows(n_dev, cap)) return;
     const int4 c = idx[i];
     cell_map[(size_t)((c.x * s.D + c.y) * s.H + c.z) * s.W + c.w] = i;
 }
@@ -348,10 +365,10 @@ static bool shape_ok(const int* shape, int batch, SpShape& s) {
 using namespace heal;
 
 extern "C" int heal_mean_vfe(const float* voxels, const int32_t* num_points, int n_voxels, int max_points,
-                             int n_feat, float* out, void* stream) {
+                             int n_feat, float* out, const int32_t* n_dev, void* stream) {
     if (n_voxels <= 0) return 0;
     k_mean_vfe<<<ceil_div(n_voxels * n_feat, 256), 256, 0, (hipStream_t)stream>>>(voxels, num_points, n_voxels,
-                                                                                 max_points, n_feat, out);
+                                                                                 max_points, n_feat, n_dev, out);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -364,7 +381,7 @@ extern "C" size_t heal_sp_sort_workspace(int n) {
 // Sort the active sites by linear coordinate: sorted_indices[i] = indices[perm[i]].
 extern "C" int heal_sp_sort_sites(const int32_t* indices, int n, const int32_t* shape_host, int batch,
                                   int32_t* sorted_indices, int32_t* perm, void* ws, size_t ws_bytes,
-                                  void* stream) {
+                                  const int32_t* n_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     SpShape sh;
     HEAL_REQUIRE(shape_ok(shape_host, batch, sh), "sp_sort_sites: bad shape");
@@ -375,13 +392,14 @@ extern "C" int heal_sp_sort_sites(const int32_t* indices, int n, const int32_t* 
     int* scratch = a.take<int>(sort_scratch_words(n));
     HEAL_REQUIRE(a.ok(), "sp_sort_sites: workspace too small");
     const int4* idx = reinterpret_cast<const int4*>(indices);
-    k_sp_keys<<<ceil_div(n, 256), 256, 0, s>>>(idx, n, sh, keys[0], vals[0]);
+    k_sp_keys<<<ceil_div(n, 256), 256, 0, s>>>(idx, n, n_dev, sh, keys[0], vals[0]);
     const uint64_t cells = (uint64_t)batch * sh.D * sh.H * sh.W;
     int bits = 1;
     while (bits < 32 && (1ull << bits) < cells) ++bits;
     int res = 0;
     if (radix_sort_pairs(keys, vals, n, bits, &res, scratch, s)) return 1;
-    k_sp_apply_perm<<<ceil_div(n, 256), 256, 0, s>>>(idx, vals[res], n, reinterpret_cast<int4*>(sorted_indices), perm);
+    k_sp_apply_perm<<<ceil_div(n, 256), 256, 0, s>>>(idx, vals[res], n, n_dev, reinterpret_cast<int4*>(sorted_indices),
+                                                     perm);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -390,15 +408,16 @@ extern "C" size_t heal_sp_table_capacity(int n) { return pow2_cap(n); }
 
 // Build the hash grid of a site set: table_keys[cap] u32, table_vals[cap] i32 (cap = heal_sp_table_capacity(n)).
 extern "C" int heal_sp_hash_build(const int32_t* indices, int n, const int32_t* shape_host, int batch,
-                                  uint32_t* table_keys, int32_t* table_vals, size_t table_cap, void* stream) {
+                                  uint32_t* table_keys, int32_t* table_vals, size_t table_cap, const int32_t* n_dev,
+                                  void* stream) {
     hipStream_t s = (hipStream_t)stream;
     SpShape sh;
     HEAL_REQUIRE(shape_ok(shape_host, batch, sh), "sp_hash_build: bad shape");
     HEAL_REQUIRE(table_cap >= pow2_cap(n) && (table_cap & (table_cap - 1)) == 0, "sp_hash_build: bad table capacity");
     HEAL_HIP(hipMemsetAsync(table_keys, 0xFF, table_cap * sizeof(uint32_t), s));
     if (n > 0) {
-        k_sp_hash_insert<<<ceil_div(n, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(indices), n, sh, table_keys,
-                                                          table_vals, (uint32_t)table_cap - 1);
+        k_sp_hash_insert<<<ceil_div(n, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(indices), n, n_dev, sh,
+                                                          table_keys, table_vals, (uint32_t)table_cap - 1);
         HEAL_LAUNCH_CHECK();
     }
     return 0;
@@ -418,14 +437,15 @@ extern "C" int heal_sp_neighbors(const int32_t* out_indices, int n_out, const in
                                  const int32_t* stride_host, const int32_t* padding_host,
                                  const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
                                  const uint32_t* table_keys, const int32_t* table_vals, size_t table_cap,
-                                 int32_t* nbr, void* stream) {
+                                 int32_t* nbr, const int32_t* n_out_dev, void* stream) {
     SpConvGeom g;
     if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
     if (n_out <= 0) return 0;
     const int K = g.k[0] * g.k[1] * g.k[2];
     const long long total = (long long)n_out * K;
     k_sp_nbr<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const int4*>(out_indices), n_out, g, table_keys, table_vals, (uint32_t)table_cap - 1, nbr);
+        reinterpret_cast<const int4*>(out_indices), n_out, n_out_dev, g, table_keys, table_vals, (uint32_t)table_cap - 1,
+        nbr);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -445,7 +465,7 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
                                  const int32_t* stride_host, const int32_t* padding_host,
                                  const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
                                  int32_t* out_indices, int out_cap, int32_t* n_out, void* ws, size_t ws_bytes,
-                                 void* stream) {
+                                 const int32_t* n_in_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     SpConvGeom g;
     if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
@@ -464,7 +484,7 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
     HEAL_HIP(hipMemsetAsync(okey, 0xFF, (size_t)cap * 4, s));
     const long long total = (long long)n_in * K;
     k_sp_candidates<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(reinterpret_cast<const int4*>(in_indices), n_in,
-                                                                    g, okey, cap - 1);
+                                                                    n_in_dev, g, okey, cap - 1);
     k_sp_slot_flags<<<ceil_div((int)cap, 256), 256, 0, s>>>(okey, (int)cap, flag);
     if (scan_exclusive(flag, flag, (int)cap, n_out, cscratch, s)) return 1;
     // unique keys -> compact; pad the tail with 0xFFFFFFFF so that a fixed-size sort puts them last
@@ -487,7 +507,7 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
 // out[o] = act( BN( sum_tap W[tap]^T in[nbr[o][tap]] ) ); weight [K][Cin][Cout].
 extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in,
                             int c_out, const float* weight, const float* bn_scale, const float* bn_shift,
-                            int relu, float* feat_out, void* stream) {
+                            int relu, float* feat_out, const int32_t* n_out_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n_out <= 0) return 0;
     // Block shape sweep on MI355X (SECOND encoder, 43 k voxels, 64->64 layers): 32 sites x 4 tap-waves 97 us;
@@ -495,7 +515,7 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
     const int blocks = ceil_div(n_out, 32);
 #define HEAL_SP_CASE(CI, CO)                                                                              \
     if (c_in == CI && c_out == CO) {                                                                      \
-        k_sp_conv<CI, CO, 4, 2><<<blocks, 256, 0, s>>>(feat_in, nbr, n_out, kernel_volume, weight,        \
+        k_sp_conv<CI, CO, 4, 2><<<blocks, 256, 0, s>>>(feat_in, nbr, n_out, n_out_dev, kernel_volume, weight,    \
                                                        bn_scale, bn_shift, relu, feat_out);               \
         HEAL_LAUNCH_CHECK();                                                                              \
         return 0;                                                                                         \
@@ -513,7 +533,7 @@ extern "C" size_t heal_sp_to_bev_workspace(int batch, int D, int H, int W) {
 // Sparse tensor -> dense [B, C*D, H, W] (channel = c*D + z), every element written.
 extern "C" int heal_sp_to_bev(const float* features, const int32_t* indices, int n, int channels,
                               const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes,
-                              void* stream) {
+                              const int32_t* n_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     SpShape sh;
     HEAL_REQUIRE(shape_ok(shape_host, batch, sh), "sp_to_bev: bad shape");
@@ -525,7 +545,7 @@ extern "C" int heal_sp_to_bev(const float* features, const int32_t* indices, int
     HEAL_REQUIRE(a.ok(), "sp_to_bev: workspace too small");
     HEAL_HIP(hipMemsetAsync(cell_map, 0xFF, cells * 4, s));
     if (n > 0)
-        k_sp_fill_map<<<ceil_div(n, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(indices), n, sh, cell_map);
+        k_sp_fill_map<<<ceil_div(n, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(indices), n, n_dev, sh, cell_map);
     const int cells4 = sh.H * sh.W / 4;
     dim3 grid(ceil_div(cells4, 256), ceil_div(channels, 16), batch * sh.D);
     k_sp_dense<<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(cell_map), features, cells4, channels, sh.D,

@@ -100,19 +100,19 @@ class SECOND(nn.Module):
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         inp = data_dict[f"inputs_{modality_name}"]
+        n_dev = None
         if "points" in inp:
-            vs, cs, ns = [], [], []
-            for b, pts in enumerate(inp["points"]):
-                v, c, n = ops.voxelize(pts, self.lidar_range, self.voxel_size, self.max_points, self.max_voxels,
-                                       batch_idx=b, sync=True)
-                vs.append(v); cs.append(c); ns.append(n)
-            voxels, coords, num = torch.cat(vs), torch.cat(cs), torch.cat(ns)
+            # K1 per agent into collated buffers, the voxel count stays on the device: the whole encoder runs without
+            # a host round trip (sparse layers take capacity + device count)
+            voxels, coords, num, offsets = ops.voxelize_collated(inp["points"], self.lidar_range, self.voxel_size,
+                                                                 self.max_points, self.max_voxels)
             batch_size = len(inp["points"])
+            n_dev = offsets[batch_size:batch_size + 1]
         else:
             voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
             batch_size = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
         batch_dict = {"voxel_features": voxels, "voxel_coords": coords, "voxel_num_points": num,
-                      "batch_size": batch_size}
+                      "batch_size": batch_size, "n_voxels_dev": n_dev}
         batch_dict = self.vfe(batch_dict)
         batch_dict = self.spconv_block(batch_dict)
         batch_dict = self.map_to_bev(batch_dict)

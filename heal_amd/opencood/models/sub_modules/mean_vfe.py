@@ -18,5 +18,5 @@ class MeanVFE(nn.Module):
         num = batch_dict["voxel_num_points"]
         if num.dtype != torch.int32:
             num = num.to(torch.int32)
-        batch_dict["voxel_features"] = ops.mean_vfe(batch_dict["voxel_features"], num)
+        batch_dict["voxel_features"] = ops.mean_vfe(batch_dict["voxel_features"], num, batch_dict.get("n_voxels_dev"))
         return batch_dict

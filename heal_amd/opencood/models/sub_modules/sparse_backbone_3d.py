@@ -64,16 +64,16 @@ class _Block(nn.Sequential):
             nbr = nbr_cache.get(conv.indice_key)
             if nbr is None:
                 nbr = x.neighbors(x.indices, x.spatial_shape, conv.kernel_size, (1, 1, 1),
-                                  tuple(k // 2 for k in conv.kernel_size))
+                                  tuple(k // 2 for k in conv.kernel_size), n_out_dev=x.n_dev)
                 nbr_cache[conv.indice_key] = nbr
-            feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True)
-            y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size)
+            feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=x.n_dev)
+            y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.n_dev, x._checks)
             y._table = x._table
             return y
-        out_idx, out_shape = x.out_sites(conv.kernel_size, conv.stride, conv.padding)
-        nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding)
-        feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True)
-        return SparseTensor(feats, out_idx, out_shape, x.batch_size)
+        out_idx, out_shape, n_out_dev = x.out_sites(conv.kernel_size, conv.stride, conv.padding)
+        nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, n_out_dev=n_out_dev)
+        feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=n_out_dev)
+        return SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks)
 
 
 def _block(cin, cout, k, key, stride=1, padding=0, conv_type="subm"):
@@ -103,7 +103,8 @@ class VoxelBackBone8x(nn.Module):
     def forward(self, batch_dict):
         from heal_amd.ops import SparseTensor
         x = SparseTensor.from_unsorted(batch_dict["voxel_features"], batch_dict["voxel_coords"].int().contiguous(),
-                                       self.sparse_shape, int(batch_dict["batch_size"]))
+                                       self.sparse_shape, int(batch_dict["batch_size"]),
+                                       n_dev=batch_dict.get("n_voxels_dev"))
         cache = {}
         x = self.conv_input.run(x, cache)
         for stage in (self.conv1, self.conv2, self.conv3, self.conv4):

@@ -349,43 +349,59 @@ def _i3(v):
     return _host_array([int(x) for x in v], ctypes.c_int32)
 
 
-def mean_vfe(voxels, num_points):
-    """MeanVFE: voxels [M,P,F], num_points [M] -> [M,F]."""
+def _optr(t):
+    return _ptr(t) if t is not None else None
+
+
+def mean_vfe(voxels, num_points, n_dev=None):
+    """MeanVFE: voxels [M,P,F], num_points [M] -> [M,F].  n_dev: optional device row count (M is then the capacity)."""
     voxels = _need(voxels, torch.float32, "voxels")
     num_points = _need(num_points, torch.int32, "num_points")
     M, P, F = (int(v) for v in voxels.shape)
     out = torch.empty((M, F), dtype=torch.float32, device=voxels.device)
-    _capi.call("heal_mean_vfe", _ptr(voxels), _ptr(num_points), M, P, F, _ptr(out), _stream())
+    _capi.call("heal_mean_vfe", _ptr(voxels), _ptr(num_points), M, P, F, _ptr(out), _optr(n_dev), _stream())
     return out
 
 
 class SparseTensor:
-    """features [n,C] f32 + indices [n,4] i32 (b,z,y,x) sorted by linear coordinate + shape (D,H,W)."""
+    """features [n,C] f32 + indices [n,4] i32 (b,z,y,x) sorted by linear coordinate + shape (D,H,W).
 
-    def __init__(self, features, indices, spatial_shape, batch_size):
+    `n_dev` (int32 [1] on the device, or None): when set, the buffers have CAPACITY rows and the live row count stays
+    on the device -- no host round trip anywhere in the encoder (HIP-graph capturable).  Strided layers then size their
+    outputs by a capacity bound (2x the input capacity) instead of the exact count; `overflow()` reports, after the
+    fact, whether any layer produced more sites than its capacity."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, n_dev=None, checks=None):
         self.features = features
         self.indices = indices
         self.spatial_shape = [int(v) for v in spatial_shape]
         self.batch_size = int(batch_size)
+        self.n_dev = n_dev
+        self._checks = checks if checks is not None else []
         self._table = None
 
     @property
     def n(self):
+        """Rows of the buffers (= live rows when n_dev is None, capacity otherwise)."""
         return int(self.indices.shape[0])
 
+    def overflow(self):
+        """Host check (synchronises): True if a strided layer found more active sites than its capacity."""
+        return any(int(c.item()) > cap for c, cap in self._checks)
+
     @staticmethod
-    def from_unsorted(features, indices, spatial_shape, batch_size):
+    def from_unsorted(features, indices, spatial_shape, batch_size, n_dev=None):
         """Sort the sites by linear coordinate (K3 keeps them sorted for coherent tiles)."""
         features = _need(features, torch.float32, "features")
         indices = _need(indices, torch.int32, "indices")
         n = int(indices.shape[0])
         dev = indices.device
         sorted_idx = torch.empty_like(indices)
-        perm = torch.empty((n,), dtype=torch.int32, device=dev)
+        perm = torch.zeros((n,), dtype=torch.int32, device=dev)  # zeros: padding rows gather row 0, harmlessly
         ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
         _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
-                   _ptr(perm), _ptr(ws), ws.numel(), _stream())
-        return SparseTensor(features.index_select(0, perm.long()), sorted_idx, spatial_shape, batch_size)
+                   _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
+        return SparseTensor(features.index_select(0, perm.long()), sorted_idx, spatial_shape, batch_size, n_dev)
 
     def table(self):
         if self._table is None:
@@ -394,36 +410,41 @@ class SparseTensor:
             keys = torch.empty((cap,), dtype=torch.int32, device=dev)
             vals = torch.empty((cap,), dtype=torch.int32, device=dev)
             _capi.call("heal_sp_hash_build", _ptr(self.indices), self.n, _i3(self.spatial_shape), self.batch_size,
-                       _ptr(keys), _ptr(vals), cap, _stream())
+                       _ptr(keys), _ptr(vals), cap, _optr(self.n_dev), _stream())
             self._table = (keys, vals, cap)
         return self._table
 
-    def neighbors(self, out_indices, out_shape, ksize, stride, padding):
+    def neighbors(self, out_indices, out_shape, ksize, stride, padding, n_out_dev=None):
         keys, vals, cap = self.table()
         n_out = int(out_indices.shape[0])
         K = int(ksize[0] * ksize[1] * ksize[2])
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.indices.device)
         _capi.call("heal_sp_neighbors", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
                    _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(keys), _ptr(vals), cap,
-                   _ptr(nbr), _stream())
+                   _ptr(nbr), _optr(n_out_dev), _stream())
         return nbr
 
     def out_sites(self, ksize, stride, padding):
-        """Active output sites of a strided conv: (indices [n_out,4] sorted, out_shape)."""
+        """Active output sites of a strided conv: (indices sorted, out_shape, n_out_dev).  Exact-size indices and
+        n_out_dev None when this tensor carries host counts; capacity-size indices plus the device count otherwise."""
         out_shape = [(self.spatial_shape[d] + 2 * padding[d] - ksize[d]) // stride[d] + 1 for d in range(3)]
         K = int(ksize[0] * ksize[1] * ksize[2])
         dev = self.indices.device
         cells = self.batch_size * out_shape[0] * out_shape[1] * out_shape[2]
-        out_cap = max(1, min(self.n * min(K, 8), cells))
+        worst = max(1, min(self.n * min(K, 8), cells))
+        out_cap = worst if self.n_dev is None else max(1, min(worst, 2 * self.n))
         out_idx = torch.empty((out_cap, 4), dtype=torch.int32, device=dev)
         n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
         ws = _workspace("sp_out_sites", _capi.query("heal_sp_out_sites_workspace", self.n, K), dev)
         _capi.call("heal_sp_out_sites", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
                    _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
-                   _ptr(ws), ws.numel(), _stream())
-        return out_idx[:int(n_out.item())], out_shape
+                   _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
+        if self.n_dev is None:
+            return out_idx[:int(n_out.item())], out_shape, None
+        self._checks.append((n_out, out_cap))
+        return out_idx, out_shape, n_out
 
-    def conv(self, nbr, weight, bn_scale, bn_shift, relu=True):
+    def conv(self, nbr, weight, bn_scale, bn_shift, relu=True, n_out_dev=None):
         """Gather-GEMM: weight [K,Cin,Cout]; returns features [n_out,Cout]."""
         weight = _need(weight, torch.float32, "weight")
         K, cin, cout = (int(v) for v in weight.shape)
@@ -432,7 +453,7 @@ class SparseTensor:
         with _Timed(f"sp_conv_{cin}_{cout}"):
             _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight),
                        _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
-                       int(bool(relu)), _ptr(out), _stream())
+                       int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
         return out
 
     def dense(self):
@@ -443,7 +464,7 @@ class SparseTensor:
         out = torch.empty((self.batch_size, C * D, H, W), dtype=torch.float32, device=dev)
         ws = _workspace("sp_to_bev", _capi.query("heal_sp_to_bev_workspace", self.batch_size, D, H, W), dev)
         _capi.call("heal_sp_to_bev", _ptr(self.features), _ptr(self.indices), self.n, C, _i3(self.spatial_shape),
-                   self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _stream())
+                   self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
         return out
 
 

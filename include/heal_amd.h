@@ -161,37 +161,46 @@ int heal_bev_pool(const float* depth_logit, const float* feat, const float* frus
  * A sparse tensor is features [n,C] f32 + indices [n,4] i32 (b,z,y,x) + spatial shape (D,H,W) host.
  * Site sets are kept sorted by linear coordinate.  Shapes / kernel / stride / padding are host int[3]
  * in (z,y,x) order.
+ * Row counts: every entry point takes the host value `n` AND an optional device pointer (`n_dev`, `n_out_dev`,
+ * `n_in_dev`; NULL = use n).  With a device pointer, `n` is the CAPACITY of the buffers and the live row count is
+ * min(*ptr, n): the whole encoder then runs without a host round trip (strided layers produce their site count on the
+ * device) and can be captured in a HIP graph.  Rows beyond the live count are unspecified.
  * -----------------------------------------------------------------------------------------------*/
 int heal_mean_vfe(const float* voxels, const int32_t* num_points, int n_voxels, int max_points, int n_feat,
-                  float* out, void* stream);
+                  float* out, const int32_t* n_dev, void* stream);
 size_t heal_sp_sort_workspace(int n);
 int heal_sp_sort_sites(const int32_t* indices, int n, const int32_t* shape_host, int batch,
-                       int32_t* sorted_indices, int32_t* perm, void* ws, size_t ws_bytes, void* stream);
+                       int32_t* sorted_indices, int32_t* perm, void* ws, size_t ws_bytes, const int32_t* n_dev,
+                       void* stream);
 size_t heal_sp_table_capacity(int n);
 int heal_sp_hash_build(const int32_t* indices, int n, const int32_t* shape_host, int batch,
-                       uint32_t* table_keys, int32_t* table_vals, size_t table_cap, void* stream);
+                       uint32_t* table_keys, int32_t* table_vals, size_t table_cap, const int32_t* n_dev,
+                       void* stream);
 /* nbr [n_out, K] i32: input row feeding output site o through tap (kz,ky,kx) row-major, or -1;
  * input coordinate = o*stride - padding + tap (cross-correlation).  Submanifold: pass the input
  * sites as out_indices with stride 1 and padding k/2.                                              */
 int heal_sp_neighbors(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
                       const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
                       const int32_t* out_shape_host, int batch, const uint32_t* table_keys,
-                      const int32_t* table_vals, size_t table_cap, int32_t* nbr, void* stream);
+                      const int32_t* table_vals, size_t table_cap, int32_t* nbr, const int32_t* n_out_dev,
+                      void* stream);
 /* active output sites of a strided sparse conv (site active iff some active input falls in its
- * receptive field), sorted; out_indices [out_cap,4], n_out [1] device                              */
+ * receptive field), sorted; out_indices [out_cap,4]; n_out [1] device <- number of active output sites
+ * (NOT clamped: a value above out_cap tells the caller that sites were dropped)                     */
 size_t heal_sp_out_sites_workspace(int n_in, int kernel_volume);
 int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int32_t* ksize_host,
                       const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
                       const int32_t* out_shape_host, int batch, int32_t* out_indices, int out_cap,
-                      int32_t* n_out, void* ws, size_t ws_bytes, void* stream);
+                      int32_t* n_out, void* ws, size_t ws_bytes, const int32_t* n_in_dev, void* stream);
 /* feat_out[o] = act(bn_scale * sum_tap W[tap]^T feat_in[nbr[o][tap]] + bn_shift); weight [K,Cin,Cout]
  * (spconv 1.2.1 layout [kz,ky,kx,Cin,Cout]); fp32 MFMA, fixed summation order                       */
 int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in, int c_out,
                  const float* weight, const float* bn_scale, const float* bn_shift, int relu,
-                 float* feat_out, void* stream);
+                 float* feat_out, const int32_t* n_out_dev, void* stream);
 size_t heal_sp_to_bev_workspace(int batch, int D, int H, int W);
 int heal_sp_to_bev(const float* features, const int32_t* indices, int n, int channels,
-                   const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes, void* stream);
+                   const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes,
+                   const int32_t* n_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K6  per-pixel multi-head attention over agents.

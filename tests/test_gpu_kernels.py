@@ -370,7 +370,7 @@ def test_sparse_conv_layer_vs_dense_oracle(cin, cout, ksize, stride, padding, su
         nbr = x.neighbors(x.indices, shape, ksize, (1, 1, 1), tuple(k // 2 for k in ksize))
         out = ops.SparseTensor(x.conv(nbr, dev(w.reshape(K, cin, cout)), dev(scale), dev(shift)), x.indices, shape, batch)
     else:
-        oi, oshape = x.out_sites(ksize, stride, padding)
+        oi, oshape, _ = x.out_sites(ksize, stride, padding)
         nbr = x.neighbors(oi, oshape, ksize, stride, padding)
         out = ops.SparseTensor(x.conv(nbr, dev(w.reshape(K, cin, cout)), dev(scale), dev(shift)), oi, oshape, batch)
     dense, mask = O.densify(feats, idx, shape, batch)
@@ -414,6 +414,42 @@ def test_second_encoder_vs_dense_oracle():
     with torch.no_grad():
         got2 = enc({"inputs_m3": {"points": [dev(pts[0::2]), dev(pts[1::2])]}}, "m3").cpu().numpy()
     np.testing.assert_array_equal(got2, got)
+
+
+def test_sparse_device_counts_and_capacity_overflow_report():
+    """No-host-sync mode of the sparse family: capacity-sized buffers + device row counts give the exact-size result;
+    a strided layer that activates more sites than its capacity bound (isolated voxels dilate 8x) is reported."""
+    from heal_amd import ops
+    rng = np.random.default_rng(0)
+    shape = [9, 32, 32]
+    # dense-ish blob: N_out < N_in
+    zz, yy, xx = np.meshgrid(np.arange(1, 7), np.arange(4, 20), np.arange(4, 20), indexing="ij")
+    idx = np.stack([np.zeros(zz.size), zz.ravel(), yy.ravel(), xx.ravel()], 1).astype(np.int32)
+    idx = idx[rng.permutation(len(idx))[:900]]
+    feats = rng.standard_normal((len(idx), 16)).astype(np.float32)
+    cap = len(idx) + 77  # padding rows behind the live ones
+    fpad = np.concatenate([feats, np.full((77, 16), 7.0, np.float32)])
+    ipad = np.concatenate([idx, np.full((77, 4), 3, np.int32)])
+    n_dev = torch.tensor([len(idx)], dtype=torch.int32).cuda()
+    exact = ops.SparseTensor.from_unsorted(dev(feats), dev(idx), shape, 1)
+    lazy = ops.SparseTensor.from_unsorted(dev(fpad), dev(ipad), shape, 1, n_dev=n_dev)
+    n = len(idx)
+    assert torch.equal(lazy.indices[:n], exact.indices) and torch.equal(lazy.features[:n], exact.features)
+    k, st, pd = (3, 3, 3), (2, 2, 2), (1, 1, 1)
+    oi, osh, _ = exact.out_sites(k, st, pd)
+    oj, osh2, n_out_dev = lazy.out_sites(k, st, pd)
+    m = int(n_out_dev.item())
+    assert osh == osh2 and m == oi.shape[0] and torch.equal(oj[:m], oi) and not lazy.overflow()
+    w = torch.randn((27, 16, 32)).cuda(); sc = torch.ones(32).cuda(); sh = torch.zeros(32).cuda()
+    a = exact.conv(exact.neighbors(oi, osh, k, st, pd), w, sc, sh)
+    b = lazy.conv(lazy.neighbors(oj, osh2, k, st, pd, n_out_dev=n_out_dev), w, sc, sh, n_out_dev=n_out_dev)
+    assert torch.equal(b[:m], a)
+    # isolated voxels on odd coordinates: each activates 8 output sites -> exceeds the 2x capacity bound
+    iso = np.array([[0, z, y, x] for z in (1, 5) for y in range(1, 30, 4) for x in range(1, 30, 4)], np.int32)
+    t = ops.SparseTensor.from_unsorted(dev(np.ones((len(iso), 4), np.float32)), dev(iso), shape, 1,
+                                       n_dev=torch.tensor([len(iso)], dtype=torch.int32).cuda())
+    _, _, cnt = t.out_sites(k, st, pd)
+    assert int(cnt.item()) == 8 * len(iso) and t.overflow()
 
 
 # ---------------------------------------------------------------------------------------------- K7
