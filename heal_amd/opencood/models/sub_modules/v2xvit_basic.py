@@ -124,8 +124,15 @@ class BaseWindowAttention(nn.Module):
         qkv = self.to_qkv(x).view(L, nh, ws, nw, ws, 3, m, d)
         qkv = qkv.permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, L * m * nh * nw, ws * ws, d)
         if self.relative_pos_embedding:
-            ri = self.relative_indices
-            bias = self.pos_embedding[ri[:, :, 0], ri[:, :, 1]]
+            # the reference keeps `relative_indices` as a plain (host) attribute -- not a buffer, so it is not in the
+            # state_dict; index with a cached device copy: a host index tensor costs an H2D copy per call and cannot
+            # be captured in a HIP graph
+            ri = self.__dict__.get("_ri_dev")
+            if ri is None or ri[0].device != x.device:
+                r = self.relative_indices.to(x.device)
+                ri = (r[:, :, 0].contiguous(), r[:, :, 1].contiguous())
+                self.__dict__["_ri_dev"] = ri
+            bias = self.pos_embedding[ri[0], ri[1]]
         else:
             bias = self.pos_embedding
         dots = torch.baddbmm(bias.unsqueeze(0).expand(qkv.shape[1], -1, -1), qkv[0], qkv[1].transpose(1, 2),

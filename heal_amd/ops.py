@@ -368,7 +368,8 @@ class SparseTensor:
 
     `n_dev` (int32 [1] on the device, or None): when set, the buffers have CAPACITY rows and the live row count stays
     on the device -- no host round trip anywhere in the encoder (HIP-graph capturable).  Strided layers then size their
-    outputs by a capacity bound (2x the input capacity) instead of the exact count; `overflow()` reports, after the
+    outputs by a capacity bound (the input capacity: strided layers of a LiDAR sweep shrink the site set) instead of
+    the exact count; `overflow()` reports, after the
     fact, whether any layer produced more sites than its capacity."""
 
     def __init__(self, features, indices, spatial_shape, batch_size, n_dev=None, checks=None):
@@ -432,7 +433,7 @@ class SparseTensor:
         dev = self.indices.device
         cells = self.batch_size * out_shape[0] * out_shape[1] * out_shape[2]
         worst = max(1, min(self.n * min(K, 8), cells))
-        out_cap = worst if self.n_dev is None else max(1, min(worst, 2 * self.n))
+        out_cap = worst if self.n_dev is None else max(1, min(worst, self.n))  # a strided layer of a LiDAR sweep shrinks
         out_idx = torch.empty((out_cap, 4), dtype=torch.int32, device=dev)
         n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
         ws = _workspace("sp_out_sites", _capi.query("heal_sp_out_sites_workspace", self.n, K), dev)

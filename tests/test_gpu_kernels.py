@@ -444,7 +444,7 @@ def test_sparse_device_counts_and_capacity_overflow_report():
     a = exact.conv(exact.neighbors(oi, osh, k, st, pd), w, sc, sh)
     b = lazy.conv(lazy.neighbors(oj, osh2, k, st, pd, n_out_dev=n_out_dev), w, sc, sh, n_out_dev=n_out_dev)
     assert torch.equal(b[:m], a)
-    # isolated voxels on odd coordinates: each activates 8 output sites -> exceeds the 2x capacity bound
+    # isolated voxels on odd coordinates: each activates 8 output sites -> exceeds the capacity bound
     iso = np.array([[0, z, y, x] for z in (1, 5) for y in range(1, 30, 4) for x in range(1, 30, 4)], np.int32)
     t = ops.SparseTensor.from_unsorted(dev(np.ones((len(iso), 4), np.float32)), dev(iso), shape, 1,
                                        n_dev=torch.tensor([len(iso)], dtype=torch.int32).cuda())
