@@ -111,5 +111,6 @@ class VoxelBackBone8x(nn.Module):
             for blk in stage:
                 x = blk.run(x, cache)
         out = self.conv_out.run(x, cache)
+        self.last_sparse = out  # plain attribute: lets a caller check SparseTensor.overflow() after the fact
         batch_dict.update({"encoded_spconv_tensor": out, "encoded_spconv_tensor_stride": 8})
         return batch_dict

@@ -152,11 +152,21 @@ class ScenePipeline:
         for _ in range(warmup):
             body()
         cur.synchronize()
+        self.check_sparse_capacity()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=cur):
             self._static_out = body()
         self._graph = graph
         return graph
+
+    def check_sparse_capacity(self):
+        """SECOND encoders fed with device point clouds size their strided layers by capacity (no host round trip);
+        this host-side check (it synchronises) raises if any layer found more active sites than its capacity."""
+        for name, mod in self.model.named_modules():
+            t = getattr(mod, "last_sparse", None)
+            if t is not None and t.overflow():
+                raise RuntimeError(f"{name}: a strided sparse layer produced more active sites than its capacity "
+                                   "(feed exact-size voxel inputs, or raise the capacity policy in SparseTensor.out_sites)")
 
     def replay(self):
         """Replay the captured step; returns (pred_box3d | None, scores | None) like step()."""
