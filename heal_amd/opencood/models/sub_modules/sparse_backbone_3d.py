@@ -67,13 +67,13 @@ class _Block(nn.Sequential):
                                   tuple(k // 2 for k in conv.kernel_size), n_out_dev=x.n_dev)
                 nbr_cache[conv.indice_key] = nbr
             feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=x.n_dev)
-            y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.n_dev, x._checks)
+            y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.n_dev, x._checks, x._root_cap)
             y._table = x._table
             return y
         out_idx, out_shape, n_out_dev = x.out_sites(conv.kernel_size, conv.stride, conv.padding)
         nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, n_out_dev=n_out_dev)
         feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=n_out_dev)
-        return SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks)
+        return SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks, x._root_cap)
 
 
 def _block(cin, cout, k, key, stride=1, padding=0, conv_type="subm"):
