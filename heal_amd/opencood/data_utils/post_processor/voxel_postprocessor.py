@@ -45,6 +45,59 @@ class VoxelPostprocessor:
             return np.stack([cx, cy, cz, l, h, w, r_], axis=-1)
         sys.exit('Unknown bbx order.')
 
+    # ---------------------------------------------------------------------------------------------- training labels
+    @staticmethod
+    def _standup_boxes(boxes, order):
+        """boxes_to_corners_3d + corner2d_to_standup_box (box_utils.py:152-204,225-248) on a float32 device tensor
+        [n,7]: min / max of the 8 rotated corners in x and y -> [n,4] (x1,y1,x2,y2).  float32 like the reference, whose
+        check_numpy_to_torch converts every numpy input with .float()."""
+        b = boxes[:, [0, 1, 2, 5, 4, 3, 6]] if order == 'hwl' else boxes
+        t = torch.tensor([[1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, -1],
+                          [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1]], dtype=torch.float32, device=boxes.device) / 2
+        c = b[:, None, 3:6] * t[None]
+        cosa, sina = torch.cos(b[:, 6])[:, None], torch.sin(b[:, 6])[:, None]
+        x = (c[..., 0] * cosa + c[..., 1] * (-sina)) + c[..., 2] * 0.0   # rows of points @ [[c,s,0],[-s,c,0],[0,0,1]]
+        y = (c[..., 0] * sina + c[..., 1] * cosa) + c[..., 2] * 0.0
+        x = x + b[:, None, 0]
+        y = y + b[:, None, 1]
+        return torch.stack([x.min(1)[0], y.min(1)[0], x.max(1)[0], y.max(1)[0]], 1).contiguous()
+
+    def generate_label(self, **kwargs):
+        """voxel_postprocessor.py:85-207 with the IoU / assignment core on the GPU (heal_label_assign).
+        gt_box_center (max_num,7), anchors (H,W,A,7), mask (max_num) as numpy -> dict of numpy float64 arrays
+        pos_equal_one (H,W,A), neg_equal_one (H,W,A), targets (H,W,7A), like the reference."""
+        assert self.params['order'] == 'hwl', 'Currently Voxel only supporthwl bbx order.'
+        gt_box_center, anchors, masks = kwargs['gt_box_center'], kwargs['anchors'], kwargs['mask']
+        dev = torch.device("cuda", torch.cuda.current_device())
+        H, W, A = anchors.shape[:3]
+        key = (id(anchors), anchors.shape)
+        hit = self._anchor_cache.get(("label",) + key)
+        if hit is None:
+            a64 = torch.from_numpy(np.ascontiguousarray(anchors).reshape(-1, 7)).to(dev)
+            hit = (a64, self._standup_boxes(a64.float(), self.params['order']), anchors)
+            self._anchor_cache[("label",) + key] = hit
+        a64, a_boxes = hit[0], hit[1]
+        gt_all = torch.from_numpy(np.ascontiguousarray(gt_box_center)).to(dev)
+        valid = torch.from_numpy(np.ascontiguousarray(masks) == 1).to(dev)
+        gt_valid = gt_all[valid]
+        g_boxes = self._standup_boxes(gt_valid.float(), self.params['order']) if gt_valid.shape[0] else \
+            torch.zeros((0, 4), dtype=torch.float32, device=dev)
+        t = self.params['target_args']
+        assigned, neg = ops.label_assign(a_boxes, g_boxes, t['pos_threshold'], t['neg_threshold'])
+        pos_idx = torch.nonzero(assigned >= 0)[:, 0]
+        # the reference indexes gt_box_center (all rows) with the index into the masked subset (:172-190)
+        g = gt_all[assigned[pos_idx].long()].double()
+        an = a64[pos_idx]
+        an_d = torch.sqrt(an[:, 4] ** 2 + an[:, 5] ** 2)
+        tgt = torch.zeros((a64.shape[0], 7), dtype=torch.float64, device=dev)
+        tgt[pos_idx] = torch.stack([(g[:, 0] - an[:, 0]) / an_d, (g[:, 1] - an[:, 1]) / an_d, (g[:, 2] - an[:, 2]) / an[:, 3],
+                                    torch.log(g[:, 3] / an[:, 3]), torch.log(g[:, 4] / an[:, 4]),
+                                    torch.log(g[:, 5] / an[:, 5]), g[:, 6] - an[:, 6]], 1)
+        pos = (assigned >= 0).double()
+        return {'pos_equal_one': pos.view(H, W, A).cpu().numpy(),
+                'neg_equal_one': neg.double().view(H, W, A).cpu().numpy(),
+                'targets': tgt.view(H, W, A * 7).cpu().numpy()}
+
     def _anchors_f32(self, anchor_box, device):
         """anchors as contiguous fp32 on the device (delta_to_boxes3d does `.float()`), cached."""
         key = (anchor_box.data_ptr() if isinstance(anchor_box, torch.Tensor) else id(anchor_box), str(device))
@@ -52,7 +105,8 @@ class VoxelPostprocessor:
         if hit is None:
             t = anchor_box if isinstance(anchor_box, torch.Tensor) else torch.from_numpy(np.asarray(anchor_box))
             hit = t.to(device=device, dtype=torch.float32).contiguous()
-            self._anchor_cache = {key: hit}
+            self._anchor_cache = {k: v for k, v in self._anchor_cache.items() if isinstance(k, tuple) and k and k[0] == "label"}
+            self._anchor_cache[key] = hit
         return hit
 
     def post_process(self, data_dict, output_dict):

@@ -269,6 +269,23 @@ def quad_iou(a, b):
     return out
 
 
+def label_assign(anchor_boxes, gt_boxes, pos_threshold, neg_threshold):
+    """Anchor labelling core of generate_label: stand-up boxes [N,4] / [G,4] f32 cuda -> (assigned [N] i32: gt index of a
+    positive anchor or -1, neg [N] u8)."""
+    a = _need(anchor_boxes, torch.float32, "anchor_boxes")
+    g = _need(gt_boxes, torch.float32, "gt_boxes")
+    if a.dim() != 2 or a.shape[1] != 4 or g.dim() != 2 or g.shape[1] != 4:
+        raise _capi.HealAmdError("label_assign: boxes must be [n,4]")
+    n, k = int(a.shape[0]), int(g.shape[0])
+    assigned = torch.empty((n,), dtype=torch.int32, device=a.device)
+    neg = torch.empty((n,), dtype=torch.uint8, device=a.device)
+    need = _capi.query("heal_label_assign_workspace", k)
+    ws = _workspace("label_assign", need, a.device)
+    _capi.call("heal_label_assign", _ptr(a), n, _ptr(g) if k else None, k, float(pos_threshold), float(neg_threshold),
+               _ptr(assigned), _ptr(neg), _ptr(ws), need, _stream())
+    return assigned, neg
+
+
 _BEV_MODES = {"overlap": 0, "iou": 1, "iou_normal": 2}
 
 

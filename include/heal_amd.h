@@ -296,6 +296,19 @@ size_t heal_nms_bev_workspace(int n);
 int heal_nms_bev(const float* boxes_sorted, int n, float thresh, int rotated, void* workspace,
                  size_t workspace_bytes, long long* keep, int* num_keep, void* stream);
 
+/* ---- training-side anchor labelling --------------------------------------------------------
+ * heal_label_assign: the IoU / assignment core of VoxelPostprocessor.generate_label
+ *   (opencood/data_utils/post_processor/voxel_postprocessor.py:139-165), replacing the Cython bbox_overlaps
+ *   (opencood/utils/box_overlaps.pyx:17-57) and the numpy argmax / where / unique bookkeeping around it.
+ *   anchor_boxes [n_anchors,4], gt_boxes [n_gt,4] f32: axis-aligned stand-up boxes (x1,y1,x2,y2), n_gt <= 512.
+ *   assigned [n_anchors] i32 <- gt index of a positive anchor (first gt with IoU > pos_threshold; else, for the best
+ *   anchor of a gt with IoU > 0, the smallest such gt), -1 otherwise; neg [n_anchors] u8 <- 1 where every IoU is
+ *   below neg_threshold, except the best anchors.  IoU arithmetic bit-exact with the Cython routine.              */
+size_t heal_label_assign_workspace(int n_gt);
+int heal_label_assign(const float* anchor_boxes, int n_anchors, const float* gt_boxes, int n_gt,
+                      float pos_threshold, float neg_threshold, int32_t* assigned, uint8_t* neg, void* ws,
+                      size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

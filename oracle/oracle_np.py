@@ -460,3 +460,79 @@ def second_backbone(sd, prefix, vfe_features, indices, sparse_shape, batch):
                                         np.asarray(sd[bp + "running_mean"]), np.asarray(sd[bp + "running_var"]))
     B, C, D, H, W = dense.shape
     return dense.reshape(B, C * D, H, W).numpy()
+
+
+# ---- training-side label path -------------------------------------------------------------------------
+def bbox_overlaps(boxes, query_boxes):
+    """opencood/utils/box_overlaps.pyx:17-57 (Fast R-CNN bbox_overlaps, the `+1` pixel convention), fp32 throughout:
+    boxes [N,4], query_boxes [K,4] (x1,y1,x2,y2) -> IoU [N,K].  PINNED: bit-exact against the reference's compiled
+    Cython routine (oracle/_ref/box_overlaps*.so, tests/golden/label.npz)."""
+    # Arithmetic types as Cython generates them (oracle/_ref/box_overlaps.c): differences of two float32 are float32,
+    # every `+ 1` is `+ 1.0` in DOUBLE, products of such terms are double, and the result is rounded once when stored
+    # in the float32 variable; `iw * ih` is a float32 product; the final division is float32.
+    b = np.asarray(boxes, F32)[:, None, :]
+    q = np.asarray(query_boxes, F32)[None, :, :]
+    D = np.float64
+    box_area = (((q[..., 2] - q[..., 0]).astype(D) + 1.0) * ((q[..., 3] - q[..., 1]).astype(D) + 1.0)).astype(F32)
+    iw = ((np.minimum(b[..., 2], q[..., 2]) - np.maximum(b[..., 0], q[..., 0])).astype(D) + 1.0).astype(F32)
+    ih = ((np.minimum(b[..., 3], q[..., 3]) - np.maximum(b[..., 1], q[..., 1])).astype(D) + 1.0).astype(F32)
+    inter = (iw * ih).astype(F32)
+    ua = (((b[..., 2] - b[..., 0]).astype(D) + 1.0) * ((b[..., 3] - b[..., 1]).astype(D) + 1.0)
+          + box_area.astype(D) - inter.astype(D)).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ov = (inter / ua).astype(F32)
+    return np.where((iw > 0) & (ih > 0), ov, F32(0)).astype(F32)
+
+
+def standup_boxes(boxes_center, order="hwl"):
+    """boxes_to_corners_3d + corner2d_to_standup_box (box_utils.py:152-204,225-248): axis-aligned (x1,y1,x2,y2) of the
+    rotated footprint, float64 like the reference's np.zeros default."""
+    assert order == "hwl"
+    c = boxes_to_corners_3d_hwl(np.asarray(boxes_center))
+    return np.stack([c[:, :, 0].min(1), c[:, :, 1].min(1), c[:, :, 0].max(1), c[:, :, 1].max(1)], 1).astype(np.float64)
+
+
+def generate_label(gt_box_center, anchors, mask, pos_threshold, neg_threshold, order="hwl"):
+    """VoxelPostprocessor.generate_label (voxel_postprocessor.py:85-207): anchors [H,W,A,7], gt_box_center [max,7],
+    mask [max] -> pos_equal_one [H,W,A], neg_equal_one [H,W,A], targets [H,W,7A] (float64 like the reference)."""
+    H, W, A = anchors.shape[:3]
+    an = np.asarray(anchors).reshape(-1, 7)
+    gt_all = np.asarray(gt_box_center)
+    gt = gt_all[np.asarray(mask) == 1]
+    an_d = np.sqrt(an[:, 4] ** 2 + an[:, 5] ** 2)
+    iou = bbox_overlaps(standup_boxes(an, order).astype(F32), standup_boxes(gt, order).astype(F32)) \
+        if len(gt) else np.zeros((len(an), 0), F32)
+    pos = np.zeros(len(an))
+    neg = np.zeros(len(an))
+    tgt = np.zeros((len(an), 7))
+    assigned = np.full(len(an), -1, np.int64)
+    # (1) anchors above the positive threshold take the SMALLEST gt index above it (np.where order + np.unique first hit)
+    above = iou > pos_threshold
+    has = above.any(1) if iou.shape[1] else np.zeros(len(an), bool)
+    if has.any():
+        assigned[has] = above[has].argmax(1)
+    # (2) the best anchor of every gt (first maximum, only if its IoU is > 0) becomes positive too; an anchor that is
+    #     the best of several gts and not already positive keeps the smallest such gt
+    best = []
+    for g in range(iou.shape[1]):
+        a = int(iou[:, g].argmax())
+        if iou[a, g] > 0:
+            best.append(a)
+            if assigned[a] < 0:
+                assigned[a] = g
+    p = np.nonzero(assigned >= 0)[0]
+    pos[p] = 1
+    neg[(iou < neg_threshold).all(1)] = 1
+    if best:
+        neg[best] = 0
+    # NOTE the reference indexes gt_box_center (all rows), not the masked subset, with the masked gt index
+    # (voxel_postprocessor.py:172-190): identical when the valid boxes come first, as the datasets produce them
+    g = gt_all[assigned[p]]
+    tgt[p, 0] = (g[:, 0] - an[p, 0]) / an_d[p]
+    tgt[p, 1] = (g[:, 1] - an[p, 1]) / an_d[p]
+    tgt[p, 2] = (g[:, 2] - an[p, 2]) / an[p, 3]
+    tgt[p, 3] = np.log(g[:, 3] / an[p, 3])
+    tgt[p, 4] = np.log(g[:, 4] / an[p, 4])
+    tgt[p, 5] = np.log(g[:, 5] / an[p, 5])
+    tgt[p, 6] = g[:, 6] - an[p, 6]
+    return pos.reshape(H, W, A), neg.reshape(H, W, A), tgt.reshape(H, W, A * 7)

@@ -352,6 +352,47 @@ def gen_oldstyle_small():
     json.dump(allk, open(path, "w"))
 
 
+def gen_label():
+    """VoxelPostprocessor.generate_label (voxel_postprocessor.py:85-207) with the reference's compiled Cython
+    bbox_overlaps (oracle/_ref, built from opencood/utils/box_overlaps.pyx)."""
+    from oracle import cref
+    cref.build_ref()
+    vp = R.ref("opencood.data_utils.post_processor.voxel_postprocessor")
+    bo = R.ref("opencood.utils.box_overlaps")
+    assert bo.bbox_overlaps is not None, "oracle/_ref/box_overlaps*.so was not built"
+    yu = R.ref("opencood.hypes_yaml.yaml_utils")
+    hy = load_hypes("LiDAROnly/lidar_pyramid.yaml")
+    replace_ranges(hy, SMALL_RANGE)
+    hy = yu.load_general_params(hy)
+    post = vp.VoxelPostprocessor(hy["postprocess"], train=True)
+    anchors = post.generate_anchor_box()  # [64,64,2,7] f64
+    rng = np.random.default_rng(21)
+    max_num = 24
+    out = {"anchors": anchors, "pos_threshold": hy["postprocess"]["target_args"]["pos_threshold"],
+           "neg_threshold": hy["postprocess"]["target_args"]["neg_threshold"]}
+    for tag, n in (("a", 14), ("b", 0), ("c", 5)):
+        gt = np.zeros((max_num, 7), np.float32)
+        gt[:n] = np.concatenate([rng.uniform(-22, 22, (n, 2)), rng.uniform(-1.5, -0.5, (n, 1)),
+                                 rng.uniform(1.4, 1.8, (n, 1)), rng.uniform(1.5, 2.1, (n, 1)),
+                                 rng.uniform(3.5, 4.8, (n, 1)), rng.uniform(-3.1, 3.1, (n, 1))], 1)
+        if tag == "c":          # two objects on top of each other (shared best anchor) and one far outside the grid
+            gt[1] = gt[0]; gt[1, 0] += 0.05
+            gt[2, :2] = (60.0, 60.0)
+        mask = np.zeros(max_num, np.float32); mask[:n] = 1
+        lab = post.generate_label(gt_box_center=gt, anchors=anchors, mask=mask)
+        out.update({f"{tag}_gt": gt, f"{tag}_mask": mask, f"{tag}_pos": lab["pos_equal_one"],
+                    f"{tag}_neg": lab["neg_equal_one"], f"{tag}_targets": lab["targets"]})
+    # the raw Cython routine on random boxes (incl. degenerate / disjoint)
+    b1 = np.concatenate([rng.uniform(-20, 20, (300, 2)), rng.uniform(-20, 20, (300, 2))], 1).astype(np.float32)
+    b1[:, 2:] = b1[:, :2] + rng.uniform(0, 8, (300, 2)).astype(np.float32)
+    b2 = b1[rng.permutation(300)[:40]] + rng.uniform(-1, 1, (40, 4)).astype(np.float32)
+    out.update(ov_boxes=b1, ov_query=b2, ov=bo.bbox_overlaps(np.ascontiguousarray(b1), np.ascontiguousarray(b2)))
+    save("label", **out)
+
+
+GENS_EXTRA = {"label": gen_label}
+
+
 def pcdet_boxes(rng, n, spread):
     b = np.zeros((n, 7), np.float32)
     b[:, 0:2] = rng.uniform(-spread, spread, (n, 2))
@@ -380,6 +421,7 @@ def gen_pcdet_iou():
 
 
 GENS["pcdet_iou"] = gen_pcdet_iou
+GENS.update(GENS_EXTRA)
 GENS["oldstyle_small"] = gen_oldstyle_small
 
 

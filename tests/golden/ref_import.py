@@ -116,8 +116,20 @@ def install():
         m.__path__ = [os.path.join(REF, *pkg.split("."))]
     _stub("opencood.visualization.vis_utils")
     _stub("opencood.visualization.debug_plot", plot_feature=lambda *a, **k: None)
-    # Cython extension used by label generation only (not on the inference path)
-    _stub("opencood.utils.box_overlaps", bbox_overlaps=None)
+    # Cython extension used by label generation only (not on the inference path): the reference's own .pyx compiled by
+    # oracle/Makefile.ref when available (oracle/_ref/box_overlaps*.so), a stub otherwise
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref")
+    real = None
+    if os.path.isdir(ref_dir) and any(f.startswith("box_overlaps") and f.endswith(".so") for f in os.listdir(ref_dir)):
+        sys.path.insert(0, ref_dir)
+        try:
+            real = importlib.import_module("box_overlaps")
+        finally:
+            sys.path.remove(ref_dir)
+    if real is not None:
+        sys.modules["opencood.utils.box_overlaps"] = real
+    else:
+        _stub("opencood.utils.box_overlaps", bbox_overlaps=None)
 
 
 def ref(module):

@@ -164,3 +164,17 @@ def test_pcdet_known_answers_and_nms_rule():
     assert cref.pcdet_nms(e, 0.3).tolist() == [0, 3]
     assert cref.pcdet_nms(e, 0.34).tolist() == [0, 1, 2, 3]
     assert cref.pcdet_nms(e[:0], 0.3).tolist() == []
+
+
+def test_label_path_oracle_bit_exact_vs_reference_golden(golden):
+    """bbox_overlaps restated with the exact float/double mix Cython generates -> bit-exact against the
+    reference's compiled routine; generate_label equal to the reference's on three scenes (14 objects, none, and a
+    pair of stacked objects plus one outside the grid)."""
+    g = golden("label")
+    np.testing.assert_array_equal(O.bbox_overlaps(g["ov_boxes"], g["ov_query"]), g["ov"])
+    for tag in "abc":
+        pos, neg, tgt = O.generate_label(g[f"{tag}_gt"], g["anchors"], g[f"{tag}_mask"], float(g["pos_threshold"]),
+                                         float(g["neg_threshold"]))
+        np.testing.assert_array_equal(pos, g[f"{tag}_pos"])
+        np.testing.assert_array_equal(neg, g[f"{tag}_neg"])
+        np.testing.assert_allclose(tgt, g[f"{tag}_targets"], rtol=1e-12, atol=1e-12)
