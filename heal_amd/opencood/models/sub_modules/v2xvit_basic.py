@@ -121,8 +121,6 @@ class BaseWindowAttention(nn.Module):
         L, H, W, C = x.shape
         ws, m, d = self.window_size, self.heads, self.dim_head
         nh, nw = H // ws, W // ws
-        qkv = self.to_qkv(x).view(L, nh, ws, nw, ws, 3, m, d)
-        qkv = qkv.permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, L * m * nh * nw, ws * ws, d)
         if self.relative_pos_embedding:
             # the reference keeps `relative_indices` as a plain (host) attribute -- not a buffer, so it is not in the
             # state_dict; index with a cached device copy: a host index tensor costs an H2D copy per call and cannot
@@ -135,6 +133,14 @@ class BaseWindowAttention(nn.Module):
             bias = self.pos_embedding[ri[0], ri[1]]
         else:
             bias = self.pos_embedding
+        qkv = self.to_qkv(x)
+        from heal_amd import ops
+        if x.is_cuda and ops.window_attention_supported(ws, d, H, W):
+            # one kernel per window size: Q K^T, bias, softmax and P V without materialising the window re-layouts or
+            # the [windows, T, T] score tensor (heal_window_attention)
+            return self.to_out[0](ops.window_attention(qkv, bias, m, d, ws, self.scale))
+        qkv = qkv.view(L, nh, ws, nw, ws, 3, m, d)
+        qkv = qkv.permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, L * m * nh * nw, ws * ws, d)
         dots = torch.baddbmm(bias.unsqueeze(0).expand(qkv.shape[1], -1, -1), qkv[0], qkv[1].transpose(1, 2),
                              beta=1.0, alpha=self.scale)
         out = torch.bmm(dots.softmax(dim=-1), qkv[2])                    # [L*m*nh*nw, ws*ws, d]

@@ -269,6 +269,30 @@ def quad_iou(a, b):
     return out
 
 
+_WINDOW_ATTN_SHAPES = {(4, 16), (8, 32), (16, 64), (4, 32), (8, 16), (8, 64), (4, 64)}
+
+
+def window_attention_supported(window, dim_head, H, W):
+    return (int(window), int(dim_head)) in _WINDOW_ATTN_SHAPES and H % window == 0 and W % window == 0
+
+
+def window_attention(qkv, pos_bias, heads, dim_head, window, scale):
+    """Fused window attention: qkv [L,H,W,3*heads*dim_head] (packed q|k|v), pos_bias [T,T] or None -> [L,H,W,heads*dim_head]."""
+    qkv = _need(qkv, torch.float32, "qkv")
+    L, H, W, C3 = (int(v) for v in qkv.shape)
+    if C3 != 3 * heads * dim_head or not window_attention_supported(window, dim_head, H, W):
+        raise _capi.HealAmdError(f"window_attention: unsupported shape (window {window}, dim_head {dim_head}, map {H}x{W})")
+    if pos_bias is not None:
+        pos_bias = _need(pos_bias, torch.float32, "pos_bias")
+        if tuple(pos_bias.shape) != (window * window, window * window):
+            raise _capi.HealAmdError("window_attention: pos_bias must be [window^2, window^2]")
+    out = torch.empty((L, H, W, heads * dim_head), dtype=torch.float32, device=qkv.device)
+    with _Timed(f"window_attention_ws{window}"):
+        _capi.call("heal_window_attention", _ptr(qkv), _optr(pos_bias), L, H, W, int(heads), int(dim_head), int(window),
+                   float(scale), _ptr(out), _stream())
+    return out
+
+
 def label_assign(anchor_boxes, gt_boxes, pos_threshold, neg_threshold):
     """Anchor labelling core of generate_label: stand-up boxes [N,4] / [G,4] f32 cuda -> (assigned [N] i32: gt index of a
     positive anchor or -1, neg [N] u8)."""

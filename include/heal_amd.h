@@ -296,6 +296,14 @@ size_t heal_nms_bev_workspace(int n);
 int heal_nms_bev(const float* boxes_sorted, int n, float thresh, int rotated, void* workspace,
                  size_t workspace_bytes, long long* keep, int* num_keep, void* stream);
 
+/* heal_window_attention: fused window attention of the V2X-ViT pyramid (opencood/models/sub_modules/mswin.py:46-80):
+ *   out[l,y,x,h*d:(h+1)*d] = (softmax(scale * Q K^T + pos_bias) V) inside every window x window tile, per agent and head.
+ *   qkv [n_agents,H,W,3*heads*dim_head] f32 = the packed to_qkv projection (q | k | v chunks, each (head, dim));
+ *   pos_bias [T,T] (T = window^2, gathered relative-position embedding) or NULL; out [n_agents,H,W,heads*dim_head].
+ *   (window, dim_head) in {(4,16),(8,32),(16,64),(4,32),(8,16),(8,64),(4,64)}; H, W multiples of window.          */
+int heal_window_attention(const float* qkv, const float* pos_bias, int n_agents, int H, int W, int heads,
+                          int dim_head, int window, float scale, float* out, void* stream);
+
 /* ---- training-side anchor labelling --------------------------------------------------------
  * heal_label_assign: the IoU / assignment core of VoxelPostprocessor.generate_label
  *   (opencood/data_utils/post_processor/voxel_postprocessor.py:139-165), replacing the Cython bbox_overlaps

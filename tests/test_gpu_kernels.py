@@ -672,3 +672,27 @@ def test_label_assign_and_generate_label_match_reference_golden(golden):
         np.testing.assert_array_equal(lab["neg_equal_one"], g[f"{tag}_neg"])
         np.testing.assert_allclose(lab["targets"], g[f"{tag}_targets"], rtol=1e-6, atol=1e-7)
         assert lab["targets"].dtype == np.float64 and lab["pos_equal_one"].shape == g[f"{tag}_pos"].shape
+
+
+@pytest.mark.parametrize("ws,heads,d,L,H,W", [(4, 16, 16, 3, 16, 24), (8, 8, 32, 2, 32, 16), (16, 4, 64, 2, 32, 48),
+                                              (8, 4, 64, 1, 16, 16)])
+def test_window_attention_vs_torch(ws, heads, d, L, H, W):
+    """Fused window attention (mswin.py:46-80) against the explicit window re-layout + baddbmm + softmax + bmm in fp64."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(ws * 100 + d)
+    qkv = torch.randn((L, H, W, 3 * heads * d), generator=g).cuda()
+    T = ws * ws
+    bias = torch.randn((T, T), generator=g).cuda()
+    scale = d ** -0.5
+    got = ops.window_attention(qkv, bias, heads, d, ws, scale)
+    nh, nw = H // ws, W // ws
+    q = qkv.double().view(L, nh, ws, nw, ws, 3, heads, d).permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, -1, T, d)
+    dots = q[0] @ q[1].transpose(1, 2) * scale + bias.double()
+    ref = dots.softmax(-1) @ q[2]
+    ref = ref.view(L, heads, nh, nw, ws, ws, d).permute(0, 2, 4, 3, 5, 1, 6).reshape(L, H, W, heads * d)
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    got0 = ops.window_attention(qkv, None, heads, d, ws, scale)
+    ref0 = ((q[0] @ q[1].transpose(1, 2) * scale).softmax(-1) @ q[2]).view(L, heads, nh, nw, ws, ws, d) \
+        .permute(0, 2, 4, 3, 5, 1, 6).reshape(L, H, W, heads * d)
+    assert float((got0.double() - ref0).abs().max() / ref0.abs().max()) < 1e-5
