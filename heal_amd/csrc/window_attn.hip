@@ -19,14 +19,22 @@ namespace heal {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// waves per block: one per 16-row slab up to 4; the 256-token window runs 8 waves that share K AND V in LDS (150 KB, one
+// block per CU, two waves per SIMD) and moves P from the MFMA D layout to the A layout with lane shuffles instead of an
+// LDS slice -- no global load is left inside its MFMA loops.
+template <int WS>
+constexpr int wattn_waves() { return WS * WS == 256 ? 8 : ((WS * WS / 16) < 4 ? (WS * WS / 16) : 4); }
+
 template <int WS, int D>
-__global__ __launch_bounds__(64 * ((WS * WS / 16) < 4 ? (WS * WS / 16) : 4)) void k_window_attn(
+__global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
     const float* __restrict__ qkv /*[L,H,W,3,m,D]*/, const float* __restrict__ bias /*[T,T] or null*/, int H, int W,
     int m, float scale, float* __restrict__ out /*[L,H,W,m*D]*/) {
-    constexpr int T = WS * WS, KC = D / 4, NCB = T / 16, NB = D / 16, NW = (T / 16 < 4 ? T / 16 : 4);
-    constexpr int KSTR = D + 4, PSTR = T + 4;
+    constexpr int T = WS * WS, KC = D / 4, NCB = T / 16, NB = D / 16, NW = wattn_waves<WS>();
+    constexpr bool BIG = T == 256;                      // V in LDS, P through shuffles
+    constexpr int KSTR = D + 4, PSTR = T + 4, VSTR = D + 16;  // VSTR % 64 == 16: k-rows of a B fragment in disjoint banks
     __shared__ __attribute__((aligned(16))) float sK[T * KSTR];
-    __shared__ float sP[NW][16 * PSTR];
+    __shared__ __attribute__((aligned(16))) float sV[BIG ? T * VSTR : 4];
+    __shared__ float sP[BIG ? 1 : NW][BIG ? 4 : 16 * PSTR];
     const int nww = W / WS;
     const int ih = blockIdx.x / nww, iw = blockIdx.x - ih * nww, h = blockIdx.y, l = blockIdx.z;
     const int MD = m * D;
@@ -42,11 +50,14 @@ __global__ __launch_bounds__(64 * ((WS * WS / 16) < 4 ? (WS * WS / 16) : 4)) voi
         const int t = e / (D / 4), c4 = e - t * (D / 4);
         const float4 v = *reinterpret_cast<const float4*>(base + tok(t) + MD + c4 * 4);
         *reinterpret_cast<float4*>(&sK[t * KSTR + c4 * 4]) = v;
+        if constexpr (BIG)
+            *reinterpret_cast<float4*>(&sV[t * VSTR + c4 * 4]) =
+                *reinterpret_cast<const float4*>(base + tok(t) + 2 * MD + c4 * 4);
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lk = lane >> 4, ln = lane & 15;
-    float* sp = sP[wave];
+    float* sp = sP[BIG ? 0 : wave];
     for (int slab = wave; slab < T / 16; slab += NW) {
         // ---- S = Q K^T ------------------------------------------------------------------------------------------
         float a[KC];
@@ -95,23 +106,43 @@ __global__ __launch_bounds__(64 * ((WS * WS / 16) < 4 ? (WS * WS / 16) : 4)) voi
             for (int o = 8; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o, 64);
             sum[r] = 1.f / sum[r];
         }
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sp[(lk * 4 + r) * PSTR + cb * 16 + ln] = s[cb][r] * sum[r];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- O = P V ----------------------------------------------------------------------------------------------
         f32x4 o[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) o[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int kc = 0; kc < T / 4; ++kc) {
-            const float p = sp[ln * PSTR + kc * 4 + lk];
-            const float* vp = base + tok(kc * 4 + lk) + 2 * MD;
+        if constexpr (!BIG) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vp[nb * 16 + ln], o[nb], 0, 0, 0);
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sp[(lk * 4 + r) * PSTR + cb * 16 + ln] = s[cb][r] * sum[r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- O = P V: A = P from the wave's LDS slice, B = V from global (64-B runs, L2-resident) --------------
+#pragma unroll 4
+            for (int kc = 0; kc < T / 4; ++kc) {
+                const float p = sp[ln * PSTR + kc * 4 + lk];
+                const float* vp = base + tok(kc * 4 + lk) + 2 * MD;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vp[nb * 16 + ln], o[nb], 0, 0, 0);
+            }
+        } else {
+            // ---- O = P V: P moves D layout -> A layout by shuffles.  A-lane (m = ln, k = lk) of k-step kc needs
+            // P[row ln][col 4kc + lk], which sits in lane ((ln >> 2) << 4 | (4 (kc & 3) + lk)), register s[kc >> 2][ln & 3].
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[cb][r] *= sum[r];
+            const int rsel = ln & 3;
+#pragma unroll
+            for (int kc = 0; kc < T / 4; ++kc) {
+                const int srcl = ((ln >> 2) << 4) | (4 * (kc & 3) + lk);
+                const float p0 = __shfl(s[kc >> 2][0], srcl, 64), p1 = __shfl(s[kc >> 2][1], srcl, 64);
+                const float p2 = __shfl(s[kc >> 2][2], srcl, 64), p3 = __shfl(s[kc >> 2][3], srcl, 64);
+                const float p = rsel == 0 ? p0 : rsel == 1 ? p1 : rsel == 2 ? p2 : p3;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, sV[(kc * 4 + lk) * VSTR + nb * 16 + ln], o[nb], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -140,7 +171,7 @@ extern "C" int heal_window_attention(const float* qkv, const float* pos_bias, in
     const dim3 grid((H / window) * (W / window), heads, n_agents);
 #define HEAL_WA(WS_, D_)                                                                                        \
     if (window == WS_ && dim_head == D_) {                                                                      \
-        constexpr int NW_ = (WS_ * WS_ / 16) < 4 ? (WS_ * WS_ / 16) : 4;                                        \
+        constexpr int NW_ = wattn_waves<WS_>();                                                                  \
         k_window_attn<WS_, D_><<<grid, 64 * NW_, 0, s>>>(qkv, pos_bias, H, W, heads, scale, out);               \
         HEAL_LAUNCH_CHECK();                                                                                    \
         return 0;                                                                                               \

@@ -135,11 +135,10 @@ class BaseWindowAttention(nn.Module):
             bias = self.pos_embedding
         qkv = self.to_qkv(x)
         from heal_amd import ops
-        if x.is_cuda and ws <= 8 and ops.window_attention_supported(ws, d, H, W):
+        if x.is_cuda and ops.window_attention_supported(ws, d, H, W):
             # one kernel per window size: Q K^T, bias, softmax and P V without materialising the window re-layouts or
-            # the [windows, T, T] score tensor (heal_window_attention): 15.8x (ws 4) and 3.9x (ws 8) faster than the
-            # library sequence at 8 agents x 128 x 128; at ws 16 the kernel is at parity (one block per CU: the window's
-            # K alone is 70 KB of LDS and V streams from L2), so the library path stays for it
+            # the [windows, T, T] score tensor (heal_window_attention): 16x (ws 4), 4x (ws 8) and 1.7x (ws 16) faster
+            # than the library sequence at 8 agents x 128 x 128
             return self.to_out[0](ops.window_attention(qkv, bias, m, d, ws, self.scale))
         qkv = qkv.view(L, nh, ws, nw, ws, 3, m, d)
         qkv = qkv.permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, L * m * nh * nw, ws * ws, d)
