@@ -113,6 +113,95 @@ __global__ __launch_bounds__(256) void k_pfn(const float4* __restrict__ voxels, 
     }
 }
 
+// Four pillars per wave: 16 lanes per pillar, 4 output channels per lane.  The one-pillar-per-wave kernel above is
+// load-latency-bound (a pillar is ~5 points of work); packing four pillars into a wave quarters the number of waves that
+// each wait out the same round trip (33 k pillars: 24.6 -> see DESIGN.md), and a lane's 4 channels leave as one 16-B store.
+// P <= 32 (two points per lane).  Same arithmetic per channel as k_pfn: 10-term fmaf chain, BN, ReLU, running max.
+__global__ __launch_bounds__(256) void k_pfn4(const float4* __restrict__ voxels, int P,
+                                             const int4* __restrict__ coords,
+                                             const int* __restrict__ num_points, int n_voxels,
+                                             const int* __restrict__ n_voxels_dev,
+                                             const float* __restrict__ weight /*[64][10]*/,
+                                             const float* __restrict__ bn_scale,
+                                             const float* __restrict__ bn_shift, PfnGeom g,
+                                             float* __restrict__ pillar_feat /*[M][64]*/,
+                                             int* __restrict__ cell_map /*[n_agents][ny*nx]*/) {
+    __shared__ __attribute__((aligned(16))) float sfeat[4][4][32][PFN_FROW];  // [wave][pillar][point][feature]
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int q = l >> 4, i = l & 15;  // pillar slot of the wave, lane inside the 16-lane group
+    int M = n_voxels;
+    if (n_voxels_dev != nullptr) M = min(M, *n_voxels_dev);
+    float w[4][10], sc[4], sh[4], padv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = i * 4 + j;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) w[j][k] = weight[c * 10 + k];
+        sc[j] = bn_scale[c]; sh[j] = bn_shift[c];
+        padv[j] = fmaxf(sh[j], 0.f);
+    }
+    const int stride = gridDim.x * 16;
+    for (int m0 = (blockIdx.x * 4 + wave) * 4; m0 < M; m0 += stride) {
+        const int m = m0 + q;
+        const bool live_p = m < M;
+        int4 cd = make_int4(0, 0, 0, 0);
+        int np = 0;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+        if (live_p) {
+            cd = coords[m]; np = num_points[m];
+            if (i < P) pa = voxels[(size_t)m * P + i];
+            if (i + 16 < P) pb = voxels[(size_t)m * P + i + 16];
+        }
+        // mean over the COUNT of the sum over all P rows (pillar_vfe.py:118-121): reduce inside the 16-lane group
+        float sx = pa.x + pb.x, sy = pa.y + pb.y, sz = pa.z + pb.z;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64);
+        }
+        const float fn = (float)np;
+        const float mx = sx / fn, my = sy / fn, mz = sz / fn;
+        const float cxm = (float)cd.w * g.vx + g.xo, cym = (float)cd.z * g.vy + g.yo, czm = (float)cd.y * g.vz + g.zo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = i + 16 * h;
+            const float4 pt = h ? pb : pa;
+            const float k = p < np ? 1.f : 0.f;  // features *= mask (pillar_vfe.py:145-149)
+            float4* dst = reinterpret_cast<float4*>(&sfeat[wave][q][p][0]);
+            dst[0] = make_float4(pt.x * k, pt.y * k, pt.z * k, pt.w * k);
+            dst[1] = make_float4((pt.x - mx) * k, (pt.y - my) * k, (pt.z - mz) * k, (pt.x - cxm) * k);
+            dst[2] = make_float4((pt.y - cym) * k, (pt.z - czm) * k, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float best[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) best[j] = (np < P) ? padv[j] : 0.f;  // zeroed rows give relu(shift); ReLU >= 0
+        const int live_n = min(np, P);
+        for (int p = 0; p < live_n; ++p) {
+            const float4* src = reinterpret_cast<const float4*>(&sfeat[wave][q][p][0]);
+            const float4 a = src[0], b = src[1], c = src[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = a.x * w[j][0];
+                acc = fmaf(a.y, w[j][1], acc); acc = fmaf(a.z, w[j][2], acc); acc = fmaf(a.w, w[j][3], acc);
+                acc = fmaf(b.x, w[j][4], acc); acc = fmaf(b.y, w[j][5], acc); acc = fmaf(b.z, w[j][6], acc);
+                acc = fmaf(b.w, w[j][7], acc); acc = fmaf(c.x, w[j][8], acc); acc = fmaf(c.y, w[j][9], acc);
+                best[j] = fmaxf(best[j], fmaf(acc, sc[j], sh[j]));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live_p) {
+            *reinterpret_cast<float4*>(&pillar_feat[(size_t)m * PFN_C + i * 4]) = make_float4(best[0], best[1], best[2], best[3]);
+            if (i == 0) {
+                const int idx = cd.y + cd.z * g.nx + cd.w;  // z + y*nx + x (point_pillar_scatter.py:58)
+                if (cd.x >= 0 && cd.x < g.n_agents && idx >= 0 && idx < g.ny * g.nx)
+                    atomicMax(&cell_map[(size_t)cd.x * g.ny * g.nx + idx], m);
+            }
+        }
+    }
+}
+
 using vf4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ void st_nt(float4* p, float4 v) {
     vf4 t = {v.x, v.y, v.z, v.w};
@@ -218,8 +307,14 @@ extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, cons
         const int blocks = min(ceil_div(n_voxels, 4), 256 * 32);
         const float4* v4 = reinterpret_cast<const float4*>(voxels);
         const int4* c4 = reinterpret_cast<const int4*>(coords);
-        k_pfn<<<blocks, 256, 0, s>>>(v4, max_points, c4, num_points, n_voxels, n_voxels_dev, weight,
-                                     bn_scale, bn_shift, g, pf, cell_map);
+        static const bool one_per_wave = getenv("HEAL_PFN_1PW") != nullptr;  // A/B switch
+        if (max_points <= 32 && !one_per_wave)
+            k_pfn4<<<min(ceil_div(n_voxels, 16), 256 * 16), 256, 0, s>>>(v4, max_points, c4, num_points, n_voxels,
+                                                                         n_voxels_dev, weight, bn_scale, bn_shift, g, pf,
+                                                                         cell_map);
+        else
+            k_pfn<<<blocks, 256, 0, s>>>(v4, max_points, c4, num_points, n_voxels, n_voxels_dev, weight,
+                                         bn_scale, bn_shift, g, pf, cell_map);
         HEAL_LAUNCH_CHECK();
     }
     return heal_canvas_from_map(cell_map, pf, n_agents, channels, ny * nx, canvas, s);
