@@ -22,6 +22,9 @@ _SIGNATURES = {
     "heal_voxelize_workspace": (c_size_t, [c_int, c_int]),
     "heal_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_voxelize_batch_workspace": (c_size_t, [c_int, c_int]),
+    "heal_voxelize_batch": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "heal_pfn_scatter_workspace": (c_size_t, [c_int] * 5),
     "heal_pfn_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_void_p, c_void_p, c_void_p, c_int,

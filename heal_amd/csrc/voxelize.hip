@@ -155,6 +155,84 @@ __global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pt
     if (l == 0) num_points[base + v] = c;
 }
 
+// ---- batched form: every agent of a modality in ONE launch chain -----------------------------------------------------
+// The chain above is launch-bound (~15 kernels of <= 10 us for a 55 k-point sweep), so n agents cost n chains.  Here the
+// agents' clouds are concatenated (host-known offsets), cell keys carry the agent (agent * cells + cell) and ONE chain of
+// the same length serves all of them: the scan of the "first point of its cell" flags numbers voxels in (agent,
+// first-appearance) order, which is exactly the collated layout of collate_batch_list.
+constexpr int VOX_MAX_BATCH = 16;
+struct VoxBatch {
+    int B;
+    int pt_off[VOX_MAX_BATCH + 1];  // points of agent b: [pt_off[b], pt_off[b+1])
+};
+
+__device__ __forceinline__ int vox_agent(const VoxBatch& vb, int i) {
+    int a = 0;
+#pragma unroll 1
+    while (a + 1 < vb.B && i >= vb.pt_off[a + 1]) ++a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
+                                                    uint32_t cells, uint32_t* __restrict__ tkey,
+                                                    uint32_t* __restrict__ tmin, uint32_t mask,
+                                                    int* __restrict__ slot_of) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= vb.pt_off[vb.B]) return;
+    int cx, cy, cz;
+    if (!point_cell(pts[i], g, cx, cy, cz)) { slot_of[i] = -1; return; }
+    const uint32_t cell = (uint32_t)vox_agent(vb, i) * cells +
+                          (((uint32_t)cz * (uint32_t)g.grid[1] + (uint32_t)cy) * (uint32_t)g.grid[0] + (uint32_t)cx);
+    uint32_t slot = hash_u32(cell) & mask;
+    for (;;) {
+        const uint32_t prev = atomicCAS(&tkey[slot], HASH_EMPTY, cell);
+        if (prev == HASH_EMPTY || prev == cell) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&tmin[slot], (uint32_t)i);
+    slot_of[i] = (int)slot;
+}
+
+// per-agent bases: vbase[b] = voxels found before agent b's first point (scan value there), obase[b] = first output row
+// of agent b = sum over earlier agents of min(found, max_voxels); offsets_out[0..B] = obase (collated row offsets)
+__global__ void k_voxb_bases(const int* __restrict__ vid_excl, const int* __restrict__ total, VoxBatch vb,
+                             int max_voxels, int* __restrict__ vbase, int* __restrict__ obase,
+                             int* __restrict__ offsets_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = vb.pt_off[vb.B];
+    int acc = 0;
+    for (int b = 0; b <= vb.B; ++b) {
+        const int v = (b == vb.B || vb.pt_off[b] >= n) ? *total : vid_excl[vb.pt_off[b]];
+        vbase[b] = v;
+        if (b > 0) acc += min(v - vbase[b - 1], min(max_voxels, vb.pt_off[b] - vb.pt_off[b - 1]));
+        obase[b] = acc;
+        offsets_out[b] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_voxb_assign(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
+                                                    const int* __restrict__ slot_of,
+                                                    const uint32_t* __restrict__ tmin,
+                                                    const int* __restrict__ vid_excl, int max_voxels, int sentinel,
+                                                    const int* __restrict__ vbase, const int* __restrict__ obase,
+                                                    uint32_t* __restrict__ tvid, int* __restrict__ coords) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= vb.pt_off[vb.B]) return;
+    const int s = slot_of[i];
+    if (s < 0 || tmin[s] != (uint32_t)i) return;
+    const int a = vox_agent(vb, i);
+    const int vl = vid_excl[i] - vbase[a];  // first-appearance rank inside the agent
+    if (vl < max_voxels) {
+        const int row = obase[a] + vl;
+        tvid[s] = (uint32_t)row;
+        int cx, cy, cz;
+        point_cell(pts[i], g, cx, cy, cz);
+        reinterpret_cast<int4*>(coords)[row] = make_int4(a, cz, cy, cx);
+    } else {
+        tvid[s] = (uint32_t)sentinel;  // voxels past max_voxels are dropped
+    }
+}
+
 static int key_bits_for(int cap) {
     int b = 1;
     while ((1u << b) <= (uint32_t)cap) ++b;  // need to represent `cap` itself (the sentinel)
@@ -258,6 +336,76 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
     k_vox_write<<<ceil_div(cap, 4), 256, 0, s>>>(pts, w.vals[res], w.seg_start, w.count, w.total, cap,
                                                  max_points, reinterpret_cast<float4*>(voxels),
                                                  num_points, n_voxels, row_offset, row_offset_next);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+
+extern "C" size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents) {
+    if (n_points_total < 1) n_points_total = 1;
+    Arena a(nullptr, 0);
+    VoxWs w;
+    carve(a, n_points_total, n_points_total, w);
+    return a.off + align_up((size_t)(2 * (VOX_MAX_BATCH + 1)) * sizeof(int)) + 256;
+}
+
+extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_offsets_host, int n_agents,
+                                   const float* range_host, const float* voxel_size_host, int max_points,
+                                   int max_voxels, float* voxels, int32_t* coords, int32_t* num_points,
+                                   int32_t* row_offsets, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n_agents >= 1 && n_agents <= VOX_MAX_BATCH, "voxelize_batch: 1..%d agents per call", VOX_MAX_BATCH);
+    HEAL_REQUIRE(max_points >= 1 && max_voxels >= 1 && row_offsets != nullptr, "voxelize_batch: bad arguments");
+    VoxBatch vb;
+    vb.B = n_agents;
+    for (int b = 0; b <= n_agents; ++b) {
+        vb.pt_off[b] = point_offsets_host[b];
+        HEAL_REQUIRE(b == 0 ? vb.pt_off[0] == 0 : vb.pt_off[b] >= vb.pt_off[b - 1], "voxelize_batch: offsets must ascend from 0");
+    }
+    const int n = vb.pt_off[n_agents];
+    if (n == 0) {
+        HEAL_HIP(hipMemsetAsync(row_offsets, 0, sizeof(int) * (size_t)(n_agents + 1), s));
+        return 0;
+    }
+    VoxGrid g;
+    int64_t cells = 1;
+    for (int j = 0; j < 3; ++j) {
+        g.rmin[j] = range_host[j];
+        g.vsize[j] = voxel_size_host[j];
+        double gs = ((double)range_host[3 + j] - (double)range_host[j]) / (double)voxel_size_host[j];
+        g.grid[j] = (int)__builtin_rint(gs);
+        HEAL_REQUIRE(g.grid[j] >= 1, "voxelize_batch: empty grid on axis %d", j);
+        cells *= g.grid[j];
+    }
+    HEAL_REQUIRE(cells * n_agents < 0xFFFFFFFFll, "voxelize_batch: agents x cells exceeds 32-bit keys");
+    int cap = 0;  // rows of the collated outputs: sum of min(n_b, max_voxels)
+    for (int b = 0; b < n_agents; ++b) cap += (vb.pt_off[b + 1] - vb.pt_off[b]) < max_voxels ? (vb.pt_off[b + 1] - vb.pt_off[b]) : max_voxels;
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "voxelize_batch: workspace must be 256-B aligned");
+    Arena a(ws, ws_bytes);
+    VoxWs w;
+    HEAL_REQUIRE(carve(a, n, n, w), "voxelize_batch: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    int* vbase = a.take<int>(VOX_MAX_BATCH + 1);
+    int* obase = a.take<int>(VOX_MAX_BATCH + 1);
+    HEAL_REQUIRE(a.ok(), "voxelize_batch: workspace too small");
+
+    const float4* pts = reinterpret_cast<const float4*>(points);
+    const int nb = ceil_div(n, 256);
+    HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, (size_t)((char*)w.tvid - (char*)w.tkey), s));
+    HEAL_HIP(hipMemsetAsync(w.count, 0, (size_t)(cap + 1) * sizeof(int), s));
+    k_voxb_insert<<<nb, 256, 0, s>>>(pts, vb, g, (uint32_t)cells, w.tkey, w.tmin, w.tcap - 1, w.slot_of);
+    k_vox_flag<<<nb, 256, 0, s>>>(w.slot_of, w.tmin, n, w.flag);
+    if (scan_exclusive(w.flag, w.flag, n, w.total, w.scratch, s)) return 1;
+    k_voxb_bases<<<1, 64, 0, s>>>(w.flag, w.total, vb, max_voxels, vbase, obase, row_offsets);
+    k_voxb_assign<<<nb, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.flag, max_voxels, cap, vbase, obase, w.tvid,
+                                     coords);
+    k_vox_keys<<<nb, 256, 0, s>>>(w.slot_of, w.tvid, n, cap, w.keys[0], w.vals[0], w.count);
+    int res = 0;
+    if (radix_sort_pairs(w.keys, w.vals, n, key_bits_for(cap), &res, w.scratch, s)) return 1;
+    k_vox_heads<<<nb, 256, 0, s>>>(w.keys[res], n, cap, w.seg_start);
+    // rows written: row_offsets[n_agents] (device); n_voxels_out goes to a scratch word
+    k_vox_write<<<ceil_div(cap, 4), 256, 0, s>>>(pts, w.vals[res], w.seg_start, w.count, row_offsets + n_agents, cap,
+                                                 max_points, reinterpret_cast<float4*>(voxels), num_points, w.total + 1,
+                                                 nullptr, nullptr);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -116,15 +116,28 @@ def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxel
         if p.dim() != 2 or p.shape[1] != 4:
             raise _capi.HealAmdError("points must be [N,4]")
     dev = pts[0].device
-    caps = [max(1, min(int(p.shape[0]), int(max_voxels))) for p in pts]
-    cap = sum(caps)
+    caps = [min(int(p.shape[0]), int(max_voxels)) for p in pts]
+    cap = max(1, sum(caps))
     voxels = torch.empty((cap, max_points, 4), dtype=torch.float32, device=dev)
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
     offsets = torch.zeros((len(pts) + 1,), dtype=torch.int32, device=dev)
-    counts = torch.zeros((len(pts),), dtype=torch.int32, device=dev)
     rng = _host_array([float(v) for v in lidar_range], ctypes.c_float)
     vs = _host_array([float(v) for v in voxel_size], ctypes.c_float)
+    if len(pts) <= 16:
+        # ONE launch chain for all agents (heal_voxelize_batch): the clouds are concatenated, keys carry the agent
+        bounds = [0]
+        for p in pts:
+            bounds.append(bounds[-1] + int(p.shape[0]))
+        allp = pts[0] if len(pts) == 1 else torch.cat(pts, 0)
+        nbytes = _capi.query("heal_voxelize_batch_workspace", bounds[-1], len(pts))
+        ws = _workspace("voxelize", nbytes, dev)
+        with _Timed("voxelize"):
+            _capi.call("heal_voxelize_batch", _ptr(allp), _host_array(bounds, ctypes.c_int32), len(pts), rng, vs,
+                       int(max_points), int(max_voxels), _ptr(voxels), _ptr(coords), _ptr(num), _ptr(offsets), _ptr(ws),
+                       ws.numel(), _stream())
+        return voxels, coords, num, offsets
+    counts = torch.zeros((len(pts),), dtype=torch.int32, device=dev)
     for b, p in enumerate(pts):
         n = int(p.shape[0])
         nbytes = _capi.query("heal_voxelize_workspace", n, int(max_voxels))

@@ -619,6 +619,14 @@ def test_voxelize_collated_equals_per_agent():
         lo, hi = int(off[b]), int(off[b + 1])
         assert hi - lo == vb.shape[0]
         assert torch.equal(v[lo:hi], vb) and torch.equal(c[lo:hi], cb) and torch.equal(n[lo:hi], nb)
+    # both caps inside a batch: max_voxels = 3000 truncates every agent at its own 3000th voxel, P = 2 truncates voxels
+    v, c, n, off = ops.voxelize_collated(pts, R, [0.4, 0.4, 4], 2, 3000)
+    off = off.cpu().numpy()
+    for b, p in enumerate(pts[:3]):
+        vb, cb, nb = ops.voxelize(p, R, [0.4, 0.4, 4], 2, 3000, batch_idx=b)
+        lo, hi = int(off[b]), int(off[b + 1])
+        assert hi - lo == vb.shape[0] == 3000
+        assert torch.equal(v[lo:hi], vb) and torch.equal(c[lo:hi], cb) and torch.equal(n[lo:hi], nb)
 
 
 def test_convnext_block_nchw_path_vs_reference_formula():
