@@ -235,6 +235,21 @@ class _Deblock(nn.Sequential):
         from heal_amd import ops
         if isinstance(conv, nn.ConvTranspose2d):
             w, b = self._cache.get(conv, bn, transposed=True)
+            k = conv.kernel_size[0]
+            if (_CONV1X1 and x.is_cuda and conv.kernel_size == conv.stride and conv.kernel_size[0] == conv.kernel_size[1]
+                    and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.groups == 1
+                    and ops.conv1x1_supported(int(w.shape[0]), int(w.shape[1]) * k * k, int(x.shape[2] * x.shape[3]))):
+                # kernel == stride: the transposed convolution is a pointwise convolution to Cout*k*k channels followed
+                # by a depth-to-space shuffle; bias and ReLU commute with the shuffle, so they ride in the conv1x1
+                # epilogue (the library path is GEMM + col2im + a bias/ReLU pass)
+                key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+                if getattr(self, "_ps_key", None) != key:
+                    cin, cout = int(w.shape[0]), int(w.shape[1])
+                    self._ps = (w.permute(1, 2, 3, 0).reshape(cout * k * k, cin, 1, 1).contiguous(),
+                                b.repeat_interleave(k * k).contiguous())
+                    self._ps_key = key
+                y = ops.conv1x1(x, self._ps[0], self._ps[1], None, 1)
+                return y if k == 1 else F.pixel_shuffle(y, k)
             y = F.conv_transpose2d(x, w, None, conv.stride, conv.padding, conv.output_padding, conv.groups)
             return ops.bias_act_(y, b, None, True)
         w, b = self._cache.get(conv, bn)

@@ -704,3 +704,21 @@ def test_window_attention_vs_torch(ws, heads, d, L, H, W):
     ref0 = ((q[0] @ q[1].transpose(1, 2) * scale).softmax(-1) @ q[2]).view(L, heads, nh, nw, ws, ws, d) \
         .permute(0, 2, 4, 3, 5, 1, 6).reshape(L, H, W, heads * d)
     assert float((got0.double() - ref0).abs().max() / ref0.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("k,cin,cout,H,W", [(1, 64, 128, 32, 32), (2, 128, 128, 16, 24), (4, 256, 128, 8, 8)])
+def test_deblock_transposed_conv_as_conv1x1_plus_shuffle(k, cin, cout, H, W):
+    """base_bev_backbone_resnet.py:49-74 deblocks: ConvTranspose2d(kernel = stride) + BN(eps 1e-3) + ReLU, evaluated as
+    heal_conv1x1 + depth-to-space, against torch's conv_transpose2d + batch_norm + relu in fp64."""
+    import torch.nn as nn
+    from heal_amd.opencood.models.sub_modules.bev_blocks import _Deblock
+    from tests.golden.detfill import fill_module
+    blk = fill_module(_Deblock(nn.ConvTranspose2d(cin, cout, k, stride=k, bias=False),
+                               nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01))).cuda().eval()
+    x = torch.randn((2, cin, H, W), generator=torch.Generator().manual_seed(k)).cuda()
+    with torch.no_grad():
+        got = blk(x)
+        d = blk.double()
+        ref = torch.relu(d[1](torch.nn.functional.conv_transpose2d(x.double(), d[0].weight, None, k)))
+    assert got.shape == ref.shape == (2, cout, k * H, k * W)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
