@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, n_agents, port, tmp):
+def _worker(rank, world, n_agents, port, tmp, wire=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,7 +40,9 @@ def _worker(rank, world, n_agents, port, tmp):
     ls = [torch.stack([_agent_maps(a)[1][l] for a in mine]) if mine else torch.zeros((0, 1) + SHAPES[l][1:])
           for l in range(len(SHAPES))]
     buf = hd.pack_levels(lf, ls, hd.slots_per_rank(n_agents, world))
-    gathered = hd.all_gather_packed(buf, world)
+    if wire is not None:  # the optional half-size wire format of ShardedCollab (cast, gather, cast back)
+        buf = buf.to(getattr(torch, wire))
+    gathered = hd.all_gather_packed(buf, world).float()
     levels = hd.unpack_levels(gathered, SHAPES, n_agents, world)
     if rank == 0:
         torch.save([(f.clone(), s.clone()) for f, s in levels], tmp)
@@ -73,3 +75,18 @@ def test_ownership_and_padding_rules():
     g = hd.all_gather_packed(buf, 1)
     lv = hd.unpack_levels(g, SHAPES, 1, 1)
     assert all(torch.equal(f, torch.ones((1,) + s)) for (f, _), s in zip(lv, SHAPES))
+
+
+def test_all_gather_fp16_wire_format_world2(tmp_path):
+    """the exchange buffer may travel as fp16 (opt-in): same ownership / order, values within fp16
+    rounding (2^-11 relative), zero padding slots stay exactly zero (they must still be masked by the fusion kernel)."""
+    world, n_agents = 2, 3
+    out = str(tmp_path / "levels16.pt")
+    mp.spawn(_worker, args=(world, n_agents, _free_port(), out, "float16"), nprocs=world, join=True)
+    levels = torch.load(out)
+    for l, (f, s) in enumerate(levels):
+        want_f = torch.stack([_agent_maps(a)[0][l] for a in range(n_agents)])
+        want_s = torch.stack([_agent_maps(a)[1][l] for a in range(n_agents)])
+        assert float((f - want_f).abs().max()) <= 2.0 ** -11 * float(want_f.abs().max()) * 1.01
+        assert float((s - want_s).abs().max()) <= 2.0 ** -11 * 1.01
+        assert not torch.equal(f, want_f)  # the cast really happened
