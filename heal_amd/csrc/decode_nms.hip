@@ -238,7 +238,7 @@ constexpr int NMS_SPLIT = 8, NMS_COLS = 64 / NMS_SPLIT;
 __global__ __launch_bounds__(64 * NMS_SPLIT) void k_nms_mask(NmsBufs nb, int top, int words, float thr) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
-    const int K = min(*nb.n_cand, top);
+    const int K = nb.n_cand ? min(*nb.n_cand, top) : top;
     if (bi * 64 >= K || bj * 64 >= K) return;
     __shared__ float cq[64][8];
     __shared__ float cbb[64][4];  // axis-aligned bounds (xmin, xmax, ymin, ymax) of the column quads
@@ -450,4 +450,40 @@ extern "C" int heal_quad_iou(const float* a, int n, const float* b, int m, float
     k_quad_iou<<<ceil_div(n * m, 256), 256, 0, (hipStream_t)stream>>>(a, n, b, m, iou);
     HEAL_LAUNCH_CHECK();
     return 0;
+}
+
+
+// ---- standalone rotated NMS over quads (opencood/utils/box_utils.py:693-738 nms_rotated) ---------------------------
+namespace heal {
+int launch_bev_nms_walk(const unsigned long long* mask, int n, int W, unsigned long long* removed, long long* keep,
+                        int* num_keep, hipStream_t s);  // iou3d.hip
+}
+
+extern "C" size_t heal_nms_quads_workspace(int n) {
+    if (n < 1) n = 1;
+    const size_t W = ((size_t)n + 63) / 64;
+    return align_up((size_t)n * W * sizeof(unsigned long long)) + align_up(W * sizeof(unsigned long long)) + 256;
+}
+
+extern "C" int heal_nms_quads(const float* quads_sorted, int n, float thresh, void* workspace, size_t workspace_bytes,
+                              long long* keep, int* num_keep, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n >= 0 && num_keep != nullptr, "nms_quads: bad arguments");
+    if (n == 0) {
+        HEAL_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), s));
+        return 0;
+    }
+    HEAL_REQUIRE(quads_sorted && keep && workspace, "nms_quads: null pointer");
+    HEAL_REQUIRE(workspace_bytes >= heal_nms_quads_workspace(n) && ((uintptr_t)workspace & 7) == 0,
+                 "nms_quads: workspace too small or misaligned");
+    const int W = (n + 63) / 64;
+    Arena a(workspace, workspace_bytes);
+    NmsBufs nb;
+    nb.corners = nullptr; nb.scores = nullptr; nb.inrange = nullptr; nb.n_cand = nullptr;
+    nb.quads = const_cast<float*>(quads_sorted);
+    nb.mask = a.take<unsigned long long>((size_t)n * W);
+    unsigned long long* removed = a.take<unsigned long long>(W);
+    k_nms_mask<<<dim3(W, W), 64 * NMS_SPLIT, 0, s>>>(nb, n, W, thresh);
+    HEAL_LAUNCH_CHECK();
+    return launch_bev_nms_walk(nb.mask, n, W, removed, keep, num_keep, s);
 }

@@ -213,6 +213,14 @@ __global__ __launch_bounds__(256) void k_bev_nms_walk(const unsigned long long* 
     if (threadIdx.x == 0) *num_keep = base_s;
 }
 
+// shared with heal_nms_quads (decode_nms.hip): greedy walk over an upper-triangular suppression bit matrix
+int launch_bev_nms_walk(const unsigned long long* mask, int n, int W, unsigned long long* removed, long long* keep,
+                        int* num_keep, hipStream_t s) {
+    k_bev_nms_walk<<<1, 256, 0, s>>>(mask, n, W, removed, keep, num_keep);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace heal
 
 using namespace heal;

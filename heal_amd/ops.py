@@ -370,6 +370,21 @@ def camera_matrices(rots, trans, intrins, post_rots, post_trans):
     return out
 
 
+def nms_quads(quads_sorted, thresh):
+    """Greedy rotated NMS over quads [n,4,2] f32 cuda already in descending-score order -> (keep [n] i64, count [1] i32)
+    on the device; keep[:count] are indices into the given order, in pick order."""
+    q = _need(quads_sorted, torch.float32, "quads_sorted")
+    if q.dim() != 3 or tuple(q.shape[1:]) != (4, 2):
+        raise _capi.HealAmdError("nms_quads: quads must be [n,4,2]")
+    n = int(q.shape[0])
+    keep = torch.empty((n,), dtype=torch.int64, device=q.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=q.device)
+    need = _capi.query("heal_nms_quads_workspace", n)
+    ws = _workspace("nms_quads", need, q.device)
+    _capi.call("heal_nms_quads", _ptr(q), n, float(thresh), _ptr(ws), need, _ptr(keep), _ptr(count), _stream())
+    return keep, count
+
+
 def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
     """K4.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum [D,fH,fW,3]
     (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,

@@ -308,6 +308,14 @@ size_t heal_nms_bev_workspace(int n);
 int heal_nms_bev(const float* boxes_sorted, int n, float thresh, int rotated, void* workspace,
                  size_t workspace_bytes, long long* keep, int* num_keep, void* stream);
 
+/* heal_nms_quads: rotated NMS over projected footprints, the body of opencood/utils/box_utils.py:693-738 (nms_rotated:
+ *   greedy, IoU of the quads = corners[0:4,:2] as convex polygons in fp64 like shapely/GEOS, cast to f32, `> thresh`
+ *   suppresses).  quads_sorted [n,4,2] f32 ALREADY in descending-score order (the caller's `scores.argsort()[::-1][:1000]`);
+ *   keep [n] i64 <- indices into that order, ascending (= pick order); *num_keep device.                          */
+size_t heal_nms_quads_workspace(int n);
+int heal_nms_quads(const float* quads_sorted, int n, float thresh, void* workspace, size_t workspace_bytes,
+                   long long* keep, int* num_keep, void* stream);
+
 /* heal_window_attention: fused window attention of the V2X-ViT pyramid (opencood/models/sub_modules/mswin.py:46-80):
  *   out[l,y,x,h*d:(h+1)*d] = (softmax(scale * Q K^T + pos_bias) V) inside every window x window tile, per agent and head.
  *   qkv [n_agents,H,W,3*heads*dim_head] f32 = the packed to_qkv projection (q | k | v chunks, each (head, dim));

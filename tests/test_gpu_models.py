@@ -254,3 +254,32 @@ def test_heterogeneous_collab_runs_all_modalities():
     assert out["cls_preds"].shape == (1, 2, 256, 256) and out["reg_preds"].shape == (1, 14, 256, 256)
     assert all(torch.isfinite(out[k]).all() for k in ("cls_preds", "reg_preds", "dir_preds"))
     assert [tuple(o.shape) for o in out["occ_single_list"]] == [(5, 1, 256, 256), (5, 1, 128, 128), (5, 1, 64, 64)]
+
+
+def test_box_utils_mirror_matches_reference_golden(golden):
+    """opencood/utils/box_utils.py + common_utils.py helpers against the reference's own outputs
+    stored by gen_decode: corners, projection, limit_period, the two box filters and nms_rotated (run by the reference
+    with a Polygon stand-in backed by the oracle's fp64 clip)."""
+    from heal_amd.opencood.utils import box_utils as bu, common_utils as cu
+    g = golden("decode")
+    boxes = torch.from_numpy(g["cmp_boxes"]).cuda()
+    corners = bu.boxes_to_corners_3d(boxes, "hwl")
+    np.testing.assert_allclose(corners.cpu().numpy(), g["cmp_corners"], rtol=1e-5, atol=1e-5)
+    assert isinstance(bu.boxes_to_corners_3d(g["cmp_boxes"], "hwl"), np.ndarray)
+    proj = bu.project_box3d(torch.from_numpy(g["cmp_corners"]).cuda(), torch.from_numpy(g["tf_tfm"]).cuda())
+    np.testing.assert_allclose(proj.cpu().numpy(), g["cmp_proj"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(cu.limit_period(boxes[:, 6] - 0.7853, 0, np.pi).cpu().numpy(), g["cmp_limit0"], atol=1e-6)
+    np.testing.assert_allclose(cu.limit_period(g["cmp_boxes"][:, 6], 0.5, 2 * np.pi), g["cmp_limit1"], atol=1e-6)
+    pj = torch.from_numpy(g["cmp_proj"]).cuda()
+    np.testing.assert_array_equal(bu.remove_large_pred_bbx(pj).cpu().numpy(), g["cmp_large"])
+    np.testing.assert_array_equal(bu.remove_bbx_abnormal_z(pj).cpu().numpy(), g["cmp_absz"])
+    keep = bu.nms_rotated(pj, torch.from_numpy(g["cmp_scores"]).cuda(), 0.15)
+    assert keep.dtype == np.int32
+    # scores 5 and 6 tie in the fixture: compare as sets plus the score sequence (tie order is implementation-defined)
+    assert set(keep.tolist()) == set(g["cmp_keep"].tolist())
+    np.testing.assert_array_equal(g["cmp_scores"][keep], g["cmp_scores"][g["cmp_keep"]])
+    assert bu.nms_rotated(pj[:0], torch.zeros(0).cuda(), 0.15).size == 0
+    iou = cu.compute_iou(cu.convert_format(g["cmp_proj"])[0], cu.convert_format(g["cmp_proj"])[:5])
+    assert iou.dtype == np.float32 and abs(float(iou[0]) - 1.0) < 1e-6
+    m = bu.get_mask_for_boxes_within_range_torch(pj, g["gt_range"].tolist())
+    assert m.dtype == torch.bool and m.shape[0] == pj.shape[0]
