@@ -98,6 +98,69 @@ class VoxelPostprocessor:
                 'neg_equal_one': neg.double().view(H, W, A).cpu().numpy(),
                 'targets': tgt.view(H, W, A * 7).cpu().numpy()}
 
+    @staticmethod
+    def delta_to_boxes3d(deltas, anchors):
+        """voxel_postprocessor.py:407-453: regression maps (N,7A,H,W) + anchors (H,W,A,7) -> boxes (N,H*W*A,7)."""
+        N = deltas.shape[0]
+        d = deltas.permute(0, 2, 3, 1).contiguous().view(N, -1, 7)
+        a = anchors.to(d.device).view(-1, 7).float()
+        a_d = torch.sqrt(a[:, 4] ** 2 + a[:, 5] ** 2)
+        out = torch.zeros_like(d)
+        out[..., 0] = d[..., 0] * a_d + a[:, 0]
+        out[..., 1] = d[..., 1] * a_d + a[:, 1]
+        out[..., 2] = d[..., 2] * a[:, 3] + a[:, 2]
+        out[..., 3:6] = torch.exp(d[..., 3:6]) * a[:, 3:6]
+        out[..., 6] = d[..., 6] + a[:, 6]
+        return out
+
+    def _post_process_multi(self, data_dict, output_dict):
+        """Late fusion (voxel_postprocessor.py:277-405 with several cavs): every cav's candidates are decoded, projected
+        with its own transformation matrix and pooled before the filters and ONE rotated NMS.  Same steps, in the
+        reference's order, as tensor ops on the device + heal_nms_quads; the single-cav hot path above stays on the
+        fused kernel."""
+        from heal_amd.opencood.utils import box_utils
+        from heal_amd.opencood.utils.common_utils import limit_period
+        boxes3d_list, scores_list = [], []
+        thr = self.params['target_args']['score_threshold']
+        for cav_id, out in output_dict.items():
+            assert cav_id in data_dict
+            cav = data_dict[cav_id]
+            cls = out['cls_preds'] if 'cls_preds' in out else out['psm']
+            reg = out['reg_preds'] if 'reg_preds' in out else out['rm']
+            dirp = out.get('dir_preds', out.get('dm'))
+            if 'iou_preds' in out:
+                raise NotImplementedError("iou_preds rescoring is not used by the HEAL configs")
+            prob = torch.sigmoid(cls.permute(0, 2, 3, 1)).reshape(1, -1)
+            box3d = self.delta_to_boxes3d(reg, cav['anchor_box'] if isinstance(cav['anchor_box'], torch.Tensor)
+                                          else torch.from_numpy(np.asarray(cav['anchor_box'])))
+            assert box3d.shape[0] == 1
+            mask = torch.gt(prob, thr).view(-1)
+            boxes3d, scores = box3d[0][mask], prob[0][mask]
+            if dirp is not None and len(boxes3d) != 0:
+                dir_args = self.params['dir_args']
+                nb = dir_args['num_bins']
+                labels = torch.max(dirp.permute(0, 2, 3, 1).contiguous().reshape(-1, nb)[mask], dim=-1)[1]
+                period = 2 * np.pi / nb
+                rot = limit_period(boxes3d[..., 6] - dir_args['dir_offset'], 0, period)
+                boxes3d[..., 6] = rot + dir_args['dir_offset'] + period * labels.to(dirp.dtype)
+                boxes3d[..., 6] = limit_period(boxes3d[..., 6], 0.5, 2 * np.pi)
+            if len(boxes3d) != 0:
+                corners = box_utils.boxes_to_corners_3d(boxes3d, order=self.params['order'])
+                tfm = cav['transformation_matrix']
+                tfm = tfm if isinstance(tfm, torch.Tensor) else torch.from_numpy(np.asarray(tfm))
+                boxes3d_list.append(box_utils.project_box3d(corners, tfm.to(corners.device).float()))
+                scores_list.append(scores)
+        if not boxes3d_list:
+            return None, None
+        pred, scores = torch.vstack(boxes3d_list), torch.cat(scores_list)
+        keep = torch.logical_and(box_utils.remove_large_pred_bbx(pred), box_utils.remove_bbx_abnormal_z(pred))
+        pred, scores = pred[keep], scores[keep]
+        keep = torch.from_numpy(box_utils.nms_rotated(pred, scores, self.params['nms_thresh']).astype(np.int64)).to(pred.device)
+        pred, scores = pred[keep], scores[keep]
+        kept, mask = box_utils.mask_boxes_outside_range_numpy(pred.cpu().numpy(), self.params['gt_range'], order=None,
+                                                              return_mask=True)
+        return torch.from_numpy(kept).to(pred.device), scores[torch.from_numpy(mask).to(pred.device)]
+
     def _anchors_f32(self, anchor_box, device):
         """anchors as contiguous fp32 on the device (delta_to_boxes3d does `.float()`), cached."""
         key = (anchor_box.data_ptr() if isinstance(anchor_box, torch.Tensor) else id(anchor_box), str(device))
@@ -115,7 +178,7 @@ class VoxelPostprocessor:
         if self.params['order'] != 'hwl':
             raise NotImplementedError("the decode kernel implements order 'hwl' (PointPillars / HEAL configs)")
         if len(output_dict) != 1:
-            raise NotImplementedError("late-fusion post-processing over several cavs is not on the hot path")
+            return self._post_process_multi(data_dict, output_dict)
         cav_id = next(iter(output_dict.keys()))
         out = output_dict[cav_id]
         cav = data_dict[cav_id]

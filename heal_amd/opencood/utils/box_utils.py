@@ -70,6 +70,21 @@ def get_mask_for_boxes_within_range_torch(boxes, gt_range):
     return torch.all(torch.all(boxes[:, :, :2] >= lo, dim=-1) & torch.all(boxes[:, :, :2] <= hi, dim=-1), dim=-1)
 
 
+def mask_boxes_outside_range_numpy(boxes, limit_range, order, min_num_corners=8, return_mask=False):
+    """box_utils.py:384-421: boxes (N,7) or corners (N,8,3) as numpy; a box stays when at least `min_num_corners`
+    corners lie inside [min, max] on all three axes."""
+    assert boxes.shape[1] == 8 or boxes.shape[1] == 7
+    new_boxes = boxes.copy()
+    if boxes.shape[1] == 7:
+        new_boxes = boxes_to_corners_3d(new_boxes, order)
+    limit_range = np.asarray(limit_range)
+    mask = ((new_boxes >= limit_range[0:3]) & (new_boxes <= limit_range[3:6])).all(axis=2)
+    mask = mask.sum(axis=1) >= min_num_corners
+    if return_mask:
+        return boxes[mask], mask
+    return boxes[mask]
+
+
 def remove_large_pred_bbx(bbx_3d):
     """box_utils.py:840-869, including its quirks: the 'z' extent is computed from column 1 (y) and enters the mask as a
     truth value (non-zero), exactly as the reference does."""

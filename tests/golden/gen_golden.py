@@ -143,6 +143,14 @@ def gen_decode():
             pred, score = post.post_process(data_dict, output_dict)
         out.update({f"{tag}_tfm": tfm, f"{tag}_cls": cls, f"{tag}_reg": reg, f"{tag}_dir": dirp,
                     f"{tag}_boxes3d": boxes3d[0], f"{tag}_pred": pred.numpy(), f"{tag}_score": score.numpy()})
+    # late fusion: both cavs (identity and transformed) in ONE post_process call -> pooled candidates, one NMS
+    data2 = {k: {"transformation_matrix": torch.from_numpy(out[f"{t}_tfm"]), "anchor_box": torch.from_numpy(anchors)}
+             for k, t in (("ego", "id"), ("cav1", "tf"))}
+    out2 = {k: {"cls_preds": torch.from_numpy(out[f"{t}_cls"]), "reg_preds": torch.from_numpy(out[f"{t}_reg"]),
+                "dir_preds": torch.from_numpy(out[f"{t}_dir"])} for k, t in (("ego", "id"), ("cav1", "tf"))}
+    with torch.no_grad():
+        pred2, score2 = post.post_process(data2, out2)
+    out.update(late_pred=pred2.numpy(), late_score=score2.numpy())
     # component functions
     boxes = np.concatenate([rng.uniform(-20, 20, (40, 2)), rng.uniform(-2.5, 0, (40, 1)),
                             rng.uniform(1.2, 2.0, (40, 1)), rng.uniform(1.4, 2.2, (40, 1)),

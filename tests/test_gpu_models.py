@@ -283,3 +283,30 @@ def test_box_utils_mirror_matches_reference_golden(golden):
     assert iou.dtype == np.float32 and abs(float(iou[0]) - 1.0) < 1e-6
     m = bu.get_mask_for_boxes_within_range_torch(pj, g["gt_range"].tolist())
     assert m.dtype == torch.bool and m.shape[0] == pj.shape[0]
+
+
+def test_late_fusion_post_process_matches_reference_golden(golden):
+    """VoxelPostprocessor.post_process with SEVERAL cavs (late fusion, voxel_postprocessor.py:277-405): candidates of all
+    cavs pooled, one rotated NMS.  Golden from the reference's own post_process on the two fixture cavs."""
+    from heal_amd import configs
+    from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    g = golden("decode")
+    hy = configs.lidar_pyramid(SMALL_RANGE)
+    post = VoxelPostprocessor(hy["postprocess"], train=False)
+    anchors = torch.from_numpy(g["anchors"]).cuda()
+    b3 = post.delta_to_boxes3d(dev(g["id_reg"]), anchors)
+    np.testing.assert_allclose(b3[0].cpu().numpy(), g["id_boxes3d"], rtol=1e-5, atol=1e-5)
+    data = {k: {"transformation_matrix": torch.from_numpy(g[f"{t}_tfm"]).cuda(), "anchor_box": anchors}
+            for k, t in (("ego", "id"), ("cav1", "tf"))}
+    out = {k: {"cls_preds": dev(g[f"{t}_cls"]), "reg_preds": dev(g[f"{t}_reg"]), "dir_preds": dev(g[f"{t}_dir"])}
+           for k, t in (("ego", "id"), ("cav1", "tf"))}
+    pred, score = post.post_process(data, out)
+    assert pred.shape == g["late_pred"].shape
+    np.testing.assert_allclose(score.cpu().numpy(), g["late_score"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pred.cpu().numpy(), g["late_pred"], rtol=1e-4, atol=1e-4)
+    # a single cav through the general path equals the fused kernel path
+    one_d, one_o = {"ego": data["ego"]}, {"ego": out["ego"]}
+    p1, s1 = post._post_process_multi(one_d, one_o)
+    p2, s2 = post.post_process(one_d, one_o)
+    np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=1e-4, atol=1e-4)
