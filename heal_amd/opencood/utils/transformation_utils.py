@@ -25,3 +25,49 @@ def pairwise_to_host(pairwise_t_matrix):
     else:
         arr = np.asarray(pairwise_t_matrix)
     return arr, arr.dtype == np.float64
+
+
+# ---- pose algebra the datasets / tools call around the hot path (host numpy, 4x4 matrices) ---------------------------
+def regroup(x, record_len):
+    """transformation_utils.py:16-19 (and fusion_in_one.py:48-51): split the agent axis by scene."""
+    cum_sum_len = torch.cumsum(record_len, dim=0)
+    return torch.tensor_split(x, cum_sum_len[:-1].cpu())
+
+
+def x_to_world(pose):
+    """transformation_utils.py:264-307: pose [x, y, z, roll, yaw, pitch] (degrees, CARLA convention) -> T_world_x."""
+    x, y, z, roll, yaw, pitch = pose[:]
+    c_y, s_y = np.cos(np.radians(yaw)), np.sin(np.radians(yaw))
+    c_r, s_r = np.cos(np.radians(roll)), np.sin(np.radians(roll))
+    c_p, s_p = np.cos(np.radians(pitch)), np.sin(np.radians(pitch))
+    m = np.identity(4)
+    m[0, 3], m[1, 3], m[2, 3] = x, y, z
+    m[0, 0] = c_p * c_y
+    m[0, 1] = c_y * s_p * s_r - s_y * c_r
+    m[0, 2] = -c_y * s_p * c_r - s_y * s_r
+    m[1, 0] = s_y * c_p
+    m[1, 1] = s_y * s_p * s_r + c_y * c_r
+    m[1, 2] = -s_y * s_p * c_r + c_y * s_r
+    m[2, 0] = s_p
+    m[2, 1] = -c_p * s_r
+    m[2, 2] = c_p * c_r
+    return m
+
+
+def x1_to_x2(x1, x2):
+    """transformation_utils.py:310-334: T_x2_x1 = inv(T_world_x2) @ T_world_x1."""
+    return np.dot(np.linalg.inv(x_to_world(x2)), x_to_world(x1))
+
+
+def get_pairwise_transformation(base_data_dict, max_cav, proj_first):
+    """transformation_utils.py:21-66: (L,L,4,4) float64, [i,j] = T_j<-i = solve(T_world_j, T_world_i); identity on the
+    diagonal, for unused slots and when the clouds were projected to the ego first."""
+    pairwise = np.tile(np.eye(4), (max_cav, max_cav, 1, 1))
+    if proj_first:
+        return pairwise
+    t_list = [x_to_world(c['params']['lidar_pose']) for c in base_data_dict.values()]
+    for i in range(len(t_list)):
+        for j in range(len(t_list)):
+            if i != j:
+                pairwise[i, j] = np.linalg.solve(t_list[j], t_list[i])
+    return pairwise

@@ -398,7 +398,19 @@ def gen_label():
     save("label", **out)
 
 
-GENS_EXTRA = {"label": gen_label}
+def gen_pose():
+    """Pose algebra of opencood/utils/transformation_utils.py (x_to_world, x1_to_x2, get_pairwise_transformation)."""
+    tu = R.ref("opencood.utils.transformation_utils")
+    rng = np.random.default_rng(31)
+    poses = np.concatenate([rng.uniform(-80, 80, (4, 3)), rng.uniform(-180, 180, (4, 3))], 1)
+    base = {k: {"params": {"lidar_pose": poses[k].tolist()}} for k in range(4)}
+    save("pose", poses=poses, x_to_world=np.stack([tu.x_to_world(p.tolist()) for p in poses]),
+         x1_to_x2=tu.x1_to_x2(poses[1].tolist(), poses[2].tolist()),
+         pairwise=tu.get_pairwise_transformation(base, 5, False),
+         pairwise_proj_first=tu.get_pairwise_transformation(base, 5, True))
+
+
+GENS_EXTRA = {"label": gen_label, "pose": gen_pose}
 
 
 def pcdet_boxes(rng, n, spread):

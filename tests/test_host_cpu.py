@@ -262,3 +262,24 @@ def test_oracle_sparse_conv_known_answers():
     assert act == {(z, y_, x) for z in (0, 1) for y_ in (0, 1) for x in (0, 1)}
     np.testing.assert_allclose(float(y2[0, 0, 0, 0, 0]), 3.0, rtol=1e-6)     # sees only the first site
     np.testing.assert_allclose(float(y2[0, 0, 0, 0, 1]), 33.0, rtol=1e-6)    # sees both
+
+
+def test_pose_algebra_mirror_matches_reference_golden(golden):
+    """opencood/utils/transformation_utils.py:21-66,264-334 (host numpy): x_to_world, x1_to_x2,
+    get_pairwise_transformation -- the producers of `pairwise_t_matrix` -- against the reference's outputs; the
+    synthetic scene generator must agree with them too."""
+    from heal_amd import synth
+    from heal_amd.opencood.utils import transformation_utils as tu
+    g = golden("pose")
+    poses = g["poses"]
+    for k, p in enumerate(poses):
+        np.testing.assert_array_equal(tu.x_to_world(p.tolist()), g["x_to_world"][k])
+        np.testing.assert_allclose(synth.x_to_world(p.tolist()), g["x_to_world"][k], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(tu.x1_to_x2(poses[1].tolist(), poses[2].tolist()), g["x1_to_x2"])
+    base = {k: {"params": {"lidar_pose": poses[k].tolist()}} for k in range(4)}
+    np.testing.assert_array_equal(tu.get_pairwise_transformation(base, 5, False), g["pairwise"])
+    np.testing.assert_array_equal(tu.get_pairwise_transformation(base, 5, True), g["pairwise_proj_first"])
+    np.testing.assert_allclose(synth.pairwise_t_matrix([p.tolist() for p in poses], 5), g["pairwise"], rtol=1e-12, atol=1e-12)
+    import torch
+    parts = tu.regroup(torch.arange(10).view(5, 2), torch.tensor([2, 3]))
+    assert [tuple(p.shape) for p in parts] == [(2, 2), (3, 2)]
