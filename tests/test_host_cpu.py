@@ -283,3 +283,24 @@ def test_pose_algebra_mirror_matches_reference_golden(golden):
     import torch
     parts = tu.regroup(torch.arange(10).view(5, 2), torch.tensor([2, 3]))
     assert [tuple(p.shape) for p in parts] == [(2, 2), (3, 2)]
+
+
+def test_inference_utils_mirror_contract():
+    """opencood/tools/inference_utils.py: the model-calling helpers only need model(dict) and dataset.post_process."""
+    from heal_amd.opencood.tools import inference_utils as iu
+
+    class DS:
+        def post_process(self, batch, out):
+            return ("boxes", sorted(out.keys()), "gt")
+
+        def post_process_no_fusion(self, batch, out):
+            return ("boxes_nf", sorted(batch.keys()), "gt")
+
+    model = lambda d: {"cls_preds": d["x"], "depth_items": 7} if "d" in d else {"cls_preds": d["x"]}
+    batch = {"ego": {"x": 1, "d": 1}, "cav1": {"x": 2}}
+    r = iu.inference_late_fusion(batch, model, DS())
+    assert r == {"pred_box_tensor": "boxes", "pred_score": ["cav1", "ego"], "gt_box_tensor": "gt"}
+    r = iu.inference_intermediate_fusion(batch, model, DS())
+    assert r["pred_score"] == ["ego"] and r["depth_items"] == 7
+    assert iu.inference_no_fusion(batch, model, DS(), single_gt=True)["pred_score"] == ["ego"]
+    assert iu.inference_no_fusion(batch, model, DS())["pred_score"] == ["cav1", "ego"]
