@@ -17,7 +17,7 @@ import torch
 
 import heal_amd.compat as compat
 from heal_amd import configs
-from heal_amd.pipeline import Scene, fill_deterministic
+from heal_amd.pipeline import Scene, calibrate_heads, fill_deterministic
 
 compat.install_as_opencood()
 from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor  # noqa: E402
@@ -48,9 +48,10 @@ def main():
         hypes = yaml_utils.load_yaml(path)
     model = train_utils.create_model(hypes)        # HeterPyramidCollab, found by name like the reference does
     model = fill_deterministic(model, 3).to(dev).eval()   # stands in for load_state_dict(checkpoint)
-    model.cls_head.bias.data.fill_(-4.6)           # untrained heads: keep the candidate count realistic
     dataset = SyntheticDataset(hypes, dev)
     scene = Scene(a.agents, seed=11, device=dev)
+    # untrained heads: shift the classification bias so that a realistic number of anchors pass the score threshold
+    calibrate_heads(model, scene.model_input(), hypes["postprocess"]["target_args"]["score_threshold"], 400)
     batch = {"ego": dict(scene.model_input(), anchor_box=dataset.anchor_box,
                          transformation_matrix=torch.eye(4, device=dev))}
     batch = train_utils.to_device(batch, dev)

@@ -81,6 +81,28 @@ class Scene:
         return d
 
 
+@torch.no_grad()
+def calibrate_heads(model, model_input, score_threshold, target_candidates=600):
+    """Random-init heads put an arbitrary fraction of the 131 072 anchors above the score threshold.  Shift the
+    classification bias (a parameter like any other) so that about `target_candidates` anchors pass -- a busy but
+    realistic frame for decode + NMS -- and keep regressed boxes near their anchors (std 0.15), otherwise exp(delta)
+    sizes fail the reference's size / z filters and nothing reaches the NMS.  Returns the bias shift."""
+    out = model(model_input)
+    std = float(out["reg_preds"].std())
+    if std > 0:
+        for name, p in model.named_parameters():
+            if name.startswith("reg_head"):
+                p.mul_(0.15 / std)
+    logits = out["cls_preds"].flatten()
+    k = min(max(int(target_candidates), 1), logits.numel() - 1)
+    kth = torch.topk(logits, k).values[-1]
+    shift = float(np.log(score_threshold / (1.0 - score_threshold))) - float(kth)
+    for name, p in model.named_parameters():
+        if name.startswith("cls_head") and name.endswith("bias"):
+            p.add_(shift)
+    return shift
+
+
 class ScenePipeline:
     def __init__(self, hypes, device, seed=0):
         self.hypes = hypes
@@ -92,26 +114,8 @@ class ScenePipeline:
 
     @torch.no_grad()
     def calibrate_cls_bias(self, scene, target_candidates=600):
-        """Random-init heads put an arbitrary fraction of the 131 072 anchors above the 0.2 score
-        threshold.  Shift the classification bias (a parameter like any other) so that about
-        `target_candidates` anchors pass -- a busy but realistic frame for decode + NMS."""
-        out = self.model(scene.model_input())
-        # keep regressed boxes near their anchors (std 0.15), otherwise exp(delta) sizes fail the
-        # reference's size / z filters and nothing reaches the NMS
-        std = float(out["reg_preds"].std())
-        if std > 0:
-            for name, p in self.model.named_parameters():
-                if name.startswith("reg_head"):
-                    p.mul_(0.15 / std)
-        logits = out["cls_preds"].flatten()
-        k = min(max(int(target_candidates), 1), logits.numel() - 1)
-        kth = torch.topk(logits, k).values[-1]
-        thr = self.hypes["postprocess"]["target_args"]["score_threshold"]
-        shift = float(np.log(thr / (1.0 - thr))) - float(kth)
-        for name, p in self.model.named_parameters():
-            if name.startswith("cls_head") and name.endswith("bias"):
-                p.add_(shift)
-        return shift
+        return calibrate_heads(self.model, scene.model_input(),
+                               self.hypes["postprocess"]["target_args"]["score_threshold"], target_candidates)
 
     @torch.no_grad()
     def forward(self, scene):
