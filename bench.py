@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying a "
                     "captured HIP graph of the step (the heterogeneous scene is ~800 launches: host-bound when eager)")
+    ap.add_argument("--parallel", default="agents", choices=["agents", "replicas"],
+                    help="N>1: 'agents' (default, BASELINE north_star) shards the agents of ONE scene over the ranks with one "
+                         "all-gather (strong scaling); 'replicas' runs one independent scene per rank, no collective "
+                         "(weak scaling; the throughput upper bound of SURVEY 8e)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +128,7 @@ def main():
     if os.environ.get("HEAL_MIOPEN_BENCHMARK", "0") == "1":
         torch.backends.cudnn.benchmark = True  # MIOpen find mode: time the applicable solvers once per shape
     from heal_amd import configs, ops
-    from heal_amd.dist import ShardedCollab, owned_agents
+    from heal_amd.dist import make_sharded, owned_agents
     from heal_amd.pipeline import Scene, ScenePipeline
 
     # everything runs on one non-default stream, so that an optional HIP-graph capture of the step reuses the
@@ -135,21 +139,21 @@ def main():
     n_agents = len(mods)
     lidar_only = all(m == "m1" for m in mods)
     baseline_model = a.workload == "scene8_second_v2xvit"
+    replicas = world > 1 and a.parallel == "replicas"
+    solo = world == 1 or replicas      # this rank runs whole scenes by itself
     if baseline_model:
-        if world > 1:
-            raise SystemExit("the agent-sharded path is implemented for the pyramid-fusion model (scene5*, pair)")
         hypes = configs.lidar_baseline("v2xvit", max_cav=n_agents, modality="m3")
     elif lidar_only:
         hypes = configs.lidar_pyramid(max_cav=max(5, n_agents))
     else:
         hypes = configs.heal_heter(tuple(sorted(set(mods))), max_cav=max(5, n_agents))
     pipe = ScenePipeline(hypes, dev, seed=0)
-    scene = Scene(n_agents, seed=4, device=dev, modalities=mods)
+    scene = Scene(n_agents, seed=4 + (rank if replicas else 0), device=dev, modalities=mods)
     cls_shift = pipe.calibrate_cls_bias(scene)
     batch = {"ego": {"transformation_matrix": pipe.tfm, "anchor_box": pipe.anchor_box}}
 
     use_graph = False
-    if world == 1:
+    if solo:
         def step():
             return pipe.step(scene)
         if not a.eager:
@@ -165,7 +169,7 @@ def main():
                 torch.cuda.synchronize()
     else:
         wire = torch.float16 if os.environ.get("HEAL_WIRE", "fp32") == "fp16" else None  # opt-in half-size exchange
-        sharded = ShardedCollab(pipe.model, rank, world, wire_dtype=wire)
+        sharded = make_sharded(pipe.model, rank, world, wire_dtype=wire)
         mine = owned_agents(n_agents, rank, world)
         local_inputs = scene.inputs_for(mine)
         inp = scene.model_input()
@@ -188,6 +192,7 @@ def main():
                                       dir_args["num_bins"], pipe.post.params["nms_thresh"],
                                       np.eye(4, dtype=np.float32), pipe.post.params["gt_range"], sync=False)
             if sharded.capture(inp, n_agents, local_inputs, post_fn):
+                pipe.check_sparse_capacity()
                 use_graph = True
             elif sharded._capture_error is not None:
                 e = sharded._capture_error
@@ -224,7 +229,7 @@ def main():
         # same K steps, right after the timed graph replays (events cannot be recorded inside a graph)
         ops.TIMING = {}
         for _ in range(a.steps):
-            if world == 1:
+            if solo:
                 pipe.step(scene)
             else:
                 eager_step()
@@ -252,7 +257,7 @@ def main():
             # one launch of the operator = the collated LiDAR agents this rank encodes (reference: one PillarVFE +
             # PointPillarScatter call per modality batch); algorithmic bytes = sum over those agents
             lidar_ids = [i for i, m in enumerate(mods) if m == "m1"]
-            if world > 1:
+            if not solo:
                 lidar_ids = [i for i in lidar_ids if i in owned_agents(n_agents, 0, world)]
             order = sorted(scene.points)
             m_launch = [m_per_agent[order.index(i)] for i in lidar_ids if i in order]
@@ -272,15 +277,16 @@ def main():
         kernels = {k: {"calls": c, "mean_ms": round(ms, 5)} for k, (c, ms) in sorted(timing.items())}
         line = {
             "metric": "scenes/sec (5-agent OPV2V-H, PointPillars+PyramidFusion)",
-            "value": round(a.steps / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+            "value": round((world if replicas else 1) * a.steps / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {desc}", "agents": n_agents,
                        "pillars_per_agent": m_per_agent, "modalities": mods,
                        "points_per_agent": [int(scene.points[k].shape[0]) for k in sorted(scene.points)],
-                       "parallelism": "1 GPU" if world == 1 else (f"agent-sharded over {world} ranks, 1 all-gather"
+                       "parallelism": "1 GPU" if world == 1 else f"{world} independent scene replicas, no collective" if replicas
+                       else (f"agent-sharded over {world} ranks, 1 all-gather"
                                                                    + (" (fp16 wire)" if os.environ.get("HEAL_WIRE") == "fp16" else "")),
-                       "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if world == 1
+                       "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if solo
                                   else "hipGraph(local stage) -> all-gather -> hipGraph(fusion tail + decode/NMS)"),
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "op_timing_ms": kernels,

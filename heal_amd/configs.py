@@ -233,6 +233,19 @@ def oldstyle_pointpillar(fusion_method=None, lidar_range=FULL_RANGE, max_cav=5, 
     return load_general_params(h)
 
 
+def oldstyle_lss(encoder="EfficientNet", final_dim=(384, 512), lidar_range=FULL_RANGE, max_cav=5):
+    """Old-style camera detector (opencood/models/lift_splat_shoot.py): core_method lift_splat_shoot, `image_inputs`
+    key, resnet18-trunk BevEncode on the 256x256 pooled grid, stride-2 shrink header to the 128x128 anchor map."""
+    h = _common(lidar_range, max_cav)
+    enc = _camera_modality(lidar_range, final_dim, encoder)["encoder_args"]
+    args = dict(enc, bevout_feature=128,
+                shrink_header={"kernal_size": [3], "stride": [2], "padding": [1], "dim": [128], "input_dim": 128},
+                dir_args=copy.deepcopy(DIR_ARGS))
+    h["name"] = "heal_amd_lift_splat_shoot"
+    h["model"] = {"core_method": "lift_splat_shoot", "args": args}
+    return load_general_params(h)
+
+
 def dump_yaml(hypes, path):
     def plain(o):
         if isinstance(o, dict):

@@ -59,6 +59,21 @@ def unpack_levels(gathered, shapes, n_agents, world):
     return out
 
 
+def pack_maps(x, n_slots):
+    """Single-scale models: x [n_local, C, H, W] (already in the ego frame) -> [n_slots, C*H*W], unused slots zero."""
+    n_local = x.shape[0]
+    buf = torch.zeros((n_slots, x.shape[1] * x.shape[2] * x.shape[3]), dtype=x.dtype, device=x.device)
+    if n_local:
+        buf[:n_local] = x.reshape(n_local, -1)
+    return buf
+
+
+def unpack_maps(gathered, shape, n_agents, world):
+    """gathered [world, n_slots, C*H*W] -> [n_agents, C, H, W] in SCENE agent order (slot s of rank r = agent r + s*world)."""
+    rows = torch.stack([gathered[a % world, a // world] for a in range(n_agents)])
+    return rows.reshape((n_agents,) + tuple(shape))
+
+
 def all_gather_packed(buf, world):
     """The path's single collective: every rank contributes its [n_slots, per_slot] buffer."""
     if world == 1:
@@ -69,14 +84,13 @@ def all_gather_packed(buf, world):
     return out.view(world, n_slots, per_slot)
 
 
-class ShardedCollab:
-    """HeterPyramidCollab forward split at the fusion boundary, one scene, `world` ranks.
+class _Sharded:
+    """One scene, `world` ranks, model forward split at the fusion boundary.
 
-    The work of a rank is three stages: `local` (encode own agents, pyramid stages, occupancy heads, warp
-    into the ego frame, pack), the all-gather, and -- on rank 0 -- `tail` (fusion, deblocks, shrink head,
-    detection heads).  `local` and `tail` contain no collective and no host round trip, so each can be
-    captured once into a HIP graph and replayed (`capture`); the collective stays an ordinary stream op
-    between the two replays."""
+    The work of a rank is three stages: `local` (encode own agents, everything per-agent, warp into the ego frame,
+    pack), the all-gather, and -- on rank 0 -- `tail` (fusion, shrink head, detection heads).  `local` and `tail`
+    contain no collective and no host round trip, so each can be captured once into a HIP graph and replayed
+    (`capture`); the collective stays an ordinary stream op between the two replays."""
 
     def __init__(self, model, rank, world, wire_dtype=None):
         """wire_dtype: dtype of the all-gathered buffer.  None / torch.float32 = exact (default); torch.float16 halves the
@@ -88,75 +102,39 @@ class ShardedCollab:
         self.wire_dtype = wire_dtype if wire_dtype is not None else torch.float32
         self._g_local = self._g_tail = None
 
-    # ---- stage 1: everything a rank can do alone ---------------------------------------------------------
-    @torch.no_grad()
-    def local(self, scene_input, n_agents, local_inputs):
-        from heal_amd import ops
-        from heal_amd.opencood.models.fuse_modules.pyramid_fuse import crop_window
-        from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
-        m = self.model
-        pairwise, grid_f64 = pairwise_to_host(scene_input["pairwise_t_matrix"])
-        affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)[0]  # [L,L,2,3]
-        mine = owned_agents(n_agents, self.rank, self.world)
-        mods = scene_input["agent_modality_list"]
-        pb = m.pyramid_backbone
-        n_slots = slots_per_rank(n_agents, self.world)
-        level_feats, level_scores = [], []
-        if mine:
-            feats = {}
-            for mod in m.modality_name_list:
-                if f"inputs_{mod}" in local_inputs:
-                    feats[mod] = m.encode_modality(local_inputs, mod)
-            cursor = {k: 0 for k in feats}
-            parts = []
-            for a in mine:
-                parts.append(feats[mods[a]][cursor[mods[a]]])
-                cursor[mods[a]] += 1
-            x = torch.stack(parts)
-            if m.compress:
-                x = m.compressor(x)
-            stages = pb.get_multiscale_feature(x)
-            for i, f in enumerate(stages):
-                occ = getattr(pb, f"single_head_{i}")(f)
-                fe_all, se_all = [], []
-                for k, a in enumerate(mine):
-                    crop = None
-                    if mods[a] in m.cam_crop_info:
-                        info = m.cam_crop_info[mods[a]]
-                        crop = [crop_window(f.shape[2], f.shape[3], info[f"crop_ratio_H_{mods[a]}"],
-                                            info[f"crop_ratio_W_{mods[a]}"])]
-                    fe, se = ops.warp_agent(f[k], occ[k], affine[0, a], grid_f64, crop)
-                    fe_all.append(fe); se_all.append(se)
-                level_feats.append(torch.stack(fe_all))
-                level_scores.append(torch.stack(se_all))
-        else:
-            dev = next(m.parameters()).device
-            shapes = self._level_shapes()
-            level_feats = [torch.zeros((0,) + s, device=dev) for s in shapes]
-            level_scores = [torch.zeros((0, 1) + s[1:], device=dev) for s in shapes]
-        buf = pack_levels(level_feats, level_scores, n_slots)
+    def prepare(self, scene_input, n_agents, local_inputs):
+        """Hook: anything ranks must agree on before the first `local` (may communicate; never captured)."""
+
+    def _wire(self, buf):
         return buf if self.wire_dtype == buf.dtype else buf.to(self.wire_dtype)
 
-    # ---- stage 3 (rank 0): fusion and the fixed tail -------------------------------------------------------
-    @torch.no_grad()
-    def tail(self, gathered, n_agents):
-        from heal_amd import ops
+    def _own_features(self, scene_input, n_agents, local_inputs):
+        """Encode the agents this rank owns: ([n_mine, C, H, W] in scene order | None, owned agent ids)."""
         m = self.model
-        pb = m.pyramid_backbone
-        fused = []
-        if gathered.dtype != torch.float32:
-            gathered = gathered.float()
-        for feats_ego, scores_ego in unpack_levels(gathered, self._level_shapes(), n_agents, self.world):
-            fused.append(ops.fuse_warped(feats_ego, scores_ego).unsqueeze(0))
-        y = pb.decode_multiscale_feature(fused)
-        cls_preds, reg_preds, dir_preds = m.heads(y)
-        return {"pyramid": "collab", "cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
+        mine = owned_agents(n_agents, self.rank, self.world)
+        if not mine:
+            return None, mine
+        mods = scene_input["agent_modality_list"]
+        feats = {}
+        for mod in m.modality_name_list:
+            if f"inputs_{mod}" in local_inputs:
+                feats[mod] = m.encode_modality(local_inputs, mod)
+        cursor = {k: 0 for k in feats}
+        parts = []
+        for a in mine:
+            parts.append(feats[mods[a]][cursor[mods[a]]])
+            cursor[mods[a]] += 1
+        x = torch.stack(parts)
+        if m.compress:
+            x = m.compressor(x)
+        return x, mine
 
     @torch.no_grad()
     def forward(self, scene_input, n_agents, local_inputs):
         """local_inputs: {'inputs_mX': ...} for the agents this rank owns, in scene order (the
         reference's collated layout, restricted to the local agents).  Returns the model output dict
         on rank 0, None elsewhere."""
+        self.prepare(scene_input, n_agents, local_inputs)
         buf = self.local(scene_input, n_agents, local_inputs)
         gathered = all_gather_packed(buf, self.world)
         if self.rank != 0:
@@ -233,6 +211,62 @@ class ShardedCollab:
         self._g_tail.replay()
         return self._static_post
 
+
+class ShardedCollab(_Sharded):
+    """HeterPyramidCollab (heter_pyramid_collab.py:133-209): the shard is every pyramid level's features + occupancy
+    scores, warped to the ego frame by the owning rank."""
+
+    # ---- stage 1: everything a rank can do alone ---------------------------------------------------------
+    @torch.no_grad()
+    def local(self, scene_input, n_agents, local_inputs):
+        from heal_amd import ops
+        from heal_amd.opencood.models.fuse_modules.pyramid_fuse import crop_window
+        from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
+        m = self.model
+        pairwise, grid_f64 = pairwise_to_host(scene_input["pairwise_t_matrix"])
+        affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)[0]  # [L,L,2,3]
+        mods = scene_input["agent_modality_list"]
+        pb = m.pyramid_backbone
+        n_slots = slots_per_rank(n_agents, self.world)
+        level_feats, level_scores = [], []
+        x, mine = self._own_features(scene_input, n_agents, local_inputs)
+        if mine:
+            stages = pb.get_multiscale_feature(x)
+            for i, f in enumerate(stages):
+                occ = getattr(pb, f"single_head_{i}")(f)
+                fe_all, se_all = [], []
+                for k, a in enumerate(mine):
+                    crop = None
+                    if mods[a] in m.cam_crop_info:
+                        info = m.cam_crop_info[mods[a]]
+                        crop = [crop_window(f.shape[2], f.shape[3], info[f"crop_ratio_H_{mods[a]}"],
+                                            info[f"crop_ratio_W_{mods[a]}"])]
+                    fe, se = ops.warp_agent(f[k], occ[k], affine[0, a], grid_f64, crop)
+                    fe_all.append(fe); se_all.append(se)
+                level_feats.append(torch.stack(fe_all))
+                level_scores.append(torch.stack(se_all))
+        else:
+            dev = next(m.parameters()).device
+            shapes = self._level_shapes()
+            level_feats = [torch.zeros((0,) + s, device=dev) for s in shapes]
+            level_scores = [torch.zeros((0, 1) + s[1:], device=dev) for s in shapes]
+        return self._wire(pack_levels(level_feats, level_scores, n_slots))
+
+    # ---- stage 3 (rank 0): fusion and the fixed tail -------------------------------------------------------
+    @torch.no_grad()
+    def tail(self, gathered, n_agents):
+        from heal_amd import ops
+        m = self.model
+        pb = m.pyramid_backbone
+        fused = []
+        if gathered.dtype != torch.float32:
+            gathered = gathered.float()
+        for feats_ego, scores_ego in unpack_levels(gathered, self._level_shapes(), n_agents, self.world):
+            fused.append(ops.fuse_warped(feats_ego, scores_ego).unsqueeze(0))
+        y = pb.decode_multiscale_feature(fused)
+        cls_preds, reg_preds, dir_preds = m.heads(y)
+        return {"pyramid": "collab", "cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
+
     def _level_shapes(self):
         m = self.model
         fb = m.args["fusion_backbone"]
@@ -244,3 +278,63 @@ class ShardedCollab:
             H, W = H // s, W // s
             shapes.append((c, H, W))
         return shapes
+
+
+class ShardedBaseline(_Sharded):
+    """HeterModelBaseline (heter_model_baseline.py:155-236; BASELINE config 5: SECOND + V2X-ViT): the shard is
+    the owning rank's shrinker output warped into the ego frame, [C, H, W] per agent (256 x 128 x 128 = 16.8 MB);
+    rank 0 reduces the gathered ego-frame stack with the model's fusion operator (max / att / V2XTransformer)."""
+
+    _shape = None
+
+    def prepare(self, scene_input, n_agents, local_inputs):
+        """Ranks that own no agent (world > n_agents) still contribute a zero slot of the right size: the [C, H, W] of
+        the shared map is learnt once from the ranks that do own agents (one MAX all-reduce of three integers)."""
+        if self._shape is not None:
+            return
+        dev = next(self.model.parameters()).device
+        shape = torch.zeros(3, dtype=torch.int64, device=dev)
+        if owned_agents(n_agents, self.rank, self.world):
+            self.local(scene_input, n_agents, local_inputs)   # sets self._shape
+            shape = torch.tensor(self._shape, dtype=torch.int64, device=dev)
+        if self.world > 1:
+            dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+        self._shape = tuple(int(v) for v in shape.tolist())
+
+    @torch.no_grad()
+    def local(self, scene_input, n_agents, local_inputs):
+        from heal_amd.opencood.models.fuse_modules.fusion_in_one import warp_to_ego
+        from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
+        m = self.model
+        pairwise, _ = pairwise_to_host(scene_input["pairwise_t_matrix"])
+        affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)
+        f64 = affine.dtype == "float64"
+        n_slots = slots_per_rank(n_agents, self.world)
+        x, mine = self._own_features(scene_input, n_agents, local_inputs)
+        if mine:
+            ego = warp_to_ego(x, [affine[0][0, a] for a in mine], f64)
+            self._shape = tuple(ego.shape[1:])
+        else:
+            dev = next(m.parameters()).device
+            ego = torch.zeros((0,) + self._shape, device=dev)
+        return self._wire(pack_maps(ego, n_slots))
+
+    @torch.no_grad()
+    def tail(self, gathered, n_agents):
+        m = self.model
+        if gathered.dtype != torch.float32:
+            gathered = gathered.float()
+        ego = unpack_maps(gathered, self._shape, n_agents, self.world)
+        fused = m.fusion_net.fuse_warped(ego).unsqueeze(0)
+        cls_preds, reg_preds, dir_preds = m.heads(fused)
+        return {"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
+
+
+def make_sharded(model, rank, world, wire_dtype=None):
+    """The agent-sharded runner that matches the model class."""
+    name = type(model).__name__
+    if name == "HeterPyramidCollab":
+        return ShardedCollab(model, rank, world, wire_dtype)
+    if name == "HeterModelBaseline":
+        return ShardedBaseline(model, rank, world, wire_dtype)
+    raise NotImplementedError(f"no agent-sharded split for {name}")

@@ -29,46 +29,44 @@ def _host_affine(affine_matrix):
     return a, a.dtype == np.float64
 
 
-class MaxFusion(nn.Module):
+class _WarpThenFuse(nn.Module):
+    """The three operators share one shape: warp every agent of a scene into the ego frame (K5), then reduce the
+    ego-frame stack with `fuse_warped` ([n,C,H,W] -> [C,H,W]).  The agent-sharded path (heal_amd/dist.py) warps on the
+    owning rank and calls `fuse_warped` on the gathered stack."""
+
     def forward(self, x, record_len, affine_matrix):
         aff, f64 = _host_affine(affine_matrix)
         out = []
         for b, feats in enumerate(regroup(x, record_len)):
             n = feats.shape[0]
-            out.append(warp_to_ego(feats, aff[b][0, :n], f64).max(dim=0)[0])
+            out.append(self.fuse_warped(warp_to_ego(feats, aff[b][0, :n], f64)))
         return torch.stack(out)
 
 
-class AttFusion(nn.Module):
+class MaxFusion(_WarpThenFuse):
+    def fuse_warped(self, ego):
+        return ego.max(dim=0)[0]
+
+
+class AttFusion(_WarpThenFuse):
     def __init__(self, feature_dims):
         super().__init__()
         self.sqrt_dim = float(np.sqrt(feature_dims))
         self.feature_dims = feature_dims
 
-    def forward(self, xx, record_len, affine_matrix):
-        aff, f64 = _host_affine(affine_matrix)
-        out = []
-        for b, feats in enumerate(regroup(xx, record_len)):
-            n, C, H, W = feats.shape
-            x = warp_to_ego(feats, aff[b][0, :n], f64)
-            x = x.view(n, C, H * W).permute(2, 0, 1).contiguous()       # [HW, n, C]
-            h = ops.agent_attention(x, x, x, heads=1, scale=1.0 / self.sqrt_dim, out_rows=1)  # ego row only
-            out.append(h[:, 0, :].t().reshape(C, H, W))
-        return torch.stack(out)
+    def fuse_warped(self, ego):
+        n, C, H, W = ego.shape
+        x = ego.reshape(n, C, H * W).permute(2, 0, 1).contiguous()      # [HW, n, C]
+        h = ops.agent_attention(x, x, x, heads=1, scale=1.0 / self.sqrt_dim, out_rows=1)  # ego row only
+        return h[:, 0, :].t().reshape(C, H, W)
 
 
-class V2XViTFusion(nn.Module):
+class V2XViTFusion(_WarpThenFuse):
     def __init__(self, args):
         super().__init__()
         from heal_amd.opencood.models.sub_modules.v2xvit_basic import V2XTransformer
         self.fusion_net = V2XTransformer(args["transformer"])
 
-    def forward(self, x, record_len, affine_matrix):
-        aff, f64 = _host_affine(affine_matrix)
-        out = []
-        for b, feats in enumerate(regroup(x, record_len)):
-            n = feats.shape[0]
-            ego = warp_to_ego(feats, aff[b][0, :n], f64)                 # [n,C,H,W]; the 3 prior channels are zero
-            fused = self.fusion_net(ego.permute(0, 2, 3, 1).contiguous())   # [H,W,C]
-            out.append(fused.permute(2, 0, 1))
-        return torch.stack(out)
+    def fuse_warped(self, ego):
+        fused = self.fusion_net(ego.permute(0, 2, 3, 1).contiguous())       # [n,H,W,C] -> [H,W,C]; the 3 prior channels are zero
+        return fused.permute(2, 0, 1)

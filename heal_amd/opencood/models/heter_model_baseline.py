@@ -72,6 +72,21 @@ class HeterModelBaseline(nn.Module):
             for p in self.compressor.parameters():
                 p.requires_grad_(True)
 
+    def encode_modality(self, data_dict, m):
+        """encoder -> backbone -> shrinker (-> camera crop) for all agents of modality m (:170-196)."""
+        f = getattr(self, f"encoder_{m}")(data_dict, m)
+        f = getattr(self, f"backbone_{m}")({"spatial_features": f})["spatial_features_2d"]
+        f = getattr(self, f"shrinker_{m}")(f)
+        if self.sensor_type_dict[m] == "camera":
+            _, _, H, W = f.shape
+            f = center_crop(f, int(H * getattr(self, f"crop_ratio_H_{m}")), int(W * getattr(self, f"crop_ratio_W_{m}")))
+        return f
+
+    def heads(self, fused):
+        if self.shrink_flag:
+            fused = self.shrink_conv(fused)
+        return detection_heads(fused, self.cls_head, self.reg_head, self.dir_head)
+
     def forward(self, data_dict):
         output_dict = {}
         agent_modality_list = data_dict["agent_modality_list"]
@@ -83,15 +98,9 @@ class HeterModelBaseline(nn.Module):
         for m in self.modality_name_list:
             if m not in counts:
                 continue
-            f = getattr(self, f"encoder_{m}")(data_dict, m)
-            f = getattr(self, f"backbone_{m}")({"spatial_features": f})["spatial_features_2d"]
-            f = getattr(self, f"shrinker_{m}")(f)
-            if self.sensor_type_dict[m] == "camera":
-                _, _, H, W = f.shape
-                f = center_crop(f, int(H * getattr(self, f"crop_ratio_H_{m}")), int(W * getattr(self, f"crop_ratio_W_{m}")))
-                if getattr(self, f"depth_supervision_{m}"):
-                    output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
-            feats[m] = f
+            feats[m] = self.encode_modality(data_dict, m)
+            if self.sensor_type_dict[m] == "camera" and getattr(self, f"depth_supervision_{m}"):
+                output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
         cursor = {m: 0 for m in self.modality_name_list}
         parts = []
         for m in agent_modality_list:
@@ -104,8 +113,6 @@ class HeterModelBaseline(nn.Module):
             output_dict.update({"cls_preds_single": self.cls_head_single(x), "reg_preds_single": self.reg_head_single(x),
                                 "dir_preds_single": self.dir_head_single(x)})
         fused = self.fusion_net(x, record_len, affine_matrix)
-        if self.shrink_flag:
-            fused = self.shrink_conv(fused)
-        cls_preds, reg_preds, dir_preds = detection_heads(fused, self.cls_head, self.reg_head, self.dir_head)
+        cls_preds, reg_preds, dir_preds = self.heads(fused)
         output_dict.update({"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds})
         return output_dict

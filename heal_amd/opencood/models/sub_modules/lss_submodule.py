@@ -1,5 +1,6 @@
 """Camera feature extractors of the Lift-Splat encoder (reference: opencood/models/sub_modules/
-lss_submodule.py:17-233): `Up`, `CamEncode` (EfficientNet-b0 trunk), `CamEncode_Resnet101`.
+lss_submodule.py:17-233): `Up`, `CamEncode` (EfficientNet-b0 trunk), `CamEncode_Resnet101`, and
+`BevEncode` (:236-273, the resnet18-trunk BEV decoder of the old-style `lift_splat_shoot.py` model).
 
 The reference takes the two trunks from third-party packages that are not in its tree
 (efficientnet_pytorch==0.7.0, torchvision); they are restated here from the packages' published
@@ -15,7 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from heal_amd.opencood.models.sub_modules.bev_blocks import Bottleneck, ConvBN, _FoldCache, _require_eval
+from heal_amd.opencood.models.sub_modules.bev_blocks import (BasicBlock, Bottleneck, ConvBN, _FoldCache, _require_eval,
+                                                             conv_bias_act)
 
 
 class Up(nn.Module):
@@ -245,3 +247,43 @@ class CamEncode_Resnet101(_CamEncodeBase):
         f = ConvBN.run(x[:, :3, :, :], self.conv1, self.bn1, self._c, relu=True)
         f = self.layer2(self.layer1(self.maxpool(f)))
         return self.heads(f, x)
+
+
+class BevEncode(nn.Module):
+    """lss_submodule.py:236-273: 7x7/2 stem + torchvision resnet18 layer1..3 (BasicBlocks; restated with the package's
+    parameter names `layerK.i.{conv1,bn1,conv2,bn2,downsample.0,downsample.1}`), `Up(64+256 -> 256, x4)`, then
+    x2 bilinear -> 3x3 conv + BN + ReLU -> 1x1 conv.  All conv+BN pairs run folded (eval only)."""
+
+    def __init__(self, inC, outC):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inC, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = self._make_layer(64, 64, 1)
+        self.layer2 = self._make_layer(64, 128, 2)
+        self.layer3 = self._make_layer(128, 256, 2)
+        self.up1 = Up(64 + 256, 256, scale_factor=4)
+        self.up2 = nn.Sequential(
+            nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+            nn.Conv2d(256, 128, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU(inplace=True),
+            nn.Conv2d(128, outC, kernel_size=1, padding=0))
+        self._c = [_FoldCache(), _FoldCache()]
+
+    @staticmethod
+    def _make_layer(inplanes, planes, stride):
+        down = None
+        if stride != 1 or inplanes != planes:
+            down = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        return nn.Sequential(BasicBlock(inplanes, planes, stride, down), BasicBlock(planes, planes))
+
+    def forward(self, x):
+        _require_eval(self)
+        from heal_amd import ops
+        x = ConvBN.run(x, self.conv1, self.bn1, self._c[0], relu=True)
+        x1 = self.layer1(x)
+        x = self.layer3(self.layer2(x1))
+        x = self.up1(x, x1)
+        x = ops.upsample2x_bilinear(x) if x.is_cuda else self.up2[0](x)
+        x = ConvBN.run(x, self.up2[1], self.up2[2], self._c[1], relu=True)
+        last = self.up2[4]
+        return conv_bias_act(x, last.weight, last.bias, last.stride, last.padding, 1, 1, False)

@@ -90,3 +90,25 @@ def test_all_gather_fp16_wire_format_world2(tmp_path):
         assert float((f - want_f).abs().max()) <= 2.0 ** -11 * float(want_f.abs().max()) * 1.01
         assert float((s - want_s).abs().max()) <= 2.0 ** -11 * 1.01
         assert not torch.equal(f, want_f)  # the cast really happened
+
+
+def _map_worker(rank, world, n_agents, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = hd.owned_agents(n_agents, rank, world)
+    x = torch.stack([_agent_maps(a)[0][0] for a in mine]) if mine else torch.zeros((0,) + SHAPES[0])
+    gathered = hd.all_gather_packed(hd.pack_maps(x, hd.slots_per_rank(n_agents, world)), world)
+    if rank == 0:
+        torch.save(hd.unpack_maps(gathered, SHAPES[0], n_agents, world).clone(), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_agents", [8, 3, 1])
+def test_all_gather_of_single_scale_maps_world2(tmp_path, n_agents):
+    """The exchange of ShardedBaseline (HeterModelBaseline: one ego-frame map per agent, no scores)."""
+    out = str(tmp_path / "maps.pt")
+    mp.spawn(_map_worker, args=(2, n_agents, _free_port(), out), nprocs=2, join=True)
+    want = torch.stack([_agent_maps(a)[0][0] for a in range(n_agents)])
+    assert torch.equal(torch.load(out), want)

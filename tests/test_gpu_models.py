@@ -310,3 +310,55 @@ def test_late_fusion_post_process_matches_reference_golden(golden):
     p2, s2 = post.post_process(one_d, one_o)
     np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_oldstyle_lift_splat_shoot_vs_plain_torch():
+    """SURVEY 8f-3, opencood/models/lift_splat_shoot.py.  torchvision's resnet18 is not importable in the build container
+    (no golden), so the BEV decoder is checked against a plain fp32 torch restatement of lss_submodule.py:236-273 --
+    unfused conv2d / batch_norm / relu / interpolate -- fed with the model's own K4 output (K4 has its own parity tests),
+    followed by downsample_conv.py:7-49 and the three 1x1 heads."""
+    import torch.nn.functional as F
+    from heal_amd import configs
+    from heal_amd.pipeline import Scene
+    model = build(configs.oldstyle_lss())
+    sd = model.state_dict()
+    scene = Scene(2, seed=5, device="cuda", modalities=["m2", "m2"])
+    image_inputs = scene.inputs_for([0, 1])["inputs_m2"]
+
+    def cbr(x, conv, bn, stride=1, pad=1, relu=True):
+        y = F.conv2d(x, sd[conv + ".weight"], None, stride, pad)
+        y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"],
+                         False, 0.0, 1e-5)
+        return F.relu(y) if relu else y
+
+    def block(x, p, stride):
+        idt = x
+        if (p + ".downsample.0.weight") in sd:
+            idt = cbr(x, p + ".downsample.0", p + ".downsample.1", stride, 0, relu=False)
+        y = cbr(x, p + ".conv1", p + ".bn1", stride)
+        return F.relu(cbr(y, p + ".conv2", p + ".bn2", relu=False) + idt)
+
+    with torch.no_grad():
+        out = model({"image_inputs": image_inputs})
+        bev, depth_items = model.get_voxels(image_inputs)
+        assert tuple(bev.shape) == (2, 128, 256, 256) and depth_items is not None
+        x = cbr(bev, "bevencode.conv1", "bevencode.bn1", 2, 3)
+        x1 = block(block(x, "bevencode.layer1.0", 1), "bevencode.layer1.1", 1)
+        x = block(block(x1, "bevencode.layer2.0", 2), "bevencode.layer2.1", 1)
+        x = block(block(x, "bevencode.layer3.0", 2), "bevencode.layer3.1", 1)
+        x = torch.cat([x1, F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True)], 1)
+        x = cbr(cbr(x, "bevencode.up1.conv.0", "bevencode.up1.conv.1"), "bevencode.up1.conv.3", "bevencode.up1.conv.4")
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        x = cbr(x, "bevencode.up2.1", "bevencode.up2.2")
+        x = F.conv2d(x, sd["bevencode.up2.4.weight"], sd["bevencode.up2.4.bias"])
+        want_bev = x
+        got_bev = model.bevencode(bev)
+        x = F.relu(F.conv2d(x, sd["shrink_conv.layers.0.double_conv.0.weight"], sd["shrink_conv.layers.0.double_conv.0.bias"], 2, 1))
+        x = F.relu(F.conv2d(x, sd["shrink_conv.layers.0.double_conv.2.weight"], sd["shrink_conv.layers.0.double_conv.2.bias"], 1, 1))
+        want = {k: F.conv2d(x, sd[h + ".weight"], sd[h + ".bias"])
+                for k, h in (("cls_preds", "cls_head"), ("reg_preds", "reg_head"), ("dir_preds", "dir_head"))}
+    assert tuple(out["cls_preds"].shape) == (2, 2, 128, 128) and tuple(out["reg_preds"].shape) == (2, 14, 128, 128)
+    assert rel_err(got_bev.cpu().numpy(), want_bev.cpu().numpy()) < 1e-3
+    for k, w in want.items():
+        assert float(w.abs().max()) > 0
+        assert rel_err(out[k].cpu().numpy(), w.cpu().numpy()) < 1e-3, k
