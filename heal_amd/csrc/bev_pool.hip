@@ -18,6 +18,8 @@
 //                    (sequential fp32, more accurate than the reference's cumsum difference), emit a
 //                    compact row and the cell->row map
 //   k_canvas         (shared with K2) one streaming pass writes the whole [B, C*nz, ny, nx] output
+#include <stdlib.h>
+#include <string.h>
 #include "prims.h"
 #include "../../include/heal_amd.h"
 
@@ -283,6 +285,198 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
     }
 }
 
+// ---- direct splat (default) -------------------------------------------------------------------------------
+// The sorted pipeline above costs ~10 dependent launches for 42 MB of algorithmic traffic.  The frustum has a
+// structure the sort ignores: along an image COLUMN (fixed camera, u, depth bin) the lifted points differ only in
+// the camera's vertical direction, which the one-cell-high BEV grid collapses -- the fH points of a column fall
+// into one or two cells ("runs").  One block owns (camera, u, a quarter of the depth bins):
+//   k_lss_mark   computes the cell keys of its points (lss_cell_key: the expression order of k_lss_keys, so the same
+//                keys), and for every run start zero-fills the cell's row and marks the cell in the cell->row map
+//                (plain idempotent stores: several blocks may zero the same row, nobody adds before the kernel ends)
+//   k_lss_splat  recomputes the keys, adds the depth softmax (same partial-sum partition as k_lss_keys -> same
+//                probabilities), stages the column's fH feature rows in LDS once, walks each (u, d) column along v
+//                accumulating p * feat in registers while the cell stays the same, and adds each finished run to
+//                the cell's row with hardware fp32 atomics (global_atomic_add_f32, no return).  A run is C
+//                CONSECUTIVE floats: a wave's atomic instruction covers whole cache lines (adding straight into the
+//                channel-major output -- one line per lane -- ran at ~16 G atomics/s and was no faster than the sort)
+//   k_canvas     (shared with K2) streams the [B, C*nz, ny, nx] output from the rows
+// ~12 k runs replace the 590 k-element sort, the segment pass and the tile reduce / combine.  Within a run the
+// order is v-ascending; ACROSS runs the order of the atomic adds is not fixed, so a cell fed by three or more runs
+// can differ by an ulp from call to call (the reference's `ranks.argsort()` is unstable and feeds a cumsum
+// difference: it has the same property).  HEAL_LSS_PATH=sorted selects the bit-reproducible pipeline.
+constexpr int LSS_DQ = 4;        // depth quarters per (camera, u) column
+constexpr int LSS_DPB = 16;      // depth bins per block at most (D <= 64)
+constexpr uint32_t LSS_NOKEY = 0xFFFFFFFFu;
+
+// get_geometry + the voxel_pooling index of one lifted point (heter_encoders.py:125-147, :170-186), fp32, the
+// operation order of the reference (and of k_lss_keys)
+__device__ __forceinline__ uint32_t lss_cell_key(const CamMats& cm, const float* __restrict__ fr, const LssGeom& g,
+                                                 int b) {
+    const float p0 = fr[0] - cm.post_trans[0], p1 = fr[1] - cm.post_trans[1], p2 = fr[2] - cm.post_trans[2];
+    const float* A = cm.inv_post_rot;
+    const float q0 = (A[0] * p0 + A[1] * p1) + A[2] * p2;
+    const float q1 = (A[3] * p0 + A[4] * p1) + A[5] * p2;
+    const float q2 = (A[6] * p0 + A[7] * p1) + A[8] * p2;
+    const float u0 = q0 * q2, u1 = q1 * q2, u2 = q2;
+    const float* M = cm.combine;
+    const float ex = ((M[0] * u0 + M[1] * u1) + M[2] * u2) + cm.trans[0];
+    const float ey = ((M[3] * u0 + M[4] * u1) + M[5] * u2) + cm.trans[1];
+    const float ez = ((M[6] * u0 + M[7] * u1) + M[8] * u2) + cm.trans[2];
+    const float fx = (ex - g.lo[0]) / g.dx[0];
+    const float fy = (ey - g.lo[1]) / g.dx[1];
+    const float fz = (ez - g.lo[2]) / g.dx[2];
+    if (fx > -1.f && fx < (float)g.nx[0] && fy > -1.f && fy < (float)g.nx[1] && fz > -1.f && fz < (float)g.nx[2]) {
+        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        if (ix >= 0 && ix < g.nx[0] && iy >= 0 && iy < g.nx[1] && iz >= 0 && iz < g.nx[2])
+            return (uint32_t)(b * (g.nx[0] * g.nx[1] * g.nx[2]) + (iz * g.nx[1] + iy) * g.nx[0] + ix);
+    }
+    return LSS_NOKEY;
+}
+
+// keys of the block's (u, depth quarter) slab into LDS: thread (v, part) takes the bins part, part+4, ...
+__device__ __forceinline__ void lss_slab_keys(const float* __restrict__ frustum, const CamMats* __restrict__ cams,
+                                              const LssGeom& g, int bn, int u, int db0, int nd,
+                                              uint32_t (*pk_key)[64]) {
+    const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if (v >= g.fH) return;
+    const int HW = g.fH * g.fW, pix = v * g.fW + u;
+    const CamMats cm = cams[bn];
+    for (int dl = part; dl < nd; dl += 4)
+        pk_key[dl][v] = lss_cell_key(cm, frustum + ((size_t)(db0 + dl) * HW + pix) * 3, g, bn / g.n_cams);
+}
+
+__global__ __launch_bounds__(256) void k_lss_mark(const float* __restrict__ frustum, const CamMats* __restrict__ cams,
+                                                 LssGeom g, float* __restrict__ rows, int* __restrict__ cell_map) {
+    __shared__ uint32_t pk_key[LSS_DPB][64];
+    const int u = blockIdx.x / LSS_DQ, dq = blockIdx.x % LSS_DQ, bn = blockIdx.y;
+    const int dper = (g.D + 3) / 4;
+    const int db0 = dq * dper, nd = min(db0 + dper, g.D) - db0;
+    lss_slab_keys(frustum, cams, g, bn, u, db0, nd, pk_key);
+    __syncthreads();
+    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int dl = part; dl < nd; dl += 4) {
+        const uint32_t key = l < g.fH ? pk_key[dl][l] : LSS_NOKEY;
+        const uint32_t prev = (l > 0 && l < g.fH) ? pk_key[dl][l - 1] : LSS_NOKEY;
+        unsigned long long starts = __ballot(key != LSS_NOKEY && key != prev);
+        while (starts) {
+            const int src = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const uint32_t cell = __shfl(key, src, 64);
+            float* r = rows + (size_t)cell * g.C;
+            for (int c = l; c < g.C; c += 64) r[c] = 0.f;
+            if (l == 0) cell_map[cell] = (int)cell;
+        }
+    }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void k_lss_splat(const float* __restrict__ depth_logit,
+                                                  const float* __restrict__ featT /*[BN,HW,C]*/,
+                                                  const float* __restrict__ frustum,
+                                                  const CamMats* __restrict__ cams, LssGeom g,
+                                                  float* __restrict__ rows) {
+    __shared__ float red[4][64];
+    __shared__ float pk_p[LSS_DPB][64];
+    __shared__ uint32_t pk_key[LSS_DPB][64];
+    extern __shared__ float4 xs4[];  // [fH][C]
+    const float* xs = reinterpret_cast<const float*>(xs4);
+
+    const int HW = g.fH * g.fW;
+    const int u = blockIdx.x / LSS_DQ, dq = blockIdx.x % LSS_DQ, bn = blockIdx.y;
+    const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const bool live = v < g.fH;
+    const int dper = (g.D + 3) / 4;  // the softmax partition of k_lss_keys (identical partial sums)
+    const int db0 = dq * dper, nd = min(db0 + dper, g.D) - db0;
+
+    // this thread's logits: pixel (v, u), bins [part*dper, ...) -- read once, kept in registers
+    float lgr[LSS_DPB];
+    {
+        const float* lg = depth_logit + (size_t)bn * g.D * HW + (live ? v * g.fW + u : 0);
+        const int d0 = part * dper;
+#pragma unroll
+        for (int i = 0; i < LSS_DPB; ++i)
+            lgr[i] = (live && i < dper && d0 + i < g.D) ? lg[(size_t)(d0 + i) * HW] : -INFINITY;
+    }
+    // stage the column's feature rows
+    {
+        const int c4n = g.C / 4;
+        const float4* src = reinterpret_cast<const float4*>(featT);
+        for (int i = threadIdx.x; i < g.fH * c4n; i += 256) {
+            const int r = i / c4n, c4 = i - r * c4n;
+            xs4[i] = src[((size_t)bn * HW + (size_t)r * g.fW + u) * c4n + c4];
+        }
+    }
+    lss_slab_keys(frustum, cams, g, bn, u, db0, nd, pk_key);
+    // softmax over depth (lss_submodule.py:130): max, exp, normalise -- sequential over the bins of a part, parts
+    // combined as ((r0 + r1) + r2) + r3, like k_lss_keys
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LSS_DPB; ++i) mx = fmaxf(mx, lgr[i]);
+    red[part][v] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][v], red[1][v]), fmaxf(red[2][v], red[3][v]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LSS_DPB; ++i)
+        if (lgr[i] != -INFINITY) sum += expf(lgr[i] - mx);
+    red[part][v] = sum;
+    __syncthreads();
+    const float den = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
+    if (part == dq && live) {
+#pragma unroll
+        for (int i = 0; i < LSS_DPB; ++i)
+            if (i < nd) pk_p[i][v] = expf(lgr[i] - mx) / den;
+    }
+    __syncthreads();
+
+    // one wave per (u, d) column: runs along v
+    const int l = threadIdx.x & 63;
+    for (int dl = part; dl < nd; dl += 4) {
+        float acc[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
+        uint32_t cur = LSS_NOKEY;
+        auto flush = [&]() {
+            if (cur == LSS_NOKEY) return;
+            float* o = rows + (size_t)cur * g.C;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c = l + 64 * k;
+                if (c < g.C) unsafeAtomicAdd(o + c, acc[k]);
+                acc[k] = 0.f;
+            }
+        };
+        for (int v0 = 0; v0 < g.fH; v0 += 4) {
+            uint32_t key[4];
+            float p[4], x[4][CPL];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int vv = min(v0 + t, g.fH - 1);
+                key[t] = (v0 + t < g.fH) ? pk_key[dl][vv] : LSS_NOKEY;
+                p[t] = pk_p[dl][vv];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int c = l + 64 * k;
+                    x[t][k] = c < g.C ? xs[vv * g.C + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (key[t] != cur) {
+                    flush();
+                    cur = key[t];
+                }
+                if (cur != LSS_NOKEY) {
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) acc[k] += p[t] * x[t][k];
+                }
+            }
+        }
+        flush();
+    }
+}
+
 // One thread per camera: the 3x3 algebra of get_geometry (closed-form adjugate inverses, fp32) in ONE launch instead
 // of ~90 tiny elementwise kernels per camera modality.
 __device__ __forceinline__ void inv3x3(const float* m, float* o) {
@@ -392,6 +586,23 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     HEAL_REQUIRE(carve(a, n_agents, n_cams, D, HW, channels, cells_total, w),
                  "bev_pool: workspace too small (%zu < %zu)", ws_bytes, a.off);
 
+    const char* path_env = getenv("HEAL_LSS_PATH");
+    const bool sorted_path = (path_env && strcmp(path_env, "sorted") == 0) || fH > 64 || D > 64 ||
+                             (size_t)fH * channels * sizeof(float) > 54 * 1024;  // static 9 KB + dynamic <= 64 KB of LDS
+    if (!sorted_path) {
+        HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
+        const dim3 grid(fW * LSS_DQ, n_agents * n_cams);
+        const CamMats* cm = reinterpret_cast<const CamMats*>(cam_mats);
+        k_lss_mark<<<grid, 256, 0, s>>>(frustum, cm, g, w.rows, w.cell_map);
+        k_lss_transpose<<<dim3(ceil_div(HW, 32), ceil_div(channels, 32), n_agents * n_cams), 256, 0, s>>>(
+            feat, channels, HW, w.featT);
+        const size_t lds = (size_t)fH * channels * sizeof(float);
+        if (channels <= 64) k_lss_splat<1><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+        else if (channels <= 128) k_lss_splat<2><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+        else k_lss_splat<4><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+        HEAL_LAUNCH_CHECK();
+        return heal_canvas_from_map(w.cell_map, w.rows, n_agents * g.nx[2], channels, g.nx[0] * g.nx[1], out, s);
+    }
     HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
     const uint32_t invalid_key = (uint32_t)cells_total;
     k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 64), 256, 0, s>>>(
