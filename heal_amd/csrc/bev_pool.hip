@@ -477,6 +477,152 @@ __global__ __launch_bounds__(256) void k_lss_splat(const float* __restrict__ dep
     }
 }
 
+// ---- the same splat on the matrix cores ------------------------------------------------------------------------
+// k_lss_splat spends its time issuing the v-walk on the vector ALUs (~12 instructions per lifted point).  In the
+// common case a (u, d) column is ONE run, so the column's result is a matrix-vector product, and the 16 depth bins
+// of a block share the feature rows:  out[d, c] = sum_v P'[d, v] X[v, c]  with  P'[d, v] = p[d, v] where the point's
+// cell is the column's MAIN cell (the cell of its first valid point) and 0 elsewhere -- a [16 x fH] x [fH x C] GEMM
+// per block on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate).  Points of a column that fall in another cell
+// (a pitched camera; none for a level rig) are walked afterwards exactly like k_lss_splat does, main-cell points
+// skipped.  One block = (camera, u, 16 depth bins); wave w owns the channel tiles w, w+4, ...
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int LSS_MT = 16;  // depth bins per block = MFMA M
+
+__global__ __launch_bounds__(256) void k_lss_splat_mfma(const float* __restrict__ depth_logit,
+                                                       const float* __restrict__ featT /*[BN,HW,C]*/,
+                                                       const float* __restrict__ frustum,
+                                                       const CamMats* __restrict__ cams, LssGeom g, int n_dt,
+                                                       float* __restrict__ rows) {
+    __shared__ float red[4][64];
+    __shared__ float pk_p[LSS_MT][64];       // p[dl][v] (unmasked; the leftover walk reads it)
+    __shared__ uint32_t pk_key[LSS_MT][64];  // key[dl][v]
+    __shared__ float pT[64][LSS_MT];         // P'[v][dl]: A operand, v-major so that a fragment read is conflict-free
+    __shared__ uint32_t mk[LSS_MT];          // main cell of column dl
+    __shared__ int has_left[LSS_MT];
+    extern __shared__ float4 xs4[];          // X[fH4][C + 16]
+    float* xs = reinterpret_cast<float*>(xs4);
+
+    const int HW = g.fH * g.fW;
+    const int u = blockIdx.x / n_dt, dt = blockIdx.x % n_dt, bn = blockIdx.y;
+    const int v = threadIdx.x & 63, part = threadIdx.x >> 6, l = v;
+    const bool live = v < g.fH;
+    const int pix = live ? v * g.fW + u : 0;
+    const int LD = g.C + 16;                 // LD % 64 == 16: the 4 k-rows of a B fragment hit disjoint bank groups
+    const int fH4 = (g.fH + 3) & ~3;
+
+    // this thread's logits: pixel (v, u), bins part, part + 4, ... -- read once, kept in registers
+    float lgr[16];
+    {
+        const float* lg = depth_logit + (size_t)bn * g.D * HW + pix;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = part + 4 * i;
+            lgr[i] = (live && d < g.D) ? lg[(size_t)d * HW] : -INFINITY;
+        }
+    }
+    // stage the column's feature rows (rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop)
+    {
+        const int c4n = g.C / 4, ld4 = LD / 4;
+        const float4* src = reinterpret_cast<const float4*>(featT);
+        for (int i = threadIdx.x; i < fH4 * c4n; i += 256) {
+            const int r = i / c4n, c4 = i - r * c4n;
+            xs4[r * ld4 + c4] = r < g.fH ? src[((size_t)bn * HW + (size_t)r * g.fW + u) * c4n + c4]
+                                         : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // cell keys of the block's 16 bins: thread (v, part) takes dl = part, part + 4, part + 8, part + 12
+    uint32_t mykey[4];
+    {
+        const CamMats cm = cams[bn];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dl = part + 4 * j, d = dt * LSS_MT + dl;
+            mykey[j] = (live && d < g.D) ? lss_cell_key(cm, frustum + ((size_t)d * HW + pix) * 3, g, bn / g.n_cams)
+                                         : LSS_NOKEY;
+            pk_key[dl][v] = mykey[j];
+        }
+    }
+    // softmax over depth (lss_submodule.py:130)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, lgr[i]);
+    red[part][v] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][v], red[1][v]), fmaxf(red[2][v], red[3][v]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (lgr[i] != -INFINITY) sum += expf(lgr[i] - mx);
+    red[part][v] = sum;
+    // main cell of each column: the cell of its first valid point (keys were written before the barriers above)
+    for (int dl = part; dl < LSS_MT; dl += 4) {
+        const uint32_t key = pk_key[dl][l];
+        const unsigned long long valid = __ballot(key != LSS_NOKEY);
+        const uint32_t m = valid ? __shfl(key, __builtin_ctzll(valid), 64) : LSS_NOKEY;
+        const unsigned long long left = __ballot(key != LSS_NOKEY && key != m);
+        if (l == 0) {
+            mk[dl] = m;
+            has_left[dl] = left != 0ull;
+        }
+    }
+    __syncthreads();
+    const float den = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
+    // probabilities of the block's bins: bin d = 16 dt + dl sits in lgr[4 dt + (dl >> 2)] of the thread with
+    // part == (dl & 3), i.e. this thread's own dl = part + 4 j
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if ((i >> 2) != dt) continue;  // block-uniform
+        const int j = i & 3, dl = part + 4 * j;
+        const float p = (live && lgr[i] != -INFINITY) ? expf(lgr[i] - mx) / den : 0.f;
+        pk_p[dl][v] = p;
+        pT[v][dl] = (mykey[j] != LSS_NOKEY && mykey[j] == mk[dl]) ? p : 0.f;
+    }
+    __syncthreads();
+
+    // GEMM: D[dl, c] = sum_v P'[v][dl] X[v][c]
+    const int lk = l >> 4, ln = l & 15;
+    const int ksteps = fH4 / 4;  // <= 16
+    float afr[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) afr[ks] = ks < ksteps ? pT[ks * 4 + lk][ln] : 0.f;
+    const int n_tiles = g.C / 16;
+    for (int nt = part; nt < n_tiles; nt += 4) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* xb = xs + lk * LD + nt * 16 + ln;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], xb[ks * 4 * LD], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t cell = mk[lk * 4 + r];
+            if (cell != LSS_NOKEY) unsafeAtomicAdd(rows + (size_t)cell * g.C + nt * 16 + ln, acc[r]);
+        }
+    }
+
+    // leftovers: points of a column outside its main cell, walked as runs along v
+    for (int dl = part; dl < LSS_MT; dl += 4) {
+        if (!has_left[dl]) continue;
+        const uint32_t skip = mk[dl];
+        for (int c0 = 0; c0 < g.C; c0 += 64) {
+            const int c = c0 + l;
+            float acc = 0.f;
+            uint32_t cur = LSS_NOKEY;
+            for (int vv = 0; vv <= g.fH; ++vv) {
+                uint32_t key = vv < g.fH ? pk_key[dl][vv] : LSS_NOKEY;
+                if (key == skip) key = LSS_NOKEY;
+                if (key != cur) {
+                    if (cur != LSS_NOKEY && c < g.C) unsafeAtomicAdd(rows + (size_t)cur * g.C + c, acc);
+                    acc = 0.f;
+                    cur = key;
+                }
+                if (cur != LSS_NOKEY && c < g.C) acc += pk_p[dl][vv] * xs[vv * LD + c];
+            }
+        }
+    }
+}
+
 // One thread per camera: the 3x3 algebra of get_geometry (closed-form adjugate inverses, fp32) in ONE launch instead
 // of ~90 tiny elementwise kernels per camera modality.
 __device__ __forceinline__ void inv3x3(const float* m, float* o) {
@@ -588,7 +734,7 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
 
     const char* path_env = getenv("HEAL_LSS_PATH");
     const bool sorted_path = (path_env && strcmp(path_env, "sorted") == 0) || fH > 64 || D > 64 ||
-                             (size_t)fH * channels * sizeof(float) > 54 * 1024;  // static 9 KB + dynamic <= 64 KB of LDS
+                             (size_t)(fH + 4) * (channels + 16) * sizeof(float) > 48 * 1024;  // static 14 KB + dynamic <= 64 KB of LDS
     if (!sorted_path) {
         HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
         const dim3 grid(fW * LSS_DQ, n_agents * n_cams);
@@ -596,10 +742,17 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
         k_lss_mark<<<grid, 256, 0, s>>>(frustum, cm, g, w.rows, w.cell_map);
         k_lss_transpose<<<dim3(ceil_div(HW, 32), ceil_div(channels, 32), n_agents * n_cams), 256, 0, s>>>(
             feat, channels, HW, w.featT);
-        const size_t lds = (size_t)fH * channels * sizeof(float);
-        if (channels <= 64) k_lss_splat<1><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
-        else if (channels <= 128) k_lss_splat<2><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
-        else k_lss_splat<4><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+        if (path_env && strcmp(path_env, "walk") == 0) {  // the vector-ALU walk (kept for A/B: scripts/k4_bench.py)
+            const size_t lds = (size_t)fH * channels * sizeof(float);
+            if (channels <= 64) k_lss_splat<1><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+            else if (channels <= 128) k_lss_splat<2><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+            else k_lss_splat<4><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
+        } else {
+            const int n_dt = ceil_div(D, LSS_MT);
+            const size_t lds = (size_t)((fH + 3) & ~3) * (channels + 16) * sizeof(float);
+            k_lss_splat_mfma<<<dim3(fW * n_dt, n_agents * n_cams), 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g,
+                                                                                  n_dt, w.rows);
+        }
         HEAL_LAUNCH_CHECK();
         return heal_canvas_from_map(w.cell_map, w.rows, n_agents * g.nx[2], channels, g.nx[0] * g.nx[1], out, s);
     }

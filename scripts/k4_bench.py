@@ -1,4 +1,5 @@
-"""K4 A/B: direct splat (default) vs the sorted pipeline (HEAL_LSS_PATH=sorted), standalone launches, HIP events.
+"""K4 A/B: direct splat on the matrix cores (default) vs the vector-ALU walk (HEAL_LSS_PATH=walk) vs the sorted
+pipeline (HEAL_LSS_PATH=sorted), standalone launches, HIP events.
 Usage: python scripts/k4_bench.py   (on the GPU box)"""
 import json
 import os
@@ -25,7 +26,7 @@ def run(final_dim, C=128, n_agents=1, iters=30):
     ft = torch.from_numpy(rng.standard_normal((n_agents * N, C, fH, fW)).astype(np.float32)).cuda()
     res = {}
     outs = {}
-    for path in ("sorted", "splat"):
+    for path in ("sorted", "walk", "splat"):
         os.environ["HEAL_LSS_PATH"] = path
         for _ in range(5):
             out = ops.bev_pool(dl, ft, frustum, mats, n_agents, N, dx.tolist(), bx.tolist(), nx.tolist())
@@ -41,6 +42,7 @@ def run(final_dim, C=128, n_agents=1, iters=30):
         outs[path] = out
     a, b = outs["sorted"], outs["splat"]
     res["max_rel_diff"] = float((a - b).abs().max() / a.abs().max())
+    res["max_rel_diff_walk"] = float((a - outs["walk"]).abs().max() / a.abs().max())
     res["nonzero_cells"] = int((a != 0).any(dim=1).sum())
     alg = (dl.numel() + ft.numel() + a.numel()) * 4
     res["alg_MB"] = alg / 1e6
