@@ -320,6 +320,51 @@ def test_bev_pool_full_size_vs_oracle(n_agents, C, final_dim):
     assert (out != 0).any(axis=1).sum() > 1000
 
 
+def _pitched_rig(final_dim, n_cams=4):
+    """synth.camera_rig with every camera pitched / rolled (10..25 deg) and a resize + crop post-transform: the points
+    of an image column then spread over several BEV cells (several runs per column, and runs that leave the grid)."""
+    from heal_amd import synth
+    rig = synth.camera_rig(0, n_cams, final_dim[0], final_dim[1])
+    for k in range(n_cams):
+        a, r = np.deg2rad(10.0 + 5.0 * k), np.deg2rad(4.0 * k - 6.0)
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Rz = np.array([[np.cos(r), -np.sin(r), 0], [np.sin(r), np.cos(r), 0], [0, 0, 1]])
+        rig["rots"][k] = (rig["rots"][k].astype(np.float64) @ Rx @ Rz).astype(np.float32)
+        rig["post_rots"][k] = np.diag([0.9, 0.9, 1.0]).astype(np.float32)
+        rig["post_trans"][k] = np.array([-7.0 + k, 3.0, 0.0], np.float32)
+    return rig
+
+
+@pytest.mark.parametrize("path", ["splat", "walk", "sorted"])
+def test_bev_pool_pitched_cameras_vs_oracle(path, monkeypatch):
+    """K4 with cameras that are NOT level: image columns break into several runs, the case the level synthetic rig
+    never produces (the matrix-core path handles the column's main cell as a GEMM and walks the rest)."""
+    from heal_amd import ops
+    monkeypatch.setenv("HEAL_LSS_PATH", path)
+    final_dim, C, n_agents, D, N = (336, 448), 64, 2, 48, 4
+    rng = np.random.default_rng(11)
+    fH, fW = final_dim[0] // 8, final_dim[1] // 8
+    frustum = O.create_frustum(list(final_dim), 8, [2, 50, 48], "LID")
+    dx, bx, nx = O.gen_dx_bx([-51.2, 51.2, 0.4], [-51.2, 51.2, 0.4], [-10, 10, 20.0])
+    rig = _pitched_rig(final_dim, N)
+    cam = {k: np.tile(v[None], (n_agents,) + (1,) * v.ndim).astype(np.float32) for k, v in rig.items()}
+    depth_logit = rng.standard_normal((n_agents * N, D, fH, fW)).astype(np.float32)
+    feat = rng.standard_normal((n_agents * N, C, fH, fW)).astype(np.float32)
+    out = ops.bev_pool(dev(depth_logit), dev(feat), dev(frustum), _cam_mats(cam), n_agents, N, dx.tolist(),
+                       bx.tolist(), nx.tolist()).cpu().numpy()
+    geom = O.lss_geometry(frustum, cam["rots"], cam["trans"], cam["intrins"], cam["post_rots"], cam["post_trans"])
+    # the case this test exists for: columns with more than one run
+    idx = np.trunc((geom - (bx - dx / 2)) / dx).astype(np.int64)[0]            # [N,D,fH,fW,3]
+    ok = ((idx >= 0) & (idx < nx)).all(-1)
+    key = np.where(ok, idx[..., 1] * nx[0] + idx[..., 0], -1)
+    runs = (key[:, :, 0] >= 0).sum() + ((key[:, :, 1:] != key[:, :, :-1]) & (key[:, :, 1:] >= 0)).sum()
+    assert runs > 2 * N * D * fW, runs
+    x = O.lift(depth_logit, feat).reshape(n_agents, N, C, D, fH, fW).transpose(0, 1, 3, 4, 5, 2)
+    ref = O.bev_pool(geom, x, dx, bx, nx)
+    _pool_close(out, ref)
+    assert (out != 0).any(axis=1).sum() > 1000
+
+
 # ---------------------------------------------------------------------------------------------- K3
 def _random_sites(rng, n, shape, batch):
     D, H, W = shape
