@@ -7,7 +7,9 @@
 // (QuickCumsum.forward) and opencood/models/sub_modules/lss_submodule.py:129-134
 // (softmax(depth)[:,None] * feat[:,:,None], a 302 MB/agent tensor the reference materialises).
 //
-// MI355X formulation -- the 302 MB lifted tensor is never formed:
+// MI355X formulation -- the 302 MB lifted tensor is never formed.  Two pipelines: the default "splat" (column runs
+// as a GEMM on the matrix cores + contiguous fp32 atomics, see k_lss_mark / k_lss_splat_mfma below) and the
+// bit-reproducible sorted pipeline (HEAL_LSS_PATH=sorted):
 //   k_lss_keys       one thread per camera pixel: softmax over the D depth bins in registers, frustum
 //                    geometry in fp32 (same operation order as the reference), cell key per point
 //   radix sort       stable sort of (cell key, point index): points of a cell become contiguous, in
