@@ -167,16 +167,21 @@ class _Sharded:
         cur.synchronize()
         self._capture_error = None
         ok = True
-        try:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: the process-group watchdog thread may query events while we capture
-            with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
-                self._static_buf = self.local(scene_input, n_agents, local_inputs)
-            self._g_local = g
-        except Exception as e:  # noqa: BLE001 - reported by the caller, path falls back to eager
-            self._capture_error = e
-            ok = False
-            torch.cuda.synchronize()
+        self._g_local = None
+        if not owned_agents(n_agents, self.rank, self.world):
+            # a rank without agents (world > n_agents) contributes a constant all-zero slot: nothing to capture
+            self._static_buf = self.local(scene_input, n_agents, local_inputs)
+        else:
+            try:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: the process-group watchdog thread may query events while we capture
+                with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
+                    self._static_buf = self.local(scene_input, n_agents, local_inputs)
+                self._g_local = g
+            except Exception as e:  # noqa: BLE001 - reported by the caller, path falls back to eager
+                self._capture_error = e
+                ok = False
+                torch.cuda.synchronize()
         if not self._agree(ok, dev):
             self._g_local = None
             return False
@@ -200,7 +205,8 @@ class _Sharded:
         return True
 
     def replay(self):
-        self._g_local.replay()
+        if self._g_local is not None:   # None: this rank owns no agent, its slot is the constant zero buffer
+            self._g_local.replay()
         if self.world > 1:
             n_slots, per_slot = self._static_buf.shape
             dist.all_gather_into_tensor(self._static_gathered.view(self.world * n_slots, per_slot), self._static_buf)

@@ -46,7 +46,7 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None):
         out = sharded.forward(scene.model_input(), len(mods), scene.inputs_for(mine))
         # the same through graph(local) -> all-gather -> graph(tail)
         captured = sharded.capture(scene.model_input(), len(mods), scene.inputs_for(mine))
-        assert captured or len(mods) < world, sharded._capture_error   # an idle rank's empty stage may refuse capture
+        assert captured, sharded._capture_error
         rep = out
         if captured:
             rep = sharded.replay()
@@ -60,7 +60,7 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_agents", [3, 2])
+@pytest.mark.parametrize("n_agents", [3, 2, 1])
 def test_sharded_forward_equals_single_process(tmp_path, n_agents):
     import torch.multiprocessing as mp
     out = str(tmp_path / "o.pt")
