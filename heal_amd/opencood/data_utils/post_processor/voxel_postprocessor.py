@@ -1,6 +1,7 @@
 """VoxelPostprocessor (reference: opencood/data_utils/post_processor/voxel_postprocessor.py):
 generate_anchor_box (:30-83) on the host, post_process (:245-405) on the gfx950 decode + rotated-NMS
-kernel K8 (heal_decode_nms)."""
+kernel K8 (heal_decode_nms), generate_label (:85-207) on heal_label_assign, collate_batch (:210-243) and the
+inherited generate_gt_bbx (base_postprocessor.py:47-107) on the host."""
 import math
 import sys
 
@@ -97,6 +98,29 @@ class VoxelPostprocessor:
         return {'pos_equal_one': pos.view(H, W, A).cpu().numpy(),
                 'neg_equal_one': neg.double().view(H, W, A).cpu().numpy(),
                 'targets': tgt.view(H, W, A * 7).cpu().numpy()}
+
+    @staticmethod
+    def collate_batch(label_batch_list):
+        """voxel_postprocessor.py:210-243: stack the per-frame label dictionaries of generate_label."""
+        keys = ("targets", "pos_equal_one", "neg_equal_one")
+        return {k: torch.from_numpy(np.array([frame[k] for frame in label_batch_list])) for k in keys}
+
+    def generate_gt_bbx(self, data_dict):
+        """base_postprocessor.py:47-107: ground-truth corners [N,8,3] in the ego frame for evaluation.  Every cav's valid
+        `object_bbx_center` rows go to corners (`params['order']`), through its `transformation_matrix_clean`; objects
+        seen by several cavs are kept once (first occurrence of each id, ids visited in `set` order like the
+        reference); boxes with any corner outside `gt_range` (x, y and z) are dropped."""
+        from heal_amd.opencood.utils import box_utils
+        corners, ids = [], []
+        for cav_content in data_dict.values():
+            centers = cav_content["object_bbx_center"][cav_content["object_bbx_mask"] == 1]
+            c = box_utils.boxes_to_corners_3d(centers, self.params["order"])
+            corners.append(box_utils.project_box3d(c.float(), cav_content["transformation_matrix_clean"]))
+            ids += cav_content["object_ids"]
+        corners = torch.vstack(corners)
+        picked = corners[[ids.index(x) for x in set(ids)]]
+        kept = box_utils.mask_boxes_outside_range_numpy(picked.cpu().numpy(), self.params["gt_range"], order=None)
+        return torch.from_numpy(kept).to(device=corners.device)
 
     @staticmethod
     def delta_to_boxes3d(deltas, anchors):

@@ -410,7 +410,45 @@ def gen_pose():
          pairwise_proj_first=tu.get_pairwise_transformation(base, 5, True))
 
 
-GENS_EXTRA = {"label": gen_label, "pose": gen_pose}
+def gen_gt():
+    """BasePostprocessor.generate_gt_bbx (base_postprocessor.py:47-107) on a two-cav dictionary with shared object ids
+    and out-of-range boxes, and VoxelPostprocessor.collate_batch (voxel_postprocessor.py:210-243)."""
+    vp = R.ref("opencood.data_utils.post_processor.voxel_postprocessor")
+    yu = R.ref("opencood.hypes_yaml.yaml_utils")
+    tu = R.ref("opencood.utils.transformation_utils")
+    hy = load_hypes("LiDAROnly/lidar_pyramid.yaml")
+    replace_ranges(hy, SMALL_RANGE)
+    hy = yu.load_general_params(hy)
+    post = vp.VoxelPostprocessor(hy["postprocess"], train=False)
+    rng = np.random.default_rng(41)
+    max_num = 20
+    out = {"order": np.array(hy["postprocess"]["order"]), "gt_range": np.array(hy["postprocess"]["gt_range"], np.float64)}
+    data = {}
+    id_sets = {"ego": [3, 7, 11, 12, 19, 25, 31], "cav1": [7, 40, 12, 41, 3, 42]}
+    poses = {"ego": [0, 0, 0, 0, 0, 0], "cav1": [6.0, -4.0, 0.3, 0.0, 35.0, 0.0]}
+    for name, ids in id_sets.items():
+        n = len(ids)
+        c = np.zeros((max_num, 7), np.float32)
+        c[:n] = np.concatenate([rng.uniform(-30, 30, (n, 2)), rng.uniform(-2.5, 0.5, (n, 1)),
+                                rng.uniform(1.4, 1.8, (n, 1)), rng.uniform(1.5, 2.1, (n, 1)),
+                                rng.uniform(3.5, 4.8, (n, 1)), rng.uniform(-3.1, 3.1, (n, 1))], 1)
+        m = np.zeros(max_num, np.float32); m[:n] = 1
+        t = tu.x1_to_x2(poses[name], poses["ego"]).astype(np.float32)
+        data[name] = {"object_bbx_center": torch.from_numpy(c), "object_bbx_mask": torch.from_numpy(m),
+                      "object_ids": list(ids), "transformation_matrix_clean": torch.from_numpy(t)}
+        out.update({f"{name}_center": c, f"{name}_mask": m, f"{name}_ids": np.array(ids), f"{name}_tfm": t})
+    out["gt_box"] = post.generate_gt_bbx(data).numpy()
+    frames = [{"pos_equal_one": rng.integers(0, 2, (4, 4, 2)).astype(np.float64),
+               "neg_equal_one": rng.integers(0, 2, (4, 4, 2)).astype(np.float64),
+               "targets": rng.standard_normal((4, 4, 14))} for _ in range(3)]
+    col = vp.VoxelPostprocessor.collate_batch(frames)
+    for k, fr in enumerate(frames):
+        out.update({f"frame{k}_{n}": v for n, v in fr.items()})
+    out.update({f"col_{n}": v.numpy() for n, v in col.items()})
+    save("gt", **out)
+
+
+GENS_EXTRA = {"label": gen_label, "pose": gen_pose, "gt": gen_gt}
 
 
 def pcdet_boxes(rng, n, spread):

@@ -86,6 +86,26 @@ def test_oldstyle_lift_splat_shoot_keys():
         create_model({"model": {"core_method": "lift_splat_shoot", "args": {"grid_conf": {}}}})
 
 
+def test_generate_gt_bbx_and_collate_batch_match_reference(golden):
+    """Evaluation-side companions of post_process: BasePostprocessor.generate_gt_bbx on two cavs with shared
+    object ids and out-of-range boxes, VoxelPostprocessor.collate_batch -- equal to the imported reference's outputs."""
+    from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    g = golden("gt")
+    post = VoxelPostprocessor({"order": str(g["order"]), "gt_range": g["gt_range"].tolist(), "anchor_args": {"num": 2}},
+                              train=False)
+    data = {name: {"object_bbx_center": torch.from_numpy(g[f"{name}_center"]),
+                   "object_bbx_mask": torch.from_numpy(g[f"{name}_mask"]),
+                   "object_ids": g[f"{name}_ids"].tolist(),
+                   "transformation_matrix_clean": torch.from_numpy(g[f"{name}_tfm"])} for name in ("ego", "cav1")}
+    got = post.generate_gt_bbx(data)
+    assert got.dtype == torch.float32 and tuple(got.shape) == g["gt_box"].shape
+    np.testing.assert_allclose(got.numpy(), g["gt_box"], rtol=0, atol=1e-5)
+    frames = [{n: g[f"frame{k}_{n}"] for n in ("pos_equal_one", "neg_equal_one", "targets")} for k in range(3)]
+    col = VoxelPostprocessor.collate_batch(frames)
+    for n in ("pos_equal_one", "neg_equal_one", "targets"):
+        assert col[n].dtype == torch.float64 and np.array_equal(col[n].numpy(), g[f"col_{n}"])
+
+
 def test_yaml_loader_round_trip(tmp_path):
     from heal_amd import configs
     from heal_amd.opencood.hypes_yaml import yaml_utils
