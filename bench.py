@@ -103,7 +103,19 @@ def main():
                     help="N>1: 'agents' (default, BASELINE north_star) shards the agents of ONE scene over the ranks with one "
                          "all-gather (strong scaling); 'replicas' runs one independent scene per rank, no collective "
                          "(weak scaling; the throughput upper bound of SURVEY 8e)")
+    ap.add_argument("--watchdog-s", type=int, default=1200,
+                    help="hard wall-clock limit of this process: a hung collective ends the job instead of the box")
     a = ap.parse_args()
+
+    if a.watchdog_s > 0:
+        import threading
+
+        def _expire():
+            print(f"[bench] watchdog: no result after {a.watchdog_s} s, exiting", file=sys.stderr, flush=True)
+            os._exit(3)
+        wd = threading.Timer(a.watchdog_s, _expire)
+        wd.daemon = True
+        wd.start()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
