@@ -285,6 +285,47 @@ extern "C" size_t heal_voxelize_workspace(int n_points, int max_voxels) {
     return a.off + 256;
 }
 
+namespace heal {
+struct PointMask {
+    float lo[3], hi[3];
+    int use_range, use_ego;
+};
+
+__global__ __launch_bounds__(256) void k_mask_points(const float4* pts, int n, PointMask m, float4* out) {  // may alias
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    bool keep = true;
+    if (m.use_range)  // pcd_utils.py:58-63 (a NaN coordinate fails every comparison: dropped, like numpy)
+        keep = p.x > m.lo[0] && p.x < m.hi[0] && p.y > m.lo[1] && p.y < m.hi[1] && p.z > m.lo[2] && p.z < m.hi[2];
+    if (m.use_ego) {  // pcd_utils.py:84-86
+        const bool body = p.x >= -1.95f && p.x <= 2.95f && p.y >= -1.1f && p.y <= 1.1f;
+        keep = keep && !body;
+    }
+    const float nan = __int_as_float(0x7fc00000);
+    out[i] = keep ? p : float4{nan, nan, nan, nan};
+}
+}  // namespace heal
+
+extern "C" int heal_mask_points(const float* points, int n_points, const float* range_host, int mask_ego, float* out,
+                                void* stream) {
+    HEAL_REQUIRE(n_points >= 0, "mask_points: bad size");
+    if (n_points == 0) return 0;
+    HEAL_REQUIRE(points && out, "mask_points: null pointer");
+    HEAL_REQUIRE((((uintptr_t)points | (uintptr_t)out) & 15) == 0, "mask_points: points / out must be 16-byte aligned");
+    heal::PointMask m;
+    m.use_range = range_host != nullptr;
+    m.use_ego = mask_ego != 0;
+    for (int k = 0; k < 3; ++k) {
+        m.lo[k] = range_host ? range_host[k] : 0.f;
+        m.hi[k] = range_host ? range_host[3 + k] : 0.f;
+    }
+    heal::k_mask_points<<<heal::ceil_div(n_points, 256), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(points), n_points, m, reinterpret_cast<float4*>(out));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int heal_voxelize(const float* points, int n_points, const float* range_host,
                              const float* voxel_size_host, int max_points, int max_voxels,
                              int batch_idx, float* voxels, int32_t* coords, int32_t* num_points,

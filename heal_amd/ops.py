@@ -106,6 +106,19 @@ def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=
     return voxels[:m], coords[:m], num[:m]
 
 
+def mask_points(points, limit_range=None, mask_ego=True, out=None):
+    """pcd_utils.mask_points_by_range / mask_ego_points on the device: points [N,4] f32 cuda -> same-shape tensor in
+    which dropped points are NaN (the voxeliser skips them; order and length are kept, so there is no host sync)."""
+    points = _need(points, torch.float32, "points")
+    if points.dim() != 2 or points.shape[1] != 4:
+        raise _capi.HealAmdError("points must be [N,4]")
+    if out is None:
+        out = torch.empty_like(points)
+    rng = _host_array([float(v) for v in limit_range], ctypes.c_float) if limit_range is not None else None
+    _capi.call("heal_mask_points", _ptr(points), int(points.shape[0]), rng, 1 if mask_ego else 0, _ptr(out), _stream())
+    return out
+
+
 def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxels):
     """K1 for every agent of a modality into ONE set of collated buffers (collate_batch_list,
     sp_voxel_preprocessor.py:110-147) without a host round trip: agent b's rows follow agent b-1's, the running row

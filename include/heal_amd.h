@@ -64,6 +64,18 @@ int heal_voxelize_batch(const float* points, const int32_t* point_offsets_host, 
                         float* voxels, int32_t* coords, int32_t* num_points, int32_t* row_offsets,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* heal_mask_points: the point filters the dataset applies right before the voxeliser, on the device.
+ * Replaces: opencood/utils/pcd_utils.py:41-67 (mask_points_by_range: strict > / < on x, y, z) and :70-88
+ *           (mask_ego_points: drop -1.95 <= x <= 2.95 and -1.1 <= y <= 1.1), called from the datasets'
+ *           get_item_single_car before SpVoxelPreprocessor.preprocess.
+ *   points [n_points,4] f32 -> out [n_points,4] f32 (may alias points): a kept point is copied, a dropped point
+ *   becomes four NaNs.  The cloud keeps its length and order -- no compaction, no host round trip -- and the
+ *   voxeliser drops NaN points, so heal_voxelize(out) equals the reference's preprocess(points[mask]) exactly
+ *   (first-come voxel order and both caps only see surviving points).  range_host: 6 floats or NULL (no range
+ *   filter); mask_ego: 0 | 1.  Comparisons in fp32 against the fp32-rounded bounds, like numpy on a float32 array. */
+int heal_mask_points(const float* points, int n_points, const float* range_host, int mask_ego, float* out,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K2  fused pillar feature net + scatter to the dense BEV canvas.
  * Replaces: opencood/models/sub_modules/pillar_vfe.py:105-155 (PillarVFE.forward),

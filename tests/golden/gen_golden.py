@@ -448,7 +448,28 @@ def gen_gt():
     save("gt", **out)
 
 
-GENS_EXTRA = {"label": gen_label, "pose": gen_pose, "gt": gen_gt}
+def gen_pcd():
+    """opencood/utils/pcd_utils.py: mask_points_by_range, mask_ego_points, lidar_project on a synthetic sweep salted
+    with points exactly on the range faces / the ego-box faces and with a NaN point."""
+    pu = R.ref("opencood.utils.pcd_utils")
+    tu = R.ref("opencood.utils.transformation_utils")
+    rng = np.random.default_rng(51)
+    pts = synth.lidar_frame(77)[::14].copy()
+    edge = np.array([[-25.6, 0, -1, .5], [25.6, 1, -1, .5], [3, -25.6, -1, .5], [3, 25.6, -1, .5], [5, 5, -3, .5],
+                     [5, 5, 1, .5], [-1.95, 0, -1, .5], [2.95, 0.5, -1, .5], [1, -1.1, -1, .5], [1, 1.1, -1, .5],
+                     [-1.9500001, 0, -1, .5], [2.9500003, 0, -1, .5], [1, 1.1000001, -1, .5], [0, 0, -1, .5],
+                     [np.nan, 0, 0, .5], [25.599998, 25.599998, 0.99999994, .5]], np.float32)
+    pts[rng.choice(len(pts), len(edge), replace=False)] = edge
+    ego = pu.mask_ego_points(pts)
+    both = pu.mask_points_by_range(ego, SMALL_RANGE)
+    only_range = pu.mask_points_by_range(pts, SMALL_RANGE)
+    tfm = tu.x1_to_x2([6.0, -4.0, 0.3, 1.0, 35.0, -2.0], [1.0, 2.0, 0.1, 0.0, -10.0, 0.5])
+    save("pcd", points=pts, lidar_range=np.array(SMALL_RANGE, np.float64), ego=ego, ego_range=both,
+         only_range=only_range, tfm=tfm, projected=pu.lidar_project(both, tfm),
+         stacked=pu.projected_lidar_stack([both[:5], ego[:3]]))
+
+
+GENS_EXTRA = {"label": gen_label, "pose": gen_pose, "gt": gen_gt, "pcd": gen_pcd}
 
 
 def pcdet_boxes(rng, n, spread):

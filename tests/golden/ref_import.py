@@ -97,6 +97,7 @@ def install():
     sh = _stub("shapely")
     sh.geometry = _stub("shapely.geometry", Polygon=_Polygon, Point=object, MultiPoint=object)
     _stub("pyquaternion", Quaternion=object)
+    _stub("pypcd").pypcd = _stub("pypcd.pypcd")          # .pcd file reader (disk I/O, not on the path)
     _stub("efficientnet_pytorch", EfficientNet=object)
     tv = _stub("torchvision")
     tv.transforms = _stub("torchvision.transforms", CenterCrop=_CenterCrop, Compose=_PassThrough,

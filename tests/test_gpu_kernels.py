@@ -320,6 +320,33 @@ def test_bev_pool_full_size_vs_oracle(n_agents, C, final_dim):
     assert (out != 0).any(axis=1).sum() > 1000
 
 
+def test_mask_points_then_voxelize_equals_reference_filters_then_oracle(golden):
+    """heal_mask_points (pcd_utils.mask_ego_points + mask_points_by_range on the device, dropped points -> NaN) followed
+    by K1 must equal the reference's host filters followed by the oracle voxeliser: bit exact, face-exact points and a
+    NaN point included (tests/golden/pcd.npz, generated from the imported reference)."""
+    from heal_amd import ops
+    from heal_amd.opencood.utils import pcd_utils
+    g = golden("pcd")
+    rng = g["lidar_range"].tolist()
+    pts = dev(g["points"])
+    masked = pcd_utils.mask_points_by_range(pcd_utils.mask_ego_points(pts), rng)     # device path of the mirror
+    assert masked.shape == pts.shape
+    kept = ~torch.isnan(masked).any(dim=1)
+    assert np.array_equal(masked[kept].cpu().numpy(), g["ego_range"])
+    one = ops.mask_points(pts, rng, mask_ego=True)
+    assert np.array_equal(one.cpu().numpy(), masked.cpu().numpy(), equal_nan=True)
+    only = ops.mask_points(pts, rng, mask_ego=False)
+    assert np.array_equal(only[~torch.isnan(only).any(dim=1)].cpu().numpy(), g["only_range"])
+    inplace = pts.clone()
+    ops.mask_points(inplace, rng, mask_ego=True, out=inplace)
+    assert np.array_equal(inplace.cpu().numpy(), one.cpu().numpy(), equal_nan=True)
+    for vs, P in (([0.4, 0.4, 4], 32), ([0.1, 0.1, 0.1], 5)):
+        v, c, n = ops.voxelize(one, rng, vs, P, 70000)
+        ov, oc, on = cref.voxelize(g["ego_range"], rng, vs, P, 70000, batch_idx=0)
+        assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(n.cpu().numpy(), on)
+        assert np.array_equal(v.cpu().numpy(), ov)
+
+
 def _pitched_rig(final_dim, n_cams=4):
     """synth.camera_rig with every camera pitched / rolled (10..25 deg) and a resize + crop post-transform: the points
     of an image column then spread over several BEV cells (several runs per column, and runs that leave the grid)."""

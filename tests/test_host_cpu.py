@@ -106,6 +106,23 @@ def test_generate_gt_bbx_and_collate_batch_match_reference(golden):
         assert col[n].dtype == torch.float64 and np.array_equal(col[n].numpy(), g[f"col_{n}"])
 
 
+def test_pcd_utils_host_mirror_matches_reference(golden):
+    """opencood/utils/pcd_utils.py filters / projection (numpy contract) against the imported reference's outputs,
+    including points exactly on the range and ego-box faces and a NaN point."""
+    from heal_amd.opencood.utils import pcd_utils
+    g = golden("pcd")
+    pts, rng = g["points"], g["lidar_range"].tolist()
+    ego = pcd_utils.mask_ego_points(pts)
+    assert np.array_equal(ego, g["ego"], equal_nan=True)
+    both = pcd_utils.mask_points_by_range(ego, rng)
+    assert np.array_equal(both, g["ego_range"])
+    assert np.array_equal(pcd_utils.mask_points_by_range(pts, rng), g["only_range"])
+    proj = pcd_utils.lidar_project(both, g["tfm"])
+    assert proj.dtype == g["projected"].dtype and np.array_equal(proj, g["projected"])
+    assert np.array_equal(pcd_utils.projected_lidar_stack([both[:5], ego[:3]]), g["stacked"])
+    assert pcd_utils.shuffle_points(both).shape == both.shape
+
+
 def test_yaml_loader_round_trip(tmp_path):
     from heal_amd import configs
     from heal_amd.opencood.hypes_yaml import yaml_utils
