@@ -1,7 +1,6 @@
 """Shared construction logic of the heterogeneous models (reference: the per-modality loops at
 heter_pyramid_collab.py:35-77, heter_pyramid_single.py:30-63, heter_model_late.py:26-69)."""
 import importlib
-from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F

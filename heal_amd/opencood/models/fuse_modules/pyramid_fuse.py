@@ -1,6 +1,5 @@
 """PyramidFusion (reference: opencood/models/fuse_modules/pyramid_fuse.py:65-168) on top of the
 fused warp + occupancy-softmax kernel K5 (heal_warp_fuse)."""
-import numpy as np
 import torch
 import torch.nn as nn
 

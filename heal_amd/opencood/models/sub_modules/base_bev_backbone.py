@@ -4,7 +4,6 @@ so that checkpoint keys `blocks.{i}.{1,2,4,5,...}` match; Conv+BN pairs are fold
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from heal_amd.opencood.models.sub_modules.bev_blocks import _Deblock, _FoldCache, _require_eval, conv_bias_act
 

@@ -4,7 +4,6 @@ single-process stacking in scene agent order."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

@@ -5,7 +5,6 @@ the single-process model."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """End-to-end parity of the host-side model mirror (heal_amd.opencood) on the GPU against the
 reference's golden outputs: same closed-form weights (tests/golden/detfill.py), same inputs."""
-import copy
 
 import numpy as np
 import pytest
