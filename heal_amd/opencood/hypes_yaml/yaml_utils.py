@@ -1,9 +1,11 @@
-"""YAML config surface (reference: opencood/hypes_yaml/yaml_utils.py:14-49 load_yaml,
-:337-369 load_general_params).  The reference's own YAML files parse unchanged."""
+"""YAML config surface (reference: opencood/hypes_yaml/yaml_utils.py:14-49 load_yaml, :337-369 load_general_params,
+and the post-parsers of the old-style model files: :97-137 load_point_pillar_params, :140-180 load_second_params,
+:295-334 load_lift_splat_shoot_params; :234-249 save_yaml).  The reference's own YAML files parse unchanged."""
 import math
 import os
 import re
 
+import numpy as np
 import yaml
 
 _FLOAT_RE = re.compile(u'''^(?:
@@ -36,12 +38,49 @@ def load_general_params(param):
     return param
 
 
-_PARSERS = {"load_general_params": load_general_params}
+def _grid_size(param):
+    r = param['preprocess']['cav_lidar_range']
+    return np.round((np.array(r[3:6]) - np.array(r[0:3])) / np.array(param['preprocess']['args']['voxel_size'])).astype(np.int64)
+
+
+def load_point_pillar_params(param):
+    """yaml_utils.py:97-137 (opencood/models/point_pillar*.py): the scatter grid size + the anchor grid (ceil)."""
+    param['model']['args']['point_pillar_scatter']['grid_size'] = _grid_size(param)
+    return load_general_params(param)
+
+
+def load_lift_splat_shoot_params(param):
+    """yaml_utils.py:295-334 (opencood/models/lift_splat_shoot*.py): the anchor grid only."""
+    return load_general_params(param)
+
+
+def load_second_params(param):
+    """yaml_utils.py:140-180 (opencood/models/second*.py): `grid_size` of the sparse encoder; W/H/D truncate (int(),
+    not ceil like the other parsers)."""
+    r = param['preprocess']['cav_lidar_range']
+    vw, vh, vd = param['preprocess']['args']['voxel_size'][:3]
+    param['model']['args']['grid_size'] = _grid_size(param)
+    a = param['postprocess']['anchor_args']
+    a['vw'], a['vh'], a['vd'] = vw, vh, vd
+    a['W'], a['H'], a['D'] = int((r[3] - r[0]) / vw), int((r[4] - r[1]) / vh), int((r[5] - r[2]) / vd)
+    param['postprocess'].update({'anchor_args': a})
+    return param
+
+
+def save_yaml(data, save_name):
+    """yaml_utils.py:234-249."""
+    with open(save_name, 'w') as outfile:
+        yaml.dump(data, outfile, default_flow_style=False)
+
+
+_PARSERS = {"load_general_params": load_general_params, "load_point_pillar_params": load_point_pillar_params,
+            "load_second_params": load_second_params, "load_lift_splat_shoot_params": load_lift_splat_shoot_params}
 
 
 def load_yaml(file, opt=None):
     """Load a yaml file; `opt.model_dir` (if set) replaces `file` with <model_dir>/config.yaml; the
-    `yaml_parser` key selects the post-parser (only load_general_params is on the HEAL path)."""
+    `yaml_parser` key selects the post-parser (load_general_params on the HEAL path, the old-style model files' parsers;
+    voxel / bev / stage-1 parsers belong to detectors outside the scope and raise)."""
     if opt and getattr(opt, "model_dir", None):
         file = os.path.join(opt.model_dir, 'config.yaml')
     with open(file, 'r') as stream:
