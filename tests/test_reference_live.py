@@ -1,0 +1,107 @@
+"""Host mirrors against the LIVE reference functions on seeded random inputs (build container only: skipped where
+/root/reference is absent).  Complements the committed golden fixtures: every pure-host function of
+opencood/utils/{box_utils,common_utils,transformation_utils,camera_utils}.py that the mirror restates is called on both
+sides with the same arguments (numpy and torch variants) and must return equal values, dtypes and container types."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/opencood"), reason="reference tree not present")
+
+
+def _ref(mod):
+    from tests.golden import ref_import as R
+    return R.ref(mod)
+
+
+def _eq(a, b, tol=0.0):
+    assert type(a) is type(b), (type(a), type(b))
+    if isinstance(a, torch.Tensor):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        a, b = a.numpy(), b.numpy()
+    if isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        if tol:
+            np.testing.assert_allclose(a, b, rtol=0, atol=tol)
+        else:
+            assert np.array_equal(a, b, equal_nan=True)
+    elif isinstance(a, (tuple, list)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _eq(x, y, tol)
+    else:
+        assert a == b
+
+
+def _boxes(rng, n):
+    return np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(-3, 1, (n, 1)), rng.uniform(1.3, 2.0, (n, 1)),
+                           rng.uniform(1.4, 2.2, (n, 1)), rng.uniform(3.0, 6.0, (n, 1)), rng.uniform(-4, 4, (n, 1))],
+                          1).astype(np.float32)
+
+
+def test_box_utils_live():
+    from heal_amd.opencood.utils import box_utils as mine
+    theirs = _ref("opencood.utils.box_utils")
+    rng = np.random.default_rng(0)
+    b = _boxes(rng, 300)
+    for order in ("hwl", "lwh"):
+        _eq(mine.boxes_to_corners_3d(b, order), theirs.boxes_to_corners_3d(b, order))
+        _eq(mine.boxes_to_corners_3d(torch.from_numpy(b), order), theirs.boxes_to_corners_3d(torch.from_numpy(b), order))
+        _eq(mine.mask_boxes_outside_range_numpy(b, [-30, -30, -3, 30, 30, 1], order),
+            theirs.mask_boxes_outside_range_numpy(b, [-30, -30, -3, 30, 30, 1], order))
+    corners = theirs.boxes_to_corners_3d(b, "hwl")
+    tc = torch.from_numpy(corners)
+    pts = rng.standard_normal((50, 7, 5)).astype(np.float32)
+    ang = rng.uniform(-4, 4, 50).astype(np.float32)
+    _eq(mine.rotate_points_along_z(pts, ang), theirs.common_utils.rotate_points_along_z(pts, ang))
+    _eq(mine.box3d_to_2d(corners), theirs.box3d_to_2d(corners))
+    _eq(mine.corner2d_to_standup_box(corners[:, :4, :2]), theirs.corner2d_to_standup_box(corners[:, :4, :2]))
+    _eq(mine.corner_to_standup_box_torch(tc), theirs.corner_to_standup_box_torch(tc))
+    tfm = _ref("opencood.utils.transformation_utils").x1_to_x2([3, -2, 0.5, 1, 40, -2], [0, 1, 0, 0, -15, 0])
+    _eq(mine.project_box3d(corners, tfm.astype(np.float32)), theirs.project_box3d(corners, tfm.astype(np.float32)))
+    _eq(mine.project_box3d(tc, torch.from_numpy(tfm).float()), theirs.project_box3d(tc, torch.from_numpy(tfm).float()))
+    _eq(mine.get_mask_for_boxes_within_range_torch(tc, [-30, -30, -3, 30, 30, 1]),
+        theirs.get_mask_for_boxes_within_range_torch(tc, [-30, -30, -3, 30, 30, 1]))
+    _eq(mine.mask_boxes_outside_range_numpy(corners, [-30, -30, -3, 30, 30, 1], None, 5, True),
+        theirs.mask_boxes_outside_range_numpy(corners, [-30, -30, -3, 30, 30, 1], None, 5, True))
+    big = tc.clone()
+    big[::7] *= 3.0
+    _eq(mine.remove_large_pred_bbx(big), theirs.remove_large_pred_bbx(big))
+    _eq(mine.remove_bbx_abnormal_z(tc), theirs.remove_bbx_abnormal_z(tc))
+
+
+def test_common_transformation_camera_utils_live():
+    from heal_amd.opencood.utils import camera_utils as cam_mine
+    from heal_amd.opencood.utils import common_utils as com_mine
+    from heal_amd.opencood.utils import transformation_utils as tf_mine
+    com, tf, cam = _ref("opencood.utils.common_utils"), _ref("opencood.utils.transformation_utils"), \
+        _ref("opencood.utils.camera_utils")
+    rng = np.random.default_rng(1)
+    v = rng.uniform(-20, 20, 1000).astype(np.float32)
+    for off, per in ((0.5, 2 * np.pi), (0.0, np.pi), (1.0, 2 * np.pi)):
+        _eq(com_mine.limit_period(v, off, per), com.limit_period(v, off, per))
+        _eq(com_mine.limit_period(torch.from_numpy(v), off, per), com.limit_period(torch.from_numpy(v), off, per))
+    for x in (v, torch.from_numpy(v), 3.0):
+        a, b = com_mine.check_numpy_to_torch(x), com.check_numpy_to_torch(x)
+        _eq(a[0], b[0])
+        assert a[1] == b[1]
+    poses = np.concatenate([rng.uniform(-80, 80, (6, 3)), rng.uniform(-180, 180, (6, 3))], 1)
+    for p in poses:
+        _eq(tf_mine.x_to_world(p.tolist()), tf.x_to_world(p.tolist()))
+    _eq(tf_mine.x1_to_x2(poses[0].tolist(), poses[1].tolist()), tf.x1_to_x2(poses[0].tolist(), poses[1].tolist()))
+    base = {k: {"params": {"lidar_pose": poses[k].tolist()}} for k in range(4)}
+    for proj_first in (False, True):
+        _eq(tf_mine.get_pairwise_transformation(base, 5, proj_first), tf.get_pairwise_transformation(base, 5, proj_first))
+    pair = torch.from_numpy(tf.get_pairwise_transformation(base, 5, False))[None]
+    for H, W, ratio, down in ((204.8, 204.8, 1, 1), (102.4, 204.8, 0.4, 2)):
+        want = tf.normalize_pairwise_tfm(pair, H, W, ratio, down)
+        got = tf_mine.normalize_pairwise_tfm(pair.numpy(), H, W, ratio, down)
+        np.testing.assert_array_equal(np.asarray(got), want.numpy())
+    for bounds in (([-51.2, 51.2, 0.4], [-51.2, 51.2, 0.4], [-10, 10, 20.0]), ([-48, 48, 0.8], [-24, 24, 0.8], [-3, 1, 4.0])):
+        for a, b in zip(cam_mine.gen_dx_bx(*bounds), cam.gen_dx_bx(*bounds)):
+            np.testing.assert_array_equal(np.asarray(a, dtype=np.float64), b.double().numpy())
+    for mode in ("UD", "LID"):
+        np.testing.assert_array_equal(np.asarray(cam_mine.depth_discretization(2, 50, 48, mode)),
+                                      np.asarray(cam.depth_discretization(2, 50, 48, mode)))
