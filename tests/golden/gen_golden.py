@@ -25,7 +25,18 @@ SMALL_RANGE = [-25.6, -25.6, -3, 25.6, 25.6, 1]
 torch.set_num_threads(8)
 
 
+SEED_SHIFT = 0     # tests/test_reference_live.py re-runs the generators with other seeds ...
+CAPTURE = None     # ... and collects their outputs here instead of writing fixtures
+
+
+def _rng(seed):
+    return np.random.default_rng(seed + SEED_SHIFT)
+
+
 def save(name, **arrays):
+    if CAPTURE is not None:
+        CAPTURE[name] = {k: np.asarray(v) for k, v in arrays.items()}
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  " + ", ".join(
@@ -46,7 +57,7 @@ def small_lidar_inputs(seeds, lidar_range=SMALL_RANGE, voxel_size=(0.4, 0.4, 4),
     """Voxelised (oracle voxeliser) synthetic frames, collated like collate_batch_list."""
     vf, vc, vn = [], [], []
     for b, seed in enumerate(seeds):
-        pts = synth.lidar_frame(seed)
+        pts = synth.lidar_frame(seed + SEED_SHIFT)
         near = (np.abs(pts[:, 0]) < lidar_range[3] + 2) & (np.abs(pts[:, 1]) < lidar_range[4] + 2)
         pts = pts[near][:n_points]
         v, c, n = cref.voxelize(pts, lidar_range, voxel_size, max_points, 70000, batch_idx=b)
@@ -83,7 +94,7 @@ def gen_warp_fuse():
     tu = R.ref("opencood.utils.transformation_utils")
     tt = R.ref("opencood.models.sub_modules.torch_transformation_utils")
     pf = R.ref("opencood.models.fuse_modules.pyramid_fuse")
-    rng = np.random.default_rng(5)
+    rng = _rng(5)
     out = {}
     for tag, (n, C, H, W, dtype) in {"sq": (3, 8, 32, 32, np.float64), "rect": (2, 4, 24, 40, np.float64),
                                      "f32": (3, 8, 32, 32, np.float32)}.items():
@@ -123,7 +134,7 @@ def gen_decode():
     post = vp.VoxelPostprocessor(hy["postprocess"], train=False)
     anchors = post.generate_anchor_box()  # [64,64,2,7] f64
     H, W, A = anchors.shape[:3]
-    rng = np.random.default_rng(9)
+    rng = _rng(9)
     out = {"anchors": anchors, "gt_range": np.array(SMALL_RANGE)}
     for tag, tfm in {"id": np.eye(4, dtype=np.float32),
                      "tf": synth.x_to_world([3.0, -2.0, 0.1, 0.0, 25.0, 0.0]).astype(np.float32)}.items():
@@ -237,7 +248,7 @@ def gen_lss():
     ns.frustum = he.LiftSplatShoot.create_frustum(ns)
     D, fH, fW, _ = ns.frustum.shape
     B, N, C = 2, 4, 16
-    rng = np.random.default_rng(3)
+    rng = _rng(3)
     rig = synth.camera_rig(0, N, 48, 64)
     cam = {k: np.tile(v[None], (B,) + (1,) * v.ndim).astype(np.float32) for k, v in rig.items()}
     # a non-trivial post augmentation on agent 1
@@ -263,7 +274,7 @@ def gen_fusion_small():
     fio = R.ref("opencood.models.fuse_modules.fusion_in_one")
     tu = R.ref("opencood.utils.transformation_utils")
     hy = load_hypes("LiDAROnly/lidar_v2xvit.yaml")
-    rng = np.random.default_rng(13)
+    rng = _rng(13)
     n, C, H, W = 3, 256, 32, 32
     x = rng.standard_normal((n, C, H, W)).astype(np.float32)
     Hm = Wm = 51.2
@@ -374,7 +385,7 @@ def gen_label():
     hy = yu.load_general_params(hy)
     post = vp.VoxelPostprocessor(hy["postprocess"], train=True)
     anchors = post.generate_anchor_box()  # [64,64,2,7] f64
-    rng = np.random.default_rng(21)
+    rng = _rng(21)
     max_num = 24
     out = {"anchors": anchors, "pos_threshold": hy["postprocess"]["target_args"]["pos_threshold"],
            "neg_threshold": hy["postprocess"]["target_args"]["neg_threshold"]}
@@ -401,7 +412,7 @@ def gen_label():
 def gen_pose():
     """Pose algebra of opencood/utils/transformation_utils.py (x_to_world, x1_to_x2, get_pairwise_transformation)."""
     tu = R.ref("opencood.utils.transformation_utils")
-    rng = np.random.default_rng(31)
+    rng = _rng(31)
     poses = np.concatenate([rng.uniform(-80, 80, (4, 3)), rng.uniform(-180, 180, (4, 3))], 1)
     base = {k: {"params": {"lidar_pose": poses[k].tolist()}} for k in range(4)}
     save("pose", poses=poses, x_to_world=np.stack([tu.x_to_world(p.tolist()) for p in poses]),
@@ -420,7 +431,7 @@ def gen_gt():
     replace_ranges(hy, SMALL_RANGE)
     hy = yu.load_general_params(hy)
     post = vp.VoxelPostprocessor(hy["postprocess"], train=False)
-    rng = np.random.default_rng(41)
+    rng = _rng(41)
     max_num = 20
     out = {"order": np.array(hy["postprocess"]["order"]), "gt_range": np.array(hy["postprocess"]["gt_range"], np.float64)}
     data = {}
@@ -453,7 +464,7 @@ def gen_pcd():
     with points exactly on the range faces / the ego-box faces and with a NaN point."""
     pu = R.ref("opencood.utils.pcd_utils")
     tu = R.ref("opencood.utils.transformation_utils")
-    rng = np.random.default_rng(51)
+    rng = _rng(51)
     pts = synth.lidar_frame(77)[::14].copy()
     edge = np.array([[-25.6, 0, -1, .5], [25.6, 1, -1, .5], [3, -25.6, -1, .5], [3, 25.6, -1, .5], [5, 5, -3, .5],
                      [5, 5, 1, .5], [-1.95, 0, -1, .5], [2.95, 0.5, -1, .5], [1, -1.1, -1, .5], [1, 1.1, -1, .5],
@@ -488,7 +499,7 @@ def gen_pcdet_iou():
     compiled where it lies, oracle/Makefile.ref)."""
     from oracle import cref
     assert cref.build_ref() and cref.ref_lib() is not None
-    rng = np.random.default_rng(77)
+    rng = _rng(77)
     a, b = pcdet_boxes(rng, 160, 7.0), pcdet_boxes(rng, 120, 7.0)
     # hand-made edge cases: identical, half-shifted, touching, contained, 90 deg, far away, degenerate
     edge = np.array([[0, 0, 0, 4, 2, 1, 0], [0, 0, 0, 4, 2, 1, 0], [2, 0, 0, 4, 2, 1, 0], [4, 0, 0, 4, 2, 1, 0],
