@@ -64,6 +64,14 @@ def _common(lidar_range, max_cav):
             "nms_thresh": 0.15,
             "dir_args": copy.deepcopy(DIR_ARGS),
         },
+        # the loss block of the reference's *_pyramid.yaml files (training side)
+        "loss": {"core_method": "point_pillar_pyramid_loss", "args": {
+            "pos_cls_weight": 2.0,
+            "cls": {"type": "SigmoidFocalLoss", "alpha": 0.25, "gamma": 2.0, "weight": 1.0},
+            "reg": {"type": "WeightedSmoothL1Loss", "sigma": 3.0, "codewise": True, "weight": 2.0},
+            "dir": {"type": "WeightedSoftmaxClassificationLoss", "weight": 0.2, "args": copy.deepcopy(DIR_ARGS)},
+            "depth": {"weight": 1.0},
+            "pyramid": {"relative_downsample": [1, 2, 4], "weight": [0.4, 0.2, 0.1]}}},
     }
 
 

@@ -1,0 +1,161 @@
+"""Detection losses of the anchor heads (training side; reference: opencood/loss/point_pillar_loss.py:14-244).
+
+Host-side torch code in the reference and here (no native op on either side): sigmoid focal loss on the anchor
+scores, smooth-L1 with the sin-difference yaw encoding on the box deltas, softmax cross-entropy on the direction bins.
+Same constructor `args` (the yaml `loss.args` subtree), `forward(output_dict, target_dict, suffix="")`, `loss_dict`
+bookkeeping and `logging` signature.  The optional IoU branch (:99-117) is kept with the reference's key spelling."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from heal_amd.opencood.utils.common_utils import limit_period
+
+
+def one_hot_f(tensor, num_bins, dim=-1, on_value=1.0, dtype=torch.float32):
+    """point_pillar_loss.py:206-209."""
+    out = torch.zeros(*list(tensor.shape), num_bins, dtype=dtype, device=tensor.device)
+    out.scatter_(dim, tensor.unsqueeze(dim).long(), on_value)
+    return out
+
+
+def softmax_cross_entropy_with_logits(logits, labels):
+    """point_pillar_loss.py:211-217: class axis last on both; labels one-hot."""
+    order = list(range(logits.dim()))
+    logits = logits.permute(0, order[-1], *order[1:-1])
+    return torch.nn.functional.cross_entropy(logits, labels.max(dim=-1)[1], reduction="none")
+
+
+def weighted_smooth_l1_loss(preds, targets, sigma=3.0, weights=None):
+    """point_pillar_loss.py:219-227: quadratic below 1/sigma^2, linear above."""
+    a = torch.abs(preds - targets)
+    small = torch.le(a, 1 / (sigma ** 2)).type_as(a)
+    loss = small * 0.5 * torch.pow(a * sigma, 2) + (a - 0.5 / (sigma ** 2)) * (1.0 - small)
+    if weights is not None:
+        loss *= weights
+    return loss
+
+
+def sigmoid_focal_loss(preds, targets, weights=None, **kwargs):
+    """point_pillar_loss.py:230-244: numerically stable sigmoid cross-entropy x (1 - p_t)^gamma x alpha_t."""
+    assert 'gamma' in kwargs and 'alpha' in kwargs
+    ce = torch.clamp(preds, min=0) - preds * targets.type_as(preds)
+    ce += torch.log1p(torch.exp(-torch.abs(preds)))
+    p = torch.sigmoid(preds)
+    p_t = (targets * p) + ((1 - targets) * (1 - p))
+    loss = torch.pow(1.0 - p_t, kwargs['gamma']) * (targets * kwargs['alpha'] + (1 - targets) * (1 - kwargs['alpha'])) * ce
+    if weights is not None:
+        loss *= weights
+    return loss
+
+
+class PointPillarLoss(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.pos_cls_weight = args['pos_cls_weight']
+        self.cls = args['cls']
+        self.reg = args['reg']
+        self.dir = args.get('dir')
+        self.iou = args.get('iou')
+        if self.iou is not None:
+            from heal_amd.opencood.pcdet_utils.iou3d_nms.iou3d_nms_utils import aligned_boxes_iou3d_gpu
+            self.iou_loss_func = aligned_boxes_iou3d_gpu
+        self.loss_dict = {}
+
+    @staticmethod
+    def _rows(x, batch_size, width):
+        """[N, A*width, H, W] head map -> [N, H*W*A, width] in anchor order."""
+        return x.permute(0, 2, 3, 1).contiguous().view(batch_size, -1, width)
+
+    def forward(self, output_dict, target_dict, suffix=""):
+        if 'record_len' in output_dict:
+            batch_size = int(output_dict['record_len'].sum())
+        elif 'batch_size' in output_dict:
+            batch_size = output_dict['batch_size']
+        else:
+            batch_size = target_dict['pos_equal_one'].shape[0]
+        cls_labls = target_dict['pos_equal_one'].view(batch_size, -1, 1)
+        positives = cls_labls > 0
+        negatives = target_dict['neg_equal_one'].view(batch_size, -1, 1) > 0
+        pos_normalizer = positives.sum(1, keepdim=True).float()
+        for old, new in (('psm', 'cls_preds'), ('rm', 'reg_preds'), ('dm', 'dir_preds')):  # old-style head names
+            if f'{old}{suffix}' in output_dict:
+                output_dict[f'{new}{suffix}'] = output_dict[f'{old}{suffix}']
+        total_loss = 0
+
+        cls_weights = positives * self.pos_cls_weight + negatives * 1.0
+        cls_weights /= torch.clamp(pos_normalizer, min=1.0)
+        cls_loss = sigmoid_focal_loss(self._rows(output_dict[f'cls_preds{suffix}'], batch_size, 1), cls_labls,
+                                      weights=cls_weights, **self.cls)
+        cls_loss = cls_loss.sum() * self.cls['weight'] / batch_size
+
+        reg_weights = positives / torch.clamp(pos_normalizer, min=1.0)
+        reg_preds, reg_targets = self.add_sin_difference(self._rows(output_dict[f'reg_preds{suffix}'], batch_size, 7),
+                                                         target_dict['targets'].view(batch_size, -1, 7))
+        reg_loss = weighted_smooth_l1_loss(reg_preds, reg_targets, weights=reg_weights, sigma=self.reg['sigma'])
+        reg_loss = reg_loss.sum() * self.reg['weight'] / batch_size
+
+        if self.dir:
+            dir_targets = self.get_direction_target(target_dict['targets'].view(batch_size, -1, 7))
+            dir_logits = self._rows(output_dict[f"dir_preds{suffix}"], batch_size, 2)
+            dir_loss = softmax_cross_entropy_with_logits(dir_logits.view(-1, self.anchor_num),
+                                                         dir_targets.view(-1, self.anchor_num))
+            dir_loss = dir_loss.flatten() * reg_weights.flatten()
+            dir_loss = dir_loss.sum() * self.dir['weight'] / batch_size
+            total_loss += dir_loss
+            self.loss_dict.update({'dir_loss': dir_loss.item()})
+
+        if self.iou:
+            from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+            iou_preds = output_dict["iou_preds{suffix}"].permute(0, 2, 3, 1).contiguous()  # (sic) literal key, :100
+            pos = reg_weights.squeeze(dim=-1) > 0
+            boxes_pred = VoxelPostprocessor.delta_to_boxes3d(
+                output_dict[f'reg_preds{suffix}'].permute(0, 2, 3, 1).contiguous().detach(), output_dict['anchor_box'])[pos]
+            boxes_tgt = VoxelPostprocessor.delta_to_boxes3d(target_dict['targets'], output_dict['anchor_box'])[pos]
+            hwl_to_lwh = [0, 1, 2, 5, 4, 3, 6]
+            tgt = self.iou_loss_func(boxes_pred.float()[:, hwl_to_lwh], boxes_tgt.float()[:, hwl_to_lwh]).detach().squeeze()
+            iou_loss = weighted_smooth_l1_loss(iou_preds.view(batch_size, -1)[pos], 2 * tgt.view(-1) - 1,
+                                               weights=reg_weights[pos].view(-1), sigma=self.iou['sigma'])
+            iou_loss = iou_loss.sum() * self.iou['weight'] / batch_size
+            total_loss += iou_loss
+            self.loss_dict.update({'iou_loss': iou_loss.item()})
+
+        total_loss += reg_loss + cls_loss
+        self.loss_dict.update({'total_loss': total_loss.item(), 'reg_loss': reg_loss.item(), 'cls_loss': cls_loss.item()})
+        return total_loss
+
+    @staticmethod
+    def add_sin_difference(boxes1, boxes2, dim=6):
+        """point_pillar_loss.py:131-142: sin(a - b) = sin a cos b - cos a sin b, one factor on each side."""
+        assert dim != -1
+        a, b = boxes1[..., dim:dim + 1], boxes2[..., dim:dim + 1]
+        enc1, enc2 = torch.sin(a) * torch.cos(b), torch.cos(a) * torch.sin(b)
+        return (torch.cat([boxes1[..., :dim], enc1, boxes1[..., dim + 1:]], dim=-1),
+                torch.cat([boxes2[..., :dim], enc2, boxes2[..., dim + 1:]], dim=-1))
+
+    def get_direction_target(self, reg_targets):
+        """point_pillar_loss.py:144-170: one-hot direction bin of (target yaw residual + anchor yaw)."""
+        num_bins = self.dir['args']['num_bins']
+        dir_offset = self.dir['args']['dir_offset']
+        anchor_yaw = np.deg2rad(np.array(self.dir['args']['anchor_yaw']))
+        self.anchor_yaw_map = torch.from_numpy(anchor_yaw).view(1, -1, 1)
+        self.anchor_num = self.anchor_yaw_map.shape[1]
+        n = reg_targets.shape[1]
+        anchor_map = self.anchor_yaw_map.repeat(1, n // self.anchor_num, 1).to(reg_targets.device)
+        rot_gt = reg_targets[..., -1] + anchor_map[..., -1]
+        offset_rot = limit_period(rot_gt - dir_offset, 0, 2 * np.pi)
+        bins = torch.clamp(torch.floor(offset_rot / (2 * np.pi / num_bins)).long(), min=0, max=num_bins - 1)
+        return one_hot_f(bins, num_bins)
+
+    _LOG_FIELDS = (("Loss", "total_loss", None), ("Conf Loss", "cls_loss", "Confidence_loss"),
+                   ("Loc Loss", "reg_loss", "Regression_loss"), ("Dir Loss", "dir_loss", "Dir_loss"),
+                   ("IoU Loss", "iou_loss", "Iou_loss"))
+
+    def logging(self, epoch, batch_id, batch_len, writer=None, suffix=""):
+        """point_pillar_loss.py:174-204 (and the subclasses' extra fields via _LOG_FIELDS)."""
+        vals = [(label, self.loss_dict.get(key, 0), tag) for label, key, tag in self._LOG_FIELDS]
+        print("[epoch %d][%d/%d]%s || " % (epoch, batch_id + 1, batch_len, suffix)
+              + " || ".join("%s: %.4f" % (label, v) for label, v, _ in vals))
+        if writer is not None:
+            for _, v, tag in vals:
+                if tag is not None:
+                    writer.add_scalar(tag + suffix, v, epoch * batch_len + batch_id)

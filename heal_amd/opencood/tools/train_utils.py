@@ -13,6 +13,18 @@ def create_model(hypes):
     raise ImportError(f"no class matching '{target}' in heal_amd.opencood.models.{name}")
 
 
+def create_loss(hypes):
+    """train_utils.py:177-210: the class in heal_amd.opencood.loss.<core_method> whose lower-cased name is the
+    core_method without underscores, constructed with hypes['loss']['args']."""
+    name = hypes['loss']['core_method']
+    lib = importlib.import_module("heal_amd.opencood.loss." + name)
+    target = name.replace('_', '').lower()
+    for cname, cls in lib.__dict__.items():
+        if cname.lower() == target:
+            return cls(hypes['loss']['args'])
+    raise ImportError(f"no class matching '{target}' in heal_amd.opencood.loss.{name}")
+
+
 def to_device(inputs, device):
     if isinstance(inputs, list):
         return [to_device(x, device) for x in inputs]

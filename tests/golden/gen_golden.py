@@ -480,7 +480,32 @@ def gen_pcd():
          stacked=pu.projected_lidar_stack([both[:5], ego[:3]]))
 
 
-GENS_EXTRA = {"label": gen_label, "pose": gen_pose, "gt": gen_gt, "pcd": gen_pcd}
+def gen_loss():
+    """PointPillarPyramidLoss of the reference (loss block of LiDAROnly/lidar_pyramid.yaml) on the seeded inputs of
+    tests/test_reference_live.py::_loss_inputs: loss value and gradients per (seed, pyramid mode, suffix)."""
+    from tests.test_reference_live import _leafs, _loss_inputs
+    yu = R.ref("opencood.hypes_yaml.yaml_utils")
+    tu = R.ref("opencood.tools.train_utils")
+    hy = load_hypes("LiDAROnly/lidar_pyramid.yaml")
+    out = {}
+    for fg in (0, 1):
+        hy["loss"]["args"]["depth"]["use_fg_mask"] = bool(fg)
+        crit = tu.create_loss(hy)
+        for seed, mode, suffix in ((0, "collab", ""), (1, "collab", "_single"), (2, "single", "")):
+            o, t = _loss_inputs(seed + SEED_SHIFT)
+            o["pyramid"] = mode
+            leafs = _leafs(o)
+            loss = crit(o, t, suffix)
+            loss.backward()
+            tag = f"fg{fg}_s{seed}"
+            out[f"{tag}_loss"] = loss.detach().numpy()
+            for k, leaf in enumerate(leafs):
+                if leaf.grad is not None:
+                    out[f"{tag}_grad{k}"] = leaf.grad.numpy()
+    save("loss", **out)
+
+
+GENS_EXTRA = {"label": gen_label, "pose": gen_pose, "gt": gen_gt, "pcd": gen_pcd, "loss": gen_loss}
 
 
 def pcdet_boxes(rng, n, spread):

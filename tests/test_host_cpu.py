@@ -123,6 +123,32 @@ def test_pcd_utils_host_mirror_matches_reference(golden):
     assert pcd_utils.shuffle_points(both).shape == both.shape
 
 
+def test_pyramid_loss_matches_reference_golden(golden):
+    """SURVEY 8f-2 (training side): PointPillarPyramidLoss value and gradients against the imported reference's
+    (tests/golden/loss.npz), fused heads / per-agent occupancy pass / single-agent model, with and without the depth
+    foreground mask."""
+    from heal_amd import configs
+    from heal_amd.opencood.tools.train_utils import create_loss
+    from tests.test_reference_live import _leafs, _loss_inputs
+    g = golden("loss")
+    for fg in (0, 1):
+        hy = configs.lidar_pyramid()
+        hy["loss"]["args"]["depth"]["use_fg_mask"] = bool(fg)
+        crit = create_loss(hy)
+        for seed, mode, suffix in ((0, "collab", ""), (1, "collab", "_single"), (2, "single", "")):
+            out, tgt = _loss_inputs(seed)
+            out["pyramid"] = mode
+            leafs = _leafs(out)
+            loss = crit(out, tgt, suffix)
+            loss.backward()
+            tag = f"fg{fg}_s{seed}"
+            np.testing.assert_allclose(loss.detach().numpy(), g[f"{tag}_loss"], rtol=1e-6)
+            for k, leaf in enumerate(leafs):
+                assert (leaf.grad is not None) == (f"{tag}_grad{k}" in g.files), (tag, k)
+                if leaf.grad is not None:
+                    np.testing.assert_allclose(leaf.grad.numpy(), g[f"{tag}_grad{k}"], rtol=1e-5, atol=1e-9)
+
+
 def test_yaml_loader_round_trip(tmp_path):
     from heal_amd import configs
     from heal_amd.opencood.hypes_yaml import yaml_utils

@@ -141,3 +141,89 @@ def test_oracle_against_live_reference_with_other_seeds(shift, with_decode, monk
         checks.test_post_process_matches_reference(golden)
     checks.test_lss_geometry_and_pool_match_reference(golden)
     checks.test_label_path_oracle_bit_exact_vs_reference_golden(golden)
+
+
+def _loss_inputs(seed, n=2, H=16, W=24, levels=(1, 2, 4), with_depth=True):
+    g = torch.Generator().manual_seed(seed)
+    out = {"cls_preds": torch.randn((n, 2, H, W), generator=g), "reg_preds": torch.randn((n, 14, H, W), generator=g) * 0.3,
+           "dir_preds": torch.randn((n, 4, H, W), generator=g),
+           "occ_single_list": [torch.randn((n, 1, H // k, W // k), generator=g) for k in levels]}
+    if with_depth:
+        out["depth_items_m2"] = (torch.randn((n * 4, 12, 6, 8), generator=g),
+                                 torch.randint(0, 12, (n * 4, 6, 8), generator=g),
+                                 (torch.rand((n * 4, 6, 8), generator=g) > 0.6).float())
+    pos = (torch.rand((n, H, W, 2), generator=g) > 0.93).float()
+    neg = ((torch.rand((n, H, W, 2), generator=g) > 0.2).float()) * (1 - pos)
+    tgt = torch.randn((n, H, W, 14), generator=g) * 0.4
+    return out, {"pos_equal_one": pos, "neg_equal_one": neg, "targets": tgt}
+
+
+def _leafs(out):
+    ts = [out["cls_preds"], out["reg_preds"], out["dir_preds"]] + list(out["occ_single_list"])
+    if "depth_items_m2" in out:
+        ts.append(out["depth_items_m2"][0])
+    for t in ts:
+        t.requires_grad_(True)
+    return ts
+
+
+@pytest.mark.parametrize("use_fg_mask", [False, True])
+def test_losses_match_live_reference_values_and_gradients(use_fg_mask):
+    """opencood/loss/point_pillar{,_depth,_pyramid}_loss.py: value, loss_dict and the gradient w.r.t. every head /
+    occupancy / depth input, for the fused heads (suffix ""), the per-agent occupancy pass ("_single" on a 'collab'
+    output) and the 'single' pyramid model, on CPU with the loss block of the reference's own lidar_pyramid.yaml."""
+    from heal_amd.opencood.hypes_yaml import yaml_utils
+    from heal_amd.opencood.tools.train_utils import create_loss
+    hypes = yaml_utils.load_yaml("/root/reference/opencood/hypes_yaml/opv2v/LiDAROnly/lidar_pyramid.yaml")
+    hypes["loss"]["args"]["depth"]["use_fg_mask"] = use_fg_mask
+    mine = create_loss(hypes)
+    theirs = _ref("opencood.tools.train_utils").create_loss(hypes)
+    assert type(mine).__name__ == type(theirs).__name__ == "PointPillarPyramidLoss"
+    for seed, mode, suffix in ((0, "collab", ""), (1, "collab", "_single"), (2, "single", "")):
+        grads = []
+        for crit in (mine, theirs):
+            out, tgt = _loss_inputs(seed)
+            out["pyramid"] = mode
+            leafs = _leafs(out)
+            loss = crit(out, tgt, suffix)
+            loss.backward()
+            grads.append((loss.detach(), [None if t.grad is None else t.grad.clone() for t in leafs], dict(crit.loss_dict)))
+        (la, ga, da), (lb, gb, db) = grads
+        assert torch.equal(la, lb), (mode, suffix, la, lb)
+        assert set(da) == set(db)
+        for k in da:
+            assert float(da[k]) == float(db[k]), k
+        for x, y in zip(ga, gb):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y)
+
+
+def test_loss_components_match_live_reference():
+    mine, theirs = __import__("heal_amd.opencood.loss.point_pillar_loss", fromlist=["x"]), \
+        _ref("opencood.loss.point_pillar_loss")
+    g = torch.Generator().manual_seed(5)
+    p, t = torch.randn((3, 500, 7), generator=g), torch.randn((3, 500, 7), generator=g)
+    w = torch.rand((3, 500, 1), generator=g)
+    _eq(mine.weighted_smooth_l1_loss(p, t, 3.0, w), theirs.weighted_smooth_l1_loss(p, t, 3.0, w))
+    lab = (torch.rand((3, 500, 1), generator=g) > 0.9).float()
+    _eq(mine.sigmoid_focal_loss(p[..., :1], lab, weights=w, alpha=0.25, gamma=2.0),
+        theirs.sigmoid_focal_loss(p[..., :1], lab, weights=w, alpha=0.25, gamma=2.0))
+    _eq(mine.PointPillarLoss.add_sin_difference(p, t), theirs.PointPillarLoss.add_sin_difference(p, t))
+    bins = torch.randint(0, 2, (3, 500), generator=g)
+    _eq(mine.one_hot_f(bins, 2), theirs.one_hot_f(bins, 2))
+    _eq(mine.softmax_cross_entropy_with_logits(p[..., :2].reshape(-1, 2), mine.one_hot_f(bins, 2).view(-1, 2)),
+        theirs.softmax_cross_entropy_with_logits(p[..., :2].reshape(-1, 2), theirs.one_hot_f(bins, 2).view(-1, 2)))
+    dmine, dtheirs = __import__("heal_amd.opencood.loss.point_pillar_depth_loss", fromlist=["x"]), \
+        _ref("opencood.loss.point_pillar_depth_loss")
+    logit, idx = torch.randn((4, 12, 6, 8), generator=g), torch.randint(0, 12, (4, 6, 8), generator=g)
+    for red in ("none", "mean", "sum"):
+        _eq(dmine.FocalLoss(0.25, 2.0, red)(logit, idx), dtheirs.FocalLoss(0.25, 2.0, red)(logit, idx))
+    # smooth_target: the reference pins its kernel to "cuda" at construction (:131), so the known answer is computed here
+    sm = dmine.FocalLoss(0.25, 2.0, "none", smooth_target=True)(logit, idx)
+    oh = torch.nn.functional.one_hot(idx, 12).float()
+    smooth = 0.9 * oh
+    smooth[..., 1:] += 0.2 * oh[..., :-1]
+    smooth[..., :-1] += 0.2 * oh[..., 1:]
+    focal = -0.25 * (1 - logit.softmax(1)) ** 2 * logit.log_softmax(1)
+    np.testing.assert_allclose(sm.numpy(), (smooth.permute(0, 3, 1, 2) * focal).sum(1).numpy(), rtol=1e-5, atol=1e-6)
