@@ -227,3 +227,50 @@ def test_loss_components_match_live_reference():
     smooth[..., :-1] += 0.2 * oh[..., 1:]
     focal = -0.25 * (1 - logit.softmax(1)) ** 2 * logit.log_softmax(1)
     np.testing.assert_allclose(sm.numpy(), (smooth.permute(0, 3, 1, 2) * focal).sum(1).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_optimizer_scheduler_helpers_match_live_reference(tmp_path, capsys):
+    """tools/train_utils.py: load_saved_model (best-val file, last-epoch file, empty directory), setup_optimizer and
+    setup_lr_schedular with the optimizer / scheduler blocks of the reference's own lidar_pyramid.yaml."""
+    import warnings
+    from heal_amd.opencood.hypes_yaml import yaml_utils
+    from heal_amd.opencood.tools import train_utils as mine
+    theirs = _ref("opencood.tools.train_utils")
+    hypes = yaml_utils.load_yaml("/root/reference/opencood/hypes_yaml/opv2v/LiDAROnly/lidar_pyramid.yaml")
+
+    def net(seed):
+        torch.manual_seed(seed)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
+    src = net(1)
+    d_last, d_best, d_empty = tmp_path / "last", tmp_path / "best", tmp_path / "empty"
+    for d in (d_last, d_best, d_empty):
+        d.mkdir()
+    partial = {k: v for k, v in src.state_dict().items() if not k.startswith("2.")}
+    partial["extra.weight"] = torch.zeros(1)
+    torch.save(net(7).state_dict(), d_last / "net_epoch3.pth")
+    torch.save(partial, d_last / "net_epoch12.pth")
+    torch.save(src.state_dict(), d_best / "net_epoch_bestval_at23.pth")
+    torch.save(net(9).state_dict(), d_best / "net_epoch30.pth")
+    for d in (d_last, d_best, d_empty):
+        a, b = net(100), net(100)
+        ea, _ = mine.load_saved_model(str(d), a)
+        out_mine = capsys.readouterr().out
+        eb, _ = theirs.load_saved_model(str(d), b)
+        out_theirs = capsys.readouterr().out
+        assert ea == eb == {"last": 12, "best": 23, "empty": 0}[d.name]
+        for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(x, y), (d.name, k)
+        assert out_mine.splitlines()[0] == out_theirs.splitlines()[0] if out_theirs else not out_mine
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for init_epoch in (None, 0, 17):
+            m1, m2 = net(3), net(3)
+            o1, o2 = mine.setup_optimizer(hypes, m1), theirs.setup_optimizer(hypes, m2)
+            assert type(o1) is type(o2) and o1.defaults == o2.defaults
+            s1, s2 = mine.setup_lr_schedular(hypes, o1, init_epoch), theirs.setup_lr_schedular(hypes, o2, init_epoch)
+            assert type(s1) is type(s2) and s1.get_last_lr() == s2.get_last_lr() and s1.last_epoch == s2.last_epoch
+        for core in ("step", "exponential"):
+            h = {"lr_scheduler": {"core_method": core, "step_size": 4, "gamma": 0.5}, "optimizer": hypes["optimizer"]}
+            s1 = mine.setup_lr_schedular(h, mine.setup_optimizer(h, net(3)), 9)
+            s2 = theirs.setup_lr_schedular(h, theirs.setup_optimizer(h, net(3)), 9)
+            assert type(s1) is type(s2) and s1.get_last_lr() == s2.get_last_lr()
