@@ -85,7 +85,9 @@ class _Polygon:
         return _Area(self._parts(other)[1])
 
 
-def install():
+def install(stub_opencood_packages=True):
+    """stub_opencood_packages=False: third-party stubs only; the reference's own package __init__ files then run (used by
+    the overlay test, where heal_amd's modules stand in for the ones that need spconv / the CUDA extensions)."""
     if REF not in sys.path:
         sys.path.insert(0, REF)
     if not os.path.isdir(REF):
@@ -111,8 +113,8 @@ def install():
           SparseInverseConv3d=object, SparseConvTensor=object)
     # package __init__ files that drag in unrelated detectors / visualisation: register the
     # packages with their real __path__ but without executing __init__.py
-    for pkg in ("opencood.data_utils.post_processor", "opencood.data_utils.pre_processor",
-                "opencood.visualization"):
+    for pkg in (("opencood.data_utils.post_processor", "opencood.data_utils.pre_processor", "opencood.visualization")
+                if stub_opencood_packages else ("opencood.visualization",)):
         m = _stub(pkg)
         m.__path__ = [os.path.join(REF, *pkg.split("."))]
     _stub("opencood.visualization.vis_utils")
