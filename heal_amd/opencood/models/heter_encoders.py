@@ -44,15 +44,15 @@ class PointPillar(nn.Module):
             self._fold_key = key
         return self._fold
 
-    def encode_points(self, point_list):
+    def encode_points(self, point_list, max_points=None, max_voxels=None):
         """Raw device point clouds -> canvas with NO host round trip: K1 per agent into collated buffers (the running
         row offset stays on the device), then ONE K2 launch over all agents of the modality -- the reference's collated
         PillarVFE + PointPillarScatter call (heter_encoders.py:46-49), 3x67 MB written by one streaming kernel."""
         scale, shift = self._bn()
         weight = self.pillar_vfe.pfn_layers[0].linear.weight.detach()
         ny, nx = self.scatter.ny, self.scatter.nx
-        v, c, n, offsets = ops.voxelize_collated(point_list, self.lidar_range, self.voxel_size, self.max_points,
-                                                 self.max_voxels)
+        v, c, n, offsets = ops.voxelize_collated(point_list, self.lidar_range, self.voxel_size,
+                                                 int(max_points or self.max_points), int(max_voxels or self.max_voxels))
         k = len(point_list)
         return ops.pfn_scatter(v, c, n, weight, scale, shift, self.voxel_size, self.lidar_range, k, ny, nx,
                                n_voxels_dev=offsets[k:k + 1])
@@ -61,8 +61,8 @@ class PointPillar(nn.Module):
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         inp = data_dict[f"inputs_{modality_name}"]
-        if "points" in inp:
-            return self.encode_points(inp["points"])
+        if "points" in inp:  # the caps travel with the clouds when they come from SpVoxelPreprocessor's deferred mode
+            return self.encode_points(inp["points"], inp.get("max_points_per_voxel"), inp.get("max_voxels"))
         voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
         # point_pillar_scatter.py:45 reads the batch size back from the device the same way
         n_agents = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
@@ -104,8 +104,9 @@ class SECOND(nn.Module):
         if "points" in inp:
             # K1 per agent into collated buffers, the voxel count stays on the device: the whole encoder runs without
             # a host round trip (sparse layers take capacity + device count)
-            voxels, coords, num, offsets = ops.voxelize_collated(inp["points"], self.lidar_range, self.voxel_size,
-                                                                 self.max_points, self.max_voxels)
+            voxels, coords, num, offsets = ops.voxelize_collated(
+                inp["points"], self.lidar_range, self.voxel_size, int(inp.get("max_points_per_voxel") or self.max_points),
+                int(inp.get("max_voxels") or self.max_voxels))
             batch_size = len(inp["points"])
             n_dev = offsets[batch_size:batch_size + 1]
         else:

@@ -149,6 +149,42 @@ def test_pyramid_loss_matches_reference_golden(golden):
                     np.testing.assert_allclose(leaf.grad.numpy(), g[f"{tag}_grad{k}"], rtol=1e-5, atol=1e-9)
 
 
+def test_preprocessor_deferred_mode_needs_no_gpu_and_survives_the_dataset_merges(monkeypatch):
+    """SpVoxelPreprocessor with `defer_to_device`: preprocess() runs in forked DataLoader workers, so it must not touch the
+    GPU; what it returns has to pass through the datasets' merge_features_to_dict (values gathered into lists, twice) and
+    collate_batch into the encoder's device-points input."""
+    from collections import OrderedDict
+    from heal_amd import ops
+    from heal_amd.opencood.data_utils.pre_processor.sp_voxel_preprocessor import SpVoxelPreprocessor
+    monkeypatch.setattr(ops, "voxelize", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    params = {"cav_lidar_range": [-102.4, -102.4, -3, 102.4, 102.4, 1],
+              "args": {"voxel_size": [0.4, 0.4, 4], "max_points_per_voxel": 32, "max_voxel_train": 32000,
+                       "max_voxel_test": 70000, "defer_to_device": True}}
+    pre = SpVoxelPreprocessor(params, train=False)
+    rng = np.random.default_rng(0)
+    clouds = [rng.standard_normal((n, c)) for n, c in ((100, 4), (50, 5), (7, 4))]
+    per_cav = [pre.preprocess(c) for c in clouds]
+    assert all(d["points"].dtype == np.float32 and d["points"].shape[1] == 4 for d in per_cav)
+
+    def merge(dicts):  # common_utils.merge_features_to_dict (:48-92) without the image branches
+        out = OrderedDict()
+        for d in dicts:
+            for k, v in d.items():
+                out.setdefault(k, [])
+                out[k] += v if isinstance(v, list) else [v]
+        return out
+    sample0, sample1 = merge(per_cav[:2]), merge(per_cav[2:])          # per scene, then across the batch
+    batch = pre.collate_batch(merge([sample0, sample1]))
+    assert [tuple(t.shape) for t in batch["points"]] == [(100, 4), (50, 4), (7, 4)]
+    assert batch["max_points_per_voxel"] == 32 and batch["max_voxels"] == 70000
+    np.testing.assert_array_equal(batch["points"][1].numpy(), clouds[1][:, :4].astype(np.float32))
+    assert len(pre.collate_batch(per_cav)["points"]) == 3               # list form (late fusion datasets)
+    assert SpVoxelPreprocessor(params, train=True).preprocess(clouds[0])["max_voxels"] == 32000
+    monkeypatch.setenv("HEAL_DEFER_VOXELIZE", "1")
+    params["args"].pop("defer_to_device")
+    assert "points" in SpVoxelPreprocessor(params, train=False).preprocess(clouds[0])
+
+
 def test_yaml_loader_round_trip(tmp_path):
     from heal_amd import configs
     from heal_amd.opencood.hypes_yaml import yaml_utils
