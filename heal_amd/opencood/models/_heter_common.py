@@ -1,6 +1,7 @@
 """Shared construction logic of the heterogeneous models (reference: the per-modality loops at
 heter_pyramid_collab.py:35-77, heter_pyramid_single.py:30-63, heter_model_late.py:26-69)."""
 import importlib
+from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F
@@ -17,6 +18,49 @@ def find_encoder(core_method):
         if name.lower() == target:
             return cls
     raise KeyError(f"encoder '{core_method}' not found in heter_encoders")
+
+
+def modality_stems(model, args, make_backbone):
+    """The per-modality part all heterogeneous models share: `encoder_mX`, `depth_supervision_mX`, `backbone_mX` and, for
+    camera modalities, the crop ratios that bring the camera BEV grid to the LiDAR range.  A generator: after each
+    modality's stem the caller registers its own per-modality modules (aligner, shrinker, heads ...), which keeps the
+    registration order -- and therefore parameter order -- of the reference's loops."""
+    model.modality_name_list = modality_names(args)
+    model.cav_range = args["lidar_range"]
+    model.sensor_type_dict = OrderedDict()
+    for m in model.modality_name_list:
+        setting = args[m]
+        model.sensor_type_dict[m] = setting["sensor_type"]
+        setattr(model, f"encoder_{m}", find_encoder(setting["core_method"])(setting["encoder_args"]))
+        setattr(model, f"depth_supervision_{m}", bool(setting["encoder_args"].get("depth_supervision", False)))
+        setattr(model, f"backbone_{m}", make_backbone(setting))
+        if setting["sensor_type"] == "camera":
+            grid = setting["camera_mask_args"]["grid_conf"]
+            setattr(model, f"crop_ratio_W_{m}", model.cav_range[3] / grid["xbound"][1])
+            setattr(model, f"crop_ratio_H_{m}", model.cav_range[4] / grid["ybound"][1])
+        yield m, setting
+
+
+def crop_camera_feature(model, m, feature):
+    """Camera BEV maps cover the camera grid; keep the centre that corresponds to the LiDAR range (no-op for LiDAR)."""
+    if model.sensor_type_dict[m] != "camera":
+        return feature
+    H, W = feature.shape[-2:]
+    return center_crop(feature, int(H * getattr(model, f"crop_ratio_H_{m}")), int(W * getattr(model, f"crop_ratio_W_{m}")))
+
+
+def wants_depth_items(model, m):
+    """True for a camera modality configured with depth supervision: the model output then carries the encoder's
+    `depth_items` (depth_logit, depth_gt_indices) under `depth_items_mX`."""
+    return model.sensor_type_dict[m] == "camera" and bool(getattr(model, f"depth_supervision_{m}"))
+
+
+def anchor_heads(in_channels, args):
+    """cls / reg / dir 1x1 heads with the reference's channel counts."""
+    import torch.nn as nn
+    a = args["anchor_number"]
+    return (nn.Conv2d(in_channels, a, kernel_size=1), nn.Conv2d(in_channels, 7 * a, kernel_size=1),
+            nn.Conv2d(in_channels, args["dir_args"]["num_bins"] * a, kernel_size=1))
 
 
 def center_crop(x, target_h, target_w):

@@ -70,3 +70,16 @@ class V2XViTFusion(_WarpThenFuse):
     def fuse_warped(self, ego):
         fused = self.fusion_net(ego.permute(0, 2, 3, 1).contiguous())       # [n,H,W,C] -> [H,W,C]; the 3 prior channels are zero
         return fused.permute(2, 0, 1)
+
+
+def build_fusion(args):
+    """The single-scale fusion operator a model YAML names (`fusion_method`: max | att | v2xvit; the other methods of
+    fusion_in_one.py belong to papers outside the hot-path scope)."""
+    method = args["fusion_method"]
+    if method == "max":
+        return MaxFusion()
+    if method == "att":
+        return AttFusion(args["att"]["feat_dim"])
+    if method == "v2xvit":
+        return V2XViTFusion(args["v2xvit"])
+    raise NotImplementedError(f"fusion_method '{method}' is outside the hot-path scope (SURVEY 2, row 2)")

@@ -1,13 +1,14 @@
 """HeterModelBaseline -- single-scale heterogeneous collaboration with a pluggable fusion operator
 (reference: opencood/models/heter_model_baseline.py:26-236).  In scope: fusion_method max / att / v2xvit
 (BASELINE config 5 uses v2xvit)."""
-from collections import Counter, OrderedDict
+from collections import Counter
 
 import torch
 import torch.nn as nn
 
-from heal_amd.opencood.models._heter_common import detection_heads, center_crop, find_encoder, modality_names
-from heal_amd.opencood.models.fuse_modules.fusion_in_one import AttFusion, MaxFusion, V2XViTFusion
+from heal_amd.opencood.models._heter_common import (anchor_heads, crop_camera_feature, detection_heads, modality_stems,
+                                                     wants_depth_items)
+from heal_amd.opencood.models.fuse_modules.fusion_in_one import build_fusion
 from heal_amd.opencood.models.sub_modules.base_bev_backbone import BaseBEVBackbone
 from heal_amd.opencood.models.sub_modules.bev_blocks import DownsampleConv, NaiveCompressor
 from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
@@ -17,47 +18,21 @@ class HeterModelBaseline(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.args = args
-        self.modality_name_list = modality_names(args)
         self.ego_modality = args["ego_modality"]
-        self.cav_range = args["lidar_range"]
-        self.sensor_type_dict = OrderedDict()
-        for m in self.modality_name_list:
-            setting = args[m]
-            sensor = setting["sensor_type"]
-            self.sensor_type_dict[m] = sensor
-            setattr(self, f"encoder_{m}", find_encoder(setting["core_method"])(setting["encoder_args"]))
-            setattr(self, f"depth_supervision_{m}", bool(setting["encoder_args"].get("depth_supervision", False)))
-            setattr(self, f"backbone_{m}", BaseBEVBackbone(setting["backbone_args"],
-                                                           setting["backbone_args"].get("inplanes", 64)))
+        for m, setting in modality_stems(self, args, lambda st: BaseBEVBackbone(st["backbone_args"],
+                                                                                 st["backbone_args"].get("inplanes", 64))):
             setattr(self, f"shrinker_{m}", DownsampleConv(setting["shrink_header"]))
-            if sensor == "camera":
-                gc = setting["camera_mask_args"]["grid_conf"]
-                setattr(self, f"crop_ratio_W_{m}", self.cav_range[3] / gc["xbound"][1])
-                setattr(self, f"crop_ratio_H_{m}", self.cav_range[4] / gc["ybound"][1])
         self.H = self.cav_range[4] - self.cav_range[1]
         self.W = self.cav_range[3] - self.cav_range[0]
         self.fake_voxel_size = 1
         self.supervise_single = bool(args.get("supervise_single", False))
         if self.supervise_single:
-            c = args["in_head_single"]
-            self.cls_head_single = nn.Conv2d(c, args["anchor_number"], kernel_size=1)
-            self.reg_head_single = nn.Conv2d(c, args["anchor_number"] * 7, kernel_size=1)
-            self.dir_head_single = nn.Conv2d(c, args["anchor_number"] * args["dir_args"]["num_bins"], kernel_size=1)
-        method = args["fusion_method"]
-        if method == "max":
-            self.fusion_net = MaxFusion()
-        elif method == "att":
-            self.fusion_net = AttFusion(args["att"]["feat_dim"])
-        elif method == "v2xvit":
-            self.fusion_net = V2XViTFusion(args["v2xvit"])
-        else:
-            raise NotImplementedError(f"fusion_method '{method}' is outside the hot-path scope (SURVEY 2, row 2)")
+            self.cls_head_single, self.reg_head_single, self.dir_head_single = anchor_heads(args["in_head_single"], args)
+        self.fusion_net = build_fusion(args)
         self.shrink_flag = "shrink_header" in args
         if self.shrink_flag:
             self.shrink_conv = DownsampleConv(args["shrink_header"])
-        self.cls_head = nn.Conv2d(args["in_head"], args["anchor_number"], kernel_size=1)
-        self.reg_head = nn.Conv2d(args["in_head"], 7 * args["anchor_number"], kernel_size=1)
-        self.dir_head = nn.Conv2d(args["in_head"], args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
+        self.cls_head, self.reg_head, self.dir_head = anchor_heads(args["in_head"], args)
         self.compress = "compressor" in args
         if self.compress:
             self.compressor = NaiveCompressor(args["compressor"]["input_dim"], args["compressor"]["compress_ratio"])
@@ -76,11 +51,7 @@ class HeterModelBaseline(nn.Module):
         """encoder -> backbone -> shrinker (-> camera crop) for all agents of modality m (:170-196)."""
         f = getattr(self, f"encoder_{m}")(data_dict, m)
         f = getattr(self, f"backbone_{m}")({"spatial_features": f})["spatial_features_2d"]
-        f = getattr(self, f"shrinker_{m}")(f)
-        if self.sensor_type_dict[m] == "camera":
-            _, _, H, W = f.shape
-            f = center_crop(f, int(H * getattr(self, f"crop_ratio_H_{m}")), int(W * getattr(self, f"crop_ratio_W_{m}")))
-        return f
+        return crop_camera_feature(self, m, getattr(self, f"shrinker_{m}")(f))
 
     def heads(self, fused):
         if self.shrink_flag:
@@ -99,7 +70,7 @@ class HeterModelBaseline(nn.Module):
             if m not in counts:
                 continue
             feats[m] = self.encode_modality(data_dict, m)
-            if self.sensor_type_dict[m] == "camera" and getattr(self, f"depth_supervision_{m}"):
+            if wants_depth_items(self, m):
                 output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
         cursor = {m: 0 for m in self.modality_name_list}
         parts = []

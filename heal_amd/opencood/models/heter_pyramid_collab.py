@@ -2,12 +2,13 @@
 heter_pyramid_collab.py:21-209).  Same constructor `args`, same forward(data_dict) keys, same
 state_dict key names; encoders, fusion and scatter run on the gfx950 kernels of libheal_amd.
 """
-from collections import Counter, OrderedDict
+from collections import Counter
 
 import torch
 import torch.nn as nn
 
-from heal_amd.opencood.models._heter_common import detection_heads, center_crop, find_encoder, modality_names, record_len_to_list
+from heal_amd.opencood.models._heter_common import (anchor_heads, crop_camera_feature, detection_heads, modality_stems,
+                                                     record_len_to_list, wants_depth_items)
 from heal_amd.opencood.models.fuse_modules.pyramid_fuse import PyramidFusion
 from heal_amd.opencood.models.sub_modules.bev_blocks import (AlignNet, DownsampleConv, NaiveCompressor,
                                                              ResNetBEVBackbone)
@@ -18,24 +19,13 @@ class HeterPyramidCollab(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.args = args
-        self.modality_name_list = modality_names(args)
-        self.cav_range = args["lidar_range"]
-        self.sensor_type_dict = OrderedDict()
         self.cam_crop_info = {}
-        for m in self.modality_name_list:
-            setting = args[m]
-            sensor = setting["sensor_type"]
-            self.sensor_type_dict[m] = sensor
-            setattr(self, f"encoder_{m}", find_encoder(setting["core_method"])(setting["encoder_args"]))
-            setattr(self, f"depth_supervision_{m}", bool(setting["encoder_args"].get("depth_supervision", False)))
-            setattr(self, f"backbone_{m}", ResNetBEVBackbone(setting["backbone_args"]))
+        for m, setting in modality_stems(self, args, lambda st: ResNetBEVBackbone(st["backbone_args"])):
             setattr(self, f"aligner_{m}", AlignNet(setting["aligner_args"]))
-            if sensor == "camera":
-                gc = setting["camera_mask_args"]["grid_conf"]
-                setattr(self, f"crop_ratio_W_{m}", self.cav_range[3] / gc["xbound"][1])
-                setattr(self, f"crop_ratio_H_{m}", self.cav_range[4] / gc["ybound"][1])
-                setattr(self, f"xdist_{m}", gc["xbound"][1] - gc["xbound"][0])
-                setattr(self, f"ydist_{m}", gc["ybound"][1] - gc["ybound"][0])
+            if setting["sensor_type"] == "camera":
+                grid = setting["camera_mask_args"]["grid_conf"]
+                setattr(self, f"xdist_{m}", grid["xbound"][1] - grid["xbound"][0])
+                setattr(self, f"ydist_{m}", grid["ybound"][1] - grid["ybound"][0])
                 self.cam_crop_info[m] = {f"crop_ratio_W_{m}": getattr(self, f"crop_ratio_W_{m}"),
                                          f"crop_ratio_H_{m}": getattr(self, f"crop_ratio_H_{m}")}
         self.H = self.cav_range[4] - self.cav_range[1]
@@ -45,10 +35,7 @@ class HeterPyramidCollab(nn.Module):
         self.shrink_flag = "shrink_header" in args
         if self.shrink_flag:
             self.shrink_conv = DownsampleConv(args["shrink_header"])
-        self.cls_head = nn.Conv2d(args["in_head"], args["anchor_number"], kernel_size=1)
-        self.reg_head = nn.Conv2d(args["in_head"], 7 * args["anchor_number"], kernel_size=1)
-        self.dir_head = nn.Conv2d(args["in_head"], args["dir_args"]["num_bins"] * args["anchor_number"],
-                                  kernel_size=1)
+        self.cls_head, self.reg_head, self.dir_head = anchor_heads(args["in_head"], args)
         self.compress = "compressor" in args
         if self.compress:
             self.compressor = NaiveCompressor(args["compressor"]["input_dim"], args["compressor"]["compress_ratio"])
@@ -67,12 +54,7 @@ class HeterPyramidCollab(nn.Module):
         """encoder -> light backbone -> aligner (-> camera pad) for all agents of modality m."""
         feature = getattr(self, f"encoder_{m}")(data_dict, m)
         feature = getattr(self, f"backbone_{m}")({"spatial_features": feature})["spatial_features_2d"]
-        feature = getattr(self, f"aligner_{m}")(feature)
-        if self.sensor_type_dict[m] == "camera":
-            _, _, H, W = feature.shape
-            feature = center_crop(feature, int(H * getattr(self, f"crop_ratio_H_{m}")),
-                                  int(W * getattr(self, f"crop_ratio_W_{m}")))
-        return feature
+        return crop_camera_feature(self, m, getattr(self, f"aligner_{m}")(feature))
 
     def heads(self, fused_feature):
         if self.shrink_flag:
@@ -91,7 +73,7 @@ class HeterPyramidCollab(nn.Module):
             if m not in counts:
                 continue
             feats[m] = self.encode_modality(data_dict, m)
-            if self.sensor_type_dict[m] == "camera" and getattr(self, f"depth_supervision_{m}"):
+            if wants_depth_items(self, m):
                 output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
         if len(feats) == 1 and len(counts) == 1:
             heter_feature_2d = next(iter(feats.values()))  # already in scene order
