@@ -163,6 +163,10 @@ int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void
  *             upstream, so no host round trip is needed in the middle of the forward pass
  *   dx,bx host 3 floats each, nx host 3 ints (gen_dx_bx, camera_utils.py:129-134)
  *   out [n_agents, C*nz, ny, nx] f32, every element written
+ *   Summation order: within one image column (camera, u, depth bin) fixed; across columns that feed the same cell the
+ *   default path adds with fp32 hardware atomics, so results can differ in the last bit from call to call (like the
+ *   reference's unstable argsort + cumsum difference).  Environment HEAL_LSS_PATH=sorted selects the bit-reproducible
+ *   radix-sort pipeline (same interface, same workspace).
  * -----------------------------------------------------------------------------------------------*/
 /* heal_camera_matrices: the per-camera 3x3 algebra of get_geometry (heter_encoders.py:137-146): fills the `cam_mats`
  *   rows consumed by heal_bev_pool from rots/intrins/post_rots [n,3,3] and trans/post_trans [n,3] (all f32 device),
