@@ -20,8 +20,9 @@ def main():
     checkout, tool = os.path.abspath(sys.argv[1]), sys.argv[2]
     if not os.path.isdir(os.path.join(checkout, "opencood")):
         raise SystemExit(f"{checkout} does not contain an `opencood` package")
-    import torch.multiprocessing as mp
-    mp.set_start_method("spawn", force=True)   # DataLoader workers that touch the device need their own HIP context
+    # DataLoader workers are forked and cannot create a HIP context: voxelisation and label assignment are deferred to
+    # the main process (SpVoxelPreprocessor / VoxelPostprocessor `defer` mode)
+    os.environ.setdefault("HEAL_DEFER_VOXELIZE", "1")
     from heal_amd import compat
     compat.overlay_reference(checkout)
     sys.argv = [os.path.join(checkout, "opencood", "tools", tool + ".py")] + sys.argv[3:]

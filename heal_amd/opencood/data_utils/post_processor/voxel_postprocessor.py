@@ -3,6 +3,7 @@ generate_anchor_box (:30-83) on the host, post_process (:245-405) on the gfx950 
 kernel K8 (heal_decode_nms), generate_label (:85-207) on heal_label_assign, collate_batch (:210-243) and the
 inherited generate_gt_bbx (base_postprocessor.py:47-107) on the host."""
 import math
+import os
 import sys
 
 import numpy as np
@@ -11,12 +12,39 @@ import torch
 from heal_amd import ops
 
 
+_DEFERRED_ANCHORS = None
+
+
+def resolve_deferred_labels(target_dict):
+    """Turn the deferred label inputs of a collated batch (see VoxelPostprocessor.defer) into `pos_equal_one`,
+    `neg_equal_one`, `targets` -- float64 tensors on the labels' device, exactly what the non-deferred path delivers --
+    and store them in `target_dict`.  A no-op for ordinary label dictionaries and for already resolved ones."""
+    if 'deferred_gt_box_center' not in target_dict or 'pos_equal_one' in target_dict:
+        return target_dict
+    gt, mask, anchors = target_dict['deferred_gt_box_center'], target_dict['deferred_mask'], target_dict['deferred_anchors']
+    post = VoxelPostprocessor({'order': 'hwl', 'anchor_args': {'num': int(anchors.shape[2])},
+                               'target_args': {'pos_threshold': target_dict['deferred_pos_threshold'],
+                                               'neg_threshold': target_dict['deferred_neg_threshold']}}, train=True)
+    post.defer = False
+    anchors_np = anchors.detach().cpu().numpy()
+    frames = [post.generate_label(gt_box_center=gt[b].detach().cpu().numpy(), anchors=anchors_np,
+                                  mask=mask[b].detach().cpu().numpy()) for b in range(gt.shape[0])]
+    for k, v in VoxelPostprocessor.collate_batch(frames).items():
+        target_dict[k] = v.to(gt.device)
+    return target_dict
+
+
 class VoxelPostprocessor:
     def __init__(self, anchor_params, train):
         self.params = anchor_params
         self.train = train
         self.anchor_num = self.params['anchor_args']['num']
         self._anchor_cache = {}
+        # Deferred labels (`postprocess.defer_to_device: true` or HEAL_DEFER_VOXELIZE=1, the switch of the deferred
+        # voxeliser): generate_label runs inside the datasets' forked DataLoader workers, where no HIP context can be
+        # created, so it only packs its inputs; the assignment happens on the device when a loss first reads the labels
+        # (resolve_deferred_labels).  Inference never reads them and never pays for them.
+        self.defer = bool(self.params.get('defer_to_device', False)) or os.environ.get("HEAL_DEFER_VOXELIZE", "0") == "1"
 
     def generate_anchor_box(self):
         a = self.params['anchor_args']
@@ -69,6 +97,12 @@ class VoxelPostprocessor:
         pos_equal_one (H,W,A), neg_equal_one (H,W,A), targets (H,W,7A), like the reference."""
         assert self.params['order'] == 'hwl', 'Currently Voxel only supporthwl bbx order.'
         gt_box_center, anchors, masks = kwargs['gt_box_center'], kwargs['anchors'], kwargs['mask']
+        if self.defer:
+            global _DEFERRED_ANCHORS
+            _DEFERRED_ANCHORS = anchors       # one anchor grid per process; collate_batch (same worker) attaches it once
+            t = self.params['target_args']
+            return {'deferred_gt_box_center': np.asarray(gt_box_center), 'deferred_mask': np.asarray(masks),
+                    'deferred_pos_threshold': float(t['pos_threshold']), 'deferred_neg_threshold': float(t['neg_threshold'])}
         dev = torch.device("cuda", torch.cuda.current_device())
         H, W, A = anchors.shape[:3]
         key = (id(anchors), anchors.shape)
@@ -102,6 +136,13 @@ class VoxelPostprocessor:
     @staticmethod
     def collate_batch(label_batch_list):
         """voxel_postprocessor.py:210-243: stack the per-frame label dictionaries of generate_label."""
+        if label_batch_list and 'deferred_gt_box_center' in label_batch_list[0]:
+            first = label_batch_list[0]
+            return {'deferred_gt_box_center': torch.from_numpy(np.array([f['deferred_gt_box_center'] for f in label_batch_list])),
+                    'deferred_mask': torch.from_numpy(np.array([f['deferred_mask'] for f in label_batch_list])),
+                    'deferred_anchors': torch.from_numpy(np.ascontiguousarray(_DEFERRED_ANCHORS)),
+                    'deferred_pos_threshold': first['deferred_pos_threshold'],
+                    'deferred_neg_threshold': first['deferred_neg_threshold']}
         keys = ("targets", "pos_equal_one", "neg_equal_one")
         return {k: torch.from_numpy(np.array([frame[k] for frame in label_batch_list])) for k in keys}
 

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import resolve_deferred_labels
 from heal_amd.opencood.utils.common_utils import limit_period
 
 
@@ -67,6 +68,7 @@ class PointPillarLoss(nn.Module):
         return x.permute(0, 2, 3, 1).contiguous().view(batch_size, -1, width)
 
     def forward(self, output_dict, target_dict, suffix=""):
+        target_dict = resolve_deferred_labels(target_dict)
         if 'record_len' in output_dict:
             batch_size = int(output_dict['record_len'].sum())
         elif 'batch_size' in output_dict:

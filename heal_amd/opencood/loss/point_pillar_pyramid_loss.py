@@ -4,6 +4,7 @@ depth losses on the fused heads and a focal occupancy loss on every pyramid leve
 import torch
 import torch.nn.functional as F
 
+from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import resolve_deferred_labels
 from heal_amd.opencood.loss.point_pillar_depth_loss import PointPillarDepthLoss
 from heal_amd.opencood.loss.point_pillar_loss import sigmoid_focal_loss
 
@@ -19,6 +20,7 @@ class PointPillarPyramidLoss(PointPillarDepthLoss):
         self.num_levels = len(self.relative_downsample)
 
     def forward(self, output_dict, target_dict, suffix=""):
+        target_dict = resolve_deferred_labels(target_dict)   # the occupancy loss reads the anchor labels as well
         if output_dict['pyramid'] == 'collab':
             return self.forward_collab(output_dict, target_dict, suffix)
         if output_dict['pyramid'] == 'single':

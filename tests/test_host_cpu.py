@@ -185,6 +185,41 @@ def test_preprocessor_deferred_mode_needs_no_gpu_and_survives_the_dataset_merges
     assert "points" in SpVoxelPreprocessor(params, train=False).preprocess(clouds[0])
 
 
+def test_deferred_labels_pack_in_the_worker_and_resolve_at_the_loss(monkeypatch):
+    """VoxelPostprocessor with `defer_to_device`: generate_label / collate_batch (DataLoader worker side) must not touch
+    the GPU and must carry everything the assignment needs; resolve_deferred_labels (loss side) adds the three label
+    tensors once.  The assignment itself is the ordinary generate_label (GPU-tested); here it is replaced by a recorder."""
+    from heal_amd import configs
+    from heal_amd.opencood.data_utils.post_processor import voxel_postprocessor as vp
+    hy = configs.lidar_pyramid(SMALL_RANGE)
+    post = vp.VoxelPostprocessor(dict(hy["postprocess"], defer_to_device=True), train=True)
+    anchors = post.generate_anchor_box()
+    H, W, A = anchors.shape[:3]
+    rng = np.random.default_rng(3)
+    gts = [rng.standard_normal((20, 7)).astype(np.float32) for _ in range(2)]
+    masks = [np.r_[np.ones(k), np.zeros(20 - k)].astype(np.float32) for k in (5, 0)]
+    frames = [post.generate_label(gt_box_center=g, anchors=anchors, mask=m) for g, m in zip(gts, masks)]   # no GPU here
+    batch = post.collate_batch(frames)
+    assert tuple(batch["deferred_gt_box_center"].shape) == (2, 20, 7) and tuple(batch["deferred_anchors"].shape) == anchors.shape
+    assert batch["deferred_pos_threshold"] == 0.6 and batch["deferred_neg_threshold"] == 0.45
+    from heal_amd.opencood.tools.train_utils import to_device
+    assert to_device(batch, "cpu")["deferred_pos_threshold"] == 0.6          # floats pass through to_device
+    calls = []
+
+    def fake_generate_label(self, **kw):
+        assert not self.defer
+        calls.append((kw["gt_box_center"].copy(), kw["mask"].copy(), kw["anchors"].shape))
+        return {"pos_equal_one": np.zeros((H, W, A)), "neg_equal_one": np.ones((H, W, A)), "targets": np.zeros((H, W, 7 * A))}
+    monkeypatch.setattr(vp.VoxelPostprocessor, "generate_label", fake_generate_label)
+    out = vp.resolve_deferred_labels(batch)
+    assert out is batch and len(calls) == 2 and np.array_equal(calls[1][0], gts[1]) and np.array_equal(calls[0][1], masks[0])
+    assert tuple(batch["pos_equal_one"].shape) == (2, H, W, A) and batch["targets"].dtype == torch.float64
+    vp.resolve_deferred_labels(batch)
+    assert len(calls) == 2                                                    # resolved once
+    plain = {"pos_equal_one": torch.zeros(1)}
+    assert vp.resolve_deferred_labels(plain) is plain and len(calls) == 2
+
+
 def test_yaml_loader_round_trip(tmp_path):
     from heal_amd import configs
     from heal_amd.opencood.hypes_yaml import yaml_utils
