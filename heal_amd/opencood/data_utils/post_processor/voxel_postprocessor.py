@@ -42,8 +42,9 @@ class VoxelPostprocessor:
         self._anchor_cache = {}
         # Deferred labels (`postprocess.defer_to_device: true` or HEAL_DEFER_VOXELIZE=1, the switch of the deferred
         # voxeliser): generate_label runs inside the datasets' forked DataLoader workers, where no HIP context can be
-        # created, so it only packs its inputs; the assignment happens on the device when a loss first reads the labels
-        # (resolve_deferred_labels).  Inference never reads them and never pays for them.
+        # created.  train=False: the labels are unused, zeros are returned.  train=True: it only packs its inputs and
+        # the assignment happens on the device when a loss first reads the labels (resolve_deferred_labels); datasets
+        # whose collate reads the label tensors by key (the heter datasets) need num_workers=0 and no deferral instead.
         self.defer = bool(self.params.get('defer_to_device', False)) or os.environ.get("HEAL_DEFER_VOXELIZE", "0") == "1"
 
     def generate_anchor_box(self):
@@ -97,6 +98,12 @@ class VoxelPostprocessor:
         pos_equal_one (H,W,A), neg_equal_one (H,W,A), targets (H,W,7A), like the reference."""
         assert self.params['order'] == 'hwl', 'Currently Voxel only supporthwl bbx order.'
         gt_box_center, anchors, masks = kwargs['gt_box_center'], kwargs['anchors'], kwargs['mask']
+        if self.defer and not self.train:
+            # test time: tools/inference.py never reads the anchor labels the datasets prepare for every sample (the heter
+            # datasets even collate them per agent), so no assignment is run: all-zero arrays of the reference's shapes
+            H, W, A = anchors.shape[:3]
+            return {'pos_equal_one': np.zeros((H, W, A)), 'neg_equal_one': np.zeros((H, W, A)),
+                    'targets': np.zeros((H, W, A * 7))}
         if self.defer:
             global _DEFERRED_ANCHORS
             _DEFERRED_ANCHORS = anchors       # one anchor grid per process; collate_batch (same worker) attaches it once

@@ -70,3 +70,80 @@ def test_overlay_refuses_to_run_after_opencood_was_imported():
             "try:\n    compat.overlay_reference()\nexcept RuntimeError as e:\n    print('REFUSED')\n" % ROOT)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert "REFUSED" in res.stdout, res.stdout + res.stderr
+
+
+DATASET_SCRIPT = r'''
+import importlib, json, os, sys, tempfile
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["HEAL_DEFER_VOXELIZE"] = "1"      # DataLoader-worker mode: neither K1 nor the label assignment may touch the GPU
+from tests.golden import ref_import as R
+R.install(stub_opencood_packages=False)
+for name in ("h5py", "tensorboardX"):
+    R._stub(name, SummaryWriter=object)
+from heal_amd import compat, synth
+compat.overlay_reference("/root/reference")
+import torch, yaml
+
+# a two-vehicle OPV2V scenario on disk: <root>/test/<scenario>/<cav>/<timestamp>.yaml + .pcd
+root = tempfile.mkdtemp(prefix="opv2v_")
+scen = os.path.join(root, "test", "2021_08_18_19_48_05")
+poses = {"641": [10.0, 5.0, 1.9, 0.0, 12.0, 0.0], "650": [22.0, -3.0, 1.9, 0.0, -170.0, 0.0]}
+spots = {101: (18, 6, 10), 102: (30, -8, -160), 103: (5, 12, 95), 104: (150, 150, 0)}     # 104 is out of range
+vehicles = {k: {"angle": [0.0, float(a), 0.0], "center": [0.0, 0.0, 0.8], "extent": [2.3, 1.0, 0.8],
+                "location": [float(x), float(y), 0.05], "speed": 3.0} for k, (x, y, a) in spots.items()}
+clouds = {}
+for i, (cav, pose) in enumerate(poses.items()):
+    d = os.path.join(scen, cav)
+    os.makedirs(d)
+    meta = {"lidar_pose": pose, "true_ego_pos": pose, "predicted_ego_pos": pose, "ego_speed": 5.0, "vehicles": vehicles}
+    for c in range(4):
+        meta["camera%%d" %% c] = {"cords": pose, "extrinsic": np.eye(4).tolist(), "intrinsic": np.eye(3).tolist()}
+    yaml.safe_dump(meta, open(os.path.join(d, "000068.yaml"), "w"))
+    open(os.path.join(d, "000068.pcd"), "w").write("placeholder: the .pcd reader (open3d) is replaced below")
+    clouds[os.path.join(d, "000068.pcd")] = synth.lidar_frame(40 + i)
+assign = os.path.join(root, "assign.json")
+json.dump({"2021_08_18_19_48_05": {"641": "m1", "650": "m1"}}, open(assign, "w"))
+importlib.import_module("opencood.utils.pcd_utils").pcd_to_np = lambda f: clouds[f]
+
+yu = importlib.import_module("opencood.hypes_yaml.yaml_utils")            # everything below is the REFERENCE's code ...
+hy = yu.load_yaml("/root/reference/opencood/hypes_yaml/opv2v/LiDAROnly/lidar_pyramid.yaml")
+hy["validate_dir"] = hy["test_dir"] = os.path.join(root, "test")
+hy["heter"]["assignment_path"] = assign
+dataset = importlib.import_module("opencood.data_utils.datasets").build_dataset(hy, visualize=False, train=False)
+assert type(dataset.pre_processor_m1).__mro__[1].__module__.startswith("heal_amd.")   # ... around this repo's processors
+batch = dataset.collate_batch_test([dataset[0]])
+tu = importlib.import_module("opencood.tools.train_utils")
+batch = tu.to_device(batch, torch.device("cpu"))
+ego = batch["ego"]
+
+# the input contract of the model mirrors (SURVEY 8b)
+assert ego["agent_modality_list"] == ["m1", "m1"] and ego["record_len"].tolist() == [2]
+assert tuple(ego["pairwise_t_matrix"].shape) == (1, 5, 5, 4, 4) and ego["pairwise_t_matrix"].dtype == torch.float64
+assert tuple(ego["anchor_box"].shape) == (256, 256, 2, 7)
+inp = ego["inputs_m1"]
+assert set(inp) == {"points", "max_points_per_voxel", "max_voxels"} and inp["max_voxels"] == 70000
+assert len(inp["points"]) == 2 and all(p.dtype == torch.float32 and p.shape[1] == 4 and p.shape[0] > 1000 for p in inp["points"])
+for p in inp["points"]:      # the dataset's own shuffle_points + mask_ego_points ran before our preprocess (:144-146)
+    assert not bool(((p[:, 0] >= -1.95) & (p[:, 0] <= 2.95) & (p[:, 1] >= -1.1) & (p[:, 1] <= 1.1)).any())
+assert {"pos_equal_one", "neg_equal_one", "targets"} <= set(ego["label_dict"])
+
+# this repo's model (built by the reference's create_model) accepts exactly this dictionary
+from tests.test_glue_cpu import _stub_model
+model = _stub_model(tu.create_model(hy), 64, lidar_hw=(256, 256))
+with torch.no_grad():
+    out = model(ego)
+assert out["pyramid"] == "collab" and out["cls_preds"].shape[1] == 2 and out["occ_single_list"][0].shape[0] == 2
+gt = dataset.post_processor.generate_gt_bbx(batch)      # evaluation side: 3 of the 4 vehicles are in range, seen twice
+assert tuple(gt.shape) == (3, 8, 3), gt.shape
+print("DATASET-OK")
+'''
+
+
+def test_reference_dataset_on_a_synthetic_opv2v_scenario_feeds_the_model_contract():
+    """The reference's OPV2VBaseDataset + IntermediateheterFusionDataset, unmodified, read a synthetic two-vehicle OPV2V
+    scenario from disk under the overlay with the processors in deferred (DataLoader-worker) mode, and what
+    `collate_batch_test` + `to_device` hand over is what this repo's model mirror reads."""
+    res = subprocess.run([sys.executable, "-c", DATASET_SCRIPT % ROOT], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env={**os.environ, "PYTHONPATH": ROOT})
+    assert res.returncode == 0 and "DATASET-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
