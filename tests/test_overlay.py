@@ -147,3 +147,114 @@ def test_reference_dataset_on_a_synthetic_opv2v_scenario_feeds_the_model_contrac
     res = subprocess.run([sys.executable, "-c", DATASET_SCRIPT % ROOT], capture_output=True, text=True, timeout=600,
                          cwd=ROOT, env={**os.environ, "PYTHONPATH": ROOT})
     assert res.returncode == 0 and "DATASET-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+HETERO_SCRIPT = r'''
+import importlib, json, os, sys, tempfile, warnings
+import numpy as np
+warnings.simplefilter("ignore")
+sys.path.insert(0, %r)
+os.environ["HEAL_DEFER_VOXELIZE"] = "1"
+from tests.golden import ref_import as R
+R.install(stub_opencood_packages=False)
+for name in ("h5py", "tensorboardX"):
+    R._stub(name, SummaryWriter=object)
+import torch
+from PIL import Image
+
+# the image has no torchvision / opencv: the three transforms and two cv2 calls the camera branch of the dataset uses are
+# restated from their documented behaviour, for this test only
+class ToTensor:
+    def __call__(self, pic):
+        a = np.array(pic)
+        a = a[:, :, None] if a.ndim == 2 else a
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return t.float().div(255) if t.dtype == torch.uint8 else t
+class Normalize:
+    def __init__(self, mean, std):
+        self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+    def __call__(self, x):
+        return (x - self.mean) / self.std
+class Compose:
+    def __init__(self, ts):
+        self.ts = ts
+    def __call__(self, x):
+        for t in self.ts:
+            x = t(x)
+        return x
+tvt = sys.modules["torchvision.transforms"]
+tvt.ToTensor, tvt.Normalize, tvt.Compose = ToTensor, Normalize, Compose
+cv2 = sys.modules["cv2"]
+cv2.imread = lambda f, *a: np.array(Image.open(f))
+cv2.cvtColor = lambda img, code: img if img.ndim == 2 else img[..., 0]
+cv2.COLOR_BGR2GRAY = 6
+
+from heal_amd import compat, synth
+compat.overlay_reference("/root/reference")
+import yaml
+
+root = tempfile.mkdtemp(prefix="opv2v_h_")
+scen = os.path.join(root, "test", "2021_08_18_19_48_05")
+poses = {"641": [10.0, 5.0, 1.9, 0.0, 12.0, 0.0], "650": [22.0, -3.0, 1.9, 0.0, -170.0, 0.0],
+         "659": [15.0, 14.0, 1.9, 0.0, 80.0, 0.0], "668": [2.0, -9.0, 1.9, 0.0, 40.0, 0.0]}
+assignment = {"641": "m1", "650": "m2", "659": "m3", "668": "m4"}      # PointPillars, LSS-EfficientNet, SECOND, LSS-ResNet
+spots = {101: (18, 6, 10), 102: (30, -8, -160), 103: (5, 12, 95), 104: (150, 150, 0)}
+vehicles = {k: {"angle": [0.0, float(a), 0.0], "center": [0.0, 0.0, 0.8], "extent": [2.3, 1.0, 0.8],
+                "location": [float(x), float(y), 0.05], "speed": 3.0} for k, (x, y, a) in spots.items()}
+rig = synth.camera_rig(0, 4, 600, 800)
+clouds = {}
+for i, (cav, pose) in enumerate(poses.items()):
+    d = os.path.join(scen, cav)
+    os.makedirs(d)
+    meta = {"lidar_pose": pose, "true_ego_pos": pose, "predicted_ego_pos": pose, "ego_speed": 5.0, "vehicles": vehicles}
+    for c in range(4):
+        ext = np.eye(4)
+        ext[:3, :3], ext[:3, 3] = rig["rots"][c], rig["trans"][c]
+        meta["camera%%d" %% c] = {"cords": pose, "extrinsic": ext.tolist(), "intrinsic": rig["intrins"][c].tolist()}
+        g = np.random.default_rng(10 * i + c)
+        Image.fromarray(g.integers(0, 255, (600, 800, 3), dtype=np.uint8)).save(os.path.join(d, "000068_camera%%d.png" %% c))
+        Image.fromarray(g.integers(0, 255, (600, 800), dtype=np.uint8)).save(os.path.join(d, "000068_depth%%d.png" %% c))
+    Image.fromarray(np.zeros((256, 256), np.uint8)).save(os.path.join(d, "000068_bev_visibility.png"))
+    yaml.safe_dump(meta, open(os.path.join(d, "000068.yaml"), "w"))
+    open(os.path.join(d, "000068.pcd"), "w").write("placeholder")
+    clouds[os.path.join(d, "000068.pcd")] = synth.lidar_frame(40 + i)
+    clouds[os.path.join(d, "000068_32.pcd")] = synth.lidar_frame(40 + i)[::2]     # lidar_channels_dict: m3 reads the 32-line file
+assign = os.path.join(root, "assign.json")
+json.dump({"2021_08_18_19_48_05": assignment}, open(assign, "w"))
+importlib.import_module("opencood.utils.pcd_utils").pcd_to_np = lambda f: clouds[f]
+
+yu = importlib.import_module("opencood.hypes_yaml.yaml_utils")
+tu = importlib.import_module("opencood.tools.train_utils")
+hy = yu.load_yaml("/root/reference/opencood/hypes_yaml/opv2v/MoreModality/HEAL/final_infer/m1m2m3m4.yaml")
+hy["validate_dir"] = hy["test_dir"] = os.path.join(root, "test")
+hy["heter"]["assignment_path"] = assign
+dataset = importlib.import_module("opencood.data_utils.datasets").build_dataset(hy, visualize=False, train=False)
+ego = tu.to_device(dataset.collate_batch_test([dataset[0]]), torch.device("cpu"))["ego"]
+assert ego["agent_modality_list"] == ["m1", "m2", "m3", "m4"] and ego["record_len"].tolist() == [4]
+for m, P in (("m1", 32), ("m3", 5)):        # PointPillars / SECOND: raw clouds + the caps of that modality's preprocess block
+    inp = ego["inputs_" + m]
+    assert len(inp["points"]) == 1 and inp["points"][0].dtype == torch.float32 and inp["max_points_per_voxel"] == P, (m, inp)
+for m, (H, W) in (("m2", (384, 512)), ("m4", (336, 448))):
+    inp = ego["inputs_" + m]
+    assert tuple(inp["imgs"].shape) == (1, 4, 4, H, W)                    # RGB + depth channel; CamEncode reads [:, :3]
+    for k, shp in (("rots", (1, 4, 3, 3)), ("trans", (1, 4, 3)), ("intrins", (1, 4, 3, 3)), ("post_rots", (1, 4, 3, 3)),
+                   ("post_trans", (1, 4, 3))):
+        assert tuple(inp[k].shape) == shp and inp[k].dtype == torch.float32, (m, k)
+
+from tests.test_glue_cpu import _stub_model
+model = tu.create_model(hy)
+assert type(model).__module__ == "heal_amd.opencood.models.heter_pyramid_collab"
+model = _stub_model(model, 64, camera_hw=(128, 128), lidar_hw=(256, 256))
+with torch.no_grad():
+    out = model(ego)
+assert out["pyramid"] == "collab" and out["occ_single_list"][0].shape[0] == 4 and out["reg_preds"].shape[1] == 14
+print("HETERO-OK")
+'''
+
+
+def test_reference_dataset_four_modalities_feed_the_model_contract():
+    """Same as above with the reference's 4-modality HEAL YAML (final_infer/m1m2m3m4.yaml): one PointPillars, one
+    Lift-Splat/EfficientNet, one SECOND and one Lift-Splat/ResNet agent, camera PNGs and depth maps on disk."""
+    res = subprocess.run([sys.executable, "-c", HETERO_SCRIPT % ROOT], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env={**os.environ, "PYTHONPATH": ROOT})
+    assert res.returncode == 0 and "HETERO-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
