@@ -1,0 +1,101 @@
+"""GPU tests written at the end of round 1 when the round's GPU budget was already spent: they have never run on a
+device.  They are marked xfail(strict=False) so that the suite reports them (XPASS = fine, XFAIL = a finding for round 2)
+without letting unverified TEST code fail the run; the code paths they cover are exercised with stand-in kernels by the
+CPU suite (tests/test_glue_cpu.py, tests/test_host_cpu.py).  Round 2: run them, fix what they find, drop the marker."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="added without GPU budget left; to be verified in round 2")]
+
+SMALL_RANGE = [-25.6, -25.6, -3, 25.6, 25.6, 1]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _hetero_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from heal_amd import configs
+    from heal_amd.dist import make_sharded, owned_agents
+    from heal_amd.pipeline import Scene, ScenePipeline
+    mods = ["m1", "m2", "m4"]
+    pipe = ScenePipeline(configs.heal_heter(("m1", "m2", "m4")), "cuda:0", seed=5)
+    scene = Scene(len(mods), seed=6, device="cuda:0", modalities=mods)
+    sharded = make_sharded(pipe.model, rank, world)
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    with torch.no_grad():
+        out = sharded.forward(scene.model_input(), len(mods), scene.inputs_for(owned_agents(len(mods), rank, world)))
+        torch.cuda.synchronize()
+        if rank == 0:
+            ref = pipe.model(scene.model_input())
+            torch.save({k: (out[k].cpu(), ref[k].cpu()) for k in ("cls_preds", "reg_preds", "dir_preds")}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_scene_with_camera_agents_equals_single_process(tmp_path):
+    """Rank 1 owns the EfficientNet camera agent, rank 0 the LiDAR ego and the ResNet camera agent: the rank-local warp
+    with the camera crop window (heal_warp_agent) + all-gather + fusion tail must reproduce the single-process model."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "h.pt")
+    mp.spawn(_hetero_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for k, (got, ref) in torch.load(out).items():
+        assert float(ref.abs().max()) > 0
+        err = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+        assert err < 1e-3, (k, err)
+
+
+def test_deferred_labels_resolve_to_the_direct_assignment():
+    from heal_amd import configs
+    from heal_amd.opencood.data_utils.post_processor import voxel_postprocessor as vp
+    hy = configs.lidar_pyramid(SMALL_RANGE)
+    direct = vp.VoxelPostprocessor(hy["postprocess"], train=True)
+    deferred = vp.VoxelPostprocessor(dict(hy["postprocess"], defer_to_device=True), train=True)
+    anchors = direct.generate_anchor_box()
+    rng = np.random.default_rng(8)
+    frames_d, frames_w = [], []
+    for n in (9, 0, 3):
+        gt = np.zeros((20, 7), np.float32)
+        gt[:n] = np.concatenate([rng.uniform(-22, 22, (n, 2)), rng.uniform(-1.5, -0.5, (n, 1)), rng.uniform(1.4, 1.8, (n, 1)),
+                                 rng.uniform(1.5, 2.1, (n, 1)), rng.uniform(3.5, 4.8, (n, 1)), rng.uniform(-3.1, 3.1, (n, 1))], 1)
+        mask = np.zeros(20, np.float32)
+        mask[:n] = 1
+        frames_d.append(direct.generate_label(gt_box_center=gt, anchors=anchors, mask=mask))
+        frames_w.append(deferred.generate_label(gt_box_center=gt, anchors=anchors, mask=mask))
+    want = direct.collate_batch(frames_d)
+    batch = {k: (v.cuda() if hasattr(v, "cuda") else v) for k, v in deferred.collate_batch(frames_w).items()}
+    got = vp.resolve_deferred_labels(batch)
+    for k in ("pos_equal_one", "neg_equal_one", "targets"):
+        assert got[k].is_cuda and got[k].dtype == want[k].dtype and torch.equal(got[k].cpu(), want[k]), k
+    assert float(want["pos_equal_one"].sum()) > 0
+
+
+def test_encoder_uses_the_caps_carried_by_deferred_inputs():
+    from heal_amd import configs, synth
+    from heal_amd.opencood.tools.train_utils import create_model
+    from tests.golden.detfill import fill_module
+    model = fill_module(create_model(configs.m1_single_pyramid(SMALL_RANGE))).cuda().eval()
+    pts = torch.from_numpy(synth.lidar_frame(3)).cuda()
+    pts = pts[(pts[:, 0].abs() < 25) & (pts[:, 1].abs() < 25)][:9000].contiguous()
+    enc = model.encoder_m1
+    with torch.no_grad():
+        plain = enc({"inputs_m1": {"points": [pts]}}, "m1")
+        same = enc({"inputs_m1": {"points": [pts], "max_points_per_voxel": 32, "max_voxels": 70000}}, "m1")
+        capped = enc({"inputs_m1": {"points": [pts], "max_points_per_voxel": 32, "max_voxels": 50}}, "m1")
+    assert torch.equal(plain, same)
+    occupied = lambda t: int((t != 0).any(dim=1).sum())  # noqa: E731
+    assert occupied(capped) == 50 < occupied(plain)
