@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="scene5", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=4,
+                    help="distinct synthetic frames (same agent layout, different clouds / images / poses) resident in HBM; "
+                         "the steps cycle through them, so every step sees a NEW frame like tools/inference.py's loop")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying a "
                     "captured HIP graph of the step (the heterogeneous scene is ~800 launches: host-bound when eager)")
     ap.add_argument("--parallel", default="agents", choices=["agents", "replicas"],
@@ -141,7 +144,7 @@ def main():
         torch.backends.cudnn.benchmark = True  # MIOpen find mode: time the applicable solvers once per shape
     from heal_amd import configs, ops
     from heal_amd.dist import make_sharded, owned_agents
-    from heal_amd.pipeline import Scene, ScenePipeline
+    from heal_amd.pipeline import Scene, ScenePipeline, StaticInputs
 
     # everything runs on one non-default stream, so that an optional HIP-graph capture of the step reuses the
     # stream (and MIOpen state) of the eager warm-up
@@ -160,21 +163,29 @@ def main():
     else:
         hypes = configs.heal_heter(tuple(sorted(set(mods))), max_cav=max(5, n_agents))
     pipe = ScenePipeline(hypes, dev, seed=0)
-    scene = Scene(n_agents, seed=4 + (rank if replicas else 0), device=dev, modalities=mods)
+    seed0 = 4 + (1000 * rank if replicas else 0)
+    frames = [Scene(n_agents, seed=seed0 + 17 * i, device=dev, modalities=mods) for i in range(max(1, a.frames))]
+    scene = frames[0]
     cls_shift = pipe.calibrate_cls_bias(scene)
     batch = {"ego": {"transformation_matrix": pipe.tfm, "anchor_box": pipe.anchor_box}}
+    tick = [0]
+
+    def next_frame():
+        f = frames[tick[0] % len(frames)]
+        tick[0] += 1
+        return f
 
     use_graph = False
     if solo:
         def step():
-            return pipe.step(scene)
+            return pipe.step(next_frame())
         if not a.eager:
             try:
                 pipe.capture(scene)
                 use_graph = True
 
                 def step():  # noqa: F811
-                    return pipe.replay()
+                    return pipe.replay(next_frame())   # copies the frame into the graph's static input buffers first
             except Exception as e:  # a path with a host round trip (e.g. SECOND's site counts) cannot be captured
                 print(f"[bench] HIP graph capture unavailable for this workload ({type(e).__name__}: {e}); "
                       "running eagerly", file=sys.stderr)
@@ -183,10 +194,13 @@ def main():
         wire = torch.float16 if os.environ.get("HEAL_WIRE", "fp32") == "fp16" else None  # opt-in half-size exchange
         sharded = make_sharded(pipe.model, rank, world, wire_dtype=wire)
         mine = owned_agents(n_agents, rank, world)
-        local_inputs = scene.inputs_for(mine)
-        inp = scene.model_input()
+        # this rank's sensor inputs + the scene's pose matrices in fixed device buffers; every step loads the next frame
+        static = StaticInputs(scene, agents=mine)
+        local_inputs = static.inputs_for(mine)
+        inp = static.scene_meta()
 
         def step():
+            static.load(next_frame())
             out = sharded.forward(inp, n_agents, local_inputs)
             if rank == 0:
                 return pipe.post.post_process(batch, {"ego": out})
@@ -204,7 +218,7 @@ def main():
                                       dir_args["num_bins"], pipe.post.params["nms_thresh"],
                                       np.eye(4, dtype=np.float32), pipe.post.params["gt_range"], sync=False)
             if sharded.capture(inp, n_agents, local_inputs, post_fn):
-                pipe.check_sparse_capacity()
+                sharded.check_sparse_capacity()
                 use_graph = True
             elif sharded._capture_error is not None:
                 e = sharded._capture_error
@@ -213,6 +227,7 @@ def main():
             if use_graph:
 
                 def step():  # noqa: F811
+                    static.load(next_frame())
                     res_ = sharded.replay()
                     if rank != 0:
                         return None, None
@@ -242,7 +257,7 @@ def main():
         ops.TIMING = {}
         for _ in range(a.steps):
             if solo:
-                pipe.step(scene)
+                pipe.step(next_frame())
             else:
                 eager_step()
         torch.cuda.synchronize()

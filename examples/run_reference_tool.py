@@ -23,6 +23,10 @@ def main():
     # DataLoader workers are forked and cannot create a HIP context: voxelisation and label assignment are deferred to
     # the main process (SpVoxelPreprocessor / VoxelPostprocessor `defer` mode)
     os.environ.setdefault("HEAL_DEFER_VOXELIZE", "1")
+    if tool.startswith("inference"):
+        # the inference drivers never read the anchor labels the datasets build per sample: skip the assignment.  NOT for
+        # train.py, whose validation pass computes the loss on them (train.py:153-154)
+        os.environ.setdefault("HEAL_INFERENCE_ONLY", "1")
     from heal_amd import compat
     compat.overlay_reference(checkout)
     sys.argv = [os.path.join(checkout, "opencood", "tools", tool + ".py")] + sys.argv[3:]

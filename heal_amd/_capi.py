@@ -31,9 +31,9 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_float,
                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+    "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),
-    "heal_warp_agent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+    "heal_warp_agent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "heal_fuse_warped": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_decode_nms_workspace": (c_size_t, [c_int, c_int]),

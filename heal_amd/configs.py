@@ -114,8 +114,8 @@ def m1_late(lidar_range=FULL_RANGE):
     return load_general_params(h)
 
 
-def _camera_modality(lidar_range, final_dim, encoder):
-    grid_conf = {"xbound": [-51.2, 51.2, 0.4], "ybound": [-51.2, 51.2, 0.4], "zbound": [-10, 10, 20.0],
+def _camera_modality(lidar_range, final_dim, encoder, cam_bound=51.2):
+    grid_conf = {"xbound": [-cam_bound, cam_bound, 0.4], "ybound": [-cam_bound, cam_bound, 0.4], "zbound": [-10, 10, 20.0],
                  "ddiscr": [2, 50, 48], "mode": "LID"}
     data_aug_conf = {"resize_lim": [0.65, 0.7] if encoder == "EfficientNet" else [0.56, 0.61],
                      "final_dim": list(final_dim), "rot_lim": [-3.6, 3.6], "H": 600, "W": 800, "rand_flip": False,
@@ -147,10 +147,12 @@ def _second_modality(lidar_range):
     }
 
 
-def heal_heter(modalities=("m1", "m2", "m3", "m4"), lidar_range=FULL_RANGE, max_cav=5):
+def heal_heter(modalities=("m1", "m2", "m3", "m4"), lidar_range=FULL_RANGE, max_cav=5, cam_bound=51.2, cam_dims=None):
     """HEAL final-infer collaborative model with several modalities (m1 PointPillars LiDAR,
     m2 Lift-Splat EfficientNet 384x512, m4 Lift-Splat Resnet101 336x448; m3 SECOND when built) --
-    MoreModality/HEAL/final_infer/m1m2m3m4.yaml, BASELINE config 4."""
+    MoreModality/HEAL/final_infer/m1m2m3m4.yaml, BASELINE config 4.  `cam_bound` / `cam_dims` ({"m2": (H, W), ...})
+    shrink the camera BEV grid and the image sizes for reduced-size parity tests."""
+    cam_dims = dict({"m2": (384, 512), "m4": (336, 448)}, **(cam_dims or {}))
     h = _common(lidar_range, max_cav)
     h["name"] = "heal_amd_opv2v_" + "".join(modalities)
     args = {"ego_modality": "m1", "lidar_range": list(lidar_range), "supervise_single": True}
@@ -158,11 +160,11 @@ def heal_heter(modalities=("m1", "m2", "m3", "m4"), lidar_range=FULL_RANGE, max_
         if m == "m1":
             args[m] = _pointpillar_modality(lidar_range, "identity")
         elif m == "m2":
-            args[m] = _camera_modality(lidar_range, (384, 512), "EfficientNet")
+            args[m] = _camera_modality(lidar_range, cam_dims["m2"], "EfficientNet", cam_bound)
         elif m == "m3":
             args[m] = _second_modality(lidar_range)
         elif m == "m4":
-            args[m] = _camera_modality(lidar_range, (336, 448), "Resnet101")
+            args[m] = _camera_modality(lidar_range, cam_dims["m4"], "Resnet101", cam_bound)
         else:
             raise NotImplementedError(f"modality {m}")
     args.update({"fusion_backbone": _fusion_backbone(), "shrink_header": _shrink_header(), "in_head": 256,

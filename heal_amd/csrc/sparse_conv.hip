@@ -38,7 +38,8 @@ struct SpShape {
 };
 
 __device__ __forceinline__ uint32_t sp_key(const SpShape& s, int b, int z, int y, int x) {
-    return (uint32_t)(((b * s.D + z) * s.H + y) * s.W + x);
+    // unsigned arithmetic: the cell count is < 2^32 (shape_ok) but exceeds 2^31 from batch 13 on at [41,2048,2048]
+    return (((uint32_t)b * (uint32_t)s.D + (uint32_t)z) * (uint32_t)s.H + (uint32_t)y) * (uint32_t)s.W + (uint32_t)x;
 }
 
 __device__ __forceinline__ int sp_lookup(const uint32_t* __restrict__ tkey, const int* __restrict__ tval,

@@ -26,6 +26,8 @@ constexpr int WF_MAXA = 8;     // agents handled per launch (max_cav is 5..8 in 
 constexpr int WF_TW = 32, WF_TH = 8;  // pixel tile per 256-thread block
 
 struct WarpParams {
+    const double* mdev;     // device copy of the affine rows [n_agents][6] (wins over `m` when non-null: a captured HIP
+                            // graph then follows the poses of the frame it is replayed on instead of the captured ones)
     double m[WF_MAXA][6];   // rows of affine_matrix[b][0, a]: m00 m01 m02 m10 m11 m12
     int crop[WF_MAXA][4];   // (h0,h1,w0,w1) window where the score is kept; h1<=h0: keep everything
     int n_agents, C, H, W;
@@ -45,6 +47,12 @@ __device__ __forceinline__ T base_coord(int j, int n) {
     const T step = (T)2 / (T)(n - 1);
     const T v = (j < n / 2) ? (T)-1 + step * (T)j : (T)1 - step * (T)(n - 1 - j);
     return v * (T)(n - 1) / (T)n;
+}
+
+__device__ __forceinline__ void load_affine(const WarpParams& p, int a, double (&m)[6]) {
+    // wave-uniform: six scalar loads from the kernel arguments or from the device buffer
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[k] = p.mdev ? p.mdev[a * 6 + k] : p.m[a][k];
 }
 
 template <typename T>
@@ -150,8 +158,10 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
         for (int k = 0; k < 4; ++k) { off[a][k] = 0; wt[a][k] = 0.f; }
         {
             float gx, gy;
-            if (p.grid_f64) grid_point<double>(p.m[a], h, w, p.H, p.W, gx, gy);
-            else grid_point<float>(p.m[a], h, w, p.H, p.W, gx, gy);
+            double m[6];
+            load_affine(p, a, m);
+            if (p.grid_f64) grid_point<double>(m, h, w, p.H, p.W, gx, gy);
+            else grid_point<float>(m, h, w, p.H, p.W, gx, gy);
             const Taps t = make_taps(gx, gy, p.H, p.W);
             prob[a] = sample_score(occ + (size_t)a * HW, t, p.W, p.crop[a]);
             const int o4[4] = {t.off, t.off + 1, t.off + p.W, t.off + p.W + 1};
@@ -211,8 +221,10 @@ __global__ __launch_bounds__(256) void k_warp_agent(const float* __restrict__ fe
     if (w >= p.W || h >= p.H) return;
     const int HW = p.H * p.W;
     float gx, gy;
-    if (p.grid_f64) grid_point<double>(p.m[0], h, w, p.H, p.W, gx, gy);
-    else grid_point<float>(p.m[0], h, w, p.H, p.W, gx, gy);
+    double m[6];
+    load_affine(p, 0, m);
+    if (p.grid_f64) grid_point<double>(m, h, w, p.H, p.W, gx, gy);
+    else grid_point<float>(m, h, w, p.H, p.W, gx, gy);
     const Taps t = make_taps(gx, gy, p.H, p.W);
     const int pix = h * p.W + w;
     if (bk.z == 0 && score_ego != nullptr) score_ego[pix] = sample_score(occ, t, p.W, p.crop[0]);
@@ -250,14 +262,15 @@ __global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ 
 }
 
 static int fill_params(WarpParams& p, int n_agents, int C, int H, int W, const double* affine_host,
-                       int grid_f64, const int32_t* crop_host) {
+                       const double* affine_dev, int grid_f64, const int32_t* crop_host) {
     HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "warp_fuse: n_agents must be in [1,%d] (got %d)",
                  WF_MAXA, n_agents);
     HEAL_REQUIRE(C >= 1 && H >= 1 && W >= 1, "warp_fuse: bad shape");
-    HEAL_REQUIRE(affine_host != nullptr, "warp_fuse: affine is NULL");
+    HEAL_REQUIRE(affine_host != nullptr || affine_dev != nullptr, "warp_fuse: affine is NULL (host and device)");
     p.n_agents = n_agents; p.C = C; p.H = H; p.W = W; p.grid_f64 = grid_f64;
+    p.mdev = affine_dev;
     for (int a = 0; a < WF_MAXA; ++a) {
-        for (int k = 0; k < 6; ++k) p.m[a][k] = a < n_agents ? affine_host[a * 6 + k] : 0.0;
+        for (int k = 0; k < 6; ++k) p.m[a][k] = (a < n_agents && affine_host) ? affine_host[a * 6 + k] : 0.0;
         for (int k = 0; k < 4; ++k) p.crop[a][k] = (a < n_agents && crop_host) ? crop_host[a * 4 + k] : 0;
     }
     return 0;
@@ -268,10 +281,10 @@ static int fill_params(WarpParams& p, int n_agents, int C, int H, int W, const d
 using namespace heal;
 
 extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents, int channels, int H,
-                              int W, const double* affine_host, int grid_f64, const int32_t* crop_host,
-                              float* out, void* stream) {
+                              int W, const double* affine_host, const double* affine_dev, int grid_f64,
+                              const int32_t* crop_host, float* out, void* stream) {
     WarpParams p;
-    if (fill_params(p, n_agents, channels, H, W, affine_host, grid_f64, crop_host)) return 1;
+    if (fill_params(p, n_agents, channels, H, W, affine_host, affine_dev, grid_f64, crop_host)) return 1;
     // channels per block: the per-pixel prologue (grid, taps, scores, softmax) is recomputed by every
     // channel block, so use as few channel blocks as still give ~1024 workgroups
     const int tiles = ceil_div(W, WF_TW) * ceil_div(H, WF_TH);
@@ -291,10 +304,10 @@ extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents
 }
 
 extern "C" int heal_warp_agent(const float* feat, const float* occ, int channels, int H, int W,
-                               const double* affine_host, int grid_f64, const int32_t* crop_host,
-                               float* feat_ego, float* score_ego, void* stream) {
+                               const double* affine_host, const double* affine_dev, int grid_f64,
+                               const int32_t* crop_host, float* feat_ego, float* score_ego, void* stream) {
     WarpParams p;
-    if (fill_params(p, 1, channels, H, W, affine_host, grid_f64, crop_host)) return 1;
+    if (fill_params(p, 1, channels, H, W, affine_host, affine_dev, grid_f64, crop_host)) return 1;
     constexpr int CCH = 16;
     dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, CCH));
     k_warp_agent<CCH><<<grid, 256, 0, (hipStream_t)stream>>>(feat, occ, p, feat_ego, score_ego);

@@ -160,11 +160,14 @@ class _Sharded:
         cur = torch.cuda.current_stream(dev)
         if cur == torch.cuda.default_stream(dev):
             raise RuntimeError("capture() must be called under a non-default stream")
+        from heal_amd import ops
         for _ in range(warmup):
             out = self.forward(scene_input, n_agents, local_inputs)
             if post_fn is not None and self.rank == 0:
                 post_fn(out)
         cur.synchronize()
+        ops.verify_sparse_capacity()
+        self._graph_checks, self._replays = [], 0
         self._capture_error = None
         ok = True
         self._g_local = None
@@ -178,6 +181,7 @@ class _Sharded:
                 with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
                     self._static_buf = self.local(scene_input, n_agents, local_inputs)
                 self._g_local = g
+                self._graph_checks = ops.take_sparse_checks()   # counters in the graph's pool: re-checked after replays
             except Exception as e:  # noqa: BLE001 - reported by the caller, path falls back to eager
                 self._capture_error = e
                 ok = False
@@ -204,9 +208,19 @@ class _Sharded:
             return False
         return True
 
+    def check_sparse_capacity(self):
+        """Host check (synchronises) of the capacity counters the captured local stage wrote; raises on overflow."""
+        from heal_amd import ops
+        ops.verify_sparse_capacity(self._graph_checks)
+
     def replay(self):
+        """graph(local) -> all-gather -> graph(tail).  The graphs read whatever the buffers behind the captured inputs hold
+        (pipeline.StaticInputs.load puts the next frame there: sensor data AND poses)."""
         if self._g_local is not None:   # None: this rank owns no agent, its slot is the constant zero buffer
             self._g_local.replay()
+            self._replays += 1
+            if self._graph_checks and self._replays % 32 == 0:
+                self.check_sparse_capacity()
         if self.world > 1:
             n_slots, per_slot = self._static_buf.shape
             dist.all_gather_into_tensor(self._static_gathered.view(self.world * n_slots, per_slot), self._static_buf)
@@ -314,7 +328,7 @@ class ShardedBaseline(_Sharded):
         m = self.model
         pairwise, _ = pairwise_to_host(scene_input["pairwise_t_matrix"])
         affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)
-        f64 = affine.dtype == "float64"
+        f64 = str(affine.dtype).endswith("float64")   # numpy or torch dtype
         n_slots = slots_per_rank(n_agents, self.world)
         x, mine = self._own_features(scene_input, n_agents, local_inputs)
         if mine:

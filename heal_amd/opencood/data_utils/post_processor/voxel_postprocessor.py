@@ -46,6 +46,9 @@ class VoxelPostprocessor:
         # the assignment happens on the device when a loss first reads the labels (resolve_deferred_labels); datasets
         # whose collate reads the label tensors by key (the heter datasets) need num_workers=0 and no deferral instead.
         self.defer = bool(self.params.get('defer_to_device', False)) or os.environ.get("HEAL_DEFER_VOXELIZE", "0") == "1"
+        # labels are never read (tools/inference.py): `postprocess.inference_only: true` or HEAL_INFERENCE_ONLY=1
+        self.inference_only = (bool(self.params.get('inference_only', False))
+                               or os.environ.get("HEAL_INFERENCE_ONLY", "0") == "1")
 
     def generate_anchor_box(self):
         a = self.params['anchor_args']
@@ -98,9 +101,11 @@ class VoxelPostprocessor:
         pos_equal_one (H,W,A), neg_equal_one (H,W,A), targets (H,W,7A), like the reference."""
         assert self.params['order'] == 'hwl', 'Currently Voxel only supporthwl bbx order.'
         gt_box_center, anchors, masks = kwargs['gt_box_center'], kwargs['anchors'], kwargs['mask']
-        if self.defer and not self.train:
-            # test time: tools/inference.py never reads the anchor labels the datasets prepare for every sample (the heter
-            # datasets even collate them per agent), so no assignment is run: all-zero arrays of the reference's shapes
+        if self.defer and self.inference_only:
+            # tools/inference.py never reads the anchor labels the datasets prepare for every sample (the heter datasets
+            # even collate them per agent), so under an EXPLICIT inference-only switch no assignment is run: all-zero arrays
+            # of the reference's shapes.  `train=False` alone is not that switch: tools/train.py builds its validation set
+            # with train=False and computes the loss on these labels (train.py:153-154)
             H, W, A = anchors.shape[:3]
             return {'pos_equal_one': np.zeros((H, W, A)), 'neg_equal_one': np.zeros((H, W, A)),
                     'targets': np.zeros((H, W, A * 7))}
@@ -239,10 +244,10 @@ class VoxelPostprocessor:
         hit = self._anchor_cache.get(key)
         if hit is None:
             t = anchor_box if isinstance(anchor_box, torch.Tensor) else torch.from_numpy(np.asarray(anchor_box))
-            hit = t.to(device=device, dtype=torch.float32).contiguous()
+            hit = (t.to(device=device, dtype=torch.float32).contiguous(), anchor_box)  # keep the source alive: key = address
             self._anchor_cache = {k: v for k, v in self._anchor_cache.items() if isinstance(k, tuple) and k and k[0] == "label"}
             self._anchor_cache[key] = hit
-        return hit
+        return hit[0]
 
     def post_process(self, data_dict, output_dict):
         """-> (pred_box3d [K,8,3], scores [K]) or (None, None).  Intermediate / single-agent form:

@@ -22,8 +22,11 @@ def warp_to_ego(x, affine_rows, grid_f64=True):
 
 
 def _host_affine(affine_matrix):
+    """-> (affine matrix, grid_is_f64).  CUDA tensors stay on the device (read by the warp kernel at run time)."""
     if isinstance(affine_matrix, torch.Tensor):
-        a = affine_matrix.detach().cpu().numpy()
+        if affine_matrix.is_cuda:
+            return affine_matrix.detach(), affine_matrix.dtype == torch.float64
+        a = affine_matrix.detach().numpy()
     else:
         a = np.asarray(affine_matrix)
     return a, a.dtype == np.float64

@@ -18,10 +18,16 @@ def normalize_pairwise_tfm(pairwise_t_matrix, H, W, discrete_ratio, downsample_r
 
 
 def pairwise_to_host(pairwise_t_matrix):
-    """The fusion kernels take the (tiny) affine matrices as launch arguments: bring the pairwise
-    matrix to the host once per forward.  Returns (numpy array, grid_is_f64)."""
+    """Where the fusion kernels read the (tiny) affine matrices from.  Returns (matrix, grid_is_f64).
+
+    A CUDA tensor STAYS on the device (what the reference's `train_utils.to_device` hands to the model): the warp kernels
+    then read the poses from device memory at run time -- no host round trip, and a captured HIP graph follows the poses
+    of the frame it is replayed on.  Host tensors / numpy arrays are returned as numpy and travel as launch arguments."""
     if isinstance(pairwise_t_matrix, torch.Tensor):
-        arr = pairwise_t_matrix.detach().cpu().numpy()
+        if pairwise_t_matrix.is_cuda:
+            t = pairwise_t_matrix.detach()
+            return t, t.dtype == torch.float64
+        arr = pairwise_t_matrix.detach().numpy()
     else:
         arr = np.asarray(pairwise_t_matrix)
     return arr, arr.dtype == np.float64

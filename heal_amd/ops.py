@@ -61,14 +61,50 @@ def _need(t, dtype, name):
     return t.contiguous()
 
 
+_WS_RETIRED = []
+
+
 def _workspace(key, nbytes, device):
-    """Grow-only per-(op, device) scratch buffer (256-B aligned by the caching allocator)."""
+    """Grow-only per-(op, device) scratch buffer (256-B aligned by the caching allocator).  A buffer that is outgrown is
+    RETIRED, not freed: a captured HIP graph may have its address baked in, and handing the memory back to the caching
+    allocator would let a later replay scribble over somebody else's tensor."""
     k = (key, device.index)
     buf = _WS.get(k)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _WS[k] = buf
     return buf
+
+
+# ---- capacity checks of the no-host-sync sparse path ---------------------------------------------------------------------
+# Strided sparse layers that run without a host round trip size their outputs by a capacity bound and record
+# (device counter, capacity) here.  Whoever synchronises with the host next on the same stream (decode_nms(sync=True),
+# ScenePipeline.replay) verifies them, so a frame denser than the bound raises instead of silently dropping sites.
+_SPARSE_CHECKS = []
+
+
+def take_sparse_checks():
+    """Hand over (and forget) the pending checks, e.g. to keep those recorded inside a captured graph."""
+    global _SPARSE_CHECKS
+    out, _SPARSE_CHECKS = _SPARSE_CHECKS, []
+    return out
+
+
+def verify_sparse_capacity(checks=None):
+    """Raise if any recorded strided sparse layer produced more active sites than its capacity (synchronises: one small
+    D2H copy).  checks=None: verify and clear the pending list."""
+    pending = take_sparse_checks() if checks is None else checks
+    if not pending:
+        return
+    counts = torch.cat([c.reshape(1) for c, _ in pending]).cpu().tolist()
+    for n, (_, cap) in zip(counts, pending):
+        if n > cap:
+            raise _capi.HealAmdError(
+                f"sparse conv: a strided layer produced {n} active sites, more than its capacity {cap} in the no-host-sync "
+                "mode (sites beyond the capacity were dropped: the result is invalid).  Feed exact-size voxel inputs or "
+                "raise the capacity policy (SparseTensor.out_sites)")
 
 
 def _host_array(values, ctype):
@@ -199,9 +235,23 @@ def pfn_scatter(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_si
     return canvas
 
 
-def _affine_host(affine_rows):
+def _affine_args(affine_rows, n):
+    """-> (keep-alive object, host pointer, device pointer).  A CUDA tensor of affine rows stays on the device (no host
+    round trip; a captured graph then reads the poses at replay time); anything else is passed by value from the host."""
+    if isinstance(affine_rows, torch.Tensor) and affine_rows.is_cuda:
+        a = affine_rows.detach()
+        if a.dtype != torch.float64:
+            a = a.double()
+        a = a.reshape(-1, 6).contiguous()
+        if int(a.shape[0]) != n:
+            raise _capi.HealAmdError(f"affine rows: expected {n} x (2,3), got {tuple(affine_rows.shape)}")
+        return a, ctypes.c_void_p(0), ctypes.c_void_p(a.data_ptr())
+    if isinstance(affine_rows, torch.Tensor):
+        affine_rows = affine_rows.detach().numpy()
     a = np.ascontiguousarray(np.asarray(affine_rows, dtype=np.float64).reshape(-1, 6))
-    return a, a.ctypes.data_as(ctypes.c_void_p)
+    if a.shape[0] != n:
+        raise _capi.HealAmdError(f"affine rows: expected {n} x (2,3), got {a.shape}")
+    return a, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(0)
 
 
 def _crop_host(crop, n):
@@ -212,15 +262,16 @@ def _crop_host(crop, n):
 
 
 def warp_fuse(feats, occ, affine_rows, grid_f64=True, crop=None):
-    """K5 fused.  feats [n,C,H,W], occ [n,1,H,W] logits, affine_rows [n,2,3] (host) -> [C,H,W]."""
+    """K5 fused.  feats [n,C,H,W], occ [n,1,H,W] logits, affine_rows [n,2,3] (host array, or a CUDA tensor that is then
+    read on the device at run time) -> [C,H,W]."""
     feats = _need(feats, torch.float32, "feats")
     occ = _need(occ, torch.float32, "occ")
     n, C, H, W = (int(v) for v in feats.shape)
     out = torch.empty((C, H, W), dtype=torch.float32, device=feats.device)
-    a, ap = _affine_host(affine_rows)
+    a, ap, adev = _affine_args(affine_rows, n)
     c, cp = _crop_host(crop, n)
     with _Timed(f"warp_fuse_c{C}"):
-        _capi.call("heal_warp_fuse", _ptr(feats), _ptr(occ), n, C, H, W, ap, int(bool(grid_f64)), cp,
+        _capi.call("heal_warp_fuse", _ptr(feats), _ptr(occ), n, C, H, W, ap, adev, int(bool(grid_f64)), cp,
                    _ptr(out), _stream())
     return out
 
@@ -232,9 +283,9 @@ def warp_agent(feat, occ, affine_row, grid_f64=True, crop=None):
     C, H, W = (int(v) for v in feat.shape[-3:])
     feat_ego = torch.empty((C, H, W), dtype=torch.float32, device=feat.device)
     score_ego = torch.empty((1, H, W), dtype=torch.float32, device=feat.device)
-    a, ap = _affine_host(affine_row)
+    a, ap, adev = _affine_args(affine_row, 1)
     c, cp = _crop_host(crop, 1)
-    _capi.call("heal_warp_agent", _ptr(feat), _ptr(occ), C, H, W, ap, int(bool(grid_f64)), cp,
+    _capi.call("heal_warp_agent", _ptr(feat), _ptr(occ), C, H, W, ap, adev, int(bool(grid_f64)), cp,
                _ptr(feat_ego), _ptr(score_ego), _stream())
     return feat_ego, score_ego
 
@@ -280,6 +331,8 @@ def decode_nms(cls, reg, dirp, anchors, score_thr, dir_offset, num_bins, nms_thr
     if not sync:
         return out_c, out_s, out_n
     k = int(out_n.item())
+    if _SPARSE_CHECKS and not torch.cuda.is_current_stream_capturing():
+        verify_sparse_capacity()   # first host sync after a no-sync SECOND encoder: its capacity counters are final now
     if k == 0:
         return None, None
     return out_c[:k], out_s[:k]
@@ -528,6 +581,9 @@ class SparseTensor:
         if self.n_dev is None:
             return out_idx[:int(n_out.item())], out_shape, None
         self._checks.append((n_out, out_cap))
+        _SPARSE_CHECKS.append((n_out, out_cap))
+        if len(_SPARSE_CHECKS) > 4096:   # nobody verifies (no host sync on this path at all): keep the list bounded
+            del _SPARSE_CHECKS[:2048]
         return out_idx, out_shape, n_out
 
     def conv(self, nbr, weight, bn_scale, bn_shift, relu=True, n_out_dev=None):

@@ -81,6 +81,77 @@ class Scene:
         return d
 
 
+class StaticInputs:
+    """Fixed-address device buffers holding one scene's inputs, so that a HIP graph captured around them can be replayed
+    on OTHER frames (opencood/tools/inference.py:131-165 sees a new batch every iteration): `load(scene)` copies a scene
+    in, `model_input()` / `inputs_for()` hand out views with the same layout `Scene` produces.
+
+    * point clouds: one buffer per LiDAR agent with `slack` x the first scene's point count as capacity; the unused tail
+      holds NaN points, which the voxeliser drops (same rows, same order as the un-padded cloud);
+    * camera agents: images and rig tensors, fixed shapes;
+    * `pairwise_t_matrix`: float64 [1,L,L,4,4] ON THE DEVICE -- the warp kernels read the poses at run time
+      (heal_warp_fuse / heal_warp_agent `affine_dev`), so a replay uses the poses of the frame that was loaded."""
+
+    def __init__(self, scene, slack=1.25, agents=None):
+        """agents: restrict the sensor buffers to these agent ids (a rank of the agent-sharded job only feeds its own
+        agents); the pose matrices are always held."""
+        self.device = scene.device
+        self.modalities = list(scene.modalities)
+        self.n_agents = scene.n_agents
+        self.record_len = list(scene.record_len)
+        self.points, self.cameras = {}, {}
+        keep = set(range(scene.n_agents)) if agents is None else set(agents)
+        for k, p in scene.points.items():
+            if k not in keep:
+                continue
+            cap = max(1024, (int(int(p.shape[0]) * slack) + 1023) // 1024 * 1024)
+            self.points[k] = torch.full((cap, 4), float("nan"), dtype=torch.float32, device=self.device)
+        for k, cam in scene.cameras.items():
+            if k in keep:
+                self.cameras[k] = {name: torch.empty_like(t) for name, t in cam.items()}
+        self.pairwise = torch.empty(tuple(scene.pairwise.shape), dtype=torch.float64, device=self.device)
+        self._pairwise_pinned = torch.empty(tuple(scene.pairwise.shape), dtype=torch.float64).pin_memory()
+        self.load(scene)
+
+    def load(self, scene):
+        """Copy `scene` into the static buffers (asynchronous on the current stream apart from the pinned staging of the
+        4x4 pose matrices).  The scene must have the captured layout: same modalities, clouds within capacity."""
+        if list(scene.modalities) != self.modalities:
+            raise ValueError(f"scene layout {scene.modalities} differs from the captured layout {self.modalities}")
+        for k, buf in self.points.items():
+            p = scene.points[k]
+            n = int(p.shape[0])
+            if n > buf.shape[0]:
+                raise ValueError(f"agent {k}: {n} points exceed the static capacity {buf.shape[0]} of the captured graph "
+                                 "(capture with a larger `slack`)")
+            buf[:n].copy_(p, non_blocking=True)
+            if n < buf.shape[0]:
+                buf[n:].fill_(float("nan"))
+        for k, cam in self.cameras.items():
+            for name, t in cam.items():
+                t.copy_(scene.cameras[k][name], non_blocking=True)
+        pw = scene.pairwise
+        if isinstance(pw, torch.Tensor) and pw.is_cuda:
+            self.pairwise.copy_(pw.to(torch.float64), non_blocking=True)
+        else:
+            # the pinned staging buffer is reused: make sure the previous frame's H2D copy has left it
+            torch.cuda.current_stream(self.device).synchronize()
+            self._pairwise_pinned.copy_(torch.as_tensor(np.asarray(pw), dtype=torch.float64))
+            self.pairwise.copy_(self._pairwise_pinned, non_blocking=True)
+
+    def scene_meta(self):
+        """What the agent-sharded runner reads besides a rank's own sensor inputs: layout and (device) poses."""
+        return {"agent_modality_list": list(self.modalities), "record_len": self.record_len,
+                "pairwise_t_matrix": self.pairwise}
+
+    # the two accessors below mirror Scene's
+    def inputs_for(self, agents):
+        return Scene.inputs_for(self, agents)
+
+    def model_input(self):
+        return Scene.model_input(self)
+
+
 @torch.no_grad()
 def calibrate_heads(model, model_input, score_threshold, target_candidates=600):
     """Random-init heads put an arbitrary fraction of the 131 072 anchors above the score threshold.  Shift the
@@ -135,13 +206,16 @@ class ScenePipeline:
     # captured once into a HIP graph and replayed; the only host interaction left per scene is reading
     # the box count.
     @torch.no_grad()
-    def capture(self, scene, warmup=3):
+    def capture(self, scene, warmup=3, slack=1.25):
+        """Capture the whole step around STATIC input buffers initialised from `scene` (StaticInputs); `replay()` re-runs
+        it on whatever the buffers hold, `replay(other_scene)` loads another frame of the same layout first."""
         from heal_amd import ops
         dir_args = self.post.params.get("dir_args", {"dir_offset": 0.7853, "num_bins": 2})
         anchors = self.post._anchors_f32(self.anchor_box, self.device)
+        self._static_in = static = StaticInputs(scene, slack)
 
         def body():
-            out = self.model(scene.model_input())
+            out = self.model(static.model_input())
             return ops.decode_nms(out["cls_preds"], out["reg_preds"], out.get("dir_preds"), anchors,
                                   self.post.params["target_args"]["score_threshold"], dir_args["dir_offset"],
                                   dir_args["num_bins"], self.post.params["nms_thresh"],
@@ -156,27 +230,31 @@ class ScenePipeline:
         for _ in range(warmup):
             body()
         cur.synchronize()
-        self.check_sparse_capacity()
+        ops.verify_sparse_capacity()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=cur):
             self._static_out = body()
+        # the capacity counters written inside the graph live in its private pool: keep them to re-check after every replay
+        self._graph_checks = ops.take_sparse_checks()
         self._graph = graph
         return graph
 
     def check_sparse_capacity(self):
         """SECOND encoders fed with device point clouds size their strided layers by capacity (no host round trip);
         this host-side check (it synchronises) raises if any layer found more active sites than its capacity."""
-        for name, mod in self.model.named_modules():
-            t = getattr(mod, "last_sparse", None)
-            if t is not None and t.overflow():
-                raise RuntimeError(f"{name}: a strided sparse layer produced more active sites than its capacity "
-                                   "(feed exact-size voxel inputs, or raise the capacity policy in SparseTensor.out_sites)")
+        from heal_amd import ops
+        ops.verify_sparse_capacity(getattr(self, "_graph_checks", None))
 
-    def replay(self):
-        """Replay the captured step; returns (pred_box3d | None, scores | None) like step()."""
+    def replay(self, scene=None):
+        """Replay the captured step -- on `scene` (loaded into the static input buffers first) or on whatever the buffers
+        hold; returns (pred_box3d | None, scores | None) like step()."""
+        if scene is not None:
+            self._static_in.load(scene)
         self._graph.replay()
         corners, scores, count = self._static_out
         k = int(count.item())
+        if self._graph_checks:   # after the sync above: a denser frame than the capacity policy allows must not pass silently
+            self.check_sparse_capacity()
         if k == 0:
             return None, None
         return corners[:k], scores[:k]

@@ -106,7 +106,12 @@ int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* 
  *           mask (pyramid_fuse.py:147-162).
  *   feats  [n_agents,C,H,W]; occ [n_agents,1,H,W] (logits of single_head_i)
  *   affine_host: host, n_agents*6 doubles = rows of affine_matrix[b][0, a] (2x3) from
- *                normalize_pairwise_tfm (opencood/utils/transformation_utils.py:68-92)
+ *                normalize_pairwise_tfm (opencood/utils/transformation_utils.py:68-92); may be NULL
+ *                when affine_dev is given
+ *   affine_dev:  the same rows in DEVICE memory, or NULL.  When non-NULL the kernel reads the poses
+ *                at run time (the reference keeps pairwise_t_matrix on the device too,
+ *                train_utils.to_device): a HIP graph captured around the call then follows whatever
+ *                the buffer holds at replay time instead of freezing the captured frame's poses
  *   grid_f64: non-zero -> sampling grid computed in fp64 then rounded to fp32 (the reference's
  *             behaviour when pairwise_t_matrix is float64), zero -> fp32 throughout
  *   crop_host: host, n_agents*4 ints (h0,h1,w0,w1) rectangle where the camera score is KEPT
@@ -114,14 +119,14 @@ int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* 
  *   out    [C,H,W]
  * -----------------------------------------------------------------------------------------------*/
 int heal_warp_fuse(const float* feats, const float* occ, int n_agents, int channels, int H, int W,
-                   const double* affine_host, int grid_f64, const int32_t* crop_host,
-                   float* out, void* stream);
+                   const double* affine_host, const double* affine_dev, int grid_f64,
+                   const int32_t* crop_host, float* out, void* stream);
 
 /* Same operator split for agent-sharded execution: warp ONE agent's features and score
  * into the ego frame (rank-local, before the all-gather) ...                                      */
 int heal_warp_agent(const float* feat, const float* occ, int channels, int H, int W,
-                    const double* affine_host, int grid_f64, const int32_t* crop_host,
-                    float* feat_ego, float* score_ego, void* stream);
+                    const double* affine_host, const double* affine_dev, int grid_f64,
+                    const int32_t* crop_host, float* feat_ego, float* score_ego, void* stream);
 /* ... and fuse already-warped stacks (after the all-gather): -inf mask, softmax over agents, sum. */
 int heal_fuse_warped(const float* feats_ego, const float* scores_ego, int n_agents, int channels,
                      int H, int W, float* out, void* stream);

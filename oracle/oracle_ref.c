@@ -8,13 +8,14 @@
  *   - voxelisation  -> spconv (unpinned; 1.2.1 VoxelGeneratorV2 or 2.x Point2VoxelCPU3d), called at
  *     opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:46-68.   PARITY UNPINNED: restated
  *     from the library's published algorithm and pinned by known-answer tests
- *     written for this build (tests/test_oracle_voxelize.py).
+ *     written for this build (tests/test_host_cpu.py::test_oracle_voxelize_*).
  *   - rotated IoU   -> shapely==2.0.0 / GEOS, called at opencood/utils/common_utils.py:230-270 from
  *     opencood/utils/box_utils.py:693-738 (nms_rotated).  PARITY UNPINNED for the GEOS arithmetic;
  *     the control flow of nms_rotated is restated line by line, the geometry is a convex clip in
- *     fp64 checked against analytic cases and scipy (tests/test_oracle_nms.py).
+ *     fp64 checked against analytic cases and scipy (tests/test_host_cpu.py::test_oracle_quad_iou_*,
+ *     test_oracle_nms_control_flow).
  *
- * Build: gcc -O2 -ffp-contract=off -shared -fPIC (see oracle/build.py).
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC (see oracle/cref.py).
  */
 #include <math.h>
 #include <stdint.h>

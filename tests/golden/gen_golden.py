@@ -270,6 +270,121 @@ def gen_lss():
          **{f"cam_{k}": v for k, v in cam.items()})
 
 
+# --------------------------------------------------------------------------------------------------
+HETERO_CAMS = {"m2": (96, 128), "m4": (80, 96)}   # reduced final_dim (multiples of 32 / 16 so every Up stage lines up)
+
+
+def hetero_small_args(hy):
+    """BASELINE config 4 (MoreModality/HEAL/final_infer/m1m2m3m4.yaml) shrunk to +-25.6 m: m3 (spconv) removed, the
+    camera grid shrunk with the LiDAR range (crop ratio stays 2), small images."""
+    args = copy.deepcopy(hy["model"]["args"])
+    args.pop("m3", None)
+    replace_ranges(args, SMALL_RANGE)
+    for m, dim in HETERO_CAMS.items():
+        for gc in (args[m]["encoder_args"]["grid_conf"], args[m]["camera_mask_args"]["grid_conf"]):
+            gc["xbound"] = [-12.8, 12.8, 0.4]
+            gc["ybound"] = [-12.8, 12.8, 0.4]
+        args[m]["encoder_args"]["data_aug_conf"]["final_dim"] = list(dim)
+    return args
+
+
+class _CpuTorch:
+    """The reference hard-codes `.to(torch.device("cuda"))` in LiftSplatShoot.__init__ (heter_encoders.py:93-99); there is
+    no GPU in the build container.  Module-namespace proxy of `torch` whose `device()` always answers cpu -- harness only,
+    no arithmetic."""
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    @staticmethod
+    def device(*a, **k):
+        return torch.device("cpu")
+
+
+def hetero_small_inputs(agents, seed0=70):
+    """Scene inputs in the reference's collated layout for `agents` (list of modality names in scene order)."""
+    rng = _rng(seed0)
+    lidar = [i for i, m in enumerate(agents) if m == "m1"]
+    data = {"agent_modality_list": list(agents), "record_len": torch.tensor([len(agents)])}
+    arrays = {}
+    vf, vc, vn = small_lidar_inputs([seed0 + 1 + i for i in range(len(lidar))], n_points=7000)
+    data["inputs_m1"] = {"voxel_features": torch.from_numpy(vf), "voxel_coords": torch.from_numpy(vc),
+                         "voxel_num_points": torch.from_numpy(vn)}
+    arrays.update(voxel_features=vf, voxel_coords=vc, voxel_num_points=vn)
+    for m, (H, W) in HETERO_CAMS.items():
+        ids = [i for i, a in enumerate(agents) if a == m]
+        if not ids:
+            continue
+        rigs = []
+        for j, i in enumerate(ids):
+            rig = synth.camera_rig(seed0 + i, 4, H, W)
+            if j == 0:  # a non-trivial post augmentation (resize + crop offset) on the first agent of the modality
+                rig["post_rots"][:, 0, 0] = 0.9
+                rig["post_rots"][:, 1, 1] = 0.9
+                rig["post_trans"][:, 0] = 2.0
+                rig["post_trans"][:, 1] = -1.0
+            rigs.append(rig)
+        cam = {k: np.stack([r[k] for r in rigs]).astype(np.float32) for k in rigs[0]}
+        imgs = rng.standard_normal((len(ids), 4, 4, H, W)).astype(np.float32)
+        imgs[:, :, 3] = rng.uniform(1.0, 60.0, size=imgs[:, :, 3].shape).astype(np.float32)  # depth channel (metres)
+        cam["imgs"] = imgs
+        data[f"inputs_{m}"] = {k: torch.from_numpy(v.copy()) for k, v in cam.items()}
+        arrays.update({f"{m}_{k}": v for k, v in cam.items()})
+    poses = synth.agent_poses(seed0 + 9, len(agents), r_min=4.0, r_max=12.0)
+    pw = synth.pairwise_t_matrix(poses, 5)[None]
+    data["pairwise_t_matrix"] = torch.from_numpy(pw.copy())
+    arrays["pairwise"] = pw
+    return data, arrays
+
+
+def gen_hetero_small():
+    """BASELINE config 4 at reduced size through the REFERENCE's HeterPyramidCollab: LiDAR PointPillars agents + Lift-Splat
+    camera agents (EfficientNet-b0 and ResNet101 variants) + ConvNeXt aligners + camera crop/pad + PyramidFusion with the
+    camera crop mask.  Only the two third-party image trunks are stand-ins (oracle/trunks.py); the fixture
+    also keeps the camera encoders' intermediate tensors (depth logits, image features, pooled BEV map)."""
+    from oracle import trunks as T
+    lss = R.ref("opencood.models.sub_modules.lss_submodule")
+    he = R.ref("opencood.models.heter_encoders")
+    m = R.ref("opencood.models.heter_pyramid_collab")
+    lss.EfficientNet = T.EfficientNet
+    lss.resnet101 = T.resnet101
+    he.torch = _CpuTorch()
+    try:
+        hy = load_hypes("MoreModality/HEAL/final_infer/m1m2m3m4.yaml")
+        model = fill_module(m.HeterPyramidCollab(hetero_small_args(hy))).eval()
+    finally:
+        he.torch = torch
+    agents = ["m1", "m2", "m4", "m1"]
+    data, arrays = hetero_small_inputs(agents)
+    taps = {}
+
+    def tap(name):
+        def hook(_mod, _inp, out):
+            taps[name] = out.detach().numpy().copy()
+        return hook
+    hooks = []
+    for mm in ("m2", "m4"):
+        enc = getattr(model, f"encoder_{mm}")
+        hooks += [enc.camencode.depth_head.register_forward_hook(tap(f"{mm}_depth_logit")),
+                  enc.camencode.image_head.register_forward_hook(tap(f"{mm}_x_img")),
+                  enc.register_forward_hook(tap(f"{mm}_bev")),
+                  getattr(model, f"aligner_{mm}").register_forward_hook(tap(f"{mm}_aligned"))]
+    with torch.no_grad():
+        o = model(data)
+    for h in hooks:
+        h.remove()
+    out = dict(arrays)
+    out.update(taps)
+    out.update(cls=o["cls_preds"].numpy(), reg=o["reg_preds"].numpy(), dir=o["dir_preds"].numpy(),
+               agents=np.array(agents))
+    for i, occ in enumerate(o["occ_single_list"]):
+        out[f"occ{i}"] = occ.numpy()
+    for mm in ("m2", "m4"):
+        dl, gt = o[f"depth_items_{mm}"]
+        out[f"{mm}_depth_gt_indices"] = gt.numpy()
+    save("hetero_small", **out)
+
+
 def gen_fusion_small():
     fio = R.ref("opencood.models.fuse_modules.fusion_in_one")
     tu = R.ref("opencood.utils.transformation_utils")
@@ -538,6 +653,7 @@ def gen_pcdet_iou():
 GENS["pcdet_iou"] = gen_pcdet_iou
 GENS.update(GENS_EXTRA)
 GENS["oldstyle_small"] = gen_oldstyle_small
+GENS["hetero_small"] = gen_hetero_small
 
 
 if __name__ == "__main__":

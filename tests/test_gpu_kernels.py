@@ -276,13 +276,19 @@ def _cam_mats(cam):
     return LiftSplatShoot.camera_matrices(t["rots"], t["trans"], t["intrins"], t["post_rots"], t["post_trans"])
 
 
-def _pool_close(got, want, rtol=1e-3, atol=1e-4, max_bad_cells=2e-3):
-    """Per-cell sums must agree; a point that sits within one ulp of a cell edge may fall on the other
-    side of it in a different fp32 evaluation of the same geometry, so a tiny fraction of cells is
-    allowed to differ -- and then the TOTAL must still be conserved."""
+def _pool_close(got, want, rtol=1e-3, atol=1e-4, max_bad_cells=0, name="bev_pool"):
+    """Per-cell sums must agree.  `max_bad_cells` is an ABSOLUTE number of BEV cells allowed to differ (0 against the
+    reference's golden vector, whose geometry the kernel reproduces operation for operation; a stated handful against the
+    numpy oracle, whose 3x3 products are evaluated in another order so that a point within one ulp of a cell edge may land
+    in the neighbouring cell).  The count found is always recorded (tests/report.py) and printed on failure; the TOTAL per
+    channel must be conserved either way."""
+    from tests.report import note
     bad = ~np.isclose(got, want, rtol=rtol, atol=atol)
-    bad_cells = bad.any(axis=1).mean()
-    assert bad_cells <= max_bad_cells, f"{bad_cells:.2e} of the BEV cells differ"
+    n_bad = int(bad.any(axis=1).sum())
+    occupied = int((np.abs(want).sum(axis=1) > 0).sum())
+    note(name, bad_cells=n_bad, occupied_cells=occupied, allowed=int(max_bad_cells),
+         max_abs_err=float(np.abs(got - want).max()))
+    assert n_bad <= max_bad_cells, f"{n_bad} of {occupied} occupied BEV cells differ (allowed: {max_bad_cells})"
     np.testing.assert_allclose(got.sum(axis=(2, 3)), want.sum(axis=(2, 3)), rtol=2e-3, atol=1e-2)
 
 
@@ -294,7 +300,7 @@ def test_bev_pool_matches_reference_golden(golden):
     out = ops.bev_pool(dev(g["depth_logit"]), dev(g["feat"]), dev(g["frustum"]), _cam_mats(cam), B, N,
                        g["dx"].tolist(), g["bx"].tolist(), g["nx"].tolist()).cpu().numpy()
     assert out.shape == g["pooled"].shape
-    _pool_close(out, g["pooled"])
+    _pool_close(out, g["pooled"], max_bad_cells=0, name="bev_pool_reference_golden")
 
 
 @pytest.mark.parametrize("n_agents,C,final_dim", [(2, 128, (384, 512)), (1, 128, (336, 448)), (1, 16, (64, 96))])
@@ -316,7 +322,7 @@ def test_bev_pool_full_size_vs_oracle(n_agents, C, final_dim):
     x = lifted.reshape(n_agents, N, C, D, fH, fW).transpose(0, 1, 3, 4, 5, 2)
     ref = O.bev_pool(geom, x, dx, bx, nx)
     assert out.shape == ref.shape == (n_agents, C, 256, 256)
-    _pool_close(out, ref)
+    _pool_close(out, ref, max_bad_cells=8, name=f"bev_pool_full_size_{n_agents}_{C}_{final_dim[0]}")
     assert (out != 0).any(axis=1).sum() > 1000
 
 
@@ -388,7 +394,7 @@ def test_bev_pool_pitched_cameras_vs_oracle(path, monkeypatch):
     assert runs > 2 * N * D * fW, runs
     x = O.lift(depth_logit, feat).reshape(n_agents, N, C, D, fH, fW).transpose(0, 1, 3, 4, 5, 2)
     ref = O.bev_pool(geom, x, dx, bx, nx)
-    _pool_close(out, ref)
+    _pool_close(out, ref, max_bad_cells=8, name=f"bev_pool_pitched_{path}")
     assert (out != 0).any(axis=1).sum() > 1000
 
 
@@ -480,7 +486,11 @@ def test_second_encoder_vs_dense_oracle():
     sd = {k: t.cpu().numpy() for k, t in enc.state_dict().items()}
     ref = O.second_backbone(sd, "spconv_block.", O.mean_vfe(v, n), c, [41, 128, 128], 2)
     assert got.shape == ref.shape == (2, 128, 16, 16)
-    assert np.array_equal(got != 0, ref != 0) or np.mean((got != 0) != (ref != 0)) < 1e-3
+    # no separate "same non-zero mask" allowance: a wrong active site shows up as an O(1) value against a zero, which the
+    # absolute tolerance below catches; post-ReLU values within 2e-4 of zero are the only ones that may differ in sign
+    from tests.report import note
+    note("second_encoder_vs_dense_oracle", nonzero_mask_mismatch=int(((got != 0) != (ref != 0)).sum()),
+         max_abs_err=float(np.abs(got - ref).max()), ref_abs_max=float(np.abs(ref).max()))
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4)
     # the device point-cloud path gives the same result as the voxel path
     with torch.no_grad():
@@ -520,8 +530,13 @@ def test_sparse_device_counts_and_capacity_overflow_report():
     iso = np.array([[0, z, y, x] for z in (1, 5) for y in range(1, 30, 4) for x in range(1, 30, 4)], np.int32)
     t = ops.SparseTensor.from_unsorted(dev(np.ones((len(iso), 4), np.float32)), dev(iso), shape, 1,
                                        n_dev=torch.tensor([len(iso)], dtype=torch.int32).cuda())
+    ops.verify_sparse_capacity()          # everything recorded so far stayed within capacity: no error, list cleared
     _, _, cnt = t.out_sites(k, st, pd)
     assert int(cnt.item()) == 8 * len(iso) and t.overflow()
+    # ... and the violation reaches the next host synchronisation of the path as an exception, not as silently dropped sites
+    with pytest.raises(Exception, match="more than its capacity"):
+        ops.verify_sparse_capacity()
+    assert not ops.take_sparse_checks()   # verified checks are consumed
 
 
 # ---------------------------------------------------------------------------------------------- K7

@@ -1,7 +1,6 @@
-"""GPU tests written at the end of round 1 when the round's GPU budget was already spent: they have never run on a
-device.  They are marked xfail(strict=False) so that the suite reports them (XPASS = fine, XFAIL = a finding for round 2)
-without letting unverified TEST code fail the run; the code paths they cover are exercised with stand-in kernels by the
-CPU suite (tests/test_glue_cpu.py, tests/test_host_cpu.py).  Round 2: run them, fix what they find, drop the marker."""
+"""GPU tests of three late round-1 paths: the agent-sharded scene with camera agents (rank-local warp with the camera crop
+window), deferred label resolution on the device, and the voxel caps carried by deferred-mode inputs.  They passed on the
+device at the end of round 1 (GPUTEST_r01: XPASS) and are ordinary tests since round 2."""
 import os
 import socket
 
@@ -9,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="added without GPU budget left; to be verified in round 2")]
+pytestmark = pytest.mark.gpu
 
 SMALL_RANGE = [-25.6, -25.6, -3, 25.6, 25.6, 1]
 

@@ -255,6 +255,147 @@ def test_heterogeneous_collab_runs_all_modalities():
     assert [tuple(o.shape) for o in out["occ_single_list"]] == [(5, 1, 256, 256), (5, 1, 128, 128), (5, 1, 64, 64)]
 
 
+
+def _hetero_small_model_and_data(g):
+    from heal_amd import configs
+    agents = [str(a) for a in g["agents"]]
+    dims = {m: tuple(int(v) for v in g[f"{m}_imgs"].shape[-2:]) for m in ("m2", "m4")}
+    model = build(configs.heal_heter(("m1", "m2", "m4"), SMALL_RANGE, cam_bound=12.8, cam_dims=dims))
+    data = {"inputs_m1": {"voxel_features": dev(g["voxel_features"]), "voxel_coords": dev(g["voxel_coords"], torch.int32),
+                          "voxel_num_points": dev(g["voxel_num_points"], torch.int32)},
+            "agent_modality_list": agents, "record_len": torch.tensor([len(agents)]),
+            "pairwise_t_matrix": torch.from_numpy(g["pairwise"]).cuda()}
+    for m in ("m2", "m4"):
+        data[f"inputs_{m}"] = {k: dev(g[f"{m}_{k}"]) for k in ("imgs", "rots", "trans", "intrins", "post_rots", "post_trans")}
+    return model, data, agents
+
+
+def test_heterogeneous_collab_matches_reference(golden):
+    """BASELINE config 4 at reduced size (+-25.6 m, small images): m1 PointPillars agents + m2 (EfficientNet-b0) and m4
+    (ResNet101) Lift-Splat agents through HeterPyramidCollab vs the REFERENCE's own model (tests/golden/gen_golden.py::
+    gen_hetero_small; only the two third-party image trunks are stand-ins).  Pins row a9 (Up, heads, depth softmax, lift)
+    and the camera crop / crop-mask path against the reference, stage by stage."""
+    g = golden("hetero_small")
+    model, data, agents = _hetero_small_model_and_data(g)
+    taps = {}
+    hooks = []
+    for m in ("m2", "m4"):
+        enc = getattr(model, f"encoder_{m}")
+        hooks.append(enc.camencode.register_forward_hook(
+            lambda _m, _i, out, m=m: taps.update({f"{m}_depth_logit": out[1], f"{m}_x_img": out[2], f"{m}_items": out[0]})))
+        hooks.append(enc.register_forward_hook(lambda _m, _i, out, m=m: taps.update({f"{m}_bev": out})))
+        hooks.append(getattr(model, f"aligner_{m}").register_forward_hook(
+            lambda _m, _i, out, m=m: taps.update({f"{m}_aligned": out})))
+    with torch.no_grad():
+        out = model(data)
+    for h in hooks:
+        h.remove()
+    report = {}
+    for m in ("m2", "m4"):
+        for k in ("depth_logit", "x_img", "bev", "aligned"):
+            report[f"{m}_{k}"] = rel_err(taps[f"{m}_{k}"].cpu().numpy(), g[f"{m}_{k}"])
+        # the lift never materialises in this build: form softmax(depth) x features from OUR head outputs and compare with
+        # the reference's new_x recomputed from ITS head outputs (lss_submodule.py:131-134)
+        ours = taps[f"{m}_depth_logit"].softmax(1).unsqueeze(1) * taps[f"{m}_x_img"].unsqueeze(2)
+        ref = torch.from_numpy(g[f"{m}_depth_logit"]).softmax(1).unsqueeze(1) * torch.from_numpy(g[f"{m}_x_img"]).unsqueeze(2)
+        report[f"{m}_lift"] = rel_err(ours.cpu().numpy(), ref.numpy())
+        # occupied BEV cells must be the same set (geometry does not depend on the features)
+        occ_ours = (taps[f"{m}_bev"].abs().sum(1) > 0).cpu().numpy()
+        occ_ref = np.abs(g[f"{m}_bev"]).sum(1) > 0
+        assert int((occ_ours != occ_ref).sum()) == 0, (m, int((occ_ours != occ_ref).sum()))
+        items = taps[f"{m}_items"]
+        np.testing.assert_array_equal(items[1].cpu().numpy(), g[f"{m}_depth_gt_indices"])
+        assert f"depth_items_{m}" in out
+    for i in range(3):
+        report[f"occ{i}"] = rel_err(out["occ_single_list"][i].cpu().numpy(), g[f"occ{i}"])
+    for key, name in (("cls_preds", "cls"), ("reg_preds", "reg"), ("dir_preds", "dir")):
+        report[key] = rel_err(out[key].cpu().numpy(), g[name])
+    bad = {k: v for k, v in report.items() if not v < 1e-3}
+    assert not bad, (bad, report)
+
+
+
+def test_config5_second_v2xvit_composition_vs_oracle():
+    """BASELINE config 5 (SECOND encoders -> BaseBEVBackbone -> shrinker -> V2X-ViT -> heads, heter_model_baseline.py:155-236)
+    on a reduced grid (+-12.8 m, sparse shape [41,256,256]): the whole model on the GPU against the same model fed with the
+    ORACLE's SECOND encoder output (dense restatement of the sparse-conv rules).  The tail (backbone, shrinker, fusion,
+    heads) is pinned separately by the reference goldens of `baseline_small` / `fusion_small`; this test pins the composition:
+    batch order, height compression layout, device row counts feeding dense maps."""
+    from heal_amd import configs, synth
+    from oracle import cref
+    from oracle import oracle_np as O
+    r = [-12.8, -12.8, -3, 12.8, 12.8, 1]
+    model = build(configs.lidar_baseline("v2xvit", r, max_cav=5, modality="m3"))
+    pts = synth.lidar_frame(5)
+    pts = pts[(np.abs(pts[:, 0]) < 13) & (np.abs(pts[:, 1]) < 13)]
+    clouds = [np.ascontiguousarray(pts[b::3]) for b in range(3)]
+    vs, cs, ns = [], [], []
+    for b, p in enumerate(clouds):
+        v, c, n = cref.voxelize(p, r, [0.1, 0.1, 0.1], 5, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    v, c, n = np.concatenate(vs), np.concatenate(cs), np.concatenate(ns)
+    poses = synth.agent_poses(11, 3, r_min=2.0, r_max=6.0)
+    pw = torch.from_numpy(synth.pairwise_t_matrix(poses, 5)[None])
+    base = {"agent_modality_list": ["m3"] * 3, "record_len": torch.tensor([3]), "pairwise_t_matrix": pw}
+    with torch.no_grad():
+        out_vox = model(dict(base, inputs_m3={"voxel_features": dev(v), "voxel_coords": dev(c, torch.int32),
+                                               "voxel_num_points": dev(n, torch.int32)}))
+        out_pts = model(dict(base, inputs_m3={"points": [dev(p) for p in clouds]}))
+        enc_gpu = model.encoder_m3({"inputs_m3": {"points": [dev(p) for p in clouds]}}, "m3")
+    sd = {k: t.cpu().numpy() for k, t in model.state_dict().items()}
+    enc_ref = O.second_backbone(sd, "encoder_m3.spconv_block.", O.mean_vfe(v, n), c, [41, 256, 256], 3)
+    assert enc_ref.shape == tuple(enc_gpu.shape) == (3, 128, 32, 32)
+    np.testing.assert_allclose(enc_gpu.cpu().numpy(), enc_ref, rtol=2e-3, atol=2e-4)
+    enc_t = dev(enc_ref)
+    orig = model.encoder_m3.forward
+    model.encoder_m3.forward = lambda data_dict, modality_name: enc_t
+    try:
+        with torch.no_grad():
+            out_ref = model(dict(base, inputs_m3={}))
+    finally:
+        model.encoder_m3.forward = orig
+    for key in ("cls_preds", "reg_preds", "dir_preds"):
+        assert tuple(out_vox[key].shape)[2:] == (16, 16)
+        e = rel_err(out_vox[key].cpu().numpy(), out_ref[key].cpu().numpy())
+        assert e < 2e-3, (key, e)
+        # device point clouds (K1 on the GPU, device row counts) and host-sized voxel inputs give the same scene output
+        e2 = rel_err(out_pts[key].cpu().numpy(), out_vox[key].cpu().numpy())
+        assert e2 < 1e-4, (key, e2)
+
+
+def test_config5_second_v2xvit_full_scale_scene():
+    """BASELINE config 5 as a whole at full size: 8 SECOND agents, +-102.4 m, V2X-ViT fusion, decode + rotated NMS; eager step,
+    hipGraph replay of the same scene and replay on a DIFFERENT scene through the static input buffers."""
+    from heal_amd import configs
+    from heal_amd.pipeline import Scene, ScenePipeline
+    hypes = configs.lidar_baseline("v2xvit", max_cav=8, modality="m3")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pipe = ScenePipeline(hypes, "cuda:0", seed=0)
+        scene = Scene(8, seed=4, device="cuda:0", modalities=["m3"] * 8)
+        pipe.calibrate_cls_bias(scene)
+        with torch.no_grad():
+            out = pipe.forward(scene)
+        assert out["cls_preds"].shape == (1, 2, 256, 256) and out["reg_preds"].shape == (1, 14, 256, 256)
+        assert all(bool(torch.isfinite(out[k]).all()) for k in ("cls_preds", "reg_preds", "dir_preds"))
+        boxes, scores = pipe.step(scene)
+        assert boxes is not None and boxes.shape[1:] == (8, 3) and bool(torch.isfinite(boxes).all())
+        assert bool((scores[:-1] >= scores[1:]).all())
+        pipe.capture(scene)
+        b2, s2 = pipe.replay()
+        assert b2.shape == boxes.shape
+        np.testing.assert_allclose(s2.cpu().numpy(), scores.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        other = Scene(8, seed=19, device="cuda:0", modalities=["m3"] * 8)
+        eb, es = pipe.step(other)
+        rb, rs = pipe.replay(other)
+        assert (eb is None) == (rb is None)
+        if eb is not None:
+            assert rb.shape == eb.shape
+            np.testing.assert_allclose(rs.cpu().numpy(), es.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(rb.cpu().numpy(), eb.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    torch.cuda.synchronize()
+
+
 def test_box_utils_mirror_matches_reference_golden(golden):
     """opencood/utils/box_utils.py + common_utils.py helpers against the reference's own outputs
     stored by gen_decode: corners, projection, limit_period, the two box filters and nms_rotated (run by the reference

@@ -461,3 +461,22 @@ def test_inference_utils_mirror_contract():
     assert r["pred_score"] == ["ego"] and r["depth_items"] == 7
     assert iu.inference_no_fusion(batch, model, DS(), single_gt=True)["pred_score"] == ["ego"]
     assert iu.inference_no_fusion(batch, model, DS())["pred_score"] == ["cav1", "ego"]
+
+
+def test_deferred_validation_labels_are_not_zeroed_without_the_inference_switch(monkeypatch):
+    """tools/train.py validates with train=False datasets and computes the loss on their labels: the deferred mode must
+    pack the label inputs there too; only the explicit inference-only switch may hand out all-zero labels."""
+    from heal_amd import configs
+    from heal_amd.opencood.data_utils.post_processor import voxel_postprocessor as vp
+    monkeypatch.delenv("HEAL_INFERENCE_ONLY", raising=False)
+    hy = configs.lidar_pyramid(SMALL_RANGE)
+    gt = np.zeros((20, 7), np.float32)
+    gt[0] = [3, 4, -1, 1.6, 1.8, 4.0, 0.3]
+    mask = np.r_[1.0, np.zeros(19)].astype(np.float32)
+    val = vp.VoxelPostprocessor(dict(hy["postprocess"], defer_to_device=True), train=False)
+    anchors = val.generate_anchor_box()
+    out = val.generate_label(gt_box_center=gt, anchors=anchors, mask=mask)
+    assert "deferred_gt_box_center" in out and "pos_equal_one" not in out
+    inf = vp.VoxelPostprocessor(dict(hy["postprocess"], defer_to_device=True, inference_only=True), train=False)
+    out = inf.generate_label(gt_box_center=gt, anchors=anchors, mask=mask)
+    assert float(np.abs(out["pos_equal_one"]).sum()) == 0 and out["targets"].shape[-1] == 14

@@ -178,3 +178,54 @@ def test_label_path_oracle_bit_exact_vs_reference_golden(golden):
         np.testing.assert_array_equal(pos, g[f"{tag}_pos"])
         np.testing.assert_array_equal(neg, g[f"{tag}_neg"])
         np.testing.assert_allclose(tgt, g[f"{tag}_targets"], rtol=1e-12, atol=1e-12)
+
+
+# ---- BASELINE config 4 (heterogeneous scene) at reduced size: oracle model vs the REFERENCE's HeterPyramidCollab -----------
+def _hetero_small(golden):
+    from heal_amd import configs
+    from heal_amd.opencood.tools.train_utils import create_model
+    from tests.golden.detfill import fill_module
+    g = golden("hetero_small")
+    agents = [str(a) for a in g["agents"]]
+    dims = {m: tuple(int(v) for v in g[f"{m}_imgs"].shape[-2:]) for m in ("m2", "m4")}
+    hy = configs.heal_heter(("m1", "m2", "m4"), [-25.6, -25.6, -3, 25.6, 25.6, 1], cam_bound=12.8, cam_dims=dims)
+    sd = fill_module(create_model(hy)).state_dict()   # closed-form weights; key names == the reference's (checked at gen time)
+    data = {"agent_modality_list": agents, "pairwise_t_matrix": g["pairwise"],
+            "inputs_m1": {k: g[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+    for m in ("m2", "m4"):
+        data[f"inputs_{m}"] = {k: g[f"{m}_{k}"] for k in ("imgs", "rots", "trans", "intrins", "post_rots", "post_trans")}
+    return g, hy, sd, data
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_hetero_oracle_model_matches_reference(golden):
+    """oracle/model_ref.heter_pyramid_collab (trunks -> Up -> heads -> lift -> voxel pooling -> backbone -> ConvNeXt aligner ->
+    camera crop/pad -> pyramid with the camera crop mask -> heads) against the reference's own outputs, stage by stage."""
+    from oracle import model_ref
+    g, hy, sd, data = _hetero_small(golden)
+    taps = {}
+    out = model_ref.heter_pyramid_collab(sd, hy["model"]["args"], data, taps=taps)
+    rep = {}
+    for m in ("m2", "m4"):
+        for k in ("depth_logit", "x_img", "bev", "aligned"):
+            rep[f"{m}_{k}"] = _rel(taps[f"{m}_{k}"], g[f"{m}_{k}"])
+        assert np.array_equal(np.abs(taps[f"{m}_bev"]).sum(1) > 0, np.abs(g[f"{m}_bev"]).sum(1) > 0)
+    for i in range(3):
+        rep[f"occ{i}"] = _rel(out["occ_single_list"][i], g[f"occ{i}"])
+    for k, name in (("cls_preds", "cls"), ("reg_preds", "reg"), ("dir_preds", "dir")):
+        rep[k] = _rel(out[k], g[name])
+    bad = {k: v for k, v in rep.items() if not v < 1e-4}
+    assert not bad, (bad, rep)
+
+
+def test_hetero_oracle_model_from_trunk_boundary(golden):
+    """Same, started at the reference's (depth_logit, x_img) boundary: what is pinned does not depend on the unpinned trunks."""
+    from oracle import model_ref
+    g, hy, sd, data = _hetero_small(golden)
+    boundary = {m: (g[f"{m}_depth_logit"], g[f"{m}_x_img"]) for m in ("m2", "m4")}
+    out = model_ref.heter_pyramid_collab(sd, hy["model"]["args"], data, boundary=boundary)
+    for k, name in (("cls_preds", "cls"), ("reg_preds", "reg"), ("dir_preds", "dir")):
+        assert _rel(out[k], g[name]) < 1e-4, (k, _rel(out[k], g[name]))
