@@ -44,6 +44,8 @@ _SIGNATURES = {
     "heal_bev_pool_workspace": (c_size_t, [c_int] * 9),
     "heal_bev_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_bev_pool_pm_workspace": (c_size_t, [c_int] * 5),
+    "heal_bev_pool_pm": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "heal_mean_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_sort_workspace": (c_size_t, [c_int]),
     "heal_sp_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
@@ -71,7 +73,7 @@ _SIGNATURES = {
     "heal_camera_matrices": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     "heal_layernorm_nchw": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_void_p, c_void_p]),
     "heal_se_gate": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p, c_void_p]),
-    "heal_conv1x1": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
+    "heal_conv1x1": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p]),
     "heal_nms_quads_workspace": (c_size_t, [c_int]),
     "heal_nms_quads": (c_int, [c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "heal_window_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,

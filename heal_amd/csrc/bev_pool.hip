@@ -287,28 +287,41 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
     }
 }
 
-// ---- direct splat (default) -------------------------------------------------------------------------------
+// ---- fused lift + splat (default) --------------------------------------------------------------------------------
 // The sorted pipeline above costs ~10 dependent launches for 42 MB of algorithmic traffic.  The frustum has a
 // structure the sort ignores: along an image COLUMN (fixed camera, u, depth bin) the lifted points differ only in
 // the camera's vertical direction, which the one-cell-high BEV grid collapses -- the fH points of a column fall
-// into one or two cells ("runs").  One block owns (camera, u, a quarter of the depth bins):
-//   k_lss_mark   computes the cell keys of its points (lss_cell_key: the expression order of k_lss_keys, so the same
-//                keys), and for every run start zero-fills the cell's row and marks the cell in the cell->row map
-//                (plain idempotent stores: several blocks may zero the same row, nobody adds before the kernel ends)
-//   k_lss_splat  recomputes the keys, adds the depth softmax (same partial-sum partition as k_lss_keys -> same
-//                probabilities), stages the column's fH feature rows in LDS once, walks each (u, d) column along v
-//                accumulating p * feat in registers while the cell stays the same, and adds each finished run to
-//                the cell's row with hardware fp32 atomics (global_atomic_add_f32, no return).  A run is C
-//                CONSECUTIVE floats: a wave's atomic instruction covers whole cache lines (adding straight into the
-//                channel-major output -- one line per lane -- ran at ~16 G atomics/s and was no faster than the sort)
-//   k_canvas     (shared with K2) streams the [B, C*nz, ny, nx] output from the rows
-// ~12 k runs replace the 590 k-element sort, the segment pass and the tile reduce / combine.  Within a run the
-// order is v-ascending; ACROSS runs the order of the atomic adds is not fixed, so a cell fed by three or more runs
-// can differ by an ulp from call to call (the reference's `ranks.argsort()` is unstable and feeds a cumsum
-// difference: it has the same property).  HEAL_LSS_PATH=sorted selects the bit-reproducible pipeline.
-constexpr int LSS_DQ = 4;        // depth quarters per (camera, u) column
-constexpr int LSS_DPB = 16;      // depth bins per block at most (D <= 64)
+// into one or a few cells ("runs").  In the common case a (u, d) column is ONE run, so the column's result is a
+// matrix-vector product, and the 16 depth bins of a block share the feature rows:
+//     out[d, c] = sum_v P'[d, v] X[v, c],   P'[d, v] = p[d, v] where the point's cell is the column's MAIN cell (the
+// cell of its first valid point), 0 elsewhere -- a [16 x fH] x [fH x C] GEMM per block on v_mfma_f32_16x16x4_f32.
+// Points of a column that fall in another cell (a pitched camera; none for a level rig) are walked afterwards as runs
+// along v.
+//
+// TWO launches, no memset, no transposition, no separate mark pass:
+//   k_lss_scatter  block = (camera, u, 16 depth bins).  Input is the PIXEL-MAJOR head tensor [BN, fH*fW, C + D] the fused
+//                  image_head | depth_head convolution writes (heal_conv1x1 out_pixel_major): a pixel's C features and D
+//                  depth logits are one contiguous 704-B row, so every load is coalesced.  One wave per image row v:
+//                  lanes = depth bins, softmax by wave reductions (once per point), cell key of the block's bins in the
+//                  reference's fp32 operation order (lss_cell_key), the column GEMM on the matrix cores, then C
+//                  consecutive floats per column added to the cell's row with hardware fp32 atomics
+//                  (global_atomic_add_f32: whole cache lines per wave instruction) and the cell tagged flags[cell] = gen.
+//   k_lss_canvas   streams the [B, C*nz, ny, nx] output once (K2's canvas writer shape: 4 cells x CG channels per thread,
+//                  16-B stores) from the tagged rows and ZEROES every row slice it has read.
+// Scratch contract (heal_bev_pool_pm): `rows` is all-zero on entry and all-zero again on exit (self-cleaning), flags hold
+// the tag (generation + 1) of the call that last touched a cell, state = {generation, block ticket}: the last block of
+// k_lss_canvas bumps the generation, so nothing is ever memset.  Order of the atomic adds across columns is not fixed:
+// a cell fed by three or more columns can differ by an ulp from call to call (the reference's unstable `argsort` feeding a
+// cumsum difference has the same property); HEAL_LSS_PATH=sorted selects the bit-reproducible pipeline.
 constexpr uint32_t LSS_NOKEY = 0xFFFFFFFFu;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int LSS_MT = 16;  // depth bins per block = MFMA M
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 // get_geometry + the voxel_pooling index of one lifted point (heter_encoders.py:125-147, :170-186), fp32, the
 // operation order of the reference (and of k_lss_keys)
@@ -335,169 +348,16 @@ __device__ __forceinline__ uint32_t lss_cell_key(const CamMats& cm, const float*
     return LSS_NOKEY;
 }
 
-// keys of the block's (u, depth quarter) slab into LDS: thread (v, part) takes the bins part, part+4, ...
-__device__ __forceinline__ void lss_slab_keys(const float* __restrict__ frustum, const CamMats* __restrict__ cams,
-                                              const LssGeom& g, int bn, int u, int db0, int nd,
-                                              uint32_t (*pk_key)[64]) {
-    const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
-    if (v >= g.fH) return;
-    const int HW = g.fH * g.fW, pix = v * g.fW + u;
-    const CamMats cm = cams[bn];
-    for (int dl = part; dl < nd; dl += 4)
-        pk_key[dl][v] = lss_cell_key(cm, frustum + ((size_t)(db0 + dl) * HW + pix) * 3, g, bn / g.n_cams);
-}
-
-__global__ __launch_bounds__(256) void k_lss_mark(const float* __restrict__ frustum, const CamMats* __restrict__ cams,
-                                                 LssGeom g, float* __restrict__ rows, int* __restrict__ cell_map) {
-    __shared__ uint32_t pk_key[LSS_DPB][64];
-    const int u = blockIdx.x / LSS_DQ, dq = blockIdx.x % LSS_DQ, bn = blockIdx.y;
-    const int dper = (g.D + 3) / 4;
-    const int db0 = dq * dper, nd = min(db0 + dper, g.D) - db0;
-    lss_slab_keys(frustum, cams, g, bn, u, db0, nd, pk_key);
-    __syncthreads();
-    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;
-    for (int dl = part; dl < nd; dl += 4) {
-        const uint32_t key = l < g.fH ? pk_key[dl][l] : LSS_NOKEY;
-        const uint32_t prev = (l > 0 && l < g.fH) ? pk_key[dl][l - 1] : LSS_NOKEY;
-        unsigned long long starts = __ballot(key != LSS_NOKEY && key != prev);
-        while (starts) {
-            const int src = __builtin_ctzll(starts);
-            starts &= starts - 1;
-            const uint32_t cell = __shfl(key, src, 64);
-            float* r = rows + (size_t)cell * g.C;
-            for (int c = l; c < g.C; c += 64) r[c] = 0.f;
-            if (l == 0) cell_map[cell] = (int)cell;
-        }
-    }
-}
-
-template <int CPL>
-__global__ __launch_bounds__(256) void k_lss_splat(const float* __restrict__ depth_logit,
-                                                  const float* __restrict__ featT /*[BN,HW,C]*/,
-                                                  const float* __restrict__ frustum,
-                                                  const CamMats* __restrict__ cams, LssGeom g,
-                                                  float* __restrict__ rows) {
-    __shared__ float red[4][64];
-    __shared__ float pk_p[LSS_DPB][64];
-    __shared__ uint32_t pk_key[LSS_DPB][64];
-    extern __shared__ float4 xs4[];  // [fH][C]
-    const float* xs = reinterpret_cast<const float*>(xs4);
-
-    const int HW = g.fH * g.fW;
-    const int u = blockIdx.x / LSS_DQ, dq = blockIdx.x % LSS_DQ, bn = blockIdx.y;
-    const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const bool live = v < g.fH;
-    const int dper = (g.D + 3) / 4;  // the softmax partition of k_lss_keys (identical partial sums)
-    const int db0 = dq * dper, nd = min(db0 + dper, g.D) - db0;
-
-    // this thread's logits: pixel (v, u), bins [part*dper, ...) -- read once, kept in registers
-    float lgr[LSS_DPB];
-    {
-        const float* lg = depth_logit + (size_t)bn * g.D * HW + (live ? v * g.fW + u : 0);
-        const int d0 = part * dper;
-#pragma unroll
-        for (int i = 0; i < LSS_DPB; ++i)
-            lgr[i] = (live && i < dper && d0 + i < g.D) ? lg[(size_t)(d0 + i) * HW] : -INFINITY;
-    }
-    // stage the column's feature rows
-    {
-        const int c4n = g.C / 4;
-        const float4* src = reinterpret_cast<const float4*>(featT);
-        for (int i = threadIdx.x; i < g.fH * c4n; i += 256) {
-            const int r = i / c4n, c4 = i - r * c4n;
-            xs4[i] = src[((size_t)bn * HW + (size_t)r * g.fW + u) * c4n + c4];
-        }
-    }
-    lss_slab_keys(frustum, cams, g, bn, u, db0, nd, pk_key);
-    // softmax over depth (lss_submodule.py:130): max, exp, normalise -- sequential over the bins of a part, parts
-    // combined as ((r0 + r1) + r2) + r3, like k_lss_keys
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < LSS_DPB; ++i) mx = fmaxf(mx, lgr[i]);
-    red[part][v] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0][v], red[1][v]), fmaxf(red[2][v], red[3][v]));
-    __syncthreads();
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < LSS_DPB; ++i)
-        if (lgr[i] != -INFINITY) sum += expf(lgr[i] - mx);
-    red[part][v] = sum;
-    __syncthreads();
-    const float den = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
-    if (part == dq && live) {
-#pragma unroll
-        for (int i = 0; i < LSS_DPB; ++i)
-            if (i < nd) pk_p[i][v] = expf(lgr[i] - mx) / den;
-    }
-    __syncthreads();
-
-    // one wave per (u, d) column: runs along v
-    const int l = threadIdx.x & 63;
-    for (int dl = part; dl < nd; dl += 4) {
-        float acc[CPL];
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
-        uint32_t cur = LSS_NOKEY;
-        auto flush = [&]() {
-            if (cur == LSS_NOKEY) return;
-            float* o = rows + (size_t)cur * g.C;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const int c = l + 64 * k;
-                if (c < g.C) unsafeAtomicAdd(o + c, acc[k]);
-                acc[k] = 0.f;
-            }
-        };
-        for (int v0 = 0; v0 < g.fH; v0 += 4) {
-            uint32_t key[4];
-            float p[4], x[4][CPL];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int vv = min(v0 + t, g.fH - 1);
-                key[t] = (v0 + t < g.fH) ? pk_key[dl][vv] : LSS_NOKEY;
-                p[t] = pk_p[dl][vv];
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int c = l + 64 * k;
-                    x[t][k] = c < g.C ? xs[vv * g.C + c] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (key[t] != cur) {
-                    flush();
-                    cur = key[t];
-                }
-                if (cur != LSS_NOKEY) {
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) acc[k] += p[t] * x[t][k];
-                }
-            }
-        }
-        flush();
-    }
-}
-
-// ---- the same splat on the matrix cores ------------------------------------------------------------------------
-// k_lss_splat spends its time issuing the v-walk on the vector ALUs (~12 instructions per lifted point).  In the
-// common case a (u, d) column is ONE run, so the column's result is a matrix-vector product, and the 16 depth bins
-// of a block share the feature rows:  out[d, c] = sum_v P'[d, v] X[v, c]  with  P'[d, v] = p[d, v] where the point's
-// cell is the column's MAIN cell (the cell of its first valid point) and 0 elsewhere -- a [16 x fH] x [fH x C] GEMM
-// per block on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate).  Points of a column that fall in another cell
-// (a pitched camera; none for a level rig) are walked afterwards exactly like k_lss_splat does, main-cell points
-// skipped.  One block = (camera, u, 16 depth bins); wave w owns the channel tiles w, w+4, ...
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int LSS_MT = 16;  // depth bins per block = MFMA M
-
-__global__ __launch_bounds__(256) void k_lss_splat_mfma(const float* __restrict__ depth_logit,
-                                                       const float* __restrict__ featT /*[BN,HW,C]*/,
-                                                       const float* __restrict__ frustum,
-                                                       const CamMats* __restrict__ cams, LssGeom g, int n_dt,
-                                                       float* __restrict__ rows) {
-    __shared__ float red[4][64];
+// The frustum of create_frustum (heter_encoders.py:110-123) is separable -- frustum[d][v][u] = (xs[u], ys[v], ds[d]) --
+// and is read as such (three short axes instead of D*fH*fW strided triples); the host wrapper verifies the property once
+// per frustum tensor and takes the sorted pipeline for anything else.
+__global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
+                                                    const float* __restrict__ frustum,
+                                                    const CamMats* __restrict__ cams, LssGeom g, int n_dt,
+                                                    float* __restrict__ rows, int* __restrict__ flags,
+                                                    const int* __restrict__ state) {
     __shared__ float pk_p[LSS_MT][64];       // p[dl][v] (unmasked; the leftover walk reads it)
-    __shared__ uint32_t pk_key[LSS_MT][64];  // key[dl][v]
+    __shared__ uint32_t pk_key[LSS_MT][64];  // key[dl][v]; NOKEY for v >= fH and bins >= D
     __shared__ float pT[64][LSS_MT];         // P'[v][dl]: A operand, v-major so that a fragment read is conflict-free
     __shared__ uint32_t mk[LSS_MT];          // main cell of column dl
     __shared__ int has_left[LSS_MT];
@@ -506,59 +366,52 @@ __global__ __launch_bounds__(256) void k_lss_splat_mfma(const float* __restrict_
 
     const int HW = g.fH * g.fW;
     const int u = blockIdx.x / n_dt, dt = blockIdx.x % n_dt, bn = blockIdx.y;
-    const int v = threadIdx.x & 63, part = threadIdx.x >> 6, l = v;
-    const bool live = v < g.fH;
-    const int pix = live ? v * g.fW + u : 0;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int LD = g.C + 16;                 // LD % 64 == 16: the 4 k-rows of a B fragment hit disjoint bank groups
     const int fH4 = (g.fH + 3) & ~3;
+    const int gen = state[0] + 1;  // tag of this call: >= 1, a zero-filled flag array matches nothing
+    const float* __restrict__ hcol = head + ((size_t)bn * HW + u) * CT;  // pixel (v, u) = hcol + v * fW * CT
 
-    // this thread's logits: pixel (v, u), bins part, part + 4, ... -- read once, kept in registers
-    float lgr[16];
-    {
-        const float* lg = depth_logit + (size_t)bn * g.D * HW + pix;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = part + 4 * i;
-            lgr[i] = (live && d < g.D) ? lg[(size_t)d * HW] : -INFINITY;
-        }
-    }
-    // stage the column's feature rows (rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop)
+    // stage the column's feature rows: 512-B contiguous runs (rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop)
     {
         const int c4n = g.C / 4, ld4 = LD / 4;
-        const float4* src = reinterpret_cast<const float4*>(featT);
         for (int i = threadIdx.x; i < fH4 * c4n; i += 256) {
             const int r = i / c4n, c4 = i - r * c4n;
-            xs4[r * ld4 + c4] = r < g.fH ? src[((size_t)bn * HW + (size_t)r * g.fW + u) * c4n + c4]
+            xs4[r * ld4 + c4] = r < g.fH ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
                                          : float4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // cell keys of the block's 16 bins: thread (v, part) takes dl = part, part + 4, part + 8, part + 12
-    uint32_t mykey[4];
+    // one wave per image row v, lanes = depth bins: softmax over depth (lss_submodule.py:130) by wave reductions -- every
+    // logit is read once, coalesced -- and the cell keys of the block's 16 bins
     {
         const CamMats cm = cams[bn];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int dl = part + 4 * j, d = dt * LSS_MT + dl;
-            mykey[j] = (live && d < g.D) ? lss_cell_key(cm, frustum + ((size_t)d * HW + pix) * 3, g, bn / g.n_cams)
-                                         : LSS_NOKEY;
-            pk_key[dl][v] = mykey[j];
+        const int dl = l - dt * LSS_MT;
+        const bool mine = dl >= 0 && dl < LSS_MT;
+        const float fr_x = frustum[(size_t)u * 3 + 0];
+        const float fr_d = l < g.D ? frustum[(size_t)l * HW * 3 + 2] : 0.f;
+        for (int v = wave; v < 64; v += 4) {
+            float p = 0.f;
+            uint32_t key = LSS_NOKEY;
+            if (v < g.fH) {  // wave-uniform
+                const float lg = l < g.D ? hcol[(size_t)v * g.fW * CT + g.C + l] : -INFINITY;
+                const float mx = wave_max(lg);
+                const float e = l < g.D ? expf(lg - mx) : 0.f;
+                const float den = wave_sum(e);
+                p = e / den;
+                if (mine && l < g.D) {
+                    const float fr[3] = {fr_x, frustum[(size_t)v * g.fW * 3 + 1], fr_d};
+                    key = lss_cell_key(cm, fr, g, bn / g.n_cams);
+                }
+            }
+            if (mine) {
+                pk_key[dl][v] = key;
+                pk_p[dl][v] = key != LSS_NOKEY ? p : 0.f;
+            }
         }
     }
-    // softmax over depth (lss_submodule.py:130)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, lgr[i]);
-    red[part][v] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0][v], red[1][v]), fmaxf(red[2][v], red[3][v]));
-    __syncthreads();
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (lgr[i] != -INFINITY) sum += expf(lgr[i] - mx);
-    red[part][v] = sum;
-    // main cell of each column: the cell of its first valid point (keys were written before the barriers above)
-    for (int dl = part; dl < LSS_MT; dl += 4) {
+    // main cell of each column: the cell of its first valid point; tag it
+    for (int dl = wave; dl < LSS_MT; dl += 4) {
         const uint32_t key = pk_key[dl][l];
         const unsigned long long valid = __ballot(key != LSS_NOKEY);
         const uint32_t m = valid ? __shfl(key, __builtin_ctzll(valid), 64) : LSS_NOKEY;
@@ -566,30 +419,26 @@ __global__ __launch_bounds__(256) void k_lss_splat_mfma(const float* __restrict_
         if (l == 0) {
             mk[dl] = m;
             has_left[dl] = left != 0ull;
+            if (m != LSS_NOKEY) flags[m] = gen;
         }
     }
     __syncthreads();
-    const float den = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
-    // probabilities of the block's bins: bin d = 16 dt + dl sits in lgr[4 dt + (dl >> 2)] of the thread with
-    // part == (dl & 3), i.e. this thread's own dl = part + 4 j
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if ((i >> 2) != dt) continue;  // block-uniform
-        const int j = i & 3, dl = part + 4 * j;
-        const float p = (live && lgr[i] != -INFINITY) ? expf(lgr[i] - mx) / den : 0.f;
-        pk_p[dl][v] = p;
-        pT[v][dl] = (mykey[j] != LSS_NOKEY && mykey[j] == mk[dl]) ? p : 0.f;
+    for (int j = 0; j < 4; ++j) {
+        const int dl = wave + 4 * j;
+        const uint32_t key = pk_key[dl][l];
+        pT[l][dl] = (key != LSS_NOKEY && key == mk[dl]) ? pk_p[dl][l] : 0.f;
     }
     __syncthreads();
 
-    // GEMM: D[dl, c] = sum_v P'[v][dl] X[v][c]
+    // GEMM: D[dl, c] = sum_v P'[v][dl] X[v][c]; wave w owns the channel tiles w, w+4, ...
     const int lk = l >> 4, ln = l & 15;
     const int ksteps = fH4 / 4;  // <= 16
     float afr[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) afr[ks] = ks < ksteps ? pT[ks * 4 + lk][ln] : 0.f;
     const int n_tiles = g.C / 16;
-    for (int nt = part; nt < n_tiles; nt += 4) {
+    for (int nt = wave; nt < n_tiles; nt += 4) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* xb = xs + lk * LD + nt * 16 + ln;
 #pragma unroll
@@ -604,7 +453,7 @@ __global__ __launch_bounds__(256) void k_lss_splat_mfma(const float* __restrict_
     }
 
     // leftovers: points of a column outside its main cell, walked as runs along v
-    for (int dl = part; dl < LSS_MT; dl += 4) {
+    for (int dl = wave; dl < LSS_MT; dl += 4) {
         if (!has_left[dl]) continue;
         const uint32_t skip = mk[dl];
         for (int c0 = 0; c0 < g.C; c0 += 64) {
@@ -615,12 +464,56 @@ __global__ __launch_bounds__(256) void k_lss_splat_mfma(const float* __restrict_
                 uint32_t key = vv < g.fH ? pk_key[dl][vv] : LSS_NOKEY;
                 if (key == skip) key = LSS_NOKEY;
                 if (key != cur) {
-                    if (cur != LSS_NOKEY && c < g.C) unsafeAtomicAdd(rows + (size_t)cur * g.C + c, acc);
+                    if (cur != LSS_NOKEY) {
+                        if (c < g.C) unsafeAtomicAdd(rows + (size_t)cur * g.C + c, acc);
+                        if (l == 0 && c0 == 0) flags[cur] = gen;
+                    }
                     acc = 0.f;
                     cur = key;
                 }
                 if (cur != LSS_NOKEY && c < g.C) acc += pk_p[dl][vv] * xs[vv * LD + c];
             }
+        }
+    }
+}
+
+// canvas[b][c][cell] = flags[b][cell] == gen ? rows[b*cells + cell][c] : 0, 4 cells x 4 channels per thread (one float4
+// row read per tagged cell, a 4x4 register transpose, four 16-B stores), the row slice zeroed behind the read.  The last
+// block to finish bumps the generation (state[0]) and resets the ticket (state[1]).
+__global__ __launch_bounds__(256) void k_lss_canvas(const int4* __restrict__ flags4, float* __restrict__ rows, int cells4,
+                                                   int channels, float4* __restrict__ canvas4, int* __restrict__ state,
+                                                   int total_blocks) {
+    const int gen = state[0] + 1;  // tag of this call: >= 1, a zero-filled flag array matches nothing
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z, c0 = blockIdx.y * 4;
+    if (t < cells4) {
+        const int4 f = flags4[(size_t)b * cells4 + t];
+        float4* out = canvas4 + ((size_t)b * channels + c0) * cells4 + t;
+        const bool h0 = f.x == gen, h1 = f.y == gen, h2 = f.z == gen, h3 = f.w == gen;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(h0 | h1 | h2 | h3)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[(size_t)c * cells4] = z;
+        } else {
+            float4* r = reinterpret_cast<float4*>(rows + ((size_t)b * cells4 * 4 + (size_t)t * 4) * channels + c0);
+            const size_t rs = channels / 4;  // float4 stride between consecutive cells' rows
+            const float4 a0 = h0 ? r[0] : z, a1 = h1 ? r[rs] : z, a2 = h2 ? r[2 * rs] : z, a3 = h3 ? r[3 * rs] : z;
+            out[0] = make_float4(a0.x, a1.x, a2.x, a3.x);
+            out[(size_t)cells4] = make_float4(a0.y, a1.y, a2.y, a3.y);
+            out[(size_t)2 * cells4] = make_float4(a0.z, a1.z, a2.z, a3.z);
+            out[(size_t)3 * cells4] = make_float4(a0.w, a1.w, a2.w, a3.w);
+            if (h0) r[0] = z;
+            if (h1) r[rs] = z;
+            if (h2) r[2 * rs] = z;
+            if (h3) r[3 * rs] = z;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // every block read `gen` (first statement) before it takes a ticket, so the bump cannot be observed by this launch
+        if (atomicAdd(&state[1], 1) == total_blocks - 1) {
+            state[1] = 0;
+            state[0] = gen;
         }
     }
 }
@@ -734,30 +627,6 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     HEAL_REQUIRE(carve(a, n_agents, n_cams, D, HW, channels, cells_total, w),
                  "bev_pool: workspace too small (%zu < %zu)", ws_bytes, a.off);
 
-    const char* path_env = getenv("HEAL_LSS_PATH");
-    const bool sorted_path = (path_env && strcmp(path_env, "sorted") == 0) || fH > 64 || D > 64 ||
-                             (size_t)(fH + 4) * (channels + 16) * sizeof(float) > 48 * 1024;  // static 14 KB + dynamic <= 64 KB of LDS
-    if (!sorted_path) {
-        HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
-        const dim3 grid(fW * LSS_DQ, n_agents * n_cams);
-        const CamMats* cm = reinterpret_cast<const CamMats*>(cam_mats);
-        k_lss_mark<<<grid, 256, 0, s>>>(frustum, cm, g, w.rows, w.cell_map);
-        k_lss_transpose<<<dim3(ceil_div(HW, 32), ceil_div(channels, 32), n_agents * n_cams), 256, 0, s>>>(
-            feat, channels, HW, w.featT);
-        if (path_env && strcmp(path_env, "walk") == 0) {  // the vector-ALU walk (kept for A/B: scripts/k4_bench.py)
-            const size_t lds = (size_t)fH * channels * sizeof(float);
-            if (channels <= 64) k_lss_splat<1><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
-            else if (channels <= 128) k_lss_splat<2><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
-            else k_lss_splat<4><<<grid, 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g, w.rows);
-        } else {
-            const int n_dt = ceil_div(D, LSS_MT);
-            const size_t lds = (size_t)((fH + 3) & ~3) * (channels + 16) * sizeof(float);
-            k_lss_splat_mfma<<<dim3(fW * n_dt, n_agents * n_cams), 256, lds, s>>>(depth_logit, w.featT, frustum, cm, g,
-                                                                                  n_dt, w.rows);
-        }
-        HEAL_LAUNCH_CHECK();
-        return heal_canvas_from_map(w.cell_map, w.rows, n_agents * g.nx[2], channels, g.nx[0] * g.nx[1], out, s);
-    }
     HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
     const uint32_t invalid_key = (uint32_t)cells_total;
     k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 64), 256, 0, s>>>(
@@ -784,4 +653,64 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     HEAL_LAUNCH_CHECK();
     // out [B, C*nz, ny, nx] viewed as B*nz maps of [C, ny*nx]
     return heal_canvas_from_map(w.cell_map, w.rows, n_agents * g.nx[2], channels, g.nx[0] * g.nx[1], out, s);
+}
+
+
+// ---- pixel-major entry point (the production path) ---------------------------------------------------------------------
+namespace heal {
+struct LssPmWs { float* rows; int* flags; int* state; };
+static bool carve_pm(Arena& a, int channels, int cells_total, LssPmWs& w) {
+    w.state = a.take<int>(64);                                   // {generation, block ticket}
+    w.flags = a.take<int>(cells_total);
+    w.rows = a.take<float>(((size_t)cells_total + 1) * channels);
+    return a.ok();
+}
+}  // namespace heal
+
+extern "C" size_t heal_bev_pool_pm_workspace(int n_agents, int channels, int nx, int ny, int nz) {
+    Arena a(nullptr, 0);
+    LssPmWs w;
+    carve_pm(a, channels, n_agents * nx * ny * nz, w);
+    return a.off + 256;
+}
+
+extern "C" int heal_bev_pool_pm(const float* head, int head_stride, const float* frustum, const float* cam_mats,
+                                int n_agents, int n_cams, int D, int fH, int fW, int channels, const float* dx_host,
+                                const float* bx_host, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
+                                void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n_agents >= 1 && n_cams >= 1 && D >= 1 && fH >= 1 && fW >= 1, "bev_pool_pm: bad shape");
+    HEAL_REQUIRE(channels >= 16 && channels <= 256 && channels % 16 == 0,
+                 "bev_pool_pm: channels must be a multiple of 16 in [16,256] (got %d)", channels);
+    HEAL_REQUIRE(fH <= 64 && D <= 64, "bev_pool_pm: fH and D must be <= 64 (got %d, %d): use heal_bev_pool", fH, D);
+    HEAL_REQUIRE(head_stride >= channels + D && head_stride % 4 == 0 && ((uintptr_t)head & 15) == 0,
+                 "bev_pool_pm: head rows must hold C + D floats, 16-B aligned (stride %d)", head_stride);
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "bev_pool_pm: workspace must be 256-B aligned");
+    const size_t lds = (size_t)((fH + 3) & ~3) * (channels + 16) * sizeof(float);
+    HEAL_REQUIRE(lds <= 48 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS budget: use heal_bev_pool", lds);
+    LssGeom g;
+    for (int k = 0; k < 3; ++k) {
+        g.dx[k] = dx_host[k];
+        g.lo[k] = bx_host[k] - dx_host[k] / 2.f;  // (self.bx - self.dx/2.) in fp32
+        g.nx[k] = nx_host[k];
+        HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool_pm: empty grid");
+    }
+    g.n_agents = n_agents; g.n_cams = n_cams; g.D = D; g.fH = fH; g.fW = fW; g.C = channels;
+    HEAL_REQUIRE((g.nx[0] * g.nx[1]) % 4 == 0, "bev_pool_pm: nx*ny must be a multiple of 4");
+    const int64_t cells_total64 = (int64_t)g.nx[0] * g.nx[1] * g.nx[2] * n_agents;
+    HEAL_REQUIRE(cells_total64 < (1ll << 30), "bev_pool_pm: problem too large");
+    const int cells_total = (int)cells_total64;
+    Arena a(ws, ws_bytes);
+    LssPmWs w;
+    HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_pool_pm: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    const int n_dt = ceil_div(D, LSS_MT);
+    k_lss_scatter<<<dim3(fW * n_dt, n_agents * n_cams), 256, lds, s>>>(head, head_stride, frustum,
+                                                                      reinterpret_cast<const CamMats*>(cam_mats), g, n_dt,
+                                                                      w.rows, w.flags, w.state);
+    const int cells4 = g.nx[0] * g.nx[1] / 4;
+    const dim3 grid(ceil_div(cells4, 256), channels / 4, n_agents * g.nx[2]);
+    k_lss_canvas<<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(w.flags), w.rows, cells4, channels,
+                                      reinterpret_cast<float4*>(out), w.state, (int)(grid.x * grid.y * grid.z));
+    HEAL_LAUNCH_CHECK();
+    return 0;
 }

@@ -28,7 +28,7 @@ template <int BM, int BN, int KC, int STRIDE>
 __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 const float* __restrict__ in_scale, int Cin, int Kpad, int Cout,
-                                                int HW, int Wo, int in_W, int in_HW, int act,
+                                                int HW, int Wo, int in_W, int in_HW, int act, int out_pm,
                                                 float* __restrict__ y) {
     // HW / Wo: OUTPUT pixels per image / per row; in_W / in_HW: input row width / pixels per image.  STRIDE 1: in == out.
     constexpr int MT = BM / 64;      // m-tiles per wave
@@ -132,6 +132,34 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             for (int ks = 0; ks < KS; ++ks) a_cur[mt][ks] = a_nxt[mt][ks];
     }
 
+    if (out_pm) {
+        // Pixel-major output y[n][pixel][Cout] (what K4's lift + BEV pool reads: one pixel's channels are one contiguous
+        // row).  MFMA leaves D[row = lk*4 + r][col = ln]: a lane holds 4 CONSECUTIVE channels of one pixel -> one 16-B
+        // store per (mt, nt), the four lk groups complete a 64-B run per pixel.  No residual in this layout.
+        float* __restrict__ yout = y + (size_t)n * HW * Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = m0 + (wave * MT + mt) * 16 + lk * 4;
+            if (co >= Cout) continue;  // Cout % 4 == 0 (host): a float4 is all-in or all-out
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int p = p0 + nt * 16 + ln;
+                if (p >= HW) continue;
+                float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z,
+                                       acc[mt][nt][3] + bv.w);
+                if (act == 1) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                } else if (act == 2) {
+                    v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
+                    v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+                }
+                *reinterpret_cast<float4*>(yout + (size_t)p * Cout + co) = v;
+            }
+        }
+        return;
+    }
     // Epilogue.  MFMA leaves D[row = lk*4 + r][col = ln] per (mt, nt): written directly, a store instruction covers 4 rows
     // x 64 B.  Instead each wave transposes its 16 x BN tile through its own LDS slice (the B buffers are free after the
     // last barrier) and streams float4 rows: BN*4-byte contiguous segments for the stores and the residual loads.
@@ -184,7 +212,7 @@ using namespace heal;
 
 extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
                             const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
-                            float* y, void* stream) {
+                            int out_pixel_major, float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv1x1: bad shape");
     HEAL_REQUIRE(stride == 1 || stride == 2, "conv1x1: stride must be 1 or 2 (got %d)", stride);
     const int kpad = (cin + 31) / 32 * 32, mpad = (cout + 63) / 64 * 64;  // dims of the zero-padded fragment layout
@@ -193,6 +221,10 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
     else HEAL_REQUIRE(Wo % 4 == 0, "conv1x1: output width must be a multiple of 4 for stride 2 (got %d)", Wo);
     HEAL_REQUIRE(act >= 0 && act <= 3, "conv1x1: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (GELU)");
     HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
+    if (out_pixel_major) {
+        HEAL_REQUIRE(residual == nullptr && act != 3, "conv1x1: pixel-major output takes no residual / GELU");
+        HEAL_REQUIRE(cout % 4 == 0 && ((uintptr_t)bias & 15) == 0, "conv1x1: pixel-major output needs Cout %% 4 == 0 and a 16-B aligned bias");
+    }
     hipStream_t s = (hipStream_t)stream;
     // Tile choice (BM, BN, KC).  Measured on MI355X at the PyramidFusion shapes (scripts/conv1x1_bench.py --sweep): the
     // smallest tile wins everywhere (64 channels x 64 pixels: 48 VGPR + 16 AGPR, 20 KB LDS -> 8 waves/SIMD); the kernel
@@ -207,7 +239,7 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
 #define HEAL_C1(BM_, BN_, KC_, ST_)                                                                              \
     if (bm == BM_ && bn == BN_ && kc == KC_ && stride == ST_) {                                                  \
         k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                    \
-            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, y);                \
+            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, y); \
         launched = true;                                                                                         \
     }
     bool launched = false;

@@ -172,9 +172,15 @@ class LiftSplatShoot(nn.Module):
         (heal_camera_matrices): [B,N,...] -> [B*N, 27] = rots @ inv(intrins) | inv(post_rots) | post_trans | trans | 0."""
         return ops.camera_matrices(rots, trans, intrins, post_rots, post_trans)
 
+    _pixel_major_pool = True
+
     def pool(self, depth_logit, x_img, cam_mats, B, N):
         return ops.bev_pool(depth_logit, x_img, self.frustum(x_img.device), cam_mats, B, N, self.dx_host,
                             self.bx_host, self.nx_host)
+
+    def pool_pixel_major(self, head, cam_mats, B, N, fH, fW):
+        return ops.bev_pool_pm(head, self.camC, self.D, fH, fW, self.frustum(head.device), cam_mats, B, N, self.dx_host,
+                               self.bx_host, self.nx_host)
 
     def forward(self, data_dict, modality_name):
         if self.training and torch.is_grad_enabled():
@@ -182,15 +188,19 @@ class LiftSplatShoot(nn.Module):
         inp = data_dict[f"inputs_{modality_name}"]
         x = inp["imgs"]
         B, N, C, imH, imW = x.shape
-        items, depth_logit, x_img = self.camencode(x.view(B * N, C, imH, imW))
+        res = self.camencode(x.view(B * N, C, imH, imW), pixel_major=self._pixel_major_pool)
         if self.depth_supervision:
-            self.depth_items = items
+            self.depth_items = res[0]
         cam = self.camera_matrices(inp["rots"], inp["trans"], inp["intrins"], inp["post_rots"], inp["post_trans"])
-        return self.pool(depth_logit.contiguous(), x_img.contiguous(), cam, B, N)
+        if len(res) == 2:   # (items, head): pixel-major fused heads -> K4 without a transposition pass
+            return self.pool_pixel_major(res[1], cam, B, N, imH // self.downsample, imW // self.downsample)
+        return self.pool(res[1].contiguous(), res[2].contiguous(), cam, B, N)
 
 
 class LiftSplatShootVoxel(LiftSplatShoot):
     """heter_encoders.py:244-301: max over the z bins instead of folding them into channels."""
+
+    _pixel_major_pool = False   # the z-max variant keeps the NCHW entry point
 
     def pool(self, depth_logit, x_img, cam_mats, B, N):
         out = super().pool(depth_logit, x_img, cam_mats, B, N)

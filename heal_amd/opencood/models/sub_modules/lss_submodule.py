@@ -195,6 +195,45 @@ class _CamEncodeBase(nn.Module):
             items = (depth_logit, self.gt_depth_indices(x) if x.shape[1] > 3 else None)
         return items, depth_logit, x_img
 
+    def _fused_head(self):
+        """image_head | depth_head as ONE [C + D, 512] pointwise weight (cached per parameter version)."""
+        hs = (self.image_head, self.depth_head)
+        key = tuple((h.weight.data_ptr(), h.weight._version, h.bias.data_ptr(), h.bias._version) for h in hs)
+        hit = self.__dict__.get("_heal_fused_head")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, torch.cat([h.weight for h in hs], 0).contiguous(), torch.cat([h.bias for h in hs], 0).contiguous())
+            self.__dict__["_heal_fused_head"] = hit  # plain attribute: not a parameter, not in the state_dict
+        return hit[1], hit[2]
+
+    def heads_pixel_major(self, features, x):
+        """The two 1x1 heads (lss_submodule.py:113,127) as one convolution that writes PIXEL-MAJOR [BN, fH*fW, C + D] (a pixel's
+        C image features, then its D depth logits: one contiguous row) -- the layout K4 (heal_bev_pool_pm) reads, so the lift
+        needs no transposition pass.  -> (depth_items | None, head).  `depth_items[0]` is the [BN,D,fH,fW] VIEW of the logits."""
+        from heal_amd import ops
+        w, b = self._fused_head()
+        head = ops.conv1x1(features, w, b, None, 0, pixel_major=True)
+        items = None
+        if self.depth_supervision:
+            BN, _, fH, fW = features.shape
+            depth_logit = head[:, :, self.C:].view(BN, fH, fW, self.D).permute(0, 3, 1, 2)
+            items = (depth_logit, self.gt_depth_indices(x) if x.shape[1] > 3 else None)
+        return items, head
+
+    def pixel_major_ok(self, features):
+        from heal_amd import ops
+        return (features.is_cuda and (self.C + self.D) % 4 == 0
+                and ops.conv1x1_supported(features.shape[1], self.C + self.D, int(features.shape[2] * features.shape[3]))
+                and ops.bev_pool_pm_supported(self.D, int(features.shape[2]), self.C))
+
+    def forward(self, x, pixel_major=False):
+        """x [BN, 3|4, H, W] -> (depth_items | None, depth_logit [BN,D,fH,fW], x_img [BN,C,fH,fW]); with pixel_major=True and
+        a shape the fused path takes: (depth_items | None, head [BN, fH*fW, C + D])."""
+        f = self.features(x)
+        if pixel_major and self.pixel_major_ok(f):
+            return self.heads_pixel_major(f, x)
+        return self.heads(f, x)
+
 
 class CamEncode(_CamEncodeBase):
     """lss_submodule.py:39-138 with the EfficientNet-b0 trunk."""
@@ -209,13 +248,13 @@ class CamEncode(_CamEncodeBase):
         self.depth_head = nn.Conv2d(512, self.D, kernel_size=1, padding=0)
         self.image_head = nn.Conv2d(512, self.C, kernel_size=1, padding=0)
 
-    def forward(self, x):
-        """x [BN, 3|4, H, W] -> (depth_items | None, depth_logit [BN,D,fH,fW], x_img [BN,C,fH,fW])."""
+    def features(self, x):
+        """lss_submodule.py:87-111: trunk endpoints -> Up (-> Up) -> [BN, 512, fH, fW]."""
         ep = self.trunk.endpoints(x[:, :3, :, :])
         f = self.up1(ep["reduction_5"], ep["reduction_4"])
         if self.downsample == 8:
             f = self.up2(f, ep["reduction_3"])
-        return self.heads(f, x)
+        return f
 
 
 class CamEncode_Resnet101(_CamEncodeBase):
@@ -242,11 +281,11 @@ class CamEncode_Resnet101(_CamEncodeBase):
         layers += [Bottleneck(planes * 4, planes, expansion=4) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def forward(self, x):
+    def features(self, x):
+        """lss_submodule.py:196-210: conv1 -> bn1 -> relu -> maxpool -> layer1 -> layer2 -> [BN, 512, fH, fW]."""
         _require_eval(self)
         f = ConvBN.run(x[:, :3, :, :], self.conv1, self.bn1, self._c, relu=True)
-        f = self.layer2(self.layer1(self.maxpool(f)))
-        return self.heads(f, x)
+        return self.layer2(self.layer1(self.maxpool(f)))
 
 
 class BevEncode(nn.Module):

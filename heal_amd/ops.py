@@ -451,10 +451,84 @@ def nms_quads(quads_sorted, thresh):
     return keep, count
 
 
+_ZWS = {}
+
+
+def _workspace_zeroed(key, nbytes, device):
+    """Scratch with a zero-on-entry / zero-on-exit contract (heal_bev_pool_pm): allocated zero-filled ONCE and then owned by
+    the operator, which leaves it clean after every call.  Outgrown buffers are retired, not freed (captured graphs)."""
+    k = (key, device.index)
+    buf = _ZWS.get(k)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
+        buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ZWS[k] = buf
+    return buf
+
+
+_FRUSTUM_OK = {}
+
+
+def _frustum_separable(frustum):
+    """True if frustum[d][v][u] == (xs[u], ys[v], ds[d]) -- what create_frustum builds (heter_encoders.py:110-123) and what
+    heal_bev_pool_pm assumes.  Checked once per tensor (a host sync; not during graph capture)."""
+    key = (frustum.data_ptr(), frustum._version, tuple(frustum.shape))
+    hit = _FRUSTUM_OK.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _capi.HealAmdError("bev_pool: first use of a frustum tensor inside a graph capture (run one eager step first)")
+        D, fH, fW, _ = frustum.shape
+        sep = torch.stack((frustum[0, 0, :, 0].view(1, 1, fW).expand(D, fH, fW),
+                           frustum[0, :, 0, 1].view(1, fH, 1).expand(D, fH, fW),
+                           frustum[:, 0, 0, 2].view(D, 1, 1).expand(D, fH, fW)), -1)
+        if len(_FRUSTUM_OK) > 64:
+            _FRUSTUM_OK.clear()
+        hit = (bool(torch.equal(sep, frustum)), frustum)  # keep the tensor alive: the key is its address
+        _FRUSTUM_OK[key] = hit
+    return hit[0]
+
+
+def bev_pool_pm_supported(D, fH, C):
+    import os
+    return (os.environ.get("HEAL_LSS_PATH", "") != "sorted" and fH <= 64 and D <= 64 and C % 16 == 0 and 16 <= C <= 256
+            and ((fH + 3) // 4 * 4) * (C + 16) * 4 <= 48 * 1024)
+
+
+def bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
+    """K4, production path.  head [n_agents*n_cams, fH*fW, >= C + D] f32 cuda, PIXEL-MAJOR: per pixel the C image features
+    followed by the D depth logits (what conv1x1(..., pixel_major=True) of the fused image_head | depth_head weight
+    writes); frustum [D,fH,fW,3]; cam_mats [n_agents*n_cams,27] -> [n_agents, C*nz, ny, nx]."""
+    head = _need(head, torch.float32, "head")
+    frustum = _need(frustum, torch.float32, "frustum")
+    cam_mats = _need(cam_mats, torch.float32, "cam_mats")
+    BN, HW, CT = (int(v) for v in head.shape)
+    if (BN != n_agents * n_cams or HW != fH * fW or CT < C + D or tuple(frustum.shape) != (D, fH, fW, 3)
+            or tuple(cam_mats.shape) != (BN, 27)):
+        raise _capi.HealAmdError("bev_pool_pm: inconsistent shapes")
+    if not bev_pool_pm_supported(D, fH, C) or not _frustum_separable(frustum):
+        raise _capi.HealAmdError("bev_pool_pm: shape / frustum outside the fused path (use bev_pool)")
+    nxi = [int(v) for v in nx]
+    dev = head.device
+    out = torch.empty((n_agents, C * nxi[2], nxi[1], nxi[0]), dtype=torch.float32, device=dev)
+    nbytes = _capi.query("heal_bev_pool_pm_workspace", n_agents, C, nxi[0], nxi[1], nxi[2])
+    # one scratch per problem shape: the zero-on-exit invariant holds for ONE carving of the buffer only
+    ws = _workspace_zeroed(("bev_pool_pm", n_agents, C, nxi[0], nxi[1], nxi[2]), nbytes, dev)
+    with _Timed("bev_pool"):
+        _capi.call("heal_bev_pool_pm", _ptr(head), CT, _ptr(frustum), _ptr(cam_mats), n_agents, n_cams, D, fH, fW, C,
+                   _host_array([float(v) for v in dx], ctypes.c_float),
+                   _host_array([float(v) for v in bx], ctypes.c_float),
+                   _host_array(nxi, ctypes.c_int32), _ptr(out), _ptr(ws), ws.numel(), _stream())
+    return out
+
+
 def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
-    """K4.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum [D,fH,fW,3]
-    (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,
-    trans 3, pad 3); dx,bx host float[3], nx host int[3] -> [n_agents, C*nz, ny, nx]."""
+    """K4 on the reference's NCHW tensors.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum
+    [D,fH,fW,3] (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,
+    trans 3, pad 3); dx,bx host float[3], nx host int[3] -> [n_agents, C*nz, ny, nx].
+
+    Shapes the fused path takes are re-laid pixel-major (one torch copy) and go through bev_pool_pm, the kernel the models
+    run; everything else (and HEAL_LSS_PATH=sorted) takes the bit-reproducible radix-sort pipeline."""
     depth_logit = _need(depth_logit, torch.float32, "depth_logit")
     feat = _need(feat, torch.float32, "feat")
     frustum = _need(frustum, torch.float32, "frustum")
@@ -465,6 +539,9 @@ def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx)
     cam_mats = _need(cam_mats, torch.float32, "cam_mats")
     if tuple(cam_mats.shape) != (BN, 27):
         raise _capi.HealAmdError("bev_pool: cam_mats must be [n_agents*n_cams, 27]")
+    if bev_pool_pm_supported(D, fH, C) and D % 4 == 0 and _frustum_separable(frustum):
+        head = torch.cat([feat, depth_logit], 1).permute(0, 2, 3, 1).reshape(BN, fH * fW, C + D).contiguous()
+        return bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx, nx)
     nxi = [int(v) for v in nx]
     dev = feat.device
     out = torch.empty((n_agents, C * nxi[2], nxi[1], nxi[0]), dtype=torch.float32, device=dev)
@@ -687,9 +764,10 @@ def conv1x1_supported(cin, cout, hw, stride=1, out_w=None):
     return stride == 2 and out_w is not None and out_w % 4 == 0 and hw >= 64
 
 
-def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1):
+def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixel_major=False):
     """Pointwise convolution with fused prologue / epilogue: act(W (in_scale . x) + bias (+ residual));
-    act 0 none | 1 ReLU | 2 SiLU; stride 1 | 2.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin]."""
+    act 0 none | 1 ReLU | 2 SiLU; stride 1 | 2.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin].
+    pixel_major=True: the result comes back as [n, Ho*Wo, Cout] (a pixel's channels contiguous) instead of NCHW."""
     x = _need(x, torch.float32, "x")
     n, cin, H, W = (int(v) for v in x.shape)
     cout = int(w.shape[0])
@@ -698,7 +776,14 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1):
     if int(w.shape[1]) != cin or not hard_ok:
         raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HxW={H}x{W} stride={stride}")
     frag = conv1x1_fragments(w)
-    y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if pixel_major:
+        if residual is not None or cout % 4 != 0:
+            raise _capi.HealAmdError("conv1x1: pixel-major output needs Cout % 4 == 0 and takes no residual")
+        y = torch.empty((n, Ho * Wo, cout), dtype=torch.float32, device=x.device)
+        if bias is not None:
+            bias = _need(bias, torch.float32, "bias")
+    else:
+        y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
         if tuple(residual.shape) != tuple(y.shape):
@@ -708,7 +793,7 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1):
     with _Timed(f"conv1x1_{cin}_{cout}" + ("_s2" if stride == 2 else "")):
         _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
                    _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
-                   n, cin, cout, H, W, int(stride), int(act), _ptr(y), _stream())
+                   n, cin, cout, H, W, int(stride), int(act), int(bool(pixel_major)), _ptr(y), _stream())
     return y
 
 

@@ -92,6 +92,8 @@ class StaticInputs:
     * `pairwise_t_matrix`: float64 [1,L,L,4,4] ON THE DEVICE -- the warp kernels read the poses at run time
       (heal_warp_fuse / heal_warp_agent `affine_dev`), so a replay uses the poses of the frame that was loaded."""
 
+    CAMERA_DIMS = Scene.CAMERA_DIMS
+
     def __init__(self, scene, slack=1.25, agents=None):
         """agents: restrict the sensor buffers to these agent ids (a rank of the agent-sharded job only feeds its own
         agents); the pose matrices are always held."""

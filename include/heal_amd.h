@@ -168,10 +168,17 @@ int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void
  *             upstream, so no host round trip is needed in the middle of the forward pass
  *   dx,bx host 3 floats each, nx host 3 ints (gen_dx_bx, camera_utils.py:129-134)
  *   out [n_agents, C*nz, ny, nx] f32, every element written
- *   Summation order: within one image column (camera, u, depth bin) fixed; across columns that feed the same cell the
- *   default path adds with fp32 hardware atomics, so results can differ in the last bit from call to call (like the
- *   reference's unstable argsort + cumsum difference).  Environment HEAL_LSS_PATH=sorted selects the bit-reproducible
- *   radix-sort pipeline (same interface, same workspace).
+ *   heal_bev_pool takes the reference's NCHW tensors and runs the bit-reproducible radix-sort pipeline (stable sort of
+ *   the 590 k lifted points by cell, segmented reduction in point order): any shape, ~10 launches.
+ *   heal_bev_pool_pm is the production path (two launches): `head` [n_agents*n_cams, fH*fW, head_stride] is the PIXEL-MAJOR
+ *   output of the fused image_head | depth_head convolution (heal_conv1x1 out_pixel_major): per pixel C image features
+ *   followed by D depth logits (head_stride >= C + D floats); fH <= 64, D <= 64, a separable frustum (frustum[d][v][u] =
+ *   (xs[u], ys[v], ds[d]), what create_frustum builds).  Within one image column (camera, u, depth bin) the summation
+ *   order is fixed; across columns that feed the same cell it adds with fp32 hardware atomics, so a result can differ in
+ *   the last bit from call to call (like the reference's unstable argsort + cumsum difference).
+ *   SCRATCH CONTRACT of heal_bev_pool_pm: `ws` must be ZERO-FILLED before its first use and must not be written by anyone
+ *   else; every call leaves it in the state the next call needs (rows zeroed behind the reads, generation-tagged flags),
+ *   so no memset is ever launched.
  * -----------------------------------------------------------------------------------------------*/
 /* heal_camera_matrices: the per-camera 3x3 algebra of get_geometry (heter_encoders.py:137-146): fills the `cam_mats`
  *   rows consumed by heal_bev_pool from rots/intrins/post_rots [n,3,3] and trans/post_trans [n,3] (all f32 device),
@@ -184,6 +191,10 @@ int heal_bev_pool(const float* depth_logit, const float* feat, const float* frus
                   const float* cam_mats, int n_agents, int n_cams, int D, int fH, int fW, int channels,
                   const float* dx_host, const float* bx_host, const int32_t* nx_host,
                   float* out, void* ws, size_t ws_bytes, void* stream);
+size_t heal_bev_pool_pm_workspace(int n_agents, int channels, int nx, int ny, int nz);
+int heal_bev_pool_pm(const float* head, int head_stride, const float* frustum, const float* cam_mats, int n_agents,
+                     int n_cams, int D, int fH, int fW, int channels, const float* dx_host, const float* bx_host,
+                     const int32_t* nx_host, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3  SECOND encoder: MeanVFE, sparse 3-D convolution (submanifold and strided), sparse -> dense BEV.
@@ -306,10 +317,13 @@ int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce
  *   second pixel); y/residual [n,Cout,Ho,Wo], Ho = (H-1)/stride+1; Ho*Wo % 4 == 0 (stride 1) or Wo % 4 == 0 (stride 2);
  *   in_scale [n,Cin] or NULL (per-image, per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU | 3 GELU (erf).
  *   weight_frag = W zero-padded to [Mpad = ceil64(Cout), Kpad = ceil32(Cin)] in MFMA A-fragment order
- *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)], mt < Mpad/16, ks < Kpad/4.                */
+ *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)], mt < Mpad/16, ks < Kpad/4.
+ *   out_pixel_major != 0: y is written as [n, Ho*Wo, Cout] (a pixel's channels contiguous; Cout % 4 == 0, no residual) --
+ *   the layout heal_bev_pool_pm reads, produced by the fused image_head | depth_head convolution of CamEncode
+ *   (lss_submodule.py:113-131) so that the lift never needs a transposition pass.                              */
 int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
-                 const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act, float* y,
-                 void* stream);
+                 const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
+                 int out_pixel_major, float* y, void* stream);
 
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265

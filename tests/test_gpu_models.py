@@ -281,8 +281,15 @@ def test_heterogeneous_collab_matches_reference(golden):
     hooks = []
     for m in ("m2", "m4"):
         enc = getattr(model, f"encoder_{m}")
-        hooks.append(enc.camencode.register_forward_hook(
-            lambda _m, _i, out, m=m: taps.update({f"{m}_depth_logit": out[1], f"{m}_x_img": out[2], f"{m}_items": out[0]})))
+        def cam_hook(mod, _i, out, m=m):
+            items, head = out          # production path: fused heads, pixel-major [BN, fH*fW, C + D]
+            BN, HW, _ = head.shape
+            fH, fW = items[0].shape[-2:]
+            taps.update({f"{m}_x_img": head[:, :, :mod.C].reshape(BN, fH, fW, mod.C).permute(0, 3, 1, 2),
+                         f"{m}_depth_logit": head[:, :, mod.C:].reshape(BN, fH, fW, mod.D).permute(0, 3, 1, 2),
+                         f"{m}_items": items})
+            assert torch.equal(items[0], taps[f"{m}_depth_logit"])
+        hooks.append(enc.camencode.register_forward_hook(cam_hook))
         hooks.append(enc.register_forward_hook(lambda _m, _i, out, m=m: taps.update({f"{m}_bev": out})))
         hooks.append(getattr(model, f"aligner_{m}").register_forward_hook(
             lambda _m, _i, out, m=m: taps.update({f"{m}_aligned": out})))
@@ -376,7 +383,8 @@ def test_config5_second_v2xvit_full_scale_scene():
         pipe.calibrate_cls_bias(scene)
         with torch.no_grad():
             out = pipe.forward(scene)
-        assert out["cls_preds"].shape == (1, 2, 256, 256) and out["reg_preds"].shape == (1, 14, 256, 256)
+        # 256^2 after the 8x sparse encoder, 128^2 after the stride-2 shrinker (m3's shrink_header, lidar_v2xvit-style YAML)
+        assert out["cls_preds"].shape == (1, 2, 128, 128) and out["reg_preds"].shape == (1, 14, 128, 128)
         assert all(bool(torch.isfinite(out[k]).all()) for k in ("cls_preds", "reg_preds", "dir_preds"))
         boxes, scores = pipe.step(scene)
         assert boxes is not None and boxes.shape[1:] == (8, 3) and bool(torch.isfinite(boxes).all())

@@ -77,6 +77,7 @@ import importlib, json, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, %r)
 os.environ["HEAL_DEFER_VOXELIZE"] = "1"      # DataLoader-worker mode: neither K1 nor the label assignment may touch the GPU
+os.environ["HEAL_INFERENCE_ONLY"] = "1"      # what examples/run_reference_tool.py sets for tools/inference*.py (labels never read)
 from tests.golden import ref_import as R
 R.install(stub_opencood_packages=False)
 for name in ("h5py", "tensorboardX"):
@@ -155,6 +156,7 @@ import numpy as np
 warnings.simplefilter("ignore")
 sys.path.insert(0, %r)
 os.environ["HEAL_DEFER_VOXELIZE"] = "1"
+os.environ["HEAL_INFERENCE_ONLY"] = "1"
 from tests.golden import ref_import as R
 R.install(stub_opencood_packages=False)
 for name in ("h5py", "tensorboardX"):
