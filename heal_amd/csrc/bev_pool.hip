@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
 //   k_lss_canvas   streams the [B, C*nz, ny, nx] output once (K2's canvas writer shape: 4 cells x CG channels per thread,
 //                  16-B stores) from the tagged rows and ZEROES every row slice it has read.
 // Scratch contract (heal_bev_pool_pm): `rows` is all-zero on entry and all-zero again on exit (self-cleaning), flags hold
-// the tag (generation + 1) of the call that last touched a cell, state = {generation, block ticket}: the last block of
-// k_lss_canvas bumps the generation, so nothing is ever memset.  Order of the atomic adds across columns is not fixed:
+// the tag of the call that last touched a cell, state = {generation, tag of the call in flight}: k_lss_scatter tags with
+// generation + 1 and publishes the tag, k_lss_canvas adopts it as the new generation, so nothing is ever memset.  Order of the atomic adds across columns is not fixed:
 // a cell fed by three or more columns can differ by an ulp from call to call (the reference's unstable `argsort` feeding a
 // cumsum difference has the same property); HEAL_LSS_PATH=sorted selects the bit-reproducible pipeline.
 constexpr uint32_t LSS_NOKEY = 0xFFFFFFFFu;
@@ -351,67 +351,132 @@ __device__ __forceinline__ uint32_t lss_cell_key(const CamMats& cm, const float*
 // The frustum of create_frustum (heter_encoders.py:110-123) is separable -- frustum[d][v][u] = (xs[u], ys[v], ds[d]) --
 // and is read as such (three short axes instead of D*fH*fW strided triples); the host wrapper verifies the property once
 // per frustum tensor and takes the sorted pipeline for anything else.
+//
+// Measured anatomy of the first version of this kernel (m2, 768 blocks, rocprofv3, scripts/k4_dbg.sh): loads 6.6 us,
+// softmax + keys 15.3 us, main cells 1.8 us, GEMM + atomics 3.4 us (the atomics themselves: 0.4 us).  The softmax was one
+// wave per image row with two ds_bpermute reductions per row and the keys ran on 16 of 64 lanes: a chain of dependent
+// long-latency instructions at 3 waves per SIMD.  Now: logits go through an LDS tile (coalesced 192-B rows in, one thread
+// per (pixel, quarter of the bins) out), the softmax is a register loop with two block reductions through LDS, and the 768
+// keys of a block are 3 independent evaluations per thread.
+constexpr int LSS_LGS = 65;   // LDS row stride of the logit tile (floats): lane v reads lgs[v][d] -> bank (v + d) % 32
+
 __global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
                                                     const float* __restrict__ frustum,
                                                     const CamMats* __restrict__ cams, LssGeom g, int n_dt,
                                                     float* __restrict__ rows, int* __restrict__ flags,
-                                                    const int* __restrict__ state) {
+                                                    int* __restrict__ state, int dbg) {
+    __shared__ float red[4][64];
     __shared__ float pk_p[LSS_MT][64];       // p[dl][v] (unmasked; the leftover walk reads it)
     __shared__ uint32_t pk_key[LSS_MT][64];  // key[dl][v]; NOKEY for v >= fH and bins >= D
     __shared__ float pT[64][LSS_MT];         // P'[v][dl]: A operand, v-major so that a fragment read is conflict-free
     __shared__ uint32_t mk[LSS_MT];          // main cell of column dl
     __shared__ int has_left[LSS_MT];
-    extern __shared__ float4 xs4[];          // X[fH4][C + 16]
+    extern __shared__ float4 xs4[];          // X[fH4][C + 16], then the logit tile lgs[fH][LSS_LGS]
     float* xs = reinterpret_cast<float*>(xs4);
 
     const int HW = g.fH * g.fW;
     const int u = blockIdx.x / n_dt, dt = blockIdx.x % n_dt, bn = blockIdx.y;
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int part = threadIdx.x >> 6, l = threadIdx.x & 63, v = l;
     const int LD = g.C + 16;                 // LD % 64 == 16: the 4 k-rows of a B fragment hit disjoint bank groups
     const int fH4 = (g.fH + 3) & ~3;
-    const int gen = state[0] + 1;  // tag of this call: >= 1, a zero-filled flag array matches nothing
+    float* lgs = xs + (size_t)fH4 * LD;
+    const int gen = state[0] + 1;            // tag of this call: >= 1, a zero-filled flag array matches nothing
     const float* __restrict__ hcol = head + ((size_t)bn * HW + u) * CT;  // pixel (v, u) = hcol + v * fW * CT
+    const bool live = v < g.fH;
 
-    // stage the column's feature rows: 512-B contiguous runs (rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop)
+    // stage the column's feature rows (512-B contiguous runs; rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop) and
+    // its logit rows (D contiguous floats per pixel).  ALL global loads of a thread are issued before the first LDS store:
+    // a load -> store loop with a run-time trip count serialises one HBM round trip per iteration (6.6 us of the first
+    // version of this kernel).
     {
-        const int c4n = g.C / 4, ld4 = LD / 4;
-        for (int i = threadIdx.x; i < fH4 * c4n; i += 256) {
+        const int c4n = g.C / 4, ld4 = LD / 4, nX = fH4 * c4n;
+        const int d4n = g.D / 4, nL = g.fH * d4n;   // D % 4 == 0 (host)
+        float4 xr[8], lr[4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = threadIdx.x + 256 * k, r = i / c4n, c4 = i - r * c4n;
+            xr[k] = (i < nX && r < g.fH) ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
+                                         : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, r = i / d4n, d4 = i - r * d4n;
+            lr[k] = i < nL ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + g.C + d4 * 4)
+                           : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = threadIdx.x + 256 * k, r = i / c4n, c4 = i - r * c4n;
+            if (i < nX) xs4[r * ld4 + c4] = xr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, r = i / d4n, d4 = i - r * d4n;
+            if (i < nL) {
+                float* dst = lgs + r * LSS_LGS + d4 * 4;
+                dst[0] = lr[k].x; dst[1] = lr[k].y; dst[2] = lr[k].z; dst[3] = lr[k].w;
+            }
+        }
+        for (int i = threadIdx.x + 2048; i < nX; i += 256) {   // C > 160: the rest of the feature rows
             const int r = i / c4n, c4 = i - r * c4n;
             xs4[r * ld4 + c4] = r < g.fH ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
                                          : float4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // one wave per image row v, lanes = depth bins: softmax over depth (lss_submodule.py:130) by wave reductions -- every
-    // logit is read once, coalesced -- and the cell keys of the block's 16 bins
+    // cell keys of the block's 16 bins: thread (v, part) takes dl = part, part + 4, part + 8, part + 12 (independent chains)
     {
         const CamMats cm = cams[bn];
-        const int dl = l - dt * LSS_MT;
-        const bool mine = dl >= 0 && dl < LSS_MT;
         const float fr_x = frustum[(size_t)u * 3 + 0];
-        const float fr_d = l < g.D ? frustum[(size_t)l * HW * 3 + 2] : 0.f;
-        for (int v = wave; v < 64; v += 4) {
-            float p = 0.f;
+        const float fr_y = live ? frustum[(size_t)v * g.fW * 3 + 1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dl = part + 4 * j, d = dt * LSS_MT + dl;
             uint32_t key = LSS_NOKEY;
-            if (v < g.fH) {  // wave-uniform
-                const float lg = l < g.D ? hcol[(size_t)v * g.fW * CT + g.C + l] : -INFINITY;
-                const float mx = wave_max(lg);
-                const float e = l < g.D ? expf(lg - mx) : 0.f;
-                const float den = wave_sum(e);
-                p = e / den;
-                if (mine && l < g.D) {
-                    const float fr[3] = {fr_x, frustum[(size_t)v * g.fW * 3 + 1], fr_d};
-                    key = lss_cell_key(cm, fr, g, bn / g.n_cams);
-                }
+            if (live && d < g.D) {
+                const float fr[3] = {fr_x, fr_y, frustum[(size_t)d * HW * 3 + 2]};
+                key = lss_cell_key(cm, fr, g, bn / g.n_cams);
             }
-            if (mine) {
-                pk_key[dl][v] = key;
-                pk_p[dl][v] = key != LSS_NOKEY ? p : 0.f;
-            }
+            pk_key[dl][v] = key;
         }
     }
     __syncthreads();
+    if (dbg & 16) return;
+    // softmax over depth (lss_submodule.py:130): thread (v, part) owns the bins [part * dper, part * dper + dper)
+    const int dper = (g.D + 3) / 4;          // <= 16
+    float e[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = part * dper + i;
+        e[i] = (live && i < dper && d < g.D) ? lgs[v * LSS_LGS + d] : -INFINITY;
+        mx = fmaxf(mx, e[i]);
+    }
+    red[part][v] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][v], red[1][v]), fmaxf(red[2][v], red[3][v]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        e[i] = e[i] != -INFINITY ? expf(e[i] - mx) : 0.f;
+        sum += e[i];
+    }
+    red[part][v] = sum;
+    __syncthreads();
+    const float den = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
+    // probabilities of the block's bins that this thread owns
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int dl = part * dper + i - dt * LSS_MT;
+        if (i < dper && dl >= 0 && dl < LSS_MT) pk_p[dl][v] = (live && pk_key[dl][v] != LSS_NOKEY) ? e[i] / den : 0.f;
+    }
+    // bins of the tile beyond D (D not a multiple of 16) belong to nobody above: p = 0
+    for (int dl = part; dl < LSS_MT; dl += 4)
+        if (dt * LSS_MT + dl >= g.D) pk_p[dl][v] = 0.f;
+    if (dbg & 32) return;
+    __syncthreads();
     // main cell of each column: the cell of its first valid point; tag it
-    for (int dl = wave; dl < LSS_MT; dl += 4) {
+    for (int dl = part; dl < LSS_MT; dl += 4) {
         const uint32_t key = pk_key[dl][l];
         const unsigned long long valid = __ballot(key != LSS_NOKEY);
         const uint32_t m = valid ? __shfl(key, __builtin_ctzll(valid), 64) : LSS_NOKEY;
@@ -425,11 +490,12 @@ __global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ h
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int dl = wave + 4 * j;
+        const int dl = part + 4 * j;
         const uint32_t key = pk_key[dl][l];
         pT[l][dl] = (key != LSS_NOKEY && key == mk[dl]) ? pk_p[dl][l] : 0.f;
     }
     __syncthreads();
+    if (dbg & 64) return;
 
     // GEMM: D[dl, c] = sum_v P'[v][dl] X[v][c]; wave w owns the channel tiles w, w+4, ...
     const int lk = l >> 4, ln = l & 15;
@@ -438,7 +504,7 @@ __global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ h
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) afr[ks] = ks < ksteps ? pT[ks * 4 + lk][ln] : 0.f;
     const int n_tiles = g.C / 16;
-    for (int nt = wave; nt < n_tiles; nt += 4) {
+    for (int nt = part; nt < n_tiles; nt += 4) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* xb = xs + lk * LD + nt * 16 + ln;
 #pragma unroll
@@ -453,7 +519,7 @@ __global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ h
     }
 
     // leftovers: points of a column outside its main cell, walked as runs along v
-    for (int dl = wave; dl < LSS_MT; dl += 4) {
+    for (int dl = part; dl < LSS_MT; dl += 4) {
         if (!has_left[dl]) continue;
         const uint32_t skip = mk[dl];
         for (int c0 = 0; c0 < g.C; c0 += 64) {
@@ -475,46 +541,49 @@ __global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ h
             }
         }
     }
+
+    // Publish the tag for k_lss_canvas in state[1] -- a word nobody READS in this kernel (every block derives the tag from
+    // state[0]); k_lss_canvas reads state[1] and writes it back to state[0], which nobody reads there.  The kernel boundary
+    // orders the two: no tickets, no returning atomics (a last-block ticket cost 7-10 us in either kernel: the returning
+    // atomic waits behind the block's outstanding stores / atomics).
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) state[1] = gen;
 }
 
-// canvas[b][c][cell] = flags[b][cell] == gen ? rows[b*cells + cell][c] : 0, 4 cells x 4 channels per thread (one float4
-// row read per tagged cell, a 4x4 register transpose, four 16-B stores), the row slice zeroed behind the read.  The last
-// block to finish bumps the generation (state[0]) and resets the ticket (state[1]).
+// canvas[b][c][cell] = flags[b][cell] == generation ? rows[b*cells + cell][c] : 0.  A thread owns 4 consecutive x cells x 4
+// channels (one float4 row read per tagged cell, a 4x4 register transpose, four 16-B stores); the four channel slices of a
+// 16-channel group sit in ADJACENT LANES, so a wave's row reads -- and the zero stores that clean the rows behind the reads
+// -- cover whole 64-B lines (16-B partial-line stores from separate blocks cost 4 us of the first version, the last-block
+// ticket that used to live in this kernel 10 us: rocprofv3, scripts/k4_dbg.sh).
 __global__ __launch_bounds__(256) void k_lss_canvas(const int4* __restrict__ flags4, float* __restrict__ rows, int cells4,
-                                                   int channels, float4* __restrict__ canvas4, int* __restrict__ state,
-                                                   int total_blocks) {
-    const int gen = state[0] + 1;  // tag of this call: >= 1, a zero-filled flag array matches nothing
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.z, c0 = blockIdx.y * 4;
-    if (t < cells4) {
-        const int4 f = flags4[(size_t)b * cells4 + t];
-        float4* out = canvas4 + ((size_t)b * channels + c0) * cells4 + t;
-        const bool h0 = f.x == gen, h1 = f.y == gen, h2 = f.z == gen, h3 = f.w == gen;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(h0 | h1 | h2 | h3)) {
+                                                   int channels, float4* __restrict__ canvas4,
+                                                   int* __restrict__ state, int dbg) {
+    const int gen = state[1];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) state[0] = gen;
+    const int s = threadIdx.x & 3;
+    const int t = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int b = blockIdx.z, c0 = blockIdx.y * 16 + s * 4;
+    if (t >= cells4) return;
+    const int4 f = flags4[(size_t)b * cells4 + t];
+    float4* out = canvas4 + ((size_t)b * channels + c0) * cells4 + t;
+    const bool h0 = f.x == gen, h1 = f.y == gen, h2 = f.z == gen, h3 = f.w == gen;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(h0 | h1 | h2 | h3)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[(size_t)c * cells4] = z;
-        } else {
-            float4* r = reinterpret_cast<float4*>(rows + ((size_t)b * cells4 * 4 + (size_t)t * 4) * channels + c0);
-            const size_t rs = channels / 4;  // float4 stride between consecutive cells' rows
-            const float4 a0 = h0 ? r[0] : z, a1 = h1 ? r[rs] : z, a2 = h2 ? r[2 * rs] : z, a3 = h3 ? r[3 * rs] : z;
-            out[0] = make_float4(a0.x, a1.x, a2.x, a3.x);
-            out[(size_t)cells4] = make_float4(a0.y, a1.y, a2.y, a3.y);
-            out[(size_t)2 * cells4] = make_float4(a0.z, a1.z, a2.z, a3.z);
-            out[(size_t)3 * cells4] = make_float4(a0.w, a1.w, a2.w, a3.w);
-            if (h0) r[0] = z;
-            if (h1) r[rs] = z;
-            if (h2) r[2 * rs] = z;
-            if (h3) r[3 * rs] = z;
-        }
+        for (int c = 0; c < 4; ++c) out[(size_t)c * cells4] = z;
+        return;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // every block read `gen` (first statement) before it takes a ticket, so the bump cannot be observed by this launch
-        if (atomicAdd(&state[1], 1) == total_blocks - 1) {
-            state[1] = 0;
-            state[0] = gen;
-        }
+    float4* r = reinterpret_cast<float4*>(rows + ((size_t)b * cells4 * 4 + (size_t)t * 4) * channels + c0);
+    const size_t rs = channels / 4;  // float4 stride between consecutive cells' rows
+    const float4 a0 = h0 ? r[0] : z, a1 = h1 ? r[rs] : z, a2 = h2 ? r[2 * rs] : z, a3 = h3 ? r[3 * rs] : z;
+    out[0] = make_float4(a0.x, a1.x, a2.x, a3.x);
+    out[(size_t)cells4] = make_float4(a0.y, a1.y, a2.y, a3.y);
+    out[(size_t)2 * cells4] = make_float4(a0.z, a1.z, a2.z, a3.z);
+    out[(size_t)3 * cells4] = make_float4(a0.w, a1.w, a2.w, a3.w);
+    if (!(dbg & 2)) {
+        if (h0) r[0] = z;
+        if (h1) r[rs] = z;
+        if (h2) r[2 * rs] = z;
+        if (h3) r[3 * rs] = z;
     }
 }
 
@@ -660,7 +729,7 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
 namespace heal {
 struct LssPmWs { float* rows; int* flags; int* state; };
 static bool carve_pm(Arena& a, int channels, int cells_total, LssPmWs& w) {
-    w.state = a.take<int>(64);                                   // {generation, block ticket}
+    w.state = a.take<int>(64);                                   // {generation, tag of the call in flight}
     w.flags = a.take<int>(cells_total);
     w.rows = a.take<float>(((size_t)cells_total + 1) * channels);
     return a.ok();
@@ -686,8 +755,9 @@ extern "C" int heal_bev_pool_pm(const float* head, int head_stride, const float*
     HEAL_REQUIRE(head_stride >= channels + D && head_stride % 4 == 0 && ((uintptr_t)head & 15) == 0,
                  "bev_pool_pm: head rows must hold C + D floats, 16-B aligned (stride %d)", head_stride);
     HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "bev_pool_pm: workspace must be 256-B aligned");
-    const size_t lds = (size_t)((fH + 3) & ~3) * (channels + 16) * sizeof(float);
-    HEAL_REQUIRE(lds <= 48 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS budget: use heal_bev_pool", lds);
+    HEAL_REQUIRE(D % 4 == 0, "bev_pool_pm: D must be a multiple of 4 (got %d)", D);
+    const size_t lds = ((size_t)((fH + 3) & ~3) * (channels + 16) + (size_t)fH * LSS_LGS) * sizeof(float);
+    HEAL_REQUIRE(lds <= 64 * 1024 - 14 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS budget: use heal_bev_pool", lds);
     LssGeom g;
     for (int k = 0; k < 3; ++k) {
         g.dx[k] = dx_host[k];
@@ -704,13 +774,15 @@ extern "C" int heal_bev_pool_pm(const float* head, int head_stride, const float*
     LssPmWs w;
     HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_pool_pm: workspace too small (%zu < %zu)", ws_bytes, a.off);
     const int n_dt = ceil_div(D, LSS_MT);
+    const char* dbg_env = getenv("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     k_lss_scatter<<<dim3(fW * n_dt, n_agents * n_cams), 256, lds, s>>>(head, head_stride, frustum,
                                                                       reinterpret_cast<const CamMats*>(cam_mats), g, n_dt,
-                                                                      w.rows, w.flags, w.state);
+                                                                      w.rows, w.flags, w.state, dbg);
     const int cells4 = g.nx[0] * g.nx[1] / 4;
-    const dim3 grid(ceil_div(cells4, 256), channels / 4, n_agents * g.nx[2]);
+    const dim3 grid(ceil_div(cells4, 64), channels / 16, n_agents * g.nx[2]);
     k_lss_canvas<<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(w.flags), w.rows, cells4, channels,
-                                      reinterpret_cast<float4*>(out), w.state, (int)(grid.x * grid.y * grid.z));
+                                      reinterpret_cast<float4*>(out), w.state, dbg);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -7,7 +7,10 @@ def normalize_pairwise_tfm(pairwise_t_matrix, H, W, discrete_ratio, downsample_r
     """transformation_utils.py:68-92 -- [B,L,L,4,4] -> [B,L,L,2,3] for F.affine_grid; dtype kept
     (float64 when the matrix comes from the dataset's numpy array).  Accepts torch or numpy."""
     if isinstance(pairwise_t_matrix, torch.Tensor):
-        a = pairwise_t_matrix[:, :, :, [0, 1], :][:, :, :, :, [0, 1, 3]]
+        # rows 0,1 x columns 0,1,3 by SLICES (an index list would become an index tensor uploaded from the host, which a
+        # stream capture does not permit: the device-resident pose matrix is normalised inside the captured graph)
+        t = pairwise_t_matrix
+        a = torch.cat([t[..., 0:2, 0:2], t[..., 0:2, 3:4]], dim=-1)
     else:
         a = np.asarray(pairwise_t_matrix)[:, :, :, [0, 1], :][:, :, :, :, [0, 1, 3]].copy()
     a[..., 0, 1] = a[..., 0, 1] * H / W

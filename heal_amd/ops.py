@@ -491,8 +491,8 @@ def _frustum_separable(frustum):
 
 def bev_pool_pm_supported(D, fH, C):
     import os
-    return (os.environ.get("HEAL_LSS_PATH", "") != "sorted" and fH <= 64 and D <= 64 and C % 16 == 0 and 16 <= C <= 256
-            and ((fH + 3) // 4 * 4) * (C + 16) * 4 <= 48 * 1024)
+    return (os.environ.get("HEAL_LSS_PATH", "") != "sorted" and fH <= 64 and D <= 64 and D % 4 == 0 and C % 16 == 0
+            and 16 <= C <= 256 and (((fH + 3) // 4 * 4) * (C + 16) + fH * 65) * 4 <= 50 * 1024)
 
 
 def bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):

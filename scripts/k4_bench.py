@@ -1,5 +1,5 @@
-"""K4 A/B: direct splat on the matrix cores (default) vs the vector-ALU walk (HEAL_LSS_PATH=walk) vs the sorted
-pipeline (HEAL_LSS_PATH=sorted), standalone launches, HIP events.
+"""K4 timing: the production path (heal_bev_pool_pm on the pixel-major head tensor the fused image_head | depth_head convolution
+writes; 2 launches) vs the bit-reproducible sorted pipeline on the reference's NCHW tensors, standalone, HIP events.
 Usage: python scripts/k4_bench.py   (on the GPU box)"""
 import json
 import os
@@ -13,7 +13,43 @@ from heal_amd import ops, synth  # noqa: E402
 from oracle import oracle_np as O  # noqa: E402  (bench script: geometry helpers only)
 
 
-def run(final_dim, C=128, n_agents=1, iters=30):
+def timed(fn, iters=30, warm=5):
+    for _ in range(warm):
+        out = fn()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return float(np.median(ts)), float(np.min(ts)), out
+
+
+def timed_graph(fn, reps=20, iters=10):
+    """Device time per call with launch gaps as a captured graph sees them: `reps` calls captured once, replayed."""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return float(np.median(ts))
+
+
+def run(final_dim, C=128, n_agents=1):
     rng = np.random.default_rng(0)
     fH, fW = final_dim[0] // 8, final_dim[1] // 8
     D, N = 48, 4
@@ -24,29 +60,26 @@ def run(final_dim, C=128, n_agents=1, iters=30):
     mats = ops.camera_matrices(cam["rots"], cam["trans"], cam["intrins"], cam["post_rots"], cam["post_trans"])
     dl = torch.from_numpy(rng.standard_normal((n_agents * N, D, fH, fW)).astype(np.float32)).cuda()
     ft = torch.from_numpy(rng.standard_normal((n_agents * N, C, fH, fW)).astype(np.float32)).cuda()
+    head = torch.cat([ft, dl], 1).permute(0, 2, 3, 1).reshape(n_agents * N, fH * fW, C + D).contiguous()
+    args = (n_agents, N, dx.tolist(), bx.tolist(), nx.tolist())
     res = {}
-    outs = {}
-    for path in ("sorted", "walk", "splat"):
-        os.environ["HEAL_LSS_PATH"] = path
-        for _ in range(5):
-            out = ops.bev_pool(dl, ft, frustum, mats, n_agents, N, dx.tolist(), bx.tolist(), nx.tolist())
-        ts = []
-        for _ in range(iters):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = ops.bev_pool(dl, ft, frustum, mats, n_agents, N, dx.tolist(), bx.tolist(), nx.tolist())
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e3)
-        res[path] = float(np.median(ts))
-        outs[path] = out
-    a, b = outs["sorted"], outs["splat"]
-    res["max_rel_diff"] = float((a - b).abs().max() / a.abs().max())
-    res["max_rel_diff_walk"] = float((a - outs["walk"]).abs().max() / a.abs().max())
+    os.environ.pop("HEAL_LSS_PATH", None)
+    res["fused_pm_us"], res["fused_pm_min_us"], a = timed(lambda: ops.bev_pool_pm(head, C, D, fH, fW, frustum, mats, *args))
+    res["fused_pm_in_graph_us"] = timed_graph(lambda: ops.bev_pool_pm(head, C, D, fH, fW, frustum, mats, *args))
+    os.environ["HEAL_LSS_PATH"] = "sorted"
+    res["sorted_us"], _, b = timed(lambda: ops.bev_pool(dl, ft, frustum, mats, *args))
+    os.environ.pop("HEAL_LSS_PATH", None)
+    # the producing convolution with both epilogues (512 -> C + D at the feature resolution): what the layout change costs
+    feat512 = torch.randn((n_agents * N, 512, fH, fW), device="cuda")
+    w = torch.randn((C + D, 512, 1, 1), device="cuda") / 512 ** 0.5
+    bias = torch.randn((C + D,), device="cuda")
+    res["head_conv_nchw_us"], _, _ = timed(lambda: ops.conv1x1(feat512, w, bias, None, 0))
+    res["head_conv_pm_us"], _, _ = timed(lambda: ops.conv1x1(feat512, w, bias, None, 0, pixel_major=True))
+    res["max_rel_diff_vs_sorted"] = float((a - b).abs().max() / b.abs().max())
     res["nonzero_cells"] = int((a != 0).any(dim=1).sum())
-    alg = (dl.numel() + ft.numel() + a.numel()) * 4
+    alg = (dl.numel() + ft.numel() + a.numel()) * 4            # logits + features read, canvas written
     res["alg_MB"] = alg / 1e6
-    res["splat_frac_hbm"] = alg / (res["splat"] * 1e-6) / 8e12
+    res["fused_frac_hbm"] = alg / (res["fused_pm_in_graph_us"] * 1e-6) / 8e12
     return res
 
 
