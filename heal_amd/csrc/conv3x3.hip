@@ -1,0 +1,210 @@
+// Dense 3x3 convolution (padding 1, stride 1 | 2) on the fp32 matrix cores with the epilogue fused:
+//     y = act(W * x + b (+ residual)),  NCHW fp32 in and out.
+// Replaces the library (MIOpen Winograd / implicit-GEMM + layout transposes) convolutions and the separate bias / residual /
+// ReLU pass of the dense BEV stacks:
+//   opencood/models/sub_modules/downsample_conv.py:7-27   DoubleConv (shrink header: 384->256, 256->256 @ 256x256)
+//   opencood/models/sub_modules/resblock.py:18-64          BasicBlock conv1 (stride 1 | 2) / conv2 + BN + (identity) + ReLU
+//   opencood/models/sub_modules/base_bev_backbone.py:6-124 plain Conv-BN-ReLU stacks
+//   opencood/models/sub_modules/lss_submodule.py:17-36     Up (432->512, 552->512, 512->512 at the image feature resolution)
+//   torchvision Bottleneck.conv2 of the ResNet101 stem (lss_submodule.py:153-161)
+//   opencood/models/sub_modules/naive_compress.py:5-31
+//
+// Implicit GEMM per image:  Y[co, p] = sum_{tap, ci} W[co][ci][tap] * X[ci][p + off(tap)]  on v_mfma_f32_16x16x4_f32
+// (fp32 in, fp32 accumulate: bitwise an fmaf chain, no reduced precision anywhere).
+//   * block = 4 waves = 64 output channels x (TH x 16) output pixels; wave w owns all 64 channels (4 m-tiles) of the
+//     tile's rows [w*TH/4, (w+1)*TH/4) (NT = TH/4 n-tiles of 16 pixels): 16 | 8 independent accumulators per wave;
+//   * K loop over chunks of KC = 8 input channels.  A chunk's input patch (tile + halo, zero padding resolved at staging
+//     time) and its 9 x 8 x 64 weights go through LDS: one staging pass feeds 9 taps x 2 k-steps x MT x NT MFMAs per wave
+//     (288 | 144), i.e. every staged activation is used 9 x 64 times -- the ratio that makes a 3x3 convolution easier
+//     to keep on the matrix cores than the 1x1 (heal_conv1x1: every staged activation is used 64 times);
+//   * B fragment (activations): lane (k = l >> 4, pixel = l & 15) reads patch[k][row + dy][col*S + dx]; the per-channel
+//     stride of the patch is padded to 16 mod 32 words (stride 1) or to an odd number of words (stride 2) so that the two
+//     k-rows a 32-lane LDS phase touches fall in disjoint banks -> conflict-free ds_read_b32;
+//   * A fragment (weights): pre-laid by the host in fragment order [Cout/64][Cin/8][tap][k-step][m-tile][lane]
+//     (ops.conv3x3_fragments), so a chunk's weights are ONE contiguous 18-KB run in memory (coalesced 16-B loads, L2
+//     resident) and a fragment is 64 consecutive LDS words;
+//   * the next chunk's global loads are issued before the current chunk's MFMAs (register staging), the LDS is single
+//     buffered (28.8 KB | 36 KB per block: 4-5 blocks per CU hide the two barriers per chunk);
+//   * epilogue in registers: + bias[co] (+ residual) -> ReLU -> 64-B row segments; XCD-contiguous tile order.
+// Roofline: fp32 MFMA (157.3 TFLOP/s); HBM traffic is input (x Cout/64 re-reads, mostly L2 hits) + output.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int C3_KC = 8;                 // input channels per chunk
+constexpr int C3_KS = C3_KC / 4;         // k-steps per chunk
+constexpr int C3_WCHUNK = 9 * C3_KS * 4 * 64;  // floats of one chunk's weights (fragment order)
+
+template <int STRIDE, int TH>
+struct C3Geom {
+    static constexpr int TW = 16;
+    static constexpr int NT = TH / 4;                        // n-tiles (rows of 16 pixels) per wave
+    static constexpr int PH = (TH - 1) * STRIDE + 3;         // patch rows
+    static constexpr int PW = (TW - 1) * STRIDE + 3;         // patch columns
+    static constexpr int PE = PH * PW;                       // elements per channel
+    // per-channel LDS stride: == 16 (mod 32) for stride 1, odd for stride 2 (see header)
+    static constexpr int CS = STRIDE == 1 ? ((PE + 15) / 32 * 32 + 16) : (PE | 1);
+    static constexpr int NP = (C3_KC * PE + 255) / 256;      // patch elements staged per thread
+    static constexpr int NW = (C3_WCHUNK / 4 + 255) / 256;   // weight float4 staged per thread
+};
+
+template <int STRIDE, int TH>
+__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ wfrag,
+                                                const float* __restrict__ bias, const float* __restrict__ res,
+                                                int Cin, int nchunks, int Cout, int H, int W, int Ho, int Wo,
+                                                int tiles_x, int tiles_y, int relu, float* __restrict__ y) {
+    using G = C3Geom<STRIDE, TH>;
+    constexpr int NT = G::NT, PH = G::PH, PW = G::PW, PE = G::PE, CS = G::CS, NP = G::NP, NW = G::NW;
+    static_assert(CS >= PE, "bad patch stride");
+    __shared__ __attribute__((aligned(16))) float sW[C3_WCHUNK];
+    __shared__ float sP[C3_KC * CS];
+
+    const Block3 bk = xcd_block();       // x: Cout block (fastest: blocks sharing a patch are neighbours), y: tile, z: image
+    const int mb = bk.x, n = bk.z;
+    const int ty = bk.y / tiles_x, tx = bk.y - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * G::TW;
+    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int lk = l >> 4, ln = l & 15;
+    const size_t HWin = (size_t)H * W;
+    const float* __restrict__ xin = x + (size_t)n * Cin * HWin;
+    const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(wfrag + (size_t)mb * nchunks * C3_WCHUNK);
+
+    // staging plan of this thread (the same patch positions for every chunk): element e = tid + 256 j of the [KC][PH][PW] patch
+    int p_off[NP];       // offset inside the image plane, or -1 (outside the image / beyond the patch)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int ci = e / PE, rem = e - ci * PE, py = rem / PW, px = rem - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = e < C3_KC * PE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        p_off[j] = ok ? gy * W + gx : -1;
+    }
+
+    float pst[NP];
+    float4 wst[NW];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int ch = c * C3_KC + (threadIdx.x + 256 * j) / PE;
+            pst[j] = (p_off[j] >= 0 && ch < Cin) ? xin[(size_t)ch * HWin + p_off[j]] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            wst[j] = i < C3_WCHUNK / 4 ? wsrc[(size_t)c * (C3_WCHUNK / 4) + i] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int e = threadIdx.x + 256 * j, ci = e / PE;
+            if (e < C3_KC * PE) sP[ci * CS + (e - ci * PE)] = pst[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < C3_WCHUNK / 4) reinterpret_cast<float4*>(sW)[i] = wst[j];
+        }
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // B-fragment base of this lane: patch[lk][(wave*NT + nt)*S + dy][ln*S + dx]
+    const float* __restrict__ bbase = sP + lk * CS + (wave * NT * STRIDE) * PW + ln * STRIDE;
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1);   // global loads in flight under this chunk's MFMAs
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int ks = 0; ks < C3_KS; ++ks) {
+                float a[4], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = sW[((tap * C3_KS + ks) * 4 + mt) * 64 + l];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = bbase[ks * 4 * CS + (nt * STRIDE + dy) * PW + dx];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) {
+            __syncthreads();      // every wave is done reading this chunk
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // Epilogue.  MFMA leaves D[row = lk*4 + r][col = ln]: lane (lk, ln) holds 4 consecutive output channels of pixel
+    // (row = wave*NT + nt, col = ln) per (mt, nt); a store instruction writes 4 channel planes x 64 B.
+    const size_t HWo = (size_t)Ho * Wo;
+    float* __restrict__ yout = y + (size_t)n * Cout * HWo;
+    const float* __restrict__ rin = res ? res + (size_t)n * Cout * HWo : nullptr;
+    const int ox = ox0 + ln;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + wave * NT + nt;
+        if (oy >= Ho || ox >= Wo) continue;
+        const size_t pix = (size_t)oy * Wo + ox;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = mb * 64 + mt * 16 + lk * 4 + r;
+                if (co >= Cout) continue;
+                float v = acc[mt][nt][r] + (bias ? bias[co] : 0.f);
+                const size_t o = (size_t)co * HWo + pix;
+                if (rin) v += rin[o];
+                if (relu) v = fmaxf(v, 0.f);
+                yout[o] = v;
+            }
+        }
+    }
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
+                            int cin, int cout, int H, int W, int stride, int relu, float* y, void* stream) {
+    HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv3x3: bad shape");
+    HEAL_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2 (got %d)", stride);
+    HEAL_REQUIRE(x && weight_frag && y, "conv3x3: null pointer");
+    HEAL_REQUIRE(((uintptr_t)weight_frag & 15) == 0, "conv3x3: weight fragments must be 16-B aligned");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int nchunks = (cin + C3_KC - 1) / C3_KC, mblocks = (cout + 63) / 64;
+    hipStream_t s = (hipStream_t)stream;
+    // tile height: 16 rows (stride 1) unless the map is small enough that 8-row tiles waste fewer rows; 8 rows for stride 2
+    int th = stride == 1 ? 16 : 8;
+    if (stride == 1 && ((Ho + 7) / 8 * 8 < (Ho + 15) / 16 * 16 || (long long)n * mblocks * ((Ho + 15) / 16) * ((Wo + 15) / 16) < 512))
+        th = 8;
+    if (const char* e = getenv("HEAL_C3_TH")) { const int v = atoi(e); if (stride == 1 && (v == 8 || v == 16)) th = v; }
+    const int tiles_x = ceil_div(Wo, 16), tiles_y = ceil_div(Ho, th);
+    HEAL_REQUIRE((long long)tiles_x * tiles_y <= 65535 && n <= 65535, "conv3x3: map too large for the launch grid");
+    const dim3 grid(mblocks, tiles_x * tiles_y, n);
+#define HEAL_C3(ST_, TH_)                                                                                          \
+    k_conv3x3<ST_, TH_><<<grid, 256, 0, s>>>(x, weight_frag, bias, residual, cin, nchunks, cout, H, W, Ho, Wo,     \
+                                             tiles_x, tiles_y, relu, y)
+    if (stride == 1 && th == 16) HEAL_C3(1, 16);
+    else if (stride == 1) HEAL_C3(1, 8);
+    else HEAL_C3(2, 8);
+#undef HEAL_C3
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

@@ -8,8 +8,9 @@ naive_compress.py:5-31.
 
 Inference design (eval mode): every Conv+BatchNorm pair is folded into one convolution with bias
 (cached, re-folded when a parameter changes), ReLU and the residual add run in place -- one pass
-over each BEV map instead of three.  The convolutions themselves are library GEMM/conv calls
-(MIOpen through torch) in fp32; they are the MFMA-bound part of the path.
+over each BEV map instead of three.  Pointwise, dense 3x3 (padding 1, stride 1 | 2) and 32-group 3x3 convolutions run on
+the hand-written fp32-MFMA / stencil kernels of libheal_amd with that epilogue fused; what is left to the library
+(MIOpen through torch) are the 7x7 stems and kernel != stride transposed convolutions.
 """
 import numpy as np
 import torch
@@ -47,6 +48,7 @@ class _FoldCache:
 
 import os
 _CONV1X1 = os.environ.get("HEAL_CONV1X1", "1") == "1"  # hand-written pointwise conv with fused epilogue (K7c)
+_CONV3X3 = os.environ.get("HEAL_CONV3X3", "1") == "1"  # hand-written dense 3x3 conv on fp32 MFMA (0: MIOpen + heal_bias_act, A/B)
 
 
 def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, residual=None):
@@ -64,6 +66,10 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
         Ho, Wo = (int(x.shape[2]) - 1) // st + 1, (int(x.shape[3]) - 1) // st + 1
         if ops.conv1x1_supported(int(w.shape[1]), int(w.shape[0]), Ho * Wo, st, Wo):
             return ops.conv1x1(x, w, b, residual, 1 if relu else 0, stride=st)
+    if (_CONV3X3 and x.is_cuda and groups == 1 and tuple(w.shape[2:]) == (3, 3) and pd == 1 and dl == 1 and st in (1, 2)
+            and (padding if isinstance(padding, int) else padding[1]) == 1
+            and (stride if isinstance(stride, int) else stride[1]) == st):
+        return ops.conv3x3(x, w, b, residual, relu, st)
     y = F.conv2d(x, w, None, stride, padding, dilation, groups)
     if b is None and residual is None and not relu:
         return y

@@ -797,6 +797,52 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
     return y
 
 
+_FRAG3_CACHE = {}
+
+
+def conv3x3_fragments(w):
+    """Cached MFMA A-fragment layout of a [Cout,Cin,3,3] weight for heal_conv3x3: zero-padded to [ceil64(Cout), ceil8(Cin)],
+    ordered [Cout/64][Cin/8][tap][k-step][m-tile][lane] (see include/heal_amd.h); keyed by storage + version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _FRAG3_CACHE.get(key)
+    if hit is None:
+        if len(_FRAG3_CACHE) > 512:
+            _FRAG3_CACHE.clear()
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        mpad, kpad = (cout + 63) // 64 * 64, (cin + 7) // 8 * 8
+        wm = w.detach().reshape(cout, cin, 9)
+        if (mpad, kpad) != (cout, cin):
+            wm = torch.nn.functional.pad(wm, (0, 0, 0, kpad - cin, 0, mpad - cout))
+        # [mb, mt, ln, chunk, ks, lk, tap] -> [mb, chunk, tap, ks, mt, lk, ln]
+        f = wm.reshape(mpad // 64, 4, 16, kpad // 8, 2, 4, 9).permute(0, 3, 6, 4, 1, 5, 2).contiguous()
+        hit = (f, w)  # keep w alive: the key is its address
+        _FRAG3_CACHE[key] = hit
+    return hit[0]
+
+
+def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
+    """Dense 3x3 convolution, padding 1, stride 1 | 2, on the fp32 matrix cores with fused bias (+ residual) (+ ReLU).
+    x [n,Cin,H,W] f32 cuda, w [Cout,Cin,3,3] -> [n,Cout,Ho,Wo]."""
+    x = _need(x, torch.float32, "x")
+    n, cin, H, W = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    if tuple(w.shape[1:]) != (cin, 3, 3) or stride not in (1, 2):
+        raise _capi.HealAmdError(f"conv3x3: unsupported weight {tuple(w.shape)} / stride {stride} for input {tuple(x.shape)}")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    frag = conv3x3_fragments(w)
+    y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _need(residual, torch.float32, "residual")
+        if tuple(residual.shape) != tuple(y.shape):
+            raise _capi.HealAmdError("conv3x3: residual shape mismatch")
+    if bias is not None:
+        bias = _need(bias, torch.float32, "bias")
+    with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else "")):
+        _capi.call("heal_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W, int(stride),
+                   int(bool(relu)), _ptr(y), _stream())
+    return y
+
+
 def layernorm_nchw(x, gamma, beta, eps):
     """LayerNorm over the channel axis of x [n,C,H,W] (biased variance, eps inside the sqrt)."""
     x = _need(x, torch.float32, "x")

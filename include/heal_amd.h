@@ -325,6 +325,20 @@ int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, co
                  const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
                  int out_pixel_major, float* y, void* stream);
 
+/* heal_conv3x3: dense 3x3 convolution, padding 1, stride 1 | 2, with the epilogue fused:
+ *     y = act(W * x + bias (+ residual)),
+ *   i.e. the conv3x3 + BatchNorm (+ identity) + ReLU sequences of BasicBlock (opencood/models/sub_modules/resblock.py:18-64),
+ *   the conv + ReLU pairs of DoubleConv (downsample_conv.py:7-27: the 384->256 / 256->256 shrink header at 256x256), the
+ *   plain Conv-BN-ReLU stacks of BaseBEVBackbone (base_bev_backbone.py:6-124), `Up` of the Lift-Splat camera encoder
+ *   (lss_submodule.py:17-36) and the 3x3 convolutions of the ResNet101 stem, BatchNorm folded into W / bias by the caller.
+ *   fp32 in, fp32 accumulate on v_mfma_f32_16x16x4_f32 (implicit GEMM, no reduced precision).
+ *   x [n,Cin,H,W] f32 NCHW; y / residual [n,Cout,Ho,Wo] with Ho = (H-1)/stride + 1; bias [Cout] or NULL; relu 0 | 1.
+ *   weight_frag = W [Cout,Cin,3,3] zero-padded to [Mpad = ceil64(Cout), Kpad = ceil8(Cin)] in MFMA A-fragment order
+ *   frag[mb][chunk][tap][ks][mt][lane] = W[mb*64 + mt*16 + (lane & 15)][chunk*8 + ks*4 + (lane >> 4)][tap],
+ *   mb < Mpad/64, chunk < Kpad/8, tap = 3*ky + kx, ks < 2, mt < 4, lane < 64 (16-B aligned).                        */
+int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n, int cin,
+                 int cout, int H, int W, int stride, int relu, float* y, void* stream);
+
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265
  * (boxes_overlap_kernel, boxes_iou_bev_kernel), :267-375 (nms_kernel, nms_normal_kernel) and the host mask walk of

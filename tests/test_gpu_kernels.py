@@ -638,6 +638,64 @@ def test_conv1x1_fused_vs_torch(n, cin, cout, H, W, act, with_res, with_bias):
     assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,H,W,stride,res,relu", [
+    (1, 384, 256, 64, 64, 1, False, True),      # shrink header shape (channels), reduced map
+    (3, 64, 64, 40, 48, 1, True, True),         # BasicBlock conv2 + identity
+    (2, 64, 64, 64, 64, 2, False, True),        # BasicBlock conv1, stride 2
+    (1, 128, 64, 33, 47, 2, False, True),       # odd map, stride 2 (camera backbone 128 -> 64)
+    (4, 552, 512, 12, 16, 1, False, True),      # Up of the Lift-Splat encoder: Cin not a multiple of 8... (552 = 69 * 8)
+    (1, 67, 20, 19, 21, 1, True, False),        # ragged everything: Cin % 8 != 0, Cout % 64 != 0, map % 16 != 0
+    (2, 3, 32, 24, 40, 2, False, False),        # image stem sized channels
+    (1, 16, 130, 8, 8, 1, False, True),         # map smaller than a tile, Cout spills into a third 64-block
+])
+def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu):
+    """heal_conv3x3 (implicit GEMM on fp32 MFMA, fused bias / residual / ReLU) against torch's fp64 convolution: 1e-4
+    relative to the output scale (fp32 accumulation order differs; the north-star tolerance for features is 1e-3)."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(cin * 31 + cout + H)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn((n, cout, Ho, Wo), generator=g).cuda() if res else None
+    got = ops.conv3x3(x, w, b, r, relu, stride)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    if r is not None:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    assert got.shape == ref.shape
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    # no bias, and the fragment cache must notice an in-place weight update
+    w.mul_(-0.5)
+    got2 = ops.conv3x3(x, w, None, None, False, stride)
+    ref2 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, 1)
+    assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-4
+
+
+def test_conv3x3_full_size_properties():
+    """BASELINE-size shrink header convolution (384 -> 256 at 256 x 256): linearity in the input and exactness of a delta
+    kernel (centre tap = identity on the first 256 channels) -- properties that do not need a reference at this size."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn((1, 384, 256, 256), generator=g).cuda()
+    x2 = torch.randn((1, 384, 256, 256), generator=g).cuda()
+    w = (torch.randn((256, 384, 3, 3), generator=g) / (9 * 384) ** 0.5).cuda()
+    y1, y2, y12 = ops.conv3x3(x1, w), ops.conv3x3(x2, w), ops.conv3x3(x1 + 2.0 * x2, w)
+    err = float((y12 - (y1 + 2.0 * y2)).abs().max() / y12.abs().max())
+    assert err < 1e-4, err
+    wd = torch.zeros((256, 384, 3, 3)).cuda()
+    wd[torch.arange(256), torch.arange(256), 1, 1] = 1.0
+    assert torch.equal(ops.conv3x3(x1, wd), x1[:, :256])
+    # shifted delta: output = input shifted by one pixel with a zero border (padding 1)
+    ws = torch.zeros((256, 384, 3, 3)).cuda()
+    ws[torch.arange(256), torch.arange(256), 0, 2] = 1.0     # y[o] = x[o + (-1, +1)]
+    want = torch.zeros_like(x1[:, :256])
+    want[:, :, 1:, :-1] = x1[:, :256, :-1, 1:]
+    assert torch.equal(ops.conv3x3(x1, ws), want)
+
+
 @pytest.mark.parametrize("n,cin,cout,H,W,act", [(4, 512, 176, 48, 64, 0), (4, 512, 176, 42, 56, 0), (2, 64, 20, 12, 16, 1),
                                                 (1, 96, 68, 10, 12, 2)])
 def test_conv1x1_pixel_major_output_equals_nchw(n, cin, cout, H, W, act):
