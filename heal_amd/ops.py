@@ -820,16 +820,50 @@ def conv3x3_fragments(w):
     return hit[0]
 
 
+_FRAGW_CACHE = {}
+
+
+def conv3x3_winograd_fragments(w):
+    """Cached Winograd-domain weights U = G g G^T of a [Cout,Cin,3,3] filter bank in the lane-major fragment order
+    heal_conv3x3_winograd reads (include/heal_amd.h); keyed by storage + version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _FRAGW_CACHE.get(key)
+    if hit is None:
+        if len(_FRAGW_CACHE) > 512:
+            _FRAGW_CACHE.clear()
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        mpad, kpad = (cout + 63) // 64 * 64, (cin + 7) // 8 * 8
+        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
+                         device=w.device)
+        U = (G @ w.detach().double() @ G.t()).float().reshape(cout, cin, 16)      # xi = 4a + b
+        if (mpad, kpad) != (cout, cin):
+            U = torch.nn.functional.pad(U, (0, 0, 0, kpad - cin, 0, mpad - cout))
+        # [mb, mt, ln, chunk, ks, lk, w, xi_i] -> [mb, chunk, w, lk, ln, xi_i, ks, mt]
+        f = U.reshape(mpad // 64, 4, 16, kpad // 8, 2, 4, 8, 2).permute(0, 3, 6, 5, 2, 7, 4, 1).contiguous()
+        hit = (f, w)
+        _FRAGW_CACHE[key] = hit
+    return hit[0]
+
+
+def conv3x3_algo(stride):
+    """'winograd' (stride 1, default) | 'direct'; HEAL_C3_ALGO overrides for A/B."""
+    import os
+    a = os.environ.get("HEAL_C3_ALGO", "")
+    if stride != 1 or a == "direct":
+        return "direct"
+    return "winograd"
+
+
 def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
     """Dense 3x3 convolution, padding 1, stride 1 | 2, on the fp32 matrix cores with fused bias (+ residual) (+ ReLU).
-    x [n,Cin,H,W] f32 cuda, w [Cout,Cin,3,3] -> [n,Cout,Ho,Wo]."""
+    x [n,Cin,H,W] f32 cuda, w [Cout,Cin,3,3] -> [n,Cout,Ho,Wo].  Stride 1 runs the Winograd F(2x2,3x3) formulation
+    (heal_conv3x3_winograd), stride 2 the implicit GEMM (heal_conv3x3)."""
     x = _need(x, torch.float32, "x")
     n, cin, H, W = (int(v) for v in x.shape)
     cout = int(w.shape[0])
     if tuple(w.shape[1:]) != (cin, 3, 3) or stride not in (1, 2):
         raise _capi.HealAmdError(f"conv3x3: unsupported weight {tuple(w.shape)} / stride {stride} for input {tuple(x.shape)}")
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    frag = conv3x3_fragments(w)
     y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
@@ -837,6 +871,13 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
             raise _capi.HealAmdError("conv3x3: residual shape mismatch")
     if bias is not None:
         bias = _need(bias, torch.float32, "bias")
+    if conv3x3_algo(stride) == "winograd":
+        frag = conv3x3_winograd_fragments(w)
+        with _Timed(f"conv3x3w_{cin}_{cout}"):
+            _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
+                       int(bool(relu)), _ptr(y), _stream())
+        return y
+    frag = conv3x3_fragments(w)
     with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else "")):
         _capi.call("heal_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W, int(stride),
                    int(bool(relu)), _ptr(y), _stream())

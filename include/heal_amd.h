@@ -339,6 +339,16 @@ int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, co
 int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n, int cin,
                  int cout, int H, int W, int stride, int relu, float* y, void* stream);
 
+/* heal_conv3x3_winograd: the same operator for stride 1 evaluated with the Winograd F(2x2,3x3) minimal-filtering transform
+ *   on the matrix cores (16 transform-domain GEMMs, 2.25x fewer MFMAs than the implicit GEMM of heal_conv3x3; fp32
+ *   throughout, results differ from the direct evaluation by rounding only, ~1e-6 relative).  Same tensors as heal_conv3x3.
+ *   u_frag = U = G g G^T of every (co, ci) filter (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), zero-padded to
+ *   [Mpad = ceil64(Cout), Kpad = ceil8(Cin)], lane-major per wave:
+ *   frag[mb][chunk][w][lane][(xi_i*2 + ks)*4 + mt] = U[mb*64 + mt*16 + (lane & 15)][chunk*8 + ks*4 + (lane >> 4)][xi = 2w + xi_i],
+ *   w < 8, xi = 4a + b indexes the 4x4 transform domain (16-B aligned).                                                 */
+int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
+                          int cout, int H, int W, int relu, float* y, void* stream);
+
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265
  * (boxes_overlap_kernel, boxes_iou_bev_kernel), :267-375 (nms_kernel, nms_normal_kernel) and the host mask walk of

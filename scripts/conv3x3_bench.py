@@ -52,14 +52,18 @@ def main():
             return ops.bias_act_(y, b, r, True)
         t_lib = timed(lib)
         row = {"GF": round(flops / 1e9, 1), "miopen+bias_act_us": round(t_lib, 1), "miopen_TF": round(flops / t_lib / 1e6, 1)}
+        os.environ["HEAL_C3_ALGO"] = "direct"
         for th in ((16, 8) if st == 1 else (8,)):
             os.environ["HEAL_C3_TH"] = str(th)
             t = timed(lambda: ops.conv3x3(x, w, b, r, True, st))
-            row[f"heal_th{th}_us"] = round(t, 1)
-            row[f"heal_th{th}_TF"] = round(flops / t / 1e6, 1)
+            row[f"direct_th{th}_us"] = round(t, 1)
+            row[f"direct_th{th}_TF"] = round(flops / t / 1e6, 1)
         os.environ.pop("HEAL_C3_TH", None)
-        t = timed(lambda: ops.conv3x3(x, w, b, r, True, st))
-        row["heal_default_us"] = round(t, 1)
+        os.environ.pop("HEAL_C3_ALGO", None)
+        if st == 1:
+            t = timed(lambda: ops.conv3x3(x, w, b, r, True, st))
+            row["winograd_us"] = round(t, 1)
+            row["winograd_TF_equiv"] = round(flops / t / 1e6, 1)
         err = float((ops.conv3x3(x, w, b, r, True, st) - lib()).abs().max() / lib().abs().max())
         row["rel_diff_vs_miopen"] = err
         out[name] = row

@@ -648,10 +648,15 @@ def test_conv1x1_fused_vs_torch(n, cin, cout, H, W, act, with_res, with_bias):
     (2, 3, 32, 24, 40, 2, False, False),        # image stem sized channels
     (1, 16, 130, 8, 8, 1, False, True),         # map smaller than a tile, Cout spills into a third 64-block
 ])
-def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu):
-    """heal_conv3x3 (implicit GEMM on fp32 MFMA, fused bias / residual / ReLU) against torch's fp64 convolution: 1e-4
-    relative to the output scale (fp32 accumulation order differs; the north-star tolerance for features is 1e-3)."""
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu, algo, monkeypatch):
+    """heal_conv3x3 (implicit GEMM) / heal_conv3x3_winograd (F(2x2,3x3), stride 1) on fp32 MFMA with fused bias / residual /
+    ReLU against torch's fp64 convolution: 1e-4 relative to the output scale (fp32 accumulation order and, for Winograd, the
+    transform's rounding sequence differ; the north-star tolerance for features is 1e-3)."""
     from heal_amd import ops
+    monkeypatch.setenv("HEAL_C3_ALGO", algo)
+    if algo == "winograd" and stride != 1:
+        pytest.skip("Winograd F(2x2,3x3) is the stride-1 formulation; stride 2 always runs the implicit GEMM")
     g = torch.Generator().manual_seed(cin * 31 + cout + H)
     x = torch.randn((n, cin, H, W), generator=g).cuda()
     w = (torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5).cuda()
@@ -674,10 +679,14 @@ def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu):
     assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-4
 
 
-def test_conv3x3_full_size_properties():
-    """BASELINE-size shrink header convolution (384 -> 256 at 256 x 256): linearity in the input and exactness of a delta
-    kernel (centre tap = identity on the first 256 channels) -- properties that do not need a reference at this size."""
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_conv3x3_full_size_properties(algo, monkeypatch):
+    """BASELINE-size shrink header convolution (384 -> 256 at 256 x 256): linearity in the input and a delta kernel (centre tap
+    = identity on the first 256 channels; exact for the implicit GEMM, to rounding for Winograd) -- properties that do not
+    need a reference at this size."""
     from heal_amd import ops
+    monkeypatch.setenv("HEAL_C3_ALGO", algo)
+    exact = algo == "direct"
     g = torch.Generator().manual_seed(1)
     x1 = torch.randn((1, 384, 256, 256), generator=g).cuda()
     x2 = torch.randn((1, 384, 256, 256), generator=g).cuda()
@@ -687,13 +696,15 @@ def test_conv3x3_full_size_properties():
     assert err < 1e-4, err
     wd = torch.zeros((256, 384, 3, 3)).cuda()
     wd[torch.arange(256), torch.arange(256), 1, 1] = 1.0
-    assert torch.equal(ops.conv3x3(x1, wd), x1[:, :256])
+    got = ops.conv3x3(x1, wd)
+    assert torch.equal(got, x1[:, :256]) if exact else float((got - x1[:, :256]).abs().max()) < 1e-5
     # shifted delta: output = input shifted by one pixel with a zero border (padding 1)
     ws = torch.zeros((256, 384, 3, 3)).cuda()
     ws[torch.arange(256), torch.arange(256), 0, 2] = 1.0     # y[o] = x[o + (-1, +1)]
     want = torch.zeros_like(x1[:, :256])
     want[:, :, 1:, :-1] = x1[:, :256, :-1, 1:]
-    assert torch.equal(ops.conv3x3(x1, ws), want)
+    got = ops.conv3x3(x1, ws)
+    assert torch.equal(got, want) if exact else float((got - want).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("n,cin,cout,H,W,act", [(4, 512, 176, 48, 64, 0), (4, 512, 176, 42, 56, 0), (2, 64, 20, 12, 16, 1),
