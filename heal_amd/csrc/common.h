@@ -74,6 +74,12 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 }
 
 
+// Workgroup barrier for data exchanged through LDS only.  `__syncthreads()` compiles to `s_waitcnt vmcnt(0) lgkmcnt(0);
+// s_barrier` (its workgroup-scope fence covers global memory too), which drains every global load in flight and so exposes
+// one L2/HBM round trip per barrier in a software-pipelined loop.  This form waits for the wave's LDS operations only; global
+// loads issued before it stay in flight across the barrier (the compiler still waits for them before their first use).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- XCD-aware block index -----------------------------------------------------------------------------
 // The dispatcher is observed to place block b (x fastest) on XCD b % 8, each XCD with a private 4 MiB L2.
 // Tiled kernels whose neighbouring tiles share input (conv halos, rotated bilinear footprints) remap the

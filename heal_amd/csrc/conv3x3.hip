@@ -200,8 +200,9 @@ constexpr int WG_PROW = 24;                      // patch row stride (words): 2*
 constexpr int WG_PCI = 18 * WG_PROW;             // 432 words per channel
 constexpr int WG_VROW = 80;                      // sV row stride (64 tiles + 16): k-rows lk, lk+1 of a B fragment hit disjoint banks
 constexpr int WG_MROW = 68;                      // sM row stride: 4*68 = 16 (mod 32) -> conflict-free accumulator dump
-constexpr int WG_SMEM = 16 * 16 * WG_MROW;       // 17408 words (68 KB) >= patch (3456) + sV (10240)
-static_assert(WG_KC * WG_PCI + 16 * WG_KC * WG_VROW <= WG_SMEM, "staging buffers exceed the epilogue buffer");
+constexpr int WG_PDUMMY = 512;                   // landing zone of the staging slots beyond the patch (keeps the stores unconditional)
+constexpr int WG_SMEM = 16 * 16 * WG_MROW;       // 17408 words (68 KB) >= patch (3456) + dummy (512) + sV (10240)
+static_assert(WG_KC * WG_PCI + WG_PDUMMY + 16 * WG_KC * WG_VROW <= WG_SMEM, "staging buffers exceed the epilogue buffer");
 
 __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ x, const float4* __restrict__ ufrag,
                                                      const float* __restrict__ bias, const float* __restrict__ res,
@@ -209,50 +210,68 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                                                      float* __restrict__ y) {
     __shared__ __attribute__((aligned(16))) float smem[WG_SMEM];
     float* sP = smem;
-    float* sV = smem + WG_KC * WG_PCI;
+    float* sV = smem + WG_KC * WG_PCI + WG_PDUMMY;
     float* sM = smem;
 
+    // Block order: tile fastest, image next, Cout block SLOWEST -- the Winograd weights are the big stream (16 x Cin x 64
+    // floats per Cout block: 1.6 MB at Cin = 384, re-read by every tile) and have to stay in the XCDs' 4 MB L2s, so the
+    // blocks in flight at any time share one Cout block; the input map is then read once per Cout block.
     const Block3 bk = xcd_block();
-    const int mb = bk.x, n = bk.z;
-    const int tyb = bk.y / tiles_x, txb = bk.y - tyb * tiles_x;
+    const int mb = bk.z, n = bk.y;
+    const int tyb = bk.x / tiles_x, txb = bk.x - tyb * tiles_x;
     const int oy0 = tyb * 16, ox0 = txb * 16;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
     const size_t HW = (size_t)H * W;
     const float* __restrict__ xin = x + (size_t)n * Cin * HW;
 
-    // patch staging plan: element e = tid + 512 j of the [8][18][18] patch (same positions for every chunk)
+    // patch staging plan: element e = tid + 512 j of the [8][18][18] patch (same positions for every chunk).  Loads are
+    // UNCONDITIONAL (clamped in-bounds address; the zero padding / channel tail is applied when the value goes to LDS):
+    // predicated loads put every load in its own basic block, and the compiler's waitcnt insertion then falls back to
+    // `s_waitcnt vmcnt(0)` at each of them -- which drains the U loads issued just before and serialises one L2 round trip per
+    // chunk (visible in the ISA of the first version of this loop; scripts/wg_dbg.py: 125 + 76 us of 654 us).
     constexpr int NP = (WG_KC * 324 + 511) / 512;  // 6
-    int p_off[NP];
+    int p_off[NP];      // offset inside the image plane (clamped to 0 when outside)
+    unsigned p_ok = 0;  // bit j: element j lies inside the image and the patch
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int e = threadIdx.x + 512 * j;
         const int ci = e / 324, rem = e - ci * 324, py = rem / 18, px = rem - py * 18;
         const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-        p_off[j] = (e < WG_KC * 324 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        const bool ok = e < WG_KC * 324 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        p_off[j] = ok ? gy * W + gx : 0;
+        p_ok |= ok ? (1u << j) : 0u;
     }
     float pst[NP];
     auto load_patch = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int ch = c * WG_KC + (threadIdx.x + 512 * j) / 324;
-            pst[j] = (p_off[j] >= 0 && ch < Cin) ? xin[(size_t)ch * HW + p_off[j]] : 0.f;
+            const int ch = min(c * WG_KC + (int)(threadIdx.x + 512 * j) / 324, Cin - 1);
+            pst[j] = xin[(size_t)ch * HW + p_off[j]];
         }
     };
-    auto store_patch = [&]() {
+    int p_lds[NP];      // LDS word of element j (slots beyond the patch land in the dummy zone: no branch around the store --
+                        // a conditional store lets the compiler sink the LOAD into the branch, right in front of its wait)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int e = threadIdx.x + 512 * j;
+        const int ci = e / 324, rem = e - ci * 324, py = rem / 18, px = rem - py * 18;
+        p_lds[j] = e < WG_KC * 324 ? ci * WG_PCI + py * WG_PROW + px : WG_KC * WG_PCI + (e - WG_KC * 324);
+    }
+    auto store_patch = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int e = threadIdx.x + 512 * j;
-            const int ci = e / 324, rem = e - ci * 324, py = rem / 18, px = rem - py * 18;
-            if (e < WG_KC * 324) sP[ci * WG_PCI + py * WG_PROW + px] = pst[j];
+            const int ci = (int)(threadIdx.x + 512 * j) / 324;
+            const bool ok = ((p_ok >> j) & 1u) && c * WG_KC + ci < Cin;
+            sP[p_lds[j]] = ok ? pst[j] : 0.f;
         }
     };
     // U fragments of this wave: 16 floats per lane per chunk, lane-major: [mb][chunk][wave][lane][(xi_i*2 + ks)*4 + mt]
     const float4* __restrict__ ubase = ufrag + ((size_t)mb * nchunks * 8 + wave) * 64 * 4 + (size_t)l * 4;
-    float4 ua[4];
-    auto load_u = [&](int c) {
+    float4 ua[4], un[4];                          // this chunk's / the next chunk's U fragments
+    auto load_u = [&](int c, float4 (&dst)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ua[q] = ubase[(size_t)c * 8 * 64 * 4 + q];
+        for (int q = 0; q < 4; ++q) dst[q] = ubase[(size_t)c * 8 * 64 * 4 + q];
     };
 
     f32x4 acc[2][4][4];
@@ -268,11 +287,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
     const float* __restrict__ dsrc = sP + tci * WG_PCI + (2 * tty) * WG_PROW + 2 * ttx;
     float* __restrict__ vdst = sV + tci * WG_VROW + ttile;
 
+    // Software pipeline: the global loads of chunk c+1 (input patch -> registers, U fragments -> `un`) are issued at the TOP
+    // of iteration c and consumed at its BOTTOM (patch -> LDS) / in iteration c+1 (U), so a whole transform + MFMA phase
+    // covers their latency -- which requires barriers that do not drain VMEM (lds_barrier, common.h) and a loop body that is
+    // ONE basic block (no predicated loads, the last iteration reloads chunk nchunks-1 instead of branching).
     load_patch(0);
-    load_u(0);
-    store_patch();
+    load_u(0, ua);
+    store_patch(0);
     for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();                          // patch(c) is in LDS; every wave is done with sV of chunk c-1
+        const int cn = min(c + 1, nchunks - 1);
+        lds_barrier();                            // patch(c) is in LDS; every wave is done with sV of chunk c-1
+        load_u(cn, un);
+        load_patch(cn);
         {   // V = B^T d B for (tci, ttile)
             float d[4][4];
 #pragma unroll
@@ -297,8 +323,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                 vdst[((4 * i + 3) * WG_KC) * WG_VROW] = t[i][1] - t[i][3];
             }
         }
-        if (c + 1 < nchunks) load_patch(c + 1);   // in flight under the MFMAs
-        __syncthreads();                          // sV(c) complete; sP free
+        lds_barrier();                            // sV(c) complete; sP free (global loads stay in flight)
         {
             const float a_[16] = {ua[0].x, ua[0].y, ua[0].z, ua[0].w, ua[1].x, ua[1].y, ua[1].z, ua[1].w,
                                   ua[2].x, ua[2].y, ua[2].z, ua[2].w, ua[3].x, ua[3].y, ua[3].z, ua[3].w};
@@ -319,10 +344,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                 }
             }
         }
-        if (c + 1 < nchunks) {
-            load_u(c + 1);                        // lands during the next barrier + transform
-            store_patch();                        // sP is free since the second barrier of this chunk
-        }
+        store_patch(cn);                          // sP is free since the second barrier (last iteration: rewrites the last chunk, unused)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ua[q] = un[q];
     }
 
     // Epilogue: four passes of 16 output channels (m-tile p) through sM[xi][co][tile]
@@ -389,11 +413,11 @@ extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const floa
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int nchunks = (cin + C3_KC - 1) / C3_KC, mblocks = (cout + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
-    // tile height: 16 rows (stride 1) unless the map is small enough that 8-row tiles waste fewer rows; 8 rows for stride 2
+    // tile height: the tallest of 16 | 8 | 4 rows (stride 2: 8 | 4) that still gives every CU a couple of blocks
+    const long long per_row_tiles = (long long)n * mblocks * ((Wo + 15) / 16);
     int th = stride == 1 ? 16 : 8;
-    if (stride == 1 && ((Ho + 7) / 8 * 8 < (Ho + 15) / 16 * 16 || (long long)n * mblocks * ((Ho + 15) / 16) * ((Wo + 15) / 16) < 512))
-        th = 8;
-    if (const char* e = getenv("HEAL_C3_TH")) { const int v = atoi(e); if (stride == 1 && (v == 8 || v == 16)) th = v; }
+    while (th > 4 && per_row_tiles * ((Ho + th - 1) / th) < 512) th >>= 1;
+    if (const char* e = getenv("HEAL_C3_TH")) { const int v = atoi(e); if ((v == 4 || v == 8 || (v == 16 && stride == 1))) th = v; }
     const int tiles_x = ceil_div(Wo, 16), tiles_y = ceil_div(Ho, th);
     HEAL_REQUIRE((long long)tiles_x * tiles_y <= 65535 && n <= 65535, "conv3x3: map too large for the launch grid");
     const dim3 grid(mblocks, tiles_x * tiles_y, n);
@@ -401,8 +425,10 @@ extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const floa
     k_conv3x3<ST_, TH_><<<grid, 256, 0, s>>>(x, weight_frag, bias, residual, cin, nchunks, cout, H, W, Ho, Wo,     \
                                              tiles_x, tiles_y, relu, y)
     if (stride == 1 && th == 16) HEAL_C3(1, 16);
-    else if (stride == 1) HEAL_C3(1, 8);
-    else HEAL_C3(2, 8);
+    else if (stride == 1 && th == 8) HEAL_C3(1, 8);
+    else if (stride == 1) HEAL_C3(1, 4);
+    else if (th == 8) HEAL_C3(2, 8);
+    else HEAL_C3(2, 4);
 #undef HEAL_C3
     HEAL_LAUNCH_CHECK();
     return 0;
@@ -417,7 +443,7 @@ extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const 
     const int nchunks = (cin + WG_KC - 1) / WG_KC, mblocks = (cout + 63) / 64;
     const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 16);
     HEAL_REQUIRE((long long)tiles_x * tiles_y <= 65535 && n <= 65535, "conv3x3_winograd: map too large for the launch grid");
-    k_conv3x3_wino<<<dim3(mblocks, tiles_x * tiles_y, n), 512, 0, (hipStream_t)stream>>>(
+    k_conv3x3_wino<<<dim3(tiles_x * tiles_y, n, mblocks), 512, 0, (hipStream_t)stream>>>(
         x, reinterpret_cast<const float4*>(u_frag), bias, residual, cin, nchunks, cout, H, W, tiles_x, relu, y);
     HEAL_LAUNCH_CHECK();
     return 0;

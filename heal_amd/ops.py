@@ -845,13 +845,18 @@ def conv3x3_winograd_fragments(w):
     return hit[0]
 
 
-def conv3x3_algo(stride):
-    """'winograd' (stride 1, default) | 'direct'; HEAL_C3_ALGO overrides for A/B."""
+def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
+    """'winograd' | 'direct' for a shape; HEAL_C3_ALGO overrides for A/B.  Winograd F(2x2,3x3) is the stride-1 formulation
+    and runs one 8-wave block per CU on a 16x16-pixel x 64-channel tile: below ~one block per CU the implicit GEMM with its
+    smaller tiles fills the chip better (scripts/conv3x3_bench.py)."""
     import os
     a = os.environ.get("HEAL_C3_ALGO", "")
     if stride != 1 or a == "direct":
         return "direct"
-    return "winograd"
+    if a == "winograd":
+        return "winograd"
+    blocks = n * ((cout + 63) // 64) * ((H + 15) // 16) * ((W + 15) // 16)
+    return "winograd" if blocks >= 192 else "direct"
 
 
 def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
@@ -871,7 +876,7 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
             raise _capi.HealAmdError("conv3x3: residual shape mismatch")
     if bias is not None:
         bias = _need(bias, torch.float32, "bias")
-    if conv3x3_algo(stride) == "winograd":
+    if conv3x3_algo(stride, n, cout, H, W) == "winograd":
         frag = conv3x3_winograd_fragments(w)
         with _Timed(f"conv3x3w_{cin}_{cout}"):
             _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,

@@ -53,15 +53,19 @@ def main():
         t_lib = timed(lib)
         row = {"GF": round(flops / 1e9, 1), "miopen+bias_act_us": round(t_lib, 1), "miopen_TF": round(flops / t_lib / 1e6, 1)}
         os.environ["HEAL_C3_ALGO"] = "direct"
-        for th in ((16, 8) if st == 1 else (8,)):
+        for th in ((16, 8, 4) if st == 1 else (8, 4)):
             os.environ["HEAL_C3_TH"] = str(th)
             t = timed(lambda: ops.conv3x3(x, w, b, r, True, st))
             row[f"direct_th{th}_us"] = round(t, 1)
             row[f"direct_th{th}_TF"] = round(flops / t / 1e6, 1)
         os.environ.pop("HEAL_C3_TH", None)
         os.environ.pop("HEAL_C3_ALGO", None)
+        row["default_us"] = round(timed(lambda: ops.conv3x3(x, w, b, r, True, st)), 1)
+        row["default_algo"] = ops.conv3x3_algo(st, n, cout, H, W)
         if st == 1:
+            os.environ["HEAL_C3_ALGO"] = "winograd"
             t = timed(lambda: ops.conv3x3(x, w, b, r, True, st))
+            os.environ.pop("HEAL_C3_ALGO", None)
             row["winograd_us"] = round(t, 1)
             row["winograd_TF_equiv"] = round(flops / t / 1e6, 1)
         err = float((ops.conv3x3(x, w, b, r, True, st) - lib()).abs().max() / lib().abs().max())
