@@ -413,10 +413,15 @@ extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const floa
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int nchunks = (cin + C3_KC - 1) / C3_KC, mblocks = (cout + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
-    // tile height: the tallest of 16 | 8 | 4 rows (stride 2: 8 | 4) that still gives every CU a couple of blocks
+    // Tile height (measured, scripts/conv3x3_bench.py): the kernel is barrier-bound at 2 waves per SIMD, so more, smaller
+    // blocks win -- 4-row tiles everywhere except for deep reductions (Cin >= 256: the 18-KB weight chunk per block-chunk
+    // then dominates the staging traffic and taller tiles amortise it): 8 rows, 16 when that still leaves >= 1024 blocks.
     const long long per_row_tiles = (long long)n * mblocks * ((Wo + 15) / 16);
-    int th = stride == 1 ? 16 : 8;
-    while (th > 4 && per_row_tiles * ((Ho + th - 1) / th) < 512) th >>= 1;
+    int th = 4;
+    if (cin >= 256) {
+        th = 8;
+        if (stride == 1 && per_row_tiles * ((Ho + 15) / 16) >= 1024) th = 16;
+    }
     if (const char* e = getenv("HEAL_C3_TH")) { const int v = atoi(e); if ((v == 4 || v == 8 || (v == 16 && stride == 1))) th = v; }
     const int tiles_x = ceil_div(Wo, 16), tiles_y = ceil_div(Ho, th);
     HEAL_REQUIRE((long long)tiles_x * tiles_y <= 65535 && n <= 65535, "conv3x3: map too large for the launch grid");

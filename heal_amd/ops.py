@@ -848,7 +848,7 @@ def conv3x3_winograd_fragments(w):
 def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
     """'winograd' | 'direct' for a shape; HEAL_C3_ALGO overrides for A/B.  Winograd F(2x2,3x3) is the stride-1 formulation
     and runs one 8-wave block per CU on a 16x16-pixel x 64-channel tile: below ~one block per CU the implicit GEMM with its
-    smaller tiles fills the chip better (scripts/conv3x3_bench.py)."""
+    smaller tiles fills the chip better (measured crossover ~100 blocks, scripts/conv3x3_bench.py)."""
     import os
     a = os.environ.get("HEAL_C3_ALGO", "")
     if stride != 1 or a == "direct":
@@ -856,7 +856,7 @@ def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
     if a == "winograd":
         return "winograd"
     blocks = n * ((cout + 63) // 64) * ((H + 15) // 16) * ((W + 15) // 16)
-    return "winograd" if blocks >= 192 else "direct"
+    return "winograd" if blocks >= 96 else "direct"
 
 
 def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
