@@ -58,9 +58,12 @@ def dense_flops(model, sample_input_fn):
         return None
 
 
-def cpu_baseline(hypes, scene_points, pairwise, n_agents, cls_shift=0.0):
-    """The oracle (CPU port of the reference algorithm) timed on this box's host cores, on a bounded
-    sample: ONE scene of the same workload.  Reported, never the thing measured above."""
+def cpu_baseline(hypes, scene_cpu, cls_shift=0.0):
+    """The oracle (CPU port of the reference algorithm, oracle/) timed on this box's host cores on a bounded sample: ONE
+    scene of the SAME workload -- LiDAR agents through the C voxeliser + numpy PFN / scatter, camera agents through the
+    plain-torch trunks (oracle/trunks.py), Up, heads, numpy lift + voxel pooling; backbones, ConvNeXt aligners, pyramid
+    fusion (numpy warp + fuse), shrink head, heads as torch-CPU fp32 convolutions; decode + C rotated NMS.  Reported, never
+    the thing measured above."""
     from heal_amd.opencood.tools.train_utils import create_model
     from heal_amd.pipeline import fill_deterministic
     from oracle import cref, model_ref
@@ -72,13 +75,22 @@ def cpu_baseline(hypes, scene_points, pairwise, n_agents, cls_shift=0.0):
     sd = fill_deterministic(create_model(hypes), 0).state_dict()
     args = hypes["model"]["args"]
     r = args["lidar_range"]
+    mods = list(scene_cpu.modalities)
     t0 = time.perf_counter()
+    data = {"agent_modality_list": mods, "pairwise_t_matrix": np.asarray(scene_cpu.pairwise)}
     vs, cs, ns = [], [], []
-    for b, p in enumerate(scene_points):
-        v, c, n = cref.voxelize(p, r, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
+    for b, k in enumerate(sorted(scene_cpu.points)):
+        v, c, n = cref.voxelize(scene_cpu.points[k].numpy(), r, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
         vs.append(v); cs.append(c); ns.append(n)
-    out = model_ref.heter_pyramid_collab_m1(sd, args, np.concatenate(vs), np.concatenate(cs), np.concatenate(ns),
-                                            n_agents, pairwise)
+    if vs:
+        data["inputs_m1"] = {"voxel_features": np.concatenate(vs), "voxel_coords": np.concatenate(cs),
+                             "voxel_num_points": np.concatenate(ns)}
+    for m in sorted(set(mods)):
+        ids = [i for i, mm in enumerate(mods) if mm == m and i in scene_cpu.cameras]
+        if ids:
+            data[f"inputs_{m}"] = {key: np.stack([scene_cpu.cameras[i][key].numpy() for i in ids])
+                                   for key in ("imgs", "rots", "trans", "intrins", "post_rots", "post_trans")}
+    out = model_ref.heter_pyramid_collab(sd, args, data)
     anchors = O.generate_anchor_box(r, 0.4, 0.4, int(round((r[3] - r[0]) / 0.4)), int(round((r[4] - r[1]) / 0.4)),
                                     3.9, 1.6, 1.56, [0, 90])
     out["cls_preds"] = out["cls_preds"] + cls_shift  # same calibrated head bias as the GPU pipeline
@@ -86,8 +98,123 @@ def cpu_baseline(hypes, scene_points, pairwise, n_agents, cls_shift=0.0):
                    np.eye(4, dtype=np.float32), r)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"1 scene of the same workload ({n_agents} agents) through oracle/ "
-                      f"(C voxeliser + numpy PFN/warp/fuse + torch-CPU fp32 convs + C rotated NMS), {dt:.1f} s"}
+            "sample": f"1 scene of the same workload ({len(mods)} agents: {' '.join(mods)}) through oracle/ (C voxeliser, numpy "
+                      f"PFN / lift / voxel pooling / warp + fuse, torch-CPU fp32 image trunks and convolutions, C rotated "
+                      f"NMS), {dt:.1f} s on {cores} threads"}
+
+
+def _entry(kernel, bound, achieved, launches, launch_ms, traffic=None, **extra):
+    peak = HBM_PEAK_GBS if bound == "hbm" else FP32_PEAK_TFLOPS
+    d = {"kernel": kernel, "bound": bound, "achieved": round(achieved, 2), "peak": peak,
+         "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+         "launches": launches, "launch_ms": round(launch_ms, 5)}
+    d.update(extra)
+    return d
+
+
+def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, world, n_agents, sp_trace, ny, nx):
+    """`roofline` = the hand-written kernel family that takes the most time in this workload; `roofline_other` = every other
+    north-star kernel present.  achieved = algorithmic bytes (HBM-bound kernels) or FLOPs (MFMA-bound kernels)
+    of the recorded launches / their summed HIP-event durations, i.e. per-launch work / average launch duration."""
+    from heal_amd.dist import owned_agents
+    from heal_amd.pipeline import Scene
+    fam = {}
+
+    def add(name, kernel, bound, w):
+        f = fam.setdefault(name, {"kernel": kernel, "bound": bound, "calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        f["calls"] += w["calls"]; f["ms"] += w["total_ms"]; f["flops"] += w["flops"]; f["bytes"] += w["bytes"]
+    for name, w in work.items():
+        if name.startswith("conv1x1_"):
+            add("conv1x1", "K7 heal_conv1x1 (pointwise convolutions, fp32 MFMA, fused epilogues; all shapes of the step)", "mfma", w)
+        elif name.startswith("conv3x3w_"):
+            add("conv3x3w", "K7 heal_conv3x3_winograd (dense 3x3, F(2x2,3x3) on fp32 MFMA; FLOPs counted as the DIRECT "
+                            "convolution's 2*9*Cin*Cout*HW, the transform does 2.25x fewer)", "mfma", w)
+        elif name.startswith("conv3x3_"):
+            add("conv3x3", "K7 heal_conv3x3 (dense 3x3 implicit GEMM on fp32 MFMA: stride 2 and small maps)", "mfma", w)
+        elif name.startswith("grouped_conv3x3"):
+            add("grouped", "K7 heal_grouped_conv3x3 (32-group 3x3 stencil, vector ALU)", "mfma", w)
+        elif name.startswith("warp_fuse"):
+            add("k5", "K5 heal_warp_fuse (warp + occupancy-softmax fusion, 3 pyramid levels)", "hbm", w)
+    entries = {}
+    for key, f in fam.items():
+        if f["ms"] <= 0:
+            continue
+        ach = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["bound"] == "mfma" else (f["bytes"] / (f["ms"] * 1e-3) / 1e9)
+        entries[key] = (f["ms"], _entry(f["kernel"], f["bound"], ach, f["calls"], f["ms"] / max(f["calls"], 1),
+                                        step_ms=round(f["ms"] / max(a.steps, 1), 4)))
+    # K2: algorithmic bytes of the collated LiDAR agents this rank encodes per launch
+    if "pfn_scatter" in timing:
+        calls, mean_ms = timing["pfn_scatter"]
+        lidar_ids = [i for i, m in enumerate(mods) if m == "m1"]
+        if not solo:
+            lidar_ids = [i for i in lidar_ids if i in owned_agents(n_agents, 0, world)]
+        order = sorted(scene.points)
+        m_launch = [m_per_agent[order.index(i)] for i in lidar_ids if i in order]
+        bytes_per_launch = float(sum(k2_algorithmic_bytes(32, m, ny, nx) for m in m_launch))
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_k2_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 PMC passes (scripts/profile_round.sh)
+            tj = json.load(open(tpath))
+            if int(tj.get("agents_per_launch", -1)) == len(m_launch):
+                traffic = float(tj["k2_traffic_bytes_per_launch"])
+        entries["k2"] = (calls * mean_ms, _entry(
+            f"K2 heal_pfn_scatter, {len(m_launch)} collated LiDAR agents per launch (k_pfn + k_canvas)", "hbm",
+            bytes_per_launch / (mean_ms * 1e-3) / 1e9, calls, mean_ms, traffic, bytes_per_launch=bytes_per_launch))
+    # K4: one camera agent per launch (SURVEY 8d: logits + features read, canvas written)
+    if "bev_pool" in timing:
+        cam_ids = [i for i, m in enumerate(mods) if m in Scene.CAMERA_DIMS and (solo or i in owned_agents(n_agents, 0, world))]
+        if cam_ids:
+            per_call = []
+            for i in cam_ids:
+                H, W = Scene.CAMERA_DIMS[mods[i]]
+                fhw = (H // 8) * (W // 8)
+                per_call.append(4.0 * (4 * 48 * fhw + 4 * 128 * fhw + 128 * 256 * 256))
+            calls, mean_ms = timing["bev_pool"]
+            bts = sum(per_call) / len(per_call)
+            entries["k4"] = (calls * mean_ms, _entry(
+                "K4 heal_bev_pool_pm, one camera agent per launch (k_lss_scatter + k_lss_canvas; mean over the scene's camera agents)",
+                "hbm", bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
+    # K1: 16 N + 16 M P + 20 M bytes per agent, all LiDAR agents of a modality in one launch chain
+    if "voxelize" in timing and scene.points:
+        calls, mean_ms = timing["voxelize"]
+        P = 5 if a.workload == "scene8_second_v2xvit" else 32
+        bts = float(sum(16 * int(scene.points[k].shape[0]) + 16 * m * P + 20 * m
+                        for k, m in zip(sorted(scene.points), m_per_agent)))
+        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene, one launch chain)", "hbm",
+                                                 bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
+    if "decode_nms" in timing:
+        calls, mean_ms = timing["decode_nms"]
+        hw = 256 * 256 if a.workload != "scene8_second_v2xvit" else 128 * 128
+        bts = 4.0 * 20 * hw
+        entries["k8"] = (calls * mean_ms, _entry("K8 heal_decode_nms (decode + filters + rotated NMS; latency-bound)", "hbm",
+                                                 bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
+    # K3: per sparse layer N_in / N_out / R, bytes = 4 (N_in C_in + N_out C_out) + 4 K C_in C_out + 8 R, flops = 2 R C_in C_out
+    if sp_trace:
+        layers, tot_ms, tot_b, tot_f = [], 0.0, 0.0, 0.0
+        for t in sp_trace:
+            n_in = int(t["n_in"].item()) if hasattr(t["n_in"], "item") else int(t["n_in"])
+            n_out = int(t["n_out"].item()) if hasattr(t["n_out"], "item") else int(t["n_out"])
+            n_out = min(n_out, int(t["nbr"].shape[0]))
+            R = int((t["nbr"][:n_out] >= 0).sum().item())
+            ms = t["events"][0].elapsed_time(t["events"][1])
+            bts = 4.0 * (n_in * t["cin"] + n_out * t["cout"]) + 4.0 * t["K"] * t["cin"] * t["cout"] + 8.0 * R
+            fl = 2.0 * R * t["cin"] * t["cout"]
+            layers.append({"cin": t["cin"], "cout": t["cout"], "K": t["K"], "N_in": n_in, "N_out": n_out, "R": R,
+                           "us": round(ms * 1e3, 1), "GB/s": round(bts / (ms * 1e-3) / 1e9, 1),
+                           "frac_hbm": round(bts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "TFLOP/s": round(fl / (ms * 1e-3) / 1e12, 2),
+                           "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)})
+            tot_ms += ms; tot_b += bts; tot_f += fl
+        if tot_ms > 0:
+            entries["k3"] = (tot_ms * max(a.steps, 1), _entry(
+                "K3 heal_sp_conv (gather-GEMM on fp32 MFMA; all sparse layers of one step, rulebook kernels not included)", "hbm",
+                tot_b / (tot_ms * 1e-3) / 1e9, len(layers), tot_ms / len(layers), None,
+                mfma_tflops=round(tot_f / (tot_ms * 1e-3) / 1e12, 2),
+                mfma_frac=round(tot_f / (tot_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), layers=layers))
+    if not entries:
+        return None, []
+    order = sorted(entries, key=lambda k: -entries[k][0])
+    return entries[order[0]][1], [entries[k][1] for k in order[1:]]
 
 
 def main():
@@ -246,6 +373,7 @@ def main():
     fence()
     if not use_graph:
         ops.TIMING = {}
+        ops.SP_TRACE = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
@@ -255,14 +383,18 @@ def main():
         # per-operator HIP-event timing needs host-side launches: an instrumented eager pass over the
         # same K steps, right after the timed graph replays (events cannot be recorded inside a graph)
         ops.TIMING = {}
-        for _ in range(a.steps):
+        for i_ in range(a.steps):
+            ops.SP_TRACE = [] if i_ == a.steps - 1 else None   # sparse-layer anatomy of the last instrumented step
             if solo:
                 pipe.step(next_frame())
             else:
                 eager_step()
         torch.cuda.synchronize()
     timing = ops.timing_summary()
+    work = ops.work_summary()
+    sp_trace = ops.SP_TRACE
     ops.TIMING = None
+    ops.SP_TRACE = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,57 +403,19 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         nx = ny = 512
-        # K2 roofline: algorithmic bytes of the operator / its measured duration (HIP events)
         with torch.no_grad():
             m_per_agent = []
             for k in sorted(scene.points):
                 vs_, pp_ = ([0.1, 0.1, 0.1], 5) if baseline_model else ([0.4, 0.4, 4], 32)
                 _, _, nn_ = ops.voxelize(scene.points[k], hypes["model"]["args"]["lidar_range"], vs_, pp_, 70000)
                 m_per_agent.append(int(nn_.shape[0]))
-        roof = None
-        if "pfn_scatter" in timing:
-            calls, mean_ms = timing["pfn_scatter"]
-            # one launch of the operator = the collated LiDAR agents this rank encodes (reference: one PillarVFE +
-            # PointPillarScatter call per modality batch); algorithmic bytes = sum over those agents
-            lidar_ids = [i for i, m in enumerate(mods) if m == "m1"]
-            if not solo:
-                lidar_ids = [i for i in lidar_ids if i in owned_agents(n_agents, 0, world)]
-            order = sorted(scene.points)
-            m_launch = [m_per_agent[order.index(i)] for i in lidar_ids if i in order]
-            bytes_per_launch = float(sum(k2_algorithmic_bytes(32, m, ny, nx) for m in m_launch))
-            achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_k2_traffic.json")
-            if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 PMC passes (scripts/profile_round.sh)
-                tj = json.load(open(tpath))
-                if int(tj.get("agents_per_launch", -1)) == len(m_launch):
-                    traffic = float(tj["k2_traffic_bytes_per_launch"])
-            roof = {"kernel": f"K2 heal_pfn_scatter, {len(m_launch)} collated LiDAR agents per launch "
-                              "(map memset + k_pfn + k_canvas)", "bound": "hbm",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": bytes_per_launch, "launch_ms": round(mean_ms, 5), "launches": calls}
         kernels = {k: {"calls": c, "mean_ms": round(ms, 5)} for k, (c, ms) in sorted(timing.items())}
-        # secondary roofline entries (same definition as `roofline`: algorithmic bytes / HIP-event duration) for the other
-        # north-star kernels present in this workload; informational, never allowed to break the line
-        roof_other = []
+        roof, roof_other = None, []
         try:
-            if "bev_pool" in timing:
-                cam_ids = [i for i, m in enumerate(mods) if m in Scene.CAMERA_DIMS and (solo or i in owned_agents(n_agents, 0, world))]
-                if cam_ids:
-                    per_call = []
-                    for i in cam_ids:   # one call per camera agent: 4 cameras, D=48 bins, C=128, 256x256 cells
-                        H, W = Scene.CAMERA_DIMS[mods[i]]
-                        fhw = (H // 8) * (W // 8)
-                        per_call.append(4.0 * (4 * 48 * fhw + 4 * 128 * fhw + 128 * 256 * 256))
-                    calls, mean_ms = timing["bev_pool"]
-                    b = sum(per_call) / len(per_call)
-                    roof_other.append({"kernel": "K4 heal_bev_pool, one camera agent per launch (mean over the scene's camera agents)",
-                                       "bound": "hbm", "achieved": round(b / (mean_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                       "unit": "GB/s", "frac": round(b / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "traffic": None, "bytes_per_launch": b, "launch_ms": round(mean_ms, 5), "launches": calls})
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] secondary roofline skipped: {type(e).__name__}: {e}", file=sys.stderr)
+            roof, roof_other = roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, world, n_agents, sp_trace,
+                                               ny, nx)
+        except Exception as e:  # noqa: BLE001 - the report must never break the bench line
+            print(f"[bench] roofline report failed: {type(e).__name__}: {e}", file=sys.stderr)
         line = {
             "metric": "scenes/sec (5-agent OPV2V-H, PointPillars+PyramidFusion)",
             "value": round((world if replicas else 1) * a.steps / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
@@ -339,15 +433,8 @@ def main():
             "roofline": roof, "roofline_other": roof_other, "op_timing_ms": kernels,
         }
         if not a.no_cpu_baseline and world == 1 and not baseline_model:
-            # the CPU port covers the LiDAR (PointPillars) agents; for the heterogeneous workload the
-            # sample is the same scene with every agent treated as a LiDAR agent (stated in `sample`)
-            lidar_hypes = hypes if lidar_only else configs.lidar_pyramid(max_cav=max(5, n_agents))
-            lidar_scene = scene if lidar_only else Scene(n_agents, seed=4, device="cpu")
-            line["cpu_baseline"] = cpu_baseline(lidar_hypes,
-                                                [lidar_scene.points[k].cpu().numpy() for k in sorted(lidar_scene.points)],
-                                                scene.pairwise, n_agents, cls_shift)
-            if not lidar_only:
-                line["cpu_baseline"]["sample"] += " [all 5 agents as PointPillars LiDAR agents: the CPU port has no camera trunk]"
+            scene_cpu = Scene(n_agents, seed=seed0, device="cpu", modalities=mods)   # the same synthetic frame, host copy
+            line["cpu_baseline"] = cpu_baseline(hypes, scene_cpu, cls_shift)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

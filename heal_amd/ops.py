@@ -16,11 +16,18 @@ _WS = {}
 # Optional per-operator timing with HIP events on the launch stream (bench.py turns it on):
 # TIMING = {} enables it; every wrapper then appends (start_event, end_event) under its name.
 TIMING = None
+# SP_TRACE = [] additionally records, per sparse convolution, what its roofline needs: channel counts, taps,
+# the (device) input / output row counts and the neighbour table (-> rule pairs R), with the launch's timing events.
+SP_TRACE = None
 
 
 class _Timed:
-    def __init__(self, name):
+    """work: optional (flops, algorithmic bytes) of this launch, accumulated per name for the roofline report."""
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
         self.name = name
+        self.flops = float(flops)
+        self.nbytes = float(nbytes)
 
     def __enter__(self):
         if TIMING is not None:
@@ -32,7 +39,7 @@ class _Timed:
     def __exit__(self, *exc):
         if TIMING is not None:
             self.e1.record(torch.cuda.current_stream())
-            TIMING.setdefault(self.name, []).append((self.e0, self.e1))
+            TIMING.setdefault(self.name, []).append((self.e0, self.e1, self.flops, self.nbytes))
         return False
 
 
@@ -40,8 +47,17 @@ def timing_summary():
     """name -> (calls, mean milliseconds); call after torch.cuda.synchronize()."""
     out = {}
     for name, evs in (TIMING or {}).items():
-        ms = [a.elapsed_time(b) for a, b in evs]
+        ms = [e[0].elapsed_time(e[1]) for e in evs]
         out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out
+
+
+def work_summary():
+    """name -> dict(calls, total_ms, flops, bytes) summed over the recorded launches (call after a synchronize)."""
+    out = {}
+    for name, evs in (TIMING or {}).items():
+        out[name] = {"calls": len(evs), "total_ms": sum(e[0].elapsed_time(e[1]) for e in evs),
+                     "flops": sum(e[2] for e in evs), "bytes": sum(e[3] for e in evs)}
     return out
 
 
@@ -270,7 +286,7 @@ def warp_fuse(feats, occ, affine_rows, grid_f64=True, crop=None):
     out = torch.empty((C, H, W), dtype=torch.float32, device=feats.device)
     a, ap, adev = _affine_args(affine_rows, n)
     c, cp = _crop_host(crop, n)
-    with _Timed(f"warp_fuse_c{C}"):
+    with _Timed(f"warp_fuse_c{C}", 0.0, 4.0 * H * W * (n * (C + 1) + C)):   # read every agent's map + score, write one
         _capi.call("heal_warp_fuse", _ptr(feats), _ptr(occ), n, C, H, W, ap, adev, int(bool(grid_f64)), cp,
                    _ptr(out), _stream())
     return out
@@ -669,10 +685,15 @@ class SparseTensor:
         K, cin, cout = (int(v) for v in weight.shape)
         n_out = int(nbr.shape[0])
         out = torch.empty((n_out, cout), dtype=torch.float32, device=nbr.device)
-        with _Timed(f"sp_conv_{cin}_{cout}"):
+        # SURVEY 8d, K3 per layer: 4 (N_in C_in + N_out C_out) + 4 K C_in C_out + 8 R bytes, 2 R C_in C_out flops; with device
+        # row counts the host only knows capacities: bench.py fills in the live N_in / N_out / R of its instrumented pass
+        with _Timed(f"sp_conv_{cin}_{cout}") as tm:
             _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight),
                        _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
                        int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
+        if SP_TRACE is not None and TIMING is not None:
+            SP_TRACE.append({"cin": cin, "cout": cout, "K": K, "n_in": self.n_dev if self.n_dev is not None else self.n,
+                             "n_out": n_out_dev if n_out_dev is not None else n_out, "nbr": nbr, "events": (tm.e0, tm.e1)})
         return out
 
     def dense(self):
@@ -711,7 +732,7 @@ def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
     n, C, H, W = (int(v) for v in x.shape)
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     y = torch.empty((n, C, Ho, Wo), dtype=torch.float32, device=x.device)
-    with _Timed(f"grouped_conv3x3_c{C}"):
+    with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * (C // groups) * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
         _capi.call("heal_grouped_conv3x3", _ptr(x), _ptr(weight), _ptr(bias), n, C, int(groups), H, W, int(stride),
                    int(bool(relu)), _ptr(y), _stream())
     return y
@@ -790,7 +811,8 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
             raise _capi.HealAmdError("conv1x1: residual shape mismatch")
     if in_scale is not None:
         in_scale = _need(in_scale.reshape(n, cin), torch.float32, "in_scale")
-    with _Timed(f"conv1x1_{cin}_{cout}" + ("_s2" if stride == 2 else "")):
+    with _Timed(f"conv1x1_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * n * cin * cout * Ho * Wo,
+                4.0 * n * (cin * Ho * Wo + cout * Ho * Wo * (2 if residual is not None else 1))):
         _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
                    _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
                    n, cin, cout, H, W, int(stride), int(act), int(bool(pixel_major)), _ptr(y), _stream())
@@ -878,12 +900,13 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
         bias = _need(bias, torch.float32, "bias")
     if conv3x3_algo(stride, n, cout, H, W) == "winograd":
         frag = conv3x3_winograd_fragments(w)
-        with _Timed(f"conv3x3w_{cin}_{cout}"):
+        with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
             _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
                        int(bool(relu)), _ptr(y), _stream())
         return y
     frag = conv3x3_fragments(w)
-    with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else "")):
+    with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * cin * cout * Ho * Wo,
+                4.0 * n * (cin * H * W + cout * Ho * Wo)):
         _capi.call("heal_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W, int(stride),
                    int(bool(relu)), _ptr(y), _stream())
     return y
