@@ -725,13 +725,51 @@ def agent_attention(q, k, v, heads, scale, key_mask=None, out_rows=None):
 
 
 # ------------------------------------------------------------------------------------------------ K7
+_FRAGG_CACHE = {}
+
+
+def grouped16_fragments(weight, cg):
+    """[C, cg, 3, 3] grouped weight (cg = 16 | 8) -> MFMA A fragments of the 16-channel super-groups
+    [C/16][tap][ks][lane] (block-diagonal zero padding for cg = 8), cached per storage + version."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _FRAGG_CACHE.get(key)
+    if hit is None:
+        if len(_FRAGG_CACHE) > 512:
+            _FRAGG_CACHE.clear()
+        C = int(weight.shape[0])
+        w = weight.detach().reshape(C // 16, 16, cg, 9)                   # [sg, co, ci_in_group, tap]
+        if cg == 16:
+            full = w
+        else:                                                             # two groups of 8: rows 0-7 use ci 0-7, rows 8-15 ci 8-15
+            full = torch.zeros((C // 16, 16, 16, 9), dtype=w.dtype, device=w.device)
+            full[:, :8, :8] = w[:, :8]
+            full[:, 8:, 8:] = w[:, 8:]
+        # [sg, co(ln), ks, lk, tap] -> [sg, tap, ks, lk, ln]
+        f = full.reshape(C // 16, 16, 4, 4, 9).permute(0, 4, 2, 3, 1).contiguous()
+        hit = (f, weight)
+        _FRAGG_CACHE[key] = hit
+    return hit[0]
+
+
 def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
-    """32-group 3x3 conv (padding 1) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3]."""
+    """32-group 3x3 conv (padding 1) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3].  Stride 1 with 16 or 8
+    channels per group runs on the matrix cores (heal_grouped16_conv3x3), the rest on the vector-ALU stencil."""
+    import os
     x = _need(x, torch.float32, "x")
     weight = _need(weight, torch.float32, "weight")
     n, C, H, W = (int(v) for v in x.shape)
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     y = torch.empty((n, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    cg = C // groups
+    # measured (scripts/gconv_bench.py, 5 agents): 16 channels per group 80 -> 55 us on the matrix cores; 8 per group (paired,
+    # half the MFMAs multiply zeros) 98 vs 88 us for the stencil -> only opt-in (HEAL_GCONV_MFMA=8)
+    mode = os.environ.get("HEAL_GCONV_MFMA", "1")
+    if stride == 1 and C % 16 == 0 and W % 4 == 0 and ((cg == 16 and mode != "0") or (cg == 8 and mode == "8")):
+        frag = grouped16_fragments(weight, cg)
+        with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * cg * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
+            _capi.call("heal_grouped16_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), n, C, H, W, int(bool(relu)), _ptr(y),
+                       _stream())
+        return y
     with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * (C // groups) * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
         _capi.call("heal_grouped_conv3x3", _ptr(x), _ptr(weight), _ptr(bias), n, C, int(groups), H, W, int(stride),
                    int(bool(relu)), _ptr(y), _stream())

@@ -339,6 +339,14 @@ int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, co
 int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n, int cin,
                  int cout, int H, int W, int stride, int relu, float* y, void* stream);
 
+/* heal_grouped16_conv3x3: the 32-group 3x3 convolution of the ResNeXt bottlenecks (resblock.py:90-98,110-112; stride 1,
+ *   padding 1, folded BatchNorm bias, ReLU) on the matrix cores, for 16 or 8 channels per group: channels are processed in
+ *   16-channel super-groups (one group of 16, or two groups of 8 with block-diagonal weights).  x, y [n,C,H,W].
+ *   weight_frag[sg][tap][ks][lane] = Wsg[co = lane & 15][ci = ks*4 + (lane >> 4)][tap], sg < C/16, where Wsg is the
+ *   16x16x9 weight of the super-group (zero outside the diagonal blocks when a group has 8 channels); 16-B aligned.   */
+int heal_grouped16_conv3x3(const float* x, const float* weight_frag, const float* bias, int n, int channels, int H, int W,
+                           int relu, float* y, void* stream);
+
 /* heal_conv3x3_winograd: the same operator for stride 1 evaluated with the Winograd F(2x2,3x3) minimal-filtering transform
  *   on the matrix cores (16 transform-domain GEMMs, 2.25x fewer MFMAs than the implicit GEMM of heal_conv3x3; fp32
  *   throughout, results differ from the direct evaluation by rounding only, ~1e-6 relative).  Same tensors as heal_conv3x3.
