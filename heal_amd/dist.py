@@ -2,7 +2,9 @@
 
 The reference has no inference-time parallelism.  Everything up to and including the per-agent
 pyramid stages and occupancy heads is independent per agent in eval mode, so rank r owns scene
-agents {a : a % world == r} (the ego, agent 0, lives on rank 0).  Each rank warps its own agents'
+agents {a : (a + 1) % world == r}: round-robin starting at rank 1, because rank 0 also runs the fusion tail
+(with more ranks than agents it owns no agent at all and its tail overlaps the other ranks' next local stage;
+with fewer it gets the smallest share).  Each rank warps its own agents'
 multi-scale features and scores into the ego frame (heal_warp_agent), packs them into one buffer,
 and ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests) brings every agent's
 warped maps to every rank.  Rank 0 then runs the fusion tail (heal_fuse_warped, deblocks, shrink
@@ -12,8 +14,13 @@ import torch
 import torch.distributed as dist
 
 
+def agent_owner(a, world):
+    """Rank that encodes scene agent a (slot a // world of that rank's buffer)."""
+    return (a + 1) % world
+
+
 def owned_agents(n_agents, rank, world):
-    return [a for a in range(n_agents) if a % world == rank]
+    return [a for a in range(n_agents) if agent_owner(a, world) == rank]
 
 
 def slots_per_rank(n_agents, world):
@@ -43,10 +50,10 @@ def pack_levels(level_feats, level_scores, n_slots):
 def unpack_levels(gathered, shapes, n_agents, world):
     """gathered: [world, n_slots, per_slot]; shapes[l] = (C_l, H_l, W_l).  Returns per level
     (feats [n_agents,C,H,W], scores [n_agents,1,H,W]) in SCENE agent order."""
-    # slot s of rank r holds agent r + s*world
+    # slot s of rank r holds agent ((r - 1) mod world) + s*world
     order = []
     for a in range(n_agents):
-        order.append((a % world, a // world))
+        order.append((agent_owner(a, world), a // world))
     rows = torch.stack([gathered[r, s] for r, s in order])  # [n_agents, per_slot]
     out = []
     off = 0
@@ -69,8 +76,9 @@ def pack_maps(x, n_slots):
 
 
 def unpack_maps(gathered, shape, n_agents, world):
-    """gathered [world, n_slots, C*H*W] -> [n_agents, C, H, W] in SCENE agent order (slot s of rank r = agent r + s*world)."""
-    rows = torch.stack([gathered[a % world, a // world] for a in range(n_agents)])
+    """gathered [world, n_slots, C*H*W] -> [n_agents, C, H, W] in SCENE agent order (agent a = slot a // world of rank
+    agent_owner(a))."""
+    rows = torch.stack([gathered[agent_owner(a, world), a // world] for a in range(n_agents)])
     return rows.reshape((n_agents,) + tuple(shape))
 
 

@@ -62,8 +62,15 @@ def test_all_gather_of_packed_maps_world2(tmp_path, n_agents):
 
 
 def test_ownership_and_padding_rules():
-    assert hd.owned_agents(5, 0, 2) == [0, 2, 4] and hd.owned_agents(5, 1, 2) == [1, 3]
-    assert hd.owned_agents(5, 7, 8) == [] and hd.owned_agents(5, 0, 8) == [0]
+    # round-robin starting at rank 1: rank 0 also runs the fusion tail, so it gets the smallest share ...
+    assert hd.owned_agents(5, 0, 2) == [1, 3] and hd.owned_agents(5, 1, 2) == [0, 2, 4]
+    # ... and no agent at all when there are more ranks than agents (its tail then overlaps the others' next local stage)
+    assert hd.owned_agents(5, 7, 8) == [] and hd.owned_agents(5, 0, 8) == [] and hd.owned_agents(5, 1, 8) == [0]
+    assert hd.owned_agents(5, 5, 8) == [4] and hd.owned_agents(8, 0, 8) == [7]
+    for world in (1, 2, 3, 4, 5, 8):   # a partition, and agent a sits in slot a // world of its owner
+        owned = [hd.owned_agents(5, r, world) for r in range(world)]
+        assert sorted(a for o in owned for a in o) == list(range(5))
+        assert all(o.index(a) == a // world for o in owned for a in o)
     assert hd.slots_per_rank(5, 2) == 3 and hd.slots_per_rank(5, 8) == 1 and hd.slots_per_rank(5, 4) == 2
     # padding slots are all-zero: score 0 -> masked out by the fusion kernel
     lf = [torch.ones((1,) + s) for s in SHAPES]
