@@ -197,20 +197,39 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, co
 // relative to the direct evaluation, inside the 1e-3 feature tolerance and tested at 1e-4.
 constexpr int WG_KC = 8;                         // input channels per chunk
 constexpr int WG_PROW = 24;                      // patch row stride (words): 2*24 = 48 -> the 4 tile rows of a 32-lane ds_read_b64 phase fall in disjoint bank ranges
-constexpr int WG_PCI = 18 * WG_PROW;             // 432 words per channel
-constexpr int WG_VROW = 80;                      // sV row stride (64 tiles + 16): k-rows lk, lk+1 of a B fragment hit disjoint banks
-constexpr int WG_MROW = 68;                      // sM row stride: 4*68 = 16 (mod 32) -> conflict-free accumulator dump
 constexpr int WG_PDUMMY = 512;                   // landing zone of the staging slots beyond the patch (keeps the stores unconditional)
-constexpr int WG_SMEM = 16 * 16 * WG_MROW;       // 17408 words (68 KB) >= patch (3456) + dummy (512) + sV (10240)
-static_assert(WG_KC * WG_PCI + WG_PDUMMY + 16 * WG_KC * WG_VROW <= WG_SMEM, "staging buffers exceed the epilogue buffer");
 
-__global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ x, const float4* __restrict__ ufrag,
-                                                     const float* __restrict__ bias, const float* __restrict__ res,
-                                                     int Cin, int nchunks, int Cout, int H, int W, int tiles_x, int relu,
-                                                     float* __restrict__ y) {
-    __shared__ __attribute__((aligned(16))) float smem[WG_SMEM];
+// NW = waves per block: 8 -> 16x16 output pixels (64 tiles), two transform positions per wave, one block per CU;
+//                       4 -> 8x16 output pixels (32 tiles), four transform positions per wave, TWO independent blocks per CU
+//                            (same 8 waves per CU), so one block's transform phase overlaps the other's MFMA phase.
+template <int NW>
+struct WgGeom {
+    static constexpr int TR = 2 * NW;                    // output rows of the block's tile
+    static constexpr int NTL = 8 * NW;                   // 2x2 tiles per block (TR/2 rows x 8)
+    static constexpr int XW = 16 / NW;                   // transform positions per wave
+    static constexpr int NTN = NTL / 16;                 // MFMA n-tiles per transform position
+    static constexpr int PR = TR + 2;                    // patch rows
+    static constexpr int PE = PR * 18;                   // patch elements per channel
+    static constexpr int PCI = PR * WG_PROW;             // LDS words per patch channel
+    static constexpr int VROW = NTL + 16;                // sV row stride: k-rows lk, lk+1 of a B fragment hit disjoint banks
+    static constexpr int MROW = NTL + 4;                 // sM row stride: 4*MROW = 16 (mod 32) -> conflict-free accumulator dump
+    static constexpr int STAGE = WG_KC * PCI + WG_PDUMMY + 16 * WG_KC * VROW;
+    static constexpr int SMEM = STAGE > 16 * 16 * MROW ? STAGE : 16 * 16 * MROW;   // staging buffers alias the epilogue buffer
+    static constexpr int NP = (WG_KC * PE + 64 * NW - 1) / (64 * NW);              // patch elements staged per thread
+    static constexpr int UQ = XW * 2;                    // float4 of U per lane per chunk (XW xi x 2 k-steps x 4 m-tiles floats)
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restrict__ x, const float4* __restrict__ ufrag,
+                                                         const float* __restrict__ bias, const float* __restrict__ res,
+                                                         int Cin, int nchunks, int Cout, int H, int W, int tiles_x, int relu,
+                                                         float* __restrict__ y) {
+    using G = WgGeom<NW>;
+    constexpr int NT = 64 * NW, TR = G::TR, NTL = G::NTL, XW = G::XW, NTN = G::NTN, PE = G::PE, PCI = G::PCI;
+    constexpr int VROW = G::VROW, MROW = G::MROW, NP = G::NP, UQ = G::UQ;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
     float* sP = smem;
-    float* sV = smem + WG_KC * WG_PCI + WG_PDUMMY;
+    float* sV = smem + WG_KC * PCI + WG_PDUMMY;
     float* sM = smem;
 
     // Block order: tile fastest, image next, Cout block SLOWEST -- the Winograd weights are the big stream (16 x Cin x 64
@@ -219,85 +238,79 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
     const Block3 bk = xcd_block();
     const int mb = bk.z, n = bk.y;
     const int tyb = bk.x / tiles_x, txb = bk.x - tyb * tiles_x;
-    const int oy0 = tyb * 16, ox0 = txb * 16;
+    const int oy0 = tyb * TR, ox0 = txb * 16;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
     const size_t HW = (size_t)H * W;
     const float* __restrict__ xin = x + (size_t)n * Cin * HW;
 
-    // patch staging plan: element e = tid + 512 j of the [8][18][18] patch (same positions for every chunk).  Loads are
+    // patch staging plan: element e = tid + NT j of the [8][PR][18] patch (same positions for every chunk).  Loads are
     // UNCONDITIONAL (clamped in-bounds address; the zero padding / channel tail is applied when the value goes to LDS):
     // predicated loads put every load in its own basic block, and the compiler's waitcnt insertion then falls back to
     // `s_waitcnt vmcnt(0)` at each of them -- which drains the U loads issued just before and serialises one L2 round trip per
     // chunk (visible in the ISA of the first version of this loop; scripts/wg_dbg.py: 125 + 76 us of 654 us).
-    constexpr int NP = (WG_KC * 324 + 511) / 512;  // 6
     int p_off[NP];      // offset inside the image plane (clamped to 0 when outside)
+    int p_lds[NP];      // LDS word (slots beyond the patch land in the dummy zone: no branch around the store -- a conditional
+                        // store lets the compiler sink the LOAD into the branch, right in front of its wait)
     unsigned p_ok = 0;  // bit j: element j lies inside the image and the patch
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int e = threadIdx.x + 512 * j;
-        const int ci = e / 324, rem = e - ci * 324, py = rem / 18, px = rem - py * 18;
+        const int e = threadIdx.x + NT * j;
+        const int ci = e / PE, rem = e - ci * PE, py = rem / 18, px = rem - py * 18;
         const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-        const bool ok = e < WG_KC * 324 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool ok = e < WG_KC * PE && gy >= 0 && gy < H && gx >= 0 && gx < W;
         p_off[j] = ok ? gy * W + gx : 0;
         p_ok |= ok ? (1u << j) : 0u;
+        p_lds[j] = e < WG_KC * PE ? ci * PCI + py * WG_PROW + px : WG_KC * PCI + (e - WG_KC * PE) % WG_PDUMMY;
     }
     float pst[NP];
     auto load_patch = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int ch = min(c * WG_KC + (int)(threadIdx.x + 512 * j) / 324, Cin - 1);
+            const int ch = min(c * WG_KC + (int)(threadIdx.x + NT * j) / PE, Cin - 1);
             pst[j] = xin[(size_t)ch * HW + p_off[j]];
         }
     };
-    int p_lds[NP];      // LDS word of element j (slots beyond the patch land in the dummy zone: no branch around the store --
-                        // a conditional store lets the compiler sink the LOAD into the branch, right in front of its wait)
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int e = threadIdx.x + 512 * j;
-        const int ci = e / 324, rem = e - ci * 324, py = rem / 18, px = rem - py * 18;
-        p_lds[j] = e < WG_KC * 324 ? ci * WG_PCI + py * WG_PROW + px : WG_KC * WG_PCI + (e - WG_KC * 324);
-    }
     auto store_patch = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int ci = (int)(threadIdx.x + 512 * j) / 324;
+            const int ci = (int)(threadIdx.x + NT * j) / PE;
             const bool ok = ((p_ok >> j) & 1u) && c * WG_KC + ci < Cin;
             sP[p_lds[j]] = ok ? pst[j] : 0.f;
         }
     };
-    // U fragments of this wave: 16 floats per lane per chunk, lane-major: [mb][chunk][wave][lane][(xi_i*2 + ks)*4 + mt]
-    const float4* __restrict__ ubase = ufrag + ((size_t)mb * nchunks * 8 + wave) * 64 * 4 + (size_t)l * 4;
-    float4 ua[4], un[4];                          // this chunk's / the next chunk's U fragments
-    auto load_u = [&](int c, float4 (&dst)[4]) {
+    // U fragments of this wave: XW*8 floats per lane per chunk, lane-major: [mb][chunk][wave][lane][(xi_i*2 + ks)*4 + mt]
+    const float4* __restrict__ ubase = ufrag + (((size_t)mb * nchunks * NW + wave) * 64 + l) * UQ;
+    float4 ua[UQ];
+    auto load_u = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = ubase[(size_t)c * 8 * 64 * 4 + q];
+        for (int q = 0; q < UQ; ++q) ua[q] = ubase[(size_t)c * NW * 64 * UQ + q];
     };
 
-    f32x4 acc[2][4][4];
+    f32x4 acc[XW][4][NTN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < XW; ++a)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[a][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NTN; ++nt) acc[a][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transform role of this thread: channel tci of the chunk, tile (tty, ttx) of the 8x8 tile grid
-    const int tci = threadIdx.x >> 6, ttile = threadIdx.x & 63, tty = ttile >> 3, ttx = ttile & 7;
-    const float* __restrict__ dsrc = sP + tci * WG_PCI + (2 * tty) * WG_PROW + 2 * ttx;
-    float* __restrict__ vdst = sV + tci * WG_VROW + ttile;
+    // transform role of this thread: channel tci of the chunk, tile (tty, ttx) of the (TR/2) x 8 tile grid
+    const int tci = threadIdx.x / NTL, ttile = threadIdx.x - tci * NTL, tty = ttile >> 3, ttx = ttile & 7;
+    const float* __restrict__ dsrc = sP + tci * PCI + (2 * tty) * WG_PROW + 2 * ttx;
+    float* __restrict__ vdst = sV + tci * VROW + ttile;
 
-    // Software pipeline: the global loads of chunk c+1 (input patch -> registers, U fragments -> `un`) are issued at the TOP
-    // of iteration c and consumed at its BOTTOM (patch -> LDS) / in iteration c+1 (U), so a whole transform + MFMA phase
-    // covers their latency -- which requires barriers that do not drain VMEM (lds_barrier, common.h) and a loop body that is
-    // ONE basic block (no predicated loads, the last iteration reloads chunk nchunks-1 instead of branching).
+    // Software pipeline: the global loads of chunk c+1 (input patch -> registers) are issued at the TOP of iteration c and
+    // consumed at its BOTTOM (-> LDS); the U fragments of chunk c+1 are requested right after the MFMAs of chunk c have
+    // been issued and land during the next barrier + transform.  This requires barriers that do not drain VMEM
+    // (lds_barrier, common.h) and a loop body that is ONE basic block (no predicated loads; the last iteration reloads
+    // chunk nchunks-1 instead of branching).
     load_patch(0);
-    load_u(0, ua);
+    load_u(0);
     store_patch(0);
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);
         lds_barrier();                            // patch(c) is in LDS; every wave is done with sV of chunk c-1
-        load_u(cn, un);
         load_patch(cn);
         {   // V = B^T d B for (tci, ttile)
             float d[4][4];
@@ -317,26 +330,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vdst[((4 * i + 0) * WG_KC) * WG_VROW] = t[i][0] - t[i][2];
-                vdst[((4 * i + 1) * WG_KC) * WG_VROW] = t[i][1] + t[i][2];
-                vdst[((4 * i + 2) * WG_KC) * WG_VROW] = t[i][2] - t[i][1];
-                vdst[((4 * i + 3) * WG_KC) * WG_VROW] = t[i][1] - t[i][3];
+                vdst[((4 * i + 0) * WG_KC) * VROW] = t[i][0] - t[i][2];
+                vdst[((4 * i + 1) * WG_KC) * VROW] = t[i][1] + t[i][2];
+                vdst[((4 * i + 2) * WG_KC) * VROW] = t[i][2] - t[i][1];
+                vdst[((4 * i + 3) * WG_KC) * VROW] = t[i][1] - t[i][3];
             }
         }
         lds_barrier();                            // sV(c) complete; sP free (global loads stay in flight)
         {
-            const float a_[16] = {ua[0].x, ua[0].y, ua[0].z, ua[0].w, ua[1].x, ua[1].y, ua[1].z, ua[1].w,
-                                  ua[2].x, ua[2].y, ua[2].z, ua[2].w, ua[3].x, ua[3].y, ua[3].z, ua[3].w};
+            float a_[UQ * 4];
 #pragma unroll
-            for (int xi_i = 0; xi_i < 2; ++xi_i) {
-                const float* __restrict__ vb = sV + ((2 * wave + xi_i) * WG_KC + lk) * WG_VROW + ln;
+            for (int q = 0; q < UQ; ++q) { a_[4 * q] = ua[q].x; a_[4 * q + 1] = ua[q].y; a_[4 * q + 2] = ua[q].z; a_[4 * q + 3] = ua[q].w; }
+#pragma unroll
+            for (int xi_i = 0; xi_i < XW; ++xi_i) {
+                const float* __restrict__ vb = sV + ((XW * wave + xi_i) * WG_KC + lk) * VROW + ln;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    float b[4];
+                    float b[NTN];
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) b[nt] = vb[ks * 4 * WG_VROW + nt * 16];
+                    for (int nt = 0; nt < NTN; ++nt) b[nt] = vb[ks * 4 * VROW + nt * 16];
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
                             acc[xi_i][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[(xi_i * 2 + ks) * 4 + mt], b[nt],
@@ -344,36 +358,36 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
                 }
             }
         }
+        load_u(cn);                               // next chunk's U: lands during the barrier + transform that follow
         store_patch(cn);                          // sP is free since the second barrier (last iteration: rewrites the last chunk, unused)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ua[q] = un[q];
     }
 
     // Epilogue: four passes of 16 output channels (m-tile p) through sM[xi][co][tile]
     const size_t HWo = HW;                        // stride 1, padding 1: same map size
     float* __restrict__ yout = y + (size_t)n * Cout * HWo;
     const float* __restrict__ rin = res ? res + (size_t)n * Cout * HWo : nullptr;
-    const int etile = threadIdx.x & 63, ecg = threadIdx.x >> 6, ety = etile >> 3, etx = etile & 7;
+    constexpr int CPP = NT / NTL;                 // channels handled per sweep of the block (8)
+    const int ecg = threadIdx.x / NTL, etile = threadIdx.x - ecg * NTL, ety = etile >> 3, etx = etile & 7;
     const int oy = oy0 + 2 * ety, ox = ox0 + 2 * etx;
     const bool even_w = (W & 1) == 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        __syncthreads();                          // staging buffers (first pass) / previous pass no longer read
+        lds_barrier();                            // staging buffers (first pass) / previous pass no longer read
 #pragma unroll
-        for (int xi_i = 0; xi_i < 2; ++xi_i)
+        for (int xi_i = 0; xi_i < XW; ++xi_i)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    sM[((2 * wave + xi_i) * 16 + lk * 4 + r) * WG_MROW + nt * 16 + ln] = acc[xi_i][p][nt][r];
-        __syncthreads();
+                    sM[((XW * wave + xi_i) * 16 + lk * 4 + r) * MROW + nt * 16 + ln] = acc[xi_i][p][nt][r];
+        lds_barrier();
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = ecg + 8 * h;           // channel inside the 16-channel pass
+        for (int h = 0; h < 16 / CPP; ++h) {
+            const int col = ecg + CPP * h;         // channel inside the 16-channel pass
             const int co = mb * 64 + p * 16 + col;
             float m[16];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 16 + col) * WG_MROW + etile];
+            for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 16 + col) * MROW + etile];
             if (co >= Cout || oy >= H || ox >= W) continue;
             // Y = A^T M A,  A^T = [[1,1,1,0],[0,1,-1,-1]]
             float t0[4], t1[4];
@@ -399,7 +413,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(const float* __restrict__ 
         }
     }
 }
-
 
 // ---- 32-group 3x3 convolution of the ResNeXt bottlenecks on the matrix cores ------------------------------------------------
 // heal_grouped_conv3x3 (bev_conv.hip) is a vector-ALU stencil: 21-38 TFLOP/s, 4.6x the HBM floor at 16 channels per group.
@@ -552,15 +565,21 @@ extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const floa
 
 
 extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
-                                     int cin, int cout, int H, int W, int relu, float* y, void* stream) {
+                                     int cin, int cout, int H, int W, int relu, int waves, float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv3x3_winograd: bad shape");
     HEAL_REQUIRE(x && u_frag && y, "conv3x3_winograd: null pointer");
     HEAL_REQUIRE(((uintptr_t)u_frag & 15) == 0, "conv3x3_winograd: weight fragments must be 16-B aligned");
     const int nchunks = (cin + WG_KC - 1) / WG_KC, mblocks = (cout + 63) / 64;
-    const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 16);
-    HEAL_REQUIRE((long long)tiles_x * tiles_y <= 65535 && n <= 65535, "conv3x3_winograd: map too large for the launch grid");
-    k_conv3x3_wino<<<dim3(tiles_x * tiles_y, n, mblocks), 512, 0, (hipStream_t)stream>>>(
-        x, reinterpret_cast<const float4*>(u_frag), bias, residual, cin, nchunks, cout, H, W, tiles_x, relu, y);
+    HEAL_REQUIRE(waves == 8 || waves == 4, "conv3x3_winograd: waves per block must be 8 (16x16-pixel tiles) or 4 (8x16)");
+    const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 2 * waves);
+    HEAL_REQUIRE((long long)tiles_x * tiles_y <= 2147483647ll / 4 && n <= 65535 && mblocks <= 65535,
+                 "conv3x3_winograd: map too large for the launch grid");
+    const dim3 grid(tiles_x * tiles_y, n, mblocks);
+    const float4* uf = reinterpret_cast<const float4*>(u_frag);
+    if (waves == 8)
+        k_conv3x3_wino<8><<<grid, 512, 0, (hipStream_t)stream>>>(x, uf, bias, residual, cin, nchunks, cout, H, W, tiles_x, relu, y);
+    else
+        k_conv3x3_wino<4><<<grid, 256, 0, (hipStream_t)stream>>>(x, uf, bias, residual, cin, nchunks, cout, H, W, tiles_x, relu, y);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -883,10 +883,22 @@ def conv3x3_fragments(w):
 _FRAGW_CACHE = {}
 
 
-def conv3x3_winograd_fragments(w):
+def conv3x3_winograd_waves(n=1, cout=64, H=256, W=256):
+    """Waves per Winograd block: 8 (16x16-pixel tiles, one block per CU: best operand reuse) when that still gives every CU two
+    or more blocks, else 4 (8x16-pixel tiles, two independent blocks per CU whose transform / MFMA phases overlap; measured
+    crossover, scripts/conv3x3_bench.py); HEAL_WG_WAVES overrides."""
+    import os
+    e = os.environ.get("HEAL_WG_WAVES", "")
+    if e in ("4", "8"):
+        return int(e)
+    blocks8 = n * ((cout + 63) // 64) * ((H + 15) // 16) * ((W + 15) // 16)
+    return 8 if blocks8 >= 512 else 4
+
+
+def conv3x3_winograd_fragments(w, waves=8):
     """Cached Winograd-domain weights U = G g G^T of a [Cout,Cin,3,3] filter bank in the lane-major fragment order
-    heal_conv3x3_winograd reads (include/heal_amd.h); keyed by storage + version."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
+    heal_conv3x3_winograd reads for `waves` waves per block (include/heal_amd.h); keyed by storage + version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), waves)
     hit = _FRAGW_CACHE.get(key)
     if hit is None:
         if len(_FRAGW_CACHE) > 512:
@@ -899,7 +911,7 @@ def conv3x3_winograd_fragments(w):
         if (mpad, kpad) != (cout, cin):
             U = torch.nn.functional.pad(U, (0, 0, 0, kpad - cin, 0, mpad - cout))
         # [mb, mt, ln, chunk, ks, lk, w, xi_i] -> [mb, chunk, w, lk, ln, xi_i, ks, mt]
-        f = U.reshape(mpad // 64, 4, 16, kpad // 8, 2, 4, 8, 2).permute(0, 3, 6, 5, 2, 7, 4, 1).contiguous()
+        f = U.reshape(mpad // 64, 4, 16, kpad // 8, 2, 4, waves, 16 // waves).permute(0, 3, 6, 5, 2, 7, 4, 1).contiguous()
         hit = (f, w)
         _FRAGW_CACHE[key] = hit
     return hit[0]
@@ -937,10 +949,11 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
     if bias is not None:
         bias = _need(bias, torch.float32, "bias")
     if conv3x3_algo(stride, n, cout, H, W) == "winograd":
-        frag = conv3x3_winograd_fragments(w)
+        waves = conv3x3_winograd_waves(n, cout, H, W)
+        frag = conv3x3_winograd_fragments(w, waves)
         with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
             _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
-                       int(bool(relu)), _ptr(y), _stream())
+                       int(bool(relu)), waves, _ptr(y), _stream())
         return y
     frag = conv3x3_fragments(w)
     with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * cin * cout * Ho * Wo,

@@ -351,11 +351,12 @@ int heal_grouped16_conv3x3(const float* x, const float* weight_frag, const float
  *   on the matrix cores (16 transform-domain GEMMs, 2.25x fewer MFMAs than the implicit GEMM of heal_conv3x3; fp32
  *   throughout, results differ from the direct evaluation by rounding only, ~1e-6 relative).  Same tensors as heal_conv3x3.
  *   u_frag = U = G g G^T of every (co, ci) filter (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), zero-padded to
- *   [Mpad = ceil64(Cout), Kpad = ceil8(Cin)], lane-major per wave:
- *   frag[mb][chunk][w][lane][(xi_i*2 + ks)*4 + mt] = U[mb*64 + mt*16 + (lane & 15)][chunk*8 + ks*4 + (lane >> 4)][xi = 2w + xi_i],
- *   w < 8, xi = 4a + b indexes the 4x4 transform domain (16-B aligned).                                                 */
+ *   [Mpad = ceil64(Cout), Kpad = ceil8(Cin)], lane-major per wave; `waves` = 8 (block = 64 channels x 16x16 pixels, two
+ *   transform positions per wave) or 4 (64 channels x 8x16 pixels, four positions per wave, two blocks per CU); XW = 16/waves:
+ *   frag[mb][chunk][w][lane][(xi_i*2 + ks)*4 + mt] = U[mb*64 + mt*16 + (lane & 15)][chunk*8 + ks*4 + (lane >> 4)][xi = XW*w + xi_i],
+ *   w < waves, xi_i < XW, xi = 4a + b indexes the 4x4 transform domain (16-B aligned).  The fragment order depends on `waves`. */
 int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
-                          int cout, int H, int W, int relu, float* y, void* stream);
+                          int cout, int H, int W, int relu, int waves, float* y, void* stream);
 
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265

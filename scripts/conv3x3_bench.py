@@ -64,8 +64,12 @@ def main():
         row["default_algo"] = ops.conv3x3_algo(st, n, cout, H, W)
         if st == 1:
             os.environ["HEAL_C3_ALGO"] = "winograd"
+            os.environ["HEAL_WG_WAVES"] = "8"
+            row["winograd_w8_us"] = round(timed(lambda: ops.conv3x3(x, w, b, r, True, st)), 1)
+            os.environ["HEAL_WG_WAVES"] = "4"
             t = timed(lambda: ops.conv3x3(x, w, b, r, True, st))
             os.environ.pop("HEAL_C3_ALGO", None)
+            os.environ.pop("HEAL_WG_WAVES", None)
             row["winograd_us"] = round(t, 1)
             row["winograd_TF_equiv"] = round(flops / t / 1e6, 1)
         err = float((ops.conv3x3(x, w, b, r, True, st) - lib()).abs().max() / lib().abs().max())

@@ -653,14 +653,15 @@ def test_conv1x1_fused_vs_torch(n, cin, cout, H, W, act, with_res, with_bias):
     (2, 3, 32, 24, 40, 2, False, False),        # image stem sized channels
     (1, 16, 130, 8, 8, 1, False, True),         # map smaller than a tile, Cout spills into a third 64-block
 ])
-@pytest.mark.parametrize("algo", ["winograd", "direct"])
+@pytest.mark.parametrize("algo", ["winograd", "winograd8", "direct"])
 def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu, algo, monkeypatch):
     """heal_conv3x3 (implicit GEMM) / heal_conv3x3_winograd (F(2x2,3x3), stride 1) on fp32 MFMA with fused bias / residual /
     ReLU against torch's fp64 convolution: 1e-4 relative to the output scale (fp32 accumulation order and, for Winograd, the
     transform's rounding sequence differ; the north-star tolerance for features is 1e-3)."""
     from heal_amd import ops
-    monkeypatch.setenv("HEAL_C3_ALGO", algo)
-    if algo == "winograd" and stride != 1:
+    monkeypatch.setenv("HEAL_C3_ALGO", algo.rstrip("8"))
+    monkeypatch.setenv("HEAL_WG_WAVES", "8" if algo.endswith("8") else "4")   # 16x16- or 8x16-pixel Winograd blocks
+    if algo.startswith("winograd") and stride != 1:
         pytest.skip("Winograd F(2x2,3x3) is the stride-1 formulation; stride 2 always runs the implicit GEMM")
     g = torch.Generator().manual_seed(cin * 31 + cout + H)
     x = torch.randn((n, cin, H, W), generator=g).cuda()
