@@ -106,23 +106,110 @@ __device__ __forceinline__ void decode_anchor(const float* __restrict__ cls, con
     o.pass = (x_len <= 6.f) && (y_len <= 6.f) && (y_len != 0.f) && (zmin >= -3.f) && (zmax <= 1.f);
 }
 
+// One thread per anchor: decode + filters.  Survivors are COMPACTED into a candidate list of 64-bit composites
+// (score key << 32 | anchor index; one wave-aggregated atomic per wave): all composites are distinct, and descending
+// composite order = the reference's order (descending score, ties: larger anchor index first == stable argsort reversed), so
+// the order in which the atomics hand out slots does not matter.
 __global__ __launch_bounds__(256) void k_decode_key(const float* __restrict__ cls,
                                                    const float* __restrict__ reg,
                                                    const float* __restrict__ dir,
                                                    const float* __restrict__ anchors, DecodeParams p,
-                                                   int n, uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, int* __restrict__ n_cand) {
+                                                   int n, unsigned long long* __restrict__ cand_list,
+                                                   int* __restrict__ n_cand) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     bool cand = false;
+    unsigned long long comp = 0ull;
     if (j < n) {
         Box3D b;
         decode_anchor(cls, reg, dir, anchors, p, j, false, b);
         cand = b.pass;
-        keys[j] = cand ? (__float_as_uint(b.score) - p.key_base) : 0u;
-        vals[j] = (uint32_t)j;
+        comp = ((unsigned long long)(__float_as_uint(b.score) - p.key_base) << 32) | (unsigned)j;
     }
     const unsigned long long m = __ballot(cand);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_cand, __popcll(m));
+    if (!m) return;
+    int base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(n_cand, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (cand) cand_list[base + __popcll(m & lanemask_lt())] = comp;
+}
+
+// Top-`top` of the candidate list in descending composite order -> sel[0 .. K), K = min(n_cand, top).  One block:
+//   * n_cand <= CAP (always, in practice: a few hundred to a few thousand anchors pass the score threshold): all candidates go
+//     to LDS and are sorted by a bitonic network;
+//   * more candidates: an MSB-first radix select (8-bit digits over the 64-bit composite, histogram in LDS,
+//     the list re-read from global memory per pass) finds the composite T of rank `top`; the candidates >= T are exactly the
+//     top `top` (composites are distinct) and are then sorted the same way.
+// Replaces the stable radix sort of all H*W*A keys (12 launches, ~60 us for 131 072 anchors) that only served to pick 1000.
+constexpr int TOPK_CAP = 4096, TOPK_THREADS = 1024;
+__global__ __launch_bounds__(TOPK_THREADS) void k_topk_sort(const unsigned long long* __restrict__ cand_list,
+                                                           const int* __restrict__ n_cand, int top,
+                                                           uint32_t* __restrict__ sel) {
+    __shared__ unsigned long long sbuf[TOPK_CAP];
+    __shared__ int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_need, s_count;
+    const int N = *n_cand;
+    const int K = min(N, top);
+    if (K <= 0) return;
+    int M;  // elements to sort
+    if (N <= TOPK_CAP) {
+        for (int i = threadIdx.x; i < N; i += TOPK_THREADS) sbuf[i] = cand_list[i];
+        M = N;
+    } else {
+        // radix select: after the loop, elements with (v >> shift) > prefix are in, == prefix are the ties to split further
+        if (threadIdx.x == 0) { s_prefix = 0ull; s_need = K; }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int i = threadIdx.x; i < 256; i += TOPK_THREADS) hist[i] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const int hi_shift = shift + 8;
+            for (int i = threadIdx.x; i < N; i += TOPK_THREADS) {
+                const unsigned long long v = cand_list[i];
+                const bool in_prefix = hi_shift >= 64 ? true : ((v >> hi_shift) == prefix);
+                if (in_prefix) atomicAdd(&hist[(int)((v >> shift) & 0xFFull)], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int need = s_need, d = 255;
+                for (; d > 0; --d) {           // walk the digits from the top until `need` is covered
+                    if (hist[d] >= need) break;
+                    need -= hist[d];
+                }
+                s_need = need;                  // still needed among the elements whose digit == d
+                s_prefix = (prefix << 8) | (unsigned long long)d;
+            }
+            __syncthreads();
+        }
+        // s_prefix is now the composite of rank K (need == 1): gather everything >= it
+        const unsigned long long T = s_prefix;
+        if (threadIdx.x == 0) s_count = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += TOPK_THREADS) {
+            const unsigned long long v = cand_list[i];
+            if (v >= T) { const int q = atomicAdd(&s_count, 1); if (q < TOPK_CAP) sbuf[q] = v; }
+        }
+        __syncthreads();
+        M = min(s_count, TOPK_CAP);
+    }
+    int P = 1;
+    while (P < M) P <<= 1;
+    for (int i = M + threadIdx.x; i < P; i += TOPK_THREADS) sbuf[i] = 0ull;   // pad: sorts to the end (descending)
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += TOPK_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = sbuf[i], b = sbuf[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { sbuf[i] = b; sbuf[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < K; i += TOPK_THREADS) sel[i] = (uint32_t)(sbuf[i] & 0xFFFFFFFFull);
 }
 
 // ---- fp64 convex quad IoU (same operation order as oracle/oracle_ref.c) ---------------------------
@@ -207,11 +294,11 @@ struct NmsBufs {
 __global__ __launch_bounds__(64) void k_nms_prepare(const float* __restrict__ cls, const float* __restrict__ reg,
                                                    const float* __restrict__ dir,
                                                    const float* __restrict__ anchors, DecodeParams p, int n,
-                                                   const uint32_t* __restrict__ svals, int top, NmsBufs nb) {
+                                                   const uint32_t* __restrict__ sel, int top, NmsBufs nb) {
     const int r = blockIdx.x * 64 + threadIdx.x;
     const int K = min(*nb.n_cand, top);
     if (r >= K) return;
-    const int j = (int)svals[n - 1 - r];
+    const int j = (int)sel[r];
     Box3D b;
     decode_anchor(cls, reg, dir, anchors, p, j, true, b);
     bool inside = true;
@@ -232,57 +319,70 @@ __global__ __launch_bounds__(64) void k_nms_prepare(const float* __restrict__ cl
     nb.inrange[r] = inside ? 1 : 0;
 }
 
-// One 64x64 tile per block, 8 waves: wave w tests every row of the tile against columns [8w, 8w+8), so the serial
-// chain of fp64 clips per lane is 8 long instead of 64 (the kernel is latency-bound: ~136 tiles for 1000 boxes).
+// One 64x64 tile of the upper-triangular suppression bit matrix per block (8 waves).  Phase 1: all 4096 bounding-box tests
+// (strictly separated boxes => empty intersection => IoU 0, or NaN for a degenerate pair: never above the threshold, exactly
+// as the full clip would conclude), the surviving pairs compacted into an LDS list.  Phase 2: the threads take surviving
+// pairs round-robin, one fp64 convex clip each -- the first version gave every lane 8 columns to walk serially, so a tile
+// took as long as its unluckiest lane's chain of clips (95 us for 136 tiles).
 constexpr int NMS_SPLIT = 8, NMS_COLS = 64 / NMS_SPLIT;
 __global__ __launch_bounds__(64 * NMS_SPLIT) void k_nms_mask(NmsBufs nb, int top, int words, float thr) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
     const int K = nb.n_cand ? min(*nb.n_cand, top) : top;
     if (bi * 64 >= K || bj * 64 >= K) return;
-    __shared__ float cq[64][8];
-    __shared__ float cbb[64][4];  // axis-aligned bounds (xmin, xmax, ymin, ymax) of the column quads
-    __shared__ unsigned char part[64][NMS_SPLIT];
+    __shared__ float rq[64][8], cq[64][8];
+    __shared__ float rbb[64][4], cbb[64][4];  // axis-aligned bounds (xmin, xmax, ymin, ymax)
+    __shared__ unsigned long long bits[64];
+    __shared__ unsigned short pairs[4096];
+    __shared__ int n_pairs;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
-    const int cj = bj * 64 + lane;
-    if (chunk == 0 && cj < K) {
+    if (chunk < 2) {
+        const int idx = (chunk == 0 ? bi : bj) * 64 + lane;
+        float (*q)[8] = chunk == 0 ? rq : cq;
+        float (*bb)[4] = chunk == 0 ? rbb : cbb;
         float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        if (idx < K) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float px = nb.quads[(size_t)cj * 8 + 2 * k], py = nb.quads[(size_t)cj * 8 + 2 * k + 1];
-            cq[lane][2 * k] = px; cq[lane][2 * k + 1] = py;
-            x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
+            for (int k = 0; k < 4; ++k) {
+                const float px = nb.quads[(size_t)idx * 8 + 2 * k], py = nb.quads[(size_t)idx * 8 + 2 * k + 1];
+                q[lane][2 * k] = px; q[lane][2 * k + 1] = py;
+                x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
+            }
         }
-        cbb[lane][0] = x0; cbb[lane][1] = x1; cbb[lane][2] = y0; cbb[lane][3] = y1;
+        bb[lane][0] = x0; bb[lane][1] = x1; bb[lane][2] = y0; bb[lane][3] = y1;
     }
+    if (threadIdx.x < 64) bits[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) n_pairs = 0;
     __syncthreads();
-    const int i = bi * 64 + lane;
-    unsigned bits = 0u;
-    if (i < K) {
-        float q[8];
-        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            q[2 * k] = nb.quads[(size_t)i * 8 + 2 * k]; q[2 * k + 1] = nb.quads[(size_t)i * 8 + 2 * k + 1];
-            x0 = fminf(x0, q[2 * k]); x1 = fmaxf(x1, q[2 * k]); y0 = fminf(y0, q[2 * k + 1]); y1 = fmaxf(y1, q[2 * k + 1]);
-        }
+    {   // phase 1: row = lane, columns chunk*8 .. chunk*8+7
+        const int i = bi * 64 + lane;
         const int jn = min(64, K - bj * 64);
-        for (int t = chunk * NMS_COLS; t < chunk * NMS_COLS + NMS_COLS && t < jn; ++t) {
-            if (bi == bj && t <= lane) continue;
-            // strictly separated bounding boxes => empty intersection => IoU is 0 (or NaN for a degenerate
-            // pair): never above the threshold, exactly as the full clip would conclude
-            if (cbb[t][0] > x1 || cbb[t][1] < x0 || cbb[t][2] > y1 || cbb[t][3] < y0) continue;
-            const float v = quad_iou(q, cq[t]);
-            if (v > thr) bits |= 1u << (t - chunk * NMS_COLS);
+        const float x0 = rbb[lane][0], x1 = rbb[lane][1], y0 = rbb[lane][2], y1 = rbb[lane][3];
+#pragma unroll
+        for (int t0 = 0; t0 < NMS_COLS; ++t0) {
+            const int t = chunk * NMS_COLS + t0;
+            bool live = i < K && t < jn && !(bi == bj && t <= lane) &&
+                        !(cbb[t][0] > x1 || cbb[t][1] < x0 || cbb[t][2] > y1 || cbb[t][3] < y0);
+            const unsigned long long m = __ballot(live);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&n_pairs, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (live) pairs[base + __popcll(m & lanemask_lt())] = (unsigned short)(lane * 64 + t);
+            }
         }
     }
-    part[lane][chunk] = (unsigned char)bits;
     __syncthreads();
-    if (chunk == 0 && i < K) {
-        unsigned long long w = 0ull;
-#pragma unroll
-        for (int c = 0; c < NMS_SPLIT; ++c) w |= (unsigned long long)part[lane][c] << (c * NMS_COLS);
-        nb.mask[(size_t)i * words + bj] = w;
+    const int np = n_pairs;
+    for (int e = threadIdx.x; e < np; e += 64 * NMS_SPLIT) {
+        const int pr = pairs[e], r = pr >> 6, t = pr & 63;
+        const float v = quad_iou(rq[r], cq[t]);
+        if (v > thr) atomicOr(&bits[r], 1ull << t);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = bi * 64 + threadIdx.x;
+        if (i < K) nb.mask[(size_t)i * words + bj] = bits[threadIdx.x];
     }
 }
 
@@ -362,14 +462,14 @@ __global__ __launch_bounds__(256) void k_quad_iou(const float* __restrict__ a, i
 static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 struct DecWs {
-    uint32_t *keys[2], *vals[2];
-    int* scratch;
+    unsigned long long* cand;   // [n] candidate composites (score key << 32 | anchor index)
+    uint32_t* sel;              // [top] anchor indices of the top candidates, descending
     NmsBufs nb;
 };
 
 static bool carve(Arena& a, int n, int top, DecWs& w) {
-    for (int k = 0; k < 2; ++k) { w.keys[k] = a.take<uint32_t>(n); w.vals[k] = a.take<uint32_t>(n); }
-    w.scratch = a.take<int>(sort_scratch_words(n));
+    w.cand = a.take<unsigned long long>(n);
+    w.sel = a.take<uint32_t>(top);
     const int words = ceil_div(top, 64);
     w.nb.corners = a.take<float>((size_t)top * 24);
     w.nb.scores = a.take<float>(top);
@@ -422,15 +522,14 @@ extern "C" int heal_decode_nms(const float* cls, const float* reg, const float* 
     // would collide with the "not a candidate" key 0 -- shift by one in that case
     if (score_thr <= 0.f) { key_base = 0xFFFFFFFFu; max_key += 1; }  // bits - (-1) = bits + 1
     p.key_base = key_base;
-    int key_bits = 1;
-    while (key_bits < 32 && (1u << key_bits) <= max_key) ++key_bits;
+    (void)max_key;
+    HEAL_REQUIRE(nms_top <= TOPK_CAP, "decode_nms: nms_top exceeds the top-k capacity");
 
     HEAL_HIP(hipMemsetAsync(w.nb.n_cand, 0, sizeof(int), s));
-    k_decode_key<<<ceil_div(n, 256), 256, 0, s>>>(cls, reg, dir, anchors, p, n, w.keys[0], w.vals[0], w.nb.n_cand);
-    int res = 0;
-    if (radix_sort_pairs(w.keys, w.vals, n, key_bits, &res, w.scratch, s)) return 1;
+    k_decode_key<<<ceil_div(n, 256), 256, 0, s>>>(cls, reg, dir, anchors, p, n, w.cand, w.nb.n_cand);
+    k_topk_sort<<<1, TOPK_THREADS, 0, s>>>(w.cand, w.nb.n_cand, nms_top, w.sel);
     const int words = ceil_div(nms_top, 64);
-    k_nms_prepare<<<ceil_div(nms_top, 64), 64, 0, s>>>(cls, reg, dir, anchors, p, n, w.vals[res], nms_top, w.nb);
+    k_nms_prepare<<<ceil_div(nms_top, 64), 64, 0, s>>>(cls, reg, dir, anchors, p, n, w.sel, nms_top, w.nb);
     k_nms_mask<<<dim3(words, words), 64 * NMS_SPLIT, 0, s>>>(w.nb, nms_top, words, nms_thr);
     const size_t reduce_lds = (size_t)words * 64 * words * sizeof(unsigned long long);
     HEAL_REQUIRE(reduce_lds <= 150 * 1024, "decode_nms: nms_top=%d needs %zu B of LDS (limit 150 KB; use <= 1088)",

@@ -253,6 +253,31 @@ def test_decode_nms_full_size_vs_oracle():
     assert not (iou > 0.15).any()
 
 
+@pytest.mark.parametrize("n_equal", [600, 9000])
+def test_decode_nms_ties_and_many_candidates_vs_oracle(n_equal):
+    """Exactly tied scores (a saturated head) below and above the single-block top-k capacity (4096): the order among equal
+    scores is 'larger anchor index first' on both sides, and with 9000 tied candidates the radix select has to split a tie
+    at the rank-1000 boundary by anchor index."""
+    from heal_amd import ops
+    rng = np.random.default_rng(n_equal)
+    H = W = 128
+    anchors = O.generate_anchor_box([-51.2, -51.2, -3, 51.2, 51.2, 1], 0.4, 0.4, 256, 256, 3.9, 1.6, 1.56, [0, 90])
+    cls = np.full((1, 2, H, W), -9.0, np.float32)
+    flat = cls.reshape(-1)
+    flat[rng.choice(flat.size, n_equal, replace=False)] = 1.25            # one exactly repeated logit
+    flat[rng.choice(flat.size, 200, replace=False)] = rng.uniform(1.0, 3.0, 200).astype(np.float32)
+    reg = (rng.standard_normal((1, 14, H, W)) * 0.05).astype(np.float32)
+    dirp = rng.standard_normal((1, 4, H, W)).astype(np.float32)
+    tfm = np.eye(4, dtype=np.float32)
+    rngb = [-51.2, -51.2, -3, 51.2, 51.2, 1]
+    pred, score = ops.decode_nms(dev(cls), dev(reg), dev(dirp), dev(anchors.astype(np.float32)), 0.2, 0.7853, 2,
+                                 0.15, tfm, rngb)
+    rp, rs = O.post_process(cls, reg, dirp, anchors, 0.2, 0.7853, 2, 0.15, tfm, rngb)
+    assert pred.shape == rp.shape, (pred.shape, rp.shape)
+    np.testing.assert_allclose(score.cpu().numpy(), rs, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pred.cpu().numpy(), rp, rtol=1e-3, atol=1e-3)
+
+
 def test_decode_nms_nothing_above_threshold():
     from heal_amd import ops
     anchors = O.generate_anchor_box([-25.6, -25.6, -3, 25.6, 25.6, 1], 0.4, 0.4, 128, 128, 3.9, 1.6, 1.56, [0, 90])
