@@ -33,7 +33,7 @@ def main():
             best = []
             for bm in (128, 64):
                 for bn in (128, 64):
-                    for kc in (32, 16):
+                    for kc in (32,):
                         if cout % bm:
                             continue
                         os.environ["HEAL_C1_CFG"] = f"{bm},{bn},{kc}"

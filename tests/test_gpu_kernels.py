@@ -668,17 +668,21 @@ def test_conv1x1_fused_vs_torch(n, cin, cout, H, W, act, with_res, with_bias):
     assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("n,cin,cout,H,W,stride,res,relu", [
+_C3_SHAPES = [
     (1, 384, 256, 64, 64, 1, False, True),      # shrink header shape (channels), reduced map
     (3, 64, 64, 40, 48, 1, True, True),         # BasicBlock conv2 + identity
     (2, 64, 64, 64, 64, 2, False, True),        # BasicBlock conv1, stride 2
     (1, 128, 64, 33, 47, 2, False, True),       # odd map, stride 2 (camera backbone 128 -> 64)
-    (4, 552, 512, 12, 16, 1, False, True),      # Up of the Lift-Splat encoder: Cin not a multiple of 8... (552 = 69 * 8)
+    (4, 552, 512, 12, 16, 1, False, True),      # Up of the Lift-Splat encoder
     (1, 67, 20, 19, 21, 1, True, False),        # ragged everything: Cin % 8 != 0, Cout % 64 != 0, map % 16 != 0
     (2, 3, 32, 24, 40, 2, False, False),        # image stem sized channels
     (1, 16, 130, 8, 8, 1, False, True),         # map smaller than a tile, Cout spills into a third 64-block
-])
-@pytest.mark.parametrize("algo", ["winograd", "winograd8", "direct"])
+]
+# Winograd F(2x2,3x3) is the stride-1 formulation (8- and 4-wave blocks); the implicit GEMM takes every shape
+_C3_CASES = [sh + (algo,) for sh in _C3_SHAPES for algo in ("winograd", "winograd8", "direct") if algo == "direct" or sh[5] == 1]
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,stride,res,relu,algo", _C3_CASES)
 def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu, algo, monkeypatch):
     """heal_conv3x3 (implicit GEMM) / heal_conv3x3_winograd (F(2x2,3x3), stride 1) on fp32 MFMA with fused bias / residual /
     ReLU against torch's fp64 convolution: 1e-4 relative to the output scale (fp32 accumulation order and, for Winograd, the
@@ -686,8 +690,6 @@ def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu, algo, monk
     from heal_amd import ops
     monkeypatch.setenv("HEAL_C3_ALGO", algo.rstrip("8"))
     monkeypatch.setenv("HEAL_WG_WAVES", "8" if algo.endswith("8") else "4")   # 16x16- or 8x16-pixel Winograd blocks
-    if algo.startswith("winograd") and stride != 1:
-        pytest.skip("Winograd F(2x2,3x3) is the stride-1 formulation; stride 2 always runs the implicit GEMM")
     g = torch.Generator().manual_seed(cin * 31 + cout + H)
     x = torch.randn((n, cin, H, W), generator=g).cuda()
     w = (torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5).cuda()
