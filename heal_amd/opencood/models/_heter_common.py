@@ -105,3 +105,34 @@ def detection_heads(x, cls_head, reg_head, dir_head):
     y = ops.conv1x1(x, hit[1], hit[2], None, 0)
     c0, c1 = cls_head.out_channels, cls_head.out_channels + reg_head.out_channels
     return y[:, :c0], y[:, c0:c1], y[:, c1:]
+
+
+def encode_modalities(model, data_dict, present, encode):
+    """Run `encode(data_dict, m)` for every modality in `present` (model order) -> {m: features}.
+
+    The per-modality stems are independent until the fusion backbone, and two of them are long chains of small, latency-bound
+    kernels (the EfficientNet / ResNet image trunks at 1/8 .. 1/32 resolution) that leave most of the chip idle: on a HIP
+    device with more than one modality present each stem runs on its OWN side stream (fork: the side stream waits for the
+    caller's stream; join: the caller's stream waits for every side stream), so they overlap -- also inside a captured HIP graph,
+    where the fork / join become parallel branches.  Allocator discipline: a stem's tensors are allocated on its side stream
+    and only its OUTPUT crosses to the caller's stream after the join; every forward starts with the fork's wait, so a block
+    the side stream reuses is never still read by the caller's previous work.  `HEAL_PARALLEL_MODALITIES=0` serialises."""
+    import os
+    mods = [m for m in model.modality_name_list if m in present]
+    dev = next(model.parameters()).device
+    if len(mods) < 2 or dev.type != "cuda" or os.environ.get("HEAL_PARALLEL_MODALITIES", "1") != "1":
+        return {m: encode(data_dict, m) for m in mods}
+    main = torch.cuda.current_stream(dev)
+    streams = model.__dict__.setdefault("_heal_side_streams", {})
+    feats = {}
+    for m in mods[1:]:
+        s = streams.get((m, dev.index))
+        if s is None:
+            s = streams[(m, dev.index)] = torch.cuda.Stream(device=dev)
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            feats[m] = encode(data_dict, m)
+    feats[mods[0]] = encode(data_dict, mods[0])       # the first modality stays on the caller's stream
+    for m in mods[1:]:
+        main.wait_stream(streams[(m, dev.index)])
+    return {m: feats[m] for m in mods}

@@ -7,8 +7,8 @@ from collections import Counter
 import torch
 import torch.nn as nn
 
-from heal_amd.opencood.models._heter_common import (anchor_heads, crop_camera_feature, detection_heads, modality_stems,
-                                                     record_len_to_list, wants_depth_items)
+from heal_amd.opencood.models._heter_common import (anchor_heads, crop_camera_feature, detection_heads, encode_modalities,
+                                                     modality_stems, record_len_to_list, wants_depth_items)
 from heal_amd.opencood.models.fuse_modules.pyramid_fuse import PyramidFusion
 from heal_amd.opencood.models.sub_modules.bev_blocks import (AlignNet, DownsampleConv, NaiveCompressor,
                                                              ResNetBEVBackbone)
@@ -68,11 +68,8 @@ class HeterPyramidCollab(nn.Module):
         affine_matrix = normalize_pairwise_tfm(pairwise, self.H, self.W, self.fake_voxel_size)
         record_len = record_len_to_list(data_dict["record_len"])
         counts = Counter(agent_modality_list)
-        feats = {}
-        for m in self.modality_name_list:
-            if m not in counts:
-                continue
-            feats[m] = self.encode_modality(data_dict, m)
+        feats = encode_modalities(self, data_dict, counts, self.encode_modality)   # concurrent streams on a HIP device
+        for m in feats:
             if wants_depth_items(self, m):
                 output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
         if len(feats) == 1 and len(counts) == 1:

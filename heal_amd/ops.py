@@ -84,7 +84,8 @@ def _workspace(key, nbytes, device):
     """Grow-only per-(op, device) scratch buffer (256-B aligned by the caching allocator).  A buffer that is outgrown is
     RETIRED, not freed: a captured HIP graph may have its address baked in, and handing the memory back to the caching
     allocator would let a later replay scribble over somebody else's tensor."""
-    k = (key, device.index)
+    # one scratch per (operator, device, STREAM): modalities encoded on concurrent streams must not share scratch
+    k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(k)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
@@ -473,7 +474,7 @@ _ZWS = {}
 def _workspace_zeroed(key, nbytes, device):
     """Scratch with a zero-on-entry / zero-on-exit contract (heal_bev_pool_pm): allocated zero-filled ONCE and then owned by
     the operator, which leaves it clean after every call.  Outgrown buffers are retired, not freed (captured graphs)."""
-    k = (key, device.index)
+    k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ZWS.get(k)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

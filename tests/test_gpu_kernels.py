@@ -783,7 +783,7 @@ def test_bev_pool_pm_scratch_is_self_cleaning_and_repeatable():
         if shift == 1e6:
             assert float(out.abs().max()) == 0.0
         outs.append(out)
-        ws = ops._ZWS[(("bev_pool_pm", 1, C, int(nx[0]), int(nx[1]), int(nx[2])), 0)]
+        ws = ops._ZWS[(("bev_pool_pm", 1, C, int(nx[0]), int(nx[1]), int(nx[2])), 0, torch.cuda.current_stream().cuda_stream)]
         words = ws.view(torch.int32)
         gen = int(words[0].item())
         assert gen >= trial + 1, gen                           # every call advances the generation

@@ -255,6 +255,43 @@ def test_heterogeneous_collab_runs_all_modalities():
     assert [tuple(o.shape) for o in out["occ_single_list"]] == [(5, 1, 256, 256), (5, 1, 128, 128), (5, 1, 64, 64)]
 
 
+def test_concurrent_modality_streams_equal_serial(monkeypatch):
+    """The per-modality stems run on concurrent HIP streams (_heter_common.encode_modalities): the result must equal the
+    serial order's -- eagerly and through the captured graph (where the fork / join are parallel branches), on several frames
+    in a row (a stem's scratch is per stream; a shared one would be a race that shows as a frame-dependent difference)."""
+    from heal_amd import configs
+    from heal_amd.pipeline import Scene, ScenePipeline
+    hypes = configs.heal_heter()
+    mods = ["m1", "m2", "m4", "m1", "m1"]
+    frames = [Scene(5, seed=20 + i, device="cuda:0", modalities=mods) for i in range(3)]
+    keys = ("cls_preds", "reg_preds", "dir_preds")
+    with torch.no_grad():
+        monkeypatch.setenv("HEAL_PARALLEL_MODALITIES", "0")
+        serial = ScenePipeline(hypes, "cuda:0", seed=1)
+        serial.calibrate_cls_bias(frames[0])
+        want = [{k: serial.forward(f)[k].clone() for k in keys} for f in frames]
+        boxes = [serial.step(f) for f in frames]
+        assert not getattr(serial.model, "_heal_side_streams", None)
+        monkeypatch.setenv("HEAL_PARALLEL_MODALITIES", "1")
+        pipe = ScenePipeline(hypes, "cuda:0", seed=1)
+        pipe.model.load_state_dict(serial.model.state_dict())
+        for f, w in zip(frames, want):
+            got = pipe.forward(f)
+            for k in keys:
+                err = float((got[k] - w[k]).abs().max() / w[k].abs().max())
+                assert err < 1e-4, ("eager", k, err)
+        assert len(pipe.model._heal_side_streams) == 2          # m2 and m4 forked; m1 stays on the caller's stream
+        pipe.capture(frames[0], warmup=1)
+        assert pipe._graph is not None, "graph capture with forked streams fell back to eager"
+        for _round in range(2):
+            for f, (eb, es) in zip(frames, boxes):
+                rb, rs = pipe.replay(f)
+                assert (eb is None) == (rb is None)
+                if eb is not None:
+                    assert rb.shape == eb.shape
+                    np.testing.assert_allclose(rs.cpu().numpy(), es.cpu().numpy(), rtol=1e-4, atol=1e-5)
+                    np.testing.assert_allclose(rb.cpu().numpy(), eb.cpu().numpy(), rtol=1e-3, atol=1e-3)
+
 
 def _hetero_small_model_and_data(g):
     from heal_amd import configs
