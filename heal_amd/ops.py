@@ -752,9 +752,28 @@ def grouped16_fragments(weight, cg):
     return hit[0]
 
 
+_FRAGQ_CACHE = {}
+
+
+def grouped_small_fragments(weight, cg):
+    """[C, cg, 3, 3] grouped weight (cg = 4 | 8) -> A operands of heal_grouped_small_conv3x3: [C/16][tap][ci][16 output channels
+    of the super-group], cached per storage + version."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _FRAGQ_CACHE.get(key)
+    if hit is None:
+        if len(_FRAGQ_CACHE) > 512:
+            _FRAGQ_CACHE.clear()
+        C = int(weight.shape[0])
+        f = weight.detach().reshape(C // 16, 16, cg, 9).permute(0, 3, 2, 1).contiguous()   # [sg, tap, ci, co]
+        hit = (f, weight)
+        _FRAGQ_CACHE[key] = hit
+    return hit[0]
+
+
 def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
-    """32-group 3x3 conv (padding 1) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3].  Stride 1 with 16 or 8
-    channels per group runs on the matrix cores (heal_grouped16_conv3x3), the rest on the vector-ALU stencil."""
+    """32-group 3x3 conv (padding 1) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3].  Stride 1 runs on the
+    matrix cores: 16 channels per group as one 16x16 MFMA m-tile per group (heal_grouped16_conv3x3), 4 or 8 per group on the
+    16-block 4x4x1 MFMA (heal_grouped_small_conv3x3); the rest on the vector-ALU stencil."""
     import os
     x = _need(x, torch.float32, "x")
     weight = _need(weight, torch.float32, "weight")
@@ -765,6 +784,12 @@ def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
     # measured (scripts/gconv_bench.py, 5 agents): 16 channels per group 80 -> 55 us on the matrix cores; 8 per group (paired,
     # half the MFMAs multiply zeros) 98 vs 88 us for the stencil -> only opt-in (HEAL_GCONV_MFMA=8)
     mode = os.environ.get("HEAL_GCONV_MFMA", "1")
+    if stride == 1 and C % 16 == 0 and W % 4 == 0 and cg in (4, 8) and mode == "1":
+        frag = grouped_small_fragments(weight, cg)
+        with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * cg * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
+            _capi.call("heal_grouped_small_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), n, C, cg, H, W, int(bool(relu)),
+                       _ptr(y), _stream())
+        return y
     if stride == 1 and C % 16 == 0 and W % 4 == 0 and ((cg == 16 and mode != "0") or (cg == 8 and mode == "8")):
         frag = grouped16_fragments(weight, cg)
         with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * cg * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
