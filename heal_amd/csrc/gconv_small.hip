@@ -9,9 +9,10 @@
 //     D[lane l][reg r] += A[lane 4*(l/4) + r] * B[lane l]            block = l / 4, i = r, j = l % 4.
 // Mapping used here, for a 16-channel super-group sg and a run of 16 output pixels:
 //     block b = pq * 4 + hq   (pq = pixel quad 0..3, hq = which 4 output channels of the 16)
-//     -> lane l computes pixel p = (l / 16) * 4 + l % 4 for the output channels hq * 4 + {0..3}, hq = (l / 4) % 4, and holds the
-//        weight of output channel l % 16 as its A operand (36 or 72 registers: every (tap, input channel) of its group);
-//     -> its B operand is input channel ci of ITS group at pixel p (+ tap offset): the patch is staged in LDS channel-interleaved,
+//     A = activations (row i of a block = pixel pq * 4 + i), B = weights (column j = output channel hq * 4 + j):
+//     -> lane l supplies pixel p = (l / 16) * 4 + l % 4 and the weight of output channel l % 16 (36 or 72 registers: every
+//        (tap, input channel) of its group) and receives pixels (l / 16) * 4 + {0..3} of output channel l % 16: one 16-B store;
+//     -> its A operand is input channel ci of ITS group at pixel p (+ tap offset): the patch is staged in LDS channel-interleaved,
 //        [row][pixel][16 channels], so one ds_read_b128 returns the B operands of four k-steps, and the 64 lanes of a read
 //        cover 16 pixels x 64 B = 1 KiB contiguous (conflict-free for 4 channels per group; 2-way for 8, where the two halves of a
 //        group read the same 16 bytes).  A patch row read serves the three output rows it touches.
@@ -20,6 +21,7 @@
 // registers into four 16-B LDS stores), unconditional and clamped with the zero padding applied at the store.
 // Bytes: every input element is read once per tile (+ halo 1.2x, from L2), every output written once: HBM-bound at these
 // widths (0.33 GB per call at 128 channels x 256^2 x 5 agents).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/heal_amd.h"
 
@@ -27,131 +29,155 @@ namespace heal {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int CG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_gconv_small(const float* __restrict__ x, const float* __restrict__ wq,
-                                                    const float* __restrict__ bias, int C, int H, int W, int tiles_x,
-                                                    int relu, float* __restrict__ y) {
+// patch staging (macros, not lambdas: arrays captured by a lambda stay in private memory with this compiler)
+#define GS_ISSUE(TILE)                                                                                             \
+    {                                                                                                              \
+        const int tile_ = (TILE);                                                                                  \
+        const int ty_ = tile_ / tiles_x, tx_ = tile_ - ty_ * tiles_x;                                              \
+        const int oy0_ = ty_ * TH, ox0_ = tx_ * TW;                                                                \
+        ok_bits = 0;                                                                                               \
+        _Pragma("unroll") for (int it = 0; it < IT_IN; ++it) {                                                     \
+            const int u = min(t + 256 * it, N_IN - 1); /* surplus threads repeat the last item (same data) */      \
+            const int gq = u & 3, quad = (u >> 2) & 7, row = u >> 5;                                               \
+            const int gy = oy0_ - 1 + row, gx = ox0_ + quad * 4;                                                   \
+            const bool ok = gy >= 0 && gy < H && gx < W; /* W % 4 == 0: a quad is all-in or all-out */             \
+            ok_bits |= ok ? (1u << it) : 0u;                                                                       \
+            const float* src = xin + (size_t)(gq * 4) * HW + (ok ? (size_t)gy * W + gx : 0);                       \
+            vin[it][0] = *reinterpret_cast<const float4*>(src);                                                    \
+            vin[it][1] = *reinterpret_cast<const float4*>(src + HW);                                               \
+            vin[it][2] = *reinterpret_cast<const float4*>(src + 2 * HW);                                           \
+            vin[it][3] = *reinterpret_cast<const float4*>(src + 3 * HW);                                           \
+        }                                                                                                          \
+        {                                                                                                          \
+            const int u = min(t, N_HA - 1);                                                                        \
+            const int gq = u & 3, side = (u >> 2) & 1, row = u >> 3;                                               \
+            const int gy = oy0_ - 1 + row, gx = side ? ox0_ + TW : ox0_ - 1;                                       \
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;                                                \
+            ok_bits |= ok ? 256u : 0u;                                                                             \
+            const float* src = xin + (size_t)(gq * 4) * HW + (ok ? (size_t)gy * W + gx : 0);                       \
+            vha = make_float4(src[0], src[HW], src[2 * HW], src[3 * HW]);                                          \
+        }                                                                                                          \
+    }
+#define GS_COMMIT()                                                                                                \
+    {                                                                                                              \
+        _Pragma("unroll") for (int it = 0; it < IT_IN; ++it) {                                                     \
+            const int u = min(t + 256 * it, N_IN - 1);                                                             \
+            const int gq = u & 3, quad = (u >> 2) & 7, row = u >> 5;                                               \
+            const bool ok = (ok_bits >> it) & 1u;                                                                  \
+            float4* d = sP + (row * PC + 1 + quad * 4) * 4 + gq;                                                   \
+            const float4 a = vin[it][0], b = vin[it][1], c = vin[it][2], e = vin[it][3];                           \
+            d[0] = make_float4(ok ? a.x : 0.f, ok ? b.x : 0.f, ok ? c.x : 0.f, ok ? e.x : 0.f);                    \
+            d[4] = make_float4(ok ? a.y : 0.f, ok ? b.y : 0.f, ok ? c.y : 0.f, ok ? e.y : 0.f);                    \
+            d[8] = make_float4(ok ? a.z : 0.f, ok ? b.z : 0.f, ok ? c.z : 0.f, ok ? e.z : 0.f);                    \
+            d[12] = make_float4(ok ? a.w : 0.f, ok ? b.w : 0.f, ok ? c.w : 0.f, ok ? e.w : 0.f);                   \
+        }                                                                                                          \
+        {                                                                                                          \
+            const int u = min(t, N_HA - 1);                                                                        \
+            const int gq = u & 3, side = (u >> 2) & 1, row = u >> 3;                                               \
+            const bool okh = ok_bits & 256u;                                                                       \
+            sP[(row * PC + (side ? PC - 1 : 0)) * 4 + gq] =                                                        \
+                make_float4(okh ? vha.x : 0.f, okh ? vha.y : 0.f, okh ? vha.z : 0.f, okh ? vha.w : 0.f);           \
+        }                                                                                                          \
+    }
+
+template <int CG, int TH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_gconv_small(
+    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias, int C, int H, int W, int tiles_x,
+    int relu, float* __restrict__ y) {
     static_assert(CG == 4 || CG == 8, "4 or 8 channels per group");
-    constexpr int TH = 16, TW = 32, PR = TH + 2, PC = TW + 2;
+    static_assert(TH == 8 || TH == 16, "tile height");
+    constexpr int TW = 32, PR = TH + 2, PC = TW + 2, RW = TH / 4;   // RW output rows per wave
     constexpr int NSTEP = 9 * CG;            // (tap, ci) k-steps of one group
     constexpr int NB = CG / 4;               // float4 B reads per (row, segment, dx)
     __shared__ float4 sP[PR * PC * 4];       // [row][pixel][unit = channel / 4]
+    __shared__ float4 sW[NSTEP * 16 / 4];    // [tap][ci][output channel of the super-group]
     const Block3 bk = xcd_block();           // x: tile, y: super-group, z: image
-    const int ty = bk.x / tiles_x, tx = bk.x - ty * tiles_x;
     const int sg = bk.y, n = bk.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int tile0 = bk.x;
     const int t = threadIdx.x, wave = t >> 6, l = t & 63;
     const size_t HW = (size_t)H * W;
     const float* __restrict__ xin = x + ((size_t)n * C + (size_t)sg * 16) * HW;
 
-    // ---- stage the patch: interior quads (16-B loads, 4 channels x 4 pixels per item) + the two halo columns ---------------
-    constexpr int N_IN = PR * 8 * 4, IT_IN = (N_IN + 255) / 256;   // 576 items -> 3 per thread
-    constexpr int N_HA = PR * 2 * 4;                               // 144 halo items -> threads 0..143
+    // ---- patch staging: interior quads (16-B loads, 4 channels x 4 pixels per item) + the two halo columns.  issue() puts
+    // the loads of a tile in flight (unconditional, clamped), commit() transposes them into LDS with the zero padding applied.
+    constexpr int N_IN = PR * 8 * 4, IT_IN = (N_IN + 255) / 256;   // 576 | 320 items -> 3 | 2 per thread
+    constexpr int N_HA = PR * 2 * 4;                               // 144 | 80 halo items
     float4 vin[IT_IN][4];
-    unsigned ok_in = 0;
-#pragma unroll
-    for (int it = 0; it < IT_IN; ++it) {
-        const int u = min(t + 256 * it, N_IN - 1);                 // surplus threads repeat the last item (same data)
-        const int gq = u & 3, quad = (u >> 2) & 7, row = u >> 5;
-        const int gy = oy0 - 1 + row, gx = ox0 + quad * 4;
-        const bool ok = gy >= 0 && gy < H && gx < W;               // W % 4 == 0: a quad is all-in or all-out
-        ok_in |= ok ? (1u << it) : 0u;
-        const size_t off = ok ? (size_t)gy * W + gx : 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) vin[it][c] = *reinterpret_cast<const float4*>(xin + (size_t)(gq * 4 + c) * HW + off);
-    }
     float4 vha;
-    bool ok_ha;
-    {
-        const int u = min(t, N_HA - 1);
-        const int gq = u & 3, side = (u >> 2) & 1, row = u >> 3;
-        const int gy = oy0 - 1 + row, gx = side ? ox0 + TW : ox0 - 1;
-        ok_ha = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t off = ok_ha ? (size_t)gy * W + gx : 0;
-        const float* s = xin + (size_t)(gq * 4) * HW + off;
-        vha = make_float4(s[0], s[HW], s[2 * HW], s[3 * HW]);
+    unsigned ok_bits = 0;                                          // bit it: interior item valid; bit 8: halo item valid
+    GS_ISSUE(tile0)
+    // the super-group's weights [tap][ci][16]: one coalesced pass into LDS, from where every lane picks its column
+    constexpr int N_W4 = NSTEP * 16 / 4, IT_W = (N_W4 + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < IT_W; ++it) {
+        const int i = min(t + 256 * it, N_W4 - 1);
+        sW[i] = reinterpret_cast<const float4*>(wq + (size_t)sg * NSTEP * 16)[i];
     }
-    // A operands: the weights of output channel l % 16, every (tap, ci) of its group (L2-resident, 64 B per wave-load)
+    GS_COMMIT()
+    __syncthreads();
+    // B operand: the weight of output channel l % 16 for every (tap, ci) of its group, in registers for the whole run of tiles
     float wreg[NSTEP];
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) wreg[s] = wq[((size_t)sg * NSTEP + s) * 16 + (l & 15)];
-
-#pragma unroll
-    for (int it = 0; it < IT_IN; ++it) {
-        const int u = min(t + 256 * it, N_IN - 1);
-        const int gq = u & 3, quad = (u >> 2) & 7, row = u >> 5;
-        const bool ok = (ok_in >> it) & 1u;
-        float4* d = sP + (row * PC + 1 + quad * 4) * 4 + gq;
-        const float4 a = vin[it][0], b = vin[it][1], c = vin[it][2], e = vin[it][3];
-        d[0] = ok ? make_float4(a.x, b.x, c.x, e.x) : make_float4(0.f, 0.f, 0.f, 0.f);
-        d[4] = ok ? make_float4(a.y, b.y, c.y, e.y) : make_float4(0.f, 0.f, 0.f, 0.f);
-        d[8] = ok ? make_float4(a.z, b.z, c.z, e.z) : make_float4(0.f, 0.f, 0.f, 0.f);
-        d[12] = ok ? make_float4(a.w, b.w, c.w, e.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {
-        const int u = min(t, N_HA - 1);
-        const int gq = u & 3, side = (u >> 2) & 1, row = u >> 3;
-        sP[(row * PC + (side ? PC - 1 : 0)) * 4 + gq] = ok_ha ? vha : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-
-    // ---- 4 output rows x 2 segments per wave; a patch-row read feeds the (up to) three output rows it touches ------------
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) acc[o][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NSTEP; ++s) wreg[s] = reinterpret_cast<const float*>(sW)[s * 16 + (l & 15)];
+    const float bv0 = bias ? bias[sg * 16 + (l & 15)] : 0.f;
     const int p = (l >> 4) * 4 + (l & 3);                 // pixel within a 16-pixel segment
     const int unit0 = (((l >> 2) & 3) * 4 / CG) * NB;     // first 16-B unit of the lane's group within a pixel
-    const float4* __restrict__ bbase = sP + ((wave * 4) * PC + p) * 4 + unit0;
+    const float4* __restrict__ bbase = sP + ((wave * RW) * PC + p) * 4 + unit0;
+    float* __restrict__ yout = y + ((size_t)n * C + (size_t)sg * 16 + (l & 15)) * HW;
+
+    {
+        const int tile = tile0;
+        // ---- RW output rows x 2 segments per wave; a patch-row read feeds the (up to) three output rows it touches ------
+        f32x4 acc[RW][2];
 #pragma unroll
-    for (int ry = 0; ry < 6; ++ry) {
+        for (int o = 0; o < RW; ++o)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            float4 bv[2][NB];
+            for (int s = 0; s < 2; ++s) acc[o][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+        for (int ry = 0; ry < RW + 2; ++ry) {
 #pragma unroll
-                for (int h = 0; h < NB; ++h) bv[s][h] = bbase[(ry * PC + s * 16 + dx) * 4 + h];
+            for (int dx = 0; dx < 3; ++dx) {
+                float4 bv[2][NB];
 #pragma unroll
-            for (int ci = 0; ci < CG; ++ci) {
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const int dy = ry - o;
-                    if (dy < 0 || dy > 2) continue;       // compile-time after unrolling
+                    for (int h = 0; h < NB; ++h) bv[s][h] = bbase[(ry * PC + s * 16 + dx) * 4 + h];
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float4 q = bv[s][ci >> 2];
-                        const float b = (ci & 3) == 0 ? q.x : (ci & 3) == 1 ? q.y : (ci & 3) == 2 ? q.z : q.w;
-                        acc[o][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(dy * 3 + dx) * CG + ci], b, acc[o][s], 0, 0, 0);
+                for (int ci = 0; ci < CG; ++ci) {
+#pragma unroll
+                    for (int o = 0; o < RW; ++o) {
+                        const int dy = ry - o;
+                        if (dy < 0 || dy > 2) continue;       // compile-time after unrolling
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float4 q = bv[s][ci >> 2];
+                            const float b = (ci & 3) == 0 ? q.x : (ci & 3) == 1 ? q.y : (ci & 3) == 2 ? q.z : q.w;
+                            acc[o][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(b, wreg[(dy * 3 + dx) * CG + ci], acc[o][s], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
-    }
-
-    // ---- epilogue: D[l][r] = output channel ((l / 4) % 4) * 4 + r of the super-group at pixel p --------------------------
-    float* __restrict__ yout = y + ((size_t)n * C + (size_t)sg * 16) * HW;
-    const int cbase = ((l >> 2) & 3) * 4;
-    float bvv[4];
+        // ---- epilogue: D[l][r] = pixel (l / 16) * 4 + r of the segment, output channel l % 16 -> one 16-B store per tile ---
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bvv[r] = bias ? bias[sg * 16 + cbase + r] : 0.f;
+        for (int o = 0; o < RW; ++o) {
+            const int oy = oy0 + wave * RW + o;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        const int oy = oy0 + wave * 4 + o;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ox = ox0 + s * 16 + p;
-            if (oy >= H || ox >= W) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[o][s][r] + bvv[r];
-                if (relu) v = fmaxf(v, 0.f);
-                yout[(size_t)(cbase + r) * HW + (size_t)oy * W + ox] = v;
+            for (int s = 0; s < 2; ++s) {
+                const int ox = ox0 + s * 16 + (l >> 4) * 4;
+                if (oy >= H || ox >= W) continue;          // W % 4 == 0: a quad is all-in or all-out
+                float4 v = make_float4(acc[o][s][0] + bv0, acc[o][s][1] + bv0, acc[o][s][2] + bv0, acc[o][s][3] + bv0);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(yout + (size_t)oy * W + ox) = v;
             }
         }
     }
 }
+
+#undef GS_ISSUE
+#undef GS_COMMIT
 
 }  // namespace heal
 
@@ -164,13 +190,21 @@ extern "C" int heal_grouped_small_conv3x3(const float* x, const float* weight_q,
     HEAL_REQUIRE(n >= 1 && channels >= 16 && channels % 16 == 0 && H >= 1 && W >= 4 && W % 4 == 0,
                  "grouped_small_conv3x3: needs channels %% 16 == 0 and W %% 4 == 0 (got C=%d W=%d)", channels, W);
     HEAL_REQUIRE(x && weight_q && y && ((uintptr_t)x & 15) == 0, "grouped_small_conv3x3: bad pointer (x must be 16-B aligned)");
-    const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 16);
+    // tile height: 16 rows (4 channels per group), 8 rows (8 per group: 72 weight registers); HEAL_GS_TH=8|16 overrides
+    int th = group_channels == 4 ? 16 : 8;
+    if (const char* e = getenv("HEAL_GS_TH")) th = atoi(e) == 8 ? 8 : atoi(e) == 16 ? 16 : th;
+    const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, th);
     HEAL_REQUIRE(channels / 16 <= 65535 && n <= 65535, "grouped_small_conv3x3: grid limit");
     const dim3 grid(tiles_x * tiles_y, channels / 16, n);
-    if (group_channels == 4)
-        k_gconv_small<4><<<grid, 256, 0, (hipStream_t)stream>>>(x, weight_q, bias, channels, H, W, tiles_x, relu, y);
+    hipStream_t s_ = (hipStream_t)stream;
+    if (group_channels == 4 && th == 16)
+        k_gconv_small<4, 16><<<grid, 256, 0, s_>>>(x, weight_q, bias, channels, H, W, tiles_x, relu, y);
+    else if (group_channels == 4)
+        k_gconv_small<4, 8><<<grid, 256, 0, s_>>>(x, weight_q, bias, channels, H, W, tiles_x, relu, y);
+    else if (th == 16)
+        k_gconv_small<8, 16><<<grid, 256, 0, s_>>>(x, weight_q, bias, channels, H, W, tiles_x, relu, y);
     else
-        k_gconv_small<8><<<grid, 256, 0, (hipStream_t)stream>>>(x, weight_q, bias, channels, H, W, tiles_x, relu, y);
+        k_gconv_small<8, 8><<<grid, 256, 0, s_>>>(x, weight_q, bias, channels, H, W, tiles_x, relu, y);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
