@@ -133,7 +133,8 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         elif name.startswith("conv3x3_"):
             add("conv3x3", "K7 heal_conv3x3 (dense 3x3 implicit GEMM on fp32 MFMA: stride 2 and small maps)", "mfma", w)
         elif name.startswith("grouped_conv3x3"):
-            add("grouped", "K7 heal_grouped_conv3x3 (32-group 3x3 stencil, vector ALU)", "mfma", w)
+            add("grouped", "K7 heal_grouped_small_conv3x3 (32-group 3x3 of the ResNeXt bottlenecks on the 16-block 4x4x1 fp32 MFMA; "
+                           "bytes = input read once + output written once)", "hbm", w)
         elif name.startswith("warp_fuse"):
             add("k5", "K5 heal_warp_fuse (warp + occupancy-softmax fusion, 3 pyramid levels)", "hbm", w)
     entries = {}

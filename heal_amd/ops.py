@@ -756,7 +756,7 @@ _FRAGQ_CACHE = {}
 
 
 def grouped_small_fragments(weight, cg):
-    """[C, cg, 3, 3] grouped weight (cg = 4 | 8) -> A operands of heal_grouped_small_conv3x3: [C/16][tap][ci][16 output channels
+    """[C, cg, 3, 3] grouped weight (cg = 4 | 8 | 16) -> weight operands of heal_grouped_small_conv3x3: [C/16][tap][ci][16 output channels
     of the super-group], cached per storage + version."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape))
     hit = _FRAGQ_CACHE.get(key)
@@ -771,9 +771,11 @@ def grouped_small_fragments(weight, cg):
 
 
 def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
-    """32-group 3x3 conv (padding 1) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3].  Stride 1 runs on the
-    matrix cores: 16 channels per group as one 16x16 MFMA m-tile per group (heal_grouped16_conv3x3), 4 or 8 per group on the
-    16-block 4x4x1 MFMA (heal_grouped_small_conv3x3); the rest on the vector-ALU stencil."""
+    """32-group 3x3 conv (padding 1, stride 1 | 2) with fused bias + ReLU.  x [n,C,H,W], weight [C,C/groups,3,3].  4, 8 or 16
+    channels per group run on the 16-block 4x4x1 MFMA (heal_grouped_small_conv3x3; measured 5 agents, us: 128 ch 256^2 166 ->
+    98, 256 ch 128^2 84 -> 59, 512 ch 64^2 78 -> 49, stride 2: 256 ch 256^2 207 -> 107, 512 ch 128^2 122 -> 68);
+    HEAL_GCONV_MFMA=16 | 8 selects the older 16x16x4 kernel (one m-tile per 16-channel group: 53 us; pairs of 8-channel groups
+    with block-diagonal weights: 98 us), =0 the vector-ALU stencil, which also takes the shapes the MFMA kernels do not."""
     import os
     x = _need(x, torch.float32, "x")
     weight = _need(weight, torch.float32, "weight")
@@ -781,22 +783,22 @@ def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     y = torch.empty((n, C, Ho, Wo), dtype=torch.float32, device=x.device)
     cg = C // groups
-    # measured (scripts/gconv_bench.py, 5 agents): 16 channels per group 80 -> 55 us on the matrix cores; 8 per group (paired,
-    # half the MFMAs multiply zeros) 98 vs 88 us for the stencil -> only opt-in (HEAL_GCONV_MFMA=8)
     mode = os.environ.get("HEAL_GCONV_MFMA", "1")
-    if stride == 1 and C % 16 == 0 and W % 4 == 0 and cg in (4, 8) and mode == "1":
+    if C % 16 == 0 and W % 4 == 0 and Wo % 4 == 0 and mode in ("1", "s") and cg in (4, 8, 16):
         frag = grouped_small_fragments(weight, cg)
-        with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * cg * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
-            _capi.call("heal_grouped_small_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), n, C, cg, H, W, int(bool(relu)),
-                       _ptr(y), _stream())
+        with _Timed(f"grouped_conv3x3_c{C}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * C * cg * Ho * Wo,
+                    4.0 * n * C * (H * W + Ho * Wo)):
+            _capi.call("heal_grouped_small_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), n, C, cg, H, W, int(stride),
+                       int(bool(relu)), _ptr(y), _stream())
         return y
-    if stride == 1 and C % 16 == 0 and W % 4 == 0 and ((cg == 16 and mode != "0") or (cg == 8 and mode == "8")):
+    if stride == 1 and C % 16 == 0 and W % 4 == 0 and ((cg == 16 and mode != "0") or (cg == 8 and mode == "8")):   # mode "16" | "8"
         frag = grouped16_fragments(weight, cg)
         with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * cg * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
             _capi.call("heal_grouped16_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), n, C, H, W, int(bool(relu)), _ptr(y),
                        _stream())
         return y
-    with _Timed(f"grouped_conv3x3_c{C}", 2.0 * 9 * n * C * (C // groups) * Ho * Wo, 4.0 * n * C * (H * W + Ho * Wo)):
+    with _Timed(f"grouped_conv3x3_c{C}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * C * (C // groups) * Ho * Wo,
+                4.0 * n * C * (H * W + Ho * Wo)):
         _capi.call("heal_grouped_conv3x3", _ptr(x), _ptr(weight), _ptr(bias), n, C, int(groups), H, W, int(stride),
                    int(bool(relu)), _ptr(y), _stream())
     return y

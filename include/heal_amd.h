@@ -347,13 +347,14 @@ int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, co
 int heal_grouped16_conv3x3(const float* x, const float* weight_frag, const float* bias, int n, int channels, int H, int W,
                            int relu, float* y, void* stream);
 
-/* heal_grouped_small_conv3x3: the same 32-group 3x3 convolution (stride 1, padding 1, folded BatchNorm bias, ReLU) for 4 or 8
+/* heal_grouped_small_conv3x3: the same 32-group 3x3 convolution (stride 1 | 2, padding 1, folded BatchNorm bias, ReLU) for 4 or 8
  *   channels per group -- the 128- and 256-wide ResNeXt stages of PyramidFusion (resblock.py:90-98,110-112) -- on the 16-block
  *   v_mfma_f32_4x4x1_16b_f32: a block is 4 output channels x 4 pixels x 1 input channel, so no multiply is spent on the zeros
- *   of a block-diagonal weight.  x, y [n,C,H,W], C % 16 == 0, W % 4 == 0, x 16-B aligned.
+ *   of a block-diagonal weight.  x [n,C,H,W], y [n,C,Ho,Wo] (Ho = (H-1)/stride + 1), C % 16 == 0, W % 4 == 0, Wo % 4 == 0,
+ *   x and y 16-B aligned.
  *   weight_q[sg][tap][ci][co] = W[sg*16 + co][ci][tap], sg < C/16, tap = 3*ky + kx, ci < group_channels, co < 16.      */
 int heal_grouped_small_conv3x3(const float* x, const float* weight_q, const float* bias, int n, int channels,
-                               int group_channels, int H, int W, int relu, float* y, void* stream);
+                               int group_channels, int H, int W, int stride, int relu, float* y, void* stream);
 
 /* heal_conv3x3_winograd: the same operator for stride 1 evaluated with the Winograd F(2x2,3x3) minimal-filtering transform
  *   on the matrix cores (16 transform-domain GEMMs, 2.25x fewer MFMAs than the implicit GEMM of heal_conv3x3; fp32

@@ -16,16 +16,16 @@ def timeit(fn, reps=20):
     return float(np.median(ts))
 
 
-for C, hw in ((128, 256), (256, 128), (512, 64)):
+for C, hw, st in ((128, 256, 1), (256, 128, 1), (512, 64, 1), (256, 256, 2), (512, 128, 2)):
     x = torch.randn((5, C, hw, hw), device="cuda"); w = torch.randn((C, C // 32, 3, 3), device="cuda") * 0.1
     b = torch.randn((C,), device="cuda")
-    ref = torch.relu(torch.nn.functional.conv2d(x[:1].double(), w.double(), b.double(), 1, 1, 1, 32)).float()
-    line = f"C={C} ({C // 32}/group) {hw}x{hw}:"
-    for mode in ("1", "0"):
+    ref = torch.relu(torch.nn.functional.conv2d(x[:1].double(), w.double(), b.double(), st, 1, 1, 32)).float()
+    line = f"C={C} ({C // 32}/group) {hw}x{hw} stride {st}:"
+    for mode in ("1", "0", "16"):
         os.environ["HEAL_GCONV_MFMA"] = mode
-        t = timeit(lambda: ops.grouped_conv3x3(x, w, b, 32, 1, True))
-        got = ops.grouped_conv3x3(x[:1].contiguous(), w, b, 32, 1, True)
+        t = timeit(lambda: ops.grouped_conv3x3(x, w, b, 32, st, True))
+        got = ops.grouped_conv3x3(x[:1].contiguous(), w, b, 32, st, True)
         err = float((got - ref).abs().max() / ref.abs().max())
-        flops = 2.0 * 9 * 5 * C * (C // 32) * hw * hw
-        line += f"  mfma={mode}: {t:7.1f} us {2 * 4 * x.numel() / t / 1e3:6.0f} GB/s {flops / t / 1e6:5.1f} TF relerr {err:.1e}"
+        flops = 2.0 * 9 * 5 * C * (C // 32) * hw * hw / st ** 2
+        line += f"  mfma={mode}: {t:7.1f} us {4 * x.numel() * (1 + 1 / st ** 2) / t / 1e3:6.0f} GB/s {flops / t / 1e6:5.1f} TF relerr {err:.1e}"
     print(line, flush=True)

@@ -568,12 +568,13 @@ def test_sparse_device_counts_and_capacity_overflow_report():
 # ---------------------------------------------------------------------------------------------- K7
 @pytest.mark.parametrize("C,stride,H,W", [(128, 1, 64, 96), (256, 2, 64, 64), (512, 1, 32, 32), (512, 2, 34, 30),
                                           (128, 2, 37, 41), (256, 1, 40, 56), (512, 1, 19, 20), (512, 1, 19, 21), (256, 1, 128, 128),
-                                          (128, 1, 50, 44), (128, 1, 16, 32), (256, 1, 17, 36), (128, 1, 3, 4)])
-@pytest.mark.parametrize("mfma", ["1", "8", "0"])
+                                          (128, 1, 50, 44), (128, 1, 16, 32), (256, 1, 17, 36), (128, 1, 3, 4),
+                                          (256, 2, 128, 128), (128, 2, 33, 40), (256, 2, 17, 8), (128, 2, 64, 48)])
+@pytest.mark.parametrize("mfma", ["1", "8", "0", "16"])
 def test_grouped_conv3x3_vs_torch(C, stride, H, W, mfma, monkeypatch):
     """32-group 3x3: the vector-ALU stencil and the matrix-core kernels (stride 1, W % 4 == 0: 16 channels per group on 16x16x4
-    MFMA tiles, 4 and 8 per group on the 16-block 4x4x1 MFMA; HEAL_GCONV_MFMA=8 instead pairs groups of 8 into block-diagonal
-    16-channel super-groups, =0 forces the stencil) against torch fp64."""
+    MFMA tiles (HEAL_GCONV_MFMA=16, or =8 which also pairs groups of 8 into block-diagonal 16-channel super-groups); 4, 8 and 16
+    per group at stride 1 and 2 on the 16-block 4x4x1 MFMA (=1, production); =0 forces the stencil) against torch fp64."""
     from heal_amd import ops
     monkeypatch.setenv("HEAL_GCONV_MFMA", mfma)
     g = torch.Generator().manual_seed(C + stride)

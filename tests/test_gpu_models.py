@@ -265,7 +265,8 @@ def test_concurrent_modality_streams_equal_serial(monkeypatch):
     mods = ["m1", "m2", "m4", "m1", "m1"]
     frames = [Scene(5, seed=20 + i, device="cuda:0", modalities=mods) for i in range(3)]
     keys = ("cls_preds", "reg_preds", "dir_preds")
-    with torch.no_grad():
+    side = torch.cuda.Stream()   # capture() wants a non-default stream
+    with torch.no_grad(), torch.cuda.stream(side):
         monkeypatch.setenv("HEAL_PARALLEL_MODALITIES", "0")
         serial = ScenePipeline(hypes, "cuda:0", seed=1)
         serial.calibrate_cls_bias(frames[0])
@@ -292,6 +293,7 @@ def test_concurrent_modality_streams_equal_serial(monkeypatch):
                     np.testing.assert_allclose(rs.cpu().numpy(), es.cpu().numpy(), rtol=1e-4, atol=1e-5)
                     np.testing.assert_allclose(rb.cpu().numpy(), eb.cpu().numpy(), rtol=1e-3, atol=1e-3)
 
+    torch.cuda.synchronize()
 
 def _hetero_small_model_and_data(g):
     from heal_amd import configs
