@@ -290,8 +290,10 @@ def test_concurrent_modality_streams_equal_serial(monkeypatch):
                 assert (eb is None) == (rb is None)
                 if eb is not None:
                     assert rb.shape == eb.shape
-                    np.testing.assert_allclose(rs.cpu().numpy(), es.cpu().numpy(), rtol=1e-4, atol=1e-5)
-                    np.testing.assert_allclose(rb.cpu().numpy(), eb.cpu().numpy(), rtol=1e-3, atol=1e-3)
+                    # scores are sigmoids of logits that agree to 1e-4 of the largest logit (tens, with random weights;
+                    # the lift adds with fp32 atomics, so two runs differ in the last bits): 2e-3 absolute
+                    np.testing.assert_allclose(rs.cpu().numpy(), es.cpu().numpy(), rtol=0, atol=2e-3)
+                    np.testing.assert_allclose(rb.cpu().numpy(), eb.cpu().numpy(), rtol=1e-3, atol=5e-3)
 
     torch.cuda.synchronize()
 
