@@ -316,7 +316,37 @@ __global__ __launch_bounds__(256) void k_layernorm_nchw(const float* __restrict_
 #pragma unroll 8
     for (int c = 0; c < C; ++c) yo[(size_t)c * HW] = (xi[(size_t)c * HW] - mean) * inv * gamma[c] + beta[c];
 }
+
+// Single-output pointwise convolution y[n][p] = b + sum_c w[c] x[n][c][p]: the occupancy heads of PyramidFusion
+// (pyramid_fuse.py:89-91: nn.Conv2d(C, 1, kernel_size=1)).  A GEMM with one output row wastes a whole m-tile; this is a
+// streaming reduction over the channel axis: 16 B of four pixels per thread and channel, weights broadcast through scalar
+// loads, k ascending (the summation order of a plain dot product).  HBM-bound: 4 C bytes read per output pixel.
+__global__ __launch_bounds__(256) void k_channel_dot(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int C, int HW4,
+                                                    float* __restrict__ y) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= HW4) return;
+    const float4* __restrict__ xi = reinterpret_cast<const float4*>(x) + (size_t)blockIdx.y * C * HW4 + q;
+    const float b = bias ? bias[0] : 0.f;
+    float4 acc = make_float4(b, b, b, b);
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const float4 v = xi[(size_t)c * HW4];
+        const float wc = w[c];
+        acc.x = fmaf(wc, v.x, acc.x); acc.y = fmaf(wc, v.y, acc.y); acc.z = fmaf(wc, v.z, acc.z); acc.w = fmaf(wc, v.w, acc.w);
+    }
+    reinterpret_cast<float4*>(y)[(size_t)blockIdx.y * HW4 + q] = acc;
+}
 }  // namespace heal
+
+extern "C" int heal_channel_dot(const float* x, const float* weight, const float* bias, int n, int channels, int HW,
+                                float* y, void* stream) {
+    HEAL_REQUIRE(n >= 1 && channels >= 1 && HW >= 4 && HW % 4 == 0 && n <= 65535, "channel_dot: bad shape (H*W %% 4 == 0)");
+    HEAL_REQUIRE(x && weight && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "channel_dot: bad pointer");
+    heal::k_channel_dot<<<dim3(ceil_div(HW / 4, 256), n), 256, 0, (hipStream_t)stream>>>(x, weight, bias, channels, HW / 4, y);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int heal_layernorm_nchw(const float* x, const float* gamma, const float* beta, int n, int channels, int HW,
                                    float eps, float* y, void* stream) {

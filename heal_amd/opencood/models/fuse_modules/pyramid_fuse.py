@@ -29,7 +29,7 @@ def weighted_fuse(x, occ, record_len, affine_matrix, grid_f64=True, crops=None):
             crop = [crops[start + a] if crops[start + a] is not None else (0, 0, 0, 0) for a in range(n)]
         out.append(ops.warp_fuse(x[start:start + n], occ[start:start + n], rows, grid_f64, crop))
         start += n
-    return torch.stack(out)
+    return out[0].unsqueeze(0) if len(out) == 1 else torch.stack(out)   # (one scene: no copy)
 
 
 class PyramidFusion(ResNetBEVBackbone):
@@ -46,9 +46,16 @@ class PyramidFusion(ResNetBEVBackbone):
         for i in range(self.num_levels):
             setattr(self, f"single_head_{i}", nn.Conv2d(model_cfg["num_filters"][i], 1, kernel_size=1))
 
+    def occupancy_head(self, i, feature):
+        """single_head_i (pyramid_fuse.py:89-91): a one-output 1x1 convolution = a channel dot product (heal_channel_dot)."""
+        head = getattr(self, f"single_head_{i}")
+        if not self.training and ops.channel_dot_supported(feature):
+            return ops.channel_dot(feature, head.weight, head.bias)
+        return head(feature)
+
     def forward_single(self, spatial_features):
         feature_list = self.get_multiscale_feature(spatial_features)
-        occ_map_list = [getattr(self, f"single_head_{i}")(feature_list[i]) for i in range(self.num_levels)]
+        occ_map_list = [self.occupancy_head(i, feature_list[i]) for i in range(self.num_levels)]
         return self.decode_multiscale_feature(feature_list), occ_map_list
 
     def forward_collab(self, spatial_features, record_len, affine_matrix, agent_modality_list=None,
@@ -59,7 +66,7 @@ class PyramidFusion(ResNetBEVBackbone):
         use_crop = bool(cam_crop_info) and not self.training
         fused_feature_list, occ_map_list = [], []
         for i in range(self.num_levels):
-            occ_map = getattr(self, f"single_head_{i}")(feature_list[i])
+            occ_map = self.occupancy_head(i, feature_list[i])
             occ_map_list.append(occ_map)
             crops = None
             if use_crop:

@@ -991,6 +991,24 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
     return y
 
 
+def channel_dot_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and int(x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def channel_dot(x, weight, bias=None):
+    """Pointwise convolution to one output channel: x [n,C,H,W], weight [1,C,1,1] (or [C]), bias [1] -> [n,1,H,W]."""
+    x = _need(x, torch.float32, "x")
+    n, C, H, W = (int(v) for v in x.shape)
+    weight = _need(weight.reshape(-1), torch.float32, "weight")
+    if int(weight.numel()) != C:
+        raise _capi.HealAmdError(f"channel_dot: weight has {int(weight.numel())} elements for {C} channels")
+    y = torch.empty((n, 1, H, W), dtype=torch.float32, device=x.device)
+    with _Timed(f"channel_dot_{C}", 2.0 * n * C * H * W, 4.0 * n * (C + 1) * H * W):
+        _capi.call("heal_channel_dot", _ptr(x), _ptr(weight), _ptr(_need(bias, torch.float32, "bias")) if bias is not None else None,
+                   n, C, H * W, _ptr(y), _stream())
+    return y
+
+
 def layernorm_nchw(x, gamma, beta, eps):
     """LayerNorm over the channel axis of x [n,C,H,W] (biased variance, eps inside the sqrt)."""
     x = _need(x, torch.float32, "x")

@@ -301,6 +301,12 @@ int heal_depthwise_conv(const float* x, const float* weight, const float* bias, 
 int heal_layernorm_nchw(const float* x, const float* gamma, const float* beta, int n, int channels, int HW, float eps,
                         float* y, void* stream);
 
+/* heal_channel_dot: pointwise convolution to ONE output channel, y[n][p] = bias[0] + sum_c weight[c] x[n][c][p] -- the occupancy
+ *   heads `single_head_i` of PyramidFusion (opencood/models/fuse_modules/pyramid_fuse.py:89-91, nn.Conv2d(C, 1, 1)) whose logits
+ *   feed heal_warp_fuse.  x [n,C,H,W] f32, y [n,1,H,W], HW = H*W % 4 == 0, 16-B aligned; bias may be NULL.                 */
+int heal_channel_dot(const float* x, const float* weight, const float* bias, int n, int channels, int HW, float* y,
+                     void* stream);
+
 /* heal_se_gate: squeeze-excite gate of the EfficientNet MBConv block (efficientnet_pytorch MBConvBlock as called from
  *   lss_submodule.py:93-105): gate [n,C] = sigmoid(W_expand silu(W_reduce mean + b_reduce) + b_expand) from the spatial
  *   mean [n,C]; W_reduce [S,C]; w_expand_t = W_expand^T laid out [S,C] (coalesced columns); S <= 64.

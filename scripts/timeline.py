@@ -72,6 +72,16 @@ def main():
     # coarse phases: when does the last side-queue kernel end (join), etc.
     main_q = max(queues, key=queues.get)
     side_end = max((r[1] for r in step if r[3] != main_q), default=t0)
+    # the main queue in launch order, runs of the same kernel merged: where the serial part of the step goes
+    print("main-queue sequence (us at start: kernel x count = total us):", file=out)
+    seq = [r for r in step if r[3] == main_q]
+    i = 0
+    while i < len(seq):
+        j = i; tot = 0
+        while j < len(seq) and seq[j][2] == seq[i][2]:
+            tot += seq[j][1] - seq[j][0]; j += 1
+        print(f"   @{(seq[i][0] - t0) / 1e3:7.0f}  {seq[i][2][:48]:48s} x{j - i:<3d} {tot / 1e3:7.1f}", file=out)
+        i = j
     print(f"main queue {main_q}; last side-queue kernel ends at {(side_end - t0) / 1e3:.1f} us of {wall / 1e3:.1f}", file=out)
 
 

@@ -589,6 +589,21 @@ def test_grouped_conv3x3_vs_torch(C, stride, H, W, mfma, monkeypatch):
     np.testing.assert_allclose(got2.cpu().numpy(), ref2.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,C,H,W", [(5, 64, 64, 64), (2, 128, 20, 14), (1, 256, 7, 12), (3, 3, 2, 2)])
+def test_channel_dot_vs_torch(n, C, H, W):
+    """Occupancy head (Conv2d(C, 1, 1)) as a channel dot product, against torch fp64."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn((n, C, H, W), generator=g).cuda()
+    w = (torch.randn((1, C, 1, 1), generator=g) / C ** 0.5).cuda()
+    b = torch.randn((1,), generator=g).cuda()
+    for bias in (b, None):
+        got = ops.channel_dot(x, w, bias)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None if bias is None else bias.double())
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
 def test_bias_act_vs_torch():
     from heal_amd import ops
     g = torch.Generator().manual_seed(3)
