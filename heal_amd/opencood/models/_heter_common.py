@@ -91,6 +91,8 @@ def detection_heads(x, cls_head, reg_head, dir_head):
     slices.  The concatenated weight is cached per parameter version."""
     from heal_amd import ops
     heads = (cls_head, reg_head, dir_head)
+    if torch.is_grad_enabled() and (x.requires_grad or cls_head.training or cls_head.weight.requires_grad):   # gradient path
+        return cls_head(x), reg_head(x), dir_head(x)
     if not (x.is_cuda and ops.conv1x1_supported(x.shape[1], 1, int(x.shape[2] * x.shape[3]))
             and all(h.kernel_size == (1, 1) and h.stride == (1, 1) for h in heads)):
         return cls_head(x), reg_head(x), dir_head(x)
@@ -120,7 +122,8 @@ def encode_modalities(model, data_dict, present, encode):
     import os
     mods = [m for m in model.modality_name_list if m in present]
     dev = next(model.parameters()).device
-    if len(mods) < 2 or dev.type != "cuda" or os.environ.get("HEAL_PARALLEL_MODALITIES", "1") != "1":
+    if (len(mods) < 2 or dev.type != "cuda" or os.environ.get("HEAL_PARALLEL_MODALITIES", "1") != "1"
+            or torch.is_grad_enabled()):   # (a gradient path stays on one stream)
         return {m: encode(data_dict, m) for m in mods}
     main = torch.cuda.current_stream(dev)
     streams = model.__dict__.setdefault("_heal_side_streams", {})

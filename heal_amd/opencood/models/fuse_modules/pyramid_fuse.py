@@ -15,11 +15,40 @@ def crop_window(H, W, ratio_h, ratio_w):
             int(W // 2 - crop_W // 2), int(W // 2 + crop_W // 2))
 
 
+def weighted_fuse_autograd(x, occ, record_len, affine_matrix, crops=None):
+    """Gradient path of pyramid_fuse.py:17-63,139-160 with torch operators: score = sigmoid(occ) + 1e-4 (times the camera
+    crop mask when one is given), features and scores of every agent sampled bilinearly in the ego frame (zeros outside),
+    softmax over the agents with never-observed positions (score exactly 0) left out, weighted sum."""
+    import torch.nn.functional as F
+    score = torch.sigmoid(occ) + 1e-4
+    if crops is not None:
+        keep = torch.ones_like(score)
+        for a, c in enumerate(crops):
+            if c is not None:
+                keep[a] = 0
+                keep[a, :, c[0]:c[1], c[2]:c[3]] = 1
+        score = score * keep
+    out, start = [], 0
+    for b, n in enumerate(record_len):
+        M = torch.as_tensor(affine_matrix[b][0, :n], dtype=x.dtype, device=x.device)
+        xs, ss = x[start:start + n], score[start:start + n]
+        grid = F.affine_grid(M, list(xs.shape), align_corners=False)
+        feat = F.grid_sample(xs, grid, align_corners=False)
+        sc = F.grid_sample(ss, F.affine_grid(M, list(ss.shape), align_corners=False), align_corners=False)
+        sc = sc.masked_fill(sc == 0, float("-inf")).softmax(dim=0)
+        sc = torch.where(torch.isnan(sc), torch.zeros_like(sc), sc)
+        out.append((feat * sc).sum(0))
+        start += n
+    return torch.stack(out)
+
+
 def weighted_fuse(x, occ, record_len, affine_matrix, grid_f64=True, crops=None):
     """pyramid_fuse.py:17-63 with the score construction folded in.
 
     x [sum(n),C,H,W]; occ [sum(n),1,H,W] occupancy LOGITS; record_len: list of ints;
     affine_matrix: host numpy [B,L,L,2,3]; crops: per-agent (h0,h1,w0,w1) or None."""
+    if torch.is_grad_enabled() and (x.requires_grad or occ.requires_grad):
+        return weighted_fuse_autograd(x, occ, record_len, affine_matrix, crops)
     out = []
     start = 0
     for b, n in enumerate(record_len):
@@ -49,7 +78,7 @@ class PyramidFusion(ResNetBEVBackbone):
     def occupancy_head(self, i, feature):
         """single_head_i (pyramid_fuse.py:89-91): a one-output 1x1 convolution = a channel dot product (heal_channel_dot)."""
         head = getattr(self, f"single_head_{i}")
-        if not self.training and ops.channel_dot_supported(feature):
+        if not torch.is_grad_enabled() and ops.channel_dot_supported(feature):
             return ops.channel_dot(feature, head.weight, head.bias)
         return head(feature)
 

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from heal_amd import ops
+from heal_amd.opencood.models.sub_modules.bev_blocks import grad_path
 from heal_amd.opencood.models.sub_modules.pillar_vfe import PillarVFE
 from heal_amd.opencood.models.sub_modules.point_pillar_scatter import PointPillarScatter
 
@@ -58,14 +59,24 @@ class PointPillar(nn.Module):
                                n_voxels_dev=offsets[k:k + 1])
 
     def forward(self, data_dict, modality_name):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         inp = data_dict[f"inputs_{modality_name}"]
+        grad = grad_path(None, self)
         if "points" in inp:  # the caps travel with the clouds when they come from SpVoxelPreprocessor's deferred mode
-            return self.encode_points(inp["points"], inp.get("max_points_per_voxel"), inp.get("max_voxels"))
-        voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
-        # point_pillar_scatter.py:45 reads the batch size back from the device the same way
-        n_agents = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
+            if not grad:
+                return self.encode_points(inp["points"], inp.get("max_points_per_voxel"), inp.get("max_voxels"))
+            # training: K1 still voxelises on the device (no gradient flows into the points); the rows past the voxel
+            # count are dropped here, on the host's side of one synchronisation
+            v, c, n, offsets = ops.voxelize_collated(inp["points"], self.lidar_range, self.voxel_size,
+                                                     int(inp.get("max_points_per_voxel") or self.max_points),
+                                                     int(inp.get("max_voxels") or self.max_voxels))
+            m = int(offsets[len(inp["points"])].item())
+            voxels, coords, num, n_agents = v[:m], c[:m], n[:m], len(inp["points"])
+        else:
+            voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
+            # point_pillar_scatter.py:45 reads the batch size back from the device the same way
+            n_agents = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
+        if grad:   # gradient path: the PFN and the scatter as torch operators on the same parameters
+            return self.scatter.canvas(self.pillar_vfe.pillar_features(voxels, coords, num), coords, n_agents)
         if coords.dtype != torch.int32:
             coords = coords.to(torch.int32)
         if num.dtype != torch.int32:
@@ -182,12 +193,43 @@ class LiftSplatShoot(nn.Module):
         return ops.bev_pool_pm(head, self.camC, self.D, fH, fW, self.frustum(head.device), cam_mats, B, N, self.dx_host,
                                self.bx_host, self.nx_host)
 
+    def lift_pool_autograd(self, depth_logit, x_img, inp, B, N):
+        """Gradient path of get_geometry + voxel_pooling (heter_encoders.py:125-217) with torch operators: ego coordinates of
+        every frustum point, softmax(depth) x features per point, summed into its BEV cell (index_add: differentiable with
+        respect to the logits and the features), z folded into the channels.  -> [B, C*nz, ny, nx]"""
+        fr = self.frustum(x_img.device)
+        D, fH, fW, _ = fr.shape
+        C = self.camC
+        pts = fr.view(1, 1, D, fH, fW, 3) - inp["post_trans"].view(B, N, 1, 1, 1, 3)
+        pts = torch.einsum("bnij,bndhwj->bndhwi", torch.inverse(inp["post_rots"]), pts)
+        pts = torch.cat([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], -1)
+        pts = torch.einsum("bnij,bndhwj->bndhwi", inp["rots"].matmul(torch.inverse(inp["intrins"])), pts)
+        pts = pts + inp["trans"].view(B, N, 1, 1, 1, 3)
+        dx, bx = pts.new_tensor(self.dx_host), pts.new_tensor(self.bx_host)
+        cell = ((pts - (bx - dx / 2.0)) / dx).long()                      # truncation toward zero, like the reference's .long()
+        nx, ny, nz = self.nx_host
+        ok = ((cell[..., 0] >= 0) & (cell[..., 0] < nx) & (cell[..., 1] >= 0) & (cell[..., 1] < ny)
+              & (cell[..., 2] >= 0) & (cell[..., 2] < nz))
+        batch = torch.arange(B, device=pts.device).view(B, 1, 1, 1, 1).expand_as(ok)
+        flat = ((batch * nz + cell[..., 2]) * ny + cell[..., 1]) * nx + cell[..., 0]
+        prob = depth_logit.softmax(dim=1).view(B, N, D, fH, fW, 1)
+        lifted = prob * x_img.view(B, N, C, fH, fW).permute(0, 1, 3, 4, 2).unsqueeze(2)      # [B,N,D,fH,fW,C]
+        out = lifted.new_zeros((B * nz * ny * nx, C)).index_add(0, flat[ok], lifted[ok])
+        return out.view(B, nz, ny, nx, C).permute(0, 1, 4, 2, 3).reshape(B, nz * C, ny, nx)
+
     def forward(self, data_dict, modality_name):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         inp = data_dict[f"inputs_{modality_name}"]
         x = inp["imgs"]
         B, N, C, imH, imW = x.shape
+        if grad_path(x, self):
+            items, depth_logit, x_img = self.camencode(x.view(B * N, C, imH, imW), pixel_major=False)
+            if self.depth_supervision:
+                self.depth_items = items
+            out = self.lift_pool_autograd(depth_logit, x_img, inp, B, N)
+            nz = self.nx_host[2]
+            if not self._pixel_major_pool and nz > 1:   # LiftSplatShootVoxel: max over the z bins
+                out = out.view(B, nz, self.camC, out.shape[2], out.shape[3]).max(dim=1)[0]
+            return out
         res = self.camencode(x.view(B * N, C, imH, imW), pixel_major=self._pixel_major_pool)
         if self.depth_supervision:
             self.depth_items = res[0]

@@ -14,6 +14,8 @@ from heal_amd.opencood.models.sub_modules.downsample_conv import DownsampleConv
 
 
 def head(conv, x):
+    if torch.is_grad_enabled() and (x.requires_grad or conv.training or conv.weight.requires_grad):   # gradient path
+        return conv(x)
     return conv_bias_act(x, conv.weight, conv.bias, conv.stride, conv.padding, 1, 1, False)
 
 
@@ -21,8 +23,6 @@ class _PillarStem(_PillarEncoder):
     """`pillar_vfe` + `scatter` (+ K2) reading the old `processed_lidar` key (point_pillar.py:55-66)."""
 
     def encode_processed_lidar(self, data_dict):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         return super().forward({"inputs_lidar": data_dict["processed_lidar"]}, "lidar")
 
 

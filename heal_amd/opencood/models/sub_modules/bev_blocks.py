@@ -6,7 +6,8 @@ Parameter names and shapes follow the reference so its checkpoints load unchange
 downsample_conv.py:7-49, feature_alignnet.py:12-39, feature_alignnet_modules.py:12-31,299-361,
 naive_compress.py:5-31.
 
-Inference design (eval mode): every Conv+BatchNorm pair is folded into one convolution with bias
+Training / fine-tuning (gradients enabled, see `grad_path`): the blocks run conv -> BatchNorm -> ReLU as torch modules with
+autograd.  Inference design (eval mode): every Conv+BatchNorm pair is folded into one convolution with bias
 (cached, re-folded when a parameter changes), ReLU and the residual add run in place -- one pass
 over each BEV map instead of three.  Pointwise, dense 3x3 (padding 1, stride 1 | 2) and 32-group 3x3 convolutions run on
 the hand-written fp32-MFMA / stencil kernels of libheal_amd with that epilogue fused; what is left to the library
@@ -56,6 +57,11 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
     hand-written stencil kernel (heal_grouped_conv3x3); everything else is a library convolution WITHOUT
     bias followed by ONE fused in-place pass (heal_bias_act) instead of separate bias / add / ReLU kernels."""
     from heal_amd import ops
+    if torch.is_grad_enabled() and x.requires_grad:
+        y = F.conv2d(x, w, b, stride, padding, dilation, groups)   # gradient path (callers that pass raw parameters)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
     st = stride if isinstance(stride, int) else stride[0]
     pd = padding if isinstance(padding, int) else padding[0]
     dl = dilation if isinstance(dilation, int) else dilation[0]
@@ -76,11 +82,29 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
     return ops.bias_act_(y, b, residual, relu)
 
 
+def grad_path(x, *modules):
+    """True when this call has to record an autograd graph: gradients are enabled AND (the input already carries gradient OR
+    a module of the block is in training mode OR has a parameter that requires gradient).  The fused inference operators of
+    libheal_amd have no backward; on the gradient path every block runs the reference's plain composition of torch operators
+    on the SAME parameters (BatchNorm with batch statistics when training), so `opencood/tools/train.py` -- forward, loss,
+    backward, optimiser step -- works on the module tree unchanged.  Inference runs under `torch.no_grad()`
+    (ScenePipeline, inference_utils) and never takes it."""
+    if not torch.is_grad_enabled():
+        return False
+    if torch.is_tensor(x) and x.requires_grad:
+        return True
+    for m in modules:
+        if m is not None and (m.training or any(p.requires_grad for p in m.parameters())):
+            return True
+    return False
+
+
 def _require_eval(module):
+    """For the operators that still have no gradient path (the sparse 3-D encoder K3)."""
     if module.training and torch.is_grad_enabled():
         raise NotImplementedError(
-            "heal_amd implements the inference hot path; the training/backward path is listed as "
-            "'next' (SURVEY 8f).  Call model.eval() and run under torch.no_grad().")
+            f"{type(module).__name__}: no gradient path (the sparse-convolution encoder is inference-only in this build). "
+            "Call model.eval() and run under torch.no_grad(), or freeze this module (eval mode, input without gradient).")
 
 
 class ConvBN(nn.Module):
@@ -89,6 +113,11 @@ class ConvBN(nn.Module):
 
     @staticmethod
     def run(x, conv, bn, cache, relu, residual=None):
+        if grad_path(x, bn, conv):   # training / fine-tuning: conv -> BatchNorm (batch statistics when training) -> + -> ReLU
+            y = bn(conv(x))
+            if residual is not None:
+                y = y + residual
+            return F.relu(y) if relu else y
         w, b = cache.get(conv, bn)
         return conv_bias_act(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups, relu, residual)
 
@@ -122,7 +151,6 @@ class BasicBlock(nn.Module):
         self._c1, self._c2, self._cd = _FoldCache(), _FoldCache(), _FoldCache()
 
     def forward(self, x):
-        _require_eval(self)
         identity = x
         if self.downsample is not None:
             identity = ConvBN.run(x, self.downsample[0], self.downsample[1], self._cd, relu=False)
@@ -178,8 +206,7 @@ class Bottleneck(nn.Module):
                 and self.conv2.dilation == (1, 1))
 
     def forward(self, x):
-        _require_eval(self)
-        if self._fusable(x):
+        if not grad_path(x, self) and self._fusable(x):
             from heal_amd import ops
             return ops.resnext_bottleneck(x.contiguous(), *self._fused_params())
         identity = x
@@ -236,7 +263,8 @@ class _Deblock(nn.Sequential):
         self._cache = _FoldCache()
 
     def forward(self, x):
-        _require_eval(self)
+        if grad_path(x, self):
+            return super().forward(x)   # (transposed) conv -> BatchNorm -> ReLU as torch modules
         conv, bn = self[0], self[1]
         from heal_amd import ops
         if isinstance(conv, nn.ConvTranspose2d):
@@ -335,6 +363,8 @@ class DoubleConv(nn.Module):
             nn.ReLU(inplace=True))
 
     def forward(self, x):
+        if grad_path(x, self):
+            return self.double_conv(x)
         c0, c1 = self.double_conv[0], self.double_conv[2]
         x = conv_bias_act(x, c0.weight, c0.bias, c0.stride, c0.padding, 1, 1, True)
         return conv_bias_act(x, c1.weight, c1.bias, c1.stride, c1.padding, 1, 1, True)
@@ -410,11 +440,12 @@ class ConvNeXtBlock(nn.Module):
         from heal_amd import ops
         inp = x
         k = self.dwconv.kernel_size[0]
-        if x.is_cuda and k == 7 and int(x.shape[0] * x.shape[1]) <= 65535:
+        fused = x.is_cuda and not grad_path(x, self)   # the gradient path is the reference's composition below
+        if fused and k == 7 and int(x.shape[0] * x.shape[1]) <= 65535:
             x = ops.depthwise_conv(x, self.dwconv.weight, self.dwconv.bias, 1, (3, 3, 3, 3), "none")
         else:
             x = self.dwconv(x)
-        if x.is_cuda and ops.conv1x1_supported(x.shape[1], 4 * x.shape[1], int(x.shape[2] * x.shape[3])):
+        if fused and ops.conv1x1_supported(x.shape[1], 4 * x.shape[1], int(x.shape[2] * x.shape[3])):
             # NCHW all the way: channel LayerNorm in one pass, the two Linear layers as pointwise convolutions with
             # GELU / (layer scale + residual) fused -- 3 launches instead of permute, LN, 2 GEMMs, GELU, scale, add
             xn = ops.layernorm_nchw(x, self.norm.weight, self.norm.bias, self.norm.eps)
@@ -476,7 +507,6 @@ class NaiveCompressor(nn.Module):
         self._c = [_FoldCache() for _ in range(3)]
 
     def forward(self, x):
-        _require_eval(self)
         x = ConvBN.run(x, self.encoder[0], self.encoder[1], self._c[0], relu=True)
         x = ConvBN.run(x, self.decoder[0], self.decoder[1], self._c[1], relu=True)
         return ConvBN.run(x, self.decoder[3], self.decoder[4], self._c[2], relu=True)

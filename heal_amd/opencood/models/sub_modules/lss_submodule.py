@@ -16,8 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from heal_amd.opencood.models.sub_modules.bev_blocks import (BasicBlock, Bottleneck, ConvBN, _FoldCache, _require_eval,
-                                                             conv_bias_act)
+from heal_amd.opencood.models.sub_modules.bev_blocks import (BasicBlock, Bottleneck, ConvBN, _FoldCache, conv_bias_act,
+                                                             grad_path)
 
 
 class Up(nn.Module):
@@ -34,9 +34,9 @@ class Up(nn.Module):
         self._c = [_FoldCache(), _FoldCache()]
 
     def forward(self, x1, x2):
-        _require_eval(self)
         from heal_amd import ops
-        up = ops.upsample2x_bilinear(x1) if (x1.is_cuda and self.up.scale_factor == 2) else self.up(x1)
+        fused = x1.is_cuda and self.up.scale_factor == 2 and not grad_path(x1, self)
+        up = ops.upsample2x_bilinear(x1) if fused else self.up(x1)
         x = torch.cat([x2, up], dim=1)
         x = ConvBN.run(x, self.conv[0], self.conv[1], self._c[0], relu=True)
         return ConvBN.run(x, self.conv[3], self.conv[4], self._c[1], relu=True)
@@ -69,6 +69,12 @@ class _SamePadConv2d(nn.Conv2d):
 def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None):
     """conv + folded BatchNorm (+ SiLU).  Pointwise convolutions run on heal_conv1x1 with the squeeze-excite gate
     (in_scale, per image and input channel), the bias, the skip connection and the activation fused."""
+    if grad_path(x, bn, conv):   # gradient path: the package's own composition (scale, pad, conv, BatchNorm, swish, skip)
+        if in_scale is not None:
+            x = in_scale * x
+        y = bn(conv(conv.static_padding(x)))
+        y = F.silu(y) if act else y
+        return y + residual if residual is not None else y
     w, b = cache.get(conv, bn)
     if (x.is_cuda and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
             and not any(conv.same_pad)):
@@ -114,8 +120,12 @@ class _MBConv(nn.Module):
         x = _conv_bn(x, self._depthwise_conv, self._bn1, self._c[1], act=True)
         # efficientnet_pytorch MBConvBlock: s = expand(silu(reduce(avgpool(x)))); x = sigmoid(s) * x; project; (+ skip)
         from heal_amd import ops
-        gate = ops.se_gate(x.mean((2, 3)), self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight,
-                           self._se_expand.bias)
+        if grad_path(x, self):
+            s_ = self._se_expand(F.silu(self._se_reduce(x.mean((2, 3), keepdim=True))))
+            gate = torch.sigmoid(s_)[:, :, 0, 0]
+        else:
+            gate = ops.se_gate(x.mean((2, 3)), self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight,
+                               self._se_expand.bias)
         return _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False, in_scale=gate[:, :, None, None],
                         residual=inp if self.id_skip else None)
 
@@ -222,7 +232,7 @@ class _CamEncodeBase(nn.Module):
 
     def pixel_major_ok(self, features):
         from heal_amd import ops
-        return (features.is_cuda and (self.C + self.D) % 4 == 0
+        return (features.is_cuda and not grad_path(features, self) and (self.C + self.D) % 4 == 0
                 and ops.conv1x1_supported(features.shape[1], self.C + self.D, int(features.shape[2] * features.shape[3]))
                 and ops.bev_pool_pm_supported(self.D, int(features.shape[2]), self.C))
 
@@ -283,7 +293,6 @@ class CamEncode_Resnet101(_CamEncodeBase):
 
     def features(self, x):
         """lss_submodule.py:196-210: conv1 -> bn1 -> relu -> maxpool -> layer1 -> layer2 -> [BN, 512, fH, fW]."""
-        _require_eval(self)
         f = ConvBN.run(x[:, :3, :, :], self.conv1, self.bn1, self._c, relu=True)
         return self.layer2(self.layer1(self.maxpool(f)))
 
@@ -316,13 +325,12 @@ class BevEncode(nn.Module):
         return nn.Sequential(BasicBlock(inplanes, planes, stride, down), BasicBlock(planes, planes))
 
     def forward(self, x):
-        _require_eval(self)
         from heal_amd import ops
         x = ConvBN.run(x, self.conv1, self.bn1, self._c[0], relu=True)
         x1 = self.layer1(x)
         x = self.layer3(self.layer2(x1))
         x = self.up1(x, x1)
-        x = ops.upsample2x_bilinear(x) if x.is_cuda else self.up2[0](x)
+        x = ops.upsample2x_bilinear(x) if (x.is_cuda and not grad_path(x, self)) else self.up2[0](x)
         x = ConvBN.run(x, self.up2[1], self.up2[2], self._c[1], relu=True)
         last = self.up2[4]
         return conv_bias_act(x, last.weight, last.bias, last.stride, last.padding, 1, 1, False)

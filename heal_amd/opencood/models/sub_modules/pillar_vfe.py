@@ -1,5 +1,6 @@
 """PillarVFE / PFNLayer parameter containers (names as in opencood/models/sub_modules/
-pillar_vfe.py:13-100) whose forward is the fused HIP operator K2 (heal_pfn_scatter).
+pillar_vfe.py:13-100) whose inference forward is the fused HIP operator K2 (heal_pfn_scatter); `pillar_features` is the
+same arithmetic as torch operators for the gradient path (training).
 
 Only the configuration HEAL uses is implemented: one PFN layer, use_norm, use_absolute_xyz,
 no distance feature (lidar_pyramid.yaml / m1m2m3m4.yaml `pillar_vfe` block).
@@ -55,3 +56,24 @@ class PillarVFE(nn.Module):
 
     def get_output_feature_dim(self):
         return self.num_filters[-1]
+
+    def pillar_features(self, voxels, coords, num_points):
+        """Gradient path of pillar_vfe.py:63-100: [M,P,4] points of M pillars (coords [M,4] = agent,z,y,x; num_points [M]) ->
+        [M,C].  Ten inputs per point: x,y,z,intensity, offset from the pillar's mean point, offset from the pillar's centre;
+        slots past num_points are zeroed; Linear -> BatchNorm1d over the channel -> ReLU -> max over the points."""
+        M, P, _ = voxels.shape
+        cnt = num_points.to(voxels.dtype).clamp_min(1).view(M, 1, 1)
+        xyz = voxels[:, :, :3]
+        from_mean = xyz - xyz.sum(1, keepdim=True) / cnt
+        vs = voxels.new_tensor(self.voxel_size)
+        lo = voxels.new_tensor(self.point_cloud_range[:3])
+        centre = coords[:, [3, 2, 1]].to(voxels.dtype) * vs + (vs / 2 + lo)
+        from_centre = xyz - centre.view(M, 1, 3)
+        feats = torch.cat([voxels, from_mean, from_centre], -1)
+        live = torch.arange(P, device=voxels.device).view(1, P) < num_points.view(M, 1)
+        feats = feats * live.unsqueeze(-1).to(feats.dtype)
+        pfn = self.pfn_layers[0]
+        h = pfn.linear(feats)
+        if pfn.use_norm:
+            h = pfn.norm(h.permute(0, 2, 1)).permute(0, 2, 1)
+        return torch.relu(h).max(dim=1)[0]

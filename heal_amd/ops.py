@@ -74,6 +74,12 @@ def _need(t, dtype, name):
         raise _capi.HealAmdError(f"{name} must be a CUDA/HIP tensor (heal_amd has no CPU path)")
     if t.dtype != dtype:
         raise _capi.HealAmdError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if t.grad_fn is not None and torch.is_grad_enabled():
+        # an activation of a recorded autograd graph: the HIP operators have no backward, the result would silently drop out
+        # of the graph.  The modules route such calls to their gradient path (bev_blocks.grad_path); reaching this is a bug
+        # or an operator without one (sparse 3-D encoder, attention fusions).
+        raise _capi.HealAmdError(f"{name} carries autograd history: this HIP operator is inference-only (no backward). "
+                                 "Run under torch.no_grad(), or train a configuration whose blocks have a gradient path")
     return t.contiguous()
 
 

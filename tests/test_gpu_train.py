@@ -1,0 +1,86 @@
+"""GPU twin of tests/test_train_path.py: the gradient path on the device, against the inference operators and
+through a training step whose LiDAR input goes through the K1 voxeliser."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_train_path import hetero_small, synthetic_targets
+
+pytestmark = [pytest.mark.gpu, pytest.mark.grad]
+
+
+def test_gradient_path_equals_inference_operators():
+    """Same model, same inputs, eval mode: gradients enabled -> torch-operator path, torch.no_grad() -> HIP operators.
+    Heads and occupancy maps agree to 1e-3 of their scale (the north-star tolerance); the inference outputs carry no graph."""
+    _, model, data, _ = hetero_small("cuda")
+    model.eval()
+    ref = model(data)
+    assert ref["cls_preds"].requires_grad
+    with torch.no_grad():
+        got = model(data)
+    assert not got["cls_preds"].requires_grad
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-3, (k, err)
+    for i in range(3):
+        a, b = got["occ_single_list"][i], ref["occ_single_list"][i]
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-3, i
+
+
+def test_training_steps_on_the_device():
+    """train.py's iteration on the GPU: forward (gradient path), pyramid loss, backward, Adam -- finite and decreasing."""
+    from heal_amd.opencood.tools.train_utils import create_loss
+    hypes, model, data, _ = hetero_small("cuda")
+    model.train()
+    criterion = create_loss(hypes)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    losses = []
+    for _step in range(5):
+        opt.zero_grad()
+        out = model(data)
+        tgt = synthetic_targets(out, device="cuda")
+        n_agents = out["occ_single_list"][0].shape[0]
+        single = {k: v.expand(n_agents, *v.shape[1:]).contiguous() for k, v in tgt.items()}
+        loss = criterion(out, tgt) + criterion(out, single, suffix="_single")
+        assert bool(torch.isfinite(loss))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
+
+
+def test_training_from_raw_point_clouds():
+    """LiDAR agents given as device point clouds: K1 voxelises (no gradient into the points), the PFN / scatter / backbone /
+    fusion run on the gradient path; the canvas equals the inference operator's (K2) for the same clouds."""
+    from heal_amd import configs
+    from heal_amd.opencood.tools.train_utils import create_model
+    from heal_amd.pipeline import Scene
+    from tests.golden.detfill import fill_module
+    hypes = configs.lidar_pyramid([-25.6, -25.6, -3, 25.6, 25.6, 1])
+    model = fill_module(create_model(hypes)).cuda()
+    scene = Scene(2, seed=3, device="cuda:0", modalities=["m1", "m1"])
+    data = scene.model_input()
+    model.eval()
+    enc = model.encoder_m1
+    canvas_g = enc(data, "m1")                      # gradient path (parameters require grad)
+    with torch.no_grad():
+        canvas_i = enc(data, "m1")                  # K1 + K2
+    assert canvas_g.requires_grad and not canvas_i.requires_grad
+    assert float((canvas_g - canvas_i).abs().max() / canvas_i.abs().max()) < 1e-4
+    model.train()
+    out = model(data)
+    loss = sum(out[k].square().mean() for k in ("cls_preds", "reg_preds", "dir_preds"))
+    loss.backward()
+    for name, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+
+
+def test_inference_operator_refuses_autograd_activations():
+    """An activation with autograd history must never reach a HIP operator silently (its result would drop out of the graph)."""
+    from heal_amd import _capi, ops
+    x = torch.randn((1, 64, 8, 8), device="cuda", requires_grad=True) * 2.0
+    w = torch.randn((64, 64, 1, 1), device="cuda")
+    with pytest.raises(_capi.HealAmdError, match="autograd history"):
+        ops.conv1x1(x, w)
+    with torch.no_grad():
+        ops.conv1x1(x, w)   # fine without a graph

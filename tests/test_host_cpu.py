@@ -123,6 +123,7 @@ def test_pcd_utils_host_mirror_matches_reference(golden):
     assert pcd_utils.shuffle_points(both).shape == both.shape
 
 
+@pytest.mark.grad
 def test_pyramid_loss_matches_reference_golden(golden):
     """SURVEY 8f-2 (training side): PointPillarPyramidLoss value and gradients against the imported reference's
     (tests/golden/loss.npz), fused heads / per-agent occupancy pass / single-agent model, with and without the depth

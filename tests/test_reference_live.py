@@ -167,6 +167,7 @@ def _leafs(out):
     return ts
 
 
+@pytest.mark.grad
 @pytest.mark.parametrize("use_fg_mask", [False, True])
 def test_losses_match_live_reference_values_and_gradients(use_fg_mask):
     """opencood/loss/point_pillar{,_depth,_pyramid}_loss.py: value, loss_dict and the gradient w.r.t. every head /
@@ -199,6 +200,7 @@ def test_losses_match_live_reference_values_and_gradients(use_fg_mask):
                 assert torch.equal(x, y)
 
 
+@pytest.mark.grad
 def test_loss_components_match_live_reference():
     mine, theirs = __import__("heal_amd.opencood.loss.point_pillar_loss", fromlist=["x"]), \
         _ref("opencood.loss.point_pillar_loss")
@@ -229,6 +231,7 @@ def test_loss_components_match_live_reference():
     np.testing.assert_allclose(sm.numpy(), (smooth.permute(0, 3, 1, 2) * focal).sum(1).numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.grad
 def test_checkpoint_optimizer_scheduler_helpers_match_live_reference(tmp_path, capsys):
     """tools/train_utils.py: load_saved_model (best-val file, last-epoch file, empty directory), setup_optimizer and
     setup_lr_schedular with the optimizer / scheduler blocks of the reference's own lidar_pyramid.yaml."""
