@@ -261,7 +261,7 @@ class ShardedCollab(_Sharded):
         if mine:
             stages = pb.get_multiscale_feature(x)
             for i, f in enumerate(stages):
-                occ = getattr(pb, f"single_head_{i}")(f)
+                occ = pb.occupancy_head(i, f)
                 fe_all, se_all = [], []
                 for k, a in enumerate(mine):
                     crop = None
