@@ -125,7 +125,14 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         f["calls"] += w["calls"]; f["ms"] += w["total_ms"]; f["flops"] += w["flops"]; f["bytes"] += w["bytes"]
     for name, w in work.items():
         if name.startswith("conv1x1_"):
-            add("conv1x1", "K7 heal_conv1x1 (pointwise convolutions, fp32 MFMA, fused epilogues; all shapes of the step)", "mfma", w)
+            # two populations: the fusion-backbone / trunk convolutions with >= 1 GFLOP per launch (MFMA-bound; most of the
+            # family's time) and the small ones (image trunks at 1/16 .. 1/32 resolution, heads: launch / latency-bound)
+            if w["flops"] >= 1e9 * max(w["calls"], 1):
+                add("conv1x1", "K7 heal_conv1x1, launches of >= 1 GFLOP (pointwise convolutions of the fusion backbone and the "
+                               "trunks, fp32 MFMA, fused epilogues)", "mfma", w)
+            else:
+                add("conv1x1s", "K7 heal_conv1x1, launches below 1 GFLOP (image trunks at 1/16..1/32 resolution, heads: "
+                                "latency-bound)", "mfma", w)
         elif name.startswith("conv3x3w_"):
             add("conv3x3w", "K7 heal_conv3x3_winograd (dense 3x3 stride 1, F(2x2,3x3) on fp32 MFMA; achieved = EXECUTED matrix "
                             "FLOPs 2*16*Cin*Cout*tiles = direct/2.25, `direct_equiv_tflops` = the direct convolution's count)",
@@ -388,6 +395,10 @@ def main():
         # per-operator HIP-event timing needs host-side launches: an instrumented eager pass over the
         # same K steps, right after the timed graph replays (events cannot be recorded inside a graph)
         ops.TIMING = {}
+        # one stream for this pass: with the modality stems on concurrent streams an operator's event pair would also time
+        # the other streams' kernels it shares the chip with (per-operator durations, not the step time, are read from here)
+        par_env = os.environ.get("HEAL_PARALLEL_MODALITIES")
+        os.environ["HEAL_PARALLEL_MODALITIES"] = "0"
         for i_ in range(a.steps):
             ops.SP_TRACE = [] if i_ == a.steps - 1 else None   # sparse-layer anatomy of the last instrumented step
             if solo:
@@ -395,6 +406,10 @@ def main():
             else:
                 eager_step()
         torch.cuda.synchronize()
+        if par_env is None:
+            os.environ.pop("HEAL_PARALLEL_MODALITIES")
+        else:
+            os.environ["HEAL_PARALLEL_MODALITIES"] = par_env
     timing = ops.timing_summary()
     work = ops.work_summary()
     sp_trace = ops.SP_TRACE
