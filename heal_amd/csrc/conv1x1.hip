@@ -29,7 +29,10 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 const float* __restrict__ in_scale, int Cin, int Kpad, int Cout,
                                                 int HW, int Wo, int in_W, int in_HW, int act, int out_pm,
-                                                float* __restrict__ y) {
+                                                int d2s_k, int d2s_ctot, int d2s_coff, float* __restrict__ y) {
+    // out_pm: 0 NCHW | 1 pixel-major | 2 depth-to-space INTO A SLICE of a wider NCHW tensor: output channel co of pixel
+    // (h, w) lands at channel d2s_coff + co / k^2, pixel (h k + (co % k^2) / k, w k + co % k) of y [n, d2s_ctot, H k, W k] --
+    // ConvTranspose2d(kernel = stride = k) + pixel shuffle + torch.cat in the epilogue (k = 1: a plain channel-offset write).
     // HW / Wo: OUTPUT pixels per image / per row; in_W / in_HW: input row width / pixels per image.  STRIDE 1: in == out.
     constexpr int MT = BM / 64;      // m-tiles per wave
     constexpr int NT = BN / 16;      // n-tiles per wave
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             for (int ks = 0; ks < KS; ++ks) a_cur[mt][ks] = a_nxt[mt][ks];
     }
 
-    if (out_pm) {
+    if (out_pm == 1) {
         // Pixel-major output y[n][pixel][Cout] (what K4's lift + BEV pool reads: one pixel's channels are one contiguous
         // row).  MFMA leaves D[row = lk*4 + r][col = ln]: a lane holds 4 CONSECUTIVE channels of one pixel -> one 16-B
         // store per (mt, nt), the four lk groups complete a 64-B run per pixel.  No residual in this layout.
@@ -200,7 +203,20 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
                 v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752f));
                 v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
             }
-            *reinterpret_cast<float4*>(yout + o) = v;
+            if (out_pm != 2) {
+                *reinterpret_cast<float4*>(yout + o) = v;
+            } else {
+                const int kk = d2s_k * d2s_k, Ho = HW / Wo;
+                const int c = co / kk, r = co - c * kk, dy = r / d2s_k, dx = r - dy * d2s_k;
+                const int hh = p / Wo, ww = p - hh * Wo;      // Wo % 4 == 0 (host): the four pixels share a row
+                float* dst = y + (((size_t)n * d2s_ctot + d2s_coff + c) * ((size_t)Ho * d2s_k) + (size_t)hh * d2s_k + dy) *
+                                     ((size_t)Wo * d2s_k) + (size_t)ww * d2s_k + dx;
+                if (d2s_k == 1) {
+                    *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                    dst[0] = v.x; dst[d2s_k] = v.y; dst[2 * d2s_k] = v.z; dst[3 * d2s_k] = v.w;
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -210,9 +226,9 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
 
 using namespace heal;
 
-extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
-                            const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
-                            int out_pixel_major, float* y, void* stream) {
+static int conv1x1_launch(const float* x, const float* weight_frag, const float* bias, const float* residual,
+                          const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
+                          int out_pixel_major, int d2s_k, int d2s_ctot, int d2s_coff, float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv1x1: bad shape");
     HEAL_REQUIRE(stride == 1 || stride == 2, "conv1x1: stride must be 1 or 2 (got %d)", stride);
     const int kpad = (cin + 31) / 32 * 32, mpad = (cout + 63) / 64 * 64;  // dims of the zero-padded fragment layout
@@ -221,7 +237,7 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
     else HEAL_REQUIRE(Wo % 4 == 0, "conv1x1: output width must be a multiple of 4 for stride 2 (got %d)", Wo);
     HEAL_REQUIRE(act >= 0 && act <= 3, "conv1x1: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (GELU)");
     HEAL_REQUIRE(x && weight_frag && y, "conv1x1: null pointer");
-    if (out_pixel_major) {
+    if (out_pixel_major == 1) {
         HEAL_REQUIRE(residual == nullptr && act != 3, "conv1x1: pixel-major output takes no residual / GELU");
         HEAL_REQUIRE(cout % 4 == 0 && ((uintptr_t)bias & 15) == 0, "conv1x1: pixel-major output needs Cout %% 4 == 0 and a 16-B aligned bias");
     }
@@ -239,7 +255,8 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
 #define HEAL_C1(BM_, BN_, KC_, ST_)                                                                              \
     if (bm == BM_ && bn == BN_ && kc == KC_ && stride == ST_) {                                                  \
         k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                    \
-            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, y); \
+            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, d2s_k,    \
+            d2s_ctot, d2s_coff, y);                                                                              \
         launched = true;                                                                                         \
     }
     bool launched = false;
@@ -249,4 +266,24 @@ extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const floa
     HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d) stride %d", bm, bn, kc, stride);
     HEAL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, const float* residual,
+                            const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
+                            int out_pixel_major, float* y, void* stream) {
+    HEAL_REQUIRE(out_pixel_major == 0 || out_pixel_major == 1, "conv1x1: out_pixel_major must be 0 or 1");
+    return conv1x1_launch(x, weight_frag, bias, residual, in_scale, n, cin, cout, H, W, stride, act, out_pixel_major, 1, 0, 0,
+                          y, stream);
+}
+
+extern "C" int heal_conv1x1_d2s(const float* x, const float* weight_frag, const float* bias, int n, int cin, int cout, int H,
+                                int W, int act, int k, int dst_channels, int dst_channel_offset, float* y, void* stream) {
+    HEAL_REQUIRE(k >= 1 && k <= 8 && cout % (k * k) == 0, "conv1x1_d2s: Cout must be a multiple of k^2 (k = %d)", k);
+    HEAL_REQUIRE(W % 4 == 0, "conv1x1_d2s: W must be a multiple of 4 (got %d)", W);
+    HEAL_REQUIRE(dst_channel_offset >= 0 && dst_channel_offset + cout / (k * k) <= dst_channels,
+                 "conv1x1_d2s: channel slice [%d, %d) outside the %d destination channels", dst_channel_offset,
+                 dst_channel_offset + cout / (k * k), dst_channels);
+    HEAL_REQUIRE(((uintptr_t)y & 15) == 0, "conv1x1_d2s: destination must be 16-B aligned");
+    return conv1x1_launch(x, weight_frag, bias, nullptr, nullptr, n, cin, cout, H, W, 1, act, 2, k, dst_channels,
+                          dst_channel_offset, y, stream);
 }

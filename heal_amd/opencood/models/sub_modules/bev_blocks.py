@@ -262,7 +262,25 @@ class _Deblock(nn.Sequential):
         super().__init__(conv, bn, nn.ReLU())
         self._cache = _FoldCache()
 
-    def forward(self, x):
+    def out_shape(self, x):
+        """(channels, H, W) of the output for input x (what decode_multiscale_feature sizes the concatenated tensor with)."""
+        conv = self[0]
+        if isinstance(conv, nn.ConvTranspose2d):
+            return conv.out_channels, int(x.shape[2]) * conv.stride[0], int(x.shape[3]) * conv.stride[1]
+        s0, s1 = conv.stride
+        return conv.out_channels, (int(x.shape[2]) - conv.kernel_size[0]) // s0 + 1, (int(x.shape[3]) - conv.kernel_size[1]) // s1 + 1
+
+    def forward(self, x, into=None):
+        """into = (dst [n, Ctot, Ho, Wo], channel offset): write the result into that channel slice of the concatenated tensor
+        (by the convolution's own epilogue when the deblock is a kernel == stride transposed convolution) and return the slice."""
+        y = self._forward(x, into)
+        if into is not None and y.data_ptr() != into[0][:, into[1]:].data_ptr():
+            dst = into[0][:, into[1]:into[1] + y.shape[1]]
+            dst.copy_(y)
+            return dst
+        return y
+
+    def _forward(self, x, into=None):
         if grad_path(x, self):
             return super().forward(x)   # (transposed) conv -> BatchNorm -> ReLU as torch modules
         conv, bn = self[0], self[1]
@@ -282,6 +300,9 @@ class _Deblock(nn.Sequential):
                     self._ps = (w.permute(1, 2, 3, 0).reshape(cout * k * k, cin, 1, 1).contiguous(),
                                 b.repeat_interleave(k * k).contiguous())
                     self._ps_key = key
+                if into is not None and int(x.shape[3]) % 4 == 0 and into[0].is_contiguous():
+                    # bias, ReLU, the depth-to-space shuffle AND the concatenation ride in the conv1x1 epilogue
+                    return ops.conv1x1_d2s(x, self._ps[0], self._ps[1], 1, k, into[0], into[1])
                 y = ops.conv1x1(x, self._ps[0], self._ps[1], None, 1)
                 return y if k == 1 else F.pixel_shuffle(y, k)
             y = F.conv_transpose2d(x, w, None, conv.stride, conv.padding, conv.output_padding, conv.groups)
@@ -335,8 +356,20 @@ class ResNetBEVBackbone(nn.Module):
 
     def decode_multiscale_feature(self, x):
         ups = []
-        for i in range(self.num_levels):
-            ups.append(self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i])
+        if (len(self.deblocks) >= self.num_levels > 1 and x[0].is_cuda and not grad_path(x[0], self)
+                and len({self.deblocks[i].out_shape(x[i])[1:] for i in range(self.num_levels)}) == 1):
+            # inference: every deblock writes its channel slice of the concatenated tensor itself (no torch.cat pass)
+            shapes = [self.deblocks[i].out_shape(x[i]) for i in range(self.num_levels)]
+            cat = torch.empty((int(x[0].shape[0]), sum(s[0] for s in shapes), shapes[0][1], shapes[0][2]),
+                              dtype=x[0].dtype, device=x[0].device)
+            off = 0
+            for i in range(self.num_levels):
+                self.deblocks[i](x[i], into=(cat, off))
+                off += shapes[i][0]
+            ups = [cat]
+        else:
+            for i in range(self.num_levels):
+                ups.append(self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i])
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > self.num_levels:
             x = self.deblocks[-1](x)

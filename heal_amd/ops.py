@@ -891,6 +891,25 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
     return y
 
 
+def conv1x1_d2s(x, w, bias, act, k, dst, channel_offset):
+    """Pointwise convolution to Cout = C k^2 channels whose epilogue writes depth-to-space into dst[:, off:off+C] (dst
+    [n, Ctot, H k, W k], contiguous): a ConvTranspose2d(kernel = stride = k) deblock written straight into the concatenated
+    tensor.  x [n,Cin,H,W], w [C k^2, Cin, 1, 1] (row c k^2 + dy k + dx = output channel c at sub-pixel (dy, dx))."""
+    x = _need(x, torch.float32, "x")
+    dst = _need(dst, torch.float32, "dst")
+    n, cin, H, W = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    if (not dst.is_contiguous() or int(dst.shape[0]) != n or int(dst.shape[2]) != H * k or int(dst.shape[3]) != W * k
+            or cout % (k * k) or W % 4):
+        raise _capi.HealAmdError(f"conv1x1_d2s: destination {tuple(dst.shape)} does not fit x {tuple(x.shape)} at k={k}")
+    frag = conv1x1_fragments(w)
+    bias = _need(bias, torch.float32, "bias") if bias is not None else None
+    with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W, 4.0 * n * H * W * (cin + cout)):
+        _capi.call("heal_conv1x1_d2s", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None, n, cin, cout, H, W,
+                   int(act), int(k), int(dst.shape[1]), int(channel_offset), _ptr(dst), _stream())
+    return dst[:, channel_offset:channel_offset + cout // (k * k)]
+
+
 _FRAG3_CACHE = {}
 
 

@@ -331,6 +331,15 @@ int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, co
                  const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
                  int out_pixel_major, float* y, void* stream);
 
+/* heal_conv1x1_d2s: heal_conv1x1 (stride 1, no residual / gate) whose epilogue writes DEPTH-TO-SPACE INTO A CHANNEL SLICE of a
+ *   wider NCHW tensor: output channel co of pixel (h, w) goes to channel dst_channel_offset + co / k^2, pixel
+ *   (h k + (co % k^2) / k, w k + co % k) of y [n, dst_channels, H k, W k].  This is the deblock of the BEV backbones --
+ *   ConvTranspose2d(kernel = stride = k) + BatchNorm + ReLU (base_bev_backbone_resnet.py:49-74,128-131; folded weight laid out
+ *   [Cout k^2, Cin] by the caller) -- written straight into the torch.cat of the upsampled levels, so neither the pixel
+ *   shuffle nor the concatenation is a separate pass.  k = 1: a plain channel-offset write.  W % 4 == 0.            */
+int heal_conv1x1_d2s(const float* x, const float* weight_frag, const float* bias, int n, int cin, int cout, int H, int W,
+                     int act, int k, int dst_channels, int dst_channel_offset, float* y, void* stream);
+
 /* heal_conv3x3: dense 3x3 convolution, padding 1, stride 1 | 2, with the epilogue fused:
  *     y = act(W * x + bias (+ residual)),
  *   i.e. the conv3x3 + BatchNorm (+ identity) + ReLU sequences of BasicBlock (opencood/models/sub_modules/resblock.py:18-64),

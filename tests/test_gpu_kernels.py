@@ -982,3 +982,32 @@ def test_deblock_transposed_conv_as_conv1x1_plus_shuffle(k, cin, cout, H, W):
         ref = torch.relu(d[1](torch.nn.functional.conv_transpose2d(x.double(), d[0].weight, None, k)))
     assert got.shape == ref.shape == (2, cout, k * H, k * W)
     assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+    # the same deblock writing its channel slice of a wider (concatenated) tensor from the convolution's epilogue
+    blk = blk.float()
+    with torch.no_grad():
+        cat = torch.full((2, cout + 24, k * H, k * W), 7.0, device="cuda")
+        view = blk(x, into=(cat, 8))
+    assert view.data_ptr() == cat[:, 8:].data_ptr() and torch.equal(view, got)      # same values as the stand-alone path
+    assert bool((cat[:, :8] == 7.0).all()) and bool((cat[:, 8 + cout:] == 7.0).all())   # nothing written outside the slice
+
+
+def test_decode_multiscale_feature_writes_the_concatenation_in_place():
+    """ResNetBEVBackbone.decode_multiscale_feature (base_bev_backbone_resnet.py:122-138): three deblocks (k = 1, 2, 4) +
+    torch.cat, with every deblock writing its slice of the concatenated tensor itself, against the separate
+    pixel-shuffle + cat evaluation of the same modules and torch fp64."""
+    from heal_amd.opencood.models.sub_modules.bev_blocks import ResNetBEVBackbone
+    from tests.golden.detfill import fill_module
+    cfg = {"layer_nums": [1, 1, 1], "layer_strides": [1, 2, 2], "num_filters": [64, 128, 256],
+           "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]}
+    bb = fill_module(ResNetBEVBackbone(cfg, 64)).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn((2, 64, 32, 48), generator=g).cuda(), torch.randn((2, 128, 16, 24), generator=g).cuda(),
+             torch.randn((2, 256, 8, 12), generator=g).cuda()]
+    with torch.no_grad():
+        got = bb.decode_multiscale_feature(feats)
+        parts = [bb.deblocks[i](feats[i]) for i in range(3)]
+        d = bb.double()
+        ref = torch.cat([torch.relu(d.deblocks[i][1](torch.nn.functional.conv_transpose2d(
+            feats[i].double(), d.deblocks[i][0].weight, None, d.deblocks[i][0].stride))) for i in range(3)], 1)
+    assert got.shape == (2, 384, 32, 48) and torch.equal(got, torch.cat(parts, 1))
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
