@@ -69,11 +69,11 @@ _SIGNATURES = {
     "heal_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "heal_resnext_bottleneck": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_upsample2x_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "heal_depthwise_conv": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_void_p]),
+    "heal_depthwise_conv": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_void_p, c_void_p]),
     "heal_camera_matrices": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     "heal_channel_dot": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     "heal_layernorm_nchw": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_void_p, c_void_p]),
-    "heal_se_gate": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "heal_se_gate": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_int, c_void_p, c_void_p]),
     "heal_conv1x1": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p]),
     "heal_conv1x1_d2s": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_void_p]),
     "heal_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_void_p]),

@@ -196,10 +196,12 @@ __global__ __launch_bounds__(256) void k_upsample2x(const float* __restrict__ x,
 template <int K, int STRIDE>
 __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ x, const float* __restrict__ w,
                                                   const float* __restrict__ bias, int C, int H, int W, int Ho,
-                                                  int Wo, int pad_t, int pad_l, int act, float* __restrict__ y) {
+                                                  int Wo, int pad_t, int pad_l, int act, float* __restrict__ y,
+                                                  float* __restrict__ sums) {
     constexpr int TW = 32, TH = 8;
     constexpr int IW = (TW - 1) * STRIDE + K, IH = (TH - 1) * STRIDE + K;
     __shared__ float tile[IH][IW + 1];
+    __shared__ float part[4];
     const Block3 bk = xcd_block();
     const int nc = bk.z;          // n * C + c
     const int c = nc % C;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ x, 
     __syncthreads();
     const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
     const int ox = ox0 + tx, oy = oy0 + ty;
-    if (ox >= Wo || oy >= Ho) return;
+    const bool live = ox < Wo && oy < Ho;
+    if (!live && !sums) return;
     const float* __restrict__ wk = w + (size_t)c * K * K;  // block-uniform -> scalar loads
     float acc = bias ? bias[c] : 0.f;
 #pragma unroll
@@ -223,7 +226,15 @@ __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ x, 
         for (int kx = 0; kx < K; ++kx) acc = fmaf(tile[ty * STRIDE + ky][tx * STRIDE + kx], wk[ky * K + kx], acc);
     if (act == 1) acc = fmaxf(acc, 0.f);
     else if (act == 2) acc = acc / (1.f + expf(-acc));  // SiLU
-    y[(size_t)nc * Ho * Wo + (size_t)oy * Wo + ox] = acc;
+    if (live) y[(size_t)nc * Ho * Wo + (size_t)oy * Wo + ox] = acc;
+    if (sums) {
+        // the squeeze of the squeeze-excite stage that follows (MBConv: x.mean((2, 3))) rides along: block sum of the
+        // activated outputs -> one fp32 atomic per block into sums[n*C + c] (k_se_gate divides by Ho*Wo and clears it)
+        const float ws = wave_sum(live ? acc : 0.f);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) unsafeAtomicAdd(sums + nc, (part[0] + part[1]) + (part[2] + part[3]));
+    }
 }
 
 }  // namespace heal
@@ -232,13 +243,14 @@ using namespace heal;
 
 extern "C" int heal_depthwise_conv(const float* x, const float* weight, const float* bias, int n, int channels,
                                    int H, int W, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                                   int act, float* y, void* stream) {
+                                   int act, float* y, float* channel_sums, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(n >= 1 && channels >= 1 && (long long)n * channels <= 65535, "depthwise_conv: n*channels too large");
     dim3 grid(ceil_div(Wo, 32), ceil_div(Ho, 8), n * channels);
 #define HEAL_DW(KK, ST)                                                                                       \
     if (ksize == KK && stride == ST) {                                                                        \
-        k_depthwise<KK, ST><<<grid, 256, 0, s>>>(x, weight, bias, channels, H, W, Ho, Wo, pad_t, pad_l, act, y); \
+        k_depthwise<KK, ST><<<grid, 256, 0, s>>>(x, weight, bias, channels, H, W, Ho, Wo, pad_t, pad_l, act, y, \
+                                                 channel_sums);                                          \
         HEAL_LAUNCH_CHECK();                                                                                  \
         return 0;                                                                                             \
     }
@@ -254,8 +266,11 @@ namespace heal {
 // faster in isolation and 5x SLOWER inside the pipeline (cold instruction fetch between hundreds of other kernels).
 __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2t,
-                                                 const float* __restrict__ b2, int C, int S,
+                                                 const float* __restrict__ b2, int C, int S, float scale,
+                                                 int clear, float* __restrict__ mean_rw,
                                                  float* __restrict__ gate) {
+    // mean * scale is the squeezed input: scale = 1 for a mean, 1 / (Ho*Wo) for the channel SUMS heal_depthwise_conv leaves;
+    // clear: zero the sums after the last read, so the accumulator is ready for the next depthwise launch (no memset)
     __shared__ float hid[64];
     const int n = blockIdx.x;
     const float* m = mean + (size_t)n * C;
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean
         const float* wr = w1 + (size_t)j * C;
         float acc = 0.f;
 #pragma unroll 4
-        for (int c = l; c < C; c += 64) acc = fmaf(wr[c], m[c], acc);
+        for (int c = l; c < C; c += 64) acc = fmaf(wr[c], m[c] * scale, acc);
         acc = wave_sum(acc);
         if (l == 0) {
             const float v = acc + b1[j];
@@ -277,16 +292,18 @@ __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean
 #pragma unroll 8
         for (int j = 0; j < S; ++j) g = fmaf(w2t[(size_t)j * C + c], hid[j], g);
         gate[(size_t)n * C + c] = 1.f / (1.f + expf(-g));
+        if (clear) mean_rw[(size_t)n * C + c] = 0.f;      // every read of m happened before the barrier above
     }
 }
 }  // namespace heal
 
-extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
-                            const float* b_expand, int n, int channels, int squeezed, float* gate, void* stream) {
+extern "C" int heal_se_gate(float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
+                            const float* b_expand, int n, int channels, int squeezed, float scale, int clear_mean,
+                            float* gate, void* stream) {
     HEAL_REQUIRE(n >= 1 && channels >= 1 && squeezed >= 1 && squeezed <= 64, "se_gate: squeezed channels must be in [1,64]");
     HEAL_REQUIRE(mean && w_reduce && b_reduce && w_expand_t && b_expand && gate, "se_gate: null pointer");
     heal::k_se_gate<<<n, 1024, 0, (hipStream_t)stream>>>(mean, w_reduce, b_reduce, w_expand_t, b_expand, channels, squeezed,
-                                                      gate);
+                                                      scale, clear_mean, mean, gate);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

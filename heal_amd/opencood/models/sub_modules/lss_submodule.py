@@ -66,7 +66,7 @@ class _SamePadConv2d(nn.Conv2d):
         self.static_padding = nn.ZeroPad2d(self.same_pad) if (pad_h > 0 or pad_w > 0) else nn.Identity()
 
 
-def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None):
+def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None, channel_sums=None):
     """conv + folded BatchNorm (+ SiLU).  Pointwise convolutions run on heal_conv1x1 with the squeeze-excite gate
     (in_scale, per image and input channel), the bias, the skip connection and the activation fused."""
     if grad_path(x, bn, conv):   # gradient path: the package's own composition (scale, pad, conv, BatchNorm, swish, skip)
@@ -86,7 +86,8 @@ def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None):
     if (x.is_cuda and conv.groups == conv.in_channels == conv.out_channels and conv.kernel_size[0] in (3, 5)
             and conv.stride[0] in (1, 2) and x.shape[0] * conv.in_channels <= 65535):
         from heal_amd import ops
-        return ops.depthwise_conv(x.contiguous(), w, b, conv.stride[0], conv.same_pad, "silu" if act else "none")
+        return ops.depthwise_conv(x.contiguous(), w, b, conv.stride[0], conv.same_pad, "silu" if act else "none",
+                                  channel_sums=channel_sums)
     if any(conv.same_pad):
         x = F.pad(x, conv.same_pad)
     y = F.conv2d(x, w, b, conv.stride, 0, 1, conv.groups)
@@ -117,9 +118,19 @@ class _MBConv(nn.Module):
         inp = x
         if self.expand != 1:
             x = _conv_bn(x, self._expand_conv, self._bn0, self._c[0], act=True)
-        x = _conv_bn(x, self._depthwise_conv, self._bn1, self._c[1], act=True)
-        # efficientnet_pytorch MBConvBlock: s = expand(silu(reduce(avgpool(x)))); x = sigmoid(s) * x; project; (+ skip)
         from heal_amd import ops
+        dw = self._depthwise_conv
+        if (x.is_cuda and not grad_path(x, self) and dw.kernel_size[0] in (3, 5) and dw.stride[0] in (1, 2)
+                and x.shape[0] * dw.in_channels <= 65535):
+            # the squeeze (spatial mean) rides in the depthwise launch as per-channel sums; the gate kernel scales and clears them
+            sums = ops.channel_sum_buffer(int(x.shape[0]), dw.in_channels, x.device)
+            x = _conv_bn(x, dw, self._bn1, self._c[1], act=True, channel_sums=sums)
+            gate = ops.se_gate(sums, self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight,
+                               self._se_expand.bias, scale=1.0 / float(x.shape[2] * x.shape[3]), clear=True)
+            return _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False, in_scale=gate[:, :, None, None],
+                            residual=inp if self.id_skip else None)
+        x = _conv_bn(x, dw, self._bn1, self._c[1], act=True)
+        # efficientnet_pytorch MBConvBlock: s = expand(silu(reduce(avgpool(x)))); x = sigmoid(s) * x; project; (+ skip)
         if grad_path(x, self):
             s_ = self._se_expand(F.silu(self._se_reduce(x.mean((2, 3), keepdim=True))))
             gate = torch.sigmoid(s_)[:, :, 0, 0]
