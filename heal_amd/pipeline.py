@@ -34,6 +34,21 @@ def fill_deterministic(module, seed=0):
     return module
 
 
+RIG_KEYS = ("rots", "trans", "intrins", "post_rots", "post_trans")
+
+
+def pack_rig(rig, device):
+    """The five small rig tensors of a camera agent as VIEWS of one flat device tensor (`_rig`), so that loading a frame into
+    the static buffers of a captured graph is one copy for the rig instead of five."""
+    parts = [rig[k].to(torch.float32).reshape(-1) for k in RIG_KEYS]
+    flat = torch.cat(parts).to(device)
+    out, off = {"_rig": flat}, 0
+    for k, p in zip(RIG_KEYS, parts):
+        out[k] = flat[off:off + p.numel()].view(tuple(rig[k].shape))
+        off += p.numel()
+    return out
+
+
 class Scene:
     """Synthetic OPV2V-shaped scene resident on one device.  `modalities[k]` names agent k's sensor
     suite: LiDAR agents ('m1', 'm3') get a 64-line sweep, camera agents ('m2', 'm4') get four
@@ -52,7 +67,7 @@ class Scene:
                 H, W = self.CAMERA_DIMS[mod]
                 g = torch.Generator().manual_seed(seed * 1000 + k)
                 rig = synth.camera_rig(seed * 1000 + k, 4, H, W)
-                cam = {name: torch.from_numpy(v).to(self.device) for name, v in rig.items()}
+                cam = pack_rig({name: torch.from_numpy(v) for name, v in rig.items()}, self.device)
                 cam["imgs"] = torch.randn((4, 3, H, W), generator=g).to(self.device)
                 self.cameras[k] = cam
             else:
@@ -69,7 +84,9 @@ class Scene:
             mine = [a for a in agents if self.modalities[a] == mod]
             if mod in self.CAMERA_DIMS:
                 keys = ("imgs", "rots", "trans", "intrins", "post_rots", "post_trans")
-                out[f"inputs_{mod}"] = {k: torch.stack([self.cameras[a][k] for a in mine]) for k in keys}
+                # one agent of the modality: a view (no copy of the images); several: the reference's collated stack
+                out[f"inputs_{mod}"] = {k: (self.cameras[mine[0]][k].unsqueeze(0) if len(mine) == 1 else
+                                            torch.stack([self.cameras[a][k] for a in mine])) for k in keys}
             else:
                 out[f"inputs_{mod}"] = {"points": [self.points[a] for a in mine]}
         return out
@@ -108,9 +125,14 @@ class StaticInputs:
                 continue
             cap = max(1024, (int(int(p.shape[0]) * slack) + 1023) // 1024 * 1024)
             self.points[k] = torch.full((cap, 4), float("nan"), dtype=torch.float32, device=self.device)
+        self._n_points = {}
         for k, cam in scene.cameras.items():
             if k in keep:
-                self.cameras[k] = {name: torch.empty_like(t) for name, t in cam.items()}
+                if "_rig" in cam:   # rig tensors as views of one flat buffer: one copy per frame
+                    self.cameras[k] = pack_rig({name: torch.zeros_like(cam[name], device="cpu") for name in RIG_KEYS}, self.device)
+                    self.cameras[k]["imgs"] = torch.empty_like(cam["imgs"])
+                else:
+                    self.cameras[k] = {name: torch.empty_like(t) for name, t in cam.items()}
         self.pairwise = torch.empty(tuple(scene.pairwise.shape), dtype=torch.float64, device=self.device)
         self._pairwise_pinned = torch.empty(tuple(scene.pairwise.shape), dtype=torch.float64).pin_memory()
         self.load(scene)
@@ -127,11 +149,19 @@ class StaticInputs:
                 raise ValueError(f"agent {k}: {n} points exceed the static capacity {buf.shape[0]} of the captured graph "
                                  "(capture with a larger `slack`)")
             buf[:n].copy_(p, non_blocking=True)
-            if n < buf.shape[0]:
-                buf[n:].fill_(float("nan"))
+            prev = self._n_points.get(k, int(buf.shape[0]))   # rows >= prev already hold NaN points
+            if n < prev:
+                buf[n:prev].fill_(float("nan"))
+            self._n_points[k] = n
         for k, cam in self.cameras.items():
-            for name, t in cam.items():
-                t.copy_(scene.cameras[k][name], non_blocking=True)
+            src = scene.cameras[k]
+            if "_rig" in cam and "_rig" in src:
+                cam["_rig"].copy_(src["_rig"], non_blocking=True)
+                cam["imgs"].copy_(src["imgs"], non_blocking=True)
+            else:
+                for name, t in cam.items():
+                    if name != "_rig":
+                        t.copy_(src[name], non_blocking=True)
         pw = scene.pairwise
         if isinstance(pw, torch.Tensor) and pw.is_cuda:
             self.pairwise.copy_(pw.to(torch.float64), non_blocking=True)
