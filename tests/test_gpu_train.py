@@ -1,5 +1,9 @@
 """GPU twin of tests/test_train_path.py: the gradient path on the device, against the inference operators and
 through a training step whose LiDAR input goes through the K1 voxeliser."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +11,23 @@ import torch
 from tests.test_train_path import hetero_small, synthetic_targets
 
 pytestmark = [pytest.mark.gpu, pytest.mark.grad]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def in_fresh_process(test_name):
+    """Run one test of this file in its own interpreter.  The two tests that call backward() go through MIOpen's backward
+    convolutions (torch autograd on the gradient path; none of this repo's kernels run in them).  At the end of the full
+    `pytest -m gpu` session -- ~230 tests, a dozen captured graphs and their pools behind it -- one of those library kernels hit
+    `Memory access fault by GPU node` (an address on a 2 MiB segment boundary) in two consecutive full runs, while the same
+    tests pass alone and after any single test file.  A fault aborts the whole pytest process, so they are isolated: a fresh
+    process has a fresh allocator layout, and a fault there fails ONE test instead of killing the session."""
+    if os.environ.get("HEAL_TRAIN_TEST_INPROC") == "1":
+        return False
+    res = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::{test_name}", "-q", "-m", "gpu",
+                          "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env={**os.environ, "HEAL_TRAIN_TEST_INPROC": "1", "PYTHONPATH": ROOT})
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
+    return True
 
 
 def test_gradient_path_equals_inference_operators():
@@ -29,6 +50,8 @@ def test_gradient_path_equals_inference_operators():
 
 def test_training_steps_on_the_device():
     """train.py's iteration on the GPU: forward (gradient path), pyramid loss, backward, Adam -- finite and decreasing."""
+    if in_fresh_process("test_training_steps_on_the_device"):
+        return
     from heal_amd.opencood.tools.train_utils import create_loss
     hypes, model, data, _ = hetero_small("cuda")
     model.train()
@@ -52,6 +75,8 @@ def test_training_steps_on_the_device():
 def test_training_from_raw_point_clouds():
     """LiDAR agents given as device point clouds: K1 voxelises (no gradient into the points), the PFN / scatter / backbone /
     fusion run on the gradient path; the canvas equals the inference operator's (K2) for the same clouds."""
+    if in_fresh_process("test_training_from_raw_point_clouds"):
+        return
     from heal_amd import configs
     from heal_amd.opencood.tools.train_utils import create_model
     from heal_amd.pipeline import Scene
