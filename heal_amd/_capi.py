@@ -31,6 +31,7 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_float,
                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_bev_pool_backward": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p] * 6),
     "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),
     "heal_warp_agent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,

@@ -786,3 +786,88 @@ extern "C" int heal_bev_pool_pm(const float* head, int head_stride, const float*
     HEAL_LAUNCH_CHECK();
     return 0;
 }
+
+namespace heal {
+// ---- backward of the lift + splat (training) ----------------------------------------------------------------
+// Forward: out[cell(cam, d, v, u)][c] += p[cam, d, v, u] * f[cam, c, v, u],  p = softmax_d(logit[cam, :, v, u]).
+// Given G = dL/d out (re-laid cell-major [cells][C] by the caller so that a cell's gradient is one contiguous row):
+//     dL/df[c]      = sum_d p_d G[cell_d][c]
+//     dL/dlogit_d   = p_d (s_d - sum_d' p_d' s_d'),   s_d = sum_c f[c] G[cell_d][c]
+// One wave per image pixel: lanes hold the D logits (softmax by wave reductions) and C/64 feature channels each; the cell of
+// every depth bin comes from lss_cell_key -- the SAME fp32 arithmetic as the forward kernels, so forward and backward agree on
+// which cell a point belongs to; the D bins are walked with the row gather of bin d+1 independent of the reduction of bin d.
+__global__ __launch_bounds__(256) void k_lss_backward(const float* __restrict__ gcells, const float* __restrict__ depth_logit,
+                                                     const float* __restrict__ feat, const float* __restrict__ frustum,
+                                                     const CamMats* __restrict__ cams, LssGeom g,
+                                                     float* __restrict__ glogit, float* __restrict__ gfeat) {
+    constexpr int CPL = 4;                       // channels per lane (C <= 256)
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int HWf = g.fH * g.fW;
+    const long long pix = (long long)blockIdx.x * 4 + wave;
+    if (pix >= (long long)g.n_agents * g.n_cams * HWf) return;   // wave-uniform
+    const int bn = (int)(pix / HWf), vu = (int)(pix - (long long)bn * HWf);
+    const int v = vu / g.fW, u = vu - v * g.fW, b = bn / g.n_cams;
+    const float lg = l < g.D ? depth_logit[((size_t)bn * g.D + l) * HWf + vu] : -INFINITY;
+    const float mx = wave_max(lg);
+    const float e = l < g.D ? expf(lg - mx) : 0.f;
+    const float p = e / wave_sum(e);
+    uint32_t key = LSS_NOKEY;
+    if (l < g.D) key = lss_cell_key(cams[bn], frustum + ((size_t)(l * g.fH + v) * g.fW + u) * 3, g, b);
+    float f[CPL], gf[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = l + 64 * k;
+        f[k] = c < g.C ? feat[((size_t)bn * g.C + c) * HWf + vu] : 0.f;
+        gf[k] = 0.f;
+    }
+    float s_mine = 0.f;
+    for (int d = 0; d < g.D; ++d) {
+        const uint32_t kd = __shfl(key, d, 64);
+        if (kd == LSS_NOKEY) continue;               // wave-uniform
+        const float pd = __shfl(p, d, 64);
+        const float* __restrict__ row = gcells + (size_t)kd * g.C;
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = l + 64 * k;
+            const float gv = c < g.C ? row[c] : 0.f;
+            gf[k] = fmaf(pd, gv, gf[k]);
+            part = fmaf(f[k], gv, part);
+        }
+        const float s = wave_sum(part);
+        if (l == d) s_mine = s;
+    }
+    const float dot = wave_sum(p * s_mine);
+    if (l < g.D) glogit[((size_t)bn * g.D + l) * HWf + vu] = p * (s_mine - dot);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = l + 64 * k;
+        if (c < g.C) gfeat[((size_t)bn * g.C + c) * HWf + vu] = gf[k];
+    }
+}
+
+}  // namespace heal
+
+extern "C" int heal_bev_pool_backward(const float* grad_cells, const float* depth_logit, const float* feat,
+                                      const float* frustum, const float* cam_mats, int n_agents, int n_cams, int D, int fH,
+                                      int fW, int channels, const float* dx_host, const float* bx_host,
+                                      const int32_t* nx_host, float* grad_logit, float* grad_feat, void* stream) {
+    using namespace heal;
+    HEAL_REQUIRE(n_agents >= 1 && n_cams >= 1 && D >= 1 && D <= 64 && fH >= 1 && fW >= 1, "bev_pool_backward: bad shape (D <= 64)");
+    HEAL_REQUIRE(channels >= 1 && channels <= 256, "bev_pool_backward: channels must be in [1, 256] (got %d)", channels);
+    HEAL_REQUIRE(grad_cells && depth_logit && feat && frustum && cam_mats && grad_logit && grad_feat, "bev_pool_backward: null pointer");
+    LssGeom g;
+    for (int k = 0; k < 3; ++k) {
+        g.dx[k] = dx_host[k];
+        g.lo[k] = bx_host[k] - dx_host[k] / 2.f;
+        g.nx[k] = nx_host[k];
+        HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool_backward: empty grid");
+    }
+    g.n_agents = n_agents; g.n_cams = n_cams; g.D = D; g.fH = fH; g.fW = fW; g.C = channels;
+    const long long pixels = (long long)n_agents * n_cams * fH * fW;
+    HEAL_REQUIRE(pixels < (1ll << 31) - 8, "bev_pool_backward: problem too large");
+    k_lss_backward<<<(unsigned)((pixels + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        grad_cells, depth_logit, feat, frustum, reinterpret_cast<const CamMats*>(cam_mats), g, grad_logit, grad_feat);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

@@ -2,6 +2,8 @@
 PointPillar (:22-50), SECOND (:52-81), LiftSplatShoot (:83-241), LiftSplatShootVoxel (:244-301).
 Classes are discovered by name exactly as the reference does (heter_pyramid_collab.py:41-48).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -131,6 +133,26 @@ class SECOND(nn.Module):
         return batch_dict["spatial_features"]
 
 
+class _LiftPool(torch.autograd.Function):
+    """K4 with a hand-written backward: forward = heal_bev_pool (the inference kernels), backward = heal_bev_pool_backward
+    (one wave per image pixel gathers the cell gradients of its D depth bins).  Neither direction materialises the
+    [B,N,D,fH,fW,C] lifted tensor the reference's autograd keeps (0.3 GB per camera agent at BASELINE size)."""
+
+    @staticmethod
+    def forward(ctx, depth_logit, x_img, frustum, cam_mats, B, N, dx, bx, nx):
+        depth_logit, x_img = depth_logit.contiguous(), x_img.contiguous()
+        ctx.save_for_backward(depth_logit, x_img, frustum, cam_mats)
+        ctx.geom = (B, N, dx, bx, nx)
+        return ops.bev_pool(depth_logit, x_img, frustum, cam_mats, B, N, dx, bx, nx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        depth_logit, x_img, frustum, cam_mats = ctx.saved_tensors
+        B, N, dx, bx, nx = ctx.geom
+        g_logit, g_feat = ops.bev_pool_backward(grad_out.contiguous(), depth_logit, x_img, frustum, cam_mats, B, N, dx, bx, nx)
+        return g_logit, g_feat, None, None, None, None, None, None, None
+
+
 class LiftSplatShoot(nn.Module):
     """Camera agents: image trunk -> (depth logits, image features) -> fused lift + BEV pool (K4).
 
@@ -225,7 +247,13 @@ class LiftSplatShoot(nn.Module):
             items, depth_logit, x_img = self.camencode(x.view(B * N, C, imH, imW), pixel_major=False)
             if self.depth_supervision:
                 self.depth_items = items
-            out = self.lift_pool_autograd(depth_logit, x_img, inp, B, N)
+            if x.is_cuda and self.D <= 64 and self.camC <= 256 and os.environ.get("HEAL_K4_BACKWARD", "1") == "1":
+                with torch.no_grad():
+                    cam = self.camera_matrices(inp["rots"], inp["trans"], inp["intrins"], inp["post_rots"], inp["post_trans"])
+                out = _LiftPool.apply(depth_logit, x_img, self.frustum(x.device), cam, B, N, self.dx_host, self.bx_host,
+                                      self.nx_host)
+            else:   # any device: the torch composition (materialises the lifted tensor)
+                out = self.lift_pool_autograd(depth_logit, x_img, inp, B, N)
             nz = self.nx_host[2]
             if not self._pixel_major_pool and nz > 1:   # LiftSplatShootVoxel: max over the z bins
                 out = out.view(B, nz, self.camC, out.shape[2], out.shape[3]).max(dim=1)[0]

@@ -579,6 +579,30 @@ def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx)
     return out
 
 
+def bev_pool_backward(grad_out, depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
+    """Gradient of bev_pool with respect to (depth_logit, feat).  grad_out [n_agents, C*nz, ny, nx] -> (grad_logit, grad_feat)
+    with the shapes of depth_logit / feat."""
+    depth_logit = _need(depth_logit, torch.float32, "depth_logit")
+    feat = _need(feat, torch.float32, "feat")
+    frustum = _need(frustum, torch.float32, "frustum")
+    cam_mats = _need(cam_mats, torch.float32, "cam_mats")
+    BN, D, fH, fW = (int(v) for v in depth_logit.shape)
+    C = int(feat.shape[1])
+    nxi = [int(v) for v in nx]
+    if tuple(grad_out.shape) != (n_agents, C * nxi[2], nxi[1], nxi[0]) or tuple(frustum.shape) != (D, fH, fW, 3):
+        raise _capi.HealAmdError("bev_pool_backward: inconsistent shapes")
+    # cell-major rows: the gradient of one BEV cell is one contiguous row (the forward's scratch layout)
+    gcells = _need(grad_out.reshape(n_agents, nxi[2], C, nxi[1], nxi[0]).permute(0, 1, 3, 4, 2).contiguous().view(-1, C),
+                   torch.float32, "grad_out")
+    g_logit, g_feat = torch.empty_like(depth_logit), torch.empty_like(feat)
+    with _Timed("bev_pool_backward"):
+        _capi.call("heal_bev_pool_backward", _ptr(gcells), _ptr(depth_logit), _ptr(feat), _ptr(frustum), _ptr(cam_mats),
+                   n_agents, n_cams, D, fH, fW, C, _host_array([float(v) for v in dx], ctypes.c_float),
+                   _host_array([float(v) for v in bx], ctypes.c_float), _host_array(nxi, ctypes.c_int32),
+                   _ptr(g_logit), _ptr(g_feat), _stream())
+    return g_logit, g_feat
+
+
 # ------------------------------------------------------------------------------------------------ K3
 def _i3(v):
     return _host_array([int(x) for x in v], ctypes.c_int32)

@@ -246,6 +246,17 @@ int heal_sp_to_bev(const float* features, const int32_t* indices, int n, int cha
                    const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes,
                    const int32_t* n_dev, void* stream);
 
+/* heal_bev_pool_backward: gradient of heal_bev_pool / heal_bev_pool_pm with respect to the depth logits and the image
+ *   features (training; the autograd of get_geometry + softmax + voxel_pooling, heter_encoders.py:125-217, without materialising
+ *   the [B,N,D,fH,fW,C] lifted tensor).  grad_cells [n_agents*nz*ny*nx, C]: the output gradient re-laid CELL-MAJOR (row =
+ *   b*cells + (iz*ny + iy)*nx + ix, the forward's cell key; channel c of row <-> output channel iz*C + c); depth_logit / feat /
+ *   frustum / cam_mats / dx / bx / nx as in heal_bev_pool (D <= 64, C <= 256).  -> grad_logit [n_agents*n_cams,D,fH,fW],
+ *   grad_feat [n_agents*n_cams,C,fH,fW], every element written.  Cells come from the same fp32 arithmetic as the forward.  */
+int heal_bev_pool_backward(const float* grad_cells, const float* depth_logit, const float* feat, const float* frustum,
+                           const float* cam_mats, int n_agents, int n_cams, int D, int fH, int fW, int channels,
+                           const float* dx_host, const float* bx_host, const int32_t* nx_host, float* grad_logit,
+                           float* grad_feat, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K6  per-pixel multi-head attention over agents.
  * Replaces: opencood/models/sub_modules/hmsa.py:110-151 (HGTCavAttention attention core, relation

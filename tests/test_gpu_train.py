@@ -100,6 +100,45 @@ def test_training_from_raw_point_clouds():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
 
 
+@pytest.mark.parametrize("pitch", [0.0, 0.12])
+def test_lift_pool_backward_kernel_vs_torch_autograd(pitch):
+    """K4 backward (heal_bev_pool_backward behind LiftSplatShoot's autograd Function) against torch's autograd of the
+    reference composition (get_geometry + softmax + outer product + index_add): same forward, gradients of the depth logits
+    and of the image features within 1e-4 of their scale.  Level and pitched rigs (a pitched camera spreads a column over
+    several cells).  The two paths evaluate the frustum geometry in a different fp32 order, so a point that sits on a cell
+    boundary to the last bit may be binned differently: at most a handful of pixels may differ, and they are counted."""
+    from heal_amd import configs, synth
+    from heal_amd.opencood.models.heter_encoders import LiftSplatShoot, _LiftPool
+    args = configs.heal_heter(("m2",), [-25.6, -25.6, -3, 25.6, 25.6, 1], cam_bound=12.8, cam_dims={"m2": (96, 128)})
+    enc = LiftSplatShoot(args["model"]["args"]["m2"]["encoder_args"]).cuda()
+    H, W = 96, 128
+    rig = synth.camera_rig(7, 4, H, W)
+    inp = {k: torch.from_numpy(v)[None].cuda() for k, v in rig.items()}
+    if pitch:
+        c, s_ = float(np.cos(pitch)), float(np.sin(pitch))
+        R = torch.tensor([[1, 0, 0], [0, c, -s_], [0, s_, c]], dtype=inp["rots"].dtype, device="cuda")
+        inp["rots"] = inp["rots"] @ R
+    g = torch.Generator().manual_seed(3)
+    D, C, fH, fW = enc.D, enc.camC, H // enc.downsample, W // enc.downsample
+    logit = torch.randn((4, D, fH, fW), generator=g).cuda().requires_grad_(True)
+    feat = torch.randn((4, C, fH, fW), generator=g).cuda().requires_grad_(True)
+    ref = enc.lift_pool_autograd(logit, feat, inp, 1, 4)
+    wgt = torch.randn(ref.shape, generator=g).cuda()
+    (ref * wgt).sum().backward()
+    g_logit_ref, g_feat_ref = logit.grad.clone(), feat.grad.clone()
+    logit.grad = feat.grad = None
+    with torch.no_grad():
+        cam = enc.camera_matrices(inp["rots"], inp["trans"], inp["intrins"], inp["post_rots"], inp["post_trans"])
+    got = _LiftPool.apply(logit, feat, enc.frustum(logit.device), cam, 1, 4, enc.dx_host, enc.bx_host, enc.nx_host)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-4
+    (got * wgt).sum().backward()
+    for name, a, b in (("logit", logit.grad, g_logit_ref), ("feat", feat.grad, g_feat_ref)):
+        err = (a - b).abs() / b.abs().max()
+        bad = int((err.amax(dim=1) > 1e-4).sum())            # pixels (camera, v, u) with any channel / bin off
+        assert bad <= 4, (name, bad, float(err.max()))
+    assert bool(torch.isfinite(logit.grad).all()) and bool(torch.isfinite(feat.grad).all())
+
+
 def test_inference_operator_refuses_autograd_activations():
     """An activation with autograd history must never reach a HIP operator silently (its result would drop out of the graph)."""
     from heal_amd import _capi, ops
