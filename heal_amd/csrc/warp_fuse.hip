@@ -261,6 +261,83 @@ __global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ 
     }
 }
 
+// ---- backward of the fused warp + softmax-weighted sum (training) ------------------------------------------
+// out[c,p] = sum_a w_a(p) X_a[c](p),  X_a[c](p) = sum_k t_ak(p) x[a,c,off_ak],  w = masked softmax_a(S_a),
+// S_a(p) = sum_k t_ak(p) s_a[off_ak],  s = (sigmoid(occ) + 1e-4) * crop.  One thread per ego pixel, all channels:
+//   dL/dx[a,c,off_ak] += G[c,p] w_a t_ak                       (fp32 atomics: several ego pixels share a source pixel)
+//   dL/dS_a = w_a (q_a - sum_b w_b q_b),  q_a = sum_c G[c,p] X_a[c](p)     (masked agents have w = 0: no gradient)
+//   dL/docc[a,off_ak] += dL/dS_a t_ak sg (1 - sg) inside the crop window,  sg = sigmoid(occ).
+// grad_feats / grad_occ must be zero on entry.  Same sampling arithmetic as the forward (make_taps, grid dtype).
+template <int NA>
+__global__ __launch_bounds__(256) void k_warp_fuse_backward(const float* __restrict__ feats, const float* __restrict__ occ,
+                                                           WarpParams p, const float* __restrict__ gout,
+                                                           float* __restrict__ gfeats, float* __restrict__ gocc) {
+    const int w = blockIdx.x * WF_TW + (threadIdx.x & (WF_TW - 1));
+    const int h = blockIdx.y * WF_TH + (threadIdx.x / WF_TW);
+    if (w >= p.W || h >= p.H) return;
+    const int HW = p.H * p.W, pix = h * p.W + w;
+    int off[NA][4];
+    float tw[NA][4];
+    float prob[WF_MAXA], q[NA];
+#pragma unroll
+    for (int a = NA; a < WF_MAXA; ++a) prob[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        float gx, gy;
+        double m[6];
+        load_affine(p, a, m);
+        if (p.grid_f64) grid_point<double>(m, h, w, p.H, p.W, gx, gy);
+        else grid_point<float>(m, h, w, p.H, p.W, gx, gy);
+        const Taps t = make_taps(gx, gy, p.H, p.W);
+        prob[a] = sample_score(occ + (size_t)a * HW, t, p.W, p.crop[a]);
+        const int o4[4] = {t.off, t.off + 1, t.off + p.W, t.off + p.W + 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = (t.ok >> k) & 1u;
+            off[a][k] = ok ? o4[k] : -1;
+            tw[a][k] = ok ? t.w[k] : 0.f;
+        }
+        q[a] = 0.f;
+    }
+    agent_softmax(prob, NA);
+    for (int c = 0; c < p.C; ++c) {
+        const float g = gout[(size_t)c * HW + pix];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const size_t base = ((size_t)a * p.C + c) * HW;
+            float x = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (off[a][k] >= 0) {
+                    x += feats[base + off[a][k]] * tw[a][k];
+                    const float d = g * prob[a] * tw[a][k];
+                    if (d != 0.f) unsafeAtomicAdd(gfeats + base + off[a][k], d);
+                }
+            q[a] = fmaf(g, x, q[a]);
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) dot = fmaf(prob[a], q[a], dot);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const float dS = prob[a] * (q[a] - dot);
+        if (dS == 0.f) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (off[a][k] < 0) continue;
+            const int idx = off[a][k];
+            const int* crop = p.crop[a];
+            if (crop[1] > crop[0]) {
+                const int hh = idx / p.W, ww = idx - hh * p.W;
+                if (hh < crop[0] || hh >= crop[1] || ww < crop[2] || ww >= crop[3]) continue;
+            }
+            const float sg = 1.f / (1.f + expf(-occ[(size_t)a * HW + idx]));
+            unsafeAtomicAdd(gocc + (size_t)a * HW + idx, dS * tw[a][k] * sg * (1.f - sg));
+        }
+    }
+}
+
 static int fill_params(WarpParams& p, int n_agents, int C, int H, int W, const double* affine_host,
                        const double* affine_dev, int grid_f64, const int32_t* crop_host) {
     HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "warp_fuse: n_agents must be in [1,%d] (got %d)",
@@ -324,6 +401,24 @@ extern "C" int heal_fuse_warped(const float* feats_ego, const float* scores_ego,
     k_fuse_warped<<<grid, 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const float4*>(feats_ego), reinterpret_cast<const float4*>(scores_ego), n_agents,
         channels, HW4, reinterpret_cast<float4*>(out));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_warp_fuse_backward(const float* feats, const float* occ, int n_agents, int channels, int H, int W,
+                                       const double* affine_host, const double* affine_dev, int grid_f64,
+                                       const int32_t* crop_host, const float* grad_out, float* grad_feats, float* grad_occ,
+                                       void* stream) {
+    WarpParams p;
+    if (fill_params(p, n_agents, channels, H, W, affine_host, affine_dev, grid_f64, crop_host)) return 1;
+    HEAL_REQUIRE(feats && occ && grad_out && grad_feats && grad_occ, "warp_fuse_backward: null pointer");
+    dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH));
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_agents) {
+#define HEAL_WFB(N) case N: k_warp_fuse_backward<N><<<grid, 256, 0, st>>>(feats, occ, p, grad_out, grad_feats, grad_occ); break;
+        HEAL_WFB(1) HEAL_WFB(2) HEAL_WFB(3) HEAL_WFB(4) HEAL_WFB(5) HEAL_WFB(6) HEAL_WFB(7) HEAL_WFB(8)
+#undef HEAL_WFB
+    }
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -42,13 +42,35 @@ def weighted_fuse_autograd(x, occ, record_len, affine_matrix, crops=None):
     return torch.stack(out)
 
 
+class _WarpFuse(torch.autograd.Function):
+    """K5 with a hand-written backward: forward = heal_warp_fuse, backward = heal_warp_fuse_backward (one thread per ego pixel
+    re-samples every agent, scatters the map gradient through the bilinear taps and pushes the softmax gradient back to the
+    occupancy logits).  The warped [n,C,H,W] stack of the reference's autograd is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, occ, rows, grid_f64, crop):
+        x, occ = x.contiguous(), occ.contiguous()
+        ctx.save_for_backward(x, occ)
+        ctx.args = (rows, grid_f64, crop)
+        return ops.warp_fuse(x, occ, rows, grid_f64, crop)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, occ = ctx.saved_tensors
+        rows, grid_f64, crop = ctx.args
+        g_x, g_occ = ops.warp_fuse_backward(x, occ, rows, grad_out.contiguous(), grid_f64, crop)
+        return g_x, g_occ, None, None, None
+
+
 def weighted_fuse(x, occ, record_len, affine_matrix, grid_f64=True, crops=None):
     """pyramid_fuse.py:17-63 with the score construction folded in.
 
     x [sum(n),C,H,W]; occ [sum(n),1,H,W] occupancy LOGITS; record_len: list of ints;
     affine_matrix: host numpy [B,L,L,2,3]; crops: per-agent (h0,h1,w0,w1) or None."""
-    if torch.is_grad_enabled() and (x.requires_grad or occ.requires_grad):
-        return weighted_fuse_autograd(x, occ, record_len, affine_matrix, crops)
+    import os
+    grad = torch.is_grad_enabled() and (x.requires_grad or occ.requires_grad)
+    if grad and not (x.is_cuda and os.environ.get("HEAL_K5_BACKWARD", "1") == "1"):
+        return weighted_fuse_autograd(x, occ, record_len, affine_matrix, crops)   # any device: torch operators
     out = []
     start = 0
     for b, n in enumerate(record_len):
@@ -56,7 +78,10 @@ def weighted_fuse(x, occ, record_len, affine_matrix, grid_f64=True, crops=None):
         crop = None
         if crops is not None:
             crop = [crops[start + a] if crops[start + a] is not None else (0, 0, 0, 0) for a in range(n)]
-        out.append(ops.warp_fuse(x[start:start + n], occ[start:start + n], rows, grid_f64, crop))
+        if grad:   # training on the device: the HIP kernels in both directions
+            out.append(_WarpFuse.apply(x[start:start + n], occ[start:start + n], rows, grid_f64, crop))
+        else:
+            out.append(ops.warp_fuse(x[start:start + n], occ[start:start + n], rows, grid_f64, crop))
         start += n
     return out[0].unsqueeze(0) if len(out) == 1 else torch.stack(out)   # (one scene: no copy)
 

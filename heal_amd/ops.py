@@ -299,6 +299,21 @@ def warp_fuse(feats, occ, affine_rows, grid_f64=True, crop=None):
     return out
 
 
+def warp_fuse_backward(feats, occ, affine_rows, grad_out, grid_f64=True, crop=None):
+    """Gradient of warp_fuse with respect to (feats, occ): grad_out [C,H,W] -> ([n,C,H,W], [n,1,H,W])."""
+    feats = _need(feats, torch.float32, "feats")
+    occ = _need(occ, torch.float32, "occ")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    n, C, H, W = (int(v) for v in feats.shape)
+    g_feats, g_occ = torch.zeros_like(feats), torch.zeros_like(occ)
+    a, ap, adev = _affine_args(affine_rows, n)
+    c, cp = _crop_host(crop, n)
+    with _Timed(f"warp_fuse_backward_c{C}"):
+        _capi.call("heal_warp_fuse_backward", _ptr(feats), _ptr(occ), n, C, H, W, ap, adev, int(bool(grid_f64)), cp,
+                   _ptr(grad_out), _ptr(g_feats), _ptr(g_occ), _stream())
+    return g_feats, g_occ
+
+
 def warp_agent(feat, occ, affine_row, grid_f64=True, crop=None):
     """K5 split, rank-local half: feat [C,H,W], occ [1,H,W] -> (feat_ego [C,H,W], score_ego [1,H,W])."""
     feat = _need(feat, torch.float32, "feat")

@@ -122,6 +122,14 @@ int heal_warp_fuse(const float* feats, const float* occ, int n_agents, int chann
                    const double* affine_host, const double* affine_dev, int grid_f64,
                    const int32_t* crop_host, float* out, void* stream);
 
+/* heal_warp_fuse_backward: gradient of heal_warp_fuse with respect to the agents' maps and occupancy logits (training; the
+ *   autograd of warp_affine_simple x 2 + masked softmax + weighted sum, pyramid_fuse.py:17-63,145-162).  Arguments as
+ *   heal_warp_fuse plus grad_out [C,H,W]; grad_feats [n_agents,C,H,W] and grad_occ [n_agents,1,H,W] must be ZERO on entry
+ *   (bilinear taps of several ego pixels add into one source pixel: fp32 atomics).                                   */
+int heal_warp_fuse_backward(const float* feats, const float* occ, int n_agents, int channels, int H, int W,
+                            const double* affine_host, const double* affine_dev, int grid_f64, const int32_t* crop_host,
+                            const float* grad_out, float* grad_feats, float* grad_occ, void* stream);
+
 /* Same operator split for agent-sharded execution: warp ONE agent's features and score
  * into the ego frame (rank-local, before the all-gather) ...                                      */
 int heal_warp_agent(const float* feat, const float* occ, int channels, int H, int W,

@@ -139,6 +139,39 @@ def test_lift_pool_backward_kernel_vs_torch_autograd(pitch):
     assert bool(torch.isfinite(logit.grad).all()) and bool(torch.isfinite(feat.grad).all())
 
 
+@pytest.mark.parametrize("n,f64,with_crop", [(5, True, False), (3, False, True), (1, True, False)])
+def test_warp_fuse_backward_kernel_vs_torch_autograd(n, f64, with_crop):
+    """K5 backward (heal_warp_fuse_backward behind the autograd Function of weighted_fuse) against torch's autograd of the
+    reference composition (affine_grid + grid_sample x 2, masked softmax over agents, weighted sum): gradients of the agents'
+    maps and of the occupancy logits within 1e-4 of their scale; rotated / translated poses, an agent out of view, crops."""
+    from heal_amd.opencood.models.fuse_modules.pyramid_fuse import weighted_fuse, weighted_fuse_autograd
+    g = np.random.default_rng(50 + n)
+    C, H, W = 24, 40, 36
+    x = torch.from_numpy(g.standard_normal((n, C, H, W)).astype(np.float32)).cuda().requires_grad_(True)
+    occ = torch.from_numpy((g.standard_normal((n, 1, H, W)) * 2).astype(np.float32)).cuda().requires_grad_(True)
+    rows = np.zeros((1, n, n, 2, 3))
+    for a in range(n):
+        th = 0.0 if a == 0 else g.uniform(-np.pi, np.pi)
+        rows[0, 0, a] = [[np.cos(th), -np.sin(th), 0.0 if a == 0 else g.uniform(-0.7, 0.7)],
+                         [np.sin(th), np.cos(th), 0.0 if a == 0 else g.uniform(-0.7, 0.7)]]
+    if n > 2:
+        rows[0, 0, n - 1, :, 2] = [4.0, -3.0]
+    if not f64:
+        rows = rows.astype(np.float32)
+    crops = [None if a % 2 == 0 else (H // 4, 3 * H // 4, W // 5, 4 * W // 5) for a in range(n)] if with_crop else None
+    wgt = torch.from_numpy(g.standard_normal((1, C, H, W)).astype(np.float32)).cuda()
+    ref = weighted_fuse_autograd(x, occ, [n], rows, crops)
+    (ref * wgt).sum().backward()
+    gx_ref, go_ref = x.grad.clone(), occ.grad.clone()
+    x.grad = occ.grad = None
+    got = weighted_fuse(x, occ, [n], rows, grid_f64=f64, crops=crops)
+    assert got.requires_grad and float((got - ref).abs().max() / ref.abs().max()) < 1e-4
+    (got * wgt).sum().backward()
+    assert float((x.grad - gx_ref).abs().max() / gx_ref.abs().max()) < 1e-4
+    # one agent: the softmax is constant, the logits get no gradient at all (in either implementation)
+    assert float((occ.grad - go_ref).abs().max()) <= 1e-4 * float(go_ref.abs().max())
+
+
 def test_inference_operator_refuses_autograd_activations():
     """An activation with autograd history must never reach a HIP operator silently (its result would drop out of the graph)."""
     from heal_amd import _capi, ops
