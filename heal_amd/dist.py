@@ -123,10 +123,9 @@ class _Sharded:
         if not mine:
             return None, mine
         mods = scene_input["agent_modality_list"]
-        feats = {}
-        for mod in m.modality_name_list:
-            if f"inputs_{mod}" in local_inputs:
-                feats[mod] = m.encode_modality(local_inputs, mod)
+        from heal_amd.opencood.models._heter_common import encode_modalities
+        present = {mod for mod in m.modality_name_list if f"inputs_{mod}" in local_inputs}
+        feats = encode_modalities(m, local_inputs, present, m.encode_modality)   # own modalities on concurrent streams
         cursor = {k: 0 for k in feats}
         parts = []
         for a in mine:
