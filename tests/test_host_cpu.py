@@ -481,3 +481,40 @@ def test_deferred_validation_labels_are_not_zeroed_without_the_inference_switch(
     inf = vp.VoxelPostprocessor(dict(hy["postprocess"], defer_to_device=True, inference_only=True), train=False)
     out = inf.generate_label(gt_box_center=gt, anchors=anchors, mask=mask)
     assert float(np.abs(out["pos_equal_one"]).sum()) == 0 and out["targets"].shape[-1] == 14
+
+
+def test_pack_rig_views_share_one_buffer():
+    """pipeline.pack_rig: the five rig tensors of a camera agent are views of ONE flat tensor, so loading a frame into the
+    static buffers of a captured graph is one copy for the rig; values and shapes are those of the separate tensors."""
+    from heal_amd import synth
+    from heal_amd.pipeline import RIG_KEYS, pack_rig
+    rig = {k: torch.from_numpy(v) for k, v in synth.camera_rig(3, 4, 96, 128).items()}
+    packed = pack_rig(rig, "cpu")
+    flat = packed["_rig"]
+    assert flat.dim() == 1 and flat.numel() == sum(rig[k].numel() for k in RIG_KEYS)
+    for k in RIG_KEYS:
+        assert packed[k].shape == rig[k].shape and torch.equal(packed[k], rig[k].float())
+        assert packed[k].data_ptr() >= flat.data_ptr() and packed[k].data_ptr() < flat.data_ptr() + 4 * flat.numel()
+    other = pack_rig({k: torch.zeros_like(v) for k, v in rig.items()}, "cpu")
+    other["_rig"].copy_(flat)                                   # what StaticInputs.load does
+    assert all(torch.equal(other[k], packed[k]) for k in RIG_KEYS)
+
+
+def test_grad_path_switch():
+    """bev_blocks.grad_path: off under no_grad whatever the module state; on with autograd when the input carries gradient, a
+    module trains, or a module has trainable parameters (a frozen eval-mode block with a gradient-free input stays on the
+    inference operators)."""
+    import torch.nn as nn
+    from heal_amd.opencood.models.sub_modules.bev_blocks import grad_path
+    conv = nn.Conv2d(4, 4, 1)
+    x = torch.zeros(1, 4, 2, 2)
+    with torch.no_grad():
+        assert not grad_path(x, conv) and not grad_path(x.requires_grad_(False), conv.train())
+    with torch.enable_grad():
+        conv.eval()
+        assert grad_path(x, conv)                                # trainable parameters
+        for p in conv.parameters():
+            p.requires_grad_(False)
+        assert not grad_path(x, conv)                            # frozen, eval, input without gradient
+        assert grad_path(x.clone().requires_grad_(True), conv)   # gradient flows through
+        assert grad_path(x, conv.train())                        # training mode (BatchNorm statistics etc.)
