@@ -3,6 +3,9 @@ import numpy as np
 import torch
 
 
+_NORM_CONSTS = {}
+
+
 def normalize_pairwise_tfm(pairwise_t_matrix, H, W, discrete_ratio, downsample_rate=1):
     """transformation_utils.py:68-92 -- [B,L,L,4,4] -> [B,L,L,2,3] for F.affine_grid; dtype kept
     (float64 when the matrix comes from the dataset's numpy array).  Accepts torch or numpy."""
@@ -11,6 +14,18 @@ def normalize_pairwise_tfm(pairwise_t_matrix, H, W, discrete_ratio, downsample_r
         # stream capture does not permit: the device-resident pose matrix is normalised inside the captured graph)
         t = pairwise_t_matrix
         a = torch.cat([t[..., 0:2, 0:2], t[..., 0:2, 3:4]], dim=-1)
+        if t.is_cuda:
+            # the four element updates below as THREE broadcast operations with constant [2,3] tensors -- (a * m1) / d * m2, the
+            # reference's operation order element by element (x*1, x/1 are exact) -- instead of a dozen slice kernels at the head
+            # of every captured step.  The constants are cached per (shape, dtype, device); the first (eager) call creates them.
+            key = (int(H), int(W), float(discrete_ratio), float(downsample_rate), t.dtype, t.device)
+            c = _NORM_CONSTS.get(key)
+            if c is None:
+                kw, kh = downsample_rate * discrete_ratio * W, downsample_rate * discrete_ratio * H
+                mk = lambda rows: torch.tensor(rows, dtype=t.dtype, device=t.device)   # noqa: E731
+                c = (mk([[1.0, H, 1.0], [W, 1.0, 1.0]]), mk([[1.0, W, kw], [H, 1.0, kh]]), mk([[1.0, 1.0, 2.0], [1.0, 1.0, 2.0]]))
+                _NORM_CONSTS[key] = c
+            return a * c[0] / c[1] * c[2]
     else:
         a = np.asarray(pairwise_t_matrix)[:, :, :, [0, 1], :][:, :, :, :, [0, 1, 3]].copy()
     a[..., 0, 1] = a[..., 0, 1] * H / W
