@@ -80,6 +80,7 @@ _SIGNATURES = {
     "heal_conv1x1": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p]),
     "heal_conv1x1_d2s": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_void_p]),
     "heal_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_void_p]),
+    "heal_conv3x3_same": (c_int, [c_void_p] * 3 + [c_int] * 11 + [c_void_p, c_void_p]),
     "heal_grouped16_conv3x3": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p]),
     "heal_grouped_small_conv3x3": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_void_p]),
     "heal_conv3x3_winograd": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_void_p]),

@@ -56,7 +56,11 @@ template <int STRIDE, int TH>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 int Cin, int nchunks, int Cout, int H, int W, int Ho, int Wo,
-                                                int tiles_x, int tiles_y, int relu, float* __restrict__ y) {
+                                                int tiles_x, int tiles_y, int relu, int pad_t, int pad_l,
+                                                float* __restrict__ y) {
+    // relu: 0 none | 1 ReLU | 2 SiLU.  pad_t / pad_l: zero rows / columns in front of the map (1 = the symmetric padding of
+    // the BEV stacks; 0 = TensorFlow-style "same" padding of a stride-2 convolution on an even map, which pads only behind:
+    // the EfficientNet stem); what lies behind the map is zero through the bounds test either way.
     using G = C3Geom<STRIDE, TH>;
     constexpr int NT = G::NT, PH = G::PH, PW = G::PW, PE = G::PE, CS = G::CS, NP = G::NP, NW = G::NW;
     static_assert(CS >= PE, "bad patch stride");
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, co
     const int mb = bk.x, n = bk.z;
     const int ty = bk.y / tiles_x, tx = bk.y - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * G::TW;
-    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
     const size_t HWin = (size_t)H * W;
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, co
                 float v = acc[mt][nt][r] + (bias ? bias[co] : 0.f);
                 const size_t o = (size_t)co * HWo + pix;
                 if (rin) v += rin[o];
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu == 1) v = fmaxf(v, 0.f);
+                else if (relu == 2) v = v / (1.f + expf(-v));
                 yout[o] = v;
             }
         }
@@ -528,13 +533,13 @@ __global__ __launch_bounds__(256) void k_grouped16_conv3x3(const float* __restri
 
 using namespace heal;
 
-extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
-                            int cin, int cout, int H, int W, int stride, int relu, float* y, void* stream) {
+static int conv3x3_launch(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
+                          int cin, int cout, int H, int W, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu,
+                          float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv3x3: bad shape");
     HEAL_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2 (got %d)", stride);
     HEAL_REQUIRE(x && weight_frag && y, "conv3x3: null pointer");
     HEAL_REQUIRE(((uintptr_t)weight_frag & 15) == 0, "conv3x3: weight fragments must be 16-B aligned");
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int nchunks = (cin + C3_KC - 1) / C3_KC, mblocks = (cout + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
     // Tile height (measured, scripts/conv3x3_bench.py): the kernel is barrier-bound at 2 waves per SIMD, so more, smaller
@@ -552,7 +557,7 @@ extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const floa
     const dim3 grid(mblocks, tiles_x * tiles_y, n);
 #define HEAL_C3(ST_, TH_)                                                                                          \
     k_conv3x3<ST_, TH_><<<grid, 256, 0, s>>>(x, weight_frag, bias, residual, cin, nchunks, cout, H, W, Ho, Wo,     \
-                                             tiles_x, tiles_y, relu, y)
+                                             tiles_x, tiles_y, relu, pad_t, pad_l, y)
     if (stride == 1 && th == 16) HEAL_C3(1, 16);
     else if (stride == 1 && th == 8) HEAL_C3(1, 8);
     else if (stride == 1) HEAL_C3(1, 4);
@@ -563,6 +568,22 @@ extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const floa
     return 0;
 }
 
+
+extern "C" int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n,
+                            int cin, int cout, int H, int W, int stride, int relu, float* y, void* stream) {
+    HEAL_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2 (got %d)", stride);
+    return conv3x3_launch(x, weight_frag, bias, residual, n, cin, cout, H, W, stride, 1, 1, (H + 2 - 3) / stride + 1,
+                          (W + 2 - 3) / stride + 1, relu ? 1 : 0, y, stream);
+}
+
+extern "C" int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bias, int n, int cin, int cout, int H,
+                                 int W, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y, void* stream) {
+    HEAL_REQUIRE((pad_t == 0 || pad_t == 1) && (pad_l == 0 || pad_l == 1), "conv3x3_same: leading padding must be 0 or 1");
+    HEAL_REQUIRE(act >= 0 && act <= 2, "conv3x3_same: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
+    HEAL_REQUIRE(Ho >= 1 && Wo >= 1 && (Ho - 1) * stride + 3 - pad_t <= H + 1 && (Wo - 1) * stride + 3 - pad_l <= W + 1,
+                 "conv3x3_same: output %dx%d needs more than one trailing padding row / column", Ho, Wo);
+    return conv3x3_launch(x, weight_frag, bias, nullptr, n, cin, cout, H, W, stride, pad_t, pad_l, Ho, Wo, act, y, stream);
+}
 
 extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
                                      int cin, int cout, int H, int W, int relu, int waves, float* y, void* stream) {

@@ -88,6 +88,10 @@ def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None, channel_sums
         from heal_amd import ops
         return ops.depthwise_conv(x.contiguous(), w, b, conv.stride[0], conv.same_pad, "silu" if act else "none",
                                   channel_sums=channel_sums)
+    if (x.is_cuda and conv.groups == 1 and conv.kernel_size == (3, 3) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and conv.same_pad[0] in (0, 1) and conv.same_pad[2] in (0, 1) and conv.same_pad[1] <= 1 and conv.same_pad[3] <= 1):
+        from heal_amd import ops   # the 3x3 / stride-2 stem: "same" padding, bias and SiLU in the convolution's own epilogue
+        return ops.conv3x3_same(x.contiguous(), w, b, conv.stride[0], conv.same_pad, "silu" if act else "none")
     if any(conv.same_pad):
         x = F.pad(x, conv.same_pad)
     y = F.conv2d(x, w, b, conv.stride, 0, 1, conv.groups)

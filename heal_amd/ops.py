@@ -972,6 +972,24 @@ def conv3x3_fragments(w):
     return hit[0]
 
 
+def conv3x3_same(x, w, bias, stride, pad, act="none"):
+    """Dense 3x3 convolution with explicit (left, right, top, bottom) zero padding where left / top are 0 | 1 and right / bottom
+    at most 1 (TF-style "same" padding of the EfficientNet stem), bias and none | relu | silu fused.  x [n,Cin,H,W]."""
+    x = _need(x, torch.float32, "x")
+    n, cin, H, W = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    pl, pr, pt, pb = (int(v) for v in pad)
+    Ho, Wo = (H + pt + pb - 3) // stride + 1, (W + pl + pr - 3) // stride + 1
+    if pl not in (0, 1) or pt not in (0, 1) or pr > 1 or pb > 1 or tuple(w.shape[1:]) != (cin, 3, 3):
+        raise _capi.HealAmdError(f"conv3x3_same: unsupported padding {pad} / weight {tuple(w.shape)}")
+    frag = conv3x3_fragments(w)
+    y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    with _Timed(f"conv3x3_{cin}_{cout}_s{stride}same", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
+        _capi.call("heal_conv3x3_same", _ptr(x), _ptr(frag), _ptr(_need(bias, torch.float32, "bias")) if bias is not None else None,
+                   n, cin, cout, H, W, int(stride), pt, pl, Ho, Wo, {"none": 0, "relu": 1, "silu": 2}[act], _ptr(y), _stream())
+    return y
+
+
 _FRAGW_CACHE = {}
 
 

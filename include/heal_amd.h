@@ -356,6 +356,14 @@ int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, co
                  const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
                  int out_pixel_major, float* y, void* stream);
 
+/* heal_conv3x3_same: heal_conv3x3 with the zero padding given as (pad_t, pad_l) rows / columns IN FRONT of the map (0 | 1) and
+ *   whatever the output size needs behind it (at most one): TensorFlow-style "same" padding, which for a stride-2 convolution on
+ *   an even map pads only behind -- the 3x3 / stride-2 stem of the EfficientNet-b0 camera trunk (efficientnet_pytorch
+ *   Conv2dStaticSamePadding as used by lss_submodule.py:58-60) -- with bias and activation (0 none | 1 ReLU | 2 SiLU) fused.
+ *   Same weight fragment layout as heal_conv3x3.                                                                        */
+int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bias, int n, int cin, int cout, int H, int W,
+                      int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y, void* stream);
+
 /* heal_conv1x1_d2s: heal_conv1x1 (stride 1, no residual / gate) whose epilogue writes DEPTH-TO-SPACE INTO A CHANNEL SLICE of a
  *   wider NCHW tensor: output channel co of pixel (h, w) goes to channel dst_channel_offset + co / k^2, pixel
  *   (h k + (co % k^2) / k, w k + co % k) of y [n, dst_channels, H k, W k].  This is the deblock of the BEV backbones --

@@ -852,6 +852,25 @@ def test_conv1x1_rejects_unsupported_shapes():
         ops.conv1x1(torch.randn((1, 64, 8, 8)).cuda(), torch.randn((24, 32, 1, 1)).cuda())
 
 
+@pytest.mark.parametrize("n,cin,cout,H,W,stride,pad,act", [
+    (4, 3, 32, 96, 128, 2, (0, 1, 0, 1), "silu"), (2, 3, 32, 97, 63, 2, (1, 1, 1, 1), "silu"), (1, 16, 24, 20, 28, 1, (1, 1, 1, 1), "none"),
+    (2, 5, 70, 18, 22, 2, (0, 1, 1, 1), "relu")])
+def test_conv3x3_same_padding_vs_torch(n, cin, cout, H, W, stride, pad, act):
+    """heal_conv3x3_same: TF-style "same" padding (only behind the map for a stride-2 convolution on an even map -- the
+    EfficientNet stem), bias and SiLU / ReLU fused, against torch's F.pad + conv2d in fp64."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(cin * 31 + cout)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    F = torch.nn.functional
+    ref = F.conv2d(F.pad(x.double(), pad), w.double(), b.double(), stride)
+    ref = F.silu(ref) if act == "silu" else torch.relu(ref) if act == "relu" else ref
+    got = ops.conv3x3_same(x, w, b, stride, pad, act)
+    assert got.shape == ref.shape
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
 def test_se_gate_vs_torch():
     from heal_amd import ops
     g = torch.Generator().manual_seed(5)
