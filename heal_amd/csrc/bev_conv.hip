@@ -228,12 +228,15 @@ __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ x, 
     else if (act == 2) acc = acc / (1.f + expf(-acc));  // SiLU
     if (live) y[(size_t)nc * Ho * Wo + (size_t)oy * Wo + ox] = acc;
     if (sums) {
-        // the squeeze of the squeeze-excite stage that follows (MBConv: x.mean((2, 3))) rides along: block sum of the
-        // activated outputs -> one fp32 atomic per block into sums[n*C + c] (k_se_gate divides by Ho*Wo and clears it)
+        // the squeeze of the squeeze-excite stage that follows (MBConv: x.mean((2, 3))) rides along: the block sum of the
+        // activated outputs goes to sums[n*C + c][tile] -- a plain store per block (atomics into the few (n, c) words
+        // serialise at L2: 190 per word in the first MBConv stage tripled that launch's time); k_se_gate adds the tiles up in a
+        // fixed order, so the gate is bit-reproducible
         const float ws = wave_sum(live ? acc : 0.f);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
         __syncthreads();
-        if (threadIdx.x == 0) unsafeAtomicAdd(sums + nc, (part[0] + part[1]) + (part[2] + part[3]));
+        if (threadIdx.x == 0)
+            sums[(size_t)nc * (gridDim.x * gridDim.y) + bk.y * gridDim.x + bk.x] = (part[0] + part[1]) + (part[2] + part[3]);
     }
 }
 
@@ -267,19 +270,26 @@ namespace heal {
 __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2t,
                                                  const float* __restrict__ b2, int C, int S, float scale,
-                                                 int clear, float* __restrict__ mean_rw,
-                                                 float* __restrict__ gate) {
-    // mean * scale is the squeezed input: scale = 1 for a mean, 1 / (Ho*Wo) for the channel SUMS heal_depthwise_conv leaves;
-    // clear: zero the sums after the last read, so the accumulator is ready for the next depthwise launch (no memset)
+                                                 int tiles, float* __restrict__ gate) {
+    // squeezed input m[c] = scale * sum_t mean[n][c][t]: tiles = 1, scale = 1 for a spatial mean; tiles = T, scale = 1/(Ho*Wo)
+    // for the per-tile sums heal_depthwise_conv leaves (added here in tile order: deterministic)
     __shared__ float hid[64];
+    extern __shared__ float sm[];            // [C] squeezed input
     const int n = blockIdx.x;
-    const float* m = mean + (size_t)n * C;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        const float* src = mean + ((size_t)n * C + c) * tiles;
+        float acc = 0.f;
+        for (int t = 0; t < tiles; ++t) acc += src[t];
+        sm[c] = acc * scale;
+    }
+    __syncthreads();
+    const float* m = sm;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     for (int j = wave; j < S; j += 16) {  // one wave per hidden unit: coalesced row of W1, tree reduction
         const float* wr = w1 + (size_t)j * C;
         float acc = 0.f;
 #pragma unroll 4
-        for (int c = l; c < C; c += 64) acc = fmaf(wr[c], m[c] * scale, acc);
+        for (int c = l; c < C; c += 64) acc = fmaf(wr[c], m[c], acc);
         acc = wave_sum(acc);
         if (l == 0) {
             const float v = acc + b1[j];
@@ -292,18 +302,18 @@ __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean
 #pragma unroll 8
         for (int j = 0; j < S; ++j) g = fmaf(w2t[(size_t)j * C + c], hid[j], g);
         gate[(size_t)n * C + c] = 1.f / (1.f + expf(-g));
-        if (clear) mean_rw[(size_t)n * C + c] = 0.f;      // every read of m happened before the barrier above
     }
 }
 }  // namespace heal
 
-extern "C" int heal_se_gate(float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
-                            const float* b_expand, int n, int channels, int squeezed, float scale, int clear_mean,
+extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
+                            const float* b_expand, int n, int channels, int squeezed, float scale, int tiles,
                             float* gate, void* stream) {
+    HEAL_REQUIRE(tiles >= 1 && channels <= 12288, "se_gate: tiles must be >= 1 and channels <= 12288");
     HEAL_REQUIRE(n >= 1 && channels >= 1 && squeezed >= 1 && squeezed <= 64, "se_gate: squeezed channels must be in [1,64]");
     HEAL_REQUIRE(mean && w_reduce && b_reduce && w_expand_t && b_expand && gate, "se_gate: null pointer");
-    heal::k_se_gate<<<n, 1024, 0, (hipStream_t)stream>>>(mean, w_reduce, b_reduce, w_expand_t, b_expand, channels, squeezed,
-                                                      scale, clear_mean, mean, gate);
+    heal::k_se_gate<<<n, 1024, (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+        mean, w_reduce, b_reduce, w_expand_t, b_expand, channels, squeezed, scale, tiles, gate);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -66,7 +66,7 @@ class _SamePadConv2d(nn.Conv2d):
         self.static_padding = nn.ZeroPad2d(self.same_pad) if (pad_h > 0 or pad_w > 0) else nn.Identity()
 
 
-def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None, channel_sums=None):
+def _conv_bn(x, conv, bn, cache, act, in_scale=None, residual=None, channel_sums=False):
     """conv + folded BatchNorm (+ SiLU).  Pointwise convolutions run on heal_conv1x1 with the squeeze-excite gate
     (in_scale, per image and input channel), the bias, the skip connection and the activation fused."""
     if grad_path(x, bn, conv):   # gradient path: the package's own composition (scale, pad, conv, BatchNorm, swish, skip)
@@ -126,11 +126,10 @@ class _MBConv(nn.Module):
         dw = self._depthwise_conv
         if (x.is_cuda and not grad_path(x, self) and dw.kernel_size[0] in (3, 5) and dw.stride[0] in (1, 2)
                 and x.shape[0] * dw.in_channels <= 65535):
-            # the squeeze (spatial mean) rides in the depthwise launch as per-channel sums; the gate kernel scales and clears them
-            sums = ops.channel_sum_buffer(int(x.shape[0]), dw.in_channels, x.device)
-            x = _conv_bn(x, dw, self._bn1, self._c[1], act=True, channel_sums=sums)
+            # the squeeze (spatial mean) rides in the depthwise launch as per-tile sums; the gate kernel adds them up and scales
+            x, sums = _conv_bn(x, dw, self._bn1, self._c[1], act=True, channel_sums=True)
             gate = ops.se_gate(sums, self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight,
-                               self._se_expand.bias, scale=1.0 / float(x.shape[2] * x.shape[3]), clear=True)
+                               self._se_expand.bias, scale=1.0 / float(x.shape[2] * x.shape[3]), tiles=int(sums.shape[2]))
             return _conv_bn(x, self._project_conv, self._bn2, self._c[2], act=False, in_scale=gate[:, :, None, None],
                             residual=inp if self.id_skip else None)
         x = _conv_bn(x, dw, self._bn1, self._c[1], act=True)

@@ -1104,14 +1104,12 @@ def layernorm_nchw(x, gamma, beta, eps):
 _SE_T_CACHE = {}
 
 
-def se_gate(mean, w_reduce, b_reduce, w_expand, b_expand, scale=1.0, clear=False):
+def se_gate(mean, w_reduce, b_reduce, w_expand, b_expand, scale=1.0, tiles=1):
     """Squeeze-excite gate: mean [n,C] (any trailing 1-dims), w_reduce [S,C,1,1], w_expand [C,S,1,1] -> gate [n,C].
-    scale / clear: `mean` holds channel SUMS (depthwise_conv(channel_sums=...)): multiply by scale = 1/(H*W), zero it after."""
+    tiles = T, scale = 1/(H*W): `mean` holds the per-tile sums [n,C,T] of depthwise_conv(channel_sums=True)."""
     n, C = int(mean.shape[0]), int(mean.shape[1])
     S = int(w_reduce.shape[0])
-    if clear and not (mean.is_contiguous() and mean.dim() == 2):
-        raise _capi.HealAmdError("se_gate(clear=True) needs the contiguous [n,C] accumulator itself")
-    mean = _need(mean.reshape(n, C), torch.float32, "mean")
+    mean = _need(mean.reshape(n, C, int(tiles)), torch.float32, "mean")
     w_expand = _need(w_expand, torch.float32, "w_expand")
     key = (w_expand.data_ptr(), w_expand._version)
     hit = _SE_T_CACHE.get(key)
@@ -1123,7 +1121,7 @@ def se_gate(mean, w_reduce, b_reduce, w_expand, b_expand, scale=1.0, clear=False
     gate = torch.empty((n, C), dtype=torch.float32, device=mean.device)
     _capi.call("heal_se_gate", _ptr(mean), _ptr(_need(w_reduce, torch.float32, "w_reduce")),
                _ptr(_need(b_reduce, torch.float32, "b_reduce")), _ptr(hit[0]),
-               _ptr(_need(b_expand, torch.float32, "b_expand")), n, C, S, float(scale), int(bool(clear)), _ptr(gate),
+               _ptr(_need(b_expand, torch.float32, "b_expand")), n, C, S, float(scale), int(tiles), _ptr(gate),
                _stream())
     return gate
 
@@ -1148,15 +1146,14 @@ def upsample2x_bilinear(x):
     return y
 
 
-def channel_sum_buffer(n, C, device):
-    """The [n,C] accumulator of depthwise_conv(channel_sums=...): zero now, and zero again after se_gate(clear=True) has consumed
-    it -- one buffer per (shape, device, stream), never memset between uses."""
-    return _workspace_zeroed(("dw_channel_sums", n, C), 4 * n * C, device).view(torch.float32)[:n * C].view(n, C)
+def depthwise_tiles(Ho, Wo):
+    """Output tiles (32 x 8 pixels) of one depthwise_conv channel = the last dimension of its `channel_sums` argument."""
+    return ((Wo + 31) // 32) * ((Ho + 7) // 8)
 
 
 def depthwise_conv(x, weight, bias, stride, pad, act="none", channel_sums=None):
-    """Depthwise k x k conv; pad = (left, right, top, bottom) zero padding; act in none|relu|silu.  channel_sums [n,C]: the
-    per-(image, channel) sums of the outputs are added into it (the squeeze of an SE stage, folded into this launch)."""
+    """Depthwise k x k conv; pad = (left, right, top, bottom) zero padding; act in none|relu|silu.  channel_sums=True: also
+    return the per-tile sums [n, C, T] of the outputs (the squeeze of an SE stage, folded into this launch) -> (y, sums)."""
     x = _need(x, torch.float32, "x")
     weight = _need(weight, torch.float32, "weight")
     n, C, H, W = (int(v) for v in x.shape)
@@ -1165,7 +1162,7 @@ def depthwise_conv(x, weight, bias, stride, pad, act="none", channel_sums=None):
     Ho = (H + pt + pb - k) // stride + 1
     Wo = (W + pl + pr - k) // stride + 1
     y = torch.empty((n, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    sums = torch.empty((n, C, depthwise_tiles(Ho, Wo)), dtype=torch.float32, device=x.device) if channel_sums else None
     _capi.call("heal_depthwise_conv", _ptr(x), _ptr(weight), _ptr(bias), n, C, H, W, k, int(stride), pt, pl, Ho, Wo,
-               {"none": 0, "relu": 1, "silu": 2}[act], _ptr(y),
-               _ptr(_need(channel_sums, torch.float32, "channel_sums")) if channel_sums is not None else None, _stream())
-    return y
+               {"none": 0, "relu": 1, "silu": 2}[act], _ptr(y), _ptr(sums) if sums is not None else None, _stream())
+    return (y, sums) if channel_sums else y

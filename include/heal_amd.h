@@ -310,9 +310,9 @@ int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, 
  *   feature_alignnet_modules.py:314) with explicit top/left zero padding, bias and
  *   activation (0 none, 1 ReLU, 2 SiLU): the MBConv depthwise stage of the EfficientNet-b0 trunk
  *   (lss_submodule.py:93-105); x [n,C,H,W], weight [C,1,k,k] -> y [n,C,Ho,Wo].
- *   channel_sums (NULL or [n,C] f32, ZERO on entry): the sum of the activated outputs of every (image, channel) is ADDED to
- *   it (one fp32 atomic per block) -- the squeeze of the squeeze-excite stage that follows in an MBConv block, folded into
- *   this launch; heal_se_gate(scale = 1/(Ho*Wo), clear_mean = 1) consumes and clears it.                          */
+ *   channel_sums (NULL or [n,C,T] f32, T = ceil(Wo/32) * ceil(Ho/8) output tiles): every block stores the sum of its tile's
+ *   activated outputs -- the squeeze of the squeeze-excite stage that follows in an MBConv block, folded into this launch
+ *   (plain stores, every word written); heal_se_gate(scale = 1/(Ho*Wo), tiles = T) adds the tiles up in a fixed order.  */
 int heal_depthwise_conv(const float* x, const float* weight, const float* bias, int n, int channels, int H, int W,
                         int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y,
                         float* channel_sums, void* stream);
@@ -331,12 +331,11 @@ int heal_channel_dot(const float* x, const float* weight, const float* bias, int
 
 /* heal_se_gate: squeeze-excite gate of the EfficientNet MBConv block (efficientnet_pytorch MBConvBlock as called from
  *   lss_submodule.py:93-105): gate [n,C] = sigmoid(W_expand silu(W_reduce mean + b_reduce) + b_expand) from the spatial
- *   mean [n,C] * scale; W_reduce [S,C]; w_expand_t = W_expand^T laid out [S,C] (coalesced columns); S <= 64.
- *   scale = 1 for a spatial mean, 1/(Ho*Wo) for the channel sums heal_depthwise_conv accumulates; clear_mean != 0 zeroes
- *   `mean` after the last read (the accumulator is then ready for the next depthwise launch: no memset).
- *   Feeds heal_conv1x1's in_scale.                                                                               */
-int heal_se_gate(float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
-                 const float* b_expand, int n, int channels, int squeezed, float scale, int clear_mean, float* gate,
+ *   squeezed input = scale * sum_t mean[n][c][t]; W_reduce [S,C]; w_expand_t = W_expand^T laid out [S,C] (coalesced
+ *   columns); S <= 64.  tiles = 1, scale = 1: `mean` is the spatial mean [n,C]; tiles = T, scale = 1/(Ho*Wo): `mean` holds the
+ *   per-tile sums [n,C,T] heal_depthwise_conv leaves.  Feeds heal_conv1x1's in_scale.                                 */
+int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand_t,
+                 const float* b_expand, int n, int channels, int squeezed, float scale, int tiles, float* gate,
                  void* stream);
 
 /* heal_conv1x1: pointwise convolution with fused prologue/epilogue,

@@ -884,11 +884,10 @@ def test_se_gate_vs_torch():
         np.testing.assert_allclose(got.cpu().numpy(), ref.float().reshape(n, C).cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("k,stride,H,W", [(3, 1, 24, 32), (5, 2, 25, 37), (3, 2, 12, 16), (5, 1, 9, 70)])
-def test_squeeze_folded_into_depthwise_and_cleared_by_the_gate(k, stride, H, W):
-    """MBConv: depthwise -> x.mean((2, 3)) -> SE gate.  The depthwise launch accumulates the per-(image, channel) sums of its
-    outputs, heal_se_gate scales them to the mean and clears the accumulator: same gate as the separate mean, the accumulator
-    is zero again afterwards (so the next block finds it ready), twice in a row."""
+@pytest.mark.parametrize("k,stride,H,W", [(3, 1, 24, 32), (5, 2, 25, 37), (3, 2, 12, 16), (5, 1, 9, 70), (3, 1, 96, 128)])
+def test_squeeze_folded_into_depthwise(k, stride, H, W):
+    """MBConv: depthwise -> x.mean((2, 3)) -> SE gate.  The depthwise launch also stores the per-tile sums of its outputs,
+    heal_se_gate adds the tiles up (fixed order: bit-reproducible) and scales them to the mean: same gate as the separate mean."""
     from heal_amd import ops
     g = torch.Generator().manual_seed(k * 7 + stride)
     n, C, S = 4, 96, 4
@@ -900,16 +899,15 @@ def test_squeeze_folded_into_depthwise_and_cleared_by_the_gate(k, stride, H, W):
     pad = (k // 2, k // 2, k // 2, k // 2)
     plain = ops.depthwise_conv(x, w, b, stride, pad, "silu")
     want = ops.se_gate(plain.mean((2, 3)), w1, b1, w2, b2)
-    sums = ops.channel_sum_buffer(n, C, x.device)
-    assert float(sums.abs().max()) == 0.0
-    for _ in range(2):
-        y = ops.depthwise_conv(x, w, b, stride, pad, "silu", channel_sums=sums)
-        assert torch.equal(y, plain)
-        ref_sum = plain.double().sum((2, 3))
-        assert float((sums.double() - ref_sum).abs().max() / ref_sum.abs().max()) < 1e-5
-        got = ops.se_gate(sums, w1, b1, w2, b2, scale=1.0 / (plain.shape[2] * plain.shape[3]), clear=True)
-        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-6)
-        assert float(sums.abs().max()) == 0.0
+    y, sums = ops.depthwise_conv(x, w, b, stride, pad, "silu", channel_sums=True)
+    assert torch.equal(y, plain) and sums.shape == (n, C, ops.depthwise_tiles(plain.shape[2], plain.shape[3]))
+    ref_sum = plain.double().sum((2, 3))
+    assert float((sums.double().sum(2) - ref_sum).abs().max() / ref_sum.abs().max()) < 1e-5
+    got = ops.se_gate(sums, w1, b1, w2, b2, scale=1.0 / (plain.shape[2] * plain.shape[3]), tiles=int(sums.shape[2]))
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    again = ops.se_gate(ops.depthwise_conv(x, w, b, stride, pad, "silu", channel_sums=True)[1], w1, b1, w2, b2,
+                        scale=1.0 / (plain.shape[2] * plain.shape[3]), tiles=int(sums.shape[2]))
+    assert torch.equal(got, again)                        # no atomics anywhere: bit-reproducible
 
 
 def test_voxelize_collated_equals_per_agent():
