@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 const float* __restrict__ in_scale, int Cin, int Kpad, int Cout,
                                                 int HW, int Wo, int in_W, int in_HW, int act, int out_pm,
-                                                int d2s_k, int d2s_ctot, int d2s_coff, float* __restrict__ y) {
+                                                int d2s_k, int d2s_ctot, int d2s_coff, int n_img, int ksplit,
+                                                float* __restrict__ y) {
+    // ksplit > 1 (small maps with a deep reduction: 36 blocks for the 1152 -> 192 projection at 12 x 16 x 4 pixels): grid.z =
+    // ksplit * n_img, block z reduces chunk range ks of image n and writes its PARTIAL sum to y[ks][n][Cout][HW] (no bias /
+    // residual / activation: k_conv1x1_splitk_reduce adds the partials in split order and applies them).
     // out_pm: 0 NCHW | 1 pixel-major | 2 depth-to-space INTO A SLICE of a wider NCHW tensor: output channel co of pixel
     // (h, w) lands at channel d2s_coff + co / k^2, pixel (h k + (co % k^2) / k, w k + co % k) of y [n, d2s_ctot, H k, W k] --
     // ConvTranspose2d(kernel = stride = k) + pixel shuffle + torch.cat in the epilogue (k = 1: a plain channel-offset write).
@@ -44,12 +48,13 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
     static_assert(NPASS >= 1 && KC % RPP == 0, "bad staging shape");
     __shared__ __attribute__((aligned(16))) float sB[2][KC][LD];
     const Block3 bk = xcd_block();  // x: Cout chunk, y: pixel tile, z: image
-    const int m0 = bk.x * BM, p0 = bk.y * BN, n = bk.z;
+    const int m0 = bk.x * BM, p0 = bk.y * BN, n = bk.z % n_img, kpart = bk.z / n_img;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int lk = l >> 4, ln = l & 15;
     const float* __restrict__ xin = x + (size_t)n * Cin * in_HW;
     const int ksteps = Kpad / 4;    // k-steps of 4 channels over the (zero-padded) K of the fragment layout
-    const int nchunks = Kpad / KC;
+    const int nchunks_all = Kpad / KC, cps = (nchunks_all + ksplit - 1) / ksplit;
+    const int cbeg = kpart * cps, nchunks = min(cbeg + cps, nchunks_all);   // this block's chunk range [cbeg, nchunks)
     const float* __restrict__ scl = in_scale ? in_scale + (size_t)n * Cin : nullptr;
     const int sp = (threadIdx.x % TPR) * 4, sc = threadIdx.x / TPR;
     const bool pix_ok = p0 + sp < HW;  // HW % 4 == 0 (checked by the host): a float4 is all-in or all-out
@@ -97,12 +102,12 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
         }
     };
 
-    load_a(0, a_cur);
-    load_chunk(0);
+    load_a(cbeg, a_cur);
+    load_chunk(cbeg);
     store_chunk(0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+    for (int c = cbeg; c < nchunks; ++c) {
+        const int buf = (c - cbeg) & 1;
         // Software pipeline: the NEXT chunk's A fragments and B rows are requested before this chunk's MFMAs, which
         // depend on nothing outstanding (vmcnt is in-order: a load the MFMAs needed behind the HBM-latency B loads
         // would stall the matrix pipe for the whole round trip).
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
     constexpr int LDO = BN + 4;                       // 68 | 132 floats: (lk*4*LDO + ln) % 64 distinct -> conflict-free
     static_assert(4 * 16 * LDO <= 2 * KC * LD, "epilogue tile does not fit the B buffers");
     float* so = &sB[0][0][0] + wave * (16 * LDO);
-    float* __restrict__ yout = y + (size_t)n * Cout * HW;
+    float* __restrict__ yout = y + ((size_t)kpart * n_img + n) * Cout * HW;
     const float* __restrict__ rin = res ? res + (size_t)n * Cout * HW : nullptr;
     constexpr int F4_PER_ROW = BN / 4, ITERS = 16 * F4_PER_ROW / 64;
 #pragma unroll
@@ -222,13 +227,40 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
     }
 }
 
+
+// out[n][co][p] = act(sum_ks part[ks][n][co][p] + bias[co] (+ residual)), the partials added in split order (deterministic)
+__global__ __launch_bounds__(256) void k_conv1x1_splitk_reduce(const float4* __restrict__ part, const float* __restrict__ bias,
+                                                              const float4* __restrict__ res, int ksplit, int Cout, int HW4,
+                                                              size_t total4, int act, float4* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 v = part[i];
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 q = part[(size_t)k * total4 + i];
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    const float bv = bias ? bias[(i / HW4) % Cout] : 0.f;
+    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+    if (res) { const float4 q = res[i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    if (act == 1) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (act == 2) {
+        v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y)); v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+    } else if (act == 3) {
+        v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752f));
+        v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
+    }
+    y[i] = v;
+}
+
 }  // namespace heal
 
 using namespace heal;
 
 static int conv1x1_launch(const float* x, const float* weight_frag, const float* bias, const float* residual,
                           const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
-                          int out_pixel_major, int d2s_k, int d2s_ctot, int d2s_coff, float* y, void* stream) {
+                          int out_pixel_major, int d2s_k, int d2s_ctot, int d2s_coff, float* y, void* stream,
+                          int ksplit = 1, float* partials = nullptr) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv1x1: bad shape");
     HEAL_REQUIRE(stride == 1 || stride == 2, "conv1x1: stride must be 1 or 2 (got %d)", stride);
     const int kpad = (cin + 31) / 32 * 32, mpad = (cout + 63) / 64 * 64;  // dims of the zero-padded fragment layout
@@ -254,9 +286,14 @@ static int conv1x1_launch(const float* x, const float* weight_frag, const float*
     HEAL_REQUIRE(mpad % bm == 0, "conv1x1: padded Cout %d not a multiple of the tile height %d", mpad, bm);
 #define HEAL_C1(BM_, BN_, KC_, ST_)                                                                              \
     if (bm == BM_ && bn == BN_ && kc == KC_ && stride == ST_) {                                                  \
-        k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                    \
-            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, d2s_k,    \
-            d2s_ctot, d2s_coff, y);                                                                              \
+        if (ksplit > 1)                                                                                          \
+            k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n * ksplit), 256, 0, s>>>(       \
+                x, weight_frag, nullptr, nullptr, in_scale, cin, kpad, cout, HW, Wo, W, H * W, 0, 0, 1, 0, 0, n, ksplit, \
+                partials);                                                                                       \
+        else                                                                                                     \
+            k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                \
+                x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, d2s_k, \
+                d2s_ctot, d2s_coff, n, 1, y);                                                                    \
         launched = true;                                                                                         \
     }
     bool launched = false;
@@ -264,6 +301,12 @@ static int conv1x1_launch(const float* x, const float* weight_frag, const float*
     HEAL_C1(128, 128, 32, 1) HEAL_C1(64, 128, 32, 1) HEAL_C1(128, 64, 32, 1)
 #undef HEAL_C1
     HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d) stride %d", bm, bn, kc, stride);
+    if (ksplit > 1) {
+        const size_t total4 = (size_t)n * cout * HW / 4;
+        k_conv1x1_splitk_reduce<<<(unsigned)((total4 + 255) / 256), 256, 0, s>>>(
+            reinterpret_cast<const float4*>(partials), bias, reinterpret_cast<const float4*>(residual), ksplit, cout, HW / 4,
+            total4, act, reinterpret_cast<float4*>(y));
+    }
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -286,4 +329,25 @@ extern "C" int heal_conv1x1_d2s(const float* x, const float* weight_frag, const 
     HEAL_REQUIRE(((uintptr_t)y & 15) == 0, "conv1x1_d2s: destination must be 16-B aligned");
     return conv1x1_launch(x, weight_frag, bias, nullptr, nullptr, n, cin, cout, H, W, 1, act, 2, k, dst_channels,
                           dst_channel_offset, y, stream);
+}
+
+extern "C" size_t heal_conv1x1_splitk_workspace(int n, int cout, int H, int W, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * n * cout * H * W * sizeof(float) : 0;
+}
+
+extern "C" int heal_conv1x1_splitk(const float* x, const float* weight_frag, const float* bias, const float* residual,
+                                   const float* in_scale, int n, int cin, int cout, int H, int W, int act, int ksplit, float* y,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    const int nchunks = (cin + 31) / 32;
+    HEAL_REQUIRE(ksplit >= 2 && ksplit <= nchunks, "conv1x1_splitk: ksplit must be in [2, %d] (got %d)", nchunks, ksplit);
+    HEAL_REQUIRE((ksplit - 1) * ceil_div(nchunks, ksplit) < nchunks,
+                 "conv1x1_splitk: %d splits of %d chunks leave an empty split (use ceil(chunks / ceil(chunks / ksplit)))", ksplit,
+                 nchunks);
+    HEAL_REQUIRE((H * W) % 4 == 0, "conv1x1_splitk: H*W must be a multiple of 4");
+    HEAL_REQUIRE((long long)n * ksplit <= 65535, "conv1x1_splitk: n * ksplit exceeds the grid limit");
+    HEAL_REQUIRE(ws && ws_bytes >= heal_conv1x1_splitk_workspace(n, cout, H, W, ksplit) && ((uintptr_t)ws & 15) == 0,
+                 "conv1x1_splitk: workspace too small or misaligned");
+    HEAL_REQUIRE(act >= 0 && act <= 3, "conv1x1_splitk: act must be 0..3");
+    return conv1x1_launch(x, weight_frag, bias, residual, in_scale, n, cin, cout, H, W, 1, act, 0, 1, 0, 0, y, stream, ksplit,
+                          (float*)ws);
 }

@@ -5,6 +5,7 @@ libheal_amd.so.  Every function requires CUDA(HIP) tensors and raises otherwise 
 path in the product.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -896,6 +897,20 @@ def conv1x1_supported(cin, cout, hw, stride=1, out_w=None):
     return stride == 2 and out_w is not None and out_w % 4 == 0 and hw >= 64
 
 
+def conv1x1_ksplit(n, cin, cout, hw):
+    """K splits for a stride-1 NCHW pointwise convolution: 1 unless the grid is small (< 128 blocks of 64 channels x 64 pixels)
+    and the reduction deep (>= 8 chunks of 32 channels); then enough splits for ~256 blocks, at least 2 chunks each, none empty.
+    HEAL_C1_KSPLIT forces a value (0 / 1: off)."""
+    chunks = (cin + 31) // 32
+    blocks = -(-cout // 64) * -(-hw // 64) * n
+    env = os.environ.get("HEAL_C1_KSPLIT")
+    want = int(env) if env is not None else (min(chunks // 2, max(2, 256 // blocks)) if blocks < 128 and chunks >= 8 else 1)
+    if want < 2 or chunks < 2 or hw % 4:
+        return 1
+    want = min(want, chunks, 65535 // n)
+    return -(-chunks // -(-chunks // want))       # ceil(chunks / ceil(chunks / want)): no empty split
+
+
 def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixel_major=False):
     """Pointwise convolution with fused prologue / epilogue: act(W (in_scale . x) + bias (+ residual));
     act 0 none | 1 ReLU | 2 SiLU; stride 1 | 2.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin].
@@ -922,6 +937,16 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
             raise _capi.HealAmdError("conv1x1: residual shape mismatch")
     if in_scale is not None:
         in_scale = _need(in_scale.reshape(n, cin), torch.float32, "in_scale")
+    ksplit = conv1x1_ksplit(n, cin, cout, H * W) if (stride == 1 and not pixel_major) else 1
+    if ksplit > 1:
+        nbytes = _capi.query("heal_conv1x1_splitk_workspace", n, cout, H, W, ksplit)
+        ws = _workspace("conv1x1_splitk", nbytes, x.device)
+        with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W,
+                    4.0 * n * (cin * H * W + cout * H * W * (2 if residual is not None else 1))):
+            _capi.call("heal_conv1x1_splitk", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
+                       _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
+                       n, cin, cout, H, W, int(act), ksplit, _ptr(y), _ptr(ws), ws.numel(), _stream())
+        return y
     with _Timed(f"conv1x1_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * n * cin * cout * Ho * Wo,
                 4.0 * n * (cin * Ho * Wo + cout * Ho * Wo * (2 if residual is not None else 1))):
         _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,

@@ -363,6 +363,16 @@ int heal_conv1x1(const float* x, const float* weight_frag, const float* bias, co
 int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bias, int n, int cin, int cout, int H, int W,
                       int stride, int pad_t, int pad_l, int Ho, int Wo, int act, float* y, void* stream);
 
+/* heal_conv1x1_splitk: heal_conv1x1 (stride 1, NCHW) for SMALL maps with a DEEP reduction -- the MBConv projections of the
+ *   EfficientNet trunk at 1/16 .. 1/32 resolution (1152 -> 192 at 12 x 16 x 4 pixels is 36 blocks of 36 K-chunks each) -- with
+ *   the K chunks split over `ksplit` blocks: partial sums go to the workspace [ksplit][n][Cout][HW], a second launch adds them
+ *   in split order (deterministic) and applies bias / residual / activation.  ksplit in [2, ceil32(Cin)/32] with no empty
+ *   split; workspace from heal_conv1x1_splitk_workspace, 16-B aligned; H*W % 4 == 0.                                  */
+size_t heal_conv1x1_splitk_workspace(int n, int cout, int H, int W, int ksplit);
+int heal_conv1x1_splitk(const float* x, const float* weight_frag, const float* bias, const float* residual,
+                        const float* in_scale, int n, int cin, int cout, int H, int W, int act, int ksplit, float* y, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* heal_conv1x1_d2s: heal_conv1x1 (stride 1, no residual / gate) whose epilogue writes DEPTH-TO-SPACE INTO A CHANNEL SLICE of a
  *   wider NCHW tensor: output channel co of pixel (h, w) goes to channel dst_channel_offset + co / k^2, pixel
  *   (h k + (co % k^2) / k, w k + co % k) of y [n, dst_channels, H k, W k].  This is the deblock of the BEV backbones --

@@ -830,6 +830,34 @@ def test_conv1x1_padded_shapes_gate_and_skip(n, cin, cout, H, W):
     assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
 
 
+def test_conv1x1_split_k_small_maps(monkeypatch):
+    """Small maps with a deep reduction (the MBConv projections at 1/32 resolution): the K chunks split over several blocks
+    + a deterministic reduce with the epilogue, against the single-pass kernel (same chunks, different summation tree: 1e-5)
+    and torch fp64; gate, bias, residual, SiLU; split counts that do not divide the chunk count."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for n, cin, cout, H, W, act in ((4, 1152, 192, 12, 16, 0), (4, 672, 112, 24, 32, 0), (2, 300, 70, 6, 10, 2), (1, 1152, 320, 12, 16, 1)):
+        x = torch.randn((n, cin, H, W), generator=g).cuda()
+        w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).cuda()
+        b = torch.randn((cout,), generator=g).cuda()
+        gate = torch.sigmoid(torch.randn((n, cin, 1, 1), generator=g)).cuda()
+        skip = torch.randn((n, cout, H, W), generator=g).cuda()
+        monkeypatch.setenv("HEAL_C1_KSPLIT", "1")
+        one = ops.conv1x1(x, w, b, skip, act, in_scale=gate)
+        ref = torch.nn.functional.conv2d((gate * x).double(), w.double(), b.double()) + skip.double()
+        ref = torch.relu(ref) if act == 1 else torch.nn.functional.silu(ref) if act == 2 else ref
+        for ks in ("0auto", "2", "5", "7", "36"):
+            if ks == "0auto":
+                monkeypatch.delenv("HEAL_C1_KSPLIT")
+                assert ops.conv1x1_ksplit(n, cin, cout, H * W) > 1 or cin < 256
+            else:
+                monkeypatch.setenv("HEAL_C1_KSPLIT", ks)
+            got = ops.conv1x1(x, w, b, skip, act, in_scale=gate)
+            assert float((got - one).abs().max() / one.abs().max()) < 1e-5, ks
+            assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4, ks
+            assert torch.equal(got, ops.conv1x1(x, w, b, skip, act, in_scale=gate))      # deterministic
+
+
 @pytest.mark.parametrize("n,cin,cout,H,W", [(2, 64, 128, 32, 32), (1, 128, 256, 16, 24), (3, 64, 64, 9, 16)])
 def test_conv1x1_stride2_vs_torch(n, cin, cout, H, W):
     """the 1x1 stride-2 `downsample` convolution of the residual blocks (resblock.py:160-165)"""
@@ -1032,7 +1060,8 @@ def test_deblock_transposed_conv_as_conv1x1_plus_shuffle(k, cin, cout, H, W):
     with torch.no_grad():
         cat = torch.full((2, cout + 24, k * H, k * W), 7.0, device="cuda")
         view = blk(x, into=(cat, 8))
-    assert view.data_ptr() == cat[:, 8:].data_ptr() and torch.equal(view, got)      # same values as the stand-alone path
+    # same values as the stand-alone path (which may split the reduction over blocks on a tiny map: another summation tree)
+    assert view.data_ptr() == cat[:, 8:].data_ptr() and float((view - got).abs().max() / got.abs().max()) < 1e-5
     assert bool((cat[:, :8] == 7.0).all()) and bool((cat[:, 8 + cout:] == 7.0).all())   # nothing written outside the slice
 
 
@@ -1054,5 +1083,5 @@ def test_decode_multiscale_feature_writes_the_concatenation_in_place():
         d = bb.double()
         ref = torch.cat([torch.relu(d.deblocks[i][1](torch.nn.functional.conv_transpose2d(
             feats[i].double(), d.deblocks[i][0].weight, None, d.deblocks[i][0].stride))) for i in range(3)], 1)
-    assert got.shape == (2, 384, 32, 48) and torch.equal(got, torch.cat(parts, 1))
+    assert got.shape == (2, 384, 32, 48) and float((got - torch.cat(parts, 1)).abs().max() / got.abs().max()) < 1e-5
     assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
