@@ -272,7 +272,10 @@ __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean
                                                  const float* __restrict__ b2, int C, int S, float scale,
                                                  int tiles, float* __restrict__ gate) {
     // squeezed input m[c] = scale * sum_t mean[n][c][t]: tiles = 1, scale = 1 for a spatial mean; tiles = T, scale = 1/(Ho*Wo)
-    // for the per-tile sums heal_depthwise_conv leaves (added here in tile order: deterministic)
+    // for the per-tile sums heal_depthwise_conv leaves (added here in tile order: deterministic).
+    // grid = (n, channel blocks of 256): every block recomputes the S hidden units (S*C MACs, cheap) and finishes 256 output
+    // channels with FOUR threads per channel (each a quarter of the hidden units, combined by two shuffles) -- one block per
+    // image serialised S dependent loads per thread on 4 of the 256 CUs.
     __shared__ float hid[64];
     extern __shared__ float sm[];            // [C] squeezed input
     const int n = blockIdx.x;
@@ -297,12 +300,16 @@ __global__ __launch_bounds__(1024) void k_se_gate(const float* __restrict__ mean
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 1024) {  // thread per channel: column c of W2^T, coalesced across threads
-        float g = b2[c];
-#pragma unroll 8
-        for (int j = 0; j < S; ++j) g = fmaf(w2t[(size_t)j * C + c], hid[j], g);
-        gate[(size_t)n * C + c] = 1.f / (1.f + expf(-g));
+    // channel c = 256 * blockIdx.y + tid / 4, quarter q = tid % 4 of the hidden units (j = q, q + 4, ...): fixed order
+    const int c = blockIdx.y * 256 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    float g = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int j = q; j < S; j += 4) g = fmaf(w2t[(size_t)j * C + c], hid[j], g);
     }
+    g += __shfl_xor(g, 1, 64);
+    g += __shfl_xor(g, 2, 64);
+    if (c < C && q == 0) gate[(size_t)n * C + c] = 1.f / (1.f + expf(-(g + b2[c])));
 }
 }  // namespace heal
 
@@ -312,7 +319,7 @@ extern "C" int heal_se_gate(const float* mean, const float* w_reduce, const floa
     HEAL_REQUIRE(tiles >= 1 && channels <= 12288, "se_gate: tiles must be >= 1 and channels <= 12288");
     HEAL_REQUIRE(n >= 1 && channels >= 1 && squeezed >= 1 && squeezed <= 64, "se_gate: squeezed channels must be in [1,64]");
     HEAL_REQUIRE(mean && w_reduce && b_reduce && w_expand_t && b_expand && gate, "se_gate: null pointer");
-    heal::k_se_gate<<<n, 1024, (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+    heal::k_se_gate<<<dim3(n, ceil_div(channels, 256)), 1024, (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
         mean, w_reduce, b_reduce, w_expand_t, b_expand, channels, squeezed, scale, tiles, gate);
     HEAL_LAUNCH_CHECK();
     return 0;
