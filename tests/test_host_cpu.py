@@ -518,3 +518,37 @@ def test_grad_path_switch():
         assert not grad_path(x, conv)                            # frozen, eval, input without gradient
         assert grad_path(x.clone().requires_grad_(True), conv)   # gradient flows through
         assert grad_path(x, conv.train())                        # training mode (BatchNorm statistics etc.)
+
+
+def test_conv1x1_ksplit_policy_never_leaves_an_empty_split(monkeypatch):
+    """ops.conv1x1_ksplit: 1 for big grids / shallow reductions; otherwise a split count that the kernel accepts -- every split
+    owns at least one K chunk (heal_conv1x1_splitk rejects the rest), n * ksplit fits the launch grid."""
+    from heal_amd import ops
+    monkeypatch.delenv("HEAL_C1_KSPLIT", raising=False)
+    assert ops.conv1x1_ksplit(5, 256, 512, 64 * 64) == 1 and ops.conv1x1_ksplit(4, 16, 96, 192 * 256) == 1
+    assert ops.conv1x1_ksplit(4, 1152, 192, 12 * 16) > 1
+    for n in (1, 4, 700):
+        for cin in (33, 256, 300, 1152, 1153):
+            for want in (None, 2, 5, 7, 36, 1000):
+                if want is None:
+                    monkeypatch.delenv("HEAL_C1_KSPLIT", raising=False)
+                else:
+                    monkeypatch.setenv("HEAL_C1_KSPLIT", str(want))
+                ks = ops.conv1x1_ksplit(n, cin, 192, 12 * 16)
+                chunks = (cin + 31) // 32
+                assert 1 <= ks <= chunks and n * ks <= 65535
+                if ks > 1:
+                    per = -(-chunks // ks)
+                    assert (ks - 1) * per < chunks, (n, cin, want, ks)
+
+
+def test_grouped_small_fragment_layout():
+    """ops.grouped_small_fragments: [C, cg, 3, 3] -> [C/16][tap][ci][16]: element (sg, tap, ci, co) = W[sg*16 + co][ci][tap]
+    (what k_gconv_small reads as `wq[(sg * 9 cg + tap * cg + ci) * 16 + lane % 16]`)."""
+    from heal_amd import ops
+    for C, cg in ((128, 4), (256, 8), (512, 16)):
+        w = torch.arange(C * cg * 9, dtype=torch.float32).reshape(C, cg, 3, 3)
+        f = ops.grouped_small_fragments(w, cg)
+        assert tuple(f.shape) == (C // 16, 9, cg, 16) and f.is_contiguous()
+        for sg, tap, ci, co in ((0, 0, 0, 0), (C // 16 - 1, 8, cg - 1, 15), (3, 5, 1, 9)):
+            assert float(f[sg, tap, ci, co]) == float(w[sg * 16 + co, ci, tap // 3, tap % 3])
