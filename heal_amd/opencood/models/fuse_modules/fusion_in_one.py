@@ -17,6 +17,10 @@ def regroup(x, record_len):
 
 def warp_to_ego(x, affine_rows, grid_f64=True):
     """warp_affine_simple(x, t_matrix[0, :], (H, W)) for one scene: x [n,C,H,W] -> [n,C,H,W]."""
+    if torch.is_grad_enabled() and x.requires_grad:   # gradient path: affine_grid + grid_sample (torch_transformation_utils.py:323-332)
+        import torch.nn.functional as F
+        M = torch.as_tensor(affine_rows, dtype=x.dtype, device=x.device)
+        return F.grid_sample(x, F.affine_grid(M, list(x.shape), align_corners=False), align_corners=False)
     zeros = torch.zeros((1,) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
     return torch.stack([ops.warp_agent(x[a], zeros, affine_rows[a], grid_f64)[0] for a in range(x.shape[0])])
 
@@ -60,6 +64,10 @@ class AttFusion(_WarpThenFuse):
     def fuse_warped(self, ego):
         n, C, H, W = ego.shape
         x = ego.reshape(n, C, H * W).permute(2, 0, 1).contiguous()      # [HW, n, C]
+        if torch.is_grad_enabled() and ego.requires_grad:
+            # gradient path (fusion_in_one.py:14-45,126-151): softmax(x x^T / sqrt(C)) x per pixel, the ego row
+            attn = torch.softmax(torch.bmm(x, x.transpose(1, 2)) / self.sqrt_dim, dim=-1)
+            return torch.bmm(attn, x)[:, 0, :].t().reshape(C, H, W)
         h = ops.agent_attention(x, x, x, heads=1, scale=1.0 / self.sqrt_dim, out_rows=1)  # ego row only
         return h[:, 0, :].t().reshape(C, H, W)
 

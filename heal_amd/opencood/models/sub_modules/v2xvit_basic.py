@@ -86,6 +86,19 @@ class HGTCavAttention(nn.Module):
     def forward(self, x, mask=None, prior_encoding=None):
         """x [L,H,W,C] (one scene, real agents only) -> [L,H,W,C]."""
         L, H, W, C = x.shape
+        if torch.is_grad_enabled() and (x.requires_grad or self.training):
+            # gradient path (hmsa.py:110-151 for agent type 0 / relation 0): per pixel and head
+            #   att[i,j] = (q_i W_att) . k_j * scale,  out_i = sum_j softmax_j(att)[i,j] (v_j W_msg)
+            m, d = self.heads, self.dim_head
+            flat = x.reshape(L, H * W, C)
+            q = self.q_linears[0](flat).view(L, H * W, m, d)
+            k = self.k_linears[0](flat).view(L, H * W, m, d)
+            v = self.v_linears[0](flat).view(L, H * W, m, d)
+            qa = torch.einsum("lphd,hde->lphe", q, self.relation_att[0])
+            vm = torch.einsum("lphd,hde->lphe", v, self.relation_msg[0])
+            att = torch.einsum("iphd,jphd->phij", qa, k) * self.scale            # [HW, m, L, L]
+            out = torch.einsum("phij,jphd->iphd", att.softmax(dim=-1), vm)       # [L, HW, m, d]
+            return self.a_linears[0](out.reshape(L, H * W, m * d)).reshape(L, H, W, C)
         w, b = self._folded_qkv()
         qkv = torch.addmm(b, x.reshape(-1, C), w)                       # [L*H*W, 3*inner]
         inner = self.heads * self.dim_head
@@ -135,7 +148,7 @@ class BaseWindowAttention(nn.Module):
             bias = self.pos_embedding
         qkv = self.to_qkv(x)
         from heal_amd import ops
-        if x.is_cuda and ops.window_attention_supported(ws, d, H, W):
+        if x.is_cuda and ops.window_attention_supported(ws, d, H, W) and not (torch.is_grad_enabled() and (x.requires_grad or self.training)):
             # one kernel per window size: Q K^T, bias, softmax and P V without materialising the window re-layouts or
             # the [windows, T, T] score tensor (heal_window_attention): 16x (ws 4), 4x (ws 8) and 1.7x (ws 16) faster
             # than the library sequence at 8 agents x 128 x 128
