@@ -110,9 +110,22 @@ class SECOND(nn.Module):
         self.map_to_bev = HeightCompression(args["map2bev"])
 
     def forward(self, data_dict, modality_name):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         inp = data_dict[f"inputs_{modality_name}"]
+        if torch.is_grad_enabled() and self.training:
+            # gradient path: K1 still voxelises raw clouds on the device; MeanVFE and the sparse backbone run as torch
+            # operators (dense masked evaluation of the sparse convolutions: sparse_backbone_3d.py, small grids only)
+            if "points" in inp:
+                v, c, n, offsets = ops.voxelize_collated(inp["points"], self.lidar_range, self.voxel_size,
+                                                         int(inp.get("max_points_per_voxel") or self.max_points),
+                                                         int(inp.get("max_voxels") or self.max_voxels))
+                m = int(offsets[len(inp["points"])].item())
+                voxels, coords, num, batch_size = v[:m], c[:m], n[:m], len(inp["points"])
+            else:
+                voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
+                batch_size = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
+            batch_dict = self.vfe({"voxel_features": voxels, "voxel_coords": coords, "voxel_num_points": num,
+                                   "batch_size": batch_size})
+            return self.map_to_bev(self.spconv_block.forward_autograd(batch_dict))["spatial_features"]
         n_dev = None
         if "points" in inp:
             # K1 per agent into collated buffers, the voxel count stays on the device: the whole encoder runs without

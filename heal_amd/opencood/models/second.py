@@ -24,15 +24,16 @@ class Second(nn.Module):
         self.reg_head = nn.Conv2d(256 * 2, 7 * args.get("anchor_num", args["anchor_number"]), kernel_size=1)
 
     def forward(self, data_dict):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("heal_amd implements the inference hot path (SURVEY 8f: training is 'next')")
         lidar = data_dict["processed_lidar"]
         coords = lidar["voxel_coords"]
         batch_dict = {"voxel_features": lidar["voxel_features"], "voxel_coords": coords,
                       "voxel_num_points": lidar["voxel_num_points"],
                       "batch_size": int(coords[:, 0].max().item()) + 1}  # second.py:39
         batch_dict = self.mean_vfe(batch_dict)
-        batch_dict = self.backbone_3d(batch_dict)
+        if self.training and torch.is_grad_enabled():   # gradient path: dense masked evaluation (sparse_backbone_3d.py)
+            batch_dict = self.backbone_3d.forward_autograd(batch_dict)
+        else:
+            batch_dict = self.backbone_3d(batch_dict)
         batch_dict = self.height_compression(batch_dict)
         x = self.backbone_2d(batch_dict)["spatial_features_2d"]
         return {"psm": head(self.cls_head, x), "rm": head(self.reg_head, x)}

@@ -4,9 +4,16 @@ sparse_backbone_3d.py:33-152) on the gfx950 gather-GEMM kernel K3 (heal_sp_conv)
 Parameter names follow the reference (`conv_input.0.weight`, `conv_input.1.*`, `conv2.0.0.weight`, ...).
 Convolution weights are stored in spconv 1.2.1 layout [kz,ky,kx,Cin,Cout] (the layout of the authors'
 checkpoints, README "spconv 1.2.1"); spconv 2.x checkpoints ([Cout,kz,ky,kx,Cin]) are permuted on load.
+
+Gradient path (training): the HIP gather-GEMM has no backward; with autograd on the backbone runs spconv's arithmetic as a
+DENSE conv3d on the densified grid, masked by the active-site rules (submanifold: the input's sites; strided: every output
+cell with an active input in its receptive field), BatchNorm1d + ReLU on the active rows -- plain torch, differentiable, and
+only practical on small grids (the full +-102.4 m grid at 0.1 m is 172 M cells per agent); a sparse backward kernel is the
+real answer and is listed as next.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 class SparseConvParam(nn.Module):
@@ -55,6 +62,22 @@ class _Block(nn.Sequential):
             self._key = key
         return self._fold
 
+    def run_dense(self, x, mask):
+        """Gradient path of one block on dense tensors: x [B,Cin,D,H,W] (zero at inactive cells), mask [B,1,D,H,W] ->
+        (y [B,Cout,D',H',W'], mask')."""
+        conv, bn = self[0], self[1]
+        w = conv.weight.permute(4, 3, 0, 1, 2)                       # [kz,ky,kx,Cin,Cout] -> [Cout,Cin,kz,ky,kx]
+        if conv.subm:
+            y = F.conv3d(x, w, None, 1, tuple(k // 2 for k in conv.kernel_size))
+            m = mask
+        else:
+            y = F.conv3d(x, w, None, conv.stride, conv.padding)
+            m = (F.max_pool3d(mask, conv.kernel_size, conv.stride, conv.padding) > 0).to(x.dtype)
+        site = m[:, 0].nonzero(as_tuple=True)                        # (b, z, y, x) of the active output cells
+        rows = F.relu(bn(y.permute(0, 2, 3, 4, 1)[site]))            # BatchNorm1d over the ACTIVE rows only, like spconv
+        out = y.new_zeros(y.permute(0, 2, 3, 4, 1).shape).index_put(site, rows)
+        return out.permute(0, 4, 1, 2, 3), m
+
     def run(self, x, nbr_cache):
         """x: heal_amd.ops.SparseTensor -> SparseTensor."""
         from heal_amd.ops import SparseTensor
@@ -74,6 +97,17 @@ class _Block(nn.Sequential):
         nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, n_out_dev=n_out_dev)
         feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=n_out_dev)
         return SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks, x._root_cap)
+
+
+class _DenseResult:
+    """What HeightCompression reads on the gradient path: `.dense()` = [B, C*D, H, W] (channel = c*D + z)."""
+
+    def __init__(self, x):
+        self.x = x
+
+    def dense(self):
+        B, C, D, H, W = self.x.shape
+        return self.x.reshape(B, C * D, H, W)
 
 
 def _block(cin, cout, k, key, stride=1, padding=0, conv_type="subm"):
@@ -99,6 +133,22 @@ class VoxelBackBone8x(nn.Module):
         self.conv_out = _block(64, self.num_point_features, (3, 1, 1), "spconv_down2", stride=(2, 1, 1), padding=0,
                                conv_type="spconv")
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
+
+    def forward_autograd(self, batch_dict):
+        """Gradient path: dense masked evaluation (module docstring).  -> batch_dict with a dense result object."""
+        feats, coords = batch_dict["voxel_features"], batch_dict["voxel_coords"].long()
+        B = int(batch_dict["batch_size"])
+        D, H, W = self.sparse_shape
+        site = (coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3])
+        x = feats.new_zeros((B, D, H, W, feats.shape[1])).index_put(site, feats).permute(0, 4, 1, 2, 3)
+        mask = feats.new_zeros((B, D, H, W)).index_put(site, feats.new_ones(coords.shape[0])).unsqueeze(1)
+        x, mask = self.conv_input.run_dense(x, mask)
+        for stage in (self.conv1, self.conv2, self.conv3, self.conv4):
+            for blk in stage:
+                x, mask = blk.run_dense(x, mask)
+        x, mask = self.conv_out.run_dense(x, mask)
+        batch_dict.update({"encoded_spconv_tensor": _DenseResult(x), "encoded_spconv_tensor_stride": 8})
+        return batch_dict
 
     def forward(self, batch_dict):
         from heal_amd.ops import SparseTensor

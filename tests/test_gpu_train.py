@@ -172,6 +172,35 @@ def test_warp_fuse_backward_kernel_vs_torch_autograd(n, f64, with_crop):
     assert float((occ.grad - go_ref).abs().max()) <= 1e-4 * float(go_ref.abs().max())
 
 
+def test_second_gradient_path_equals_sparse_kernels():
+    """SECOND on the gradient path (dense masked conv3d) against the inference path (K3: rulebooks + gather-GEMM kernels) on a
+    small grid: the same BEV map within 1e-3 of its scale, and the same set of non-zero cells."""
+    from heal_amd import configs
+    from heal_amd.opencood.models.heter_encoders import SECOND
+    from tests.golden.detfill import fill_module
+    rng = [-6.4, -6.4, -3, 6.4, 6.4, 1]
+    enc = fill_module(SECOND(configs._second_modality(rng)["encoder_args"])).cuda().train()
+    for mod in enc.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.eval()
+    g = np.random.default_rng(9)
+    B, D, H, W = 2, 40, 128, 128
+    flat = g.choice(B * D * H * W, size=3000, replace=False)
+    coords = np.stack(np.unravel_index(flat, (B, D, H, W)), 1).astype(np.int32)
+    coords = coords[np.argsort(coords[:, 0], kind="stable")]
+    num = g.integers(1, 6, size=coords.shape[0]).astype(np.int32)
+    voxels = g.standard_normal((coords.shape[0], 5, 4)).astype(np.float32) * (np.arange(5)[None, :, None] < num[:, None, None])
+    data = {"inputs_m3": {"voxel_features": torch.from_numpy(voxels).cuda(), "voxel_coords": torch.from_numpy(coords).cuda(),
+                          "voxel_num_points": torch.from_numpy(num).cuda(), "n_agents": B}}
+    ref = enc(data, "m3")
+    assert ref.requires_grad
+    with torch.no_grad():
+        got = enc.eval()(data, "m3")
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-3
+    assert int(((got != 0) != (ref != 0)).sum()) == 0
+
+
 def test_inference_operator_refuses_autograd_activations():
     """An activation with autograd history must never reach a HIP operator silently (its result would drop out of the graph)."""
     from heal_amd import _capi, ops
