@@ -316,6 +316,334 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
     }
 }
 
+// ---- gather-GEMM, round 3: pair-compacted tiles ----------------------------------------------------------------------
+// The round-1/2 kernel above multiplies a block's 32 sites through EVERY tap that any of them has (13.3 of 27 taps are real on
+// 64-line sweeps: half of the matrix-core work was zero rows) and walks gather -> LDS -> MFMA as one serial chain per wave.
+// This formulation:
+//   * a block owns M consecutive output sites.  For each tap the (input row, local output) pairs that EXIST are compacted
+//     (wave ballot + prefix popcount) into an LDS list and cut into tiles of 16 pairs; only real pairs (plus < 16 pad rows per
+//     tap) reach the matrix cores;
+//   * a stage = TPS tiles.  All 256 threads gather the stage's input rows (16-B loads, one row = CIN*4 contiguous bytes) into
+//     registers WHILE the previous stage is multiplied, then drop them into the other half of a double-buffered LDS tile: one
+//     block barrier per stage, global latency off the critical path;
+//   * work unit = (tile, 16 output channels).  Wave w takes units w, w+4, ...: with >= 64 output channels a wave owns its
+//     channel slices exclusively (the tap's weight slice is read once per block, straight from the reference [K,Cin,Cout]
+//     layout into B fragments, kept while the tap does not change); narrower layers give each group of waves its own copy of
+//     the accumulator tile, summed in a fixed order at the end;
+//   * a tile's 16 x 16 result rows belong to 16 DIFFERENT output sites: they are added (ds_add_f32, no return) to the block's
+//     [M, COUT] accumulator in LDS.  No two waves ever add to the same word and a wave's LDS operations execute in order, so the
+//     summation order is a fixed function of the input: bit-reproducible, no cross-wave atomics;
+//   * A fragments with ONE ds_read_b128 per four k-steps: lane (row, g) reads channels 16j+4g..+3, i.e. k-step (j,i) multiplies
+//     channel 16j+4g+i -- a permutation of the reduction order that the B fragment loads mirror; row stride CIN+8 words makes
+//     the 16-lane groups of a b128 read conflict-free;
+//   * BatchNorm scale/shift + ReLU and 16-B coalesced row stores in the epilogue.
+__device__ unsigned long long g_sp_prof[16];
+#define HEAL_SP_T(k_)                                                                     \
+    if constexpr (DBG & 32) {                                                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
+        const unsigned long long now_ = __builtin_readcyclecounter();                     \
+        tprof[k_] += now_ - tlast;                                                        \
+        tlast = now_;                                                                     \
+    }
+#define HEAL_SP_TL(k_)                                                                    \
+    if constexpr (DBG & 32) {                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();                     \
+        tprof[k_] += now_ - tlast;                                                        \
+        tlast = now_;                                                                     \
+    }
+template <int V> struct ILog2 { static constexpr int v = 1 + ILog2<V / 2>::v; };
+template <> struct ILog2<1> { static constexpr int v = 0; };
+
+template <int CIN, int COUT, int M, int TPS, int DB /*double-buffered gather tile*/, int DBG = 0>
+__global__ __launch_bounds__(256) void k_sp_conv2(const float* __restrict__ feat_in, const int* __restrict__ nbr,
+                                                  int out_cap, const int* __restrict__ n_dev, int K,
+                                                  const float* __restrict__ wfrag /*heal_sp_weight_fragments*/,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  int relu, float* __restrict__ feat_out /*[n_out][COUT]*/) {
+    static_assert(CIN % 4 == 0 && (CIN < 16 || CIN % 16 == 0) && COUT % 16 == 0 && M % 64 == 0, "shape");
+    constexpr int LB = ILog2<M>::v;              // pair word = (input row << LB) | local output site
+    constexpr int KC = CIN / 4;                  // k-steps
+    constexpr int J = CIN >= 16 ? CIN / 16 : 0;  // b128 fragment reads per tile (wide rows)
+    constexpr int JW = CIN >= 16 ? J : 1;        // 16-B weight fragment registers per set
+    constexpr int NC = COUT / 16;                // 16-channel output slices
+    constexpr int COPIES = NC >= 4 ? 1 : 4 / NC; // accumulator copies (narrow layers: one per group of waves)
+    constexpr int UNITS = TPS * NC;
+    static_assert(UNITS % 4 == 0 && (NC >= 4 ? NC % 4 == 0 : 4 % NC == 0), "unit split");
+    constexpr int UPW = UNITS / 4;               // units per wave and stage
+    constexpr int ROWS = TPS * 16;               // gathered rows per stage
+    constexpr int CPR = CIN / 4;                 // 16-B chunks per row
+    constexpr int CHUNKS = ROWS * CPR;
+    static_assert(CHUNKS % 256 == 0, "gather split");
+    constexpr int CPT = CHUNKS / 256;            // DMA instructions per wave and stage
+    constexpr int CH = M / 64;                   // 64-site chunks of the block
+    constexpr int TPT = M / 16;                  // tiles per tap, worst case
+    constexpr int MAXT = 27 * TPT;               // tiles, worst case
+    constexpr uint32_t PAD = 0xFFFFFFFFu;
+    constexpr int RSA = COUT + 4;                // accumulator row stride (words): 16-B slots of different rows spread over the banks
+
+    __shared__ uint32_t s_pair[27 * M + 16 * 3 * TPS];
+    __shared__ __attribute__((aligned(16))) float s_acc[COPIES * M * RSA];
+    __shared__ __attribute__((aligned(1024))) float s_A[(DB ? 2 : 1) * ROWS * CIN];
+    __shared__ int s_tap[MAXT + 3 * TPS];        // tap of every tile
+    __shared__ int s_cnt[32];
+
+    const int n_out = live_rows(n_dev, out_cap);
+    // XCD-contiguous site ranges: neighbouring blocks share gathered rows, keep them in one L2
+    const unsigned nb_ = gridDim.x, q_ = nb_ >> 3, r_ = nb_ & 7u, x_ = blockIdx.x & 7u;
+    const int blk = (int)((x_ < r_ ? x_ * (q_ + 1) : r_ * (q_ + 1) + (x_ - r_) * q_) + (blockIdx.x >> 3));
+    const int site0 = blk * M;
+    if (site0 >= n_out) return;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int g = l >> 4, ln = l & 15;
+    const int swz = (ln * CPR) >> 4;             // XOR swizzle of the 16-B chunks of gathered row ln (see the gather)
+
+    // ---- zero the accumulator tile(s) ------------------------------------------------------------------------------
+    for (int i = tid; i < COPIES * M * RSA / 4; i += 256)
+        reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- compact the (input row, local site) pairs of every tap, tap after tap, each tap padded to whole tiles -------
+    // pass 1: neighbour ids -> registers, pair counts per tap; pass 2 (after the prefix sum over the taps): the lists.
+    // Tile t is then simply s_pair[16 t .. 16 t + 15], a stage the TPS tiles behind tile stage * TPS (taps may change inside a
+    // stage: strided layers have a handful of pairs per tap).
+    int T;
+    {
+        int v[7][CH];
+#pragma unroll
+        for (int ti = 0; ti < 7; ++ti) {
+            const int t = wave + 4 * ti;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int site = site0 + c * 64 + l;
+                v[ti][c] = (t < K && site < n_out) ? nbr[(size_t)site * K + t] : -1;
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 7; ++ti) {
+            const int t = wave + 4 * ti;
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) cnt += __popcll(__ballot(v[ti][c] >= 0));
+            if (t < K && l == 0) s_cnt[t] = cnt;
+        }
+        __syncthreads();
+        const int mine = l < K ? (s_cnt[l] + 15) >> 4 : 0;       // tiles of tap l
+        const int incl = wave_incl_scan(mine);
+        T = __shfl(incl, 63, 64);
+#pragma unroll
+        for (int ti = 0; ti < 7; ++ti) {
+            const int t = wave + 4 * ti;
+            if (t < K) {
+                const int nt = __shfl(mine, t, 64), t0 = __shfl(incl, t, 64) - nt;   // first tile of tap t
+                int base = 16 * t0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const unsigned long long have = __ballot(v[ti][c] >= 0);
+                    if (v[ti][c] >= 0)
+                        s_pair[base + __popcll(have & lanemask_lt())] = ((uint32_t)v[ti][c] << LB) | (uint32_t)(c * 64 + l);
+                    base += __popcll(have);
+                }
+                if (l < 16 && base + l < 16 * (t0 + nt)) s_pair[base + l] = PAD;
+                if (l < nt) s_tap[t0 + l] = t;
+            }
+        }
+        // the missing tiles of the last stage + the two stages past the end that the prefetches touch: all-pad tiles of the
+        // last tap (no weight reload)
+        if (wave == 3) {
+            const int last_tap = 63 - __builtin_clzll(__ballot(mine > 0) | 1ull);
+            for (int i = l; i < 16 * 3 * TPS; i += 64) s_pair[16 * T + i] = PAD;
+            if (l < 3 * TPS) s_tap[T + l] = last_tap;
+        }
+    }
+    __syncthreads();
+    const int n_stages = (T + TPS - 1) / TPS;
+
+    // ---- the gather: global -> LDS by DMA -----------------------------------------------------------------------------------
+    // global_load_lds_dwordx4: no staging registers, no ds_write pass, in flight during the MFMAs.  Instruction k = wave + 4 i
+    // of a stage writes the 1 KiB behind tile byte 1024 k, lane L its 16 B number L -- row (64 k + L) / CPR, slot L % CPR.  The
+    // LDS image is lane-linear, so the bank-conflict fix is an XOR swizzle applied on the SOURCE side (the lane fetches chunk
+    // slot ^ f(row)) and again on the fragment reads.  Pad rows and the stages past the end read row 0; their products are
+    // never accumulated.  The source rows of a stage are looked up one stage before its loads are issued.
+    // The DMA and the weight loads are issued from asm statements on purpose: hipcc's waitcnt pass treats a counted
+    // global_load_lds as a possible writer of every LDS word and as a reason to drain vmcnt(0) at the next use of ANY ordinary
+    // load, and a counted load behind a branch made it wait in the middle of the MFMA sequence.  Hidden from it, they cost no
+    // wait until the explicit vmcnt(0) in front of the stage's closing barrier.  The DMA has no VGPR destination; the weight
+    // registers are only read behind HEAL_SP_W_WAIT, which takes them "+v".  M0 is saved and restored inside the statement.
+    int g_row[CPT];
+    uint32_t g_src[CPT], g_chunk[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        g_row[i] = (64 * (wave + 4 * i) + l) / CPR;
+        g_chunk[i] = (uint32_t)((l % CPR) ^ (((g_row[i] & 15) * CPR) >> 4));
+    }
+    const uint32_t sA_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)s_A;
+#define HEAL_SP_GATHER_INDEX(stage)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                                                  \
+        const uint32_t e_ = s_pair[(stage) * ROWS + g_row[i]];                                                         \
+        g_src[i] = e_ == PAD ? 0u : e_ >> LB;                                                                          \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < UPW; ++q)                                                                    \
+        tapn[q] = __builtin_amdgcn_readfirstlane(s_tap[(stage) * TPS + (wave + 4 * q) / NC]);
+#define HEAL_SP_GATHER_ISSUE(buf_)                                                                                     \
+    if constexpr (!(DBG & 2)) {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                                              \
+            const float* gsrc_ = feat_in + (size_t)g_src[i] * CIN + g_chunk[i] * 4;                                    \
+            const uint32_t dst_ = __builtin_amdgcn_readfirstlane(sA_lds + (uint32_t)(((buf_) * ROWS * CIN + (wave + 4 * i) * 256) * 4)); \
+            uint32_t keep_;                                                                                            \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                         : "=&s"(keep_) : "v"(gsrc_), "s"(dst_) : "memory");                                           \
+        }                                                                                                              \
+    }
+// (counted forms -- the weight loads left in flight across the barrier, vmcnt(CPT) in front of the MFMAs -- measured slower than
+// one drain at the end of the stage: both prefetches have had the whole stage to land by then)
+#define HEAL_SP_VMCNT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+    // weight fragments of unit c for tap `tap_` (channel slice nb = (wave + 4 c) % NC): lane (cout ln, k-group g) holds
+    // W[tap][kperm(step, g)][16 nb + ln], pre-laid by heal_sp_weight_fragments as [tap][nb][j][lane][4] (16-B loads, 1 KiB
+    // contiguous per instruction)
+#define HEAL_SP_LOAD_W(dst_, c, tap_)                                                                                  \
+    {                                                                                                                  \
+        const float* wt_ = wfrag + ((size_t)(tap_) * NC + (wave + 4 * (c)) % NC) * (CIN * 16) + l * (CIN >= 16 ? 4 : KC); \
+        if constexpr (CIN >= 16) {                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < J; ++j)                                                              \
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_[c][j]) : "v"(wt_ + j * 256) : "memory");    \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < KC; ++kc)                                                          \
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dst_##s[c][kc]) : "v"(wt_ + kc) : "memory");       \
+        }                                                                                                              \
+    }
+    // (every asm destination is a WHOLE register variable: an element of a vector would make the compiler copy the scalar asm
+    // output into the vector right behind the load, i.e. read the register before the data has landed)
+#define HEAL_SP_W_WAIT(w_, c, n_)                                                                                     \
+    if constexpr (CIN >= 16) {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < JW; ++j)                                                                \
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w_[c][j]) : "n"(n_) : "memory");                                \
+    } else {                                                                                                          \
+        _Pragma("unroll") for (int kc = 0; kc < KC; ++kc)                                                             \
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w_##s[c][kc]) : "n"(n_) : "memory");                            \
+    }
+    constexpr int NWL = (DBG & 8) ? 0 : UPW * (CIN >= 16 ? J : KC);   // weight load instructions per stage
+
+    f32x4 wfr[UPW][JW], wnx[UPW][JW];   // wide layers: 16-B fragment registers, one set per unit (wnx: the asm destinations)
+    float wfrs[UPW][KC], wnxs[UPW][KC]; // CIN < 16: KC <= 2 scalars
+    int tapn[UPW];                      // taps of the next stage's tiles
+    const int copy = NC >= 4 ? 0 : wave / NC;
+    float* acc_base = s_acc + (size_t)copy * M * RSA;
+
+    // Every asm load and its wait statement sit inside ONE loop iteration: a loop-carried asm destination would get a compiler
+    // copy on the back edge, i.e. a read of the register before its data has landed.
+    f32x4 acc[UPW];
+    float xfr[UPW][KC];
+    uint32_t lw[UPW];
+    // fragments of the gathered rows of `stage_` (LDS buffer buf_), the pair words of this wave's tiles
+#define HEAL_SP_READ_STAGE(stage_, buf_)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < UPW; ++q) {                                                                  \
+        const int ti = (wave + 4 * q) / NC;                                                                            \
+        const float* a = &s_A[((buf_) * ROWS + ti * 16 + ln) * CIN];                                                   \
+        if constexpr (CIN >= 16) {                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < J; ++j) {                                                            \
+                const float4 t4 = *reinterpret_cast<const float4*>(a + (((4 * j + g) ^ swz) << 2));                    \
+                xfr[q][4 * j] = t4.x; xfr[q][4 * j + 1] = t4.y; xfr[q][4 * j + 2] = t4.z; xfr[q][4 * j + 3] = t4.w;    \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < KC; ++kc) xfr[q][kc] = a[((kc ^ swz) << 2) + g];                   \
+        }                                                                                                              \
+        lw[q] = s_pair[((stage_) * TPS + ti) * 16 + ln];                                                               \
+    }
+    // MFMAs (the units of a wave are independent accumulator chains).  D^T[cout][pair] = W^T X^T: weights are the A operand,
+    // gathered rows the B operand, so a lane ends up with FOUR consecutive output channels of ONE pair = one 16-B
+    // read-modify-write of the accumulator row.  Units beyond the last stage's tiles multiply pad rows; nothing of them is kept.
+#define HEAL_SP_MFMA_STAGE()                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < UPW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};                              \
+    _Pragma("unroll") for (int kc = 0; kc < KC; ++kc)                                                                  \
+        _Pragma("unroll") for (int q = 0; q < UPW; ++q) {                                                              \
+            const float wv = CIN >= 16 ? wfr[q][CIN >= 16 ? kc / 4 : 0][kc % 4] : wfrs[q][kc % KC];                    \
+            if constexpr (DBG & 4) acc[q][0] += xfr[q][kc] * wv;                                                       \
+            else acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xfr[q][kc], acc[q], 0, 0, 0);                       \
+        }
+    // the gathered rows of the stage whose source rows g_src holds; single buffer: every wave must hold its fragments first
+#define HEAL_SP_NEXT_GATHER(buf_)                                                                                      \
+    if constexpr (DB) {                                                                                                \
+        HEAL_SP_GATHER_ISSUE(buf_)                                                                                     \
+    } else {                                                                                                           \
+        lds_barrier();                                                                                                 \
+        HEAL_SP_GATHER_ISSUE(0)                                                                                        \
+    }
+    // the prefetched weights have landed -> the MFMA operand registers
+#define HEAL_SP_TAKE_W()                                                                                               \
+    if constexpr (NWL) {                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < UPW; ++q) {                                                              \
+            HEAL_SP_W_WAIT(wnx, q, 0)                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < JW; ++j) wfr[q][j] = wnx[q][j];                                      \
+            _Pragma("unroll") for (int kc = 0; kc < KC; ++kc) wfrs[q][kc] = wnxs[q][kc];                               \
+        }                                                                                                              \
+    }
+
+    HEAL_SP_GATHER_INDEX(0)
+    HEAL_SP_GATHER_ISSUE(0)
+    if constexpr (NWL) {
+#pragma unroll
+        for (int q = 0; q < UPW; ++q) HEAL_SP_LOAD_W(wnx, q, tapn[q])
+    }
+    HEAL_SP_GATHER_INDEX(1)
+    HEAL_SP_VMCNT(0);
+    HEAL_SP_TAKE_W()
+    lds_barrier();
+    for (int s = 0; s < ((DBG & 16) ? 0 : n_stages); ++s) {
+        const int buf = DB ? (s & 1) : 0;
+        HEAL_SP_READ_STAGE(s, buf)
+        // ---- prefetch for stage s+1: the weight fragments of its taps, then the gathered rows.  The weight loads are
+        // unconditional: a tap that stays is an L1 hit, and every conditional form measured slower than the reload
+        if constexpr (NWL) {
+#pragma unroll
+            for (int q = 0; q < UPW; ++q) HEAL_SP_LOAD_W(wnx, q, tapn[q])
+        }
+        HEAL_SP_NEXT_GATHER(buf ^ 1)
+        HEAL_SP_MFMA_STAGE()
+        HEAL_SP_GATHER_INDEX(s + 2)
+        // ---- add the tiles' rows to the block accumulator (exclusive owner: plain read-modify-write, in program order) ------------
+#pragma unroll
+        for (int q = 0; q < UPW; ++q) {
+            const int nb = (wave + 4 * q) % NC;
+            if (lw[q] != PAD && !(DBG & 1)) {
+                float4* p = reinterpret_cast<float4*>(&acc_base[(lw[q] & (uint32_t)(M - 1)) * RSA + nb * 16 + 4 * g]);
+                float4 o = *p;
+                o.x += acc[q][0]; o.y += acc[q][1]; o.z += acc[q][2]; o.w += acc[q][3];
+                *p = o;
+            }
+            if ((DBG & 1) && acc[q][0] == 12345.678f) acc_base[0] = 1.f;
+        }
+        HEAL_SP_VMCNT(0);   // the DMA of stage s+1 and its weights
+        HEAL_SP_TAKE_W()
+        lds_barrier();
+    }
+#undef HEAL_SP_READ_STAGE
+#undef HEAL_SP_MFMA_STAGE
+#undef HEAL_SP_NEXT_GATHER
+#undef HEAL_SP_TAKE_W
+    // ---- epilogue: sum the copies in a fixed order, BatchNorm1d (eval) + ReLU, 16-B row stores -----------------------------
+    constexpr int C4 = COUT / 4;
+    for (int i = tid; i < M * C4; i += 256) {
+        const int m = i / C4, c4 = i - m * C4;
+        const int site = site0 + m;
+        if (site >= n_out) break;
+        float4 v = *reinterpret_cast<const float4*>(&s_acc[m * RSA + c4 * 4]);
+#pragma unroll
+        for (int k = 1; k < COPIES; ++k) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[(k * M + m) * RSA + c4 * 4]);
+            v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+        }
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(feat_out + (size_t)site * COUT + c4 * 4) = v;
+    }
+#undef HEAL_SP_GATHER_INDEX
+#undef HEAL_SP_GATHER_ISSUE
+#undef HEAL_SP_VMCNT
+#undef HEAL_SP_LOAD_W
+#undef HEAL_SP_W_WAIT
+}
+
 // ---- sparse -> dense BEV ([B, C*D, H, W], channel = c*D + z : height_compression.py:21-23) ------------
 __global__ __launch_bounds__(256) void k_sp_fill_map(const int4* __restrict__ idx, int cap,
                                                     const int* __restrict__ n_dev, SpShape s,
@@ -507,10 +835,51 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
 
 // out[o] = act( BN( sum_tap W[tap]^T in[nbr[o][tap]] ) ); weight [K][Cin][Cout].
 extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in,
-                            int c_out, const float* weight, const float* bn_scale, const float* bn_shift,
-                            int relu, float* feat_out, const int32_t* n_out_dev, void* stream) {
+                            int c_out, const float* weight, const float* weight_frag, const float* bn_scale,
+                            const float* bn_shift, int relu, float* feat_out, const int32_t* n_out_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n_out <= 0) return 0;
+    // Round 3: pair-compacted tiles (k_sp_conv2).  HEAL_SP_CONV=v1 keeps the round-2 kernel for A/B; HEAL_SP_M / HEAL_SP_TPS
+    // select among the instantiated block shapes (tuning only).
+    const char* mode = getenv("HEAL_SP_CONV");
+    const int env_m = getenv("HEAL_SP_M") ? atoi(getenv("HEAL_SP_M")) : 0;
+    if (weight_frag && !(mode && mode[0] == 'v' && mode[1] == '1') && kernel_volume <= 27) {
+        const int env_tx = getenv("HEAL_SP_TPSX") ? atoi(getenv("HEAL_SP_TPSX")) : 0;
+        const int env_db = getenv("HEAL_SP_DB") ? atoi(getenv("HEAL_SP_DB")) : -1;
+        const int dbg = getenv("HEAL_SP_DBG") ? atoi(getenv("HEAL_SP_DBG")) : 0;
+#define HEAL_SP2(CI, CO, MM, TT, DD, GG)                                                                                 \
+    {                                                                                                                    \
+        k_sp_conv2<CI, CO, MM, TT, DD, GG><<<ceil_div(n_out, MM), 256, 0, s>>>(feat_in, nbr, n_out, n_out_dev,           \
+                                                                          kernel_volume, weight_frag, bn_scale, bn_shift, \
+                                                                          relu, feat_out);                               \
+        HEAL_LAUNCH_CHECK();                                                                                             \
+        return 0;                                                                                                        \
+    }
+#define HEAL_SP2_CASE(CI, CO, TT, DEF_M, DEF_TX, DEF_DB)                                          \
+    if (c_in == CI && c_out == CO) {                                                              \
+        const int m_ = env_m ? env_m : DEF_M, tx_ = env_tx ? env_tx : DEF_TX;                     \
+        const int db_ = env_db >= 0 ? env_db : DEF_DB;                                            \
+        if (m_ == 64 && tx_ == 1 && db_ == 0) HEAL_SP2(CI, CO, 64, TT, 0, 0)                      \
+        if (m_ == 64 && tx_ == 1 && db_ == 1) HEAL_SP2(CI, CO, 64, TT, 1, 0)                      \
+        if (m_ == 64 && tx_ == 2 && db_ == 0) HEAL_SP2(CI, CO, 64, 2 * TT, 0, 0)                  \
+        if (m_ == 64 && tx_ == 2 && db_ == 1) HEAL_SP2(CI, CO, 64, 2 * TT, 1, 0)                  \
+        if (m_ == 128 && tx_ == 1 && db_ == 0) HEAL_SP2(CI, CO, 128, TT, 0, 0)                    \
+        if (m_ == 128 && tx_ == 1 && db_ == 1) HEAL_SP2(CI, CO, 128, TT, 1, 0)                    \
+        if (m_ == 128 && tx_ == 2 && db_ == 0) HEAL_SP2(CI, CO, 128, 2 * TT, 0, 0)                \
+        if (m_ == 128 && tx_ == 2 && db_ == 1) HEAL_SP2(CI, CO, 128, 2 * TT, 1, 0)                \
+    }
+#define HEAL_SP2D(D) if (dbg == D && c_in == 64 && c_out == 64) HEAL_SP2(64, 64, 64, 2, 0, D)
+        HEAL_SP2D(1) HEAL_SP2D(2) HEAL_SP2D(4) HEAL_SP2D(7) HEAL_SP2D(3) HEAL_SP2D(16) HEAL_SP2D(32) HEAL_SP2D(8) HEAL_SP2D(15) HEAL_SP2D(10) HEAL_SP2D(40)
+#undef HEAL_SP2D
+        // defaults from the sweep on the 8-agent SECOND encoder (profiles/r03_k3_sweep.json): 64 sites per block, 32 pairs x
+        // 64 channels of gathered rows per stage, single-buffered gather tile (4 blocks per CU)
+        HEAL_SP2_CASE(4, 16, 16, 64, 1, 0) HEAL_SP2_CASE(16, 16, 8, 64, 1, 0) HEAL_SP2_CASE(16, 32, 8, 64, 1, 0)
+        HEAL_SP2_CASE(32, 32, 4, 64, 1, 0) HEAL_SP2_CASE(32, 64, 4, 64, 1, 0) HEAL_SP2_CASE(64, 64, 2, 64, 1, 0)
+        HEAL_SP2_CASE(64, 128, 2, 64, 1, 0)
+#undef HEAL_SP2_CASE
+#undef HEAL_SP2
+    }
+    HEAL_REQUIRE(weight != nullptr, "sp_conv: no reference-layout weight for the round-2 kernel (channels %d -> %d)", c_in, c_out);
     // Block shape sweep on MI355X (SECOND encoder, 43 k voxels, 64->64 layers): 32 sites x 4 tap-waves 97 us;
     // 16 sites x 4: 190 (weight fragments re-read twice as often); 64 sites x 4: 140 (occupancy 2); 32 sites x 8: 106.
     const int blocks = ceil_div(n_out, 32);
@@ -525,6 +894,44 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
     HEAL_SP_CASE(64, 64) HEAL_SP_CASE(64, 128) HEAL_SP_CASE(8, 16) HEAL_SP_CASE(64, 16)
 #undef HEAL_SP_CASE
     return set_error("sp_conv: channel combination %d -> %d is not instantiated", c_in, c_out);
+}
+
+// weight [K][CIN][COUT] -> the B-fragment order of k_sp_conv2 (same size).  CIN >= 16: [tap][nb][j][lane = 16 g + ln][i] =
+// W[tap][16 j + 4 g + i][16 nb + ln]; CIN < 16: [tap][nb][lane][kc] = W[tap][4 kc + g][16 nb + ln].
+__global__ __launch_bounds__(256) void k_sp_weight_frag(const float* __restrict__ w, int K, int cin, int cout,
+                                                       float* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= K * cin * cout) return;
+    const int per_tap = cin * cout, tap = t / per_tap;
+    int r = t - tap * per_tap;
+    const int nb = r / (cin * 16);
+    r -= nb * cin * 16;
+    int k, ln;
+    if (cin >= 16) {
+        const int j = r / 256, lane = (r >> 2) & 63, i = r & 3;
+        k = 16 * j + 4 * (lane >> 4) + i;
+        ln = lane & 15;
+    } else {
+        const int kc_n = cin / 4, lane = r / kc_n, kc = r - lane * kc_n;
+        k = 4 * kc + (lane >> 4);
+        ln = lane & 15;
+    }
+    out[t] = w[((size_t)tap * cin + k) * cout + nb * 16 + ln];
+}
+
+extern "C" int heal_sp_weight_fragments(const float* weight, int kernel_volume, int c_in, int c_out, float* out,
+                                        void* stream) {
+    HEAL_REQUIRE(kernel_volume >= 1 && c_in >= 4 && c_in % 4 == 0 && (c_in < 16 || c_in % 16 == 0) && c_out % 16 == 0,
+                 "sp_weight_fragments: unsupported channels %d -> %d", c_in, c_out);
+    const int n = kernel_volume * c_in * c_out;
+    k_sp_weight_frag<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(weight, kernel_volume, c_in, c_out, out);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_sp_debug_profile(unsigned long long* out16) {
+    HEAL_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sp_prof), sizeof(unsigned long long) * 16));
+    return 0;
 }
 
 extern "C" size_t heal_sp_to_bev_workspace(int batch, int D, int H, int W) {

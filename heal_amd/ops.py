@@ -638,6 +638,26 @@ def mean_vfe(voxels, num_points, n_dev=None):
     return out
 
 
+_SP_FRAGS = {}
+
+
+def sp_weight_fragments(weight):
+    """[K,Cin,Cout] -> the fragment order of the pair-compacted kernel (heal_sp_weight_fragments), cached per weight version
+    (a handful of entries: the 12 layers of the encoder).  None when the channel counts have no fragment form."""
+    K, cin, cout = (int(v) for v in weight.shape)
+    if cin % 4 or (cin >= 16 and cin % 16) or cout % 16 or cin < 4 or int(weight.shape[0]) > 27:
+        return None
+    key = (weight.data_ptr(), weight._version, K, cin, cout, str(weight.device))
+    hit = _SP_FRAGS.get(key)
+    if hit is None:
+        if len(_SP_FRAGS) > 256:
+            _SP_FRAGS.clear()
+        out = torch.empty_like(weight)
+        _capi.call("heal_sp_weight_fragments", _ptr(weight), K, cin, cout, _ptr(out), _stream())
+        hit = _SP_FRAGS[key] = (out, weight)  # keeps the source alive: data_ptr stays unique while cached
+    return hit[0]
+
+
 class SparseTensor:
     """features [n,C] f32 + indices [n,4] i32 (b,z,y,x) sorted by linear coordinate + shape (D,H,W).
 
@@ -730,12 +750,13 @@ class SparseTensor:
         """Gather-GEMM: weight [K,Cin,Cout]; returns features [n_out,Cout]."""
         weight = _need(weight, torch.float32, "weight")
         K, cin, cout = (int(v) for v in weight.shape)
+        frag = sp_weight_fragments(weight)
         n_out = int(nbr.shape[0])
         out = torch.empty((n_out, cout), dtype=torch.float32, device=nbr.device)
         # SURVEY 8d, K3 per layer: 4 (N_in C_in + N_out C_out) + 4 K C_in C_out + 8 R bytes, 2 R C_in C_out flops; with device
         # row counts the host only knows capacities: bench.py fills in the live N_in / N_out / R of its instrumented pass
         with _Timed(f"sp_conv_{cin}_{cout}") as tm:
-            _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight),
+            _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight), _optr(frag),
                        _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
                        int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
         if SP_TRACE is not None and TIMING is not None:

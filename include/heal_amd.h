@@ -245,10 +245,16 @@ int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int32_t* ksize_
                       const int32_t* out_shape_host, int batch, int32_t* out_indices, int out_cap,
                       int32_t* n_out, void* ws, size_t ws_bytes, const int32_t* n_in_dev, void* stream);
 /* feat_out[o] = act(bn_scale * sum_tap W[tap]^T feat_in[nbr[o][tap]] + bn_shift); weight [K,Cin,Cout]
- * (spconv 1.2.1 layout [kz,ky,kx,Cin,Cout]); fp32 MFMA, fixed summation order                       */
+ * (spconv 1.2.1 layout [kz,ky,kx,Cin,Cout]); fp32 MFMA, fixed summation order (bit-reproducible).
+ * weight_frag: the same weights re-laid once by heal_sp_weight_fragments (same element count) -- selects the
+ * pair-compacted kernel (only real (tap, site) pairs reach the matrix cores); NULL = round-2 kernel on `weight`.
+ * Either pointer may be NULL, not both.  n_in rows must be < 2^24.                                   */
+int heal_sp_weight_fragments(const float* weight, int kernel_volume, int c_in, int c_out, float* out, void* stream);
 int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in, int c_out,
-                 const float* weight, const float* bn_scale, const float* bn_shift, int relu,
-                 float* feat_out, const int32_t* n_out_dev, void* stream);
+                 const float* weight, const float* weight_frag, const float* bn_scale, const float* bn_shift,
+                 int relu, float* feat_out, const int32_t* n_out_dev, void* stream);
+/* tuning aid (cycle counters of one block of the instrumented kernel variant) */
+int heal_sp_debug_profile(unsigned long long* out16);
 size_t heal_sp_to_bev_workspace(int batch, int D, int H, int W);
 int heal_sp_to_bev(const float* features, const int32_t* indices, int n, int channels,
                    const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes,

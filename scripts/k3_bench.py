@@ -1,0 +1,134 @@
+"""K3 at BASELINE config 5 scale: the 12 sparse layers of VoxelBackBone8x on 8 collated 64-line sweeps (about 343 k voxels),
+layer by layer, with HIP events.  For every layer: live N_in / N_out / rule pairs R, time of `heal_sp_conv`, useful TFLOP/s and
+algorithmic GB/s, and the result compared with the round-2 kernel (HEAL_SP_CONV=v1) on the same inputs.
+Also times the rulebook entry points (sort, hash, out_sites, neighbors).
+
+    python scripts/k3_bench.py [--agents 8] [--iters 20] [--json out.json] [--modes v1,v2,v2m64]
+"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from heal_amd import configs, ops, synth
+
+LAYERS = [  # (cin, cout, ksize, stride, padding, subm, key)
+    (4, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm1"), (16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm1"),
+    (16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), False, None), (32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm2"),
+    (32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm2"), (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), False, None),
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm3"), (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm3"),
+    (64, 64, (3, 3, 3), (2, 2, 2), (0, 1, 1), False, None), (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm4"),
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm4"), (64, 64, (3, 1, 1), (2, 1, 1), (0, 0, 0), False, None)]
+
+
+def timed(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return out, e0.elapsed_time(e1) * 1e3 / iters
+
+
+def set_mode(mode):
+    """v1 | v2 | v2:m64,t2,d0 (block sites M, stage-size multiplier, double-buffered gather tile)"""
+    for k in ("HEAL_SP_CONV", "HEAL_SP_M", "HEAL_SP_TPSX", "HEAL_SP_DB"):
+        os.environ.pop(k, None)
+    if mode == "v1":
+        os.environ["HEAL_SP_CONV"] = "v1"
+    elif ":" in mode:
+        for kv in mode.split(":")[1].split("."):
+            os.environ[{"m": "HEAL_SP_M", "t": "HEAL_SP_TPSX", "d": "HEAL_SP_DB"}[kv[0]]] = kv[1:]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--modes", default="v1,v2")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--brief", action="store_true")
+    a = ap.parse_args()
+    modes = a.modes.split(",")
+    dev = torch.device("cuda:0")
+    R = configs.FULL_RANGE
+    vs, cs, ns = [], [], []
+    for b in range(a.agents):
+        pts = torch.from_numpy(synth.lidar_frame(4000 + b)).to(dev)
+        v, c, n = ops.voxelize(pts, R, [0.1, 0.1, 0.1], 5, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    v, c, n = torch.cat(vs), torch.cat(cs), torch.cat(ns)
+    feats = ops.mean_vfe(v, n)
+    rb = {}
+    x, rb["sort_sites"] = timed(lambda: ops.SparseTensor.from_unsorted(feats, c, [41, 2048, 2048], a.agents), 5)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    cache, rows, total = {}, [], {m: 0.0 for m in modes}
+    rb["hash+nbr"], rb["out_sites"] = 0.0, 0.0
+    for li, (cin, cout, k, st, pd, subm, key) in enumerate(LAYERS):
+        K = k[0] * k[1] * k[2]
+        w = (torch.randn((K, cin, cout), generator=gen) / np.sqrt(K * cin / 2)).to(dev)
+        sc = torch.empty(cout).uniform_(0.8, 1.2, generator=gen).to(dev)
+        sh = torch.empty(cout).normal_(0, 0.1, generator=gen).to(dev)
+        if subm:
+            if key not in cache:
+                x._table = None
+                nbr, t = timed(lambda: (setattr(x, "_table", None), x.neighbors(x.indices, x.spatial_shape, k, (1, 1, 1),
+                                                                               tuple(q // 2 for q in k)))[1], 5)
+                rb["hash+nbr"] += t
+                cache[key] = nbr
+            nbr = cache[key]
+            oi, oshape = x.indices, x.spatial_shape
+        else:
+            (oi, oshape, _), t = timed(lambda: x.out_sites(k, st, pd), 5)
+            rb["out_sites"] += t
+            x._table = None
+            nbr, t = timed(lambda: (setattr(x, "_table", None), x.neighbors(oi, oshape, k, st, pd))[1], 5)
+            rb["hash+nbr"] += t
+        Rp = int((nbr >= 0).sum().item())
+        n_in, n_out = x.n, int(oi.shape[0])
+        flops = 2.0 * Rp * cin * cout
+        nbytes = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * Rp
+        row = {"layer": li, "cin": cin, "cout": cout, "K": K, "N_in": n_in, "N_out": n_out, "R": Rp}
+        outs = {}
+        for m in modes:
+            set_mode(m)
+            out, us = timed(lambda: x.conv(nbr, w, sc, sh), a.iters)
+            outs[m] = out
+            total[m] += us
+            row[m] = {"us": round(us, 1), "TFLOP/s": round(flops / us * 1e-6, 2), "GB/s": round(nbytes / us * 1e-3, 1)}
+            if a.brief:
+                print(f"  L{li} {cin}->{cout} {m}: {us:.1f} us", flush=True)
+        set_mode("v2")
+        # independent reference: fp64 gather + matmul per tap with torch
+        ref = torch.zeros((n_out, cout), dtype=torch.float64, device=dev)
+        f64, w64 = x.features.double(), w.double()
+        for t in range(K):
+            j = nbr[:, t].long()
+            ref += torch.where((j >= 0)[:, None], f64[j.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=dev)) @ w64[t]
+        ref = torch.relu(ref * sc.double() + sh.double())
+        for m in modes:
+            err = float((outs[m].double() - ref).abs().max() / (ref.abs().max() + 1e-12))
+            row[m]["rel_err_vs_fp64"] = err
+            assert err < 1e-4, (li, m, err)
+        # determinism of the new kernel: two runs, bit-identical
+        o2 = x.conv(nbr, w, sc, sh)
+        assert torch.equal(o2, outs["v2"]) if "v2" in outs else True
+        best = min((row[m]["us"], m) for m in modes)
+        row["best"] = best[1]
+        total["best"] = total.get("best", 0.0) + best[0]
+        if not a.brief:
+            print(json.dumps(row), flush=True)
+        rows.append(row)
+        x = ops.SparseTensor(outs[modes[-1]], oi, oshape, a.agents)
+    summ = {"total_conv_us": {m: round(t, 1) for m, t in total.items()}, "rulebook_us": {k: round(t, 1) for k, t in rb.items()}}
+    print(json.dumps(summ))
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump({"layers": rows, **summ}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
