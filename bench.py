@@ -218,11 +218,17 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
                            "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)})
             tot_ms += ms; tot_b += bts; tot_f += fl
         if tot_ms > 0:
+            # which roof applies: 2 R Cin Cout flops over 4 (N_in Cin + N_out Cout) + 8 R bytes is 100-180 flop/B on the 32- and
+            # 64-channel layers that carry 95 % of the time, against a machine balance of 157.3 TFLOP/s : 8 TB/s = 19.7 flop/B --
+            # exact-fp32 sparse convolution is bound by the fp32 matrix cores, so `frac` is the MFMA fraction (useful flops:
+            # the tile padding the kernel executes is not counted); the algorithmic-byte rate is reported beside it
             entries["k3"] = (tot_ms * max(a.steps, 1), _entry(
-                "K3 heal_sp_conv (gather-GEMM on fp32 MFMA; all sparse layers of one step, rulebook kernels not included)", "hbm",
-                tot_b / (tot_ms * 1e-3) / 1e9, len(layers), tot_ms / len(layers), None,
-                mfma_tflops=round(tot_f / (tot_ms * 1e-3) / 1e12, 2),
-                mfma_frac=round(tot_f / (tot_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), layers=layers))
+                "K3 heal_sp_conv (pair-compacted gather-GEMM on fp32 MFMA; all sparse layers of one step, useful flops 2 R Cin Cout; "
+                "rulebook kernels not included)", "mfma",
+                tot_f / (tot_ms * 1e-3) / 1e12, len(layers), tot_ms / len(layers), None,
+                step_ms=round(tot_ms, 4), hbm_gbs=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+                hbm_frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                flop_per_byte=round(tot_f / max(tot_b, 1.0), 1), layers=layers))
     if not entries:
         return None, []
     order = sorted(entries, key=lambda k: -entries[k][0])

@@ -60,10 +60,14 @@ _SIGNATURES = {
     "heal_sp_out_sites_workspace": (c_size_t, [c_int, c_int]),
     "heal_sp_out_sites": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "heal_sp_rank_bytes": (c_size_t, [c_void_p, c_int]),
+    "heal_sp_out_sites_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "heal_sp_neighbors_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "heal_sp_weight_fragments": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_sp_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                              c_void_p, c_void_p, c_void_p]),
-    "heal_sp_debug_profile": (c_int, [c_void_p]),
     "heal_sp_to_bev_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "heal_sp_to_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p, c_void_p]),

@@ -337,21 +337,6 @@ __global__ __launch_bounds__(64 * NW) void k_sp_conv(const float* __restrict__ f
 //     channel 16j+4g+i -- a permutation of the reduction order that the B fragment loads mirror; row stride CIN+8 words makes
 //     the 16-lane groups of a b128 read conflict-free;
 //   * BatchNorm scale/shift + ReLU and 16-B coalesced row stores in the epilogue.
-__device__ unsigned long long g_sp_prof[16];
-#define HEAL_SP_T(k_)                                                                     \
-    if constexpr (DBG & 32) {                                                             \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
-        const unsigned long long now_ = __builtin_readcyclecounter();                     \
-        tprof[k_] += now_ - tlast;                                                        \
-        tlast = now_;                                                                     \
-    }
-#define HEAL_SP_TL(k_)                                                                    \
-    if constexpr (DBG & 32) {                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
-        const unsigned long long now_ = __builtin_readcyclecounter();                     \
-        tprof[k_] += now_ - tlast;                                                        \
-        tlast = now_;                                                                     \
-    }
 template <int V> struct ILog2 { static constexpr int v = 1 + ILog2<V / 2>::v; };
 template <> struct ILog2<1> { static constexpr int v = 0; };
 
@@ -389,11 +374,14 @@ __global__ __launch_bounds__(256) void k_sp_conv2(const float* __restrict__ feat
     __shared__ int s_cnt[32];
 
     const int n_out = live_rows(n_dev, out_cap);
-    // XCD-contiguous site ranges: neighbouring blocks share gathered rows, keep them in one L2
-    const unsigned nb_ = gridDim.x, q_ = nb_ >> 3, r_ = nb_ & 7u, x_ = blockIdx.x & 7u;
+    // XCD-contiguous site ranges: neighbouring blocks share gathered rows, keep them in one L2.  The permutation is over the
+    // LIVE blocks: with device-side row counts the grid is capacity-sized, and a permutation of the whole grid would hand every
+    // live block to the first XCDs (measured: 2.4x slower inside the captured pipeline than stand-alone)
+    const unsigned nb_ = (unsigned)(n_out + M - 1) / M;
+    if (blockIdx.x >= nb_) return;
+    const unsigned q_ = nb_ >> 3, r_ = nb_ & 7u, x_ = blockIdx.x & 7u;
     const int blk = (int)((x_ < r_ ? x_ * (q_ + 1) : r_ * (q_ + 1) + (x_ - r_) * q_) + (blockIdx.x >> 3));
     const int site0 = blk * M;
-    if (site0 >= n_out) return;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int g = l >> 4, ln = l & 15;
     const int swz = (ln * CPR) >> 4;             // XOR swizzle of the 16-B chunks of gathered row ln (see the gather)
@@ -677,6 +665,128 @@ __global__ __launch_bounds__(256) void k_sp_dense(const int4* __restrict__ cell_
     }
 }
 
+// ---- rank structure of a site set: occupancy bitmap + prefix counts --------------------------------------------------------
+// For the site sets the encoder PRODUCES (the outputs of its strided convolutions) the hash grid, the candidate dedup, the radix
+// sort and the hash probes of the neighbour search are all replaced by one dense structure over the output grid
+// (cells / 8 bytes: 22 MB at [8 x 21 x 1024 x 1024], nothing next to 288 GB):
+//   * k_sp_bm_mark    every input site sets the bits of the <= 8 output cells whose receptive field contains it;
+//   * k_sp_bm_count   population count per granule of 256 cells, exclusive scan -> base[granule], total = site count;
+//   * k_sp_bm_emit    walks the bitmap in order: the sites come out SORTED by linear coordinate -- no sort;
+//   * rank(key) = base[key / 256] + popcount of the granule's bits below key = the site's row.  The three x taps of a kernel row
+//     fall into one 32-B granule, and neighbouring sites query neighbouring granules (the hash scattered every probe).
+// The root site set (the voxels, a 1.4 G-cell grid at 0.1 m) keeps the hash grid.
+constexpr int SP_GRAN = 256;   // cells per granule (8 words)
+
+struct SpRank {
+    const uint32_t* bm;
+    const int* base;
+};
+
+__device__ __forceinline__ int sp_rank_lookup(const SpRank& r, uint32_t key) {
+    const uint32_t w = key >> 5;
+    const uint32_t word = r.bm[w];
+    const uint32_t bit = key & 31u;
+    if (!((word >> bit) & 1u)) return -1;
+    const uint32_t g = key >> 8;
+    const uint4* gp = reinterpret_cast<const uint4*>(r.bm + ((size_t)g << 3));
+    const uint4 a = gp[0], b = gp[1];
+    const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const int wi = (int)(w & 7u);
+    int c = __popc(word & ((1u << bit) - 1u));
+#pragma unroll
+    for (int i = 0; i < 7; ++i) c += i < wi ? __popc(ws[i]) : 0;
+    return r.base[g] + c;
+}
+
+__global__ __launch_bounds__(256) void k_sp_bm_mark(const int4* __restrict__ in_idx, int in_cap,
+                                                   const int* __restrict__ n_dev, SpConvGeom g,
+                                                   uint32_t* __restrict__ bm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= live_rows(n_dev, in_cap)) return;
+    const int4 c = in_idx[i];
+    // output o sees input i through tap k = i + p - o s, 0 <= k < K  ->  o in [ceil((i + p - K + 1) / s), floor((i + p) / s)]
+    int lo[3], hi[3];
+    const int ci[3] = {c.y, c.z, c.w};
+    const int od[3] = {g.out.D, g.out.H, g.out.W};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int a = ci[d] + g.p[d];
+        const int num = a - g.k[d] + 1;
+        lo[d] = num <= 0 ? 0 : (num + g.s[d] - 1) / g.s[d];
+        hi[d] = min(a / g.s[d], od[d] - 1);
+    }
+    for (int oz = lo[0]; oz <= hi[0]; ++oz)
+        for (int oy = lo[1]; oy <= hi[1]; ++oy)
+            for (int ox = lo[2]; ox <= hi[2]; ++ox) {
+                const uint32_t key = sp_key(g.out, c.x, oz, oy, ox);
+                const uint32_t bit = 1u << (key & 31u);
+                if (!(bm[key >> 5] & bit)) atomicOr(&bm[key >> 5], bit);
+            }
+}
+
+__global__ __launch_bounds__(256) void k_sp_bm_count(const uint4* __restrict__ bm4, int granules, int* __restrict__ cnt) {
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= granules) return;
+    const uint4 a = bm4[2 * (size_t)gi], b = bm4[2 * (size_t)gi + 1];
+    cnt[gi] = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+}
+
+// one lane per bitmap word, eight lanes per granule: the sites leave in ascending key order
+__global__ __launch_bounds__(256) void k_sp_bm_emit(const uint32_t* __restrict__ bm, const int* __restrict__ base,
+                                                   size_t words, int out_cap, SpShape s, int4* __restrict__ out_idx,
+                                                   const int* __restrict__ n_out, int* __restrict__ overflow) {
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // sticky capacity report: a captured graph re-creates n_out on every replay, this word only ever grows
+    if (overflow && w == 0 && *n_out > out_cap) atomicMax(overflow, *n_out);
+    uint32_t word = w < words ? bm[w] : 0u;
+    const int mine = __popc(word);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const int t = __shfl_up(incl, o, 8);
+        if ((threadIdx.x & 7) >= o) incl += t;
+    }
+    if (!word) return;
+    int pos = base[w >> 3] + incl - mine;
+    while (word) {
+        const int b = __ffs(word) - 1;
+        word &= word - 1u;
+        if (pos < out_cap) {
+            uint32_t k = (uint32_t)(w << 5) + (uint32_t)b;
+            const int x = k % s.W; k /= s.W;
+            const int y = k % s.H; k /= s.H;
+            const int z = k % s.D; k /= s.D;
+            out_idx[pos] = make_int4((int)k, z, y, x);
+        }
+        ++pos;
+    }
+}
+
+// neighbour rows through the rank structure of the INPUT site set: one thread per (output site, kz, ky), the kx taps of a
+// kernel row are consecutive keys
+__global__ __launch_bounds__(256) void k_sp_nbr_rank(const int4* __restrict__ out_idx, int out_cap,
+                                                    const int* __restrict__ n_dev, SpConvGeom g, SpRank r, int in_cap,
+                                                    const int* __restrict__ n_in_dev, int* __restrict__ nbr) {
+    const int KR = g.k[0] * g.k[1], KX = g.k[2];
+    const int n_in = live_rows(n_in_dev, in_cap);   // sites beyond the capacity of the input set were never emitted
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)live_rows(n_dev, out_cap) * KR) return;
+    const int o = (int)(t / KR), kr = (int)(t - (long long)o * KR);
+    const int kz = kr / g.k[1], ky = kr - kz * g.k[1];
+    const int4 c = out_idx[o];
+    const int z = c.y * g.s[0] - g.p[0] + kz;
+    const int y = c.z * g.s[1] - g.p[1] + ky;
+    const int x0 = c.w * g.s[2] - g.p[2];
+    int* dst = nbr + (size_t)o * (KR * KX) + kr * KX;
+    const bool line_ok = z >= 0 && z < g.in.D && y >= 0 && y < g.in.H;
+    const uint32_t line = line_ok ? sp_key(g.in, c.x, z, y, 0) : 0u;
+    for (int kx = 0; kx < KX; ++kx) {
+        const int x = x0 + kx;
+        int row = (line_ok && x >= 0 && x < g.in.W) ? sp_rank_lookup(r, line + (uint32_t)x) : -1;
+        dst[kx] = row < n_in ? row : -1;
+    }
+}
+
 static uint32_t pow2_cap(int64_t n) {
     uint32_t c = 1024;
     while ((int64_t)c < 2 * (n < 1 ? 1 : n)) c <<= 1;
@@ -833,6 +943,75 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
     return 0;
 }
 
+
+// ---- rank structure API --------------------------------------------------------------------------------------------------
+static size_t rank_words(const SpShape& s) {
+    const uint64_t cells = (uint64_t)s.B * s.D * s.H * s.W;
+    return (size_t)((cells + SP_GRAN - 1) / SP_GRAN) * (SP_GRAN / 32);
+}
+
+extern "C" size_t heal_sp_rank_bytes(const int32_t* shape_host, int batch) {
+    SpShape s;
+    if (!shape_ok(shape_host, batch, s)) return 0;
+    const size_t words = rank_words(s), gran = words / 8;
+    return align_up(words * 4) + align_up(gran * 4) + align_up(scan_scratch_words((int64_t)gran) * 4) + 256;
+}
+
+// Active output sites of a strided sparse convolution through an occupancy bitmap of the OUTPUT grid (no hash, no sort):
+// out_indices [out_cap,4] sorted by linear coordinate, n_out [1] device (not clamped; `overflow`, optional: a device word
+// that receives max(overflow, n_out) whenever n_out exceeds out_cap -- sticky across graph replays).  `rank` (heal_sp_rank_bytes(out_shape,
+// batch) bytes, 256-B aligned) is left holding the rank structure of the output site set: pass it to heal_sp_neighbors_rank
+// when that set is the INPUT of a later layer.
+extern "C" int heal_sp_out_sites_rank(const int32_t* in_indices, int n_in, const int32_t* ksize_host,
+                                      const int32_t* stride_host, const int32_t* padding_host,
+                                      const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
+                                      int32_t* out_indices, int out_cap, int32_t* n_out, void* rank, size_t rank_bytes,
+                                      const int32_t* n_in_dev, int32_t* overflow, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SpConvGeom g;
+    if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
+    HEAL_REQUIRE(((uintptr_t)rank & 255) == 0, "sp_out_sites_rank: rank buffer must be 256-B aligned");
+    const size_t words = rank_words(g.out), gran = words / 8;
+    HEAL_REQUIRE(gran < (1ull << 31), "sp_out_sites_rank: grid too large");
+    Arena a(rank, rank_bytes);
+    uint32_t* bm = a.take<uint32_t>(words);
+    int* base = a.take<int>(gran);
+    int* scratch = a.take<int>(scan_scratch_words((int64_t)gran));
+    HEAL_REQUIRE(a.ok(), "sp_out_sites_rank: rank buffer too small (%zu < %zu)", rank_bytes, a.off);
+    HEAL_HIP(hipMemsetAsync(bm, 0, words * 4, s));
+    if (n_in > 0)
+        k_sp_bm_mark<<<ceil_div(n_in, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(in_indices), n_in, n_in_dev, g, bm);
+    k_sp_bm_count<<<(unsigned)((gran + 255) / 256), 256, 0, s>>>(reinterpret_cast<const uint4*>(bm), (int)gran, base);
+    if (scan_exclusive(base, base, (int)gran, n_out, scratch, s)) return 1;
+    k_sp_bm_emit<<<(unsigned)((words + 255) / 256), 256, 0, s>>>(bm, base, words, out_cap, g.out,
+                                                                  reinterpret_cast<int4*>(out_indices), n_out, overflow);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+// nbr [n_out, K] through the rank structure of the input site set (built by heal_sp_out_sites_rank for `in_shape`); n_in /
+// n_in_dev: rows of the input set (sites beyond its capacity were dropped when it was emitted: they are no neighbours).
+extern "C" int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
+                                      const int32_t* stride_host, const int32_t* padding_host,
+                                      const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
+                                      const void* rank, size_t rank_bytes, int n_in, const int32_t* n_in_dev,
+                                      int32_t* nbr, const int32_t* n_out_dev, void* stream) {
+    SpConvGeom g;
+    if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
+    if (n_out <= 0) return 0;
+    const size_t words = rank_words(g.in), gran = words / 8;
+    Arena a(const_cast<void*>(rank), rank_bytes);
+    SpRank r;
+    r.bm = a.take<uint32_t>(words);
+    r.base = a.take<int>(gran);
+    HEAL_REQUIRE(a.ok() && ((uintptr_t)rank & 255) == 0, "sp_neighbors_rank: bad rank buffer");
+    const long long total = (long long)n_out * g.k[0] * g.k[1];
+    k_sp_nbr_rank<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const int4*>(out_indices), n_out, n_out_dev, g, r, n_in, n_in_dev, nbr);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 // out[o] = act( BN( sum_tap W[tap]^T in[nbr[o][tap]] ) ); weight [K][Cin][Cout].
 extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in,
                             int c_out, const float* weight, const float* weight_frag, const float* bn_scale,
@@ -869,7 +1048,7 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
         if (m_ == 128 && tx_ == 2 && db_ == 1) HEAL_SP2(CI, CO, 128, 2 * TT, 1, 0)                \
     }
 #define HEAL_SP2D(D) if (dbg == D && c_in == 64 && c_out == 64) HEAL_SP2(64, 64, 64, 2, 0, D)
-        HEAL_SP2D(1) HEAL_SP2D(2) HEAL_SP2D(4) HEAL_SP2D(7) HEAL_SP2D(3) HEAL_SP2D(16) HEAL_SP2D(32) HEAL_SP2D(8) HEAL_SP2D(15) HEAL_SP2D(10) HEAL_SP2D(40)
+        HEAL_SP2D(1) HEAL_SP2D(2) HEAL_SP2D(4) HEAL_SP2D(8) HEAL_SP2D(10) HEAL_SP2D(15) HEAL_SP2D(16)
 #undef HEAL_SP2D
         // defaults from the sweep on the 8-agent SECOND encoder (profiles/r03_k3_sweep.json): 64 sites per block, 32 pairs x
         // 64 channels of gathered rows per stage, single-buffered gather tile (4 blocks per CU)
@@ -926,11 +1105,6 @@ extern "C" int heal_sp_weight_fragments(const float* weight, int kernel_volume, 
     const int n = kernel_volume * c_in * c_out;
     k_sp_weight_frag<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(weight, kernel_volume, c_in, c_out, out);
     HEAL_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int heal_sp_debug_profile(unsigned long long* out16) {
-    HEAL_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sp_prof), sizeof(unsigned long long) * 16));
     return 0;
 }
 

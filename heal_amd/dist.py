@@ -226,6 +226,8 @@ class _Sharded:
         if self._g_local is not None:   # None: this rank owns no agent, its slot is the constant zero buffer
             self._g_local.replay()
             self._replays += 1
+            # every 32 replays: the per-replay counters only show the last frame, but the sticky overflow word
+            # (ops.sparse_overflow_flag) that the same check reads keeps a violation of ANY frame in between
             if self._graph_checks and self._replays % 32 == 0:
                 self.check_sparse_capacity()
         if self.world > 1:

@@ -91,12 +91,14 @@ class _Block(nn.Sequential):
                 nbr_cache[conv.indice_key] = nbr
             feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=x.n_dev)
             y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.n_dev, x._checks, x._root_cap)
-            y._table = x._table
+            y._table, y._rank = x._table, x._rank
             return y
-        out_idx, out_shape, n_out_dev = x.out_sites(conv.kernel_size, conv.stride, conv.padding)
+        out_idx, out_shape, n_out_dev, rank = x.out_sites_ex(conv.kernel_size, conv.stride, conv.padding)
         nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, n_out_dev=n_out_dev)
         feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=n_out_dev)
-        return SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks, x._root_cap)
+        y = SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks, x._root_cap)
+        y._rank = rank   # occupancy bitmap + prefix counts of the new site set: the later layers' neighbour queries
+        return y
 
 
 class _DenseResult:

@@ -109,6 +109,22 @@ def _workspace(key, nbytes, device):
 _SPARSE_CHECKS = []
 
 
+# Sticky form: a captured graph re-creates every n_out counter on each replay, so a check every N replays only sees
+# the LAST frame.  The rank-path out_sites kernel also atomicMax-es an overflowing count into this per-device word, which no
+# graph ever resets: verify_sparse_capacity() reads it, so an overflow on ANY replayed frame is reported at the next check.
+_SPARSE_OVERFLOW = {}
+
+
+def sparse_overflow_flag(device):
+    """int32 [1] on `device`, persistent: max over all strided sparse layers of an n_out that exceeded its capacity (0 = none).
+    Allocated at the first (eager) use, i.e. outside any graph capture."""
+    key = str(device)
+    flag = _SPARSE_OVERFLOW.get(key)
+    if flag is None:
+        flag = _SPARSE_OVERFLOW[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return flag
+
+
 def take_sparse_checks():
     """Hand over (and forget) the pending checks, e.g. to keep those recorded inside a captured graph."""
     global _SPARSE_CHECKS
@@ -120,6 +136,14 @@ def verify_sparse_capacity(checks=None):
     """Raise if any recorded strided sparse layer produced more active sites than its capacity (synchronises: one small
     D2H copy).  checks=None: verify and clear the pending list."""
     pending = take_sparse_checks() if checks is None else checks
+    for key, flag in _SPARSE_OVERFLOW.items():
+        worst = int(flag.item())
+        if worst:
+            flag.zero_()
+            raise _capi.HealAmdError(
+                f"sparse conv: a strided layer produced {worst} active sites on {key}, more than its capacity in the "
+                "no-host-sync mode, on this or an earlier (replayed) frame (sites beyond the capacity were dropped: the result "
+                "is invalid).  Feed exact-size voxel inputs or raise the capacity policy (SparseTensor.out_sites)")
     if not pending:
         return
     counts = torch.cat([c.reshape(1) for c, _ in pending]).cpu().tolist()
@@ -675,6 +699,7 @@ class SparseTensor:
         self._checks = checks if checks is not None else []
         self._root_cap = int(root_cap) if root_cap is not None else int(indices.shape[0])  # rows of the voxel set
         self._table = None
+        self._rank = None   # rank structure (bitmap + prefix counts) when this site set came out of out_sites_ex()
 
     @property
     def n(self):
@@ -711,10 +736,15 @@ class SparseTensor:
         return self._table
 
     def neighbors(self, out_indices, out_shape, ksize, stride, padding, n_out_dev=None):
-        keys, vals, cap = self.table()
         n_out = int(out_indices.shape[0])
         K = int(ksize[0] * ksize[1] * ksize[2])
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.indices.device)
+        if self._rank is not None:
+            _capi.call("heal_sp_neighbors_rank", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
+                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(self._rank), self._rank.numel(),
+                       self.n, _optr(self.n_dev), _ptr(nbr), _optr(n_out_dev), _stream())
+            return nbr
+        keys, vals, cap = self.table()
         _capi.call("heal_sp_neighbors", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
                    _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(keys), _ptr(vals), cap,
                    _ptr(nbr), _optr(n_out_dev), _stream())
@@ -723,6 +753,11 @@ class SparseTensor:
     def out_sites(self, ksize, stride, padding):
         """Active output sites of a strided conv: (indices sorted, out_shape, n_out_dev).  Exact-size indices and
         n_out_dev None when this tensor carries host counts; capacity-size indices plus the device count otherwise."""
+        return self.out_sites_ex(ksize, stride, padding)[:3]
+
+    def out_sites_ex(self, ksize, stride, padding):
+        """out_sites() plus the rank structure of the output site set (None on the hash + sort path, HEAL_SP_RULEBOOK=hash):
+        hand it to the SparseTensor built on these sites (`._rank`) and its neighbour queries skip the hash grid."""
         out_shape = [(self.spatial_shape[d] + 2 * padding[d] - ksize[d]) // stride[d] + 1 for d in range(3)]
         K = int(ksize[0] * ksize[1] * ksize[2])
         dev = self.indices.device
@@ -734,17 +769,25 @@ class SparseTensor:
         out_cap = worst if self.n_dev is None else max(1, min(worst, 2 * self._root_cap))
         out_idx = torch.empty((out_cap, 4), dtype=torch.int32, device=dev)
         n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
-        ws = _workspace("sp_out_sites", _capi.query("heal_sp_out_sites_workspace", self.n, K), dev)
-        _capi.call("heal_sp_out_sites", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
-                   _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
-                   _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
+        rank = None
+        if os.environ.get("HEAL_SP_RULEBOOK", "rank") != "hash":
+            nbytes = _capi.query("heal_sp_rank_bytes", _i3(out_shape), self.batch_size)
+            rank = torch.empty((nbytes,), dtype=torch.uint8, device=dev)   # lives as long as the site set it describes
+            _capi.call("heal_sp_out_sites_rank", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
+                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
+                       _ptr(rank), nbytes, _optr(self.n_dev), _ptr(sparse_overflow_flag(dev)), _stream())
+        else:
+            ws = _workspace("sp_out_sites", _capi.query("heal_sp_out_sites_workspace", self.n, K), dev)
+            _capi.call("heal_sp_out_sites", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
+                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
+                       _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
         if self.n_dev is None:
-            return out_idx[:int(n_out.item())], out_shape, None
+            return out_idx[:int(n_out.item())], out_shape, None, rank
         self._checks.append((n_out, out_cap))
         _SPARSE_CHECKS.append((n_out, out_cap))
         if len(_SPARSE_CHECKS) > 4096:   # nobody verifies (no host sync on this path at all): keep the list bounded
             del _SPARSE_CHECKS[:2048]
-        return out_idx, out_shape, n_out
+        return out_idx, out_shape, n_out, rank
 
     def conv(self, nbr, weight, bn_scale, bn_shift, relu=True, n_out_dev=None):
         """Gather-GEMM: weight [K,Cin,Cout]; returns features [n_out,Cout]."""

@@ -244,6 +244,21 @@ int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int32_t* ksize_
                       const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
                       const int32_t* out_shape_host, int batch, int32_t* out_indices, int out_cap,
                       int32_t* n_out, void* ws, size_t ws_bytes, const int32_t* n_in_dev, void* stream);
+/* The same two steps through a RANK STRUCTURE (occupancy bitmap of the grid + prefix counts per 256 cells) instead of hash +
+ * sort: for the site sets the encoder itself produces.  heal_sp_out_sites_rank marks the output cells, counts, and emits the
+ * sites already sorted; `rank` (heal_sp_rank_bytes(out_shape, batch) bytes, 256-B aligned, caller-owned) then holds the rank
+ * structure of that OUTPUT set and answers heal_sp_neighbors_rank queries of every later layer that reads it
+ * (row = base[key / 256] + popcount below key).  Same outputs as heal_sp_out_sites / heal_sp_neighbors, bit for bit. */
+size_t heal_sp_rank_bytes(const int32_t* shape_host, int batch);
+int heal_sp_out_sites_rank(const int32_t* in_indices, int n_in, const int32_t* ksize_host,
+                           const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
+                           const int32_t* out_shape_host, int batch, int32_t* out_indices, int out_cap,
+                           int32_t* n_out, void* rank, size_t rank_bytes, const int32_t* n_in_dev,
+                           int32_t* overflow /* optional sticky max(n_out) when n_out > out_cap */, void* stream);
+int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
+                           const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
+                           const int32_t* out_shape_host, int batch, const void* rank, size_t rank_bytes,
+                           int n_in, const int32_t* n_in_dev, int32_t* nbr, const int32_t* n_out_dev, void* stream);
 /* feat_out[o] = act(bn_scale * sum_tap W[tap]^T feat_in[nbr[o][tap]] + bn_shift); weight [K,Cin,Cout]
  * (spconv 1.2.1 layout [kz,ky,kx,Cin,Cout]); fp32 MFMA, fixed summation order (bit-reproducible).
  * weight_frag: the same weights re-laid once by heal_sp_weight_fragments (same element count) -- selects the
@@ -253,8 +268,6 @@ int heal_sp_weight_fragments(const float* weight, int kernel_volume, int c_in, i
 int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in, int c_out,
                  const float* weight, const float* weight_frag, const float* bn_scale, const float* bn_shift,
                  int relu, float* feat_out, const int32_t* n_out_dev, void* stream);
-/* tuning aid (cycle counters of one block of the instrumented kernel variant) */
-int heal_sp_debug_profile(unsigned long long* out16);
 size_t heal_sp_to_bev_workspace(int batch, int D, int H, int W);
 int heal_sp_to_bev(const float* features, const int32_t* indices, int n, int channels,
                    const int32_t* shape_host, int batch, float* out, void* ws, size_t ws_bytes,

@@ -78,15 +78,32 @@ def main():
                 nbr, t = timed(lambda: (setattr(x, "_table", None), x.neighbors(x.indices, x.spatial_shape, k, (1, 1, 1),
                                                                                tuple(q // 2 for q in k)))[1], 5)
                 rb["hash+nbr"] += t
+                if x._rank is not None:
+                    keep, x._rank = x._rank, None
+                    nbr_h, t = timed(lambda: (setattr(x, "_table", None), x.neighbors(x.indices, x.spatial_shape, k, (1, 1, 1),
+                                                                                     tuple(q // 2 for q in k)))[1], 5)
+                    x._rank = keep
+                    assert torch.equal(nbr, nbr_h)
+                rb["hash+nbr(hash)"] = rb.get("hash+nbr(hash)", 0.0) + t
                 cache[key] = nbr
             nbr = cache[key]
             oi, oshape = x.indices, x.spatial_shape
         else:
-            (oi, oshape, _), t = timed(lambda: x.out_sites(k, st, pd), 5)
+            os.environ["HEAL_SP_RULEBOOK"] = "hash"
+            (oi_h, _, _, _), t = timed(lambda: x.out_sites_ex(k, st, pd), 5)
+            rb["out_sites(hash+sort)"] = rb.get("out_sites(hash+sort)", 0.0) + t
+            os.environ["HEAL_SP_RULEBOOK"] = "rank"
+            (oi, oshape, _, rank), t = timed(lambda: x.out_sites_ex(k, st, pd), 5)
             rb["out_sites"] += t
-            x._table = None
+            assert torch.equal(oi, oi_h)
+            keep = x._rank
+            x._rank = None; x._table = None
+            nbr_h, t = timed(lambda: (setattr(x, "_table", None), x.neighbors(oi, oshape, k, st, pd))[1], 5)
+            rb["hash+nbr(hash)"] = rb.get("hash+nbr(hash)", 0.0) + t
+            x._rank = keep
             nbr, t = timed(lambda: (setattr(x, "_table", None), x.neighbors(oi, oshape, k, st, pd))[1], 5)
             rb["hash+nbr"] += t
+            assert torch.equal(nbr, nbr_h)
         Rp = int((nbr >= 0).sum().item())
         n_in, n_out = x.n, int(oi.shape[0])
         flops = 2.0 * Rp * cin * cout
@@ -122,7 +139,9 @@ def main():
         if not a.brief:
             print(json.dumps(row), flush=True)
         rows.append(row)
+        x_rank = x._rank if subm else rank
         x = ops.SparseTensor(outs[modes[-1]], oi, oshape, a.agents)
+        x._rank = x_rank
     summ = {"total_conv_us": {m: round(t, 1) for m, t in total.items()}, "rulebook_us": {k: round(t, 1) for k, t in rb.items()}}
     print(json.dumps(summ))
     if a.json:

@@ -1,4 +1,5 @@
-"""Ablation timings of k_sp_conv2 (HEAL_SP_DBG bit mask) on the real 64->64 and 4->16 layers."""
+"""Ablation timings of k_sp_conv2 on the real 64->64 layer of the 8-agent SECOND encoder (HEAL_SP_DBG bit mask: 1 no accumulator
+read-modify-write, 2 no gather DMA, 4 no MFMA, 8 no weight loads, 16 setup + epilogue only): what each part costs in place."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,11 +28,3 @@ for _ in range(2):
     oi, osh, _ = x.out_sites(k, (2, 2, 2), (1, 1, 1))
     x = ops.SparseTensor(torch.zeros((oi.shape[0], 4), device=dev), oi, osh, 8)
 run(x, 64, 64, "64->64")
-if "32" in sys.argv[1].split(","):
-    import ctypes
-    from heal_amd import _capi
-    buf = (ctypes.c_ulonglong * 16)()
-    _capi.lib().heal_sp_debug_profile(buf)
-    names = ["W-prefetch issue", "A-frag reads", "MFMA", "index(s+2)", "RMW", "wait gather loads", "gather store", "barrier"]
-    st = buf[8]
-    print("stages", st, {n: round(buf[i] / max(st, 1)) for i, n in enumerate(names)}, "cycles/stage")
