@@ -60,6 +60,13 @@ _SIGNATURES = {
     "heal_sp_out_sites_workspace": (c_size_t, [c_int, c_int]),
     "heal_sp_out_sites": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "heal_ln_stats": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "heal_linear": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                            c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                            ctypes.c_longlong, c_int, c_void_p]),
+    "heal_split_attn_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "heal_split_attn_weights": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_int] + [c_void_p] * 5 + [c_float] +
+                                [c_void_p] * 5),
     "heal_sp_rank_bytes": (c_size_t, [c_void_p, c_int]),
     "heal_sp_out_sites_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
@@ -72,7 +79,7 @@ _SIGNATURES = {
     "heal_sp_to_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p, c_void_p]),
     "heal_agent_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                                     c_int, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_int, c_void_p]),
     "heal_grouped_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
     "heal_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

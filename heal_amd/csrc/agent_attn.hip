@@ -19,13 +19,15 @@ namespace heal {
 
 constexpr int AA_MAXL = 8;
 
-template <int LANES_PER_HEAD, int L>
+template <int LANES_PER_HEAD, int L, bool AM /*agent-major tensors [L][n_pix][C] instead of [n_pix][L][C]*/>
 __global__ __launch_bounds__(256) void k_agent_attn(const float4* __restrict__ q, const float4* __restrict__ k,
                                                    const float4* __restrict__ v,
                                                    const int* __restrict__ key_mask /*[L] or null*/,
                                                    int n_pix, float scale, int out_rows,
                                                    float4* __restrict__ out) {
-    // tensors are [n_pix][L][C] with C = 256 = 64 lanes x 4 channels
+    // tensors are [n_pix][L][C] (or [L][n_pix][C]: the token order of the V2X-ViT GEMMs around this kernel; a pixel's row of
+    // one agent is 1 KiB contiguous either way) with C = 256 = 64 lanes x 4 channels
+#define HEAL_AA_ROW(p_, a_, na_) (AM ? ((size_t)(a_) * n_pix + (p_)) : ((size_t)(p_) * (na_) + (a_)))
     const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= n_pix) return;
     const int l = threadIdx.x & 63;
@@ -33,14 +35,14 @@ __global__ __launch_bounds__(256) void k_agent_attn(const float4* __restrict__ q
     bool valid[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
-        kk[j] = k[((size_t)pix * L + j) * 64 + l];
-        vv[j] = v[((size_t)pix * L + j) * 64 + l];
+        kk[j] = k[HEAL_AA_ROW(pix, j, L) * 64 + l];
+        vv[j] = v[HEAL_AA_ROW(pix, j, L) * 64 + l];
         valid[j] = key_mask == nullptr || key_mask[j] != 0;
     }
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         if (i >= out_rows) break;
-        const float4 qi = q[((size_t)pix * L + i) * 64 + l];
+        const float4 qi = q[HEAL_AA_ROW(pix, i, L) * 64 + l];
         float s[L];
         float mx = -INFINITY;
 #pragma unroll
@@ -60,17 +62,22 @@ __global__ __launch_bounds__(256) void k_agent_attn(const float4* __restrict__ q
             const float p = s[j] / den;
             acc.x += p * vv[j].x; acc.y += p * vv[j].y; acc.z += p * vv[j].z; acc.w += p * vv[j].w;
         }
-        out[((size_t)pix * out_rows + i) * 64 + l] = acc;
+        out[HEAL_AA_ROW(pix, i, out_rows) * 64 + l] = acc;
     }
+#undef HEAL_AA_ROW
 }
 
 template <int LPH>
 static int launch_l(int L, const float* q, const float* k, const float* v, const int* mask, int n_pix, float scale,
-                    int out_rows, float* out, hipStream_t s) {
+                    int out_rows, float* out, int agent_major, hipStream_t s) {
     const int blocks = ceil_div(n_pix, 4);
     const float4 *q4 = (const float4*)q, *k4 = (const float4*)k, *v4 = (const float4*)v;
     float4* o4 = (float4*)out;
-#define HEAL_AA(LL) case LL: k_agent_attn<LPH, LL><<<blocks, 256, 0, s>>>(q4, k4, v4, mask, n_pix, scale, out_rows, o4); break;
+#define HEAL_AA(LL)                                                                                                  \
+    case LL:                                                                                                         \
+        if (agent_major) k_agent_attn<LPH, LL, true><<<blocks, 256, 0, s>>>(q4, k4, v4, mask, n_pix, scale, out_rows, o4); \
+        else k_agent_attn<LPH, LL, false><<<blocks, 256, 0, s>>>(q4, k4, v4, mask, n_pix, scale, out_rows, o4);      \
+        break;
     switch (L) {
         HEAL_AA(1) HEAL_AA(2) HEAL_AA(3) HEAL_AA(4) HEAL_AA(5) HEAL_AA(6) HEAL_AA(7) HEAL_AA(8)
         default: return set_error("agent_attention: L must be in [1,%d]", AA_MAXL);
@@ -86,16 +93,16 @@ using namespace heal;
 
 extern "C" int heal_agent_attention(const float* q, const float* k, const float* v, const int32_t* key_mask,
                                     int n_pix, int n_agents, int channels, int heads, float scale, int out_rows,
-                                    float* out, void* stream) {
+                                    float* out, int agent_major, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(channels == 256, "agent_attention: channels must be 256 (got %d)", channels);
     HEAL_REQUIRE(out_rows >= 1 && out_rows <= n_agents, "agent_attention: out_rows must be in [1,n_agents]");
     if (n_pix <= 0) return 0;
     switch (heads) {
-        case 1: return launch_l<64>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
-        case 4: return launch_l<16>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
-        case 8: return launch_l<8>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
-        case 16: return launch_l<4>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, s);
+        case 1: return launch_l<64>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, agent_major, s);
+        case 4: return launch_l<16>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, agent_major, s);
+        case 8: return launch_l<8>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, agent_major, s);
+        case 16: return launch_l<4>(n_agents, q, k, v, key_mask, n_pix, scale, out_rows, out, agent_major, s);
         default: return set_error("agent_attention: heads must be 1, 4, 8 or 16 (got %d)", heads);
     }
 }

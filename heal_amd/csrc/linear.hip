@@ -1,0 +1,368 @@
+// Token-major fp32 GEMM with fused prologue / epilogue for the V2X-ViT fusion transformer, plus its two small companions
+// (LayerNorm statistics, split-attention weights).
+//
+// Reference call sites: opencood/models/sub_modules/base_transformer.py:7-40 (PreNorm = LayerNorm + fn, FeedForward = Linear,
+// GELU, Linear), hmsa.py:38-151 (per-type q/k/v/a Linear layers around the per-pixel agent attention), mswin.py:46-122 (to_qkv /
+// to_out around the window attention), split_attn.py:6-62 (global average -> fc1 -> LayerNorm -> ReLU -> fc2 -> softmax over the
+// three window branches -> weighted sum), v2xvit_basic.py:158-192 (the residual adds between them).  Round 2 ran these as
+// hipBLASLt GEMMs (7.5 ms of the 33 ms step of BASELINE config 5) with ATen LayerNorm / GELU / add / mul / mean / cat kernels
+// between them (another 5 ms, each streaming the 134 MB token tensor).
+//
+// heal_linear: Y = act(norm(X) W^T * colscale + bias) + residual for X [T, K] row-major (tokens x channels), W [N, K] (the
+// nn.Linear layout: y = x W^T, every output column is one contiguous weight row).
+//   * 128 x 128 output tile per block, 4 waves x (64 x 64) on v_mfma_f32_32x32x2_f32 (16 accumulator registers per 32 x 32
+//     block: 64 per lane).  One MFMA is 64 cycles for ONE A and ONE B float per lane, so the matrix pipe is fed by two
+//     ds_read_b128 per operand per 16 k-steps; K chunks of 32 through double-buffered LDS (73 KB: two blocks per CU).
+//   * both operands are staged [row][k] (k contiguous) with a 36-float row stride: the b128 fragment reads of the 16-lane
+//     groups fall on distinct bank slots.  Lane half h multiplies k = 16 h + s at step s -- a permutation of the reduction
+//     order that both operands share.
+//   * prologue, applied while a tile travels global -> registers -> LDS: (x - mean[t]) * rstd[t] (PreNorm's LayerNorm; its
+//     gamma / beta are folded into W / bias by the caller), and for the split-attention merge W[n][k] * colscale[group(t)][k /
+//     part][n]: the three to_out projections and the softmax-weighted sum over the window branches are ONE K = 3 x 256 GEMM
+//     whose weight rows are scaled per agent.
+//   * epilogue: bias (optionally per group of tokens), exact-erf GELU, residual add, and an output addressing that writes
+//     column parts to separate buffers (q | k | v) and rows through a [outer, inner] -> [inner, outer] transposition (the
+//     per-pixel agent attention wants [pixel, agent, C], the token tensor is [agent, pixel, C]).
+#include "common.h"
+#include "../../include/heal_amd.h"
+
+namespace heal {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct LinearArgs {
+    const float* X; int lda;          // [T, K] rows lda apart
+    int a_part_cols; long long a_part_stride;  // > 0: channel block k / a_part_cols of a token lives in X + block * a_part_stride
+    const float2* stats;              // [T] (mean, rstd) or NULL
+    const float* W;                   // [N, K]
+    const float* bias;                // [groups, N] or [N] or NULL
+    const float* colscale;            // [groups, K / cs_part, N] or NULL: W[n][k] *= colscale[g][k / cs_part][n]
+    const float* res; int ldr;        // [T_out rows, N] residual (indexed like the output) or NULL
+    float* out; int ldo;              // output rows ldo apart
+    int T, N, K;
+    int group_rows;                   // tokens per group (bias / colscale groups), 0 = one group
+    int bias_groups;                  // 1: bias is per group
+    int cs_part;                      // k extent of one colscale part
+    int map_inner, map_outer;         // out row of token t = (t % inner) * outer + t / inner  (inner = 0: identity)
+    int part_cols; long long part_stride;  // column c goes to out + (c / part_cols) * part_stride, column c % part_cols
+    int act;                          // 0 none, 1 gelu (erf), 2 relu
+};
+
+constexpr int LIN_BM = 128, LIN_BN = 128, LIN_BK = 32, LIN_RS = 36;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256, 2) void k_linear(const LinearArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_all[2 * LIN_BM * LIN_RS + 2 * LIN_BN * LIN_RS];
+    float (*sA)[LIN_BM * LIN_RS] = reinterpret_cast<float (*)[LIN_BM * LIN_RS]>(s_all);
+    float (*sB)[LIN_BN * LIN_RS] = reinterpret_cast<float (*)[LIN_BN * LIN_RS]>(s_all + 2 * LIN_BM * LIN_RS);
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = l & 31, h = l >> 5;
+    // blocks that share an A tile (same token tile, different column tiles) are neighbours in dispatch order
+    const int n_tiles = a.N / LIN_BN;
+    const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+    const int t0 = tile_m * LIN_BM, n0 = tile_n * LIN_BN;
+
+    // staging role: 4 x 16 B of the A tile and 4 x 16 B of the B tile per chunk; row r = (tid + 256 i) / 8, 16-B column c4
+    int s_row[4], s_c4[4];
+    float s_mean[4], s_rstd[4];
+    const float* a_src[4];
+    const float* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        s_row[i] = c >> 3;
+        s_c4[i] = c & 7;
+        const int t = min(t0 + s_row[i], a.T - 1);
+        a_src[i] = a.X + (size_t)t * a.lda + s_c4[i] * 4;
+        b_src[i] = a.W + (size_t)(n0 + s_row[i]) * a.K + s_c4[i] * 4;
+        s_mean[i] = 0.f; s_rstd[i] = 1.f;
+        if (a.stats) { const float2 st = a.stats[t]; s_mean[i] = st.x; s_rstd[i] = st.y; }
+    }
+    const int group = a.group_rows > 0 ? t0 / a.group_rows : 0;
+    const float* cs_base = a.colscale ? a.colscale + (size_t)group * (a.K / a.cs_part) * a.N : nullptr;
+
+    // reduction index -> offset inside a token's row (channel blocks of several tensors: see a_part_cols)
+    auto a_off = [&](int k0) -> long long {
+        if (a.a_part_cols <= 0) return k0;
+        const int blk = k0 / a.a_part_cols;
+        return (long long)blk * a.a_part_stride + (k0 - blk * a.a_part_cols);
+    };
+    float4 ra[4], rb[4];
+#define HEAL_LIN_LOAD(k0_)                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                     \
+        ra[i] = *reinterpret_cast<const float4*>(a_src[i] + a_off(k0_));                \
+        rb[i] = *reinterpret_cast<const float4*>(b_src[i] + (k0_));                     \
+    }
+#define HEAL_LIN_STORE(buf_, k0_)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+        float4 x = ra[i];                                                                                              \
+        x.x = (x.x - s_mean[i]) * s_rstd[i]; x.y = (x.y - s_mean[i]) * s_rstd[i];                                      \
+        x.z = (x.z - s_mean[i]) * s_rstd[i]; x.w = (x.w - s_mean[i]) * s_rstd[i];                                      \
+        *reinterpret_cast<float4*>(&sA[buf_][s_row[i] * LIN_RS + s_c4[i] * 4]) = x;                                    \
+        float4 w = rb[i];                                                                                              \
+        if (cs_base) {                                                                                                 \
+            const float sc = cs_base[(size_t)((k0_) / a.cs_part) * a.N + n0 + s_row[i]];                               \
+            w.x *= sc; w.y *= sc; w.z *= sc; w.w *= sc;                                                                \
+        }                                                                                                              \
+        *reinterpret_cast<float4*>(&sB[buf_][s_row[i] * LIN_RS + s_c4[i] * 4]) = w;                                    \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // (a static s_setprio for every other block, to de-phase the two blocks that share a CU, measured no change)
+    const int n_chunks = a.K / LIN_BK;
+    HEAL_LIN_LOAD(0)
+    HEAL_LIN_STORE(0, 0)
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) { HEAL_LIN_LOAD((c + 1) * LIN_BK) }   // in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        float af[2][16], bf[2][16];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float* p = &sA[buf][(wm * 64 + m * 32 + li) * LIN_RS + 16 * h];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+                af[m][4 * q] = v.x; af[m][4 * q + 1] = v.y; af[m][4 * q + 2] = v.z; af[m][4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float* p = &sB[buf][(wn * 64 + n * 32 + li) * LIN_RS + 16 * h];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+                bf[n][4 * q] = v.x; bf[n][4 * q + 1] = v.y; bf[n][4 * q + 2] = v.z; bf[n][4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], bf[n][s], acc[m][n], 0, 0, 0);
+        if (c + 1 < n_chunks) { HEAL_LIN_STORE(buf ^ 1, (c + 1) * LIN_BK) }
+        __syncthreads();
+    }
+
+#undef HEAL_LIN_LOAD
+#undef HEAL_LIN_STORE
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // The accumulators go through LDS once (C/D layout of 32x32: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)),
+    // so that every thread then owns 16-B pieces of output rows: bias / residual / output move as 16-B accesses (16 per thread
+    // instead of 64 scalar ones), and the row / part addressing is computed once per piece.
+    constexpr int CS = LIN_BN + 4;
+    float* sC = s_all;       // 128 x 132 floats = 67.6 KB of the 73.7 KB the two operand rings occupy (contiguous arrays)
+    static_assert(sizeof(s_all) >= (size_t)LIN_BM * CS * 4, "epilogue tile must fit the operand rings");
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[(wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + wn * 64 + n * 32 + li] = acc[m][n][r];
+    __syncthreads();
+    const float* bias = a.bias ? a.bias + (a.bias_groups ? (size_t)group * a.N : 0) : nullptr;
+    // this thread's 16-B column is fixed: 32 column pieces per row, 8 rows per pass
+    const int c4 = tid & 31, col = n0 + c4 * 4;
+    const int part = col / a.part_cols, pc = col - part * a.part_cols;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+    // row map (a tile never straddles an `inner` boundary: inner is a multiple of 128)
+    const long long q_ = a.map_inner > 0 ? t0 / a.map_inner : 0, rem_ = a.map_inner > 0 ? t0 - q_ * a.map_inner : t0;
+    float* obase = a.out + (size_t)part * a.part_stride + pc;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int row = (tid >> 5) + 8 * i;
+        if (t0 + row >= a.T) break;
+        const size_t orow = a.map_inner > 0 ? (size_t)(rem_ + row) * a.map_outer + (size_t)q_ : (size_t)(t0 + row);
+        float4 v = *reinterpret_cast<const float4*>(&sC[row * CS + c4 * 4]);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (a.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        else if (a.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.res) {
+            const float4 rv = *reinterpret_cast<const float4*>(a.res + orow * a.ldr + col);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        *reinterpret_cast<float4*>(obase + orow * a.ldo) = v;
+    }
+}
+
+// ---- LayerNorm statistics: one wave per token --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ x, int T, int C, float eps,
+                                                 float2* __restrict__ stats) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (t >= T) return;
+    const float* row = x + (size_t)t * C;
+    float v[8];
+    int nv = 0;
+    float s = 0.f;
+    for (int c = l * 4; c < C; c += 256, nv += 4) {   // C <= 512
+        const float4 q = *reinterpret_cast<const float4*>(row + c);
+        v[nv] = q.x; v[nv + 1] = q.y; v[nv + 2] = q.z; v[nv + 3] = q.w;
+        s += (q.x + q.y) + (q.z + q.w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float d = 0.f;
+    for (int i = 0; i < nv; ++i) d += (v[i] - mean) * (v[i] - mean);
+    const float var = wave_sum(d) / (float)C;
+    if (l == 0) stats[t] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
+// ---- split attention weights (split_attn.py:43-62) ------------------------------------------------------------------------
+// colsum[g][part][c]: sums over the group's tokens of the three window-attention outputs (BEFORE their to_out projections;
+// the projections are linear, so the average of the projected branches is the projection of the averages).
+//   gap = sum_part (mean_part W_out[part]^T + b_out[part]);  a = fc2(relu(LN(fc1(gap))));  softmax over the 3 parts per channel
+// -> scale [g][3][C] (the column scales of the merged to_out GEMM) and bias [g][C] = sum_part scale * b_out[part].
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long long part_stride, int rows_per_group, int C,
+                                               int chunk, float* __restrict__ out /*[g][parts][chunks][C]*/) {
+    const int g = blockIdx.z, part = blockIdx.y;
+    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, rows_per_group);
+    const int c = threadIdx.x;   // C <= 256
+    if (c >= C) return;
+    const float* p = x + (size_t)part * part_stride + ((size_t)g * rows_per_group + r0) * C + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4, p += 4 * (size_t)C) { s0 += p[0]; s1 += p[C]; s2 += p[2 * (size_t)C]; s3 += p[3 * (size_t)C]; }
+    for (; r < r1; ++r, p += C) s0 += *p;
+    out[(((size_t)g * gridDim.y + part) * gridDim.x + blockIdx.x) * C + c] = (s0 + s1) + (s2 + s3);   // summed in chunk order below
+}
+
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ colsum, int chunks, float inv_rows,
+                                                      const float* __restrict__ w_out /*[3][C][C] (nn.Linear [N][K])*/,
+                                                      const float* __restrict__ b_out /*[3][C]*/,
+                                                      const float* __restrict__ fc1 /*[C][C]*/, const float* __restrict__ ln_g,
+                                                      const float* __restrict__ ln_b, float eps,
+                                                      const float* __restrict__ fc2 /*[3C][C]*/, int C,
+                                                      float* __restrict__ scale /*[g][3][C]*/, float* __restrict__ bias /*[g][C]*/) {
+    __shared__ float s_mean[3 * 256], s_gap[256], s_h[256], s_red[8];
+    const int g = blockIdx.x, c = threadIdx.x;   // C == blockDim.x <= 256
+    for (int i = c; i < 3 * C; i += C) {
+        const float* q = colsum + ((size_t)g * 3 + i / C) * chunks * C + (i % C);
+        float t = 0.f;
+        for (int k = 0; k < chunks; ++k) t += q[(size_t)k * C];
+        s_mean[i] = t * inv_rows;
+    }
+    __syncthreads();
+    float gap = 0.f;
+    for (int p = 0; p < 3; ++p) {
+        const float* w = w_out + ((size_t)p * C + c) * C;
+        float d = b_out[p * C + c];
+        for (int k = 0; k < C; ++k) d = fmaf(s_mean[p * C + k], w[k], d);
+        gap += d;
+    }
+    s_gap[c] = gap;
+    __syncthreads();
+    float hval = 0.f;
+    {
+        const float* w = fc1 + (size_t)c * C;
+        for (int k = 0; k < C; ++k) hval = fmaf(s_gap[k], w[k], hval);
+    }
+    // LayerNorm over the C values of the block
+    float sm = wave_sum(hval);
+    if ((c & 63) == 0) s_red[c >> 6] = sm;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < (C + 63) / 64; ++i) tot += s_red[i];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    const float dv = (hval - mean) * (hval - mean);
+    sm = wave_sum(dv);
+    if ((c & 63) == 0) s_red[c >> 6] = sm;
+    __syncthreads();
+    tot = 0.f;
+    for (int i = 0; i < (C + 63) / 64; ++i) tot += s_red[i];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    s_h[c] = fmaxf((hval - mean) * rstd * ln_g[c] + ln_b[c], 0.f);
+    __syncthreads();
+    float lg[3];
+    for (int p = 0; p < 3; ++p) {
+        const float* w = fc2 + ((size_t)p * C + c) * C;
+        float d = 0.f;
+        for (int k = 0; k < C; ++k) d = fmaf(s_h[k], w[k], d);
+        lg[p] = d;
+    }
+    const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
+    const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx), e2 = expf(lg[2] - mx);
+    const float inv = 1.0f / (e0 + e1 + e2);
+    const float a0 = e0 * inv, a1 = e1 * inv, a2 = e2 * inv;
+    scale[((size_t)g * 3 + 0) * C + c] = a0;
+    scale[((size_t)g * 3 + 1) * C + c] = a1;
+    scale[((size_t)g * 3 + 2) * C + c] = a2;
+    bias[(size_t)g * C + c] = a0 * b_out[c] + a1 * b_out[C + c] + a2 * b_out[2 * C + c];
+}
+
+}  // namespace heal
+
+using namespace heal;
+
+extern "C" int heal_ln_stats(const float* x, int n_tokens, int channels, float eps, float* stats, void* stream) {
+    HEAL_REQUIRE(channels % 4 == 0 && channels <= 512, "ln_stats: channels must be a multiple of 4, <= 512");
+    if (n_tokens <= 0) return 0;
+    k_ln_stats<<<ceil_div(n_tokens, 4), 256, 0, (hipStream_t)stream>>>(x, n_tokens, channels, eps,
+                                                                      reinterpret_cast<float2*>(stats));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_linear(const float* x, int lda, int x_part_cols, long long x_part_stride, const float* ln_stats,
+                           const float* weight, const float* bias,
+                           int bias_per_group, const float* colscale, int colscale_part, int group_rows,
+                           const float* residual, int ldr, float* out, int ldo, int n_tokens, int n_out, int n_in,
+                           int map_inner, int map_outer, int part_cols, long long part_stride, int act, void* stream) {
+    HEAL_REQUIRE(n_out % LIN_BN == 0 && n_in % LIN_BK == 0 && n_in >= LIN_BK, "linear: N must be a multiple of 128, K of 32");
+    HEAL_REQUIRE(lda % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)weight & 15) == 0, "linear: 16-B alignment");
+    HEAL_REQUIRE(group_rows == 0 || group_rows % LIN_BM == 0, "linear: a group must be whole 128-token tiles");
+    HEAL_REQUIRE(!colscale || (colscale_part > 0 && colscale_part % LIN_BK == 0 && n_in % colscale_part == 0),
+                 "linear: bad colscale part");
+    HEAL_REQUIRE(map_inner == 0 || (map_inner > 0 && map_outer > 0 && (long long)map_inner * map_outer == n_tokens &&
+                                    map_inner % LIN_BM == 0),
+                 "linear: row map must cover the tokens, inner a multiple of 128");
+    HEAL_REQUIRE(n_out % 4 == 0 && (part_cols <= 0 || part_cols % 4 == 0) && ldo % 4 == 0 && (!residual || ldr % 4 == 0),
+                 "linear: 16-B output pieces");
+    HEAL_REQUIRE(act >= 0 && act <= 2, "linear: act in {0,1,2}");
+    if (n_tokens <= 0) return 0;
+    LinearArgs a;
+    HEAL_REQUIRE(x_part_cols == 0 || (x_part_cols % LIN_BK == 0 && n_in % x_part_cols == 0 && !ln_stats),
+                 "linear: x parts must be whole 32-channel chunks (and carry no LayerNorm)");
+    a.a_part_cols = x_part_cols; a.a_part_stride = x_part_stride;
+    a.X = x; a.lda = lda; a.stats = reinterpret_cast<const float2*>(ln_stats); a.W = weight; a.bias = bias;
+    a.colscale = colscale; a.res = residual; a.ldr = ldr; a.out = out; a.ldo = ldo; a.T = n_tokens; a.N = n_out; a.K = n_in;
+    a.group_rows = group_rows; a.bias_groups = bias_per_group; a.cs_part = colscale_part > 0 ? colscale_part : n_in;
+    a.map_inner = map_inner; a.map_outer = map_outer;
+    a.part_cols = part_cols > 0 ? part_cols : n_out; a.part_stride = part_stride; a.act = act;
+    const int tiles = ceil_div(n_tokens, LIN_BM) * (n_out / LIN_BN);
+    k_linear<<<tiles, 256, 0, (hipStream_t)stream>>>(a);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t heal_split_attn_workspace(int groups, int rows_per_group, int channels) {
+    return (size_t)groups * 3 * ceil_div(rows_per_group, 512) * channels * sizeof(float) + 256;
+}
+
+extern "C" int heal_split_attn_weights(const float* branches, long long part_stride, int groups, int rows_per_group,
+                                       int channels, const float* w_out, const float* b_out, const float* fc1,
+                                       const float* ln_gamma, const float* ln_beta, float eps, const float* fc2,
+                                       float* colsum_ws, float* scale, float* bias, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(channels <= 256 && channels % 64 == 0, "split_attn_weights: channels must be 64, 128, 192 or 256");
+    const int chunk = 512, chunks = ceil_div(rows_per_group, chunk);
+    dim3 grid(chunks, 3, groups);
+    k_colsum<<<grid, 256, 0, s>>>(branches, part_stride, rows_per_group, channels, chunk, colsum_ws);
+    k_split_weights<<<groups, channels, 0, s>>>(colsum_ws, chunks, 1.0f / (float)rows_per_group, w_out, b_out, fc1, ln_gamma, ln_beta,
+                                               eps, fc2, channels, scale, bias);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}

@@ -2,7 +2,13 @@
 hmsa.py:7-151, mswin.py:19-122, split_attn.py:6-62, base_transformer.py:7-40).
 
 Module / parameter layout mirrors the reference so that checkpoints load.  Execution differs by design:
-  * tensors stay pixel-major [L, H, W, C] (one scene); Linear layers are library GEMMs over all pixels;
+  * tensors stay pixel-major [L, H, W, C] (one scene).  Inference (round 3): every Linear is heal_linear -- the token-major
+    fp32 MFMA GEMM with PreNorm's LayerNorm applied in its prologue (statistics from heal_ln_stats, gamma / beta folded into
+    the weights) and bias / GELU / residual in its epilogue; the three to_qkv projections of the window pyramid are one
+    256 -> 2304 GEMM writing three buffers; the three to_out projections, the split-attention weighting of the branches and
+    the residual are ONE K = 768 GEMM whose weight rows are scaled per agent (heal_split_attn_weights).  No library GEMM, no
+    ATen LayerNorm / GELU / add / mul / mean / cat kernel is left on the path (`_fused_ok`; HEAL_V2XVIT_FUSED=0 restores the
+    round-2 library path for A/B);
   * HGTCavAttention: HEAL always passes a zero prior encoding (fusion_in_one.py:346-355), so every agent
     has type 0 and only relation 0 is exercised.  The per-head relation matrices are folded into the q / v
     projections once (cached), and the per-pixel L x L attention runs in the fused kernel K6;
@@ -17,7 +23,45 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from heal_amd import ops
+
+
+def _grad_path(x, module):
+    return torch.is_grad_enabled() and (x.requires_grad or module.training)
+
+
+def _fused_ok(x, module):
+    """Inference on the device with shapes heal_linear takes (channels % 128 == 0, H W % 128 == 0): the fused path."""
+    if not x.is_cuda or _grad_path(x, module) or os.environ.get("HEAL_V2XVIT_FUSED", "1") == "0":
+        return False
+    L, H, W, C = x.shape
+    return C % 128 == 0 and (H * W) % 128 == 0 and x.dtype == torch.float32
+
+
+class _Folded:
+    """Cache of derived weights, rebuilt when any source tensor changes (data_ptr / version)."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self.key:
+            with torch.no_grad():
+                self.val = build()
+            self.key = key
+        return self.val
+
+
+def _fold_ln(weight_nk, bias, norm):
+    """LayerNorm(x) W^T + b = ((x - mean) rstd) (W * gamma)^T + (b + W beta)."""
+    w = (weight_nk * norm.weight[None, :]).contiguous()
+    b = weight_nk @ norm.bias
+    if bias is not None:
+        b = b + bias
+    return w, b.contiguous()
 
 
 class PreNorm(nn.Module):
@@ -29,15 +73,34 @@ class PreNorm(nn.Module):
     def forward(self, x, **kwargs):
         return self.fn(self.norm(x), **kwargs)
 
+    def residual(self, x):
+        """fn(norm(x)) + x -- as one fused sequence when the wrapped module has one (inference on the device)."""
+        if hasattr(self.fn, "fused_residual") and _fused_ok(x, self):
+            return self.fn.fused_residual(x, self.norm)
+        return self.fn(self.norm(x)) + x
+
 
 class FeedForward(nn.Module):
     def __init__(self, dim, hidden_dim, dropout=0.0):
         super().__init__()
         self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
                                  nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+        self._f = _Folded()
 
     def forward(self, x):
+        if _grad_path(x, self):
+            return self.net(x)          # training: the reference's Sequential, both Dropouts included (base_transformer.py:19-30)
         return self.net[3](F.gelu(self.net[0](x)))
+
+    def fused_residual(self, x, norm):
+        """LayerNorm -> Linear -> GELU -> Linear -> + x as two heal_linear launches."""
+        l1, l2 = self.net[0], self.net[3]
+        if not (ops.linear_supported(1, l1.in_features, l1.out_features) and ops.linear_supported(1, l2.in_features, l2.out_features)):
+            return self.forward(norm(x)) + x
+        w1, b1 = self._f.get([l1.weight, l1.bias, norm.weight, norm.bias], lambda: _fold_ln(l1.weight, l1.bias, norm))
+        shp = x.shape
+        h = ops.linear(x, w1, b1, stats=ops.ln_stats(x, norm.eps), act="gelu")
+        return ops.linear(h, l2.weight, l2.bias, residual=x.reshape(-1, shp[-1])).view(shp)
 
 
 class HGTCavAttention(nn.Module):
@@ -59,8 +122,10 @@ class HGTCavAttention(nn.Module):
         self.relation_msg = nn.Parameter(torch.empty(num_relations, heads, dim_head, dim_head))
         nn.init.xavier_uniform_(self.relation_att)
         nn.init.xavier_uniform_(self.relation_msg)
+        self.drop_out = nn.Dropout(dropout)   # hmsa.py:57,149: applied to the projected output (active in training only)
         self._key = None
         self._qkv = None
+        self._f = _Folded()
 
     def _folded_qkv(self):
         """[dim, 3*inner] weight and bias of x -> (q W_att, k, v W_msg) for agent type 0 / relation 0:
@@ -98,7 +163,7 @@ class HGTCavAttention(nn.Module):
             vm = torch.einsum("lphd,hde->lphe", v, self.relation_msg[0])
             att = torch.einsum("iphd,jphd->phij", qa, k) * self.scale            # [HW, m, L, L]
             out = torch.einsum("phij,jphd->iphd", att.softmax(dim=-1), vm)       # [L, HW, m, d]
-            return self.a_linears[0](out.reshape(L, H * W, m * d)).reshape(L, H, W, C)
+            return self.drop_out(self.a_linears[0](out.reshape(L, H * W, m * d))).reshape(L, H, W, C)
         w, b = self._folded_qkv()
         qkv = torch.addmm(b, x.reshape(-1, C), w)                       # [L*H*W, 3*inner]
         inner = self.heads * self.dim_head
@@ -106,6 +171,20 @@ class HGTCavAttention(nn.Module):
         out = ops.agent_attention(qkv[0], qkv[1], qkv[2], self.heads, self.scale)   # [HW, L, inner]
         out = self.a_linears[0](out)                                     # [HW, L, C]
         return out.permute(1, 0, 2).reshape(L, H, W, C)
+
+    def fused_residual(self, x, norm):
+        """LayerNorm -> (q W_att | k | v W_msg) as ONE 256 -> 768 heal_linear writing three [L, HW, inner] buffers -> per-pixel
+        agent attention on agent-major tensors -> a_linear + x in the epilogue of the second heal_linear."""
+        L, H, W, C = x.shape
+        inner = self.heads * self.dim_head
+        if inner != 256 or not ops.linear_supported(1, C, 3 * inner):
+            return self.forward(norm(x)) + x
+        w, b = self._folded_qkv()                                        # [C, 3 inner], [3 inner]
+        wq, bq = self._f.get([w, b, norm.weight, norm.bias], lambda: _fold_ln(w.t().contiguous(), b, norm))
+        qkv = ops.linear(x, wq, bq, stats=ops.ln_stats(x, norm.eps), parts=3).view(3, L, H * W, inner)
+        out = ops.agent_attention(qkv[0], qkv[1], qkv[2], self.heads, self.scale, agent_major=True)   # [L, HW, inner]
+        a = self.a_linears[0]
+        return ops.linear(out, a.weight, a.bias, residual=x.reshape(-1, C)).view(L, H, W, C)
 
 
 def _relative_indices(ws):
@@ -134,18 +213,10 @@ class BaseWindowAttention(nn.Module):
         L, H, W, C = x.shape
         ws, m, d = self.window_size, self.heads, self.dim_head
         nh, nw = H // ws, W // ws
-        if self.relative_pos_embedding:
-            # the reference keeps `relative_indices` as a plain (host) attribute -- not a buffer, so it is not in the
-            # state_dict; index with a cached device copy: a host index tensor costs an H2D copy per call and cannot
-            # be captured in a HIP graph
-            ri = self.__dict__.get("_ri_dev")
-            if ri is None or ri[0].device != x.device:
-                r = self.relative_indices.to(x.device)
-                ri = (r[:, :, 0].contiguous(), r[:, :, 1].contiguous())
-                self.__dict__["_ri_dev"] = ri
-            bias = self.pos_embedding[ri[0], ri[1]]
-        else:
-            bias = self.pos_embedding
+        # the reference keeps `relative_indices` as a plain (host) attribute -- not a buffer, so it is not in the state_dict;
+        # position_bias() indexes with a cached device copy: a host index tensor costs an H2D copy per call and cannot be
+        # captured in a HIP graph
+        bias = self.position_bias(x.device)
         qkv = self.to_qkv(x)
         from heal_amd import ops
         if x.is_cuda and ops.window_attention_supported(ws, d, H, W) and not (torch.is_grad_enabled() and (x.requires_grad or self.training)):
@@ -159,7 +230,19 @@ class BaseWindowAttention(nn.Module):
                              beta=1.0, alpha=self.scale)
         out = torch.bmm(dots.softmax(dim=-1), qkv[2])                    # [L*m*nh*nw, ws*ws, d]
         out = out.view(L, m, nh, nw, ws, ws, d).permute(0, 2, 4, 3, 5, 1, 6).reshape(L, H, W, m * d)
+        if _grad_path(x, self):
+            return self.to_out(out)     # training: Linear + Dropout (mswin.py:43-44,79)
         return self.to_out[0](out)
+
+    def position_bias(self, device):
+        if self.relative_pos_embedding:
+            ri = self.__dict__.get("_ri_dev")
+            if ri is None or ri[0].device != device:
+                r = self.relative_indices.to(device)
+                ri = (r[:, :, 0].contiguous(), r[:, :, 1].contiguous())
+                self.__dict__["_ri_dev"] = ri
+            return self.pos_embedding[ri[0], ri[1]]
+        return self.pos_embedding
 
 
 class SplitAttn(nn.Module):
@@ -189,6 +272,7 @@ class PyramidWindowAttention(nn.Module):
         self.pwmsa = nn.ModuleList([BaseWindowAttention(dim, h, d, drop_out, w, relative_pos_embedding)
                                     for h, d, w in zip(heads, dim_heads, window_size)])
         self.fuse_mehod = fuse_method
+        self._f, self._fo, self._fc = _Folded(), _Folded(), _Folded()
         if fuse_method.startswith("split_attn"):
             self.split_attn = SplitAttn({"split_attn": 256, "split_attn128": 128, "split_attn64": 64}[fuse_method])
 
@@ -197,6 +281,38 @@ class PyramidWindowAttention(nn.Module):
         if self.fuse_mehod == "naive":
             return sum(outs) / len(outs)
         return self.split_attn(outs)
+
+    def fused_residual(self, x, norm):
+        """LayerNorm -> the three to_qkv projections as ONE 256 -> 3 x 768 heal_linear (three output buffers) -> three window
+        attentions -> [to_out x 3, split-attention weighting (or the plain mean), + x] as ONE K = 3 x 256 heal_linear whose
+        weight rows carry the per-agent branch weights."""
+        L, H, W, C = x.shape
+        ws = self.pwmsa
+        inner = [w.heads * w.dim_head for w in ws]
+        ok = len(ws) == 3 and all(i == C for i in inner) and all(
+            ops.window_attention_supported(w.window_size, w.dim_head, H, W) for w in ws) and ops.linear_supported(1, C, 9 * C)
+        if not ok or (self.fuse_mehod != "naive" and self.split_attn.input_dim != C):
+            return self.forward(norm(x)) + x
+        srcs = [w.to_qkv.weight for w in ws] + [norm.weight, norm.bias]
+        wq, bq = self._f.get(srcs, lambda: _fold_ln(torch.cat([w.to_qkv.weight for w in ws], 0), None, norm))
+        T = L * H * W
+        qkv = ops.linear(x, wq, bq, stats=ops.ln_stats(x, norm.eps), parts=3)        # [3, T, 3 C]
+        branches = torch.empty((3, T, C), dtype=torch.float32, device=x.device)
+        for i, w in enumerate(ws):
+            ops.window_attention(qkv[i].view(L, H, W, 3 * C), w.position_bias(x.device), w.heads, w.dim_head, w.window_size,
+                                 w.scale, out=branches[i])
+        wo, bo = self._fo.get([w.to_out[0].weight for w in ws] + [w.to_out[0].bias for w in ws], lambda: (
+            torch.stack([w.to_out[0].weight for w in ws]).contiguous(), torch.stack([w.to_out[0].bias for w in ws]).contiguous()))
+        wo_cat = self._fc.get([wo], lambda: torch.cat([wo[0], wo[1], wo[2]], 1).contiguous())   # [C, 3 C]: K runs over branches
+        if self.fuse_mehod == "naive":
+            scale = torch.full((L, 3, C), 1.0 / 3.0, dtype=torch.float32, device=x.device)
+            bias = (bo.sum(0) / 3.0).expand(L, C).contiguous()
+        else:
+            sa = self.split_attn
+            scale, bias = ops.split_attn_weights(branches, L, H * W, wo, bo, sa.fc1.weight, sa.bn1.weight, sa.bn1.bias,
+                                                 sa.bn1.eps, sa.fc2.weight)
+        return ops.linear(branches, wo_cat, bias, residual=x.reshape(-1, C), colscale=scale, colscale_part=C,
+                          group_rows=H * W, bias_per_group=True, x_parts=3).view(L, H, W, C)
 
 
 class V2XFusionBlock(nn.Module):
@@ -218,8 +334,8 @@ class V2XFusionBlock(nn.Module):
 
     def forward(self, x):
         for cav_attn, pwindow_attn in self.layers:
-            x = cav_attn(x) + x
-            x = pwindow_attn(x) + x
+            x = cav_attn.residual(x)
+            x = pwindow_attn.residual(x)
         return x
 
 
@@ -279,7 +395,7 @@ class V2XTEncoder(nn.Module):
             x = self.rte(x)
         for attn, ff in self.layers:
             x = attn(x)
-            x = ff(x) + x
+            x = ff.residual(x)
         return x
 
 

@@ -418,8 +418,9 @@ def window_attention_supported(window, dim_head, H, W):
     return (int(window), int(dim_head)) in _WINDOW_ATTN_SHAPES and H % window == 0 and W % window == 0
 
 
-def window_attention(qkv, pos_bias, heads, dim_head, window, scale):
-    """Fused window attention: qkv [L,H,W,3*heads*dim_head] (packed q|k|v), pos_bias [T,T] or None -> [L,H,W,heads*dim_head]."""
+def window_attention(qkv, pos_bias, heads, dim_head, window, scale, out=None):
+    """Fused window attention: qkv [L,H,W,3*heads*dim_head] (packed q|k|v), pos_bias [T,T] or None -> [L,H,W,heads*dim_head]
+    (written into `out` when given: a contiguous [L,H,W,heads*dim_head] view)."""
     qkv = _need(qkv, torch.float32, "qkv")
     L, H, W, C3 = (int(v) for v in qkv.shape)
     if C3 != 3 * heads * dim_head or not window_attention_supported(window, dim_head, H, W):
@@ -428,7 +429,10 @@ def window_attention(qkv, pos_bias, heads, dim_head, window, scale):
         pos_bias = _need(pos_bias, torch.float32, "pos_bias")
         if tuple(pos_bias.shape) != (window * window, window * window):
             raise _capi.HealAmdError("window_attention: pos_bias must be [window^2, window^2]")
-    out = torch.empty((L, H, W, heads * dim_head), dtype=torch.float32, device=qkv.device)
+    if out is None:
+        out = torch.empty((L, H, W, heads * dim_head), dtype=torch.float32, device=qkv.device)
+    elif not (out.is_contiguous() and out.numel() == L * H * W * heads * dim_head and out.dtype == torch.float32):
+        raise _capi.HealAmdError("window_attention: `out` must be a contiguous f32 [L,H,W,heads*dim_head] buffer")
     with _Timed(f"window_attention_ws{window}"):
         _capi.call("heal_window_attention", _ptr(qkv), _optr(pos_bias), L, H, W, int(heads), int(dim_head), int(window),
                    float(scale), _ptr(out), _stream())
@@ -820,19 +824,85 @@ class SparseTensor:
 
 
 # ------------------------------------------------------------------------------------------------ K6
-def agent_attention(q, k, v, heads, scale, key_mask=None, out_rows=None):
+def agent_attention(q, k, v, heads, scale, key_mask=None, out_rows=None, agent_major=False):
     """K6.  q,k,v [n_pix, L, 256] f32 cuda -> [n_pix, out_rows, 256] (softmax over the L agents per
-    pixel and head; key_mask [L] int32 cuda marks real agents)."""
+    pixel and head; key_mask [L] int32 cuda marks real agents).  agent_major: q, k, v [L, n_pix, 256] -> [out_rows, n_pix, 256]."""
     q = _need(q, torch.float32, "q"); k = _need(k, torch.float32, "k"); v = _need(v, torch.float32, "v")
-    n_pix, L, C = (int(x) for x in q.shape)
+    if agent_major:
+        L, n_pix, C = (int(x) for x in q.shape)
+    else:
+        n_pix, L, C = (int(x) for x in q.shape)
     rows = L if out_rows is None else int(out_rows)
-    out = torch.empty((n_pix, rows, C), dtype=torch.float32, device=q.device)
+    out = torch.empty((rows, n_pix, C) if agent_major else (n_pix, rows, C), dtype=torch.float32, device=q.device)
     if key_mask is not None:
         key_mask = _need(key_mask, torch.int32, "key_mask")
     with _Timed(f"agent_attention_h{heads}"):
-        _capi.call("heal_agent_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(key_mask), n_pix, L, C, int(heads),
-                   float(scale), rows, _ptr(out), _stream())
+        _capi.call("heal_agent_attention", _ptr(q), _ptr(k), _ptr(v), _optr(key_mask), n_pix, L, C, int(heads),
+                   float(scale), rows, _ptr(out), int(bool(agent_major)), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ K6c
+def ln_stats(x, eps):
+    """(mean, rstd) of every token of x [..., C] -> [T, 2] f32: the statistics half of a LayerNorm whose application is
+    folded into the consuming heal_linear."""
+    x = _need(x, torch.float32, "x")
+    C = int(x.shape[-1])
+    T = x.numel() // C
+    stats = torch.empty((T, 2), dtype=torch.float32, device=x.device)
+    _capi.call("heal_ln_stats", _ptr(x), T, C, float(eps), _ptr(stats), _stream())
+    return stats
+
+
+def linear_supported(n_tokens, n_in, n_out):
+    return n_out % 128 == 0 and n_in % 32 == 0 and n_in >= 32 and n_tokens > 0
+
+
+_ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2}
+
+
+def linear(x, weight, bias=None, stats=None, act=None, residual=None, out=None, row_map=None, parts=1, colscale=None,
+           colscale_part=0, group_rows=0, bias_per_group=False, x_parts=1):
+    """heal_linear: out = act(norm(x) W^T * colscale + bias) + residual on the fp32 matrix cores.
+    x [T, K] (any leading dims, contiguous), weight [N, K] (nn.Linear layout), stats from ln_stats() (gamma / beta already folded
+    into weight / bias), row_map = (inner, outer): token t is written to row (t % inner) * outer + t // inner, parts: the N
+    columns are split into `parts` equal column blocks written to out[p] -> returns [parts, T, N / parts] (parts > 1) or [T, N]."""
+    x = _need(x, torch.float32, "x")
+    weight = _need(weight, torch.float32, "weight")
+    # x_parts > 1: x is [x_parts, T, K / x_parts] -- the reduction runs over the channel blocks of several tensors (the three
+    # window-attention branches feeding the merged to_out projection) without a concatenated copy
+    xk = int(x.shape[-1])
+    K = xk * int(x_parts)
+    T = x.numel() // K
+    N = int(weight.shape[0])
+    if int(weight.shape[1]) != K or not linear_supported(T, K, N) or N % parts or (N // parts) % 4:
+        raise _capi.HealAmdError(f"linear: unsupported shape T={T} K={K} N={N} parts={parts}")
+    pc = N // parts
+    if out is None:
+        out = torch.empty((parts, T, pc) if parts > 1 else (T, N), dtype=torch.float32, device=x.device)
+    inner, outer = (int(row_map[0]), int(row_map[1])) if row_map is not None else (0, 0)
+    if residual is not None:
+        residual = _need(residual, torch.float32, "residual")
+    with _Timed(f"linear_{K}_{N}", flops=2.0 * T * K * N):
+        _capi.call("heal_linear", _ptr(x), xk, xk if x_parts > 1 else 0, T * xk, _optr(stats), _ptr(weight), _optr(bias),
+                   int(bool(bias_per_group)),
+                   _optr(colscale), int(colscale_part), int(group_rows), _optr(residual), N if residual is not None else 0,
+                   _ptr(out), pc, T, N, K, inner, outer, pc, T * pc, _ACT[act], _stream())
+    return out
+
+
+def split_attn_weights(branches, groups, rows_per_group, w_out, b_out, fc1, ln_g, ln_b, eps, fc2):
+    """branches [3, groups * rows_per_group, C] (window attention outputs before to_out) -> (scale [groups,3,C], bias [groups,C])."""
+    branches = _need(branches, torch.float32, "branches")
+    C = int(branches.shape[-1])
+    dev = branches.device
+    ws = _workspace("split_attn", _capi.query("heal_split_attn_workspace", groups, rows_per_group, C), dev)
+    scale = torch.empty((groups, 3, C), dtype=torch.float32, device=dev)
+    bias = torch.empty((groups, C), dtype=torch.float32, device=dev)
+    _capi.call("heal_split_attn_weights", _ptr(branches), int(branches.stride(0)), groups, rows_per_group, C, _ptr(w_out),
+               _ptr(b_out), _ptr(fc1), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(fc2), _ptr(ws), _ptr(scale), _ptr(bias),
+               _stream())
+    return scale, bias
 
 
 # ------------------------------------------------------------------------------------------------ K7

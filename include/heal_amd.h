@@ -295,6 +295,7 @@ int heal_bev_pool_backward(const float* grad_cells, const float* depth_logit, co
  * -----------------------------------------------------------------------------------------------*/
 int heal_agent_attention(const float* q, const float* k, const float* v, const int32_t* key_mask, int n_pix,
                          int n_agents, int channels, int heads, float scale, int out_rows, float* out,
+                         int agent_major /* 1: q, k, v, out are [n_agents, n_pix, 256] (the token order of the transformer) */,
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -476,6 +477,35 @@ int heal_nms_quads(const float* quads_sorted, int n, float thresh, void* workspa
  *   (window, dim_head) in {(4,16),(8,32),(16,64),(4,32),(8,16),(8,64),(4,64)}; H, W multiples of window.          */
 int heal_window_attention(const float* qkv, const float* pos_bias, int n_agents, int H, int W, int heads,
                           int dim_head, int window, float scale, float* out, void* stream);
+
+/* ---- V2X-ViT linear algebra (opencood/models/sub_modules/base_transformer.py:7-40, hmsa.py:38-151, mswin.py:46-122,
+ * split_attn.py:6-62, v2xvit_basic.py:158-192): token-major fp32 GEMM on v_mfma_f32_32x32x2_f32 with the LayerNorm of PreNorm
+ * in the prologue and bias / GELU / residual / re-layout in the epilogue, instead of library GEMMs with ATen kernels between.
+ * heal_ln_stats: stats [n_tokens, 2] <- (mean, 1 / sqrt(var + eps)) of every token of x [n_tokens, channels].
+ * heal_linear: out = act(norm(x) W^T * colscale + bias) + residual.
+ *   x [n_tokens, n_in] rows lda floats apart (x_part_cols > 0: channel block k / x_part_cols of a token is read from
+ *   x + block * x_part_stride, i.e. the reduction runs over several [n_tokens, x_part_cols] tensors); ln_stats (or NULL): x is replaced by (x - mean) * rstd per token (fold the
+ *   LayerNorm's gamma into W and beta W^T into bias); weight [n_out, n_in] (nn.Linear layout); bias [n_out], or
+ *   [groups, n_out] with bias_per_group; colscale (or NULL) [groups, n_in / colscale_part, n_out]: weight[n][k] is multiplied by
+ *   colscale[group][k / colscale_part][n], group = token / group_rows (the split-attention merge: three to_out projections and
+ *   the per-agent softmax weights as one K = 3 C GEMM); residual (or NULL) rows ldr apart, indexed like the output; act 0 none,
+ *   1 GELU (erf), 2 ReLU (applied before the residual).  Output addressing: token t goes to row (t % map_inner) * map_outer +
+ *   t / map_inner (map_inner = 0: row t), column c to out + (c / part_cols) * part_stride + row * ldo + c % part_cols.
+ *   n_out multiple of 128, n_in multiple of 32, group_rows multiple of 128.
+ * heal_split_attn_weights: branches = the three window-attention outputs [3][groups * rows_per_group, channels] (part_stride
+ *   floats apart), BEFORE their to_out projections w_out [3, C, C] / b_out [3, C]; -> scale [groups, 3, C] (softmax over the
+ *   three branches of fc2(relu(LN(fc1(global average of the projected sum))))) and bias [groups, C] = sum scale * b_out.     */
+int heal_ln_stats(const float* x, int n_tokens, int channels, float eps, float* stats, void* stream);
+int heal_linear(const float* x, int lda, int x_part_cols, long long x_part_stride, const float* ln_stats,
+                const float* weight, const float* bias,
+                int bias_per_group, const float* colscale, int colscale_part, int group_rows, const float* residual,
+                int ldr, float* out, int ldo, int n_tokens, int n_out, int n_in, int map_inner, int map_outer,
+                int part_cols, long long part_stride, int act, void* stream);
+size_t heal_split_attn_workspace(int groups, int rows_per_group, int channels);
+int heal_split_attn_weights(const float* branches, long long part_stride, int groups, int rows_per_group, int channels,
+                            const float* w_out, const float* b_out, const float* fc1, const float* ln_gamma,
+                            const float* ln_beta, float eps, const float* fc2, float* colsum_ws, float* scale,
+                            float* bias, void* stream);
 
 /* ---- training-side anchor labelling --------------------------------------------------------
  * heal_label_assign: the IoU / assignment core of VoxelPostprocessor.generate_label
