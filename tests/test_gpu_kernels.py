@@ -1085,3 +1085,130 @@ def test_decode_multiscale_feature_writes_the_concatenation_in_place():
             feats[i].double(), d.deblocks[i][0].weight, None, d.deblocks[i][0].stride))) for i in range(3)], 1)
     assert got.shape == (2, 384, 32, 48) and float((got - torch.cat(parts, 1)).abs().max() / got.abs().max()) < 1e-5
     assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- K6c (V2X-ViT linear algebra)
+def _gelu64(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("T,K,N,ln,act,res", [(384, 64, 128, True, "gelu", True), (256, 256, 768, True, None, False),
+                                              (1000, 96, 256, False, "relu", True), (128, 32, 128, False, None, False)])
+def test_linear_vs_fp64(T, K, N, ln, act, res):
+    """heal_linear (fp32 MFMA GEMM, LayerNorm statistics in the prologue, bias / activation / residual in the epilogue) against a
+    float64 restatement of base_transformer.py:7-40's LayerNorm -> Linear -> GELU -> (+ x); ragged token count included."""
+    from heal_amd import ops
+    rng = np.random.default_rng(T + K + N)
+    x = rng.standard_normal((T, K)).astype(np.float32) * 2 + 0.3
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) * 0.1
+    g = rng.uniform(0.5, 1.5, K).astype(np.float32); be = rng.normal(0, 0.1, K).astype(np.float32)
+    r = rng.standard_normal((T, N)).astype(np.float32)
+    x64 = x.astype(np.float64)
+    if ln:
+        mu = x64.mean(1, keepdims=True); var = x64.var(1, keepdims=True)
+        x64 = (x64 - mu) / np.sqrt(var + 1e-5) * g + be
+    ref = x64 @ w.astype(np.float64).T + b
+    if act == "gelu":
+        ref = _gelu64(ref)
+    elif act == "relu":
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    wd, bd = dev(w), dev(b)
+    stats = None
+    if ln:   # the caller folds gamma / beta into the weights (v2xvit_basic._fold_ln)
+        wd, bd = dev(w * g[None, :]), dev(b + w @ be)
+        stats = ops.ln_stats(dev(x), 1e-5)
+        mu32, rstd32 = stats.cpu().numpy().T
+        np.testing.assert_allclose(mu32, x.astype(np.float64).mean(1), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rstd32, 1 / np.sqrt(x.astype(np.float64).var(1) + 1e-5), rtol=1e-5)
+    got = ops.linear(dev(x), wd, bd, stats=stats, act=act, residual=dev(r) if res else None).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_linear_row_map_parts_and_merged_projection():
+    """Output addressing of heal_linear (column parts to separate buffers, [outer, inner] -> [inner, outer] row transposition) and
+    the split-attention merge (split_attn.py:43-62 + mswin.py:79): three to_out projections, the per-agent softmax weights over
+    the three window branches and the residual as ONE K = 3 C GEMM, against the reference's sequence in float64."""
+    from heal_amd import ops
+    rng = np.random.default_rng(5)
+    L, HW, C = 3, 256, 128
+    T = L * HW
+    x = rng.standard_normal((T, C)).astype(np.float32)
+    w3 = (rng.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32)
+    ref = (x.astype(np.float64) @ w3.astype(np.float64).T).reshape(L, HW, 3, C).transpose(2, 1, 0, 3)   # [3, HW, L, C]
+    got = ops.linear(dev(x), dev(w3), row_map=(HW, L), parts=3).view(3, HW, L, C).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    # split attention: branches [3, T, C] -> to_out_i -> radix softmax weights -> weighted sum + residual
+    br = rng.standard_normal((3, T, C)).astype(np.float32)
+    wo = (rng.standard_normal((3, C, C)) / np.sqrt(C)).astype(np.float32); bo = rng.normal(0, 0.1, (3, C)).astype(np.float32)
+    fc1 = (rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)
+    fc2 = (rng.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32)
+    lg = rng.uniform(0.5, 1.5, C).astype(np.float32); lb = rng.normal(0, 0.1, C).astype(np.float32)
+    outs = [br[i].astype(np.float64) @ wo[i].astype(np.float64).T + bo[i] for i in range(3)]          # to_out
+    gap = sum(outs).reshape(L, HW, C).mean(1)                                                          # [L, C]
+    h = gap @ fc1.astype(np.float64).T
+    h = (h - h.mean(1, keepdims=True)) / np.sqrt(h.var(1, keepdims=True) + 1e-5) * lg + lb
+    a = np.maximum(h, 0) @ fc2.astype(np.float64).T                                                    # [L, 3 C]
+    a = a.reshape(L, 3, C); a = np.exp(a - a.max(1, keepdims=True)); a /= a.sum(1, keepdims=True)       # softmax over branches
+    ref = sum(outs[i].reshape(L, HW, C) * a[:, i][:, None, :] for i in range(3)) + x.reshape(L, HW, C)
+    scale, bias = ops.split_attn_weights(dev(br), L, HW, dev(wo), dev(bo), dev(fc1), dev(lg), dev(lb), 1e-5, dev(fc2))
+    np.testing.assert_allclose(scale.cpu().numpy(), a, rtol=1e-4, atol=1e-5)
+    wo_cat = np.concatenate([wo[0], wo[1], wo[2]], 1)
+    got = ops.linear(dev(br), dev(wo_cat), bias, residual=dev(x), colscale=scale, colscale_part=C, group_rows=HW,
+                     bias_per_group=True, x_parts=3).cpu().numpy().reshape(L, HW, C)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_agent_attention_agent_major_equals_pixel_major():
+    from heal_amd import ops
+    rng = np.random.default_rng(2)
+    L, P = 5, 300
+    q, k, v = (dev(rng.standard_normal((P, L, 256)).astype(np.float32)) for _ in range(3))
+    a = ops.agent_attention(q, k, v, 8, 0.17)
+    b = ops.agent_attention(q.transpose(0, 1).contiguous(), k.transpose(0, 1).contiguous(), v.transpose(0, 1).contiguous(),
+                            8, 0.17, agent_major=True)
+    assert torch.equal(b.transpose(0, 1), a)
+
+
+def test_v2xvit_fused_path_equals_library_path(monkeypatch):
+    """The round-3 inference path of the V2X-ViT encoder (heal_linear / heal_ln_stats / heal_split_attn_weights, no library GEMM)
+    against the round-2 composition of library GEMMs and ATen kernels on the same weights (itself pinned by the reference
+    goldens fusion_small / baseline_small)."""
+    from heal_amd import configs
+    from heal_amd.opencood.models.sub_modules.v2xvit_basic import V2XTransformer
+    from tests.golden.detfill import fill_module
+    m = fill_module(V2XTransformer(configs._v2xvit_args()["transformer"])).cuda().eval()
+    x = dev(np.random.default_rng(3).standard_normal((4, 32, 48, 256)).astype(np.float32))
+    with torch.no_grad():
+        monkeypatch.setenv("HEAL_V2XVIT_FUSED", "0")
+        ref = m(x)
+        monkeypatch.setenv("HEAL_V2XVIT_FUSED", "1")
+        got = m(x)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4
+
+
+def test_rank_rulebook_equals_hash_rulebook(monkeypatch):
+    """Strided output sites and neighbour rows through the rank structure (bitmap + prefix counts) = the hash + sort path,
+    bit for bit, including the capacity-sized / device-count mode and sites dropped beyond a capacity."""
+    from heal_amd import ops
+    rng = np.random.default_rng(11)
+    shape, batch = (21, 40, 52), 3
+    idx = _random_sites(rng, 6000, shape, batch)
+    x = ops.SparseTensor.from_unsorted(dev(np.ones((len(idx), 4), np.float32)), dev(idx), shape, batch)
+    for k, st, pd in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
+        monkeypatch.setenv("HEAL_SP_RULEBOOK", "hash")
+        oi_h, osh, _, rk = x.out_sites_ex(k, st, pd)
+        assert rk is None
+        nbr_h = x.neighbors(oi_h, osh, k, st, pd)
+        monkeypatch.setenv("HEAL_SP_RULEBOOK", "rank")
+        oi, osh2, _, rank = x.out_sites_ex(k, st, pd)
+        assert osh == osh2 and torch.equal(oi, oi_h) and rank is not None
+        y = ops.SparseTensor(torch.zeros((oi.shape[0], 4), device="cuda"), oi, osh, batch)
+        y_h = ops.SparseTensor(torch.zeros((oi.shape[0], 4), device="cuda"), oi, osh, batch)
+        y._rank = rank
+        sub = (3, 3, 3)
+        assert torch.equal(y.neighbors(oi, osh, sub, (1, 1, 1), (1, 1, 1)), y_h.neighbors(oi, osh, sub, (1, 1, 1), (1, 1, 1)))
+        assert torch.equal(x.neighbors(oi, osh, k, st, pd), nbr_h)
