@@ -177,10 +177,21 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         cam_ids = [i for i, m in enumerate(mods) if m in Scene.CAMERA_DIMS and (solo or i in owned_agents(n_agents, 0, world))]
         if cam_ids:
             per_call = []
+            margs = hypes["model"]["args"]
             for i in cam_ids:
-                H, W = Scene.CAMERA_DIMS[mods[i]]
-                fhw = (H // 8) * (W // 8)
-                per_call.append(4.0 * (4 * 48 * fhw + 4 * 128 * fhw + 128 * 256 * 256))
+                # from the model configuration of that modality (not constants): D depth bins, C image features, the BEV grid;
+                # feature map = ceil(H / 8) x ceil(W / 8) (the trunks round up)
+                ca = margs[mods[i]]["encoder_args"]
+                gc = ca["grid_conf"]
+                D, C = int(gc["ddiscr"][2]), int(ca["img_features"])
+                nx = int(round((gc["xbound"][1] - gc["xbound"][0]) / gc["xbound"][2]))
+                ny = int(round((gc["ybound"][1] - gc["ybound"][0]) / gc["ybound"][2]))
+                nz = max(1, int(round((gc["zbound"][1] - gc["zbound"][0]) / gc["zbound"][2])))
+                H, W = ca["data_aug_conf"]["final_dim"]
+                ds = int(ca["img_downsample"])
+                fhw = -(-H // ds) * -(-W // ds)
+                n_cam = len(ca["data_aug_conf"].get("cams", [0, 1, 2, 3])) if isinstance(ca["data_aug_conf"].get("cams"), (list, tuple)) else 4
+                per_call.append(4.0 * (n_cam * D * fhw + n_cam * C * fhw + C * nz * ny * nx))
             calls, mean_ms = timing["bev_pool"]
             bts = sum(per_call) / len(per_call)
             entries["k4"] = (calls * mean_ms, _entry(

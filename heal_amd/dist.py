@@ -6,8 +6,9 @@ agents {a : (a + 1) % world == r}: round-robin starting at rank 1, because rank 
 (with more ranks than agents it owns no agent at all and its tail overlaps the other ranks' next local stage;
 with fewer it gets the smallest share).  Each rank warps its own agents'
 multi-scale features and scores into the ego frame (heal_warp_agent), packs them into one buffer,
-and ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests) brings every agent's
-warped maps to every rank.  Rank 0 then runs the fusion tail (heal_fuse_warped, deblocks, shrink
+and ONE exchange (RCCL over xGMI on the GPU box, gloo in the CPU tests) brings every agent's
+warped maps to rank 0 -- a gather by default, the all-gather north_star names on request
+(`collective`).  Rank 0 then runs the fusion tail (heal_fuse_warped, deblocks, shrink
 head, detection heads, decode + NMS).
 """
 import torch
@@ -82,8 +83,28 @@ def unpack_maps(gathered, shape, n_agents, world):
     return rows.reshape((n_agents,) + tuple(shape))
 
 
+def gather_packed(buf, world, rank, out=None):
+    """The path's single exchange as a GATHER to rank 0 (default since round 3): only rank 0 runs the fusion tail, so only
+    rank 0 needs the other ranks' maps -- a gather moves (world - 1) shards over rank 0's links once, the all-gather of rounds
+    1-2 delivered every shard to every rank (world times the bytes on the fabric; the same bytes INTO rank 0, which is what
+    bounds the step, so the gain is fabric load and the other ranks' HBM, not latency).  Returns [world, n_slots, per_slot] on
+    rank 0 (`out` when given), None elsewhere.  RCCL runs it as grouped send / recv; gloo has it natively."""
+    if world == 1:
+        return buf.unsqueeze(0)
+    n_slots, per_slot = buf.shape
+    buf = buf.contiguous()
+    if rank != 0:
+        dist.gather(buf, None, dst=0)
+        return None
+    if out is None:
+        out = torch.empty((world, n_slots, per_slot), dtype=buf.dtype, device=buf.device)
+    dist.gather(buf, [out[r] for r in range(world)], dst=0)
+    return out
+
+
 def all_gather_packed(buf, world):
-    """The path's single collective: every rank contributes its [n_slots, per_slot] buffer."""
+    """The exchange as the all-gather `north_star` names (HEAL_COLLECTIVE=all_gather): every rank contributes its
+    [n_slots, per_slot] buffer and receives all of them."""
     if world == 1:
         return buf.unsqueeze(0)
     n_slots, per_slot = buf.shape
@@ -100,15 +121,30 @@ class _Sharded:
     contain no collective and no host round trip, so each can be captured once into a HIP graph and replayed
     (`capture`); the collective stays an ordinary stream op between the two replays."""
 
-    def __init__(self, model, rank, world, wire_dtype=None):
-        """wire_dtype: dtype of the all-gathered buffer.  None / torch.float32 = exact (default); torch.float16 halves the
+    def __init__(self, model, rank, world, wire_dtype=None, collective=None):
+        """collective: "gather" (default: to rank 0, the only consumer) | "all_gather" (what north_star names; env
+        HEAL_COLLECTIVE).  wire_dtype: dtype of the exchanged buffer.  None / torch.float32 = exact (default); torch.float16 halves the
         bytes on xGMI (29.7 -> 14.9 MB per agent) at ~5e-4 relative rounding of the shared features --
         opt-in (env HEAL_WIRE=fp16 in bench.py), because it spends half of the 1e-3 parity budget."""
         self.model = model
         self.rank = rank
         self.world = world
         self.wire_dtype = wire_dtype if wire_dtype is not None else torch.float32
+        import os
+        self.collective = collective or os.environ.get("HEAL_COLLECTIVE", "gather")
+        if self.collective not in ("gather", "all_gather"):
+            raise ValueError(f"collective must be 'gather' or 'all_gather', got {self.collective!r}")
         self._g_local = self._g_tail = None
+
+    def _exchange(self, buf, out=None):
+        """The single exchange step: [world, n_slots, per_slot] on rank 0 (on every rank with all_gather), else None."""
+        if self.collective == "all_gather" or self.world == 1:
+            g = all_gather_packed(buf, self.world)
+            if out is not None:
+                out.copy_(g)
+                return out
+            return g
+        return gather_packed(buf, self.world, self.rank, out)
 
     def prepare(self, scene_input, n_agents, local_inputs):
         """Hook: anything ranks must agree on before the first `local` (may communicate; never captured)."""
@@ -143,7 +179,7 @@ class _Sharded:
         on rank 0, None elsewhere."""
         self.prepare(scene_input, n_agents, local_inputs)
         buf = self.local(scene_input, n_agents, local_inputs)
-        gathered = all_gather_packed(buf, self.world)
+        gathered = self._exchange(buf)
         if self.rank != 0:
             return None
         return self.tail(gathered, n_agents)
@@ -196,7 +232,8 @@ class _Sharded:
         if not self._agree(ok, dev):
             self._g_local = None
             return False
-        self._static_gathered = all_gather_packed(self._static_buf, self.world).clone()
+        g0 = self._exchange(self._static_buf)
+        self._static_gathered = g0.clone() if g0 is not None else None
         ok = True
         if self.rank == 0:
             cur.synchronize()
@@ -221,7 +258,7 @@ class _Sharded:
         ops.verify_sparse_capacity(self._graph_checks)
 
     def replay(self):
-        """graph(local) -> all-gather -> graph(tail).  The graphs read whatever the buffers behind the captured inputs hold
+        """graph(local) -> exchange (gather to rank 0 | all-gather) -> graph(tail).  The graphs read whatever the buffers behind the captured inputs hold
         (pipeline.StaticInputs.load puts the next frame there: sensor data AND poses)."""
         if self._g_local is not None:   # None: this rank owns no agent, its slot is the constant zero buffer
             self._g_local.replay()
@@ -230,9 +267,11 @@ class _Sharded:
             # (ops.sparse_overflow_flag) that the same check reads keeps a violation of ANY frame in between
             if self._graph_checks and self._replays % 32 == 0:
                 self.check_sparse_capacity()
-        if self.world > 1:
+        if self.world > 1 and self.collective == "all_gather":
             n_slots, per_slot = self._static_buf.shape
             dist.all_gather_into_tensor(self._static_gathered.view(self.world * n_slots, per_slot), self._static_buf)
+        elif self.world > 1:
+            gather_packed(self._static_buf, self.world, self.rank, self._static_gathered)
         else:
             self._static_gathered.copy_(self._static_buf.unsqueeze(0))
         if self.rank != 0:
@@ -359,11 +398,11 @@ class ShardedBaseline(_Sharded):
         return {"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
 
 
-def make_sharded(model, rank, world, wire_dtype=None):
+def make_sharded(model, rank, world, wire_dtype=None, collective=None):
     """The agent-sharded runner that matches the model class."""
     name = type(model).__name__
     if name == "HeterPyramidCollab":
-        return ShardedCollab(model, rank, world, wire_dtype)
+        return ShardedCollab(model, rank, world, wire_dtype, collective)
     if name == "HeterModelBaseline":
-        return ShardedBaseline(model, rank, world, wire_dtype)
+        return ShardedBaseline(model, rank, world, wire_dtype, collective)
     raise NotImplementedError(f"no agent-sharded split for {name}")

@@ -276,7 +276,10 @@ class LiftSplatShoot(nn.Module):
             self.depth_items = res[0]
         cam = self.camera_matrices(inp["rots"], inp["trans"], inp["intrins"], inp["post_rots"], inp["post_trans"])
         if len(res) == 2:   # (items, head): pixel-major fused heads -> K4 without a transposition pass
-            return self.pool_pixel_major(res[1], cam, B, N, imH // self.downsample, imW // self.downsample)
+            # feature-map size from the trunk's own output: the trunks round UP (7x7 s2 p3, max-pool p1, TF-same padding), so
+            # an image size not divisible by the downsample factor is not imH // downsample
+            fH, fW = self.camencode.last_feature_hw
+            return self.pool_pixel_major(res[1], cam, B, N, fH, fW)
         return self.pool(res[1].contiguous(), res[2].contiguous(), cam, B, N)
 
 

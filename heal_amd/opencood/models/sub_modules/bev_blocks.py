@@ -57,8 +57,10 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
     hand-written stencil kernel (heal_grouped_conv3x3); everything else is a library convolution WITHOUT
     bias followed by ONE fused in-place pass (heal_bias_act) instead of separate bias / add / ReLU kernels."""
     from heal_amd import ops
-    if torch.is_grad_enabled() and x.requires_grad:
-        y = F.conv2d(x, w, b, stride, padding, dilation, groups)   # gradient path (callers that pass raw parameters)
+    # gradient path (callers that pass raw parameters): also when only the WEIGHTS are trainable -- the HIP output carries no
+    # graph, so a frozen trunk in front of a trainable convolution would silently drop dL/dw (ADVICE r2)
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        y = F.conv2d(x, w, b, stride, padding, dilation, groups)
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y

@@ -237,6 +237,7 @@ class _CamEncodeBase(nn.Module):
         from heal_amd import ops
         w, b = self._fused_head()
         head = ops.conv1x1(features, w, b, None, 0, pixel_major=True)
+        self.last_feature_hw = (int(features.shape[2]), int(features.shape[3]))   # what the trunk produced (ceil(H/8), not H//8)
         items = None
         if self.depth_supervision:
             BN, _, fH, fW = features.shape

@@ -118,6 +118,8 @@ def _block(cin, cout, k, key, stride=1, padding=0, conv_type="subm"):
 
 
 class VoxelBackBone8x(nn.Module):
+    DENSE_GRAD_MAX_CELLS = 24_000_000   # dense gradient path: ~1.5 GB for the widest early activation at this size
+
     def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
         super().__init__()
         self.model_cfg = model_cfg
@@ -141,6 +143,14 @@ class VoxelBackBone8x(nn.Module):
         feats, coords = batch_dict["voxel_features"], batch_dict["voxel_coords"].long()
         B = int(batch_dict["batch_size"])
         D, H, W = self.sparse_shape
+        cells = B * D * H * W
+        if cells > self.DENSE_GRAD_MAX_CELLS:
+            raise NotImplementedError(
+                f"VoxelBackBone8x: the gradient path evaluates the sparse encoder as a dense masked conv3d; a grid of "
+                f"{B} x {D} x {H} x {W} = {cells / 1e6:.0f} M cells x >= 16 channels does not fit (limit "
+                f"{self.DENSE_GRAD_MAX_CELLS / 1e6:.0f} M cells, ~0.1 GB per channel).  Training SECOND at this range needs the "
+                "sparse backward of K3 (gather-GEMM with the transposed rulebook + per-tap weight gradient), which is not "
+                "built yet (DESIGN.md 7/8); use a smaller lidar_range / larger voxel_size, or run inference (no_grad).")
         site = (coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3])
         x = feats.new_zeros((B, D, H, W, feats.shape[1])).index_put(site, feats).permute(0, 4, 1, 2, 3)
         mask = feats.new_zeros((B, D, H, W)).index_put(site, feats.new_ones(coords.shape[0])).unsqueeze(1)

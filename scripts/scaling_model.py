@@ -1,0 +1,125 @@
+"""Predicted 1 / 2 / 4 / 8-GPU curve of the agent-sharded step from times MEASURED on one MI355X.
+
+For every world size N the ownership of heal_amd.dist is applied, every rank's `local` stage (encode its agents ... warp into
+the ego frame ... pack) and rank 0's `tail` (fuse, deblocks / transformer, heads, decode + NMS) are captured as HIP graphs
+exactly as `_Sharded.capture` does and replayed ALONE on this GPU (HIP events), and the one exchange is priced from its bytes:
+
+    exchange(N) = bytes of the fullest sender (slots_per_rank x shard) / link rate      (gather: one xGMI link per sender,
+                  senders in parallel into rank 0; 153 GB/s per link x 0.75 sustained)
+    period(N)   = max( max_r local_r + exchange,  local_0 + exchange + tail )           (rank 0 runs the tail; the other
+                  ranks' next local stage overlaps it, the next exchange waits for rank 0)
+
+This is a MODEL, not a measurement: no multi-GPU hardware was available to the builder (SCALE_r01/r02: skipped).  It is what
+the first hardware run is to be checked against.
+
+    python scripts/scaling_model.py [--workload scene5|scene8_second_v2xvit] [--json out.json]
+"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+LINK_GBS = 153.0 * 0.75
+
+
+def timed_graph(fn, stream, iters=10):
+    for _ in range(2):
+        out = fn()
+    stream.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+        out = fn()
+    for _ in range(2):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        g.replay()
+    e1.record(stream)
+    stream.synchronize()
+    return out, e0.elapsed_time(e1) / iters, g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="scene5")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    from bench import WORKLOADS
+    from heal_amd import configs, ops
+    from heal_amd.dist import make_sharded, owned_agents, slots_per_rank
+    from heal_amd.pipeline import Scene, ScenePipeline, StaticInputs
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    mods, desc = WORKLOADS[a.workload]
+    n_agents = len(mods)
+    baseline = a.workload == "scene8_second_v2xvit"
+    if baseline:
+        hypes = configs.lidar_baseline("v2xvit", max_cav=n_agents, modality="m3")
+    elif all(m == "m1" for m in mods):
+        hypes = configs.lidar_pyramid(max_cav=max(5, n_agents))
+    else:
+        hypes = configs.heal_heter(tuple(sorted(set(mods))), max_cav=max(5, n_agents))
+    pipe = ScenePipeline(hypes, dev, seed=0)
+    scene = Scene(n_agents, seed=4, device=dev, modalities=mods)
+    pipe.calibrate_cls_bias(scene)
+    dir_args = pipe.post.params.get("dir_args", {"dir_offset": 0.7853, "num_bins": 2})
+    anchors_f32 = pipe.post._anchors_f32(pipe.anchor_box, dev)
+
+    def post_fn(out):
+        return ops.decode_nms(out["cls_preds"], out["reg_preds"], out.get("dir_preds"), anchors_f32,
+                              pipe.post.params["target_args"]["score_threshold"], dir_args["dir_offset"], dir_args["num_bins"],
+                              pipe.post.params["nms_thresh"], np.eye(4, dtype=np.float32), pipe.post.params["gt_range"], sync=False)
+
+    rows = []
+    keep = []   # graphs and their outputs stay alive
+    with torch.no_grad():
+        for N in (1, 2, 4, 8):
+            runners = [make_sharded(pipe.model, r, N, collective="gather") for r in range(N)]
+            local_ms, bufs, shape = [], [None] * N, None
+            for r in range(N):
+                mine = owned_agents(n_agents, r, N)
+                if not mine:
+                    local_ms.append(0.0)
+                    continue
+                static = StaticInputs(scene, agents=mine)
+                static.load(scene)
+                li, inp = static.inputs_for(mine), static.scene_meta()
+                buf, ms, g = timed_graph(lambda: runners[r].local(inp, n_agents, li), stream)
+                keep.append((g, buf, static))
+                local_ms.append(ms)
+                bufs[r] = buf
+                shape = getattr(runners[r], "_shape", None) or shape
+            for r in range(N):   # ranks without agents contribute a zero slot
+                if bufs[r] is None:
+                    bufs[r] = torch.zeros_like(next(b for b in bufs if b is not None))
+                if shape is not None:
+                    runners[r]._shape = shape
+            gathered = torch.stack(bufs)
+            _, tail_ms, g = timed_graph(lambda: post_fn(runners[0].tail(gathered, n_agents)), stream)
+            keep.append((g, gathered))
+            shard_bytes = bufs[0].shape[1] * bufs[0].element_size()
+            senders = [r for r in range(1, N)]
+            exch_ms = (slots_per_rank(n_agents, N) * shard_bytes / (LINK_GBS * 1e9) * 1e3) if senders else 0.0
+            period = max(max(local_ms) + exch_ms, local_ms[0] + exch_ms + tail_ms)
+            rows.append({"n_gpus": N, "owned": [owned_agents(n_agents, r, N) for r in range(N)],
+                         "local_ms": [round(v, 3) for v in local_ms], "tail_ms": round(tail_ms, 3),
+                         "shard_MB": round(shard_bytes / 1e6, 2), "exchange_ms_model": round(exch_ms, 3),
+                         "period_ms_model": round(period, 3), "scenes_per_s_model": round(1e3 / period, 1)})
+            print(json.dumps(rows[-1]), flush=True)
+    base = rows[0]["period_ms_model"]
+    for r in rows:
+        r["speedup_model"] = round(base / r["period_ms_model"], 2)
+        r["efficiency_model"] = round(base / r["period_ms_model"] / r["n_gpus"], 3)
+    out = {"workload": a.workload, "link_GBs_assumed": LINK_GBS, "note": "model from single-GPU measurements; unmeasured on >1 GPU",
+           "rows": rows}
+    print(json.dumps({k: v for k, v in out.items() if k != "rows"}))
+    for r in rows:
+        print(r["n_gpus"], r["period_ms_model"], r["scenes_per_s_model"], r["speedup_model"], r["efficiency_model"])
+    if a.json:
+        json.dump(out, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

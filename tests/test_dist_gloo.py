@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, n_agents, port, tmp, wire=None):
+def _worker(rank, world, n_agents, port, tmp, wire=None, collective="all_gather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,19 +41,24 @@ def _worker(rank, world, n_agents, port, tmp, wire=None):
     buf = hd.pack_levels(lf, ls, hd.slots_per_rank(n_agents, world))
     if wire is not None:  # the optional half-size wire format of ShardedCollab (cast, gather, cast back)
         buf = buf.to(getattr(torch, wire))
-    gathered = hd.all_gather_packed(buf, world).float()
-    levels = hd.unpack_levels(gathered, SHAPES, n_agents, world)
+    if collective == "gather":   # round 3 default: only rank 0 (the fusion tail) receives the shards
+        gathered = hd.gather_packed(buf, world, rank)
+        assert (gathered is None) == (rank != 0)
+    else:
+        gathered = hd.all_gather_packed(buf, world)
     if rank == 0:
+        levels = hd.unpack_levels(gathered.float(), SHAPES, n_agents, world)
         torch.save([(f.clone(), s.clone()) for f, s in levels], tmp)
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("collective", ["all_gather", "gather"])
 @pytest.mark.parametrize("n_agents", [5, 2, 1])
-def test_all_gather_of_packed_maps_world2(tmp_path, n_agents):
+def test_all_gather_of_packed_maps_world2(tmp_path, n_agents, collective):
     world = 2
     out = str(tmp_path / "levels.pt")
-    mp.spawn(_worker, args=(world, n_agents, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, n_agents, _free_port(), out, None, collective), nprocs=world, join=True)
     levels = torch.load(out)
     for l, (f, s) in enumerate(levels):
         want_f = torch.stack([_agent_maps(a)[0][l] for a in range(n_agents)])
