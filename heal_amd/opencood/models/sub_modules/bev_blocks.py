@@ -78,10 +78,28 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
             and (padding if isinstance(padding, int) else padding[1]) == 1
             and (stride if isinstance(stride, int) else stride[1]) == st):
         return ops.conv3x3(x, w, b, residual, relu, st)
+    _library_fallthrough(x, w, stride, padding, dilation, groups)
     y = F.conv2d(x, w, None, stride, padding, dilation, groups)
     if b is None and residual is None and not relu:
         return y
     return ops.bias_act_(y, b, residual, relu)
+
+
+LIBRARY_CONV_SHAPES = {}   # (Cin, Cout, k, stride, padding, dilation, groups, H, W) -> calls: what reached MIOpen, for inspection
+
+
+def _library_fallthrough(x, w, stride, padding, dilation, groups):
+    """A convolution none of the hand-written kernels takes runs on the library (MIOpen).  That is correct but silent: a config
+    change can put library convolutions back on the path unnoticed.  Counted per shape, warned once per shape."""
+    key = (int(w.shape[1]) * groups, int(w.shape[0]), tuple(int(v) for v in w.shape[2:]), stride, padding, dilation, groups,
+           int(x.shape[2]), int(x.shape[3]))
+    n = LIBRARY_CONV_SHAPES.get(key, 0)
+    LIBRARY_CONV_SHAPES[key] = n + 1
+    if n == 0 and x.is_cuda:
+        import warnings
+        warnings.warn(f"heal_amd: convolution Cin={key[0]} Cout={key[1]} k={key[2]} stride={stride} pad={padding} dil={dilation} "
+                      f"groups={groups} on a {key[7]}x{key[8]} map is not covered by a hand-written kernel: library (MIOpen) path",
+                      RuntimeWarning, stacklevel=3)
 
 
 def grad_path(x, *modules):

@@ -285,3 +285,32 @@ def heter_pyramid_collab(sd, cfg_args, data, boundary=None, taps=None):
                 "reg_preds": F.conv2d(y, sd["reg_head.weight"], sd["reg_head.bias"]).numpy(),
                 "dir_preds": F.conv2d(y, sd["dir_head.weight"], sd["dir_head.bias"]).numpy(),
                 "occ_single_list": occs}
+
+
+def base_bev_backbone(sd, prefix, x, cfg):
+    """BaseBEVBackbone.forward (base_bev_backbone.py:96-156) from a state_dict: per level ZeroPad2d(1) + Conv2d(3, stride) + BN(1e-3)
+    + ReLU, `layer_nums` x (Conv2d(3, pad 1) + BN + ReLU); deblocks ConvTranspose2d(stride) + BN + ReLU; channel concat."""
+    ups = []
+    for i, (n, s) in enumerate(zip(cfg["layer_nums"], cfg["layer_strides"])):
+        p = f"{prefix}blocks.{i}"
+        x = F.relu(_bn(F.conv2d(F.pad(x, (1, 1, 1, 1)), sd[f"{p}.1.weight"], None, s), sd, f"{p}.2", 1e-3))
+        for k in range(n):
+            x = F.relu(_bn(F.conv2d(x, sd[f"{p}.{4 + 3 * k}.weight"], None, 1, 1), sd, f"{p}.{5 + 3 * k}", 1e-3))
+        if cfg.get("upsample_strides"):
+            ups.append(_deblock(x, sd, f"{prefix}deblocks.{i}", cfg["upsample_strides"][i]))
+        else:
+            ups.append(x)
+    return torch.cat(ups, 1) if len(ups) > 1 else ups[0]
+
+
+def second_detector(sd, args, voxels, coords, num, sparse_shape, batch):
+    """Old-style SECOND (opencood/models/second.py:33-58): MeanVFE -> VoxelBackBone8x + HeightCompression (the dense restatement
+    of the sparse-convolution rules, oracle_np.second_backbone) -> BaseBEVBackbone -> the two 1x1 heads.  -> (psm, rm) torch CPU."""
+    sd = {k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}
+    feats = O.mean_vfe(voxels, num)
+    bev = torch.from_numpy(O.second_backbone({k: v.numpy() for k, v in sd.items()}, "backbone_3d.", feats, coords, sparse_shape,
+                                             batch))
+    x = base_bev_backbone(sd, "backbone_2d.", bev, args["base_bev_backbone"])
+    psm = F.conv2d(x, sd["cls_head.weight"], sd["cls_head.bias"])
+    rm = F.conv2d(x, sd["reg_head.weight"], sd["reg_head.bias"])
+    return psm, rm

@@ -137,6 +137,32 @@ def test_lift_pool_backward_kernel_vs_torch_autograd(pitch):
         bad = int((err.amax(dim=1) > 1e-4).sum())            # pixels (camera, v, u) with any channel / bin off
         assert bad <= 4, (name, bad, float(err.max()))
     assert bool(torch.isfinite(logit.grad).all()) and bool(torch.isfinite(feat.grad).all())
+    # finite differences in FLOAT64 with the ORACLE's cell assignment (oracle_np.lss_geometry + the trunc-to-cell / bounds rule of
+    # oracle_np.bev_pool; the cell of every frustum point is fixed, so the pooled map is smooth in logits and features):
+    # directional derivative along a random direction against <device gradient, direction> (the reference above
+    # shares the device and fp32 with the kernel under test)
+    from oracle import oracle_np as O
+    rigs = {k: v.detach().cpu().numpy() for k, v in inp.items()}
+    fr = O.create_frustum(enc.data_aug_conf["final_dim"], enc.downsample, enc.grid_conf["ddiscr"], enc.grid_conf["mode"])
+    dx, bx, nx = O.gen_dx_bx(enc.grid_conf["xbound"], enc.grid_conf["ybound"], enc.grid_conf["zbound"])
+    geom = O.lss_geometry(fr, rigs["rots"], rigs["trans"], rigs["intrins"], rigs["post_rots"], rigs["post_trans"])   # [1,4,D,fH,fW,3]
+    cell = np.trunc((np.asarray(geom, np.float32) - (bx - dx / np.float32(2.0))) / dx).astype(np.int64)[0]            # [4,D,fH,fW,3]
+    ok = ((cell >= 0) & (cell < np.asarray(nx)[None, None, None, None, :])).all(-1)
+    w64 = wgt.double().cpu().numpy()[0]                                   # [C * nz, ny, nx], nz = 1
+    assert int(nx[2]) == 1
+    G = np.where(ok[..., None], w64[:, np.clip(cell[..., 1], 0, nx[1] - 1), np.clip(cell[..., 0], 0, nx[0] - 1)]
+                 .transpose(1, 2, 3, 4, 0), 0.0)                          # weight of the point's cell per channel [4,D,fH,fW,C]
+
+    def value(lg, ft):
+        e = np.exp(lg - lg.max(1, keepdims=True)); p = e / e.sum(1, keepdims=True)                  # [4,D,fH,fW]
+        return float(np.einsum("ndvu,ncvu,ndvuc->", p, ft, G))
+    l0, f0 = logit.detach().double().cpu().numpy(), feat.detach().double().cpu().numpy()
+    rng = np.random.default_rng(1)
+    dl, df = rng.standard_normal(l0.shape), rng.standard_normal(f0.shape)
+    eps = 1e-6
+    fd = (value(l0 + eps * dl, f0 + eps * df) - value(l0 - eps * dl, f0 - eps * df)) / (2 * eps)
+    an = float((logit.grad.double().cpu().numpy() * dl).sum() + (feat.grad.double().cpu().numpy() * df).sum())
+    assert abs(fd - an) <= 1e-3 * max(abs(fd), 1.0), (fd, an)
 
 
 @pytest.mark.parametrize("n,f64,with_crop", [(5, True, False), (3, False, True), (1, True, False)])
@@ -170,6 +196,15 @@ def test_warp_fuse_backward_kernel_vs_torch_autograd(n, f64, with_crop):
     assert float((x.grad - gx_ref).abs().max() / gx_ref.abs().max()) < 1e-4
     # one agent: the softmax is constant, the logits get no gradient at all (in either implementation)
     assert float((occ.grad - go_ref).abs().max()) <= 1e-4 * float(go_ref.abs().max())
+    # independent of the device and of fp32: the same composition differentiated on the CPU in FLOAT64 (the check
+    # above shares the device and the precision with the kernel under test)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    o64 = occ.detach().double().cpu().requires_grad_(True)
+    ref64 = weighted_fuse_autograd(x64, o64, [n], rows.astype(np.float64), crops)
+    (ref64 * wgt.double().cpu()).sum().backward()
+    assert float((got.detach().double().cpu() - ref64.detach()).abs().max() / ref64.abs().max()) < 1e-4
+    assert float((x.grad.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()) < 1e-4
+    assert float((occ.grad.double().cpu() - o64.grad).abs().max()) <= 1e-4 * max(float(o64.grad.abs().max()), 1e-30)
 
 
 def test_second_gradient_path_equals_sparse_kernels():
