@@ -103,6 +103,31 @@ def cpu_baseline(hypes, scene_cpu, cls_shift=0.0):
                       f"NMS), {dt:.1f} s on {cores} threads"}
 
 
+_PMC = None
+
+
+def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary of THIS workload
+    (profiles/r03_pmc_traffic_<workload>.json, scripts/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, bytes =
+    2 FETCH + WRITE per the guide's gfx950 correction), or None.  A family that is a SEQUENCE of kernels per launch (K4: scatter
+    + canvas) sums the per-dispatch means of its kernels; a family of one kernel with many shapes takes its mean."""
+    global _PMC
+    if _PMC is None:
+        _PMC = {}
+    if workload not in _PMC:
+        path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{workload}.json")
+        _PMC[workload] = json.load(open(path))["kernels"] if os.path.exists(path) else {}
+    ks = _PMC[workload]
+    tot, hit = 0.0, False
+    for pre in prefixes:
+        m = [v for k, v in ks.items() if k.startswith(pre)]
+        if m:
+            hit = True
+            d = sum(v["dispatches"] for v in m)
+            tot += sum(v["bytes_per_dispatch"] * v["dispatches"] for v in m) / max(d, 1)
+    return round(tot, 1) if hit else None
+
+
 def _entry(kernel, bound, achieved, launches, launch_ms, traffic=None, **extra):
     peak = HBM_PEAK_GBS if bound == "hbm" else FP32_PEAK_TFLOPS
     d = {"kernel": kernel, "bound": bound, "achieved": round(achieved, 2), "peak": peak,
@@ -142,6 +167,9 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         elif name.startswith("grouped_conv3x3"):
             add("grouped", "K7 heal_grouped_small_conv3x3 (32-group 3x3 of the ResNeXt bottlenecks on the 16-block 4x4x1 fp32 MFMA; "
                            "bytes = input read once + output written once)", "hbm", w)
+        elif name.startswith("linear_"):
+            add("linear", "K6c heal_linear (V2X-ViT token-major fp32 MFMA GEMM: LayerNorm prologue, bias / GELU / residual / "
+                          "split-attention merge epilogues)", "mfma", w)
         elif name.startswith("warp_fuse"):
             add("k5", "K5 heal_warp_fuse (warp + occupancy-softmax fusion, 3 pyramid levels)", "hbm", w)
     entries = {}
@@ -153,7 +181,11 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         if key == "conv3x3w":   # the wrapper counts the direct convolution's FLOPs; the kernel executes 16/36 of them
             extra["direct_equiv_tflops"] = round(ach, 2)
             ach = ach / 2.25
-        entries[key] = (f["ms"], _entry(f["kernel"], f["bound"], ach, f["calls"], f["ms"] / max(f["calls"], 1), **extra))
+        tr = pmc_traffic(a.workload, *{"conv1x1": ("heal::k_conv1x1<",), "conv1x1s": ("heal::k_conv1x1<",),
+                                       "conv3x3w": ("heal::k_conv3x3_wino<",), "conv3x3": ("heal::k_conv3x3<",),
+                                       "grouped": ("heal::k_gconv_small<",), "k5": ("heal::k_warp_fuse<",),
+                                       "linear": ("heal::k_linear",)}.get(key, ()))
+        entries[key] = (f["ms"], _entry(f["kernel"], f["bound"], ach, f["calls"], f["ms"] / max(f["calls"], 1), tr, **extra))
     # K2: algorithmic bytes of the collated LiDAR agents this rank encodes per launch
     if "pfn_scatter" in timing:
         calls, mean_ms = timing["pfn_scatter"]
@@ -196,7 +228,8 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             bts = sum(per_call) / len(per_call)
             entries["k4"] = (calls * mean_ms, _entry(
                 "K4 heal_bev_pool_pm, one camera agent per launch (k_lss_scatter + k_lss_canvas; mean over the scene's camera agents)",
-                "hbm", bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
+                "hbm", bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
+                pmc_traffic(a.workload, "heal::k_lss_scatter", "heal::k_lss_canvas"), bytes_per_launch=bts))
     # K1: 16 N + 16 M P + 20 M bytes per agent, all LiDAR agents of a modality in one launch chain
     if "voxelize" in timing and scene.points:
         calls, mean_ms = timing["voxelize"]
@@ -236,7 +269,7 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             entries["k3"] = (tot_ms * max(a.steps, 1), _entry(
                 "K3 heal_sp_conv (pair-compacted gather-GEMM on fp32 MFMA; all sparse layers of one step, useful flops 2 R Cin Cout; "
                 "rulebook kernels not included)", "mfma",
-                tot_f / (tot_ms * 1e-3) / 1e12, len(layers), tot_ms / len(layers), None,
+                tot_f / (tot_ms * 1e-3) / 1e12, len(layers), tot_ms / len(layers), pmc_traffic(a.workload, "heal::k_sp_conv2<"),
                 step_ms=round(tot_ms, 4), hbm_gbs=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
                 hbm_frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 flop_per_byte=round(tot_f / max(tot_b, 1.0), 1), layers=layers))

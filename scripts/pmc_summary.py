@@ -63,5 +63,19 @@ def main():
                   open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 
 
+    if "--json-all" in sys.argv:
+        # every heal:: kernel: mean HBM bytes per dispatch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> B; the guide's gfx950 correction:
+        # FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read).  bench.py reads this file for `roofline.traffic`.
+        allk = {}
+        for k in keys:
+            name = k.split("(")[0].replace("void ", "").strip()
+            n = fetch.get(k, write.get(k))[0]
+            allk[name] = {"dispatches": n, "fetch_KB": round(fetch.get(k, (0, 0.0))[1], 1),
+                          "write_KB": round(write.get(k, (0, 0.0))[1], 1),
+                          "bytes_per_dispatch": (2.0 * fetch.get(k, (0, 0.0))[1] + write.get(k, (0, 0.0))[1]) * 1024.0}
+        json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; bytes = (2 FETCH + WRITE) KB",
+                   "kernels": allk}, open(sys.argv[sys.argv.index("--json-all") + 1], "w"), indent=1)
+
+
 if __name__ == "__main__":
     main()
