@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinearArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // (a static s_setprio for every other block, to de-phase the two blocks that share a CU, measured no change)
+    // Measured and dropped: a static s_setprio for every other block (to de-phase the two blocks that share a CU): no change;
+    // one barrier per chunk placed in the middle of its MFMAs with half-chunk fragment double buffering (every LDS read then
+    // has 2048 cycles of MFMAs to land): 104-108 vs 104-110 TFLOP/s at 218 instead of 184 registers -- the chunk loop is not
+    // where the remaining 20-25 % to the fp32 matrix roof is lost at this clock.
     const int n_chunks = a.K / LIN_BK;
     HEAL_LIN_LOAD(0)
     HEAL_LIN_STORE(0, 0)

@@ -152,8 +152,9 @@ class _Sharded:
     def _wire(self, buf):
         return buf if self.wire_dtype == buf.dtype else buf.to(self.wire_dtype)
 
-    def _own_features(self, scene_input, n_agents, local_inputs):
-        """Encode the agents this rank owns: ([n_mine, C, H, W] in scene order | None, owned agent ids)."""
+    def _own_features(self, scene_input, n_agents, local_inputs, compress=True):
+        """Encode the agents this rank owns: ([n_mine, C, H, W] in scene order | None, owned agent ids).  compress=False leaves
+        the model's NaiveCompressor to the caller (the compressed-wire split applies only its encoder half here)."""
         m = self.model
         mine = owned_agents(n_agents, self.rank, self.world)
         if not mine:
@@ -168,7 +169,7 @@ class _Sharded:
             parts.append(feats[mods[a]][cursor[mods[a]]])
             cursor[mods[a]] += 1
         x = torch.stack(parts)
-        if m.compress:
+        if m.compress and compress:
             x = m.compressor(x)
         return x, mine
 
@@ -284,6 +285,16 @@ class ShardedCollab(_Sharded):
     """HeterPyramidCollab (heter_pyramid_collab.py:133-209): the shard is every pyramid level's features + occupancy
     scores, warped to the ego frame by the owning rank."""
 
+    def __new__(cls, model, rank, world, wire_dtype=None, collective=None, split=None):
+        import os
+        split = split or os.environ.get("HEAL_SPLIT", "levels")
+        if split == "compressed" and cls is ShardedCollab:
+            return super().__new__(ShardedCollabCompressed)
+        return super().__new__(cls)
+
+    def __init__(self, model, rank, world, wire_dtype=None, collective=None, split=None):
+        super().__init__(model, rank, world, wire_dtype, collective)
+
     # ---- stage 1: everything a rank can do alone ---------------------------------------------------------
     @torch.no_grad()
     def local(self, scene_input, n_agents, local_inputs):
@@ -348,6 +359,56 @@ class ShardedCollab(_Sharded):
         return shapes
 
 
+class ShardedCollabCompressed(ShardedCollab):
+    """The reference's bandwidth-limited deployment (naive_compress.py:5-31, heter_pyramid_collab.py:176-178): what
+    travels between agents is the ENCODER half of the model's NaiveCompressor -- [C / ratio, H, W] per agent (64 / ratio channels
+    at 256 x 256: 16.8 / ratio MB instead of the 29.7 MB of the warped pyramid levels) -- and the receiving side (rank 0) runs
+    the decoder half, the pyramid stages of ALL agents, the fusion and the heads.  Same result as the single-process model;
+    the price is that the per-agent pyramid stages no longer shard, so this split is for links much slower than xGMI
+    (`split="compressed"` / HEAL_SPLIT=compressed; the default split exchanges the warped pyramid levels)."""
+
+    def prepare(self, scene_input, n_agents, local_inputs):
+        if not self.model.compress:
+            raise ValueError("split='compressed' needs a model with a `compressor` (args['compressor'])")
+        self._scene_input = scene_input
+
+    @torch.no_grad()
+    def local(self, scene_input, n_agents, local_inputs):
+        m = self.model
+        self._scene_input = scene_input
+        n_slots = slots_per_rank(n_agents, self.world)
+        x, mine = self._own_features(scene_input, n_agents, local_inputs, compress=False)
+        if mine:
+            z = m.compressor.encode(x)
+            self._zshape = tuple(z.shape[1:])
+        else:
+            z = torch.zeros((0,) + self._compressed_shape(), device=next(m.parameters()).device)
+        return self._wire(pack_maps(z, n_slots))
+
+    def _compressed_shape(self):
+        c, h, w = self._level_shapes_input()
+        return (self.model.compressor.encoder[0].out_channels, h, w)
+
+    def _level_shapes_input(self):
+        m = self.model
+        return (m.compressor.encoder[0].in_channels, int(round(m.H / 0.8)), int(round(m.W / 0.8)))
+
+    @torch.no_grad()
+    def tail(self, gathered, n_agents):
+        from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
+        m = self.model
+        si = self._scene_input
+        if gathered.dtype != torch.float32:
+            gathered = gathered.float()
+        z = unpack_maps(gathered, self._compressed_shape(), n_agents, self.world)
+        x = m.compressor.decode(z)
+        pairwise, grid_f64 = pairwise_to_host(si["pairwise_t_matrix"])
+        affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)
+        fused, _ = m.pyramid_backbone.forward_collab(x, [n_agents], affine, si["agent_modality_list"], m.cam_crop_info, grid_f64)
+        cls_preds, reg_preds, dir_preds = m.heads(fused)
+        return {"pyramid": "collab", "cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
+
+
 class ShardedBaseline(_Sharded):
     """HeterModelBaseline (heter_model_baseline.py:155-236; BASELINE config 5: SECOND + V2X-ViT): the shard is
     the owning rank's shrinker output warped into the ego frame, [C, H, W] per agent (256 x 128 x 128 = 16.8 MB);
@@ -398,11 +459,12 @@ class ShardedBaseline(_Sharded):
         return {"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
 
 
-def make_sharded(model, rank, world, wire_dtype=None, collective=None):
-    """The agent-sharded runner that matches the model class."""
+def make_sharded(model, rank, world, wire_dtype=None, collective=None, split=None):
+    """The agent-sharded runner that matches the model class.  split: "levels" (default: warped pyramid levels travel) |
+    "compressed" (HeterPyramidCollab with a compressor: the compressor's encoder output travels)."""
     name = type(model).__name__
     if name == "HeterPyramidCollab":
-        return ShardedCollab(model, rank, world, wire_dtype, collective)
+        return ShardedCollab(model, rank, world, wire_dtype, collective, split)
     if name == "HeterModelBaseline":
         return ShardedBaseline(model, rank, world, wire_dtype, collective)
     raise NotImplementedError(f"no agent-sharded split for {name}")

@@ -559,7 +559,14 @@ class NaiveCompressor(nn.Module):
                                      nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01), nn.ReLU())
         self._c = [_FoldCache() for _ in range(3)]
 
+    def encode(self, x):
+        """The half that runs on the SENDING agent: [n, C, H, W] -> [n, C / ratio, H, W] (what travels, naive_compress.py:25)."""
+        return ConvBN.run(x, self.encoder[0], self.encoder[1], self._c[0], relu=True)
+
+    def decode(self, z):
+        """The half that runs on the RECEIVING agent (naive_compress.py:26-29)."""
+        z = ConvBN.run(z, self.decoder[0], self.decoder[1], self._c[1], relu=True)
+        return ConvBN.run(z, self.decoder[3], self.decoder[4], self._c[2], relu=True)
+
     def forward(self, x):
-        x = ConvBN.run(x, self.encoder[0], self.encoder[1], self._c[0], relu=True)
-        x = ConvBN.run(x, self.decoder[0], self.decoder[1], self._c[1], relu=True)
-        return ConvBN.run(x, self.decoder[3], self.decoder[4], self._c[2], relu=True)
+        return self.decode(self.encode(x))

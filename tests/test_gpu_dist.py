@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mods, out_path, wire=None, fusion=None):
+def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,14 +30,21 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None):
     from heal_amd.pipeline import Scene, ScenePipeline
     small = [-25.6, -25.6, -3, 25.6, 25.6, 1]
     hypes = configs.lidar_pyramid(small) if fusion is None else configs.lidar_baseline(fusion, small)
+    if split == "compressed":   # the reference's compressor option (heter_pyramid_collab.py:176-178): 64 -> 16 channels on the wire
+        hypes["model"]["args"]["compressor"] = {"input_dim": 64, "compress_ratio": 4}
     pipe = ScenePipeline(hypes, "cuda:0", seed=5)
     scene = Scene(len(mods), seed=6, device="cuda:0", modalities=mods)
     scene.points = {k: p[(p[:, 0].abs() < 28) & (p[:, 1].abs() < 28)][:6000].contiguous()
                     for k, p in scene.points.items()}
     from heal_amd import synth
     scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
-    sharded = make_sharded(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None)
+    sharded = make_sharded(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None, split=split)
     assert isinstance(sharded, ShardedCollab if fusion is None else ShardedBaseline)
+    if split == "compressed":
+        from heal_amd.dist import ShardedCollabCompressed
+        assert isinstance(sharded, ShardedCollabCompressed)
+        buf = sharded.local(scene.model_input(), len(mods), scene.inputs_for(owned_agents(len(mods), rank, world)))
+        assert buf.shape[1] == 16 * 64 * 64   # C / ratio x H x W floats per agent on the wire (the full map would be 4x)
     mine = owned_agents(len(mods), rank, world)
     work = torch.cuda.Stream()
     torch.cuda.set_stream(work)
@@ -101,3 +108,17 @@ def test_sharded_forward_fp16_wire_stays_inside_the_parity_budget(tmp_path):
         worst = max(worst, float((got - ref).abs().max() / (ref.abs().max() + 1e-12)),
                     float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)))
     assert 0.0 < worst < 1e-3, worst  # > 0: the fp16 path really ran
+
+
+def test_sharded_compressed_wire_equals_single_process(tmp_path):
+    """SURVEY 8f-4 (naive_compress.py:5-31): the compressor's ENCODER runs on the owning rank, its output (a quarter of the
+    channels) is what travels, the DECODER and everything behind it run on rank 0 -- same heads as the single-process model
+    with the same compressor, eager and as graph(local) -> gather -> graph(tail)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "c.pt")
+    mp.spawn(_worker, args=(2, _free_port(), ["m1"] * 3, out, None, None, "compressed"), nprocs=2, join=True)
+    res = torch.load(out)
+    for k, (got, ref, rep) in res.items():
+        assert float(ref.abs().max()) > 0
+        assert float((got - ref).abs().max() / (ref.abs().max() + 1e-12)) < 1e-4, k
+        assert float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)) < 1e-4, ("graph replay", k)
