@@ -72,6 +72,7 @@ _SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "heal_sp_neighbors_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "heal_sp_transpose_neighbors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_weight_fragments": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_sp_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                              c_void_p, c_void_p, c_void_p]),

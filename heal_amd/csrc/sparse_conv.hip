@@ -787,6 +787,16 @@ __global__ __launch_bounds__(256) void k_sp_nbr_rank(const int4* __restrict__ ou
     }
 }
 
+// transposed rulebook for the backward pass: nbr_t[i][tap] = the output site that input site i feeds through `tap` (a given
+// (input, tap) pair feeds exactly one output), -1 where there is none.  nbr_t must be pre-filled with -1.
+__global__ __launch_bounds__(256) void k_sp_nbr_transpose(const int* __restrict__ nbr, int out_cap, const int* __restrict__ n_dev,
+                                                         int K, int n_in, int* __restrict__ nbr_t) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)live_rows(n_dev, out_cap) * K) return;
+    const int i = nbr[t];
+    if (i >= 0 && i < n_in) nbr_t[(size_t)i * K + (int)(t % K)] = (int)(t / K);
+}
+
 static uint32_t pow2_cap(int64_t n) {
     uint32_t c = 1024;
     while ((int64_t)c < 2 * (n < 1 ? 1 : n)) c <<= 1;
@@ -1012,6 +1022,21 @@ extern "C" int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, con
     return 0;
 }
 
+// Backward rulebook (training): nbr_t [n_in, K] <- for every (o, tap) with i = nbr[o][tap] >= 0: nbr_t[i][tap] = o.  The gradient
+// of a sparse convolution with respect to its input features is then the SAME gather-GEMM with the roles swapped:
+//   d_in[i] = sum_tap W[tap] d_out[nbr_t[i][tap]]  =  heal_sp_conv(d_out, nbr_t, weight' = W[tap]^T ([Cout, Cin] per tap)).
+extern "C" int heal_sp_transpose_neighbors(const int32_t* nbr, int n_out, int kernel_volume, int n_in, int32_t* nbr_t,
+                                           const int32_t* n_out_dev, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(kernel_volume >= 1 && kernel_volume <= 27 && n_in >= 0, "sp_transpose_neighbors: bad arguments");
+    if (n_in > 0) HEAL_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * kernel_volume * sizeof(int32_t), s));
+    if (n_out <= 0 || n_in <= 0) return 0;
+    const long long total = (long long)n_out * kernel_volume;
+    k_sp_nbr_transpose<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(nbr, n_out, n_out_dev, kernel_volume, n_in, nbr_t);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 // out[o] = act( BN( sum_tap W[tap]^T in[nbr[o][tap]] ) ); weight [K][Cin][Cout].
 extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out, int kernel_volume, int c_in,
                             int c_out, const float* weight, const float* weight_frag, const float* bn_scale,
@@ -1055,6 +1080,8 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
         HEAL_SP2_CASE(4, 16, 16, 64, 1, 0) HEAL_SP2_CASE(16, 16, 8, 64, 1, 0) HEAL_SP2_CASE(16, 32, 8, 64, 1, 0)
         HEAL_SP2_CASE(32, 32, 4, 64, 1, 0) HEAL_SP2_CASE(32, 64, 4, 64, 1, 0) HEAL_SP2_CASE(64, 64, 2, 64, 1, 0)
         HEAL_SP2_CASE(64, 128, 2, 64, 1, 0)
+        // the transposed directions the gradient with respect to the input features runs through (heal_sp_transpose_neighbors)
+        HEAL_SP2_CASE(32, 16, 4, 64, 1, 0) HEAL_SP2_CASE(64, 32, 2, 64, 1, 0) HEAL_SP2_CASE(128, 64, 1, 64, 1, 0)
 #undef HEAL_SP2_CASE
 #undef HEAL_SP2
     }

@@ -5,12 +5,16 @@ Parameter names follow the reference (`conv_input.0.weight`, `conv_input.1.*`, `
 Convolution weights are stored in spconv 1.2.1 layout [kz,ky,kx,Cin,Cout] (the layout of the authors'
 checkpoints, README "spconv 1.2.1"); spconv 2.x checkpoints ([Cout,kz,ky,kx,Cin]) are permuted on load.
 
-Gradient path (training): the HIP gather-GEMM has no backward; with autograd on the backbone runs spconv's arithmetic as a
-DENSE conv3d on the densified grid, masked by the active-site rules (submanifold: the input's sites; strided: every output
-cell with an active input in its receptive field), BatchNorm1d + ReLU on the active rows -- plain torch, differentiable, and
-only practical on small grids (the full +-102.4 m grid at 0.1 m is 172 M cells per agent); a sparse backward kernel is the
-real answer and is listed as next.
+Gradient path (training).  On the device (round 3): SPARSE -- the rulebooks of the inference path, the sparse convolution as an
+autograd Function whose forward is heal_sp_conv and whose backward is (i) heal_sp_conv again on the transposed rulebook
+(heal_sp_transpose_neighbors) with weight[tap]^T for the gradient of the input features and (ii) per tap a gather of the
+paired rows + one matrix product for the weight gradient; BatchNorm1d + ReLU on the active rows and the final densification are
+torch operators on [N, C] tensors.  No dense grid: training SECOND at the reference's +-102.4 m / 0.1 m configuration (172 M
+cells per agent) fits.  Off the device (and with HEAL_SP_GRAD=dense): spconv's arithmetic as a DENSE conv3d on the densified
+grid, masked by the active-site rules -- plain torch, differentiable, only for small grids; it is what pins the sparse path
+(tests/test_gpu_train.py) and the CPU oracle comparison.
 """
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -42,6 +46,34 @@ class SparseConvParam(nn.Module):
     def flat_weight(self):
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         return self.weight.detach().reshape(K, self.in_channels, self.out_channels).contiguous()
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out[o] = sum_tap W[tap]^T x[nbr[o][tap]] on the gather-GEMM kernel, with a sparse backward."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, nbr):
+        from heal_amd import ops
+        ctx.save_for_backward(feats, weight, nbr)
+        return ops.sp_conv_raw(feats.detach().contiguous(), nbr, weight.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        from heal_amd import ops
+        feats, weight, nbr = ctx.saved_tensors
+        g = g.contiguous()
+        gf = gw = None
+        if ctx.needs_input_grad[0]:   # d x[i] = sum_tap W[tap] g[nbr_t[i][tap]]: the same kernel, roles swapped
+            nbr_t = ops.sp_transpose_neighbors(nbr, feats.shape[0])
+            gf = ops.sp_conv_raw(g, nbr_t, weight.detach().transpose(1, 2).contiguous())
+        if ctx.needs_input_grad[1]:   # d W[tap] = X_pairs^T G_pairs: gather the paired rows, one matrix product per tap
+            gw = torch.zeros_like(weight)
+            x = feats.detach()
+            for t in range(weight.shape[0]):
+                o = (nbr[:, t] >= 0).nonzero(as_tuple=True)[0]
+                if o.numel():
+                    gw[t] = x.index_select(0, nbr[o, t].long()).t() @ g.index_select(0, o)
+        return gf, gw, None
 
 
 class _Block(nn.Sequential):
@@ -77,6 +109,27 @@ class _Block(nn.Sequential):
         rows = F.relu(bn(y.permute(0, 2, 3, 4, 1)[site]))            # BatchNorm1d over the ACTIVE rows only, like spconv
         out = y.new_zeros(y.permute(0, 2, 3, 4, 1).shape).index_put(site, rows)
         return out.permute(0, 4, 1, 2, 3), m
+
+    def run_sparse_autograd(self, x, feats, nbr_cache):
+        """Gradient path on the device: x carries the SITES (heal_amd.ops.SparseTensor, no gradient), feats [n, Cin] the
+        features with autograd history -> (SparseTensor of the output sites, features [n_out, Cout])."""
+        from heal_amd.ops import SparseTensor
+        conv, bn = self[0], self[1]
+        K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
+        w = conv.weight.reshape(K, conv.in_channels, conv.out_channels)
+        if conv.subm:
+            nbr = nbr_cache.get(conv.indice_key)
+            if nbr is None:
+                nbr = x.neighbors(x.indices, x.spatial_shape, conv.kernel_size, (1, 1, 1), tuple(k // 2 for k in conv.kernel_size))
+                nbr_cache[conv.indice_key] = nbr
+            y = x
+        else:
+            out_idx, out_shape, _, rank = x.out_sites_ex(conv.kernel_size, conv.stride, conv.padding)
+            nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding)
+            y = SparseTensor(None, out_idx, out_shape, x.batch_size)
+            y._rank = rank
+        out = _SparseConvFn.apply(feats, w, nbr)
+        return y, F.relu(bn(out))     # BatchNorm1d over the active rows (batch statistics when training), like spconv
 
     def run(self, x, nbr_cache):
         """x: heal_amd.ops.SparseTensor -> SparseTensor."""
@@ -140,7 +193,10 @@ class VoxelBackBone8x(nn.Module):
 
     def forward_autograd(self, batch_dict):
         """Gradient path: dense masked evaluation (module docstring).  -> batch_dict with a dense result object."""
-        feats, coords = batch_dict["voxel_features"], batch_dict["voxel_coords"].long()
+        feats = batch_dict["voxel_features"]
+        if feats.is_cuda and os.environ.get("HEAL_SP_GRAD", "sparse") != "dense":
+            return self.forward_autograd_sparse(batch_dict)
+        coords = batch_dict["voxel_coords"].long()
         B = int(batch_dict["batch_size"])
         D, H, W = self.sparse_shape
         cells = B * D * H * W
@@ -160,6 +216,28 @@ class VoxelBackBone8x(nn.Module):
                 x, mask = blk.run_dense(x, mask)
         x, mask = self.conv_out.run_dense(x, mask)
         batch_dict.update({"encoded_spconv_tensor": _DenseResult(x), "encoded_spconv_tensor_stride": 8})
+        return batch_dict
+
+    def forward_autograd_sparse(self, batch_dict):
+        """Gradient path on the device: sparse forward AND backward (module docstring)."""
+        from heal_amd.ops import SparseTensor
+        feats = batch_dict["voxel_features"]
+        B = int(batch_dict["batch_size"])
+        with torch.no_grad():
+            x = SparseTensor.from_unsorted(torch.zeros((feats.shape[0], 1), device=feats.device),
+                                           batch_dict["voxel_coords"].int().contiguous(), self.sparse_shape, B)
+        f = feats.index_select(0, x._perm.long())       # the sites are kept sorted by linear coordinate
+        cache = {}
+        x, f = self.conv_input.run_sparse_autograd(x, f, cache)
+        for stage in (self.conv1, self.conv2, self.conv3, self.conv4):
+            for blk in stage:
+                x, f = blk.run_sparse_autograd(x, f, cache)
+        x, f = self.conv_out.run_sparse_autograd(x, f, cache)
+        D, H, W = x.spatial_shape
+        idx = x.indices.long()
+        dense = f.new_zeros((B, D, H, W, f.shape[1])).index_put((idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]), f)
+        batch_dict.update({"encoded_spconv_tensor": _DenseResult(dense.permute(0, 4, 1, 2, 3)),
+                           "encoded_spconv_tensor_stride": 8})
         return batch_dict
 
     def forward(self, batch_dict):

@@ -726,7 +726,9 @@ class SparseTensor:
         ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
         _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
                    _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
-        return SparseTensor(features.index_select(0, perm.long()), sorted_idx, spatial_shape, batch_size, n_dev)
+        st = SparseTensor(features.index_select(0, perm.long()), sorted_idx, spatial_shape, batch_size, n_dev)
+        st._perm = perm   # row i of the sorted set = input row perm[i] (the gradient path re-applies it differentiably)
+        return st
 
     def table(self):
         if self._table is None:
@@ -821,6 +823,37 @@ class SparseTensor:
         _capi.call("heal_sp_to_bev", _ptr(self.features), _ptr(self.indices), self.n, C, _i3(self.spatial_shape),
                    self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
         return out
+
+
+_SP_IDENT = {}
+
+
+def sp_conv_raw(features, nbr, weight):
+    """The bare sparse convolution (no BatchNorm, no ReLU): out[o] = sum_tap weight[tap]^T features[nbr[o][tap]].  features
+    [n_in, Cin], nbr [n_out, K] i32, weight [K, Cin, Cout] -> [n_out, Cout].  Building block of the gradient path (forward AND,
+    with the transposed rulebook and weight[tap]^T, the gradient with respect to the input features)."""
+    features = _need(features, torch.float32, "features")
+    weight = _need(weight, torch.float32, "weight")
+    K, cin, cout = (int(v) for v in weight.shape)
+    key = (cout, str(features.device))
+    ident = _SP_IDENT.get(key)
+    if ident is None:
+        ident = _SP_IDENT[key] = (torch.ones(cout, device=features.device), torch.zeros(cout, device=features.device))
+    n_out = int(nbr.shape[0])
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
+    if n_out:
+        _capi.call("heal_sp_conv", _ptr(features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight), _optr(sp_weight_fragments(weight)),
+                   _ptr(ident[0]), _ptr(ident[1]), 0, _ptr(out), None, _stream())
+    return out
+
+
+def sp_transpose_neighbors(nbr, n_in):
+    """nbr [n_out, K] -> nbr_t [n_in, K]: nbr_t[i][tap] = o where nbr[o][tap] = i (else -1): the rulebook of the backward pass."""
+    nbr = _need(nbr, torch.int32, "nbr")
+    n_out, K = (int(v) for v in nbr.shape)
+    nbr_t = torch.empty((int(n_in), K), dtype=torch.int32, device=nbr.device)
+    _capi.call("heal_sp_transpose_neighbors", _ptr(nbr), n_out, K, int(n_in), _ptr(nbr_t), None, _stream())
+    return nbr_t
 
 
 # ------------------------------------------------------------------------------------------------ K6

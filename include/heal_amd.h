@@ -259,6 +259,11 @@ int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t*
                            const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
                            const int32_t* out_shape_host, int batch, const void* rank, size_t rank_bytes,
                            int n_in, const int32_t* n_in_dev, int32_t* nbr, const int32_t* n_out_dev, void* stream);
+/* Training: nbr_t [n_in, K] i32 <- the transposed rulebook (nbr_t[i][tap] = o where nbr[o][tap] = i, else -1).  The gradient of
+ * heal_sp_conv with respect to its input features is heal_sp_conv itself on (grad_out, nbr_t, weight[tap]^T, scale 1, shift 0,
+ * no ReLU): a sparse backward -- no dense grid anywhere.                                                    */
+int heal_sp_transpose_neighbors(const int32_t* nbr, int n_out, int kernel_volume, int n_in, int32_t* nbr_t,
+                                const int32_t* n_out_dev, void* stream);
 /* feat_out[o] = act(bn_scale * sum_tap W[tap]^T feat_in[nbr[o][tap]] + bn_shift); weight [K,Cin,Cout]
  * (spconv 1.2.1 layout [kz,ky,kx,Cin,Cout]); fp32 MFMA, fixed summation order (bit-reproducible).
  * weight_frag: the same weights re-laid once by heal_sp_weight_fragments (same element count) -- selects the

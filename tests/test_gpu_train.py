@@ -207,9 +207,11 @@ def test_warp_fuse_backward_kernel_vs_torch_autograd(n, f64, with_crop):
     assert float((occ.grad.double().cpu() - o64.grad).abs().max()) <= 1e-4 * max(float(o64.grad.abs().max()), 1e-30)
 
 
-def test_second_gradient_path_equals_sparse_kernels():
-    """SECOND on the gradient path (dense masked conv3d) against the inference path (K3: rulebooks + gather-GEMM kernels) on a
-    small grid: the same BEV map within 1e-3 of its scale, and the same set of non-zero cells."""
+def test_second_gradient_path_equals_sparse_kernels(monkeypatch):
+    """SECOND on the gradient path against the inference path (K3: rulebooks + gather-GEMM kernels) on a small grid -- the same BEV
+    map within 1e-3 of its scale, the same set of non-zero cells -- and the SPARSE backward (heal_sp_conv on the transposed
+    rulebook for the feature gradients, per-tap gathered matrix products for the weight gradients; round 3) against torch's
+    autograd of the dense masked conv3d restatement of the same encoder: every parameter gradient within 1e-3 of its scale."""
     from heal_amd import configs
     from heal_amd.opencood.models.heter_encoders import SECOND
     from tests.golden.detfill import fill_module
@@ -227,8 +229,24 @@ def test_second_gradient_path_equals_sparse_kernels():
     voxels = g.standard_normal((coords.shape[0], 5, 4)).astype(np.float32) * (np.arange(5)[None, :, None] < num[:, None, None])
     data = {"inputs_m3": {"voxel_features": torch.from_numpy(voxels).cuda(), "voxel_coords": torch.from_numpy(coords).cuda(),
                           "voxel_num_points": torch.from_numpy(num).cuda(), "n_agents": B}}
-    ref = enc(data, "m3")
-    assert ref.requires_grad
+    grads = {}
+    outs = {}
+    wgt = None
+    for mode in ("dense", "sparse"):
+        monkeypatch.setenv("HEAL_SP_GRAD", mode)
+        enc.zero_grad(set_to_none=True)
+        out = enc(data, "m3")
+        assert out.requires_grad
+        if wgt is None:
+            wgt = torch.from_numpy(g.standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+        (out * wgt).sum().backward()
+        outs[mode] = out.detach()
+        grads[mode] = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    assert float((outs["sparse"] - outs["dense"]).abs().max() / outs["dense"].abs().max()) < 1e-3
+    assert set(grads["sparse"]) == set(grads["dense"]) and any("conv" in n for n in grads["dense"])
+    for n, gd in grads["dense"].items():
+        assert float((grads["sparse"][n] - gd).abs().max()) <= 1e-3 * float(gd.abs().max()) + 1e-7, n
+    ref = outs["sparse"]
     with torch.no_grad():
         got = enc.eval()(data, "m3")
     assert got.shape == ref.shape
