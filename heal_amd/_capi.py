@@ -60,6 +60,7 @@ _SIGNATURES = {
     "heal_sp_out_sites_workspace": (c_size_t, [c_int, c_int]),
     "heal_sp_out_sites": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "heal_conv_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
     "heal_ln_stats": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "heal_linear": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                             c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

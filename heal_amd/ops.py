@@ -1233,6 +1233,37 @@ def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
     return "winograd" if blocks >= 96 else "direct"
 
 
+_TAPMAJOR_CACHE = {}
+
+
+def conv_gemm_supported(cin, cout, Wo):
+    import os
+    return cout % 128 == 0 and cin % 32 == 0 and Wo % 4 == 0 and os.environ.get("HEAL_CONV_GEMM", "1") == "1"
+
+
+def conv_gemm(x, w, bias=None, residual=None, relu=False, stride=1):
+    """heal_conv_gemm: dense 3x3 (padding 1) or 1x1 convolution as an implicit GEMM on 128 x 128 x 32 tiles of the 32x32x2 fp32
+    MFMA.  x [n,Cin,H,W], w [Cout,Cin,k,k] (re-laid [Cout, k*k, Cin] once, cached) -> [n,Cout,Ho,Wo]."""
+    x = _need(x, torch.float32, "x")
+    n, cin, H, W = (int(v) for v in x.shape)
+    cout, ks = int(w.shape[0]), int(w.shape[2])
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _TAPMAJOR_CACHE.get(key)
+    if hit is None:
+        if len(_TAPMAJOR_CACHE) > 256:
+            _TAPMAJOR_CACHE.clear()
+        hit = _TAPMAJOR_CACHE[key] = (w.detach().permute(0, 2, 3, 1).reshape(cout, ks * ks, cin).contiguous(), w)
+    y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _need(residual, torch.float32, "residual")
+    name = (f"conv3x3_{cin}_{cout}" if ks == 3 else f"conv1x1_{cin}_{cout}") + ("_s2" if stride == 2 else "")
+    with _Timed(name, 2.0 * ks * ks * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
+        _capi.call("heal_conv_gemm", _ptr(x), _ptr(hit[0]), _optr(bias), _optr(residual), n, cin, cout, H, W, ks, int(stride),
+                   int(bool(relu)), _ptr(y), _stream())
+    return y
+
+
 def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
     """Dense 3x3 convolution, padding 1, stride 1 | 2, on the fp32 matrix cores with fused bias (+ residual) (+ ReLU).
     x [n,Cin,H,W] f32 cuda, w [Cout,Cin,3,3] -> [n,Cout,Ho,Wo].  Stride 1 runs the Winograd F(2x2,3x3) formulation
@@ -1257,6 +1288,12 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
             _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
                        int(bool(relu)), waves, _ptr(y), _stream())
         return y
+    if stride == 2 and cin >= 192 and conv_gemm_supported(cin, cout, Wo) and n * Ho * Wo >= 65536:
+        # the large, deep stride-2 layers: the 128 x 128 x 32 implicit GEMM on 32x32x2 MFMA (heal_conv_gemm).  Measured
+        # (scripts/conv_gemm_bench.py, profiles/r03_conv_gemm_bench.json): 384 -> 256 @256^2 x 8: 2.82 vs 3.69 ms (MIOpen 2.64);
+        # 128 -> 256: 0.97 vs 1.02; 128 -> 128 @256^2 x 5: 0.43 vs 0.31 (the short reduction does not pay for the tile): hence
+        # the Cin bound
+        return conv_gemm(x, w, bias, residual, relu, stride)
     frag = conv3x3_fragments(w)
     with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * cin * cout * Ho * Wo,
                 4.0 * n * (cin * H * W + cout * Ho * Wo)):

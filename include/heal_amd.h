@@ -421,6 +421,14 @@ int heal_conv1x1_d2s(const float* x, const float* weight_frag, const float* bias
 int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, const float* residual, int n, int cin,
                  int cout, int H, int W, int stride, int relu, float* y, void* stream);
 
+/* heal_conv_gemm: the same dense convolutions (3x3 padding 1, or 1x1; stride 1 | 2; y = act(W * x + bias (+ residual))) as an
+ *   implicit GEMM on 128 x 128 x 32 tiles of v_mfma_f32_32x32x2_f32 -- the formulation for the LARGE stride-2 layers
+ *   (BaseBEVBackbone stage heads, base_bev_backbone.py:49-74; the 384 -> 256 shrink_header of HeterModelBaseline,
+ *   downsample_conv.py:7-49), where the long reduction (9 Cin) amortises its 128 x 128 tiles.  weight_tap_major = W re-laid
+ *   [Cout, k*k, Cin] (tap = k ky + kx); Cout % 128 == 0, Cin % 32 == 0, output width % 4 == 0.                              */
+int heal_conv_gemm(const float* x, const float* weight_tap_major, const float* bias, const float* residual, int n, int cin,
+                   int cout, int H, int W, int ksize, int stride, int relu, float* y, void* stream);
+
 /* heal_grouped16_conv3x3: the 32-group 3x3 convolution of the ResNeXt bottlenecks (resblock.py:90-98,110-112; stride 1,
  *   padding 1, folded BatchNorm bias, ReLU) on the matrix cores, for 16 or 8 channels per group: channels are processed in
  *   16-channel super-groups (one group of 16, or two groups of 8 with block-diagonal weights).  x, y [n,C,H,W].

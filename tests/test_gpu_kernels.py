@@ -1234,3 +1234,25 @@ def test_rank_rulebook_equals_hash_rulebook(monkeypatch):
         sub = (3, 3, 3)
         assert torch.equal(y.neighbors(oi, osh, sub, (1, 1, 1), (1, 1, 1)), y_h.neighbors(oi, osh, sub, (1, 1, 1), (1, 1, 1)))
         assert torch.equal(x.neighbors(oi, osh, k, st, pd), nbr_h)
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,ks,stride,res", [(2, 64, 128, 40, 56, 3, 2, True), (1, 96, 256, 33, 24, 3, 2, False),
+                                                           (2, 32, 128, 18, 20, 3, 1, True), (1, 64, 128, 16, 24, 1, 1, False),
+                                                           (1, 32, 128, 15, 16, 1, 2, True)])
+def test_conv_gemm_vs_torch_fp64(n, cin, cout, H, W, ks, stride, res):
+    """heal_conv_gemm (implicit GEMM on 128 x 128 x 32 tiles of the 32x32x2 fp32 MFMA) against a float64 convolution: 3x3 padding 1
+    and 1x1, stride 1 | 2, odd map heights, tiles that straddle the map border, bias + residual + ReLU."""
+    from heal_amd import ops
+    rng = np.random.default_rng(n * 100 + cin + cout + H)
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, ks, ks)) / np.sqrt(cin * ks * ks)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = rng.standard_normal((n, cout, Ho, Wo)).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                     stride, ks // 2)
+    if res:
+        ref = ref + torch.from_numpy(r).double()
+    ref = torch.relu(ref).numpy()
+    got = ops.conv_gemm(dev(x), dev(w), dev(b), dev(r) if res else None, True, stride).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
