@@ -38,6 +38,7 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "heal_warp_agent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "heal_warp_agents_pm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "heal_fuse_warped": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_decode_nms_workspace": (c_size_t, [c_int, c_int]),
     "heal_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -53,6 +54,7 @@ _SIGNATURES = {
     "heal_sp_sort_workspace": (c_size_t, [c_int]),
     "heal_sp_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                                    c_void_p]),
+    "heal_sp_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_table_capacity": (c_size_t, [c_int]),
     "heal_sp_hash_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "heal_sp_neighbors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -242,6 +242,31 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, lon
     out[(((size_t)g * gridDim.y + part) * gridDim.x + blockIdx.x) * C + c] = (s0 + s1) + (s2 + s3);   // summed in chunk order below
 }
 
+// out[row] = (bias ? bias[row] : 0) + w[row][0..C) . vec, rows strided over the block's waves: a wave reads a weight row as 64 x 16 B
+// (coalesced; one thread per row would stride the lanes by a whole row) and reduces across lanes.  C <= 256, C % 64 == 0.
+__device__ __forceinline__ void block_matvec(const float* __restrict__ w, const float* __restrict__ bias,
+                                             const float* __restrict__ vec /*LDS*/, float* __restrict__ out /*LDS*/, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const bool on = lane * 4 < C;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) v = *reinterpret_cast<const float4*>(vec + lane * 4);
+    for (int r0 = wave * 4; r0 < C; r0 += nw * 4) {
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on && r0 + j < C) q = *reinterpret_cast<const float4*>(w + (size_t)(r0 + j) * C + lane * 4);
+            d[j] = fmaf(q.w, v.w, fmaf(q.z, v.z, fmaf(q.y, v.y, q.x * v.x)));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = wave_sum(d[j]);
+        if (lane < 4 && r0 + lane < C) {
+            const float t = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
+            out[r0 + lane] = t + (bias ? bias[r0 + lane] : 0.f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ colsum, int chunks, float inv_rows,
                                                       const float* __restrict__ w_out /*[3][C][C] (nn.Linear [N][K])*/,
                                                       const float* __restrict__ b_out /*[3][C]*/,
@@ -249,29 +274,27 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
                                                       const float* __restrict__ ln_b, float eps,
                                                       const float* __restrict__ fc2 /*[3C][C]*/, int C,
                                                       float* __restrict__ scale /*[g][3][C]*/, float* __restrict__ bias /*[g][C]*/) {
-    __shared__ float s_mean[3 * 256], s_gap[256], s_h[256], s_red[8];
+    __shared__ __attribute__((aligned(16))) float s_mean[3 * 256], s_gap[256], s_h[256], s_t[3 * 256];
+    __shared__ float s_red[8];
     const int g = blockIdx.x, c = threadIdx.x;   // C == blockDim.x <= 256
     for (int i = c; i < 3 * C; i += C) {
         const float* q = colsum + ((size_t)g * 3 + i / C) * chunks * C + (i % C);
-        float t = 0.f;
-        for (int k = 0; k < chunks; ++k) t += q[(size_t)k * C];
-        s_mean[i] = t * inv_rows;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;     // four interleaved partial sums: a fixed order, loads in flight together
+        int k = 0;
+        for (; k + 3 < chunks; k += 4) {
+            t0 += q[(size_t)k * C]; t1 += q[(size_t)(k + 1) * C]; t2 += q[(size_t)(k + 2) * C]; t3 += q[(size_t)(k + 3) * C];
+        }
+        for (; k < chunks; ++k) t0 += q[(size_t)k * C];
+        s_mean[i] = ((t0 + t1) + (t2 + t3)) * inv_rows;
     }
     __syncthreads();
-    float gap = 0.f;
-    for (int p = 0; p < 3; ++p) {
-        const float* w = w_out + ((size_t)p * C + c) * C;
-        float d = b_out[p * C + c];
-        for (int k = 0; k < C; ++k) d = fmaf(s_mean[p * C + k], w[k], d);
-        gap += d;
-    }
-    s_gap[c] = gap;
+    for (int p = 0; p < 3; ++p) block_matvec(w_out + (size_t)p * C * C, b_out + p * C, s_mean + p * C, s_t + p * C, C);
     __syncthreads();
-    float hval = 0.f;
-    {
-        const float* w = fc1 + (size_t)c * C;
-        for (int k = 0; k < C; ++k) hval = fmaf(s_gap[k], w[k], hval);
-    }
+    s_gap[c] = (s_t[c] + s_t[C + c]) + s_t[2 * C + c];
+    __syncthreads();
+    block_matvec(fc1, nullptr, s_gap, s_t, C);
+    __syncthreads();
+    const float hval = s_t[c];
     // LayerNorm over the C values of the block
     float sm = wave_sum(hval);
     if ((c & 63) == 0) s_red[c >> 6] = sm;
@@ -289,13 +312,9 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
     const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
     s_h[c] = fmaxf((hval - mean) * rstd * ln_g[c] + ln_b[c], 0.f);
     __syncthreads();
-    float lg[3];
-    for (int p = 0; p < 3; ++p) {
-        const float* w = fc2 + ((size_t)p * C + c) * C;
-        float d = 0.f;
-        for (int k = 0; k < C; ++k) d = fmaf(s_h[k], w[k], d);
-        lg[p] = d;
-    }
+    for (int p = 0; p < 3; ++p) block_matvec(fc2 + (size_t)p * C * C, nullptr, s_h, s_t + p * C, C);
+    __syncthreads();
+    const float lg[3] = {s_t[c], s_t[C + c], s_t[2 * C + c]};
     const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
     const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx), e2 = expf(lg[2] - mx);
     const float inv = 1.0f / (e0 + e1 + e2);

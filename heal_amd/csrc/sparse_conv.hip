@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256) void k_sp_apply_perm(const int4* __restrict__ 
     perm_out[i] = (int)j;
 }
 
+// out[i] = src[perm[i]] for rows of C floats (16-B pieces when C % 4 == 0): the features of a site set re-ordered by the
+// permutation heal_sp_sort_sites returns.
+template <typename V>
+__global__ __launch_bounds__(256) void k_sp_gather_rows(const V* __restrict__ src, const int* __restrict__ perm, int cap,
+                                                       const int* __restrict__ n_dev, int pieces, V* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(e / pieces), q = (int)(e - (long long)i * pieces);
+    if (i >= live_rows(n_dev, cap)) return;
+    out[(size_t)i * pieces + q] = src[(size_t)perm[i] * pieces + q];
+}
+
 __global__ __launch_bounds__(256) void k_sp_hash_insert(const int4* __restrict__ idx, int cap,
                                                        const int* __restrict__ n_dev, SpShape s,
                                                        uint32_t* __restrict__ tkey, int* __restrict__ tval,
@@ -849,6 +860,24 @@ extern "C" int heal_sp_sort_sites(const int32_t* indices, int n, const int32_t* 
     if (radix_sort_pairs(keys, vals, n, bits, &res, scratch, s)) return 1;
     k_sp_apply_perm<<<ceil_div(n, 256), 256, 0, s>>>(idx, vals[res], n, n_dev, reinterpret_cast<int4*>(sorted_indices),
                                                      perm);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+// Features of the sorted site set: out[i] = features[perm[i]] (perm from heal_sp_sort_sites; rows beyond the live count untouched).
+extern "C" int heal_sp_gather_rows(const float* features, const int32_t* perm, int n, int channels, const int32_t* n_dev,
+                                   float* out, void* stream) {
+    HEAL_REQUIRE(n >= 0 && channels >= 1, "sp_gather_rows: bad shape");
+    if (n == 0) return 0;
+    HEAL_REQUIRE(features && perm && out, "sp_gather_rows: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (channels % 4 == 0 && (((uintptr_t)features | (uintptr_t)out) & 15) == 0) {
+        const int pieces = channels / 4;
+        k_sp_gather_rows<float4><<<(unsigned)(((long long)n * pieces + 255) / 256), 256, 0, s>>>(
+            reinterpret_cast<const float4*>(features), perm, n, n_dev, pieces, reinterpret_cast<float4*>(out));
+    } else {
+        k_sp_gather_rows<float><<<(unsigned)(((long long)n * channels + 255) / 256), 256, 0, s>>>(features, perm, n, n_dev, channels, out);
+    }
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -234,6 +234,45 @@ __global__ __launch_bounds__(256) void k_warp_agent(const float* __restrict__ fe
         feat_ego[(size_t)c * HW + pix] = sample(feat + (size_t)c * HW, t, p.W);
 }
 
+// ---- warp of every agent of a scene into TOKEN-MAJOR ego-frame maps (V2X-ViT's layout) ------------------------------
+// feats [n, C, H, W] -> out [n, H, W, C]: what `warp_affine_simple` + `x.permute(0, 2, 3, 1)` produce
+// (fusion_in_one.py:352-358) in one pass: a block samples a 16 x 4 pixel tile of 64 channels (lanes along x: the four taps of
+// neighbouring pixels share cache lines), transposes it through LDS and writes 256-byte channel runs per pixel.
+constexpr int WPM_TW = 16, WPM_TH = 4, WPM_C = 64;
+__global__ __launch_bounds__(256) void k_warp_agents_pm(const float* __restrict__ feats, WarpParams p,
+                                                       float* __restrict__ out) {
+    __shared__ float s_t[WPM_TW * WPM_TH][WPM_C + 1];
+    const Block3 bk = xcd_block();
+    const int cblocks = (p.C + WPM_C - 1) / WPM_C;
+    const int a = bk.z / cblocks, c0 = (bk.z - a * cblocks) * WPM_C;
+    const int pix_l = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int w = bk.x * WPM_TW + (pix_l & (WPM_TW - 1));
+    const int h = bk.y * WPM_TH + (pix_l / WPM_TW);
+    const int HW = p.H * p.W;
+    if (w < p.W && h < p.H) {
+        float gx, gy;
+        double m[6];
+        load_affine(p, a, m);
+        if (p.grid_f64) grid_point<double>(m, h, w, p.H, p.W, gx, gy);
+        else grid_point<float>(m, h, w, p.H, p.W, gx, gy);
+        const Taps t = make_taps(gx, gy, p.H, p.W);
+        const float* src = feats + ((size_t)a * p.C + c0 + cg * 16) * HW;
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c)
+            s_t[pix_l][cg * 16 + c] = (c0 + cg * 16 + c < p.C) ? sample(src + (size_t)c * HW, t, p.W) : 0.f;
+    }
+    __syncthreads();
+    const int cq = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = (threadIdx.x >> 4) + 16 * i;
+        const int ww = bk.x * WPM_TW + (pl & (WPM_TW - 1)), hh = bk.y * WPM_TH + (pl / WPM_TW);
+        if (ww >= p.W || hh >= p.H || c0 + cq * 4 >= p.C) continue;
+        const float4 v = make_float4(s_t[pl][cq * 4], s_t[pl][cq * 4 + 1], s_t[pl][cq * 4 + 2], s_t[pl][cq * 4 + 3]);
+        *reinterpret_cast<float4*>(out + (((size_t)a * p.H + hh) * p.W + ww) * p.C + c0 + cq * 4) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ feats,
                                                     const float4* __restrict__ scores, int n, int C,
                                                     int HW4, float4* __restrict__ out) {
@@ -388,6 +427,19 @@ extern "C" int heal_warp_agent(const float* feat, const float* occ, int channels
     constexpr int CCH = 16;
     dim3 grid(ceil_div(W, WF_TW), ceil_div(H, WF_TH), ceil_div(channels, CCH));
     k_warp_agent<CCH><<<grid, 256, 0, (hipStream_t)stream>>>(feat, occ, p, feat_ego, score_ego);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_warp_agents_pm(const float* feats, int n_agents, int channels, int H, int W,
+                                   const double* affine_host, const double* affine_dev, int grid_f64, float* out,
+                                   void* stream) {
+    WarpParams p;
+    if (fill_params(p, n_agents, channels, H, W, affine_host, affine_dev, grid_f64, nullptr)) return 1;
+    HEAL_REQUIRE(feats && out, "warp_agents_pm: null pointer");
+    HEAL_REQUIRE(channels % 4 == 0, "warp_agents_pm: channels must be a multiple of 4 (got %d)", channels);
+    dim3 grid(ceil_div(W, WPM_TW), ceil_div(H, WPM_TH), n_agents * ceil_div(channels, WPM_C));
+    k_warp_agents_pm<<<grid, 256, 0, (hipStream_t)stream>>>(feats, p, out);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

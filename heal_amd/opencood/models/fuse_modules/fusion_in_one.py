@@ -82,6 +82,18 @@ class V2XViTFusion(_WarpThenFuse):
         fused = self.fusion_net(ego.permute(0, 2, 3, 1).contiguous())       # [n,H,W,C] -> [H,W,C]; the 3 prior channels are zero
         return fused.permute(2, 0, 1)
 
+    def forward(self, x, record_len, affine_matrix):
+        if not x.is_cuda or x.shape[1] % 4 or (torch.is_grad_enabled() and x.requires_grad):
+            return super().forward(x, record_len, affine_matrix)
+        # inference on the device: every agent of a scene warped straight into the transformer's token-major layout (one launch;
+        # no per-agent warp + stack + permute copy)
+        aff, f64 = _host_affine(affine_matrix)
+        out = []
+        for b, feats in enumerate(regroup(x, record_len)):
+            n = feats.shape[0]
+            out.append(self.fusion_net(ops.warp_agents_pm(feats, aff[b][0, :n], f64)).permute(2, 0, 1))
+        return torch.stack(out)
+
 
 def build_fusion(args):
     """The single-scale fusion operator a model YAML names (`fusion_method`: max | att | v2xvit; the other methods of

@@ -72,12 +72,15 @@ class HeterModelBaseline(nn.Module):
             feats[m] = self.encode_modality(data_dict, m)
             if wants_depth_items(self, m):
                 output_dict[f"depth_items_{m}"] = getattr(self, f"encoder_{m}").depth_items
-        cursor = {m: 0 for m in self.modality_name_list}
-        parts = []
-        for m in agent_modality_list:
-            parts.append(feats[m][cursor[m]])
-            cursor[m] += 1
-        x = torch.stack(parts)
+        if len(counts) == 1:      # one modality: the encoder's batch IS the agent stack (no copy)
+            x = feats[agent_modality_list[0]]
+        else:
+            cursor = {m: 0 for m in self.modality_name_list}
+            parts = []
+            for m in agent_modality_list:
+                parts.append(feats[m][cursor[m]])
+                cursor[m] += 1
+            x = torch.stack(parts)
         if self.compress:
             x = self.compressor(x)
         if self.supervise_single:

@@ -91,7 +91,19 @@ class BaseBEVBackbone(nn.Module):
         return feats
 
     def decode_multiscale_feature(self, x):
-        ups = [self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i] for i in range(self.num_levels)]
+        if (len(self.deblocks) >= self.num_levels > 1 and x[0].is_cuda and not grad_path(x[0], self)
+                and len({self.deblocks[i].out_shape(x[i])[1:] for i in range(self.num_levels)}) == 1):
+            # inference: every deblock writes its channel slice of the concatenated tensor itself (no torch.cat pass)
+            shapes = [self.deblocks[i].out_shape(x[i]) for i in range(self.num_levels)]
+            cat = torch.empty((int(x[0].shape[0]), sum(s[0] for s in shapes), shapes[0][1], shapes[0][2]),
+                              dtype=x[0].dtype, device=x[0].device)
+            off = 0
+            for i in range(self.num_levels):
+                self.deblocks[i](x[i], into=(cat, off))
+                off += shapes[i][0]
+            ups = [cat]
+        else:
+            ups = [self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i] for i in range(self.num_levels)]
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > self.num_levels:
             x = self.deblocks[-1](x)

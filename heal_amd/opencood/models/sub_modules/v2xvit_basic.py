@@ -241,7 +241,16 @@ class BaseWindowAttention(nn.Module):
                 r = self.relative_indices.to(device)
                 ri = (r[:, :, 0].contiguous(), r[:, :, 1].contiguous())
                 self.__dict__["_ri_dev"] = ri
-            return self.pos_embedding[ri[0], ri[1]]
+            pe = self.pos_embedding
+            if torch.is_grad_enabled() and pe.requires_grad:
+                return pe[ri[0], ri[1]]
+            # inference: the [T, T] table of a parameter version is looked up once, not per forward (3 index kernels per block)
+            key = (pe.data_ptr(), pe._version, str(device))
+            hit = self.__dict__.get("_bias_tab")
+            if hit is None or hit[0] != key:
+                hit = (key, pe.detach()[ri[0], ri[1]].contiguous())
+                self.__dict__["_bias_tab"] = hit
+            return hit[1]
         return self.pos_embedding
 
 

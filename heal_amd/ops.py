@@ -353,6 +353,17 @@ def warp_agent(feat, occ, affine_row, grid_f64=True, crop=None):
     return feat_ego, score_ego
 
 
+def warp_agents_pm(feats, affine_rows, grid_f64=True):
+    """warp_affine_simple + permute(0, 2, 3, 1) for one scene: feats [n,C,H,W] -> ego-frame maps, token-major [n,H,W,C]."""
+    feats = _need(feats, torch.float32, "feats")
+    n, C, H, W = (int(v) for v in feats.shape)
+    out = torch.empty((n, H, W, C), dtype=torch.float32, device=feats.device)
+    a, ap, adev = _affine_args(affine_rows, n)
+    with _Timed("warp_agents_pm", 0.0, 8.0 * n * C * H * W):
+        _capi.call("heal_warp_agents_pm", _ptr(feats), n, C, H, W, ap, adev, int(bool(grid_f64)), _ptr(out), _stream())
+    return out
+
+
 def fuse_warped(feats_ego, scores_ego):
     """K5 split, post-all-gather half: [n,C,H,W], [n,1,H,W] -> [C,H,W]."""
     feats_ego = _need(feats_ego, torch.float32, "feats_ego")
@@ -726,7 +737,10 @@ class SparseTensor:
         ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
         _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
                    _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
-        st = SparseTensor(features.index_select(0, perm.long()), sorted_idx, spatial_shape, batch_size, n_dev)
+        C = int(features.shape[1])
+        feats = torch.zeros((n, C), dtype=torch.float32, device=dev) if n_dev is not None else torch.empty((n, C), dtype=torch.float32, device=dev)
+        _capi.call("heal_sp_gather_rows", _ptr(features), _ptr(perm), n, C, _optr(n_dev), _ptr(feats), _stream())
+        st = SparseTensor(feats, sorted_idx, spatial_shape, batch_size, n_dev)
         st._perm = perm   # row i of the sorted set = input row perm[i] (the gradient path re-applies it differentiably)
         return st
 

@@ -135,6 +135,12 @@ int heal_warp_fuse_backward(const float* feats, const float* occ, int n_agents, 
 int heal_warp_agent(const float* feat, const float* occ, int channels, int H, int W,
                     const double* affine_host, const double* affine_dev, int grid_f64,
                     const int32_t* crop_host, float* feat_ego, float* score_ego, void* stream);
+/* heal_warp_agents_pm: warp every agent of a scene into the ego frame and write the maps TOKEN-MAJOR:
+ *   feats [n_agents, C, H, W] -> out [n_agents, H, W, C].  Replaces warp_affine_simple (torch_transformation_utils.py:323-332)
+ *   + `x.permute(0, 2, 3, 1)` at the entry of V2XViTFusion (opencood/models/fuse_modules/fusion_in_one.py:352-358): one pass
+ *   instead of a warp per agent, a stack and a layout copy.  C % 4 == 0; affine rows as for heal_warp_fuse.                */
+int heal_warp_agents_pm(const float* feats, int n_agents, int channels, int H, int W, const double* affine_host,
+                        const double* affine_dev, int grid_f64, float* out, void* stream);
 /* ... and fuse already-warped stacks (after the all-gather): -inf mask, softmax over agents, sum. */
 int heal_fuse_warped(const float* feats_ego, const float* scores_ego, int n_agents, int channels,
                      int H, int W, float* out, void* stream);
@@ -224,6 +230,11 @@ size_t heal_sp_sort_workspace(int n);
 int heal_sp_sort_sites(const int32_t* indices, int n, const int32_t* shape_host, int batch,
                        int32_t* sorted_indices, int32_t* perm, void* ws, size_t ws_bytes, const int32_t* n_dev,
                        void* stream);
+/* heal_sp_gather_rows: out[i] = features[perm[i]], rows of `channels` floats: the voxel features re-ordered with the
+ *   permutation of heal_sp_sort_sites (spconv keeps features and indices in the caller's order; K3 keeps both sorted by
+ *   linear coordinate, sparse_backbone_3d.py:114-116 is where the tensor is formed).  n_dev (may be NULL): live row count. */
+int heal_sp_gather_rows(const float* features, const int32_t* perm, int n, int channels, const int32_t* n_dev, float* out,
+                        void* stream);
 size_t heal_sp_table_capacity(int n);
 int heal_sp_hash_build(const int32_t* indices, int n, const int32_t* shape_host, int batch,
                        uint32_t* table_keys, int32_t* table_vals, size_t table_cap, const int32_t* n_dev,

@@ -40,6 +40,11 @@ def main():
                         best.append((timeit(lambda: ops.conv1x1(x, w, b, r, 1), 10), bm, bn, kc))
             os.environ.pop("HEAL_C1_CFG")
             print("    sweep:", " ".join(f"({bm},{bn},{kc}):{t:.0f}" for t, bm, bn, kc in sorted(best)), flush=True)
+        t_cg = None
+        if ops.conv_gemm_supported(cin, cout, hw):
+            t_cg = timeit(lambda: ops.conv_gemm(x, w, b, r, True, 1))
+            err = float((ops.conv_gemm(x, w, b, r, True, 1) - ops.conv1x1(x, w, b, r, 1)).abs().max())
+            print(f"    conv_gemm(1x1) {t_cg:7.1f} us ({2.0 * n * cin * cout * hw * hw / t_cg / 1e6:6.1f} TF)  max |diff| {err:.2e}", flush=True)
         t_lib = timeit(lambda: ops.bias_act_(F.conv2d(x, w), b, r, True))
         flops = 2.0 * n * cin * cout * hw * hw
         byts = 4.0 * n * hw * hw * (cin + cout * (2 if res else 1))

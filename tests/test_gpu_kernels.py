@@ -194,6 +194,32 @@ def test_warp_fuse_fused_vs_oracle(n, C, H, W, f64):
     np.testing.assert_allclose(out2, out, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["sq", "rect", "f32"])
+def test_warp_agents_token_major_matches_reference_golden(golden, tag):
+    """heal_warp_agents_pm (all agents of a scene, written [n,H,W,C]) against the reference's warp_affine_simple output, and
+    bit-equal to the per-agent kernel it replaces at V2X-ViT's entry; channel counts that do not fill a 64-channel block,
+    maps that do not fill a 16 x 4 tile, device-resident affine rows."""
+    from heal_amd import ops
+    g = golden("warp_fuse")
+    x = g[f"{tag}_x"]
+    n = x.shape[0]
+    rows = g[f"{tag}_affine"][0, :n]
+    f64 = rows.dtype == np.float64
+    pm = ops.warp_agents_pm(dev(x), rows, grid_f64=f64)
+    assert pm.shape == (n, x.shape[2], x.shape[3], x.shape[1]) and pm.is_contiguous()
+    np.testing.assert_allclose(pm.permute(0, 3, 1, 2).cpu().numpy(), g[f"{tag}_warped"], rtol=1e-4, atol=2e-5)
+    per_agent = torch.stack([ops.warp_agent(dev(x[a]), dev(np.zeros_like(x[a][:1])), rows[a], grid_f64=f64)[0] for a in range(n)])
+    assert torch.equal(pm.permute(0, 3, 1, 2), per_agent)
+    rng = np.random.default_rng(3)
+    for (m, C, H, W) in ((8, 256, 128, 128), (3, 72, 30, 50), (1, 4, 5, 7)):
+        y = torch.from_numpy(rng.standard_normal((m, C, H, W)).astype(np.float32)).cuda()
+        r = np.tile(np.array([[1, 0, 0, 0, 1, 0]], dtype=np.float64), (m, 1)) + 0.2 * rng.standard_normal((m, 6))
+        a = ops.warp_agents_pm(y, r)
+        b = torch.stack([ops.warp_agent(y[i], y[i][:1], r[i])[0] for i in range(m)])
+        assert torch.equal(a.permute(0, 3, 1, 2), b), (m, C, H, W)
+        assert torch.equal(ops.warp_agents_pm(y, torch.from_numpy(r).cuda()), a)
+
+
 def test_warp_fuse_identity_is_exact():
     """Linearity / idempotence property: one agent, identity transform -> output == input."""
     from heal_amd import ops
