@@ -7,15 +7,24 @@
 // first appearance, none beyond max_voxels); a point is appended to its voxel while the voxel holds
 // fewer than max_points.
 //
-// GPU formulation (order-independent, so bit-identical to the sequential scan):
-//   1. hash-grid insert: cell -> min point index          (atomicCAS claim + atomicMin)
-//   2. flag[i] = "i is the first point of its cell"; voxel id = exclusive prefix sum of flags
-//      (ballot/popcount inside the block scan)
-//   3. every point looks up its voxel id; key = id (or a sentinel for dropped points)
-//   4. stable radix sort of (voxel id, point index): points of a voxel become contiguous, still in
-//      input order -> slot = position - segment start
-//   5. one 64-lane wave per voxel writes the whole [P,4] row block (points, then zero padding):
-//      coalesced 16 B/lane stores and no memset of the output.
+// GPU formulation (order-independent, so bit-identical to the sequential scan), ONE memset + FIVE kernels for any number of
+// agents (round 3; rounds 1-2 sorted (voxel id, point index) pairs with a 3-pass radix sort: 24 launches, launch-bound):
+//   0. one memset(0xFF): hash keys | per-cell minimum point index | per-cell point counter
+//   1. k_voxb_insert: hash-grid insert, cell -> min point index, ticket   (atomicCAS claim + atomicMin + atomicAdd)
+//   2. k_vox_tile_sums: "i is the first point of its cell" flags, counted per 1024-point tile (+ the partial counts at the
+//      agent boundaries that fall inside a tile)
+//   3. k_vox_assign: every tile re-derives the prefix of all tile counts (a block-local scan of <= 4096 values: no
+//      look-back, no spin), ranks its first points -> voxel id in first-appearance order per agent, row in the collated
+//      output, coordinates; both caps applied
+//      and a segment [seg, seg + points of the cell) of one index list (prefix sums of the cells' point counts: deterministic)
+//   4. k_vox_fill: every point drops its index at seg + ticket (the ticket it drew from its cell's counter in step 1: an
+//      arbitrary but collision-free position)
+//   5. k_vox_select_write: a group of G >= P lanes per voxel sorts the segment with a bitonic network on lane shuffles (longer
+//      segments are merged in G-element chunks), keeps the P smallest point indices = the first P points in input order,
+//      whatever the execution order, gathers them and writes the row (zeros beyond): coalesced 16-B stores, no memset.
+//   (max_points > 64: steps 4-5 are an atomicMin insertion cascade into P candidate slots per voxel + a gather.  An earlier
+//   version of this round used the cascade for every P: 339 us on three 64-line sweeps -- the 32 slots of a dense pillar are one
+//   cache line and a few hundred points serialise on it -- against 12 us for fill + select.)
 #include "prims.h"
 #include "../../include/heal_amd.h"
 
@@ -48,122 +57,14 @@ __device__ __forceinline__ bool point_cell(const float4 p, const VoxGrid& g, int
     return true;
 }
 
-// 1. insert: table_key[slot] = cell, table_min[slot] = min point index; slot_of[i] = slot or -1
-__global__ __launch_bounds__(256) void k_vox_insert(const float4* __restrict__ pts, int n, VoxGrid g,
-                                                   uint32_t* __restrict__ tkey,
-                                                   uint32_t* __restrict__ tmin, uint32_t mask,
-                                                   int* __restrict__ slot_of) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    int cx, cy, cz;
-    if (!point_cell(pts[i], g, cx, cy, cz)) { slot_of[i] = -1; return; }
-    const uint32_t cell = ((uint32_t)cz * (uint32_t)g.grid[1] + (uint32_t)cy) * (uint32_t)g.grid[0] + (uint32_t)cx;
-    uint32_t slot = hash_u32(cell) & mask;
-    for (;;) {
-        const uint32_t prev = atomicCAS(&tkey[slot], HASH_EMPTY, cell);
-        if (prev == HASH_EMPTY || prev == cell) break;
-        slot = (slot + 1) & mask;
-    }
-    atomicMin(&tmin[slot], (uint32_t)i);
-    slot_of[i] = (int)slot;
-}
-
-// 2a. flags -> per-tile counts (tile = SCAN_TILE points)
-__global__ __launch_bounds__(256) void k_vox_flag(const int* __restrict__ slot_of,
-                                                 const uint32_t* __restrict__ tmin, int n,
-                                                 int* __restrict__ flag) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int s = slot_of[i];
-    flag[i] = (s >= 0 && tmin[s] == (uint32_t)i) ? 1 : 0;
-}
-
-// 2b. first points publish their voxel id into the table and write the voxel's coordinates
-__global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ pts, int n, VoxGrid g,
-                                                   const int* __restrict__ slot_of,
-                                                   const uint32_t* __restrict__ tmin,
-                                                   const int* __restrict__ vid_excl, int cap,
-                                                   int batch_idx, const int* __restrict__ row_offset,
-                                                   uint32_t* __restrict__ tvid, int* __restrict__ coords) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int base = row_offset ? *row_offset : 0;  // rows of earlier agents in a shared (collated) buffer
-    const int s = slot_of[i];
-    if (s < 0 || tmin[s] != (uint32_t)i) return;
-    const int vid = vid_excl[i];
-    tvid[s] = (uint32_t)vid;  // ids >= cap mark voxels past max_voxels
-    if (vid < cap) {
-        int cx, cy, cz;
-        point_cell(pts[i], g, cx, cy, cz);
-        reinterpret_cast<int4*>(coords)[base + vid] = make_int4(batch_idx, cz, cy, cx);
-    }
-}
-
-// 3. sort keys: voxel id, or `cap` (sorts last) for dropped points; per-voxel point counts
-__global__ __launch_bounds__(256) void k_vox_keys(const int* __restrict__ slot_of,
-                                                 const uint32_t* __restrict__ tvid, int n, int cap,
-                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                 int* __restrict__ count) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int s = slot_of[i];
-    uint32_t k = (uint32_t)cap;
-    if (s >= 0) {
-        const uint32_t v = tvid[s];
-        if (v < (uint32_t)cap) { k = v; atomicAdd(&count[v], 1); }
-    }
-    keys[i] = k;
-    vals[i] = (uint32_t)i;
-}
-
-// 4b. segment heads in the sorted order
-__global__ __launch_bounds__(256) void k_vox_heads(const uint32_t* __restrict__ skeys, int n, int cap,
-                                                  int* __restrict__ seg_start) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t k = skeys[j];
-    if (k >= (uint32_t)cap) return;
-    if (j == 0 || skeys[j - 1] != k) seg_start[k] = j;
-}
-
-// 5. one wave per voxel: rows [0,min(cnt,P)) = points in input order, the rest zeros
-__global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pts,
-                                                  const uint32_t* __restrict__ svals,
-                                                  const int* __restrict__ seg_start,
-                                                  const int* __restrict__ count,
-                                                  const int* __restrict__ total_voxels, int cap, int P,
-                                                  float4* __restrict__ voxels, int* __restrict__ num_points,
-                                                  int* __restrict__ n_voxels_out,
-                                                  const int* __restrict__ row_offset,
-                                                  int* __restrict__ row_offset_next) {
-    const int M = min(*total_voxels, cap);
-    const int base = row_offset ? *row_offset : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *n_voxels_out = M;
-        if (row_offset_next) *row_offset_next = base + M;
-    }
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= M) return;
-    const int l = threadIdx.x & 63;
-    const int c = min(count[v], P);
-    const int st = seg_start[v];
-    for (int p = l; p < P; p += 64) {
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < c) val = pts[svals[st + p]];
-        voxels[(size_t)(base + v) * P + p] = val;
-    }
-    if (l == 0) num_points[base + v] = c;
-}
-
-// ---- batched form: every agent of a modality in ONE launch chain -----------------------------------------------------
-// The chain above is launch-bound (~15 kernels of <= 10 us for a 55 k-point sweep), so n agents cost n chains.  Here the
-// agents' clouds are concatenated (host-known offsets), cell keys carry the agent (agent * cells + cell) and ONE chain of
-// the same length serves all of them: the scan of the "first point of its cell" flags numbers voxels in (agent,
-// first-appearance) order, which is exactly the collated layout of collate_batch_list.
 constexpr int VOX_MAX_BATCH = 16;
+constexpr int VOX_TILE = 1024;          // points per scan tile (4 per thread)
+constexpr int VOX_MAX_TILES = 4096;     // block-local scan of the tile counts: clouds up to 4 M points per call
+constexpr uint32_t VOX_DROPPED = 0xFFFFFFFFu;
 struct VoxBatch {
     int B;
     int pt_off[VOX_MAX_BATCH + 1];  // points of agent b: [pt_off[b], pt_off[b+1])
+    int label0;                     // coords[:, 0] of agent b = label0 + b (single-cloud form: its batch_idx)
 };
 
 __device__ __forceinline__ int vox_agent(const VoxBatch& vb, int i) {
@@ -173,10 +74,11 @@ __device__ __forceinline__ int vox_agent(const VoxBatch& vb, int i) {
     return a;
 }
 
+// 1. insert: table_key[slot] = (agent, cell), table_min[slot] = min point index; slot_of[i] = slot or -1
 __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
                                                     uint32_t cells, uint32_t* __restrict__ tkey,
-                                                    uint32_t* __restrict__ tmin, uint32_t mask,
-                                                    int* __restrict__ slot_of) {
+                                                    uint32_t* __restrict__ tmin, uint32_t* __restrict__ tcnt, uint32_t mask,
+                                                    int* __restrict__ slot_of, uint32_t* __restrict__ tick) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= vb.pt_off[vb.B]) return;
     int cx, cy, cz;
@@ -190,61 +92,265 @@ __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ 
         slot = (slot + 1) & mask;
     }
     atomicMin(&tmin[slot], (uint32_t)i);
+    tick[i] = atomicAdd(&tcnt[slot], 1u) + 1u;     // the counter starts at 0xFFFFFFFF: tickets 0, 1, ...; final value = points - 1
     slot_of[i] = (int)slot;
 }
 
-// per-agent bases: vbase[b] = voxels found before agent b's first point (scan value there), obase[b] = first output row
-// of agent b = sum over earlier agents of min(found, max_voxels); offsets_out[0..B] = obase (collated row offsets)
-__global__ void k_voxb_bases(const int* __restrict__ vid_excl, const int* __restrict__ total, VoxBatch vb,
-                             int max_voxels, int* __restrict__ vbase, int* __restrict__ obase,
-                             int* __restrict__ offsets_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int n = vb.pt_off[vb.B];
-    int acc = 0;
-    for (int b = 0; b <= vb.B; ++b) {
-        const int v = (b == vb.B || vb.pt_off[b] >= n) ? *total : vid_excl[vb.pt_off[b]];
-        vbase[b] = v;
-        if (b > 0) acc += min(v - vbase[b - 1], min(max_voxels, vb.pt_off[b] - vb.pt_off[b - 1]));
-        obase[b] = acc;
-        offsets_out[b] = acc;
+// first-point flags of a tile: point j * 256 + t of tile `tile` (j = 0..3); bit j of the result
+__device__ __forceinline__ unsigned tile_flags(const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin, int tile,
+                                               int n) {
+    unsigned f = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tile * VOX_TILE + j * 256 + (int)threadIdx.x;
+        if (i < n) {
+            const int s = slot_of[i];
+            if (s >= 0 && tmin[s] == (uint32_t)i) f |= 1u << j;
+        }
+    }
+    return f;
+}
+
+__device__ __forceinline__ int block_sum_256(int v, int* s_red) {   // all threads get the sum; s_red: 4 ints, reused
+    v = wave_sum_i(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// 2. per-tile counts of first points and of the points of their cells; partial[a] = first points of the tile holding pt_off[a]
+//    that precede pt_off[a]
+__global__ __launch_bounds__(256) void k_vox_tile_sums(const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin,
+                                                      const uint32_t* __restrict__ tcnt, VoxBatch vb, int* __restrict__ tile_sums,
+                                                      int* __restrict__ tile_cnt, int* __restrict__ partial) {
+    __shared__ int s_red[4];
+    const int n = vb.pt_off[vb.B], tile = blockIdx.x;
+    const unsigned f = tile_flags(slot_of, tmin, tile, n);
+    int pc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((f >> j) & 1u) pc += (int)(tcnt[slot_of[tile * VOX_TILE + j * 256 + (int)threadIdx.x]] + 1u);
+    const int tot = block_sum_256(__popc(f), s_red);
+    const int totc = block_sum_256(pc, s_red);
+    if (threadIdx.x == 0) { tile_sums[tile] = tot; tile_cnt[tile] = totc; }
+    for (int a = 0; a < vb.B; ++a) {      // block-uniform: a boundary inside this tile is rare
+        const int bnd = vb.pt_off[a];
+        if (bnd < tile * VOX_TILE || bnd >= (tile + 1) * VOX_TILE || bnd >= n) continue;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((f >> j) & 1u) && tile * VOX_TILE + j * 256 + (int)threadIdx.x < bnd) ++c;
+        c = block_sum_256(c, s_red);
+        if (threadIdx.x == 0) partial[a] = c;
     }
 }
 
-__global__ __launch_bounds__(256) void k_voxb_assign(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
-                                                    const int* __restrict__ slot_of,
-                                                    const uint32_t* __restrict__ tmin,
-                                                    const int* __restrict__ vid_excl, int max_voxels, int sentinel,
-                                                    const int* __restrict__ vbase, const int* __restrict__ obase,
-                                                    uint32_t* __restrict__ tvid, int* __restrict__ coords) {
+// block-local exclusive scan of v[0..n) (n <= VOX_MAX_TILES) into s_out[0..n], s_out[n] = total; thread t owns a run of k values
+__device__ __forceinline__ void block_scan_tiles(const int* __restrict__ v, int n, int* s_out, int* s_red) {
+    const int t = threadIdx.x, k = (n + 255) / 256;
+    int run = 0;
+    for (int q = t * k; q < min((t + 1) * k, n); ++q) run += v[q];
+    const int incl = wave_incl_scan(run);
+    __syncthreads();
+    if ((t & 63) == 63) s_red[t >> 6] = incl;
+    __syncthreads();
+    int off = incl - run;
+    for (int w = 0; w < (t >> 6); ++w) off += s_red[w];
+    for (int q = t * k; q < min((t + 1) * k, n); ++q) { s_out[q] = off; off += v[q]; }
+    if (t == 255) s_out[n] = off;    // (runs beyond n are empty: thread 255 holds the total)
+    __syncthreads();
+}
+
+// 3. ranks -> rows and segments.  meta[0] = rows written (M), meta[1] = base row (0 without row_offset)
+__global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
+                                                   const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin,
+                                                   const uint32_t* __restrict__ tcnt, const int* __restrict__ tile_sums,
+                                                   const int* __restrict__ tile_cnt, const int* __restrict__ partial,
+                                                   int n_tiles, int max_voxels, const int* __restrict__ row_offset,
+                                                   uint32_t* __restrict__ tvid, int* __restrict__ tseg, int* __restrict__ row_seg,
+                                                   int* __restrict__ row_cnt, int* __restrict__ coords,
+                                                   int* __restrict__ offsets_out, int* __restrict__ n_voxels_out,
+                                                   int* __restrict__ row_offset_next, int* __restrict__ meta) {
+    __shared__ int s_pre[VOX_MAX_TILES + 1];   // exclusive prefix of the tiles' first-point counts; [n_tiles] = total
+    __shared__ int s_prc[VOX_MAX_TILES + 1];   // ... of the tiles' cell-point counts (segment starts)
+    __shared__ int s_red[4], s_w[4][4], s_wc[4][4], s_vbase[VOX_MAX_BATCH + 1], s_obase[VOX_MAX_BATCH + 1];
+    const int n = vb.pt_off[vb.B], tile = blockIdx.x, t = threadIdx.x;
+    block_scan_tiles(tile_sums, n_tiles, s_pre, s_red);
+    block_scan_tiles(tile_cnt, n_tiles, s_prc, s_red);
+    if (t == 0) {
+        const int total = s_pre[n_tiles];
+        int acc = 0;
+        for (int b = 0; b <= vb.B; ++b) {
+            const int bnd = vb.pt_off[b];
+            const int v = (b == vb.B || bnd >= n) ? total : s_pre[bnd / VOX_TILE] + partial[b];
+            s_vbase[b] = v;
+            if (b > 0) acc += min(v - s_vbase[b - 1], min(max_voxels, vb.pt_off[b] - vb.pt_off[b - 1]));
+            s_obase[b] = acc;
+        }
+        if (tile == 0) {
+            const int base = row_offset ? *row_offset : 0;
+            meta[0] = acc; meta[1] = base;
+            if (offsets_out) for (int b = 0; b <= vb.B; ++b) offsets_out[b] = s_obase[b];
+            if (n_voxels_out) *n_voxels_out = acc;
+            if (row_offset_next) *row_offset_next = base + acc;
+        }
+    }
+    const unsigned f = tile_flags(slot_of, tmin, tile, n);
+    const int wave = t >> 6;
+    const unsigned long long lt = lanemask_lt();
+    int before[4], cnt[4], cbefore[4];     // first points (and their cells' points) of this wave that precede point (j, t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool first = (f >> j) & 1u;
+        const unsigned long long bal = __ballot(first);
+        before[j] = __popcll(bal & lt);
+        cnt[j] = first ? (int)(tcnt[slot_of[tile * VOX_TILE + j * 256 + t]] + 1u) : 0;
+        const int incl = wave_incl_scan(cnt[j]);
+        cbefore[j] = incl - cnt[j];
+        if ((t & 63) == 0) s_w[j][wave] = __popcll(bal);
+        if ((t & 63) == 63) s_wc[j][wave] = incl;
+    }
+    __syncthreads();
+    const int base = row_offset ? *row_offset : 0;
+    int run = s_pre[tile], runc = s_prc[tile];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = run + before[j], sg = runc + cbefore[j];
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { r += s_w[j][w]; sg += s_wc[j][w]; }
+            run += s_w[j][w];
+            runc += s_wc[j][w];
+        }
+        if (!((f >> j) & 1u)) continue;
+        const int i = tile * VOX_TILE + j * 256 + t;
+        const int a = vox_agent(vb, i);
+        const int vl = r - s_vbase[a];                 // first-appearance rank inside the agent
+        const int s = slot_of[i];
+        tseg[s] = sg;
+        if (vl < max_voxels) {
+            const int row = s_obase[a] + vl;           // row in this call's outputs (the caller's base row is added on write)
+            tvid[s] = (uint32_t)row;
+            row_seg[row] = sg;
+            row_cnt[row] = cnt[j];
+            int cx, cy, cz;
+            point_cell(pts[i], g, cx, cy, cz);
+            reinterpret_cast<int4*>(coords)[base + row] = make_int4(vb.label0 + a, cz, cy, cx);
+        } else {
+            tvid[s] = VOX_DROPPED;                     // voxels past max_voxels are dropped
+        }
+    }
+}
+
+// 4. index list: the points of a cell occupy [tseg[slot], tseg[slot] + count) in ticket order
+__global__ __launch_bounds__(256) void k_vox_fill(const int* __restrict__ slot_of, const uint32_t* __restrict__ tick,
+                                                 const int* __restrict__ tseg, int n, uint32_t* __restrict__ seg) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= vb.pt_off[vb.B]) return;
+    if (i >= n) return;
     const int s = slot_of[i];
-    if (s < 0 || tmin[s] != (uint32_t)i) return;
-    const int a = vox_agent(vb, i);
-    const int vl = vid_excl[i] - vbase[a];  // first-appearance rank inside the agent
-    if (vl < max_voxels) {
-        const int row = obase[a] + vl;
-        tvid[s] = (uint32_t)row;
-        int cx, cy, cz;
-        point_cell(pts[i], g, cx, cy, cz);
-        reinterpret_cast<int4*>(coords)[row] = make_int4(a, cz, cy, cx);
-    } else {
-        tvid[s] = (uint32_t)sentinel;  // voxels past max_voxels are dropped
+    if (s >= 0) seg[tseg[s] + (int)tick[i]] = (uint32_t)i;
+}
+
+// bitonic network over the G lanes of a group (G a power of two <= 64, groups aligned in the wave): ascending
+template <int G>
+__device__ __forceinline__ uint32_t group_sort(uint32_t v, int l) {
+#pragma unroll
+    for (int k = 2; k <= G; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(v, j, 64);
+            const bool up = (l & k) == 0 || k == G, lower = (l & j) == 0;
+            v = (lower == up) ? min(v, o) : max(v, o);
+        }
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_merge(uint32_t v, int l) {   // v bitonic -> ascending
+#pragma unroll
+    for (int j = G >> 1; j > 0; j >>= 1) {
+        const uint32_t o = __shfl_xor(v, j, 64);
+        v = ((l & j) == 0) ? min(v, o) : max(v, o);
+    }
+    return v;
+}
+
+// 5. G lanes per voxel: the P smallest point indices of its segment, ascending -> gather -> row
+template <int G>
+__global__ __launch_bounds__(256) void k_vox_select_write(const float4* __restrict__ pts, const uint32_t* __restrict__ seg,
+                                                         const int* __restrict__ row_seg, const int* __restrict__ row_cnt,
+                                                         const int* __restrict__ meta, int P, float4* __restrict__ voxels,
+                                                         int* __restrict__ num_points) {
+    const int row = blockIdx.x * (256 / G) + (int)threadIdx.x / G, l = (int)threadIdx.x & (G - 1);
+    const int M = meta[0];
+    if ((int)blockIdx.x * (256 / G) >= M) return;     // block-uniform: the grid is sized by capacity
+    // (a group past the last row idles through the shuffles with an empty segment: whole waves take the same path)
+    const bool live = row < M;
+    const int cnt = live ? row_cnt[row] : 0, st = live ? row_seg[row] : 0;
+    // the longest segment of the wave decides the trip count (wave-uniform loop: the shuffles need every lane)
+    int longest = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o, 64));
+    uint32_t best = group_sort<G>(l < cnt ? seg[st + l] : HASH_EMPTY, l);
+    for (int pos = G; pos < longest; pos += G) {
+        const uint32_t c = group_sort<G>(pos + l < cnt ? seg[st + pos + l] : HASH_EMPTY, l);
+        const uint32_t r = __shfl(c, ((int)threadIdx.x & 63 & ~(G - 1)) | (G - 1 - l), 64);   // the chunk, descending
+        best = group_merge<G>(min(best, r), l);                                              // the G smallest of both
+    }
+    if (!live || l >= P) return;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (best != HASH_EMPTY) val = pts[best];
+    const int base = meta[1];
+    voxels[(size_t)(base + row) * P + l] = val;
+    if (l == 0) num_points[base + row] = min(cnt, P);
+}
+
+// 4'. (max_points > 64) candidate slots: cand[row][0..P) ascending, 0xFFFFFFFF = empty
+__global__ __launch_bounds__(256) void k_vox_candidates(const int* __restrict__ slot_of, const uint32_t* __restrict__ tvid,
+                                                       int n, int P, uint32_t* __restrict__ cand) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = slot_of[i];
+    if (s < 0) return;
+    const uint32_t row = tvid[s];
+    if (row == VOX_DROPPED) return;
+    uint32_t* c = cand + (size_t)row * P;
+    // P smaller indices already sit in the slots (values only decrease; the occupant of the last slot came past P - 1 smaller
+    // ones): this point is not among the first P of its cell
+    if (__builtin_nontemporal_load(c + (P - 1)) < (uint32_t)i) return;
+    uint32_t v = (uint32_t)i;
+    for (int k = 0; k < P; ++k) {
+        if (__builtin_nontemporal_load(c + k) < v) continue;      // a (possibly stale, hence larger) smaller value: not our slot
+        const uint32_t old = atomicMin(c + k, v);
+        if (old == HASH_EMPTY) return;                            // took a free slot
+        if (old > v) v = old;                                     // displaced a larger index: it moves on
     }
 }
 
-static int key_bits_for(int cap) {
-    int b = 1;
-    while ((1u << b) <= (uint32_t)cap) ++b;  // need to represent `cap` itself (the sentinel)
-    return b;
+// 5'. (max_points > 64) thread (row, slot): the point or zeros; the number of points = position of the first empty slot
+__global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pts, const uint32_t* __restrict__ cand,
+                                                  const int* __restrict__ meta, int P, float4* __restrict__ voxels,
+                                                  int* __restrict__ num_points) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(e / P), p = (int)(e - (long long)row * P);
+    if (row >= meta[0]) return;
+    const int base = meta[1];
+    const uint32_t idx = cand[e];
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx != HASH_EMPTY) val = pts[idx];
+    voxels[(size_t)(base + row) * P + p] = val;
+    if (idx == HASH_EMPTY) {
+        if (p == 0 || cand[e - 1] != HASH_EMPTY) num_points[base + row] = p;
+    } else if (p == P - 1) {
+        num_points[base + row] = P;
+    }
 }
 
 struct VoxWs {
-    uint32_t *tkey, *tmin, *tvid;
-    int *slot_of, *flag, *count, *seg_start, *total;
-    uint32_t *keys[2], *vals[2];
-    int* scratch;
+    uint32_t *tkey, *tmin, *tcnt, *cand, *tvid, *tick, *seg;
+    int *slot_of, *tseg, *row_seg, *row_cnt, *tile_sums, *tile_cnt, *partial, *meta;
     uint32_t tcap;
+    size_t ff_bytes;     // tkey | tmin | tcnt (| cand): initialised by one memset(0xFF)
 };
 
 static uint32_t table_cap(int n) {
@@ -253,35 +359,91 @@ static uint32_t table_cap(int n) {
     return c;
 }
 
-static bool carve(Arena& a, int n, int cap, VoxWs& w) {
+static bool carve(Arena& a, int n, int cap, int P, VoxWs& w) {
     w.tcap = table_cap(n);
-    // tkey | tmin are contiguous so one memset(0xFF) initialises both
     w.tkey = a.take<uint32_t>(w.tcap);
     w.tmin = a.take<uint32_t>(w.tcap);
+    w.tcnt = a.take<uint32_t>(w.tcap);
+    w.cand = a.take<uint32_t>(P > 64 ? (size_t)cap * P : 1);
     w.tvid = a.take<uint32_t>(w.tcap);
+    w.ff_bytes = (size_t)((char*)w.tvid - (char*)w.tkey);
+    w.tseg = a.take<int>(w.tcap);
     w.slot_of = a.take<int>(n);
-    w.flag = a.take<int>(n);
-    w.count = a.take<int>(cap + 1);
-    w.seg_start = a.take<int>(cap + 1);
-    w.total = a.take<int>(64);
-    for (int k = 0; k < 2; ++k) { w.keys[k] = a.take<uint32_t>(n); w.vals[k] = a.take<uint32_t>(n); }
-    size_t sw = sort_scratch_words(n);
-    size_t cw = scan_scratch_words(n);
-    w.scratch = a.take<int>(sw > cw ? sw : cw);
+    w.tick = a.take<uint32_t>(n);
+    w.seg = a.take<uint32_t>(n);
+    w.row_seg = a.take<int>(cap);
+    w.row_cnt = a.take<int>(cap);
+    w.tile_sums = a.take<int>(ceil_div(n, VOX_TILE) + 1);
+    w.tile_cnt = a.take<int>(ceil_div(n, VOX_TILE) + 1);
+    w.partial = a.take<int>(VOX_MAX_BATCH + 1);
+    w.meta = a.take<int>(64);
     return a.ok();
+}
+
+// the whole chain; outputs as documented in include/heal_amd.h
+static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& g, uint32_t cells, int P, int max_voxels, int cap,
+                          const int32_t* row_offset, float* voxels, int32_t* coords, int32_t* num_points, int32_t* offsets_out,
+                          int32_t* n_voxels_out, int32_t* row_offset_next, void* ws, size_t ws_bytes, hipStream_t s,
+                          const char* who) {
+    const int n = vb.pt_off[vb.B];
+    const int n_tiles = ceil_div(n, VOX_TILE);
+    HEAL_REQUIRE(n_tiles <= VOX_MAX_TILES, "%s: at most %d points per call (got %d)", who, VOX_MAX_TILES * VOX_TILE, n);
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "%s: workspace must be 256-B aligned", who);
+    Arena a(ws, ws_bytes);
+    VoxWs w;
+    HEAL_REQUIRE(carve(a, n, cap, P, w), "%s: workspace too small (%zu < %zu)", who, ws_bytes, a.off);
+    const int nb = ceil_div(n, 256);
+    HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, w.ff_bytes, s));
+    k_voxb_insert<<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
+    k_vox_tile_sums<<<n_tiles, 256, 0, s>>>(w.slot_of, w.tmin, w.tcnt, vb, w.tile_sums, w.tile_cnt, w.partial);
+    k_vox_assign<<<n_tiles, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.tcnt, w.tile_sums, w.tile_cnt, w.partial, n_tiles,
+                                         max_voxels, row_offset, w.tvid, w.tseg, w.row_seg, w.row_cnt, coords, offsets_out,
+                                         n_voxels_out, row_offset_next, w.meta);
+    float4* vox4 = reinterpret_cast<float4*>(voxels);
+    if (P > 64) {
+        k_vox_candidates<<<nb, 256, 0, s>>>(w.slot_of, w.tvid, n, P, w.cand);
+        k_vox_write<<<(unsigned)(((long long)cap * P + 255) / 256), 256, 0, s>>>(pts, w.cand, w.meta, P, vox4, num_points);
+    } else {
+        k_vox_fill<<<nb, 256, 0, s>>>(w.slot_of, w.tick, w.tseg, n, w.seg);
+#define HEAL_VSW(G_) k_vox_select_write<G_><<<ceil_div(cap, 256 / G_), 256, 0, s>>>(pts, w.seg, w.row_seg, w.row_cnt, w.meta, P, vox4, num_points)
+        if (P > 32) HEAL_VSW(64);
+        else if (P > 16) HEAL_VSW(32);
+        else if (P > 8) HEAL_VSW(16);
+        else if (P > 4) HEAL_VSW(8);
+        else if (P > 2) HEAL_VSW(4);
+        else if (P > 1) HEAL_VSW(2);
+        else HEAL_VSW(1);
+#undef HEAL_VSW
+    }
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+static bool vox_grid(const float* range_host, const float* voxel_size_host, VoxGrid& g, int64_t& cells) {
+    cells = 1;
+    for (int j = 0; j < 3; ++j) {
+        g.rmin[j] = range_host[j];
+        g.vsize[j] = voxel_size_host[j];
+        // grid = round((max-min)/size), computed like numpy does on the python floats (fp64)
+        const double gs = ((double)range_host[3 + j] - (double)range_host[j]) / (double)voxel_size_host[j];
+        g.grid[j] = (int)__builtin_rint(gs);
+        if (g.grid[j] < 1) return false;
+        cells *= g.grid[j];
+    }
+    return true;
 }
 
 }  // namespace heal
 
 using namespace heal;
 
-extern "C" size_t heal_voxelize_workspace(int n_points, int max_voxels) {
+extern "C" size_t heal_voxelize_workspace(int n_points, int max_points, int max_voxels) {
     if (n_points < 1) n_points = 1;
     int cap = n_points < max_voxels ? n_points : max_voxels;
     if (cap < 1) cap = 1;
     Arena a(nullptr, 0);
     VoxWs w;
-    carve(a, n_points, cap, w);
+    carve(a, n_points, cap, max_points < 1 ? 1 : max_points, w);
     return a.off + 256;
 }
 
@@ -343,51 +505,27 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
         return 0;
     }
     VoxGrid g;
-    int64_t cells = 1;
-    for (int j = 0; j < 3; ++j) {
-        g.rmin[j] = range_host[j];
-        g.vsize[j] = voxel_size_host[j];
-        // grid = round((max-min)/size), computed like numpy does on the python floats (fp64)
-        double gs = ((double)range_host[3 + j] - (double)range_host[j]) / (double)voxel_size_host[j];
-        g.grid[j] = (int)__builtin_rint(gs);
-        HEAL_REQUIRE(g.grid[j] >= 1, "voxelize: empty grid on axis %d", j);
-        cells *= g.grid[j];
-    }
+    int64_t cells;
+    HEAL_REQUIRE(vox_grid(range_host, voxel_size_host, g, cells), "voxelize: empty grid");
     HEAL_REQUIRE(cells < 0xFFFFFFFFll, "voxelize: grid has too many cells (%lld)", (long long)cells);
+    VoxBatch vb;
+    vb.B = 1; vb.pt_off[0] = 0; vb.pt_off[1] = n_points; vb.label0 = batch_idx;
+    for (int b = 2; b <= VOX_MAX_BATCH; ++b) vb.pt_off[b] = n_points;
     const int cap = n_points < max_voxels ? n_points : max_voxels;
-    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "voxelize: workspace must be 256-B aligned");
-    Arena a(ws, ws_bytes);
-    VoxWs w;
-    HEAL_REQUIRE(carve(a, n_points, cap, w), "voxelize: workspace too small (%zu < %zu)", ws_bytes, a.off);
-
-    const float4* pts = reinterpret_cast<const float4*>(points);
-    const int nb = ceil_div(n_points, 256);
-    // tkey and tmin: 0xFF.. = EMPTY / +inf ; counts: 0
-    HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, (size_t)((char*)w.tvid - (char*)w.tkey), s));
-    HEAL_HIP(hipMemsetAsync(w.count, 0, (size_t)(cap + 1) * sizeof(int), s));
-    k_vox_insert<<<nb, 256, 0, s>>>(pts, n_points, g, w.tkey, w.tmin, w.tcap - 1, w.slot_of);
-    k_vox_flag<<<nb, 256, 0, s>>>(w.slot_of, w.tmin, n_points, w.flag);
-    if (scan_exclusive(w.flag, w.flag, n_points, w.total, w.scratch, s)) return 1;
-    k_vox_assign<<<nb, 256, 0, s>>>(pts, n_points, g, w.slot_of, w.tmin, w.flag, cap, batch_idx, row_offset,
-                                    w.tvid, coords);
-    k_vox_keys<<<nb, 256, 0, s>>>(w.slot_of, w.tvid, n_points, cap, w.keys[0], w.vals[0], w.count);
-    int res = 0;
-    if (radix_sort_pairs(w.keys, w.vals, n_points, key_bits_for(cap), &res, w.scratch, s)) return 1;
-    k_vox_heads<<<nb, 256, 0, s>>>(w.keys[res], n_points, cap, w.seg_start);
-    k_vox_write<<<ceil_div(cap, 4), 256, 0, s>>>(pts, w.vals[res], w.seg_start, w.count, w.total, cap,
-                                                 max_points, reinterpret_cast<float4*>(voxels),
-                                                 num_points, n_voxels, row_offset, row_offset_next);
-    HEAL_LAUNCH_CHECK();
-    return 0;
+    return voxelize_chain(reinterpret_cast<const float4*>(points), vb, g, (uint32_t)cells, max_points, max_voxels, cap, row_offset,
+                          voxels, coords, num_points, nullptr, n_voxels, row_offset_next, ws, ws_bytes, s, "voxelize");
 }
 
-
-extern "C" size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents) {
+extern "C" size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents, int max_points, int max_voxels) {
     if (n_points_total < 1) n_points_total = 1;
+    (void)n_agents;
     Arena a(nullptr, 0);
     VoxWs w;
-    carve(a, n_points_total, n_points_total, w);
-    return a.off + align_up((size_t)(2 * (VOX_MAX_BATCH + 1)) * sizeof(int)) + 256;
+    // rows: sum_b min(n_b, max_voxels) <= min(n_total, n_agents * max_voxels)
+    long long cap = (long long)(n_agents < 1 ? 1 : n_agents) * (max_voxels < 1 ? 1 : max_voxels);
+    if (cap > n_points_total) cap = n_points_total;
+    carve(a, n_points_total, (int)cap, max_points < 1 ? 1 : max_points, w);
+    return a.off + 256;
 }
 
 extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_offsets_host, int n_agents,
@@ -398,9 +536,9 @@ extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_off
     HEAL_REQUIRE(n_agents >= 1 && n_agents <= VOX_MAX_BATCH, "voxelize_batch: 1..%d agents per call", VOX_MAX_BATCH);
     HEAL_REQUIRE(max_points >= 1 && max_voxels >= 1 && row_offsets != nullptr, "voxelize_batch: bad arguments");
     VoxBatch vb;
-    vb.B = n_agents;
-    for (int b = 0; b <= n_agents; ++b) {
-        vb.pt_off[b] = point_offsets_host[b];
+    vb.B = n_agents; vb.label0 = 0;
+    for (int b = 0; b <= VOX_MAX_BATCH; ++b) {
+        vb.pt_off[b] = point_offsets_host[b <= n_agents ? b : n_agents];
         HEAL_REQUIRE(b == 0 ? vb.pt_off[0] == 0 : vb.pt_off[b] >= vb.pt_off[b - 1], "voxelize_batch: offsets must ascend from 0");
     }
     const int n = vb.pt_off[n_agents];
@@ -409,44 +547,11 @@ extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_off
         return 0;
     }
     VoxGrid g;
-    int64_t cells = 1;
-    for (int j = 0; j < 3; ++j) {
-        g.rmin[j] = range_host[j];
-        g.vsize[j] = voxel_size_host[j];
-        double gs = ((double)range_host[3 + j] - (double)range_host[j]) / (double)voxel_size_host[j];
-        g.grid[j] = (int)__builtin_rint(gs);
-        HEAL_REQUIRE(g.grid[j] >= 1, "voxelize_batch: empty grid on axis %d", j);
-        cells *= g.grid[j];
-    }
+    int64_t cells;
+    HEAL_REQUIRE(vox_grid(range_host, voxel_size_host, g, cells), "voxelize_batch: empty grid");
     HEAL_REQUIRE(cells * n_agents < 0xFFFFFFFFll, "voxelize_batch: agents x cells exceeds 32-bit keys");
     int cap = 0;  // rows of the collated outputs: sum of min(n_b, max_voxels)
     for (int b = 0; b < n_agents; ++b) cap += (vb.pt_off[b + 1] - vb.pt_off[b]) < max_voxels ? (vb.pt_off[b + 1] - vb.pt_off[b]) : max_voxels;
-    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "voxelize_batch: workspace must be 256-B aligned");
-    Arena a(ws, ws_bytes);
-    VoxWs w;
-    HEAL_REQUIRE(carve(a, n, n, w), "voxelize_batch: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    int* vbase = a.take<int>(VOX_MAX_BATCH + 1);
-    int* obase = a.take<int>(VOX_MAX_BATCH + 1);
-    HEAL_REQUIRE(a.ok(), "voxelize_batch: workspace too small");
-
-    const float4* pts = reinterpret_cast<const float4*>(points);
-    const int nb = ceil_div(n, 256);
-    HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, (size_t)((char*)w.tvid - (char*)w.tkey), s));
-    HEAL_HIP(hipMemsetAsync(w.count, 0, (size_t)(cap + 1) * sizeof(int), s));
-    k_voxb_insert<<<nb, 256, 0, s>>>(pts, vb, g, (uint32_t)cells, w.tkey, w.tmin, w.tcap - 1, w.slot_of);
-    k_vox_flag<<<nb, 256, 0, s>>>(w.slot_of, w.tmin, n, w.flag);
-    if (scan_exclusive(w.flag, w.flag, n, w.total, w.scratch, s)) return 1;
-    k_voxb_bases<<<1, 64, 0, s>>>(w.flag, w.total, vb, max_voxels, vbase, obase, row_offsets);
-    k_voxb_assign<<<nb, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.flag, max_voxels, cap, vbase, obase, w.tvid,
-                                     coords);
-    k_vox_keys<<<nb, 256, 0, s>>>(w.slot_of, w.tvid, n, cap, w.keys[0], w.vals[0], w.count);
-    int res = 0;
-    if (radix_sort_pairs(w.keys, w.vals, n, key_bits_for(cap), &res, w.scratch, s)) return 1;
-    k_vox_heads<<<nb, 256, 0, s>>>(w.keys[res], n, cap, w.seg_start);
-    // rows written: row_offsets[n_agents] (device); n_voxels_out goes to a scratch word
-    k_vox_write<<<ceil_div(cap, 4), 256, 0, s>>>(pts, w.vals[res], w.seg_start, w.count, row_offsets + n_agents, cap,
-                                                 max_points, reinterpret_cast<float4*>(voxels), num_points, w.total + 1,
-                                                 nullptr, nullptr);
-    HEAL_LAUNCH_CHECK();
-    return 0;
+    return voxelize_chain(reinterpret_cast<const float4*>(points), vb, g, (uint32_t)cells, max_points, max_voxels, cap, nullptr,
+                          voxels, coords, num_points, row_offsets, nullptr, nullptr, ws, ws_bytes, s, "voxelize_batch");
 }

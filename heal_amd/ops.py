@@ -177,7 +177,7 @@ def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
-    nbytes = _capi.query("heal_voxelize_workspace", n, int(max_voxels))
+    nbytes = _capi.query("heal_voxelize_workspace", n, int(max_points), int(max_voxels))
     ws = _workspace("voxelize", nbytes, dev)
     rng = _host_array([float(v) for v in lidar_range], ctypes.c_float)
     vs = _host_array([float(v) for v in voxel_size], ctypes.c_float)
@@ -227,7 +227,7 @@ def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxel
         for p in pts:
             bounds.append(bounds[-1] + int(p.shape[0]))
         allp = pts[0] if len(pts) == 1 else torch.cat(pts, 0)
-        nbytes = _capi.query("heal_voxelize_batch_workspace", bounds[-1], len(pts))
+        nbytes = _capi.query("heal_voxelize_batch_workspace", bounds[-1], len(pts), int(max_points), int(max_voxels))
         ws = _workspace("voxelize", nbytes, dev)
         with _Timed("voxelize"):
             _capi.call("heal_voxelize_batch", _ptr(allp), _host_array(bounds, ctypes.c_int32), len(pts), rng, vs,
@@ -237,7 +237,7 @@ def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxel
     counts = torch.zeros((len(pts),), dtype=torch.int32, device=dev)
     for b, p in enumerate(pts):
         n = int(p.shape[0])
-        nbytes = _capi.query("heal_voxelize_workspace", n, int(max_voxels))
+        nbytes = _capi.query("heal_voxelize_workspace", n, int(max_points), int(max_voxels))
         ws = _workspace("voxelize", nbytes, dev)
         with _Timed("voxelize"):
             _capi.call("heal_voxelize", _ptr(p), n, rng, vs, int(max_points), int(max_voxels), b, _ptr(voxels),

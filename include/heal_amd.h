@@ -44,7 +44,7 @@ const char* heal_last_error(void);
  *               rows go to [*row_offset, *row_offset + M) of voxels/coords/num_points (buffers shared by the agents
  *               of a modality) and *row_offset_next <- *row_offset + M feeds the next agent's call.
  * -----------------------------------------------------------------------------------------------*/
-size_t heal_voxelize_workspace(int n_points, int max_voxels);
+size_t heal_voxelize_workspace(int n_points, int max_points, int max_voxels);
 int heal_voxelize(const float* points, int n_points,
                   const float* range_host, const float* voxel_size_host,
                   int max_points, int max_voxels, int batch_idx,
@@ -52,13 +52,13 @@ int heal_voxelize(const float* points, int n_points,
                   const int32_t* row_offset, int32_t* row_offset_next,
                   void* ws, size_t ws_bytes, void* stream);
 
-/* heal_voxelize_batch: K1 for every agent of a modality in ONE launch chain (the single-cloud chain is launch-bound:
- *   ~15 kernels of <= 10 us): `points` holds the agents' clouds back to back, point_offsets_host [n_agents+1] (host)
+/* heal_voxelize_batch: K1 for every agent of a modality in ONE launch chain (one memset + five kernels, as the single-cloud
+ *   form; at most 4 M points per call): `points` holds the agents' clouds back to back, point_offsets_host [n_agents+1] (host)
  *   the boundaries.  Outputs are the collated buffers of collate_batch_list: rows of agent b at
  *   [row_offsets[b], row_offsets[b+1]) with coords (b,z,y,x); row_offsets [n_agents+1] i32 DEVICE.  Buffers need
  *   sum_b min(n_b, max_voxels) rows.  Same semantics per agent as heal_voxelize (first-come order, both caps).  <= 16
  *   agents per call.                                                                                              */
-size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents);
+size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents, int max_points, int max_voxels);
 int heal_voxelize_batch(const float* points, const int32_t* point_offsets_host, int n_agents,
                         const float* range_host, const float* voxel_size_host, int max_points, int max_voxels,
                         float* voxels, int32_t* coords, int32_t* num_points, int32_t* row_offsets,
