@@ -74,7 +74,9 @@ __device__ __forceinline__ int vox_agent(const VoxBatch& vb, int i) {
     return a;
 }
 
-// 1. insert: table_key[slot] = (agent, cell), table_min[slot] = min point index; slot_of[i] = slot or -1
+// 1. insert: table_key[slot] = (agent, cell), table_min[slot] = min point index, ticket; slot_of[i] = slot or -1.
+// (Grouping the lanes of a wave by cell first -- ballot matching, one set of atomics per group leader -- was measured on three
+// 64-line sweeps: 35 us against 26 us for this form; the matching loop costs more than the same-address atomics it saves.)
 __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
                                                     uint32_t cells, uint32_t* __restrict__ tkey,
                                                     uint32_t* __restrict__ tmin, uint32_t* __restrict__ tcnt, uint32_t mask,
