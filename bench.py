@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--frames", type=int, default=4,
                     help="distinct synthetic frames (same agent layout, different clouds / images / poses) resident in HBM; "
                          "the steps cycle through them, so every step sees a NEW frame like tools/inference.py's loop")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("HEAL_FRAMES_IN_FLIGHT", "2")),
+                    help="captured copies of the step that run concurrently on their own streams (pipeline.FramesInFlight): frame "
+                         "k + 1 is submitted while frame k runs and its boxes are read one step later; 1 = one frame at a time")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying a "
                     "captured HIP graph of the step (the heterogeneous scene is ~800 launches: host-bound when eager)")
     ap.add_argument("--parallel", default="agents", choices=["agents", "replicas"],
@@ -375,6 +378,12 @@ def main():
 
                 def step():  # noqa: F811
                     return pipe.replay(next_frame())   # copies the frame into the graph's static input buffers first
+                if a.frames_in_flight > 1:
+                    from heal_amd.pipeline import FramesInFlight
+                    ring = FramesInFlight(pipe, scene, depth=a.frames_in_flight)
+
+                    def step():  # noqa: F811
+                        return ring.step(next_frame())     # the boxes of the frame submitted `depth` steps earlier
             except Exception as e:  # a path with a host round trip (e.g. SECOND's site counts) cannot be captured
                 print(f"[bench] HIP graph capture unavailable for this workload ({type(e).__name__}: {e}); "
                       "running eagerly", file=sys.stderr)
@@ -430,8 +439,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    ring = locals().get("ring")
+    latency_ms = None
+    if ring is not None:      # latency of ONE frame through the captured step (the ring changes the rate, not this)
+        pipe.replay(next_frame())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pipe.replay(next_frame())
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t0) / 5 * 1e3
     for _ in range(a.warmup):
         step()
+    if ring is not None:
+        ring.drain()
     fence()
     if not use_graph:
         ops.TIMING = {}
@@ -439,6 +460,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
+    if ring is not None:          # every one of the K frames is finished and read back inside the timed region
+        res = (ring.drain() or [res])[-1]
     fence()
     dt = time.perf_counter() - t0
     if use_graph:
@@ -499,6 +522,8 @@ def main():
                                                                    + (" (fp16 wire)" if os.environ.get("HEAL_WIRE") == "fp16" else "")),
                        "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if solo
                                   else "hipGraph(local stage) -> all-gather -> hipGraph(fusion tail + decode/NMS)"),
+                       "frames_in_flight": (len(ring.slots) if ring is not None else 1),
+                       "frame_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "roofline_other": roof_other, "op_timing_ms": kernels,
         }

@@ -128,14 +128,16 @@ def encode_modalities(model, data_dict, present, encode):
     main = torch.cuda.current_stream(dev)
     streams = model.__dict__.setdefault("_heal_side_streams", {})
     feats = {}
+    # side streams per CALLER stream: two captured copies of the step that run concurrently (pipeline.FramesInFlight) must
+    # not share them -- the operators' scratch buffers are per stream
     for m in mods[1:]:
-        s = streams.get((m, dev.index))
+        s = streams.get((m, dev.index, main.cuda_stream))
         if s is None:
-            s = streams[(m, dev.index)] = torch.cuda.Stream(device=dev)
+            s = streams[(m, dev.index, main.cuda_stream)] = torch.cuda.Stream(device=dev)
         s.wait_stream(main)
         with torch.cuda.stream(s):
             feats[m] = encode(data_dict, m)
     feats[mods[0]] = encode(data_dict, mods[0])       # the first modality stays on the caller's stream
     for m in mods[1:]:
-        main.wait_stream(streams[(m, dev.index)])
+        main.wait_stream(streams[(m, dev.index, main.cuda_stream)])
     return {m: feats[m] for m in mods}

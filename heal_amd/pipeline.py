@@ -238,13 +238,14 @@ class ScenePipeline:
     # captured once into a HIP graph and replayed; the only host interaction left per scene is reading
     # the box count.
     @torch.no_grad()
-    def capture(self, scene, warmup=3, slack=1.25):
-        """Capture the whole step around STATIC input buffers initialised from `scene` (StaticInputs); `replay()` re-runs
-        it on whatever the buffers hold, `replay(other_scene)` loads another frame of the same layout first."""
+    def capture_slot(self, scene, warmup=3, slack=1.25):
+        """Capture the whole step around its OWN static input buffers (initialised from `scene`) on the current, non-default
+        stream -> a `_Slot` (buffers, graph, output buffers, stream).  Several slots of one pipeline share the model's
+        parameters and nothing else: scratch buffers are per stream (ops._workspace) and so are the modality side streams."""
         from heal_amd import ops
         dir_args = self.post.params.get("dir_args", {"dir_offset": 0.7853, "num_bins": 2})
         anchors = self.post._anchors_f32(self.anchor_box, self.device)
-        self._static_in = static = StaticInputs(scene, slack)
+        static = StaticInputs(scene, slack)
 
         def body():
             out = self.model(static.model_input())
@@ -265,11 +266,17 @@ class ScenePipeline:
         ops.verify_sparse_capacity()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=cur):
-            self._static_out = body()
+            static_out = body()
         # the capacity counters written inside the graph live in its private pool: keep them to re-check after every replay
-        self._graph_checks = ops.take_sparse_checks()
-        self._graph = graph
-        return graph
+        return _Slot(static, graph, static_out, ops.take_sparse_checks(), cur)
+
+    @torch.no_grad()
+    def capture(self, scene, warmup=3, slack=1.25):
+        """Capture the whole step around STATIC input buffers initialised from `scene` (StaticInputs); `replay()` re-runs
+        it on whatever the buffers hold, `replay(other_scene)` loads another frame of the same layout first."""
+        slot = self.capture_slot(scene, warmup, slack)
+        self._static_in, self._graph, self._static_out, self._graph_checks = slot.static_in, slot.graph, slot.out, slot.checks
+        return slot.graph
 
     def check_sparse_capacity(self):
         """SECOND encoders fed with device point clouds size their strided layers by capacity (no host round trip);
@@ -290,3 +297,69 @@ class ScenePipeline:
         if k == 0:
             return None, None
         return corners[:k], scores[:k]
+
+
+class _Slot:
+    """One captured copy of the step: static input buffers, HIP graph, static output buffers, the stream it replays on."""
+
+    def __init__(self, static_in, graph, out, checks, stream):
+        self.static_in, self.graph, self.out, self.checks, self.stream = static_in, graph, out, checks, stream
+        self.done = torch.cuda.Event()
+
+
+class FramesInFlight:
+    """Throughput mode of the replayed step: `depth` captured copies of the step, each on its own stream with its own static
+    input / output buffers; frame k is loaded into slot k % depth and replayed there while frame k - 1 is still running on the
+    other slot, and its boxes are read one `step()` later.  What overlaps is the latency-bound part of one frame (voxeliser,
+    image trunks at 1/16 resolution, decode + NMS: small launches that leave most CUs idle) with the matrix-bound part of its
+    neighbour -- the same effect the concurrent modality stems have inside one frame.  Every frame still runs the whole step;
+    per-frame latency is that of the plain replay (or a little more), the rate is what changes.
+
+        ring = FramesInFlight(pipe, scene, depth=2)
+        for frame in frames:  res = ring.step(frame)      # result of the frame submitted `depth` steps earlier (None at first)
+        rest = ring.drain()                               # results still in flight, oldest first
+    """
+
+    def __init__(self, pipe, scene, depth=2, warmup=3, slack=1.25):
+        from collections import deque
+        self.pipe = pipe
+        self.slots = []
+        for _ in range(depth):
+            stream = torch.cuda.Stream(device=pipe.device)
+            with torch.cuda.stream(stream):
+                self.slots.append(pipe.capture_slot(scene, warmup, slack))
+            stream.synchronize()
+        self._next = 0
+        self._inflight = deque()
+
+    def _collect(self):
+        from heal_amd import ops
+        slot = self._inflight.popleft()
+        with torch.cuda.stream(slot.stream):
+            corners, scores, count = slot.out
+            k = int(count.item())          # waits for this slot's stream only
+        if slot.checks:
+            ops.verify_sparse_capacity(slot.checks)
+        if k == 0:
+            return None, None
+        return corners[:k].clone(), scores[:k].clone()    # the slot's output buffers are overwritten by its next frame
+
+    def step(self, scene):
+        """Submit `scene`; returns the (boxes, scores) of the oldest frame in flight once the ring is full, else None."""
+        res = None
+        if len(self._inflight) == len(self.slots):
+            res = self._collect()
+        slot = self.slots[self._next % len(self.slots)]
+        self._next += 1
+        with torch.cuda.stream(slot.stream):
+            slot.static_in.load(scene)
+            slot.graph.replay()
+        self._inflight.append(slot)
+        return res
+
+    def drain(self):
+        out = []
+        while self._inflight:
+            out.append(self._collect())
+        return out
+

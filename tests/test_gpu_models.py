@@ -304,6 +304,49 @@ def test_concurrent_modality_streams_equal_serial(monkeypatch):
 
     torch.cuda.synchronize()
 
+@pytest.mark.parametrize("mods", [["m1", "m1", "m1"], ["m1", "m2", "m4", "m1", "m1"]])
+def test_frames_in_flight_equal_sequential_replay(mods):
+    """pipeline.FramesInFlight (two captured copies of the step on two streams, frame k + 1 submitted while frame k runs) returns
+    for every frame what the plain replay returns: bit-equal for LiDAR-only scenes (deterministic path), to the tolerance of the
+    camera lift's fp32 atomics otherwise; over three rounds of four frames, results delivered in submission order."""
+    from heal_amd import configs
+    from heal_amd.pipeline import FramesInFlight, Scene, ScenePipeline
+    lidar = all(m == "m1" for m in mods)
+    hypes = configs.lidar_pyramid(max_cav=5) if lidar else configs.heal_heter()
+    frames = [Scene(len(mods), seed=40 + i, device="cuda:0", modalities=mods) for i in range(4)]
+    side = torch.cuda.Stream()
+    with torch.no_grad(), torch.cuda.stream(side):
+        pipe = ScenePipeline(hypes, "cuda:0", seed=2)
+        pipe.calibrate_cls_bias(frames[0])
+        pipe.capture(frames[0], warmup=1)
+        want = []
+        for f in frames:
+            b, sc = pipe.replay(f)
+            want.append((None, None) if b is None else (b.clone(), sc.clone()))
+        assert any(b is not None for b, _ in want)
+        ring = FramesInFlight(pipe, frames[0], depth=2, warmup=1)
+        got = []
+        for _round in range(3):
+            for f in frames:
+                r = ring.step(f)
+                if r is not None:
+                    got.append(r)
+        got += ring.drain()
+    torch.cuda.synchronize()
+    assert len(got) == 12
+    for i, (b, sc) in enumerate(got):
+        wb, ws = want[i % 4]
+        assert (b is None) == (wb is None), i
+        if b is None:
+            continue
+        assert b.shape == wb.shape, i
+        if lidar:
+            assert torch.equal(b, wb) and torch.equal(sc, ws), i
+        else:
+            np.testing.assert_allclose(sc.cpu().numpy(), ws.cpu().numpy(), rtol=0, atol=2e-3)
+            np.testing.assert_allclose(b.cpu().numpy(), wb.cpu().numpy(), rtol=1e-3, atol=5e-3)
+
+
 def _hetero_small_model_and_data(g):
     from heal_amd import configs
     agents = [str(a) for a in g["agents"]]
