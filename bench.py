@@ -236,7 +236,7 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         P = 5 if a.workload == "scene8_second_v2xvit" else 32
         bts = float(sum(16 * int(scene.points[k].shape[0]) + 16 * m * P + 20 * m
                         for k, m in zip(sorted(scene.points), m_per_agent)))
-        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene, one launch chain)", "hbm",
+        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: one memset + five kernels)", "hbm",
                                                  bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
     if "decode_nms" in timing:
         calls, mean_ms = timing["decode_nms"]
