@@ -50,6 +50,13 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "heal_bev_pool_pm_workspace": (c_size_t, [c_int] * 5),
     "heal_bev_pool_pm": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "heal_pfn_train_blocks": (c_int, [c_int]),
+    "heal_pfn_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                  c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "heal_pfn_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float,
+                                 c_void_p, c_void_p]),
+    "heal_pfn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "heal_mean_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_sort_workspace": (c_size_t, [c_int]),
     "heal_sp_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,

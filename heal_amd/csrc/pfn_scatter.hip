@@ -195,10 +195,188 @@ __global__ __launch_bounds__(256) void k_pfn4(const float4* __restrict__ voxels,
             *reinterpret_cast<float4*>(&pillar_feat[(size_t)m * PFN_C + i * 4]) = make_float4(best[0], best[1], best[2], best[3]);
             if (i == 0) {
                 const int idx = cd.y + cd.z * g.nx + cd.w;  // z + y*nx + x (point_pillar_scatter.py:58)
-                if (cd.x >= 0 && cd.x < g.n_agents && idx >= 0 && idx < g.ny * g.nx)
+                if (cell_map && cd.x >= 0 && cd.x < g.n_agents && idx >= 0 && idx < g.ny * g.nx)
                     atomicMax(&cell_map[(size_t)cd.x * g.ny * g.nx + idx], m);
             }
         }
+    }
+}
+
+// ---- training: batch statistics and the backward of Linear(10 -> 64, no bias) -> BatchNorm1d -> ReLU -> max ----
+// pillar_vfe.py:25-51 (PFNLayer) in training mode normalises with the statistics of ALL M x P rows (zeroed padding rows
+// included).  With z = W f the per-channel moments are closed forms of two small sums over the rows,
+//     s1 = sum_rows f [10],   S = sum_rows f f^T [10 x 10]:   mean_c = W_c . s1 / R,   E[z_c^2] = W_c^T S W_c / R,
+// and so is every row-sum the weight gradient needs:  sum_rows xhat_c f = rstd_c ((W S)_c - mean_c s1).
+// k_pfn_moments: per-block partial sums of the 10 + 55 distinct products (the host adds the partials in float64).
+// k_pfn_backward: per pillar and channel the arg-max row p* of y = relu(scale z + shift) (a padding row counts once: z = 0,
+//   f = 0), dy = g[m][c] where y* > 0; per-block partial sums of
+//     A[c][k] = sum dy f_{p*}[k]  (64 x 10),   B[c] = sum dy,   Cx[c] = sum dy xhat_{p*}[c],   xhat = (z - mean) rstd.
+//   dW = (gamma rstd) (A - (B/R) s1 - (Cx/R) rstd ((W S) - mean s1))   [batch statistics]   |   scale A   [running statistics]
+//   dgamma = Cx, dbeta = B.
+// Both kernels stage the decorated features exactly as k_pfn4 does (same arithmetic: the arg-max agrees with the forward).
+constexpr int PFN_NMOM = 65;    // 10 sums + 55 products f_j f_k (j <= k)
+constexpr int PFN_BWD_ROW = 12; // A[c][0..10), B[c], Cx[c]
+
+__device__ __forceinline__ void pfn_stage4(const float4* __restrict__ voxels, int P, const int4* __restrict__ coords,
+                                           const int* __restrict__ num_points, int M, int m, int i, const PfnGeom& g,
+                                           float (*sf)[PFN_FROW] /*[32][12] of this pillar slot*/, int& np_out) {
+    const bool live_p = m < M;
+    int4 cd = make_int4(0, 0, 0, 0);
+    int np = 0;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+    if (live_p) {
+        cd = coords[m]; np = num_points[m];
+        if (i < P) pa = voxels[(size_t)m * P + i];
+        if (i + 16 < P) pb = voxels[(size_t)m * P + i + 16];
+    }
+    float sx = pa.x + pb.x, sy = pa.y + pb.y, sz = pa.z + pb.z;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64);
+    }
+    const float fn = (float)np;
+    const float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    const float cxm = (float)cd.w * g.vx + g.xo, cym = (float)cd.z * g.vy + g.yo, czm = (float)cd.y * g.vz + g.zo;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = i + 16 * h;
+        const float4 pt = h ? pb : pa;
+        const float k = p < np ? 1.f : 0.f;
+        float4* dst = reinterpret_cast<float4*>(&sf[p][0]);
+        dst[0] = make_float4(pt.x * k, pt.y * k, pt.z * k, pt.w * k);
+        dst[1] = make_float4((pt.x - mx) * k, (pt.y - my) * k, (pt.z - mz) * k, (pt.x - cxm) * k);
+        dst[2] = make_float4((pt.y - cym) * k, (pt.z - czm) * k, 0.f, 0.f);
+    }
+    np_out = live_p ? np : 0;
+}
+
+__global__ __launch_bounds__(256) void k_pfn_moments(const float4* __restrict__ voxels, int P, const int4* __restrict__ coords,
+                                                    const int* __restrict__ num_points, int M, PfnGeom g,
+                                                    float* __restrict__ partials /*[gridDim.x][65]*/) {
+    __shared__ __attribute__((aligned(16))) float sfeat[4][4][32][PFN_FROW];
+    __shared__ float s_red[4][PFN_NMOM];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, i = l & 15;
+    float acc[PFN_NMOM];
+#pragma unroll
+    for (int k = 0; k < PFN_NMOM; ++k) acc[k] = 0.f;
+    const int stride = gridDim.x * 16;
+    for (int m0 = (blockIdx.x * 4 + wave) * 4; m0 < M; m0 += stride) {
+        int np;
+        pfn_stage4(voxels, P, coords, num_points, M, m0 + q, i, g, sfeat[wave][q], np);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = i + 16 * h;
+            if (p >= min(np, P)) continue;       // padding rows are zero rows: nothing to add
+            float f[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) f[k] = sfeat[wave][q][p][k];
+            int t = 10;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                acc[j] += f[j];
+#pragma unroll
+                for (int k = j; k < 10; ++k) { acc[t] = fmaf(f[j], f[k], acc[t]); ++t; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < PFN_NMOM; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (l == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PFN_NMOM)
+        partials[(size_t)blockIdx.x * PFN_NMOM + threadIdx.x] =
+            (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_pfn_backward(const float4* __restrict__ voxels, int P, const int4* __restrict__ coords,
+                                                     const int* __restrict__ num_points, int M,
+                                                     const float* __restrict__ weight /*[64][10]*/,
+                                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, PfnGeom g,
+                                                     const float* __restrict__ grad /*[M][64]*/,
+                                                     float* __restrict__ partials /*[gridDim.x][64][12]*/) {
+    __shared__ __attribute__((aligned(16))) float sfeat[4][4][32][PFN_FROW];
+    __shared__ float s_red[4][16][4 * PFN_BWD_ROW];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, i = l & 15;
+    float w[4][10], sc[4], sh[4], mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = i * 4 + j;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) w[j][k] = weight[c * 10 + k];
+        sc[j] = bn_scale[c]; sh[j] = bn_shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+    }
+    float acc[4][PFN_BWD_ROW];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < PFN_BWD_ROW; ++k) acc[j][k] = 0.f;
+    const int stride = gridDim.x * 16;
+    for (int m0 = (blockIdx.x * 4 + wave) * 4; m0 < M; m0 += stride) {
+        const int m = m0 + q;
+        int np;
+        pfn_stage4(voxels, P, coords, num_points, M, m, i, g, sfeat[wave][q], np);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (m < M) {
+            const int live_n = min(np, P);
+            float best[4], zb[4];
+            int pb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {      // the padding row (if any): z = 0, y = relu(shift), no features
+                best[j] = (np < P) ? fmaxf(sh[j], 0.f) : -1.f;   // (y >= 0: -1 loses against every row)
+                zb[j] = 0.f; pb[j] = -1;
+            }
+            for (int p = 0; p < live_n; ++p) {
+                const float4* src = reinterpret_cast<const float4*>(&sfeat[wave][q][p][0]);
+                const float4 a = src[0], b = src[1], c = src[2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float z = a.x * w[j][0];
+                    z = fmaf(a.y, w[j][1], z); z = fmaf(a.z, w[j][2], z); z = fmaf(a.w, w[j][3], z);
+                    z = fmaf(b.x, w[j][4], z); z = fmaf(b.y, w[j][5], z); z = fmaf(b.z, w[j][6], z);
+                    z = fmaf(b.w, w[j][7], z); z = fmaf(c.x, w[j][8], z); z = fmaf(c.y, w[j][9], z);
+                    const float y = fmaxf(fmaf(z, sc[j], sh[j]), 0.f);
+                    if (y > best[j]) { best[j] = y; zb[j] = z; pb[j] = p; }
+                }
+            }
+            const float4 gv = *reinterpret_cast<const float4*>(&grad[(size_t)m * PFN_C + i * 4]);
+            const float gj[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dy = best[j] > 0.f ? gj[j] : 0.f;
+                acc[j][10] += dy;
+                acc[j][11] = fmaf(dy, (zb[j] - mu[j]) * rs[j], acc[j][11]);
+                if (pb[j] >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) acc[j][k] = fmaf(dy, sfeat[wave][q][pb[j]][k], acc[j][k]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // add the four pillar slots of the wave (lanes i, i + 16, i + 32, i + 48 own the same channels), then the four waves
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < PFN_BWD_ROW; ++k) {
+            float v = acc[j][k];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) s_red[wave][i][j * PFN_BWD_ROW + k] = v;
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 4 * PFN_BWD_ROW; e += 256) {
+        const int ii = e / (4 * PFN_BWD_ROW), r = e - ii * (4 * PFN_BWD_ROW);
+        partials[(size_t)blockIdx.x * (PFN_C * PFN_BWD_ROW) + e] =
+            (s_red[0][ii][r] + s_red[1][ii][r]) + (s_red[2][ii][r] + s_red[3][ii][r]);
     }
 }
 
@@ -319,3 +497,56 @@ extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, cons
     }
     return heal_canvas_from_map(cell_map, pf, n_agents, channels, ny * nx, canvas, s);
 }
+
+static PfnGeom pfn_geom(float vx, float vy, float vz, float xo, float yo, float zo) {
+    PfnGeom g;
+    g.vx = vx; g.vy = vy; g.vz = vz; g.xo = xo; g.yo = yo; g.zo = zo;
+    g.n_agents = 0; g.ny = 0; g.nx = 0;
+    return g;
+}
+
+// blocks (= rows of the partial-sum outputs) heal_pfn_moments / heal_pfn_backward use for n_voxels pillars
+extern "C" int heal_pfn_train_blocks(int n_voxels) {
+    const int b = ceil_div(n_voxels < 1 ? 1 : n_voxels, 16);
+    return b < 1024 ? b : 1024;
+}
+
+extern "C" int heal_pfn_features(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
+                                 int max_points, const float* weight, const float* bn_scale, const float* bn_shift, float vx,
+                                 float vy, float vz, float x_offset, float y_offset, float z_offset, float* pillar_feat,
+                                 void* stream) {
+    HEAL_REQUIRE(max_points >= 1 && max_points <= 32, "pfn_features: max_points must be in [1,32]");
+    HEAL_REQUIRE(n_voxels >= 0 && pillar_feat, "pfn_features: bad arguments");
+    if (n_voxels == 0) return 0;
+    k_pfn4<<<min(ceil_div(n_voxels, 16), 256 * 16), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(voxels), max_points, reinterpret_cast<const int4*>(coords), num_points, n_voxels, nullptr,
+        weight, bn_scale, bn_shift, pfn_geom(vx, vy, vz, x_offset, y_offset, z_offset), pillar_feat, nullptr);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_pfn_moments(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
+                                int max_points, float vx, float vy, float vz, float x_offset, float y_offset, float z_offset,
+                                float* partials, void* stream) {
+    HEAL_REQUIRE(max_points >= 1 && max_points <= 32, "pfn_moments: max_points must be in [1,32]");
+    HEAL_REQUIRE(n_voxels >= 1 && partials, "pfn_moments: bad arguments");
+    k_pfn_moments<<<heal_pfn_train_blocks(n_voxels), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(voxels), max_points, reinterpret_cast<const int4*>(coords), num_points, n_voxels,
+        pfn_geom(vx, vy, vz, x_offset, y_offset, z_offset), partials);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_pfn_backward(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
+                                 int max_points, const float* weight, const float* bn_scale, const float* bn_shift,
+                                 const float* mean, const float* rstd, float vx, float vy, float vz, float x_offset,
+                                 float y_offset, float z_offset, const float* grad_pillar, float* partials, void* stream) {
+    HEAL_REQUIRE(max_points >= 1 && max_points <= 32, "pfn_backward: max_points must be in [1,32]");
+    HEAL_REQUIRE(n_voxels >= 1 && grad_pillar && partials && ((uintptr_t)grad_pillar & 15) == 0, "pfn_backward: bad arguments");
+    k_pfn_backward<<<heal_pfn_train_blocks(n_voxels), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(voxels), max_points, reinterpret_cast<const int4*>(coords), num_points, n_voxels, weight,
+        bn_scale, bn_shift, mean, rstd, pfn_geom(vx, vy, vz, x_offset, y_offset, z_offset), grad_pillar, partials);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+

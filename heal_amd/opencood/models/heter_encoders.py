@@ -77,8 +77,17 @@ class PointPillar(nn.Module):
             voxels, coords, num = inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"]
             # point_pillar_scatter.py:45 reads the batch size back from the device the same way
             n_agents = int(inp["n_agents"]) if "n_agents" in inp else int(coords[:, 0].max().item()) + 1
-        if grad:   # gradient path: the PFN and the scatter as torch operators on the same parameters
-            return self.scatter.canvas(self.pillar_vfe.pillar_features(voxels, coords, num), coords, n_agents)
+        if grad:   # gradient path: the scatter as a torch index operation; the PFN on its forward / backward kernels on the
+            # device (HEAL_K2_BACKWARD=0, the CPU and max_points > 32: Linear / BatchNorm1d / max as torch operators)
+            import os
+            pfn0 = self.pillar_vfe.pfn_layers[0]
+            if (voxels.is_cuda and ops.pfn_train_supported(voxels) and getattr(pfn0, "use_norm", True)
+                    and len(self.pillar_vfe.pfn_layers) == 1 and pfn0.linear.bias is None
+                    and os.environ.get("HEAL_K2_BACKWARD", "1") == "1"):
+                feats = self.pillar_vfe.pillar_features_kernels(voxels, coords, num)
+            else:
+                feats = self.pillar_vfe.pillar_features(voxels, coords, num)
+            return self.scatter.canvas(feats, coords, n_agents)
         if coords.dtype != torch.int32:
             coords = coords.to(torch.int32)
         if num.dtype != torch.int32:

@@ -77,3 +77,66 @@ class PillarVFE(nn.Module):
         if pfn.use_norm:
             h = pfn.norm(h.permute(0, 2, 1)).permute(0, 2, 1)
         return torch.relu(h).max(dim=1)[0]
+
+    def pillar_features_kernels(self, voxels, coords, num_points):
+        """pillar_features() on the HIP kernels in BOTH directions (round 3): batch statistics from
+        heal_pfn_moments, forward heal_pfn_features, backward heal_pfn_backward -- no [M,P,64] tensor in either direction.
+        Updates the BatchNorm running statistics like nn.BatchNorm1d does in training mode."""
+        pfn = self.pfn_layers[0]
+        bn = pfn.norm
+        return _PFNFunction.apply(pfn.linear.weight, bn.weight, bn.bias, voxels, coords, num_points, bn, bn.training,
+                                  tuple(self.voxel_size), tuple(self.point_cloud_range))
+
+
+class _PFNFunction(torch.autograd.Function):
+    """Linear(10 -> 64, no bias) -> BatchNorm1d -> ReLU -> max over the points of a pillar, forward and backward on the kernels of
+    heal_amd/csrc/pfn_scatter.hip.  With z = W f every statistic of the M x P rows is a closed form of s1 = sum f and
+    S = sum f f^T (float64 on the device): mean = W s1 / R, E[z^2] = diag(W S W^T) / R."""
+
+    @staticmethod
+    def forward(ctx, weight, gamma, beta, voxels, coords, num_points, bn, training, voxel_size, lidar_range):
+        from heal_amd import ops
+        voxels, coords, num_points = voxels.detach().contiguous(), coords.detach().int().contiguous(), num_points.detach().int().contiguous()
+        w = weight.detach().contiguous()
+        R = float(voxels.shape[0] * voxels.shape[1])
+        s1 = S = None
+        if training:
+            s1, S = ops.pfn_moments(voxels, coords, num_points, voxel_size, lidar_range)
+            w64 = w.double()
+            mean64 = (w64 @ s1) / R
+            var64 = (((w64 @ S) * w64).sum(1) / R - mean64 * mean64).clamp_min(0.0)      # biased, like BatchNorm's normaliser
+            with torch.no_grad():       # running statistics: momentum update with the UNBIASED variance (nn.BatchNorm1d)
+                if bn.track_running_stats and bn.running_mean is not None:
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    bn.running_mean.mul_(1.0 - mom).add_(mean64.float(), alpha=mom)
+                    bn.running_var.mul_(1.0 - mom).add_((var64 * (R / max(R - 1.0, 1.0))).float(), alpha=mom)
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+        else:
+            mean64, var64 = bn.running_mean.detach().double(), bn.running_var.detach().double()
+        rstd64 = torch.rsqrt(var64 + bn.eps)
+        scale = (gamma.detach().double() * rstd64).float().contiguous()
+        shift = (beta.detach().double() - mean64 * gamma.detach().double() * rstd64).float().contiguous()
+        out = ops.pfn_features(voxels, coords, num_points, w, scale, shift, voxel_size, lidar_range)
+        ctx.save_for_backward(w, gamma.detach(), voxels, coords, num_points, scale, shift, mean64, rstd64)
+        ctx.extra = (training, voxel_size, lidar_range, R, s1, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from heal_amd import ops
+        w, gamma, voxels, coords, num_points, scale, shift, mean64, rstd64 = ctx.saved_tensors
+        training, voxel_size, lidar_range, R, s1, S = ctx.extra
+        A, B, Cx = ops.pfn_backward(voxels, coords, num_points, w, scale, shift, mean64.float().contiguous(),
+                                    rstd64.float().contiguous(), voxel_size, lidar_range, g.contiguous())
+        g64 = gamma.double()
+        if training:
+            w64 = w.double()
+            xf = ((w64 @ S) - mean64[:, None] * s1[None, :]) * rstd64[:, None]      # sum_rows xhat_c f
+            dW = (g64 * rstd64)[:, None] * (A - (B / R)[:, None] * s1[None, :] - (Cx / R)[:, None] * xf)
+        else:
+            dW = (g64 * rstd64)[:, None] * A
+        need = ctx.needs_input_grad
+        return (dW.float() if need[0] else None, Cx.float() if need[1] else None, B.float() if need[2] else None,
+                None, None, None, None, None, None, None)
+

@@ -283,6 +283,65 @@ def pfn_scatter(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_si
     return canvas
 
 
+def _pfn_geom(voxel_size, lidar_range):
+    vx, vy, vz = (float(v) for v in voxel_size)
+    return vx, vy, vz, vx / 2 + lidar_range[0], vy / 2 + lidar_range[1], vz / 2 + lidar_range[2]
+
+
+def _pfn_inputs(voxels, coords, num_points):
+    voxels = _need(voxels, torch.float32, "voxels")
+    coords = _need(coords, torch.int32, "coords")
+    num_points = _need(num_points, torch.int32, "num_points")
+    if voxels.dim() != 3 or voxels.shape[2] != 4 or coords.shape[1] != 4 or int(voxels.shape[1]) > 32:
+        raise _capi.HealAmdError("pfn (training kernels): expected voxels [M,P<=32,4], coords [M,4]")
+    return voxels, coords, num_points
+
+
+def pfn_train_supported(voxels):
+    return voxels.is_cuda and voxels.dim() == 3 and 1 <= int(voxels.shape[1]) <= 32 and int(voxels.shape[0]) >= 1
+
+
+def pfn_moments(voxels, coords, num_points, voxel_size, lidar_range):
+    """-> (s1 [10], S [10,10]) float64: sums over all M x P rows of the decorated, masked point features f and of f f^T."""
+    voxels, coords, num_points = _pfn_inputs(voxels, coords, num_points)
+    M, P = int(voxels.shape[0]), int(voxels.shape[1])
+    nb = _capi.query("heal_pfn_train_blocks", M)
+    part = torch.empty((nb, 65), dtype=torch.float32, device=voxels.device)
+    _capi.call("heal_pfn_moments", _ptr(voxels), _ptr(coords), _ptr(num_points), M, P, *_pfn_geom(voxel_size, lidar_range),
+               _ptr(part), _stream())
+    tot = part.double().sum(0)
+    S = torch.zeros((10, 10), dtype=torch.float64, device=voxels.device)
+    iu = torch.triu_indices(10, 10, device=voxels.device)
+    S[iu[0], iu[1]] = tot[10:]
+    S = S + S.t() - torch.diag(torch.diag(S))
+    return tot[:10], S
+
+
+def pfn_features(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_size, lidar_range):
+    """Pillar features [M,64] = max over the points of relu(scale (W f) + shift): K2's first stage without the canvas."""
+    voxels, coords, num_points = _pfn_inputs(voxels, coords, num_points)
+    M, P = int(voxels.shape[0]), int(voxels.shape[1])
+    out = torch.empty((M, 64), dtype=torch.float32, device=voxels.device)
+    _capi.call("heal_pfn_features", _ptr(voxels), _ptr(coords), _ptr(num_points), M, P, _ptr(_need(weight, torch.float32, "weight")),
+               _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
+               *_pfn_geom(voxel_size, lidar_range), _ptr(out), _stream())
+    return out
+
+
+def pfn_backward(voxels, coords, num_points, weight, bn_scale, bn_shift, mean, rstd, voxel_size, lidar_range, grad_pillar):
+    """-> (A [64,10], B [64], Cx [64]) float64: sum dy f_{p*}, sum dy, sum dy xhat_{p*} over the pillars (include/heal_amd.h)."""
+    voxels, coords, num_points = _pfn_inputs(voxels, coords, num_points)
+    M, P = int(voxels.shape[0]), int(voxels.shape[1])
+    nb = _capi.query("heal_pfn_train_blocks", M)
+    part = torch.empty((nb, 64, 12), dtype=torch.float32, device=voxels.device)
+    _capi.call("heal_pfn_backward", _ptr(voxels), _ptr(coords), _ptr(num_points), M, P, _ptr(_need(weight, torch.float32, "weight")),
+               _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
+               _ptr(_need(mean, torch.float32, "mean")), _ptr(_need(rstd, torch.float32, "rstd")),
+               *_pfn_geom(voxel_size, lidar_range), _ptr(_need(grad_pillar, torch.float32, "grad_pillar")), _ptr(part), _stream())
+    tot = part.double().sum(0)
+    return tot[:, :10], tot[:, 10], tot[:, 11]
+
+
 def _affine_args(affine_rows, n):
     """-> (keep-alive object, host pointer, device pointer).  A CUDA tensor of affine rows stays on the device (no host
     round trip; a captured graph then reads the poses at replay time); anything else is passed by value from the host."""

@@ -210,6 +210,26 @@ int heal_bev_pool_pm(const float* head, int head_stride, const float* frustum, c
                      int n_cams, int D, int fH, int fW, int channels, const float* dx_host, const float* bx_host,
                      const int32_t* nx_host, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Training of the pillar feature net: PFNLayer in training mode (pillar_vfe.py:25-51: Linear(10 -> 64, no bias) ->
+ * BatchNorm1d over ALL M x P rows, zeroed padding rows included -> ReLU -> max over the points) and its backward.  max_points <= 32.
+ *   heal_pfn_train_blocks(n_voxels)  rows B of the partial-sum outputs below
+ *   heal_pfn_moments   partials [B][65]: per-block sums over the rows of the 10 decorated features and of their 55 products
+ *                      f_j f_k (j <= k, row-major upper triangle); with z = W f:  mean_c = W_c . s1 / R,  E[z_c^2] = W_c^T S W_c / R
+ *   heal_pfn_features  the forward for given scale / shift (batch or running statistics): pillar_feat [M][64], no canvas
+ *   heal_pfn_backward  grad_pillar [M][64] -> partials [B][64][12]: per channel A[0..10) = sum dy f_{p*}, B = sum dy,
+ *                      Cx = sum dy xhat_{p*} (p* = arg-max row of the forward, dy = grad where y* > 0); the caller forms
+ *                      dW, dgamma, dbeta from the block sums (heal_amd/opencood/models/sub_modules/pillar_vfe.py).          */
+int heal_pfn_train_blocks(int n_voxels);
+int heal_pfn_features(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels, int max_points,
+                      const float* weight, const float* bn_scale, const float* bn_shift, float vx, float vy, float vz,
+                      float x_offset, float y_offset, float z_offset, float* pillar_feat, void* stream);
+int heal_pfn_moments(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels, int max_points,
+                     float vx, float vy, float vz, float x_offset, float y_offset, float z_offset, float* partials, void* stream);
+int heal_pfn_backward(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels, int max_points,
+                      const float* weight, const float* bn_scale, const float* bn_shift, const float* mean, const float* rstd,
+                      float vx, float vy, float vz, float x_offset, float y_offset, float z_offset, const float* grad_pillar,
+                      float* partials, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  SECOND encoder: MeanVFE, sparse 3-D convolution (submanifold and strided), sparse -> dense BEV.
  * Replaces: opencood/models/sub_modules/mean_vfe.py:13-31; the spconv calls of

@@ -254,6 +254,50 @@ def test_second_gradient_path_equals_sparse_kernels(monkeypatch):
     assert int(((got != 0) != (ref != 0)).sum()) == 0
 
 
+@pytest.mark.parametrize("training,P", [(True, 32), (False, 32), (True, 5)])
+def test_pfn_forward_backward_kernels_vs_torch(training, P):
+    """K2's training path on the device (heal_pfn_moments / heal_pfn_features / heal_pfn_backward behind _PFNFunction): pillar
+    features, running-statistics update and the gradients of the Linear weight and the BatchNorm affine against the torch
+    composition it replaces (PillarVFE.pillar_features) -- evaluated on the CPU in FLOAT64 on the same pillars, so the reference
+    shares neither the device nor the precision with the kernels.  Batch statistics (training mode: all M x P rows, zeroed
+    padding rows included) and running statistics (eval mode with trainable parameters); pillars that are full, partly filled
+    and single-point."""
+    import copy
+    from heal_amd import ops, synth
+    from heal_amd.opencood.models.sub_modules.pillar_vfe import PillarVFE
+    pts = torch.from_numpy(synth.lidar_frame(5)).cuda()
+    R, V = [-102.4, -102.4, -3.5, 102.4, 102.4, 1.5], [0.4, 0.4, 5.0]
+    v, c, n = ops.voxelize(pts, R, V, P, 32000)
+    assert int((n == P).sum()) > 0 and int((n == 1).sum()) > 0 and int(((n > 1) & (n < P)).sum()) > 0
+    vfe = PillarVFE({"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]}, 4, V, R).cuda()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        vfe.pfn_layers[0].linear.weight.normal_(0, 0.5)
+        vfe.pfn_layers[0].norm.weight.uniform_(0.5, 1.5)
+        vfe.pfn_layers[0].norm.bias.normal_(0, 0.3)
+        vfe.pfn_layers[0].norm.running_mean.normal_(0, 0.5)
+        vfe.pfn_layers[0].norm.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(vfe).double().cpu()
+    vfe.train(training)
+    ref.train(training)
+    gout = torch.randn((v.shape[0], 64), generator=torch.Generator().manual_seed(1))
+    out = vfe.pillar_features_kernels(v, c, n)
+    (out * gout.cuda()).sum().backward()
+    want = ref.pillar_features(v.double().cpu(), c.cpu(), n.cpu())
+    (want * gout.double()).sum().backward()
+    scale = float(want.abs().max())
+    assert float((out.double().cpu() - want).abs().max()) / scale < 1e-5
+    for name in ("linear.weight", "norm.weight", "norm.bias"):
+        got = dict(vfe.pfn_layers[0].named_parameters())[name].grad.double().cpu()
+        exp = dict(ref.pfn_layers[0].named_parameters())[name].grad
+        err = float((got - exp).abs().max() / (exp.abs().max() + 1e-30))
+        assert err < 2e-4, (name, err)
+    bn, rbn = vfe.pfn_layers[0].norm, ref.pfn_layers[0].norm
+    assert float((bn.running_mean.double().cpu() - rbn.running_mean).abs().max()) < 1e-5
+    assert float((bn.running_var.double().cpu() - rbn.running_var).abs().max() / rbn.running_var.abs().max()) < 1e-5
+    assert int(bn.num_batches_tracked) == int(rbn.num_batches_tracked)
+
+
 def test_inference_operator_refuses_autograd_activations():
     """An activation with autograd history must never reach a HIP operator silently (its result would drop out of the graph)."""
     from heal_amd import _capi, ops
