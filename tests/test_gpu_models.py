@@ -304,15 +304,18 @@ def test_concurrent_modality_streams_equal_serial(monkeypatch):
 
     torch.cuda.synchronize()
 
-@pytest.mark.parametrize("mods", [["m1", "m1", "m1"], ["m1", "m2", "m4", "m1", "m1"]])
+@pytest.mark.parametrize("mods", [["m1", "m1", "m1"], ["m1", "m2", "m4", "m1", "m1"], ["m3", "m3", "m3"]])
 def test_frames_in_flight_equal_sequential_replay(mods):
     """pipeline.FramesInFlight (two captured copies of the step on two streams, frame k + 1 submitted while frame k runs) returns
     for every frame what the plain replay returns: bit-equal for LiDAR-only scenes (deterministic path), to the tolerance of the
     camera lift's fp32 atomics otherwise; over three rounds of four frames, results delivered in submission order."""
     from heal_amd import configs
     from heal_amd.pipeline import FramesInFlight, Scene, ScenePipeline
-    lidar = all(m == "m1" for m in mods)
-    hypes = configs.lidar_pyramid(max_cav=5) if lidar else configs.heal_heter()
+    lidar = all(m in ("m1", "m3") for m in mods)
+    if mods[0] == "m3":      # SECOND encoders (capacity-sized sparse layers, checked per slot) + V2X-ViT fusion: BASELINE config 5's path
+        hypes = configs.lidar_baseline("v2xvit", max_cav=len(mods), modality="m3")
+    else:
+        hypes = configs.lidar_pyramid(max_cav=5) if lidar else configs.heal_heter()
     frames = [Scene(len(mods), seed=40 + i, device="cuda:0", modalities=mods) for i in range(4)]
     side = torch.cuda.Stream()
     with torch.no_grad(), torch.cuda.stream(side):
