@@ -338,11 +338,13 @@ class FramesInFlight:
         with torch.cuda.stream(slot.stream):
             corners, scores, count = slot.out
             k = int(count.item())          # waits for this slot's stream only
+            # the slot's output buffers are overwritten by its next frame: copy on the SLOT's stream (ordered before that
+            # replay), then let the caller's stream wait for the copy
+            res = (None, None) if k == 0 else (corners[:k].clone(), scores[:k].clone())
+        torch.cuda.current_stream(self.pipe.device).wait_stream(slot.stream)
         if slot.checks:
             ops.verify_sparse_capacity(slot.checks)
-        if k == 0:
-            return None, None
-        return corners[:k].clone(), scores[:k].clone()    # the slot's output buffers are overwritten by its next frame
+        return res
 
     def step(self, scene):
         """Submit `scene`; returns the (boxes, scores) of the oldest frame in flight once the ring is full, else None."""

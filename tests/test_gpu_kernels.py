@@ -71,6 +71,36 @@ def test_voxelize_edge_cases():
         check_voxelize(rng.uniform(-4.5, 4.5, (n, 4)).astype(np.float32), R, V, 4, 50)
 
 
+@pytest.mark.parametrize("P", [1, 2, 3, 12, 32, 48, 64, 80, 200])
+def test_voxelize_every_group_size_and_long_segments(P):
+    """The selection stage of K1 at every lane-group size (G = 1, 2, 4, 16, 32, 64 lanes per voxel for max_points <= 64) and on
+    its max_points > 64 path (atomicMin cascade), with cells that hold far more points than max_points (the first P in INPUT
+    order must survive whatever order the atomics ran in), cells with exactly P, P - 1 and one point, interleaved over the cloud
+    so that a cell's points come from many different waves and blocks."""
+    rng = np.random.default_rng(100 + P)
+    R = [-4.0, -4.0, -3.0, 4.0, 4.0, 1.0]
+    V = [0.4, 0.4, 4.0]
+    dense = rng.uniform(0.0, 0.39, (5 * P + 700, 4))                                 # one cell, >> P points
+    dense2 = rng.uniform(0.0, 0.39, (3 * P + 64, 4)) + np.array([0.8, 0.0, 0.0, 0.0])  # another, > P
+    exact = rng.uniform(0.0, 0.39, (P, 4)) + np.array([-0.8, 0.4, 0.0, 0.0])          # exactly P
+    short = rng.uniform(0.0, 0.39, (max(P - 1, 1), 4)) + np.array([-1.6, -0.8, 0.0, 0.0])
+    spread = rng.uniform(-3.9, 3.9, (3000, 4))
+    pts = np.concatenate([dense, dense2, exact, short, spread]).astype(np.float32)
+    pts = pts[rng.permutation(pts.shape[0])]
+    assert check_voxelize(pts, R, V, P, 1000) > 300
+    check_voxelize(pts, R, V, P, 37)                                                  # voxel cap on top
+    from heal_amd import ops
+    got = ops.voxelize_collated([dev(pts), dev(pts[::2].copy())], R, V, P, 1000)       # the batched form shares the chain
+    m = [int(v) for v in got[3].cpu()]
+    for b, cloud in enumerate((pts, pts[::2].copy())):
+        ov, oc, on = cref.voxelize(cloud, R, V, P, 1000, batch_idx=b)
+        sl = slice(m[b], m[b + 1])
+        assert m[b + 1] - m[b] == ov.shape[0]
+        np.testing.assert_array_equal(got[0][sl].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+        np.testing.assert_array_equal(got[1][sl].cpu().numpy(), oc)
+        np.testing.assert_array_equal(got[2][sl].cpu().numpy(), on)
+
+
 def test_voxelize_round_trip_property():
     """Size-independent properties at full size: every in-range point lands in exactly the voxel of
     its cell, no voxel is empty, slots keep input order."""
