@@ -399,9 +399,16 @@ __global__ __launch_bounds__(256) void k_nms_reduce(NmsBufs nb, int top, int wor
     const int K = min(*nb.n_cand, top);
     const int W = (K + 63) / 64;
     // upper-triangular tiles only were written (k_nms_mask): copy those, zero the rest
-    for (int e = threadIdx.x; e < K * W; e += 256) {
-        const int r = e / W, c = e - r * W;
-        smask[e] = (c >= r / 64) ? nb.mask[(size_t)r * words + c] : 0ull;
+    for (int e0 = threadIdx.x; e0 < K * W; e0 += 256 * 8) {     // eight loads in flight per thread, then the eight LDS stores
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, r = e / W, c = e - r * W;
+            v[u] = (e < K * W && c >= r / 64) ? nb.mask[(size_t)r * words + c] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + 256 * u < K * W) smask[e0 + 256 * u] = v[u];
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
@@ -413,8 +420,12 @@ __global__ __launch_bounds__(256) void k_nms_reduce(NmsBufs nb, int top, int wor
         unsigned long long rem = __shfl(removed, blk, 64);
         unsigned long long alive = 0ull;
         const int cnt = min(64, K - blk * 64);
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
         for (int i = 0; i < cnt; ++i) {
-            const unsigned long long di = __shfl(diag, i, 64);
+            // row i of the diagonal tile: i is wave-uniform -> v_readlane (a few cycles) instead of a ds_bpermute round trip per
+            // step of this serial chain (1000 candidates: 132 -> see DESIGN 3)
+            const unsigned long long di = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
             if (!((rem >> i) & 1ull)) {
                 alive |= 1ull << i;
                 rem |= di;

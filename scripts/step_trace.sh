@@ -7,6 +7,6 @@ export TMPDIR=/tmp
 D=/tmp/step_trace_$W
 rm -rf $D
 HEAL_PARALLEL_MODALITIES=0 rocprofv3 --kernel-trace --output-format csv -d $D -- \
-    python bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    python bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > /dev/null 2>&1
 python scripts/step_kernels.py $D > $OUT
 wc -l $OUT
