@@ -237,13 +237,19 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         bts = float(sum(16 * int(scene.points[k].shape[0]) + 16 * m * P + 20 * m
                         for k, m in zip(sorted(scene.points), m_per_agent)))
         entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: one memset + five kernels)", "hbm",
-                                                 bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
+                                                 bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
+                                                 pmc_traffic(a.workload, "heal::k_voxb_insert", "heal::k_vox_tile_sums", "heal::k_vox_assign",
+                                                             "heal::k_vox_fill", "heal::k_vox_select_write"),   # (+ one memset: not a kernel)
+                                                 bytes_per_launch=bts))
     if "decode_nms" in timing:
         calls, mean_ms = timing["decode_nms"]
         hw = 256 * 256 if a.workload != "scene8_second_v2xvit" else 128 * 128
         bts = 4.0 * 20 * hw
         entries["k8"] = (calls * mean_ms, _entry("K8 heal_decode_nms (decode + filters + rotated NMS; latency-bound)", "hbm",
-                                                 bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms, None, bytes_per_launch=bts))
+                                                 bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
+                                                 pmc_traffic(a.workload, "heal::k_decode_key", "heal::k_topk_sort", "heal::k_nms_prepare",
+                                                             "heal::k_nms_mask", "heal::k_nms_reduce"),
+                                                 bytes_per_launch=bts))
     # K3: per sparse layer N_in / N_out / R, bytes = 4 (N_in C_in + N_out C_out) + 4 K C_in C_out + 8 R, flops = 2 R C_in C_out
     if sp_trace:
         layers, tot_ms, tot_b, tot_f = [], 0.0, 0.0, 0.0
