@@ -61,6 +61,8 @@ _SIGNATURES = {
     "heal_sp_sort_workspace": (c_size_t, [c_int]),
     "heal_sp_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                                    c_void_p]),
+    "heal_sp_wgrad_chunks": (c_int, [c_int]),
+    "heal_sp_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_table_capacity": (c_size_t, [c_int]),
     "heal_sp_hash_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -798,6 +798,97 @@ __global__ __launch_bounds__(256) void k_sp_nbr_rank(const int4* __restrict__ ou
     }
 }
 
+// ---- weight gradient of the sparse convolution (training) --------------------------------------------------------
+//   dW[tap][ci][co] = sum over the rule pairs (i, o) of that tap of  x[i][ci] * g[o][co]
+// One block per (chunk of SPW_CHUNK output rows, tap): the chunk's valid pairs of the tap are compacted into LDS (ballot + prefix
+// count, in row order: the sum order is fixed), then taken 32 at a time: the paired rows of x and g are gathered into LDS and
+// multiplied on v_mfma_f32_16x16x4_f32 with the PAIR index as the reduction dimension (A = x^T: lane (ci, pair), B = g: lane
+// (pair, co); both read conflict-free along the channels).  A wave owns up to four of the ceil(Cin/16) x (Cout/16) output tiles.
+// Every block writes its [Cin][Cout] partial sum; the caller adds the chunks (torch.sum: fixed order -> deterministic).
+constexpr int SPW_CHUNK = 2048;     // output rows per block
+constexpr int SPW_PAIRS = 32;       // pairs per MFMA stage
+
+__global__ __launch_bounds__(256) void k_sp_wgrad(const float* __restrict__ x, const float* __restrict__ g,
+                                                 const int* __restrict__ nbr, int n_out, const int* __restrict__ n_dev, int K,
+                                                 int cin, int cout, float* __restrict__ partials /*[chunks][K][cin][cout]*/) {
+    __shared__ int s_in[SPW_CHUNK], s_out[SPW_CHUNK];
+    __shared__ int s_wcnt[4], s_total;
+    __shared__ __attribute__((aligned(16))) float sX[SPW_PAIRS][64 + 16], sG[SPW_PAIRS][64 + 16];   // row stride 80: the two k-rows of a 32-lane read phase fall in disjoint banks
+    const int chunk = blockIdx.x, tap = blockIdx.y;
+    const int live = live_rows(n_dev, n_out);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, ln = lane & 15;
+    // 1. compaction of the chunk's pairs of this tap, in row order
+    int base = 0;
+    for (int r0 = 0; r0 < SPW_CHUNK; r0 += 256) {
+        const int o = chunk * SPW_CHUNK + r0 + (int)threadIdx.x;
+        const int i = o < live ? nbr[(size_t)o * K + tap] : -1;
+        const unsigned long long bal = __ballot(i >= 0);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base + __popcll(bal & lanemask_lt());
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        if (i >= 0) { s_in[off] = i; s_out[off] = o; }
+        base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    const int n_pairs = base;
+    // 2. tiles of this wave: tile id = mt * nct + nt over ceil(cin/16) x (cout/16); ids wave, wave + 4, ...
+    const int mct = (cin + 15) / 16, nct = cout / 16, n_tiles = mct * nct;
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xq = cin / 4 > 0 ? (cin + 3) / 4 : 1, gq = cout / 4;     // 16-B pieces per row
+    for (int p0 = 0; p0 < n_pairs; p0 += SPW_PAIRS) {
+        // gather 32 rows of x and of g (zero rows past the end: they add nothing)
+        for (int e = threadIdx.x; e < SPW_PAIRS * 16; e += 256) {
+            const int p = e >> 4, q = e & 15;
+            const bool ok = p0 + p < n_pairs;
+            if (q < xq) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const float* src = x + (size_t)s_in[p0 + p] * cin + q * 4;
+                    if (cin % 4 == 0) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (q * 4 + 1 < cin) v.y = src[1]; if (q * 4 + 2 < cin) v.z = src[2]; if (q * 4 + 3 < cin) v.w = src[3]; }
+                }
+                *reinterpret_cast<float4*>(&sX[p][q * 4]) = v;
+            }
+            if (q < gq) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = *reinterpret_cast<const float4*>(g + (size_t)s_out[p0 + p] * cout + q * 4);
+                *reinterpret_cast<float4*>(&sG[p][q * 4]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = wave + 4 * q;
+            if (tile >= n_tiles) continue;
+            const int mt = tile / nct, nt = tile - mt * nct;
+            const bool a_ok = mt * 16 + ln < cin;
+#pragma unroll
+            for (int ks = 0; ks < SPW_PAIRS / 4; ++ks) {
+                const float a = a_ok ? sX[ks * 4 + lk][mt * 16 + ln] : 0.f;
+                const float b = sG[ks * 4 + lk][nt * 16 + ln];
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // 3. partial sums: D[row = lk*4 + r (ci)][col = ln (co)]
+    float* dst = partials + ((size_t)chunk * K + tap) * cin * cout;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tile = wave + 4 * q;
+        if (tile >= n_tiles) continue;
+        const int mt = tile / nct, nt = tile - mt * nct;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = mt * 16 + lk * 4 + r;
+            if (ci < cin) dst[(size_t)ci * cout + nt * 16 + ln] = acc[q][r];
+        }
+    }
+}
+
 // transposed rulebook for the backward pass: nbr_t[i][tap] = the output site that input site i feeds through `tap` (a given
 // (input, tap) pair feeds exactly one output), -1 where there is none.  nbr_t must be pre-filled with -1.
 __global__ __launch_bounds__(256) void k_sp_nbr_transpose(const int* __restrict__ nbr, int out_cap, const int* __restrict__ n_dev,
@@ -1129,6 +1220,22 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
     HEAL_SP_CASE(64, 64) HEAL_SP_CASE(64, 128) HEAL_SP_CASE(8, 16) HEAL_SP_CASE(64, 16)
 #undef HEAL_SP_CASE
     return set_error("sp_conv: channel combination %d -> %d is not instantiated", c_in, c_out);
+}
+
+// Weight gradient of a sparse convolution: partials [heal_sp_wgrad_chunks(n_out)][K][Cin][Cout] (the caller sums over the chunks).
+extern "C" int heal_sp_wgrad_chunks(int n_out) { return ceil_div(n_out < 1 ? 1 : n_out, SPW_CHUNK); }
+
+extern "C" int heal_sp_wgrad(const float* feat_in, const float* grad_out, const int32_t* nbr, int n_out, int kernel_volume,
+                             int c_in, int c_out, const int32_t* n_out_dev, float* partials, void* stream) {
+    HEAL_REQUIRE(n_out >= 1 && kernel_volume >= 1 && kernel_volume <= 27, "sp_wgrad: bad sizes");
+    HEAL_REQUIRE(c_in >= 1 && c_in <= 64 && c_out >= 16 && c_out <= 64 && c_out % 16 == 0,
+                 "sp_wgrad: channels %d -> %d not supported (Cin <= 64, Cout in {16, 32, 48, 64})", c_in, c_out);
+    HEAL_REQUIRE(feat_in && grad_out && nbr && partials, "sp_wgrad: null pointer");
+    HEAL_REQUIRE((((uintptr_t)grad_out | (uintptr_t)feat_in) & 15) == 0, "sp_wgrad: 16-B alignment");
+    k_sp_wgrad<<<dim3(heal_sp_wgrad_chunks(n_out), kernel_volume), 256, 0, (hipStream_t)stream>>>(
+        feat_in, grad_out, nbr, n_out, n_out_dev, kernel_volume, c_in, c_out, partials);
+    HEAL_LAUNCH_CHECK();
+    return 0;
 }
 
 // weight [K][CIN][COUT] -> the B-fragment order of k_sp_conv2 (same size).  CIN >= 16: [tap][nb][j][lane = 16 g + ln][i] =

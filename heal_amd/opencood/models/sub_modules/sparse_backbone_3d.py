@@ -66,13 +66,16 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:   # d x[i] = sum_tap W[tap] g[nbr_t[i][tap]]: the same kernel, roles swapped
             nbr_t = ops.sp_transpose_neighbors(nbr, feats.shape[0])
             gf = ops.sp_conv_raw(g, nbr_t, weight.detach().transpose(1, 2).contiguous())
-        if ctx.needs_input_grad[1]:   # d W[tap] = X_pairs^T G_pairs: gather the paired rows, one matrix product per tap
-            gw = torch.zeros_like(weight)
-            x = feats.detach()
-            for t in range(weight.shape[0]):
-                o = (nbr[:, t] >= 0).nonzero(as_tuple=True)[0]
-                if o.numel():
-                    gw[t] = x.index_select(0, nbr[o, t].long()).t() @ g.index_select(0, o)
+        if ctx.needs_input_grad[1]:   # d W[tap] = X_pairs^T G_pairs
+            x = feats.detach().contiguous()
+            if ops.sp_wgrad_supported(int(weight.shape[1]), int(weight.shape[2])) and os.environ.get("HEAL_SP_WGRAD", "1") == "1":
+                gw = ops.sp_wgrad(x, g, nbr)          # heal_sp_wgrad: pair-compacted gather + MFMA over the pair index
+            else:   # gather the paired rows, one matrix product per tap
+                gw = torch.zeros_like(weight)
+                for t in range(weight.shape[0]):
+                    o = (nbr[:, t] >= 0).nonzero(as_tuple=True)[0]
+                    if o.numel():
+                        gw[t] = x.index_select(0, nbr[o, t].long()).t() @ g.index_select(0, o)
         return gf, gw, None
 
 

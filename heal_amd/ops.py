@@ -920,6 +920,25 @@ def sp_conv_raw(features, nbr, weight):
     return out
 
 
+def sp_wgrad_supported(cin, cout):
+    return 1 <= cin <= 64 and cout in (16, 32, 48, 64)
+
+
+def sp_wgrad(features, grad_out, nbr):
+    """Weight gradient of the bare sparse convolution: dW[tap] = sum over the rule pairs of x[i]^T g[o] -> [K, Cin, Cout]."""
+    features = _need(features, torch.float32, "features")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    nbr = _need(nbr, torch.int32, "nbr")
+    n_out, K = (int(v) for v in nbr.shape)
+    cin, cout = int(features.shape[1]), int(grad_out.shape[1])
+    if n_out == 0:
+        return torch.zeros((K, cin, cout), dtype=torch.float32, device=features.device)
+    chunks = _capi.query("heal_sp_wgrad_chunks", n_out)
+    part = torch.empty((chunks, K, cin, cout), dtype=torch.float32, device=features.device)
+    _capi.call("heal_sp_wgrad", _ptr(features), _ptr(grad_out), _ptr(nbr), n_out, K, cin, cout, None, _ptr(part), _stream())
+    return part.sum(0)
+
+
 def sp_transpose_neighbors(nbr, n_in):
     """nbr [n_out, K] -> nbr_t [n_in, K]: nbr_t[i][tap] = o where nbr[o][tap] = i (else -1): the rulebook of the backward pass."""
     nbr = _need(nbr, torch.int32, "nbr")

@@ -295,6 +295,13 @@ int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t*
  * no ReLU): a sparse backward -- no dense grid anywhere.                                                    */
 int heal_sp_transpose_neighbors(const int32_t* nbr, int n_out, int kernel_volume, int n_in, int32_t* nbr_t,
                                 const int32_t* n_out_dev, void* stream);
+/* heal_sp_wgrad: weight gradient of a sparse convolution (spconv's indice_conv_backward, filter part):
+ *   dW[tap][ci][co] = sum over the pairs (i = nbr[o][tap] >= 0, o) of feat_in[i][ci] * grad_out[o][co].
+ *   partials [heal_sp_wgrad_chunks(n_out)][K][Cin][Cout]: one partial sum per 2048 output rows; the caller adds them (fixed
+ *   order: deterministic).  Cin <= 64, Cout in {16, 32, 48, 64}.                                                            */
+int heal_sp_wgrad_chunks(int n_out);
+int heal_sp_wgrad(const float* feat_in, const float* grad_out, const int32_t* nbr, int n_out, int kernel_volume, int c_in,
+                  int c_out, const int32_t* n_out_dev, float* partials, void* stream);
 /* feat_out[o] = act(bn_scale * sum_tap W[tap]^T feat_in[nbr[o][tap]] + bn_shift); weight [K,Cin,Cout]
  * (spconv 1.2.1 layout [kz,ky,kx,Cin,Cout]); fp32 MFMA, fixed summation order (bit-reproducible).
  * weight_frag: the same weights re-laid once by heal_sp_weight_fragments (same element count) -- selects the
