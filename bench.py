@@ -374,6 +374,7 @@ def main():
         return f
 
     use_graph = False
+    ring = None          # pipeline.FramesInFlight when more than one frame is in flight
     if solo:
         def step():
             return pipe.step(next_frame())
@@ -445,7 +446,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    ring = locals().get("ring")
     latency_ms = None
     if ring is not None:      # latency of ONE frame through the captured step (the ring changes the rate, not this)
         pipe.replay(next_frame())
