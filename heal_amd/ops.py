@@ -1311,6 +1311,37 @@ def conv3x3_winograd_fragments(w, waves=8):
     return hit[0]
 
 
+def conv3x3_winograd4_fragments(w):
+    """Cached F(4x4,3x3) Winograd-domain weights U = G g G^T (6 x 6 per filter, formed in float64) of a [Cout,Cin,3,3] filter bank
+    in the lane-major order heal_conv3x3_winograd4 reads: [Cout/32][Cin/16][wave 8][lane 64][xi_i 9][ks 4], value
+    U[xi = 9 (wave & 3) + xi_i][co = 32 mb + 16 (wave >> 2) + (lane & 15)][ci = 16 chunk + 4 ks + (lane >> 4)], zero-padded."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), "f4")
+    hit = _FRAGW_CACHE.get(key)
+    if hit is None:
+        if len(_FRAGW_CACHE) > 512:
+            _FRAGW_CACHE.clear()
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        mpad, kpad = (cout + 31) // 32 * 32, (cin + 15) // 16 * 16
+        G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                          [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64, device=w.device)
+        U = (G @ w.detach().double() @ G.t()).float().reshape(cout, cin, 36)      # xi = 6 a + b
+        if (mpad, kpad) != (cout, cin):
+            U = torch.nn.functional.pad(U, (0, 0, 0, kpad - cin, 0, mpad - cout))
+        # [mb, mt, ln, chunk, ks, lk, g, xi_i] -> [mb, chunk, mt, g, lk, ln, xi_i, ks]   (wave = 4 mt + g, lane = 16 lk + ln)
+        f = U.reshape(mpad // 32, 2, 16, kpad // 16, 4, 4, 4, 9).permute(0, 3, 1, 6, 5, 2, 7, 4).contiguous()
+        hit = (f, w)
+        _FRAGW_CACHE[key] = hit
+    return hit[0]
+
+
+def conv3x3_winograd4_ok(n, cout, H, W):
+    """F(4x4,3x3) (heal_conv3x3_winograd4) is OPT-IN: HEAL_C3_ALGO=winograd4.  Measured 0.80 - 1.03x of F(2x2,3x3) at the scenes'
+    shapes (profiles/r03_wino_f44_vs_f22.json): a quarter of the multiplications instead of 4/9, but twice the transform work per
+    output at 32 output channels per block."""
+    import os
+    return os.environ.get("HEAL_C3_ALGO", "") == "winograd4"
+
+
 def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
     """'winograd' | 'direct' for a shape; HEAL_C3_ALGO overrides for A/B.  Winograd F(2x2,3x3) is the stride-1 formulation
     and runs one 8-wave block per CU on a 16x16-pixel x 64-channel tile: below ~one block per CU the implicit GEMM with its
@@ -1319,7 +1350,7 @@ def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
     a = os.environ.get("HEAL_C3_ALGO", "")
     if stride != 1 or a == "direct":
         return "direct"
-    if a == "winograd":
+    if a in ("winograd", "winograd4"):
         return "winograd"
     blocks = n * ((cout + 63) // 64) * ((H + 15) // 16) * ((W + 15) // 16)
     return "winograd" if blocks >= 96 else "direct"
@@ -1373,6 +1404,12 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
             raise _capi.HealAmdError("conv3x3: residual shape mismatch")
     if bias is not None:
         bias = _need(bias, torch.float32, "bias")
+    if stride == 1 and conv3x3_winograd4_ok(n, cout, H, W):
+        frag = conv3x3_winograd4_fragments(w)
+        with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
+            _capi.call("heal_conv3x3_winograd4", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
+                       int(bool(relu)), _ptr(y), _stream())
+        return y
     if conv3x3_algo(stride, n, cout, H, W) == "winograd":
         waves = conv3x3_winograd_waves(n, cout, H, W)
         frag = conv3x3_winograd_fragments(w, waves)

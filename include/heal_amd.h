@@ -495,6 +495,13 @@ int heal_grouped_small_conv3x3(const float* x, const float* weight_q, const floa
 int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
                           int cout, int H, int W, int relu, int waves, float* y, void* stream);
 
+/* heal_conv3x3_winograd4: the same operator with the F(4x4,3x3) transform (36 positions, 6x6 input windows, 4x4 output tiles:
+ *   1/4 of the direct multiplications; csrc/conv3x3_wino4.hip).  u_frag: U = G g G^T in the lane-major order
+ *   [ceil(Cout/32)][ceil(Cin/16)][wave 8][lane 64][xi_i 9][ks 4] (heal_amd.ops.conv3x3_winograd4_fragments).  fp32; ~2e-5 of
+ *   the output scale against float64 in the worst case measured (F(2x2,3x3): ~1e-6).                                          */
+int heal_conv3x3_winograd4(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
+                           int cout, int H, int W, int relu, float* y, void* stream);
+
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265
  * (boxes_overlap_kernel, boxes_iou_bev_kernel), :267-375 (nms_kernel, nms_normal_kernel) and the host mask walk of

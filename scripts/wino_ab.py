@@ -1,4 +1,4 @@
-"""Winograd 3x3: pipelined kernel (HEAL_WINO_PIPE=1, default) vs the two-phase kernel (=0) at the stride-1 shapes of the two
+"""Winograd 3x3: F(4x4,3x3) (heal_conv3x3_winograd4) vs F(2x2,3x3) (heal_conv3x3_winograd) at the stride-1 shapes of the two
 BASELINE scenes.  HIP events, median.    python scripts/wino_ab.py [--json out.json]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,14 +32,16 @@ def main():
         b = torch.randn((cout,), device="cuda")
         r = torch.randn((n, cout, H, W), device="cuda") if res else None
         row = {}
-        for pipe in ("0", "1"):
-            os.environ["HEAL_WINO_PIPE"] = pipe
-            row["two_phase_us" if pipe == "0" else "pipelined_us"] = round(timed(lambda: ops.conv3x3(x, w, b, r, True, 1)), 1)
+        outs = {}
+        for algo in ("winograd", "winograd4"):
+            os.environ["HEAL_C3_ALGO"] = algo
+            row["f22_us" if algo == "winograd" else "f44_us"] = round(timed(lambda: ops.conv3x3(x, w, b, r, True, 1)), 1)
+            outs[algo] = ops.conv3x3(x, w, b, r, True, 1)
         flops = 2.0 * 9 * cin * cout * H * W * n
-        row["pipelined_direct_equiv_TFLOPs"] = round(flops / row["pipelined_us"] * 1e-6, 1)
-        row["executed_TFLOPs"] = round(flops / 2.25 / row["pipelined_us"] * 1e-6, 1)
-        row["speedup"] = round(row["two_phase_us"] / row["pipelined_us"], 3)
-        row["waves"] = ops.conv3x3_winograd_waves(n, cout, H, W)
+        row["f44_direct_equiv_TFLOPs"] = round(flops / row["f44_us"] * 1e-6, 1)
+        row["f44_executed_TFLOPs"] = round(flops / 4.0 / row["f44_us"] * 1e-6, 1)
+        row["speedup"] = round(row["f22_us"] / row["f44_us"], 3)
+        row["max_rel_diff"] = float((outs["winograd4"] - outs["winograd"]).abs().max() / outs["winograd"].abs().max())
         out[name] = row
         print(name, json.dumps(row), flush=True)
     if "--json" in sys.argv:
