@@ -528,7 +528,7 @@ def main():
                                                                    + (" (fp16 wire)" if os.environ.get("HEAL_WIRE") == "fp16" else "")),
                        "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if solo
                                   else "hipGraph(local stage) -> all-gather -> hipGraph(fusion tail + decode/NMS)"),
-                       "frames_in_flight": (len(ring.slots) if ring is not None else 1),
+                       "frames_in_flight": (ring.depth if ring is not None else 1),
                        "frame_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
                        "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
             "roofline": roof, "roofline_other": roof_other, "op_timing_ms": kernels,
