@@ -174,10 +174,13 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
         }
     }
     agent_softmax(prob, NA);
+    unsigned live = 0;       // bit a: some lane of this wave samples agent a inside its map (else every tap weight is zero)
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) wt[a][k] *= prob[a];
+        const bool any = (wt[a][0] != 0.f) | (wt[a][1] != 0.f) | (wt[a][2] != 0.f) | (wt[a][3] != 0.f);
+        live |= __ballot(any) ? (1u << a) : 0u;
     }
     const int c0 = bk.z * CCH;
     const int pix = h * p.W + w;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
         for (int u = 0; u < U; ++u) acc[u] = 0.f;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            {
+            if ((live >> a) & 1u) {   // wave-uniform: an agent whose map does not reach this tile costs no loads
                 const float* base = feats + ((size_t)a * p.C + c) * HW;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
