@@ -107,11 +107,12 @@ class _PFNFunction(torch.autograd.Function):
             var64 = (((w64 @ S) * w64).sum(1) / R - mean64 * mean64).clamp_min(0.0)      # biased, like BatchNorm's normaliser
             with torch.no_grad():       # running statistics: momentum update with the UNBIASED variance (nn.BatchNorm1d)
                 if bn.track_running_stats and bn.running_mean is not None:
-                    mom = bn.momentum if bn.momentum is not None else 0.1
-                    bn.running_mean.mul_(1.0 - mom).add_(mean64.float(), alpha=mom)
-                    bn.running_var.mul_(1.0 - mom).add_((var64 * (R / max(R - 1.0, 1.0))).float(), alpha=mom)
                     if bn.num_batches_tracked is not None:
                         bn.num_batches_tracked.add_(1)
+                    # momentum None = cumulative moving average (nn.BatchNorm1d: factor 1 / num_batches_tracked)
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(max(int(bn.num_batches_tracked), 1))
+                    bn.running_mean.mul_(1.0 - mom).add_(mean64.float(), alpha=mom)
+                    bn.running_var.mul_(1.0 - mom).add_((var64 * (R / max(R - 1.0, 1.0))).float(), alpha=mom)
         else:
             mean64, var64 = bn.running_mean.detach().double(), bn.running_var.detach().double()
         rstd64 = torch.rsqrt(var64 + bn.eps)
