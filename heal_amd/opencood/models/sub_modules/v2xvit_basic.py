@@ -187,6 +187,32 @@ class HGTCavAttention(nn.Module):
         return ops.linear(out, a.weight, a.bias, residual=x.reshape(-1, C)).view(L, H, W, C)
 
 
+    def fused_residual_ego(self, x, norm):
+        """fused_residual(x, norm)[:1] without computing the other agents' rows: keys / values of every agent (a 256 -> 512
+        heal_linear over all tokens), queries of the ego agent only (its H W tokens are the first rows of the agent-major
+        tensor), the ego row of the per-pixel agent attention, a_linear + x on the ego tokens.  Used by V2XTEncoder for the last
+        block, whose other agents' outputs nobody reads (V2XTransformer returns agent 0).  -> [1,H,W,C], or None when the shape
+        is not supported by the fused kernels (the caller then computes every agent)."""
+        L, H, W, C = x.shape
+        inner = self.heads * self.dim_head
+        if inner != 256 or not ops.linear_supported(1, C, 3 * inner):
+            return None
+        w, b = self._folded_qkv()                                        # [C, 3 inner], [3 inner]: (q W_att | k | v W_msg)
+        wq, bq = self._f.get([w, b, norm.weight, norm.bias], lambda: _fold_ln(w.t().contiguous(), b, norm))
+        if getattr(self, "_fe", None) is None:
+            self._fe = _Folded()
+        w_q, b_q, w_kv, b_kv = self._fe.get([wq, bq], lambda: (wq[:inner].contiguous(), bq[:inner].contiguous(),
+                                                                wq[inner:].contiguous(), bq[inner:].contiguous()))
+        n_pix = H * W
+        stats = ops.ln_stats(x, norm.eps)
+        kv = ops.linear(x, w_kv, b_kv, stats=stats, parts=2).view(2, L, n_pix, inner)
+        q = torch.empty((L, n_pix, inner), dtype=torch.float32, device=x.device)     # only agent 0's rows are written and read
+        ops.linear(x[0], w_q, b_q, stats=stats[:n_pix], out=q[0])
+        out = ops.agent_attention(q, kv[0], kv[1], self.heads, self.scale, out_rows=1, agent_major=True)   # [1, HW, inner]
+        a = self.a_linears[0]
+        return ops.linear(out, a.weight, a.bias, residual=x[0].reshape(-1, C)).view(1, H, W, C)
+
+
 def _relative_indices(ws):
     idx = torch.tensor([[x, y] for x in range(ws) for y in range(ws)])
     return idx[None, :, :] - idx[:, None, :] + ws - 1
@@ -400,12 +426,37 @@ class V2XTEncoder(nn.Module):
                 PreNorm(cav["dim"], FeedForward(cav["dim"], feed["mlp_dim"], dropout=feed["dropout"]))]))
 
     def forward(self, x):
+        """x [L,H,W,C] -> [L,H,W,C]; on the fused inference path [1,H,W,C]: the ego agent's rows only (see below)."""
         if self.use_RTE:
             x = self.rte(x)
-        for attn, ff in self.layers:
+        for li, (attn, ff) in enumerate(self.layers):
+            if li == len(self.layers) - 1 and x.shape[0] > 1 and _fused_ok(x, self) and os.environ.get("HEAL_V2XVIT_EGO_TAIL", "1") == "1":
+                ego = self._ego_tail(attn, ff, x)
+                if ego is not None:
+                    return ego
             x = attn(x)
             x = ff.residual(x)
         return x
+
+    def _ego_tail(self, block, ff, x):
+        """The last block, for the rows that are read.  V2XTransformer returns agent 0 of the encoder's output, and after the last
+        agent attention nothing mixes agents any more (window attention, split attention and the feed-forward are per agent):
+        the other agents' rows of that attention's output, of the window attention and of the feed-forward are never read.  The
+        reference computes and discards them (v2xvit_basic.py:183-191); here the last agent attention takes queries from the ego
+        agent only (keys / values from everyone) and what follows runs on the ego agent's H x W tokens: the same values for the
+        rows that exist (tests/test_gpu_kernels.py::test_v2xvit_ego_tail_equals_full), 1/L of the work."""
+        pairs = list(block.layers)
+        for cav, pw in pairs[:-1]:
+            x = cav.residual(x)
+            x = pw.residual(x)
+        cav, pw = pairs[-1]
+        if not hasattr(cav.fn, "fused_residual_ego"):
+            return None
+        x0 = cav.fn.fused_residual_ego(x, cav.norm)
+        if x0 is None:
+            return None
+        x0 = pw.residual(x0)
+        return ff.residual(x0)
 
 
 class V2XTransformer(nn.Module):

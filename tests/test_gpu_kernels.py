@@ -1268,6 +1268,29 @@ def test_v2xvit_fused_path_equals_library_path(monkeypatch):
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("L", [2, 5, 8])
+def test_v2xvit_ego_tail_equals_full(monkeypatch, L):
+    """The last V2X-ViT block computed for the ego agent's rows only (V2XTEncoder._ego_tail: queries of agent 0, keys / values of
+    every agent, window attention / split attention / feed-forward on agent 0's tokens) returns for the fused map what the
+    full computation returns -- the other agents' rows of the last block are never read (V2XTransformer returns agent 0).  The
+    rows that are computed go through the same kernels in the same order: bit-identical."""
+    from heal_amd import configs
+    from heal_amd.opencood.models.sub_modules.v2xvit_basic import V2XTransformer
+    from tests.golden.detfill import fill_module
+    m = fill_module(V2XTransformer(configs._v2xvit_args()["transformer"])).cuda().eval()
+    x = dev(np.random.default_rng(10 + L).standard_normal((L, 32, 48, 256)).astype(np.float32))
+    with torch.no_grad():
+        monkeypatch.setenv("HEAL_V2XVIT_EGO_TAIL", "0")
+        full = m(x)
+        monkeypatch.setenv("HEAL_V2XVIT_EGO_TAIL", "1")
+        ego = m(x)
+        assert full.shape == ego.shape == (32, 48, 256)
+        assert torch.equal(full, ego)
+        monkeypatch.setenv("HEAL_V2XVIT_FUSED", "0")          # and against the library composition (reference-pinned)
+        ref = m(x)
+    assert float((ego - ref).abs().max() / ref.abs().max()) < 2e-4
+
+
 def test_rank_rulebook_equals_hash_rulebook(monkeypatch):
     """Strided output sites and neighbour rows through the rank structure (bitmap + prefix counts) = the hash + sort path,
     bit for bit, including the capacity-sized / device-count mode and sites dropped beyond a capacity."""
