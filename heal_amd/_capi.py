@@ -50,6 +50,9 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "heal_bev_pool_pm_workspace": (c_size_t, [c_int] * 5),
     "heal_bev_pool_pm": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "heal_bev_pool_scatter": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "heal_bev_pool_emit": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_bev_stem_block": (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "heal_pfn_train_blocks": (c_int, [c_int]),
     "heal_pfn_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
@@ -137,6 +140,13 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(heal_[a-z0-9_]+)\s*\(", text)))
 
 
+def abi_version_of_header():
+    m = re.search(r"#define\s+HEAL_AMD_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    if not m:
+        raise HealAmdError(f"{HEADER} does not define HEAL_AMD_ABI_VERSION")
+    return int(m.group(1))
+
+
 def lib():
     """Load libheal_amd.so (raises if it has not been built: python -m heal_amd.build)."""
     global _lib
@@ -156,6 +166,13 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        # The argument lists above belong to ONE version of the C ABI: a stale library paired with newer Python (or the reverse)
+        # would be called with the wrong arguments and corrupt memory silently.
+        want = abi_version_of_header()
+        got = int(L.heal_abi_version()) if hasattr(L, "heal_abi_version") else -1
+        if got != want:
+            raise HealAmdError(f"{LIB_PATH} has C-ABI version {got}, include/heal_amd.h declares {want}: rebuild it "
+                               "(python -m heal_amd.build --force)")
         _lib = L
     return _lib
 

@@ -32,6 +32,7 @@ namespace heal {
 
 struct LssGeom {
     float dx[3], lo[3];  // lo = bx - dx/2
+    float rdx[3];        // fl(1 / dx) (lss_grid_coord)
     int nx[3];
     int n_agents, n_cams, D, fH, fW, C;
 };
@@ -292,36 +293,62 @@ __global__ __launch_bounds__(256) void k_lss_combine(const uint32_t* __restrict_
 // structure the sort ignores: along an image COLUMN (fixed camera, u, depth bin) the lifted points differ only in
 // the camera's vertical direction, which the one-cell-high BEV grid collapses -- the fH points of a column fall
 // into one or a few cells ("runs").  In the common case a (u, d) column is ONE run, so the column's result is a
-// matrix-vector product, and the 16 depth bins of a block share the feature rows:
+// matrix-vector product, and the depth bins of an image column share the feature rows:
 //     out[d, c] = sum_v P'[d, v] X[v, c],   P'[d, v] = p[d, v] where the point's cell is the column's MAIN cell (the
-// cell of its first valid point), 0 elsewhere -- a [16 x fH] x [fH x C] GEMM per block on v_mfma_f32_16x16x4_f32.
+// cell of its first valid point), 0 elsewhere -- a [D x fH] x [fH x C] GEMM per image column on v_mfma_f32_16x16x4_f32.
 // Points of a column that fall in another cell (a pitched camera; none for a level rig) are walked afterwards as runs
 // along v.
 //
-// TWO launches, no memset, no transposition, no separate mark pass:
-//   k_lss_scatter  block = (camera, u, 16 depth bins).  Input is the PIXEL-MAJOR head tensor [BN, fH*fW, C + D] the fused
-//                  image_head | depth_head convolution writes (heal_conv1x1 out_pixel_major): a pixel's C features and D
-//                  depth logits are one contiguous 704-B row, so every load is coalesced.  One wave per image row v:
-//                  lanes = depth bins, softmax by wave reductions (once per point), cell key of the block's bins in the
-//                  reference's fp32 operation order (lss_cell_key), the column GEMM on the matrix cores, then C
-//                  consecutive floats per column added to the cell's row with hardware fp32 atomics
-//                  (global_atomic_add_f32: whole cache lines per wave instruction) and the cell tagged flags[cell] = gen.
-//   k_lss_canvas   streams the [B, C*nz, ny, nx] output once (K2's canvas writer shape: 4 cells x CG channels per thread,
-//                  16-B stores) from the tagged rows and ZEROES every row slice it has read.
-// Scratch contract (heal_bev_pool_pm): `rows` is all-zero on entry and all-zero again on exit (self-cleaning), flags hold
-// the tag of the call that last touched a cell, state = {generation, tag of the call in flight}: k_lss_scatter tags with
-// generation + 1 and publishes the tag, k_lss_canvas adopts it as the new generation, so nothing is ever memset.  Order of the atomic adds across columns is not fixed:
-// a cell fed by three or more columns can differ by an ulp from call to call (the reference's unstable `argsort` feeding a
-// cumsum difference has the same property); HEAL_LSS_PATH=sorted selects the bit-reproducible pipeline.
+// Round 4: ONE launch, and the dense canvas is no longer part of K4.
+//   k_lss_scatter  block = (camera, image column u) with 256 * ceil(D / 16) threads: every depth bin of the column in one
+//                  block, so the column's feature rows are staged ONCE and the depth softmax is evaluated ONCE (round 3: one
+//                  block per 16 bins -> three copies of both; staging + keys were 9.2 of the kernel's 19.6 us, softmax 4.1:
+//                  scripts/k4_dbg.sh).  Input is the PIXEL-MAJOR head tensor [BN, fH*fW, C + D] of the fused
+//                  image_head | depth_head convolution (heal_conv1x1 out_pixel_major): a pixel's C features and D depth
+//                  logits are one contiguous row.  Work is split by wave role, not by barrier-separated phases:
+//                    * the first ceil(fH / 16) waves hold one pixel per lane QUAD: each lane loads its quarter of the
+//                      pixel's logits straight from global memory (16-B loads), softmax = register loop + two quad
+//                      butterflies (no LDS tile, no block reduction, no barrier) -> p[d][v] in LDS;
+//                    * every thread evaluates D*fH / blockDim cell keys (lss_cell_key, the reference's fp32 operation
+//                      order) from frustum values it requested BEFORE the feature loads, while those are in flight;
+//                    * the feature rows go global -> registers -> LDS once.
+//                  ONE barrier; main cell of every depth bin by ballot (its wave also writes the bin's A-operand row P');
+//                  ONE barrier; the [16 ceil(D/16) x fH] x [fH x C] GEMM on the matrix cores, C consecutive floats per column
+//                  added to the main cell's row with hardware fp32 atomics (whole cache lines per wave instruction), the cell
+//                  tagged flags[cell] = generation.
+// Output = the SPARSE PIXEL-MAJOR BEV map of the workspace: rows[cell][C] (cell = ((b*nz + z)*ny + y)*nx + x) + flags[cell].
+// A level rig touches <= n_cams * fW * D cells (12 288 of 65 536 at BASELINE size): 6.3 MB instead of the 33.5 MB dense
+// [C, ny, nx] canvas, 81 % of which is zeros.  Consumers:
+//   heal_bev_stem_block  the first BasicBlock convolutions of ResNetBEVBackbone (3x3 stride 2 + the 1x1 stride-2 downsample)
+//                        read the rows through the flags -- the canvas is never materialised (k_bev_stem below);
+//   heal_bev_pool_emit   any other consumer: one streaming pass writes the dense [B, C*nz, ny, nx] tensor (k_lss_canvas).
+// Scratch contract: TWO halves (rows, flags), selected by the parity of the call's generation.  k_lss_scatter of generation g
+// adds into half g & 1 (all-zero rows by induction); its CONSUMER zeroes, as side work of its own launch, the rows of the OTHER
+// half that generation g - 1 tagged (lss_clean_other_half: that half's consumer finished launches ago, and the stores hide
+// under the consumer's own MFMA / streaming work -- in the scatter they cost 2 of 16 us), so nothing is ever memset and no
+// kernel cleans rows that a neighbouring block may still be reading.  state = {generation of the last consumed call, tag of the call in
+// flight}: the scatter derives its tag from state[0] and publishes it in state[1]; the consumer (exactly one per scatter)
+// reads state[1] and writes it back to state[0] -- each word is only written in the kernel that does not read it, the kernel
+// boundary orders them: no tickets, no returning atomics.  Order of the atomic adds across columns is not fixed: a cell fed by
+// three or more columns can differ by an ulp from call to call (the reference's unstable `argsort` feeding a cumsum
+// difference has the same property); HEAL_LSS_PATH=sorted selects the bit-reproducible pipeline.
 constexpr uint32_t LSS_NOKEY = 0xFFFFFFFFu;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int LSS_MT = 16;  // depth bins per block = MFMA M
+constexpr int LSS_MT = 16;   // depth bins per MFMA m-tile
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+constexpr int LSS_PKS = 66;  // row stride (floats) of the p / key tables: conflict-free for the softmax quads' writes and the A-fragment reads
+
+// (geom - (bx - dx/2)) / dx of voxel_pooling (heter_encoders.py:170) is only ever truncated and compared with integers.  The IEEE
+// quotient q = fl(a / b) costs ~13 instructions, three per lifted point; t = fl(a * fl(1 / b)) lies within 1.5 * 2^-23 |q| of it, so
+// trunc(t) = trunc(q) and every comparison of t with an integer equals that of q UNLESS an integer lies that close to t -- only
+// then (about one point in 10^4) is the division evaluated, behind a WAVE-UNIFORM branch (a per-lane branch is if-converted and
+// the division runs for everybody).  The value used is NOT q, but it truncates and compares like q.
+__device__ __forceinline__ bool lss_near_integer(float t) { return fabsf(t - rintf(t)) <= 4e-7f * fmaxf(fabsf(t), 1.f); }
 
 // get_geometry + the voxel_pooling index of one lifted point (heter_encoders.py:125-147, :170-186), fp32, the
 // operation order of the reference (and of k_lss_keys)
@@ -337,9 +364,14 @@ __device__ __forceinline__ uint32_t lss_cell_key(const CamMats& cm, const float*
     const float ex = ((M[0] * u0 + M[1] * u1) + M[2] * u2) + cm.trans[0];
     const float ey = ((M[3] * u0 + M[4] * u1) + M[5] * u2) + cm.trans[1];
     const float ez = ((M[6] * u0 + M[7] * u1) + M[8] * u2) + cm.trans[2];
-    const float fx = (ex - g.lo[0]) / g.dx[0];
-    const float fy = (ey - g.lo[1]) / g.dx[1];
-    const float fz = (ez - g.lo[2]) / g.dx[2];
+    const float ax = ex - g.lo[0], ay = ey - g.lo[1], az = ez - g.lo[2];
+    float fx = ax * g.rdx[0], fy = ay * g.rdx[1], fz = az * g.rdx[2];
+    const bool nx_ = lss_near_integer(fx), ny_ = lss_near_integer(fy), nz_ = lss_near_integer(fz);
+    if (__builtin_amdgcn_ballot_w64(nx_ | ny_ | nz_) != 0ull) {
+        if (nx_) fx = ax / g.dx[0];
+        if (ny_) fy = ay / g.dx[1];
+        if (nz_) fz = az / g.dx[2];
+    }
     if (fx > -1.f && fx < (float)g.nx[0] && fy > -1.f && fy < (float)g.nx[1] && fz > -1.f && fz < (float)g.nx[2]) {
         const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
         if (ix >= 0 && ix < g.nx[0] && iy >= 0 && iy < g.nx[1] && iz >= 0 && iz < g.nx[2])
@@ -348,217 +380,297 @@ __device__ __forceinline__ uint32_t lss_cell_key(const CamMats& cm, const float*
     return LSS_NOKEY;
 }
 
+struct LssPmWs { float* rows[2]; int* flags[2]; int* state; };
+
+// LDS carve of k_lss_scatter (floats); shared by the kernel and the host's size computation
+struct LssLds {
+    int LD, fH4, MTOT, xs, pk_p, pk_key, total;
+    __host__ __device__ LssLds(int fH, int C, int ndt) {
+        LD = C + 16;                         // LD % 64 == 16: the 4 k-rows of a B fragment hit disjoint bank groups
+        fH4 = (fH + 3) & ~3;
+        MTOT = LSS_MT * ndt;
+        xs = 0;
+        pk_p = xs + fH4 * LD;
+        pk_key = pk_p + MTOT * LSS_PKS;
+        total = pk_key + MTOT * LSS_PKS;
+    }
+};
+
 // The frustum of create_frustum (heter_encoders.py:110-123) is separable -- frustum[d][v][u] = (xs[u], ys[v], ds[d]) --
 // and is read as such (three short axes instead of D*fH*fW strided triples); the host wrapper verifies the property once
 // per frustum tensor and takes the sorted pipeline for anything else.
-//
-// Measured anatomy of the first version of this kernel (m2, 768 blocks, rocprofv3, scripts/k4_dbg.sh): loads 6.6 us,
-// softmax + keys 15.3 us, main cells 1.8 us, GEMM + atomics 3.4 us (the atomics themselves: 0.4 us).  The softmax was one
-// wave per image row with two ds_bpermute reductions per row and the keys ran on 16 of 64 lanes: a chain of dependent
-// long-latency instructions at 3 waves per SIMD.  Now: logits go through an LDS tile (coalesced 192-B rows in, one thread
-// per (pixel, quarter of the bins) out), the softmax is a register loop with two block reductions through LDS, and the 768
-// keys of a block are 3 independent evaluations per thread.
-constexpr int LSS_LGS = 65;   // LDS row stride of the logit tile (floats): lane v reads lgs[v][d] -> bank (v + d) % 32
-
-__global__ __launch_bounds__(256) void k_lss_scatter(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
-                                                    const float* __restrict__ frustum,
-                                                    const CamMats* __restrict__ cams, LssGeom g, int n_dt,
-                                                    float* __restrict__ rows, int* __restrict__ flags,
-                                                    int* __restrict__ state, int dbg) {
-    __shared__ float red[4][64];
-    __shared__ float pk_p[LSS_MT][64];       // p[dl][v] (unmasked; the leftover walk reads it)
-    __shared__ uint32_t pk_key[LSS_MT][64];  // key[dl][v]; NOKEY for v >= fH and bins >= D
-    __shared__ float pT[64][LSS_MT];         // P'[v][dl]: A operand, v-major so that a fragment read is conflict-free
-    __shared__ uint32_t mk[LSS_MT];          // main cell of column dl
-    __shared__ int has_left[LSS_MT];
-    extern __shared__ float4 xs4[];          // X[fH4][C + 16], then the logit tile lgs[fH][LSS_LGS]
-    float* xs = reinterpret_cast<float*>(xs4);
+template <int NDT>
+__global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
+                                                          const float* __restrict__ frustum,
+                                                          const CamMats* __restrict__ cams, LssGeom g, LssPmWs ws,
+                                                          int cells_total, int dbg) {
+    constexpr int W = 4 * NDT, NTHR = 256 * NDT, MTOT = LSS_MT * NDT;
+    extern __shared__ float4 smem4[];
+    float* smem = reinterpret_cast<float*>(smem4);
+    const LssLds L(g.fH, g.C, NDT);
+    float* xs = smem + L.xs;
+    float* pk_p = smem + L.pk_p;
+    uint32_t* pk_key = reinterpret_cast<uint32_t*>(smem + L.pk_key);
 
     const int HW = g.fH * g.fW;
-    const int u = blockIdx.x / n_dt, dt = blockIdx.x % n_dt, bn = blockIdx.y;
-    const int part = threadIdx.x >> 6, l = threadIdx.x & 63, v = l;
-    const int LD = g.C + 16;                 // LD % 64 == 16: the 4 k-rows of a B fragment hit disjoint bank groups
-    const int fH4 = (g.fH + 3) & ~3;
-    float* lgs = xs + (size_t)fH4 * LD;
-    const int gen = state[0] + 1;            // tag of this call: >= 1, a zero-filled flag array matches nothing
+    const int u = blockIdx.x, bn = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int LD = L.LD, fH4 = L.fH4;
+    const int gen = ws.state[0] + 1;         // tag of this call: >= 1, a zero-filled flag array matches nothing
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    // HEAL_K4_DBG & 128: shader-clock stamps of block 0's first (softmax) and last (keys only) wave -> state[16..] (scripts/k4_stamps.py)
+    const bool stamp_on = (dbg & 128) && bid == 0 && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64);
+    int* stamp_out = ws.state + 16 + (threadIdx.x == 0 ? 0 : 16);
+    const unsigned long long stamp0 = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+#define LSS_STAMP(i) do { if (stamp_on) { __builtin_amdgcn_s_waitcnt(0); stamp_out[i] = (int)(__builtin_amdgcn_s_memtime() - stamp0); } } while (0)
+    float* __restrict__ rows = ws.rows[gen & 1];
+    int* __restrict__ flags = ws.flags[gen & 1];
     const float* __restrict__ hcol = head + ((size_t)bn * HW + u) * CT;  // pixel (v, u) = hcol + v * fW * CT
-    const bool live = v < g.fH;
 
-    // stage the column's feature rows (512-B contiguous runs; rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop) and
-    // its logit rows (D contiguous floats per pixel).  ALL global loads of a thread are issued before the first LDS store:
-    // a load -> store loop with a run-time trip count serialises one HBM round trip per iteration (6.6 us of the first
-    // version of this kernel).
-    {
-        const int c4n = g.C / 4, ld4 = LD / 4, nX = fH4 * c4n;
-        const int d4n = g.D / 4, nL = g.fH * d4n;   // D % 4 == 0 (host)
-        float4 xr[8], lr[4];
+    // -- requests, oldest first (vmcnt retires in order): frustum axes of this thread's keys, the softmax waves' logits, the
+    //    feature rows.  Every load is UNCONDITIONAL on a clamped address and masked afterwards: a predicated load sits in its own
+    //    basic block, and the waitcnt pass then drains the whole queue (vmcnt(0)) in front of the first use of ANY of them.
+    const CamMats cm = cams[bn];             // scalar loads: requested first, their latency hides under the vector loads
+    const int kb = bn / g.n_cams;
+    const int n_keys = g.D * g.fH;
+    float kfy[4], kfz[4];
+    int kd[4], kv[4];
+    const float fr_x = frustum[(size_t)u * 3 + 0];
+    {   // key i = tid + NTHR j -> (d, v) = (i / fH, i % fH): one division per thread, then steps of (NTHR / fH, NTHR % fH)
+        const int qs = NTHR / g.fH, rs = NTHR - qs * g.fH;    // wave-uniform: scalar unit
+        int dcur = tid / g.fH, vcur = tid - dcur * g.fH;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = threadIdx.x + 256 * k, r = i / c4n, c4 = i - r * c4n;
-            xr[k] = (i < nX && r < g.fH) ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
-                                         : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = threadIdx.x + 256 * k, r = i / d4n, d4 = i - r * d4n;
-            lr[k] = i < nL ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + g.C + d4 * 4)
-                           : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = threadIdx.x + 256 * k, r = i / c4n, c4 = i - r * c4n;
-            if (i < nX) xs4[r * ld4 + c4] = xr[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = threadIdx.x + 256 * k, r = i / d4n, d4 = i - r * d4n;
-            if (i < nL) {
-                float* dst = lgs + r * LSS_LGS + d4 * 4;
-                dst[0] = lr[k].x; dst[1] = lr[k].y; dst[2] = lr[k].z; dst[3] = lr[k].w;
-            }
-        }
-        for (int i = threadIdx.x + 2048; i < nX; i += 256) {   // C > 160: the rest of the feature rows
-            const int r = i / c4n, c4 = i - r * c4n;
-            xs4[r * ld4 + c4] = r < g.fH ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
-                                         : float4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {            // D * fH <= 16 NDT * 64 = 4 * NTHR
+            kd[j] = min(dcur, g.D - 1);          // clamped: the loads below are unconditional (keys past n_keys are not stored)
+            kv[j] = vcur;
+            kfy[j] = frustum[(size_t)kv[j] * g.fW * 3 + 1];
+            kfz[j] = frustum[(size_t)kd[j] * HW * 3 + 2];
+            dcur += qs;
+            vcur += rs;
+            if (vcur >= g.fH) { vcur -= g.fH; ++dcur; }
         }
     }
-    // cell keys of the block's 16 bins: thread (v, part) takes dl = part, part + 4, part + 8, part + 12 (independent chains)
+    const int n_sw = (g.fH + 15) >> 4;       // softmax waves: one pixel per lane quad
+    const int sv = w * 16 + (l >> 2), sq = l & 3, d4n = g.D >> 2;   // D % 4 == 0 (host)
+    const bool s_on = w < n_sw && sv < g.fH;
+    float4 lg[4];
+    if (w < n_sw) {
+        const float* lrow = hcol + (size_t)min(sv, g.fH - 1) * g.fW * CT + g.C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lg[k] = *reinterpret_cast<const float4*>(lrow + min(sq + 4 * k, d4n - 1) * 4);
+    }
+    const int c4n = g.C / 4, ld4 = LD / 4, nX = fH4 * c4n;
+    float4 xr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = min(tid + NTHR * k, nX - 1), r = i / c4n, c4 = i - r * c4n;
+        xr[k] = *reinterpret_cast<const float4*>(hcol + (size_t)min(r, g.fH - 1) * g.fW * CT + c4 * 4);
+    }
+
+    LSS_STAMP(0);
+    // -- cell keys (VALU work under the feature loads)
     {
-        const CamMats cm = cams[bn];
-        const float fr_x = frustum[(size_t)u * 3 + 0];
-        const float fr_y = live ? frustum[(size_t)v * g.fW * 3 + 1] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int dl = part + 4 * j, d = dt * LSS_MT + dl;
-            uint32_t key = LSS_NOKEY;
-            if (live && d < g.D) {
-                const float fr[3] = {fr_x, fr_y, frustum[(size_t)d * HW * 3 + 2]};
-                key = lss_cell_key(cm, fr, g, bn / g.n_cams);
+            if (tid + NTHR * j < n_keys) {
+                const float fr[3] = {fr_x, kfy[j], kfz[j]};
+                pk_key[kd[j] * LSS_PKS + kv[j]] = lss_cell_key(cm, fr, g, kb);
             }
-            pk_key[dl][v] = key;
         }
     }
+    LSS_STAMP(1);
+    // -- softmax over depth (lss_submodule.py:130) in the lane quads of the first waves
+    if (w < n_sw && !(dbg & 32)) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(s_on && sq + 4 * k < d4n)) lg[k] = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            mx = fmaxf(fmaxf(mx, fmaxf(lg[k].x, lg[k].y)), fmaxf(lg[k].z, lg[k].w));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float e[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x4[4] = {lg[k].x, lg[k].y, lg[k].z, lg[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e[4 * k + c] = x4[c] != -INFINITY ? __expf(x4[c] - mx) : 0.f;   // v_exp_f32: 2 ulp, far inside the 1e-3 of the BEV features
+                sum += e[4 * k + c];
+            }
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float inv = 1.f / sum;             // one division per pixel; p = e * inv is within an ulp of e / sum
+        if (s_on) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i4 = sq + 4 * k;
+                if (i4 < d4n) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pk_p[(i4 * 4 + c) * LSS_PKS + sv] = e[4 * k + c] * inv;
+                }
+            }
+        }
+    }
+    LSS_STAMP(2);
+    // -- feature rows to LDS (rows fH .. fH4-1 are zero: they meet P' = 0 in the k loop)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + NTHR * k, r = i / c4n, c4 = i - r * c4n;
+        if (i < nX) smem4[r * ld4 + c4] = r < g.fH ? xr[k] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = tid + 4 * NTHR; i < nX; i += NTHR) {   // fH4 * C / 4 > 4 blockDim: the rest of the feature rows
+        const int r = i / c4n, c4 = i - r * c4n;
+        smem4[r * ld4 + c4] = r < g.fH ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
+                                       : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    LSS_STAMP(3);
     __syncthreads();
+    LSS_STAMP(4);
     if (dbg & 16) return;
-    // softmax over depth (lss_submodule.py:130): thread (v, part) owns the bins [part * dper, part * dper + dper)
-    const int dper = (g.D + 3) / 4;          // <= 16
-    float e[16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int d = part * dper + i;
-        e[i] = (live && i < dper && d < g.D) ? lgs[v * LSS_LGS + d] : -INFINITY;
-        mx = fmaxf(mx, e[i]);
-    }
-    red[part][v] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0][v], red[1][v]), fmaxf(red[2][v], red[3][v]));
-    __syncthreads();
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        e[i] = e[i] != -INFINITY ? expf(e[i] - mx) : 0.f;
-        sum += e[i];
-    }
-    red[part][v] = sum;
-    __syncthreads();
-    const float den = ((red[0][v] + red[1][v]) + red[2][v]) + red[3][v];
-    // probabilities of the block's bins that this thread owns
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int dl = part * dper + i - dt * LSS_MT;
-        if (i < dper && dl >= 0 && dl < LSS_MT) pk_p[dl][v] = (live && pk_key[dl][v] != LSS_NOKEY) ? e[i] / den : 0.f;
-    }
-    // bins of the tile beyond D (D not a multiple of 16) belong to nobody above: p = 0
-    for (int dl = part; dl < LSS_MT; dl += 4)
-        if (dt * LSS_MT + dl >= g.D) pk_p[dl][v] = 0.f;
-    if (dbg & 32) return;
-    __syncthreads();
-    // main cell of each column: the cell of its first valid point; tag it
-    for (int dl = part; dl < LSS_MT; dl += 4) {
-        const uint32_t key = pk_key[dl][l];
-        const unsigned long long valid = __ballot(key != LSS_NOKEY);
-        const uint32_t m = valid ? __shfl(key, __builtin_ctzll(valid), 64) : LSS_NOKEY;
-        const unsigned long long left = __ballot(key != LSS_NOKEY && key != m);
-        if (l == 0) {
-            mk[dl] = m;
-            has_left[dl] = left != 0ull;
-            if (m != LSS_NOKEY) flags[m] = gen;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int dl = part + 4 * j;
-        const uint32_t key = pk_key[dl][l];
-        pT[l][dl] = (key != LSS_NOKEY && key == mk[dl]) ? pk_p[dl][l] : 0.f;
-    }
-    __syncthreads();
-    if (dbg & 64) return;
 
-    // GEMM: D[dl, c] = sum_v P'[v][dl] X[v][c]; wave w owns the channel tiles w, w+4, ...
+    // -- per wave (m-tile w / 4 = 16 depth bins, channel tiles w % 4, w % 4 + 4, ...): main cells, A operand and GEMM with no
+    //    further barrier.  Lane (lk, ln) is lane (k = lk, row ln) of the 16x16x4 A fragment: it owns depth bin d = 16 mt + ln and
+    //    the image rows v = 4 ks + lk.  Main cell of a bin = the cell of the column's first valid point: the first valid key
+    //    among the lane's own rows, then the lowest v of the four lk lanes (two xor shuffles).  The four waves of an m-tile
+    //    each derive it (12 LDS reads per lane, the same count the A fragments took from a shared P' table) -- that table, the
+    //    main-cell pass over it and the barrier between them are gone.
     const int lk = l >> 4, ln = l & 15;
     const int ksteps = fH4 / 4;  // <= 16
+    const int mt = w >> 2, nq = w & 3;
+    const int d = mt * LSS_MT + ln;
+    uint32_t kk[16];
+    float pp[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int v = 4 * ks + lk;
+        const bool on = ks < ksteps && d < g.D && v < g.fH;
+        kk[ks] = on ? pk_key[d * LSS_PKS + v] : LSS_NOKEY;
+        pp[ks] = on ? pk_p[d * LSS_PKS + v] : 0.f;
+    }
+    int fv = 1 << 20;                        // lowest image row with a valid key among this lane's rows, and its key
+    uint32_t m = LSS_NOKEY;
+#pragma unroll
+    for (int ks = 15; ks >= 0; --ks)
+        if (kk[ks] != LSS_NOKEY) { fv = 4 * ks + lk; m = kk[ks]; }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const int fo = __shfl_xor(fv, o, 64);
+        const uint32_t mo = __shfl_xor(m, o, 64);
+        if (fo < fv) { fv = fo; m = mo; }
+    }
+    bool left = false;
     float afr[16];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) afr[ks] = ks < ksteps ? pT[ks * 4 + lk][ln] : 0.f;
+    for (int ks = 0; ks < 16; ++ks) {
+        left |= kk[ks] != LSS_NOKEY && kk[ks] != m;
+        afr[ks] = (kk[ks] != LSS_NOKEY && kk[ks] == m) ? pp[ks] : 0.f;
+    }
+    LSS_STAMP(5);
+    if (nq == 0 && lk == 0 && m != LSS_NOKEY) flags[m] = gen;
+    if (dbg & 64) return;
+    uint32_t cell_r[4];                      // D[row = 4 lk + r][col = ln]: the main cell of bin 16 mt + 4 lk + r lives in lane 4 lk + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cell_r[r] = __shfl(m, lk * 4 + r, 64);
     const int n_tiles = g.C / 16;
-    for (int nt = part; nt < n_tiles; nt += 4) {
+    for (int nt = nq; nt < n_tiles; nt += 4) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* xb = xs + lk * LD + nt * 16 + ln;
+        // all B fragments of the tile first (ONE wait), then the MFMAs in groups of 4 k-steps; k-steps past fH4 / 4 meet A = 0
+        // and read a clamped (valid) feature row.  (A guard per MFMA puts every LDS read behind its own wait.)
+        float bq[16];
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], xb[ks * 4 * LD], acc, 0, 0, 0);
+        for (int q = 0; q < 16; ++q) bq[q] = xb[min(q, ksteps - 1) * 4 * LD];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (g4 * 4 < ksteps) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[g4 * 4 + q], bq[g4 * 4 + q], acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t cell = mk[lk * 4 + r];
+            const uint32_t cell = cell_r[r];
+            if (dbg & 2) continue;
+            if (dbg & 4) { if (cell != LSS_NOKEY) rows[(size_t)cell * g.C + nt * 16 + ln] = acc[r]; continue; }
             if (cell != LSS_NOKEY) unsafeAtomicAdd(rows + (size_t)cell * g.C + nt * 16 + ln, acc[r]);
         }
     }
 
-    // leftovers: points of a column outside its main cell, walked as runs along v
-    for (int dl = part; dl < LSS_MT; dl += 4) {
-        if (!has_left[dl]) continue;
-        const uint32_t skip = mk[dl];
-        for (int c0 = 0; c0 < g.C; c0 += 64) {
-            const int c = c0 + l;
-            float acc = 0.f;
-            uint32_t cur = LSS_NOKEY;
-            for (int vv = 0; vv <= g.fH; ++vv) {
-                uint32_t key = vv < g.fH ? pk_key[dl][vv] : LSS_NOKEY;
-                if (key == skip) key = LSS_NOKEY;
-                if (key != cur) {
-                    if (cur != LSS_NOKEY) {
-                        if (c < g.C) unsafeAtomicAdd(rows + (size_t)cur * g.C + c, acc);
-                        if (l == 0 && c0 == 0) flags[cur] = gen;
+    LSS_STAMP(6);
+    // -- leftovers: points of a column outside its main cell (a pitched camera; none for a level rig), walked as runs along v by
+    //    the first wave of the m-tile, 64 channels per pass
+    if (nq == 0) {
+        unsigned long long todo = __ballot(left) ;
+        todo = (todo | (todo >> 16) | (todo >> 32) | (todo >> 48)) & 0xFFFFull;     // bins (ln) with a leftover in any lk lane
+        while (todo) {
+            const int bl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int dd = mt * LSS_MT + bl;
+            const uint32_t skip = __shfl(m, bl, 64);
+            for (int c0 = 0; c0 < g.C; c0 += 64) {
+                const int c = c0 + l;
+                float acc = 0.f;
+                uint32_t cur = LSS_NOKEY;
+                for (int vv = 0; vv <= g.fH; ++vv) {
+                    uint32_t key = vv < g.fH ? pk_key[dd * LSS_PKS + vv] : LSS_NOKEY;
+                    if (key == skip) key = LSS_NOKEY;
+                    if (key != cur) {
+                        if (cur != LSS_NOKEY) {
+                            if (c < g.C) unsafeAtomicAdd(rows + (size_t)cur * g.C + c, acc);
+                            if (l == 0 && c0 == 0) flags[cur] = gen;
+                        }
+                        acc = 0.f;
+                        cur = key;
                     }
-                    acc = 0.f;
-                    cur = key;
+                    if (cur != LSS_NOKEY && c < g.C) acc += pk_p[dd * LSS_PKS + vv] * xs[vv * LD + c];
                 }
-                if (cur != LSS_NOKEY && c < g.C) acc += pk_p[dl][vv] * xs[vv * LD + c];
             }
         }
     }
 
-    // Publish the tag for k_lss_canvas in state[1] -- a word nobody READS in this kernel (every block derives the tag from
-    // state[0]); k_lss_canvas reads state[1] and writes it back to state[0], which nobody reads there.  The kernel boundary
-    // orders the two: no tickets, no returning atomics (a last-block ticket cost 7-10 us in either kernel: the returning
-    // atomic waits behind the block's outstanding stores / atomics).
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) state[1] = gen;
+    LSS_STAMP(7);
+    // Publish the tag for the consumer in state[1] -- a word nobody READS in this kernel (every block derives the tag from
+    // state[0]); the consumer reads state[1] and writes it back to state[0], which nobody reads there.
+    if (bid == 0 && tid == 0) ws.state[1] = gen;
+#undef LSS_STAMP
 }
 
-// canvas[b][c][cell] = flags[b][cell] == generation ? rows[b*cells + cell][c] : 0.  A thread owns 4 consecutive x cells x 4
-// channels (one float4 row read per tagged cell, a 4x4 register transpose, four 16-B stores); the four channel slices of a
-// 16-channel group sit in ADJACENT LANES, so a wave's row reads -- and the zero stores that clean the rows behind the reads
-// -- cover whole 64-B lines (16-B partial-line stores from separate blocks cost 4 us of the first version, the last-block
-// ticket that used to live in this kernel 10 us: rocprofv3, scripts/k4_dbg.sh).
-__global__ __launch_bounds__(256) void k_lss_canvas(const int4* __restrict__ flags4, float* __restrict__ rows, int cells4,
-                                                   int channels, float4* __restrict__ canvas4,
-                                                   int* __restrict__ state, int dbg) {
-    const int gen = state[1];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) state[0] = gen;
+// Zero the rows that generation gen - 1 tagged in the half the call in flight does NOT use; `part` of `nparts` equal cell ranges
+// per block.  Called by the consumer kernels (every block, all threads; blockDim a multiple of 64).
+__device__ __forceinline__ void lss_clean_other_half(const LssPmWs& ws, int gen, int cells_total, int channels, int part,
+                                                     int nparts) {
+    const int cpb = (cells_total + nparts - 1) / nparts;
+    const int cbeg = part * cpb, cend = min(cbeg + cpb, cells_total);
+    const int* __restrict__ flags_o = ws.flags[(gen & 1) ^ 1];
+    float4* __restrict__ rows_o4 = reinterpret_cast<float4*>(ws.rows[(gen & 1) ^ 1]);
+    const int c4n = channels / 4, l = threadIdx.x & 63;
+    const float4 z = float4{0.f, 0.f, 0.f, 0.f};
+    for (int base = cbeg + (int)(threadIdx.x & ~63u); base < cend; base += blockDim.x) {
+        const int f = flags_o[min(base + l, cend - 1)];
+        unsigned long long m = __ballot(gen > 1 && base + l < cend && f == gen - 1);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            for (int c4 = l; c4 < c4n; c4 += 64) rows_o4[(size_t)(base + j) * c4n + c4] = z;
+        }
+    }
+}
+
+// Dense emit: canvas[b][c][cell] = flags[cell] == generation ? rows[cell][c] : 0 for consumers that want the reference's
+// [B, C*nz, ny, nx] tensor.  A thread owns 4 consecutive x cells x 4 channels (one float4 row read per tagged cell, a 4x4
+// register transpose, four 16-B stores); the four channel slices of a 16-channel group sit in ADJACENT LANES, so a wave's row
+// reads cover whole 64-B lines.
+__global__ __launch_bounds__(256) void k_lss_canvas(LssPmWs ws, int cells4, int channels, float4* __restrict__ canvas4,
+                                                   int cells_total) {
+    const int gen = ws.state[1];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ws.state[0] = gen;
+    lss_clean_other_half(ws, gen, cells_total, channels, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                         gridDim.x * gridDim.y * gridDim.z);
+    const int4* __restrict__ flags4 = reinterpret_cast<const int4*>(ws.flags[gen & 1]);
+    const float* __restrict__ rows = ws.rows[gen & 1];
     const int s = threadIdx.x & 3;
     const int t = blockIdx.x * 64 + (threadIdx.x >> 2);
     const int b = blockIdx.z, c0 = blockIdx.y * 16 + s * 4;
@@ -572,18 +684,219 @@ __global__ __launch_bounds__(256) void k_lss_canvas(const int4* __restrict__ fla
         for (int c = 0; c < 4; ++c) out[(size_t)c * cells4] = z;
         return;
     }
-    float4* r = reinterpret_cast<float4*>(rows + ((size_t)b * cells4 * 4 + (size_t)t * 4) * channels + c0);
+    const float4* r = reinterpret_cast<const float4*>(rows + ((size_t)b * cells4 * 4 + (size_t)t * 4) * channels + c0);
     const size_t rs = channels / 4;  // float4 stride between consecutive cells' rows
-    const float4 a0 = h0 ? r[0] : z, a1 = h1 ? r[rs] : z, a2 = h2 ? r[2 * rs] : z, a3 = h3 ? r[3 * rs] : z;
+    float4 a0 = z, a1 = z, a2 = z, a3 = z;
+    if (h0) a0 = r[0];
+    if (h1) a1 = r[rs];
+    if (h2) a2 = r[2 * rs];
+    if (h3) a3 = r[3 * rs];
     out[0] = make_float4(a0.x, a1.x, a2.x, a3.x);
     out[(size_t)cells4] = make_float4(a0.y, a1.y, a2.y, a3.y);
     out[(size_t)2 * cells4] = make_float4(a0.z, a1.z, a2.z, a3.z);
     out[(size_t)3 * cells4] = make_float4(a0.w, a1.w, a2.w, a3.w);
-    if (!(dbg & 2)) {
-        if (h0) r[0] = z;
-        if (h1) r[rs] = z;
-        if (h2) r[2 * rs] = z;
-        if (h3) r[3 * rs] = z;
+}
+
+// ---- first block of the camera BEV backbone on the sparse pixel-major map ------------------------------------------------
+// ResNetBEVBackbone of a camera modality opens with BasicBlock(C -> 64, stride 2) (base_bev_backbone_resnet.py:88-109,
+// resblock.py:18-64): conv1 = 3x3 stride 2 pad 1 (+BN+ReLU) and downsample = 1x1 stride 2 (+BN) both read the pooled map.
+// One launch computes both from the rows / flags of k_lss_scatter, so the [C, ny, nx] canvas never exists:
+//   implicit GEMM, M = 64 output pixels of one output row, N = 64 conv1 channels (+ 64 downsample channels at the centre tap),
+//   K = 9 taps x C, on the 32x32x2 fp32 MFMA core of heal_linear: both operands staged [row][k] (k contiguous, row stride 36).
+//   A row (an input pixel at a tap) is one contiguous 128-B run of the cell's row -- or zero when the cell is not tagged with
+//   the generation in flight (the flags of a thread's two pixels x 9 taps are read once, up front); taps none of the block's
+//   64 pixels has are skipped (the map is 81 % empty: outside the cameras' 50 m radius whole tiles are).
+//   wave (wm, wn): pixels [32 wm, +32) x channels [32 wn, +32) of conv1 AND of the downsample: one 32x32 accumulator each.
+//   K chunks of BK = 64 channels (32 when C % 64 != 0), two accumulators per output so that back-to-back MFMAs are independent.
+//   Weights pre-laid by the host: main [9][C/BK][64][BK] (tap, chunk, cout, k), downsample [C/BK][64][BK].
+//   Epilogue through LDS: bias (BN folded), ReLU on the conv1 half, NCHW 16-B stores.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int BK>   // channels per K chunk: 64 (C % 64 == 0) or 32
+__global__ __launch_bounds__(256) void k_bev_stem(LssPmWs ws, int C, int nx, int ny, int cells_total,
+                                                 const float* __restrict__ wmain, const float* __restrict__ bmain,
+                                                 const float* __restrict__ wds, const float* __restrict__ bds,
+                                                 float* __restrict__ out_main, float* __restrict__ out_id, int Ho, int Wo,
+                                                 int tiles_x, int dbg) {
+    constexpr int RS = BK + 4;               // LDS row stride: 16-B aligned rows, the b128 reads of 16 lanes cover all banks
+    constexpr int NH = BK / 32;              // 128-B pieces of a row chunk per thread
+    constexpr int KH = BK / 2;               // k-steps per chunk (one 32x32x2 MFMA each: lane half h multiplies k = KH h + s)
+    __shared__ __attribute__((aligned(16))) float s_all[4 * 64 * RS];
+    __shared__ int s_tapmask;
+    float (*sA)[64 * RS] = reinterpret_cast<float (*)[64 * RS]>(s_all);
+    float (*sB)[64 * RS] = reinterpret_cast<float (*)[64 * RS]>(s_all + 2 * 64 * RS);
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, li = l & 31, h = l >> 5;
+    const int gen = ws.state[1];
+    if (blockIdx.x == 0 && tid == 0) ws.state[0] = gen;
+    const float* __restrict__ rows = ws.rows[gen & 1];
+    const int* __restrict__ flags = ws.flags[gen & 1];
+    int bx_ = blockIdx.x;
+    const int xt = bx_ % tiles_x; bx_ /= tiles_x;
+    const int oy = bx_ % Ho, b = bx_ / Ho;
+    const int ox0 = xt * 64;
+    if (tid == 0) s_tapmask = 0;
+
+    // staging role: pixel rows r0 and r0 + 32 of the A tile, 16-B column c4 of each 128-B piece; weight rows likewise.  The
+    // flags of the thread's two pixels x 9 taps are read ONCE (18 unconditional loads on clamped cells, masked afterwards: see
+    // k_lss_scatter).
+    const int r0 = tid >> 3, c4 = tid & 7;
+    int pm0 = 0, pm1 = 0;
+    const int cell_max = (b + 1) * ny * nx - 1, cell_min = b * ny * nx;
+    const int cl0 = (b * ny + 2 * oy - 1) * nx + 2 * (ox0 + r0) - 1, cl1 = cl0 + 64;   // cell of tap (0, 0) of the two pixels
+    {
+        int f0[9], f1[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            f0[t] = flags[min(max(cl0 + (t / 3) * nx + t % 3, cell_min), cell_max)];
+            f1[t] = flags[min(max(cl1 + (t / 3) * nx + t % 3, cell_min), cell_max)];
+        }
+        // side work: the rows the PREVIOUS generation tagged in the other half go back to zero (stores that drain under the MFMAs)
+        lss_clean_other_half(ws, gen, cells_total, C, blockIdx.x, gridDim.x);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = 2 * oy + t / 3 - 1, ix0 = 2 * (ox0 + r0) + t % 3 - 1, ix1 = ix0 + 64;
+            const bool iny = iy >= 0 && iy < ny;
+            pm0 |= (int)(iny && ox0 + r0 < Wo && ix0 >= 0 && ix0 < nx && f0[t] == gen) << t;
+            pm1 |= (int)(iny && ox0 + r0 + 32 < Wo && ix1 >= 0 && ix1 < nx && f1[t] == gen) << t;
+        }
+    }
+    __syncthreads();
+    {
+        int m = pm0 | pm1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+        if (l == 0 && m) atomicOr(&s_tapmask, m);
+    }
+    __syncthreads();
+    // virtual tap 9 = the centre tap once more, against the DOWNSAMPLE weights: every iteration then stages one 64 x BK A tile
+    // and one 64 x BK weight tile, and only the accumulators it feeds differ (a wave-uniform choice)
+    int tapmask = s_tapmask;
+    tapmask |= ((tapmask >> 4) & 1) << 9;
+    const int nch = C / BK;
+    const int n_it = (dbg & 2048) ? 0 : __popc(tapmask) * nch;
+
+    f32x16 acc_m[2], acc_d[2];               // two accumulators per output: consecutive MFMAs never wait for each other
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_m[0][r] = 0.f; acc_m[1][r] = 0.f; acc_d[0][r] = 0.f; acc_d[1][r] = 0.f; }
+
+    // iteration -> (tap, chunk): taps in ascending order over the set bits of tapmask
+    int it_tap = 0, it_ch = 0, rem = tapmask;
+    auto first_tap = [&]() { it_tap = rem ? __builtin_ctz(rem) : 0; rem &= rem - 1; it_ch = 0; };
+    auto next_it = [&]() { if (++it_ch == nch) first_tap(); };
+    // staging registers as NAMED float4 values (arrays of float4 written in one branch and read in another end up in scratch);
+    // the second 128-B piece (x1) exists for BK = 64 only
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, b0 = z4, b1 = z4, b2 = z4, b3 = z4;
+    auto load = [&](int t, int j) {
+        const int tp = t == 9 ? 4 : t;        // pixel tap
+        const int dy = tp / 3, dx = tp - dy * 3;
+        const float* wsrc = t == 9 ? wds + ((size_t)j * 64) * BK : wmain + ((size_t)(t * nch + j) * 64) * BK;
+        const int c0 = ((pm0 >> tp) & 1) ? cl0 + dy * nx + dx : cell_min;
+        const int c1 = ((pm1 >> tp) & 1) ? cl1 + dy * nx + dx : cell_min;
+        const float* p0 = rows + (size_t)c0 * C + j * BK + c4 * 4;
+        const float* p1 = rows + (size_t)c1 * C + j * BK + c4 * 4;
+        if (!(dbg & 512)) {
+            a00 = *reinterpret_cast<const float4*>(p0);
+            a10 = *reinterpret_cast<const float4*>(p1);
+        }
+        if (!(dbg & 1024)) {
+            b0 = *reinterpret_cast<const float4*>(wsrc + tid * 4);
+            b1 = *reinterpret_cast<const float4*>(wsrc + (tid + 256) * 4);
+        }
+        if constexpr (NH == 2) {
+            if (!(dbg & 512)) {
+                a01 = *reinterpret_cast<const float4*>(p0 + 32);
+                a11 = *reinterpret_cast<const float4*>(p1 + 32);
+            }
+            if (!(dbg & 1024)) {
+                b2 = *reinterpret_cast<const float4*>(wsrc + (tid + 512) * 4);
+                b3 = *reinterpret_cast<const float4*>(wsrc + (tid + 768) * 4);
+            }
+        }
+    };
+    auto put_a = [&](float* dst, const float4& v, bool on) {   // per component: float4 selects are lowered through scratch
+        *reinterpret_cast<float4*>(dst) = make_float4(on ? v.x : 0.f, on ? v.y : 0.f, on ? v.z : 0.f, on ? v.w : 0.f);
+    };
+    auto put_b = [&](float* sb, int q, const float4& v) {      // weight tile [64][BK] contiguous: float4 index tid + 256 q
+        const int i4 = tid + 256 * q, row = i4 / (BK / 4), col4 = i4 % (BK / 4);
+        *reinterpret_cast<float4*>(sb + row * RS + col4 * 4) = v;
+    };
+    auto store = [&](int buf, int t) {        // the mask is applied HERE: a select next to the load would wait for it at once
+        const int tp = t == 9 ? 4 : t;
+        const bool on0 = (pm0 >> tp) & 1, on1 = (pm1 >> tp) & 1;
+        put_a(&sA[buf][r0 * RS + c4 * 4], a00, on0);
+        put_a(&sA[buf][(r0 + 32) * RS + c4 * 4], a10, on1);
+        put_b(sB[buf], 0, b0);
+        put_b(sB[buf], 1, b1);
+        if constexpr (NH == 2) {
+            put_a(&sA[buf][r0 * RS + 32 + c4 * 4], a01, on0);
+            put_a(&sA[buf][(r0 + 32) * RS + 32 + c4 * 4], a11, on1);
+            put_b(sB[buf], 2, b2);
+            put_b(sB[buf], 3, b3);
+        }
+    };
+    if (n_it > 0) {
+        first_tap();
+        load(it_tap, it_ch);
+        store(0, it_tap);
+    }
+    __syncthreads();
+    for (int it = 0; it < n_it; ++it) {
+        const int buf = it & 1, t_cur = it_tap;
+        next_it();                                        // (it_tap, it_ch) now name iteration it + 1
+        if (it + 1 < n_it) load(it_tap, it_ch);           // in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        float af[KH], bf[KH];
+        {
+            const float* p = &sA[buf][(wm * 32 + li) * RS + KH * h];
+            const float* q = &sB[buf][(wn * 32 + li) * RS + KH * h];
+#pragma unroll
+            for (int k = 0; k < KH / 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(p + 4 * k);
+                af[4 * k] = v.x; af[4 * k + 1] = v.y; af[4 * k + 2] = v.z; af[4 * k + 3] = v.w;
+                const float4 u = *reinterpret_cast<const float4*>(q + 4 * k);
+                bf[4 * k] = u.x; bf[4 * k + 1] = u.y; bf[4 * k + 2] = u.z; bf[4 * k + 3] = u.w;
+            }
+        }
+        if (dbg & 256) {
+        } else if (t_cur == 9) {
+#pragma unroll
+            for (int s = 0; s < KH; ++s) acc_d[s & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc_d[s & 1], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KH; ++s) acc_m[s & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc_m[s & 1], 0, 0, 0);
+        }
+        if (it + 1 < n_it) store(buf ^ 1, it_tap);
+        __syncthreads();
+    }
+
+    // epilogue: accumulators (C/D layout of 32x32: column = lane & 31 = channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = pixel)
+    // -> sC[channel][pixel] (stride 65: conflict-free writes) -> 16-B NCHW stores; the conv1 half first, then the downsample half
+    constexpr int CS = 65;
+    float* sC = s_all;
+    static_assert(sizeof(s_all) >= (size_t)64 * CS * 4, "epilogue tile must fit the operand rings");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sC[(wn * 32 + li) * CS + px] = half ? acc_d[0][r] + acc_d[1][r] : acc_m[0][r] + acc_m[1][r];
+        }
+        __syncthreads();
+        const float* __restrict__ bias = half ? bds : bmain;
+        float* __restrict__ outp = half ? out_id : out_main;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, co = idx >> 4, p4 = idx & 15, px = p4 * 4;
+            if (ox0 + px >= Wo) continue;         // Wo % 4 == 0 (host)
+            const float* sp = &sC[co * CS + px];
+            const float bv = bias ? bias[co] : 0.f;
+            float4 v = make_float4(sp[0] + bv, sp[1] + bv, sp[2] + bv, sp[3] + bv);
+            if (!half) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(outp + (((size_t)b * 64 + co) * Ho + oy) * Wo + ox0 + px) = v;
+        }
     }
 }
 
@@ -679,6 +992,7 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     LssGeom g;
     for (int k = 0; k < 3; ++k) {
         g.dx[k] = dx_host[k];
+        g.rdx[k] = 1.f / dx_host[k];
         g.lo[k] = bx_host[k] - dx_host[k] / 2.f;  // (self.bx - self.dx/2.) in fp32
         g.nx[k] = nx_host[k];
         HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool: empty grid");
@@ -725,14 +1039,45 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
 }
 
 
-// ---- pixel-major entry point (the production path) ---------------------------------------------------------------------
+// ---- pixel-major entry points (the production path) ---------------------------------------------------------------------
 namespace heal {
-struct LssPmWs { float* rows; int* flags; int* state; };
 static bool carve_pm(Arena& a, int channels, int cells_total, LssPmWs& w) {
-    w.state = a.take<int>(64);                                   // {generation, tag of the call in flight}
-    w.flags = a.take<int>(cells_total);
-    w.rows = a.take<float>(((size_t)cells_total + 1) * channels);
+    w.state = a.take<int>(64);                                   // {generation consumed, tag of the call in flight}
+    for (int h = 0; h < 2; ++h) w.flags[h] = a.take<int>(cells_total);
+    for (int h = 0; h < 2; ++h) w.rows[h] = a.take<float>((size_t)cells_total * channels);
     return a.ok();
+}
+
+static int pm_geometry(int n_agents, int channels, const float* dx_host, const float* bx_host, const int32_t* nx_host,
+                       LssGeom& g, int& cells_total) {
+    HEAL_REQUIRE(channels >= 16 && channels <= 256 && channels % 16 == 0,
+                 "bev_pool_pm: channels must be a multiple of 16 in [16,256] (got %d)", channels);
+    for (int k = 0; k < 3; ++k) {
+        g.dx[k] = dx_host ? dx_host[k] : 1.f;
+        g.rdx[k] = 1.f / g.dx[k];
+        g.lo[k] = dx_host ? bx_host[k] - dx_host[k] / 2.f : 0.f;  // (self.bx - self.dx/2.) in fp32
+        g.nx[k] = nx_host[k];
+        HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool_pm: empty grid");
+    }
+    HEAL_REQUIRE((g.nx[0] * g.nx[1]) % 4 == 0, "bev_pool_pm: nx*ny must be a multiple of 4");
+    const int64_t cells_total64 = (int64_t)g.nx[0] * g.nx[1] * g.nx[2] * n_agents;
+    HEAL_REQUIRE(n_agents >= 1 && cells_total64 < (1ll << 30), "bev_pool_pm: problem too large");
+    cells_total = (int)cells_total64;
+    return 0;
+}
+
+template <int NDT>
+static int launch_scatter(const float* head, int head_stride, const float* frustum, const float* cam_mats, const LssGeom& g,
+                          const LssPmWs& w, int cells_total, size_t lds, int dbg, hipStream_t s) {
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per kernel (gfx950: 160 KB per CU)
+    if (!attr_set) {
+        HEAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lss_scatter<NDT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    k_lss_scatter<NDT><<<dim3(g.fW, g.n_agents * g.n_cams), 256 * NDT, lds, s>>>(
+        head, head_stride, frustum, reinterpret_cast<const CamMats*>(cam_mats), g, w, cells_total, dbg);
+    return 0;
 }
 }  // namespace heal
 
@@ -743,50 +1088,99 @@ extern "C" size_t heal_bev_pool_pm_workspace(int n_agents, int channels, int nx,
     return a.off + 256;
 }
 
-extern "C" int heal_bev_pool_pm(const float* head, int head_stride, const float* frustum, const float* cam_mats,
-                                int n_agents, int n_cams, int D, int fH, int fW, int channels, const float* dx_host,
-                                const float* bx_host, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
-                                void* stream) {
+extern "C" int heal_bev_pool_scatter(const float* head, int head_stride, const float* frustum, const float* cam_mats,
+                                     int n_agents, int n_cams, int D, int fH, int fW, int channels, const float* dx_host,
+                                     const float* bx_host, const int32_t* nx_host, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(n_agents >= 1 && n_cams >= 1 && D >= 1 && fH >= 1 && fW >= 1, "bev_pool_pm: bad shape");
-    HEAL_REQUIRE(channels >= 16 && channels <= 256 && channels % 16 == 0,
-                 "bev_pool_pm: channels must be a multiple of 16 in [16,256] (got %d)", channels);
     HEAL_REQUIRE(fH <= 64 && D <= 64, "bev_pool_pm: fH and D must be <= 64 (got %d, %d): use heal_bev_pool", fH, D);
     HEAL_REQUIRE(head_stride >= channels + D && head_stride % 4 == 0 && ((uintptr_t)head & 15) == 0,
                  "bev_pool_pm: head rows must hold C + D floats, 16-B aligned (stride %d)", head_stride);
     HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "bev_pool_pm: workspace must be 256-B aligned");
     HEAL_REQUIRE(D % 4 == 0, "bev_pool_pm: D must be a multiple of 4 (got %d)", D);
-    const size_t lds = ((size_t)((fH + 3) & ~3) * (channels + 16) + (size_t)fH * LSS_LGS) * sizeof(float);
-    HEAL_REQUIRE(lds <= 64 * 1024 - 14 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS budget: use heal_bev_pool", lds);
+    HEAL_REQUIRE(n_agents * n_cams <= 65535, "bev_pool_pm: too many cameras for one launch");
     LssGeom g;
-    for (int k = 0; k < 3; ++k) {
-        g.dx[k] = dx_host[k];
-        g.lo[k] = bx_host[k] - dx_host[k] / 2.f;  // (self.bx - self.dx/2.) in fp32
-        g.nx[k] = nx_host[k];
-        HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool_pm: empty grid");
-    }
+    int cells_total = 0;
+    if (pm_geometry(n_agents, channels, dx_host, bx_host, nx_host, g, cells_total)) return 1;
     g.n_agents = n_agents; g.n_cams = n_cams; g.D = D; g.fH = fH; g.fW = fW; g.C = channels;
-    HEAL_REQUIRE((g.nx[0] * g.nx[1]) % 4 == 0, "bev_pool_pm: nx*ny must be a multiple of 4");
-    const int64_t cells_total64 = (int64_t)g.nx[0] * g.nx[1] * g.nx[2] * n_agents;
-    HEAL_REQUIRE(cells_total64 < (1ll << 30), "bev_pool_pm: problem too large");
-    const int cells_total = (int)cells_total64;
+    const int n_dt = ceil_div(D, LSS_MT);
+    const size_t lds = (size_t)LssLds(fH, channels, n_dt).total * sizeof(float);
+    HEAL_REQUIRE(lds <= 150 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS: use heal_bev_pool", lds);
     Arena a(ws, ws_bytes);
     LssPmWs w;
     HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_pool_pm: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    const int n_dt = ceil_div(D, LSS_MT);
     const char* dbg_env = getenv("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
-    k_lss_scatter<<<dim3(fW * n_dt, n_agents * n_cams), 256, lds, s>>>(head, head_stride, frustum,
-                                                                      reinterpret_cast<const CamMats*>(cam_mats), g, n_dt,
-                                                                      w.rows, w.flags, w.state, dbg);
-    const int cells4 = g.nx[0] * g.nx[1] / 4;
-    const dim3 grid(ceil_div(cells4, 64), channels / 16, n_agents * g.nx[2]);
-    k_lss_canvas<<<grid, 256, 0, s>>>(reinterpret_cast<const int4*>(w.flags), w.rows, cells4, channels,
-                                      reinterpret_cast<float4*>(out), w.state, dbg);
+    int rc = 1;
+    switch (n_dt) {
+        case 1: rc = launch_scatter<1>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
+        case 2: rc = launch_scatter<2>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
+        case 3: rc = launch_scatter<3>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
+        case 4: rc = launch_scatter<4>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
+    }
+    if (rc) return rc;
     HEAL_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int heal_bev_pool_emit(int n_agents, int channels, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    LssGeom g;
+    int cells_total = 0;
+    if (pm_geometry(n_agents, channels, nullptr, nullptr, nx_host, g, cells_total)) return 1;
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)out & 15) == 0, "bev_pool_emit: misaligned workspace / output");
+    Arena a(ws, ws_bytes);
+    LssPmWs w;
+    HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_pool_emit: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    const int cells4 = g.nx[0] * g.nx[1] / 4;
+    const dim3 grid(ceil_div(cells4, 64), channels / 16, n_agents * g.nx[2]);
+    k_lss_canvas<<<grid, 256, 0, (hipStream_t)stream>>>(w, cells4, channels, reinterpret_cast<float4*>(out), cells_total);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_bev_pool_pm(const float* head, int head_stride, const float* frustum, const float* cam_mats,
+                                int n_agents, int n_cams, int D, int fH, int fW, int channels, const float* dx_host,
+                                const float* bx_host, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (heal_bev_pool_scatter(head, head_stride, frustum, cam_mats, n_agents, n_cams, D, fH, fW, channels, dx_host, bx_host,
+                              nx_host, ws, ws_bytes, stream))
+        return 1;
+    return heal_bev_pool_emit(n_agents, channels, nx_host, out, ws, ws_bytes, stream);
+}
+
+extern "C" int heal_bev_stem_block(int n_agents, int channels, const int32_t* nx_host, const float* w_main,
+                                   const float* b_main, const float* w_down, const float* b_down, float* out_main,
+                                   float* out_identity, void* ws, size_t ws_bytes, void* stream) {
+    LssGeom g;
+    int cells_total = 0;
+    if (pm_geometry(n_agents, channels, nullptr, nullptr, nx_host, g, cells_total)) return 1;
+    HEAL_REQUIRE(g.nx[2] == 1, "bev_stem_block: the pooled map must have one z bin (got %d)", g.nx[2]);
+    HEAL_REQUIRE(channels % 32 == 0, "bev_stem_block: channels must be a multiple of 32 (got %d)", channels);
+    HEAL_REQUIRE(w_main && w_down && out_main && out_identity, "bev_stem_block: null pointer");
+    const int Ho = (g.nx[1] - 1) / 2 + 1, Wo = (g.nx[0] - 1) / 2 + 1;
+    HEAL_REQUIRE(Wo % 4 == 0, "bev_stem_block: output width must be a multiple of 4 (got %d)", Wo);
+    HEAL_REQUIRE((((uintptr_t)w_main | (uintptr_t)w_down | (uintptr_t)out_main | (uintptr_t)out_identity) & 15) == 0 &&
+                     ((uintptr_t)ws & 255) == 0, "bev_stem_block: 16-B alignment");
+    Arena a(ws, ws_bytes);
+    LssPmWs w;
+    HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_stem_block: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    const char* dbg_env = getenv("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const int tiles_x = ceil_div(Wo, 64);
+    const int64_t blocks = (int64_t)n_agents * Ho * tiles_x;
+    HEAL_REQUIRE(blocks < (1ll << 31), "bev_stem_block: grid too large");
+    if (channels % 64 == 0)
+        k_bev_stem<64><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(w, channels, g.nx[0], g.nx[1], cells_total, w_main,
+                                                                          b_main, w_down, b_down, out_main, out_identity, Ho,
+                                                                          Wo, tiles_x, dbg);
+    else
+        k_bev_stem<32><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(w, channels, g.nx[0], g.nx[1], cells_total, w_main,
+                                                                          b_main, w_down, b_down, out_main, out_identity, Ho,
+                                                                          Wo, tiles_x, dbg);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
 namespace heal {
 // ---- backward of the lift + splat (training) ----------------------------------------------------------------
 // Forward: out[cell(cam, d, v, u)][c] += p[cam, d, v, u] * f[cam, c, v, u],  p = softmax_d(logit[cam, :, v, u]).
@@ -859,6 +1253,7 @@ extern "C" int heal_bev_pool_backward(const float* grad_cells, const float* dept
     LssGeom g;
     for (int k = 0; k < 3; ++k) {
         g.dx[k] = dx_host[k];
+        g.rdx[k] = 1.f / dx_host[k];
         g.lo[k] = bx_host[k] - dx_host[k] / 2.f;
         g.nx[k] = nx_host[k];
         HEAL_REQUIRE(g.nx[k] >= 1, "bev_pool_backward: empty grid");

@@ -1,5 +1,6 @@
 // Device-wide scan and stable radix sort (see prims.h).  gfx950, wave = 64.
 #include "prims.h"
+#include "../../include/heal_amd.h"
 
 namespace heal {
 
@@ -204,6 +205,6 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int n, int key_bits, 
 }  // namespace heal
 
 extern "C" {
-int heal_abi_version(void) { return 1; }
+int heal_abi_version(void) { return HEAL_AMD_ABI_VERSION; }
 const char* heal_last_error(void) { return heal::err_buf(); }
 }

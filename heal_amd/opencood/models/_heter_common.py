@@ -34,6 +34,9 @@ def modality_stems(model, args, make_backbone):
         setattr(model, f"encoder_{m}", find_encoder(setting["core_method"])(setting["encoder_args"]))
         setattr(model, f"depth_supervision_{m}", bool(setting["encoder_args"].get("depth_supervision", False)))
         setattr(model, f"backbone_{m}", make_backbone(setting))
+        enc, bb = getattr(model, f"encoder_{m}"), getattr(model, f"backbone_{m}")
+        if hasattr(enc, "emit_pooled") and getattr(bb, "takes_pooled", lambda: False)():
+            enc.emit_pooled = True      # K4 hands its sparse pixel-major map straight to the backbone's first block
         if setting["sensor_type"] == "camera":
             grid = setting["camera_mask_args"]["grid_conf"]
             setattr(model, f"crop_ratio_W_{m}", model.cav_range[3] / grid["xbound"][1])

@@ -228,14 +228,19 @@ class LiftSplatShoot(nn.Module):
         return ops.camera_matrices(rots, trans, intrins, post_rots, post_trans)
 
     _pixel_major_pool = True
+    # Set by the owning model when what follows is a ResNetBEVBackbone whose first block reads the sparse pixel-major map
+    # (bev_blocks.BasicBlock.takes_pooled): forward() then returns ops.PooledBEV instead of the dense [B, C*nz, ny, nx]
+    # tensor and the canvas is never written (HEAL_K4_POOLED=0 keeps the dense hand-off for A/B).
+    emit_pooled = False
 
     def pool(self, depth_logit, x_img, cam_mats, B, N):
         return ops.bev_pool(depth_logit, x_img, self.frustum(x_img.device), cam_mats, B, N, self.dx_host,
                             self.bx_host, self.nx_host)
 
     def pool_pixel_major(self, head, cam_mats, B, N, fH, fW):
+        pooled = self.emit_pooled and self.nx_host[2] == 1 and os.environ.get("HEAL_K4_POOLED", "1") == "1"
         return ops.bev_pool_pm(head, self.camC, self.D, fH, fW, self.frustum(head.device), cam_mats, B, N, self.dx_host,
-                               self.bx_host, self.nx_host)
+                               self.bx_host, self.nx_host, pooled=pooled)
 
     def lift_pool_autograd(self, depth_logit, x_img, inp, B, N):
         """Gradient path of get_geometry + voxel_pooling (heter_encoders.py:125-217) with torch operators: ego coordinates of

@@ -170,7 +170,35 @@ class BasicBlock(nn.Module):
         self.stride = stride
         self._c1, self._c2, self._cd = _FoldCache(), _FoldCache(), _FoldCache()
 
+    def takes_pooled(self):
+        """True if this block can read K4's sparse pixel-major map (ops.PooledBEV) directly: conv1 3x3 stride 2 pad 1 and a
+        1x1 stride-2 downsample, both to 64 channels -- the opening block of the camera modalities' ResNetBEVBackbone
+        (heal_bev_stem_block; the dense [C, ny, nx] canvas is then never written)."""
+        d = self.downsample
+        return (d is not None and isinstance(d[0], nn.Conv2d) and d[0].kernel_size == (1, 1) and d[0].stride == (2, 2)
+                and d[0].padding == (0, 0) and d[0].out_channels == 64 and d[0].bias is None
+                and self.conv1.stride == (2, 2) and self.conv1.out_channels == 64 and self.conv1.in_channels % 32 == 0
+                and isinstance(self.bn1, nn.BatchNorm2d) and isinstance(d[1], nn.BatchNorm2d))
+
+    def _stem_params(self):
+        from heal_amd import ops
+        w1, b1 = self._c1.get(self.conv1, self.bn1)
+        wd, bd = self._cd.get(self.downsample[0], self.downsample[1])
+        key = (self._c1.key, self._cd.key)
+        if getattr(self, "_stem_key", None) != key:
+            self._stem = ops.stem_fragments(w1, wd) + (b1, bd)
+            self._stem_key = key
+        return self._stem
+
     def forward(self, x):
+        from heal_amd import ops
+        if isinstance(x, ops.PooledBEV):
+            if (not grad_path(None, self) and self.takes_pooled() and x.channels == self.conv1.in_channels
+                    and x.stem_supported(self.conv1.out_channels, self.downsample[0].out_channels)):
+                wm, wd, b1, bd = self._stem_params()
+                out, identity = x.stem_block(wm, b1, wd, bd)
+                return ConvBN.run(out, self.conv2, self.bn2, self._c2, relu=True, residual=identity)
+            x = x.dense()
         identity = x
         if self.downsample is not None:
             identity = ConvBN.run(x, self.downsample[0], self.downsample[1], self._cd, relu=False)
@@ -370,6 +398,11 @@ class ResNetBEVBackbone(nn.Module):
                 nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
                 nn.BatchNorm2d(c_in, eps=1e-3, momentum=0.01)))
         self.num_bev_features = c_in
+
+    def takes_pooled(self):
+        """True if the first block reads K4's sparse pixel-major map directly (BasicBlock.takes_pooled)."""
+        first = getattr(self.resnet, "layer0", None)
+        return first is not None and len(first) > 0 and isinstance(first[0], BasicBlock) and first[0].takes_pooled()
 
     def get_multiscale_feature(self, spatial_features):
         return self.resnet(spatial_features)

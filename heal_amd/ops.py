@@ -628,14 +628,87 @@ def _frustum_separable(frustum):
 
 def bev_pool_pm_supported(D, fH, C):
     import os
+    mtot = (D + 15) // 16 * 16
+    fh4 = (fH + 3) // 4 * 4
+    lds = (fh4 * (C + 16) + 2 * mtot * 66) * 4   # LssLds, bev_pool.hip
     return (os.environ.get("HEAL_LSS_PATH", "") != "sorted" and fH <= 64 and D <= 64 and D % 4 == 0 and C % 16 == 0
-            and 16 <= C <= 256 and (((fH + 3) // 4 * 4) * (C + 16) + fH * 65) * 4 <= 50 * 1024)
+            and 16 <= C <= 256 and lds <= 150 * 1024)
 
 
-def bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
+class PooledBEV:
+    """The SPARSE PIXEL-MAJOR BEV map heal_bev_pool_scatter leaves in its workspace: rows[cell][C] for the cells any lifted point
+    fell into + a generation-tagged flag per cell (include/heal_amd.h, K4).  It stands for the reference's dense
+    [n_agents, C*nz, ny, nx] `voxel_pooling` result (heter_encoders.py:161-217) until somebody needs it:
+
+      * `stem_block(...)` -- the first BasicBlock of the camera ResNetBEVBackbone reads the rows through the flags, the dense
+        canvas is never written;
+      * `dense()` -- everybody else gets the reference's tensor (one streaming launch).
+
+    Exactly one of the two may be called, once: the consumer hands the workspace half back to the next scatter."""
+
+    def __init__(self, ws, n_agents, channels, nx):
+        self.ws, self.n_agents, self.channels, self.nx = ws, int(n_agents), int(channels), [int(v) for v in nx]
+        self.device = ws.device
+        self._consumed = False
+
+    @property
+    def shape(self):
+        return (self.n_agents, self.channels * self.nx[2], self.nx[1], self.nx[0])
+
+    @property
+    def is_cuda(self):
+        return True
+
+    def _take(self):
+        if self._consumed:
+            raise _capi.HealAmdError("PooledBEV: the pooled map was already consumed (one consumer per bev_pool scatter)")
+        self._consumed = True
+
+    def dense(self):
+        self._take()
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        with _Timed("bev_pool_emit"):
+            _capi.call("heal_bev_pool_emit", self.n_agents, self.channels, _host_array(self.nx, ctypes.c_int32), _ptr(out),
+                       _ptr(self.ws), self.ws.numel(), _stream())
+        return out
+
+    def stem_supported(self, cout_main, cout_down):
+        return (self.nx[2] == 1 and self.channels % 32 == 0 and cout_main == 64 and cout_down == 64
+                and ((self.nx[0] - 1) // 2 + 1) % 4 == 0)
+
+    def stem_block(self, w_main, b_main, w_down, b_down):
+        """relu(conv3x3_s2(x, W1) + b1), conv1x1_s2(x, Wd) + bd from the sparse map; w_main / w_down in the layouts of
+        stem_fragments()."""
+        self._take()
+        Ho, Wo = (self.nx[1] - 1) // 2 + 1, (self.nx[0] - 1) // 2 + 1
+        out_main = torch.empty((self.n_agents, 64, Ho, Wo), dtype=torch.float32, device=self.device)
+        out_id = torch.empty_like(out_main)
+        cin = self.channels
+        flops = 2.0 * self.n_agents * Ho * Wo * 64 * cin * 10
+        with _Timed("bev_stem_block", flops=flops):
+            _capi.call("heal_bev_stem_block", self.n_agents, cin, _host_array(self.nx, ctypes.c_int32), _ptr(w_main),
+                       _ptr(b_main), _ptr(w_down), _ptr(b_down), _ptr(out_main), _ptr(out_id), _ptr(self.ws), self.ws.numel(),
+                       _stream())
+        return out_main, out_id
+
+
+def stem_fragments(w_main, w_down):
+    """Weights of heal_bev_stem_block: w_main [64, C, 3, 3] -> [9][C/K][64][K] (tap = ky*3 + kx, K-channel chunk, cout,
+    channel in chunk); w_down [64, C, 1, 1] -> [C/K][64][K]; K = 64 when C % 64 == 0, else 32."""
+    co, c = int(w_main.shape[0]), int(w_main.shape[1])
+    if co != 64 or c % 32 != 0 or tuple(w_main.shape[2:]) != (3, 3) or tuple(w_down.shape) != (64, c, 1, 1):
+        raise _capi.HealAmdError("stem_fragments: expected [64, C, 3, 3] and [64, C, 1, 1] with C % 32 == 0")
+    k = 64 if c % 64 == 0 else 32          # K chunk of k_bev_stem
+    wm = w_main.detach().to(torch.float32).reshape(64, c // k, k, 9).permute(3, 1, 0, 2).contiguous()
+    wd = w_down.detach().to(torch.float32).reshape(64, c // k, k).permute(1, 0, 2).contiguous()
+    return wm, wd
+
+
+def bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx, nx, pooled=False):
     """K4, production path.  head [n_agents*n_cams, fH*fW, >= C + D] f32 cuda, PIXEL-MAJOR: per pixel the C image features
     followed by the D depth logits (what conv1x1(..., pixel_major=True) of the fused image_head | depth_head weight
-    writes); frustum [D,fH,fW,3]; cam_mats [n_agents*n_cams,27] -> [n_agents, C*nz, ny, nx]."""
+    writes); frustum [D,fH,fW,3]; cam_mats [n_agents*n_cams,27] -> [n_agents, C*nz, ny, nx], or with pooled=True the
+    PooledBEV hand-off (sparse pixel-major map; its consumer decides whether the dense tensor is ever written)."""
     head = _need(head, torch.float32, "head")
     frustum = _need(frustum, torch.float32, "frustum")
     cam_mats = _need(cam_mats, torch.float32, "cam_mats")
@@ -647,16 +720,17 @@ def bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx,
         raise _capi.HealAmdError("bev_pool_pm: shape / frustum outside the fused path (use bev_pool)")
     nxi = [int(v) for v in nx]
     dev = head.device
-    out = torch.empty((n_agents, C * nxi[2], nxi[1], nxi[0]), dtype=torch.float32, device=dev)
     nbytes = _capi.query("heal_bev_pool_pm_workspace", n_agents, C, nxi[0], nxi[1], nxi[2])
-    # one scratch per problem shape: the zero-on-exit invariant holds for ONE carving of the buffer only
+    # one scratch per problem shape: the two-half invariant holds for ONE carving of the buffer only
     ws = _workspace_zeroed(("bev_pool_pm", n_agents, C, nxi[0], nxi[1], nxi[2]), nbytes, dev)
-    with _Timed("bev_pool"):
-        _capi.call("heal_bev_pool_pm", _ptr(head), CT, _ptr(frustum), _ptr(cam_mats), n_agents, n_cams, D, fH, fW, C,
+    nbytes_alg = 4.0 * (BN * HW * (C + D)) + 4.0 * n_agents * C * nxi[0] * nxi[1] * nxi[2]
+    with _Timed("bev_pool", nbytes=nbytes_alg):
+        _capi.call("heal_bev_pool_scatter", _ptr(head), CT, _ptr(frustum), _ptr(cam_mats), n_agents, n_cams, D, fH, fW, C,
                    _host_array([float(v) for v in dx], ctypes.c_float),
                    _host_array([float(v) for v in bx], ctypes.c_float),
-                   _host_array(nxi, ctypes.c_int32), _ptr(out), _ptr(ws), ws.numel(), _stream())
-    return out
+                   _host_array(nxi, ctypes.c_int32), _ptr(ws), ws.numel(), _stream())
+    handle = PooledBEV(ws, n_agents, C, nxi)
+    return handle if pooled else handle.dense()
 
 
 def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):

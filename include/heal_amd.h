@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HEAL_AMD_ABI_VERSION 1
+#define HEAL_AMD_ABI_VERSION 2
 
 int heal_abi_version(void);
 const char* heal_last_error(void);
@@ -184,15 +184,28 @@ int heal_quad_iou(const float* a, int n, const float* b, int m, float* iou, void
  *   out [n_agents, C*nz, ny, nx] f32, every element written
  *   heal_bev_pool takes the reference's NCHW tensors and runs the bit-reproducible radix-sort pipeline (stable sort of
  *   the 590 k lifted points by cell, segmented reduction in point order): any shape, ~10 launches.
- *   heal_bev_pool_pm is the production path (two launches): `head` [n_agents*n_cams, fH*fW, head_stride] is the PIXEL-MAJOR
+ *   heal_bev_pool_pm is the pixel-major path the models run: `head` [n_agents*n_cams, fH*fW, head_stride] is the PIXEL-MAJOR
  *   output of the fused image_head | depth_head convolution (heal_conv1x1 out_pixel_major): per pixel C image features
  *   followed by D depth logits (head_stride >= C + D floats); fH <= 64, D <= 64, a separable frustum (frustum[d][v][u] =
  *   (xs[u], ys[v], ds[d]), what create_frustum builds).  Within one image column (camera, u, depth bin) the summation
  *   order is fixed; across columns that feed the same cell it adds with fp32 hardware atomics, so a result can differ in
  *   the last bit from call to call (like the reference's unstable argsort + cumsum difference).
- *   SCRATCH CONTRACT of heal_bev_pool_pm: `ws` must be ZERO-FILLED before its first use and must not be written by anyone
- *   else; every call leaves it in the state the next call needs (rows zeroed behind the reads, generation-tagged flags),
- *   so no memset is ever launched.
+ *   It is two steps that can also be called separately:
+ *     heal_bev_pool_scatter   ONE launch: lift + splat into the SPARSE PIXEL-MAJOR BEV map kept in `ws`: rows[cell][C] for the
+ *                             cells any point fell into + a generation-tagged flag per cell (a level rig touches <= n_cams*fW*D
+ *                             of the ny*nx cells: 19 % at BASELINE size);
+ *     then EXACTLY ONE consumer of that map, before the next scatter into the same `ws`:
+ *     heal_bev_pool_emit      the dense [n_agents, C*nz, ny, nx] tensor of the reference (every element written), or
+ *     heal_bev_stem_block     the first BasicBlock of the camera ResNetBEVBackbone read straight from the sparse map
+ *                             (base_bev_backbone_resnet.py:88-109, resblock.py:18-64 with stride 2 and a 1x1 downsample):
+ *                             out_main = relu(conv3x3_s2(x, W1) + b1), out_identity = conv1x1_s2(x, Wd) + bd, both
+ *                             [n_agents, 64, ny/2, nx/2] NCHW; BN folded into (W, b) by the caller; nz = 1, C % 32 == 0;
+ *                             w_main [9][C/K][64][K] (tap = ky*3+kx, K-channel chunk, cout, channel in chunk) and
+ *                             w_down [C/K][64][K] with K = 64 when C % 64 == 0, else 32.  The dense canvas is never
+ *                             materialised.
+ *   SCRATCH CONTRACT: `ws` must be ZERO-FILLED before its first use and must not be written by anyone else.  It holds two
+ *   (rows, flags) halves used by alternating calls; the consumer of a scatter zeroes, as side work of its own launch, the
+ *   rows the PREVIOUS scatter tagged in the other half, so no memset is ever launched.
  * -----------------------------------------------------------------------------------------------*/
 /* heal_camera_matrices: the per-camera 3x3 algebra of get_geometry (heter_encoders.py:137-146): fills the `cam_mats`
  *   rows consumed by heal_bev_pool from rots/intrins/post_rots [n,3,3] and trans/post_trans [n,3] (all f32 device),
@@ -206,6 +219,14 @@ int heal_bev_pool(const float* depth_logit, const float* feat, const float* frus
                   const float* dx_host, const float* bx_host, const int32_t* nx_host,
                   float* out, void* ws, size_t ws_bytes, void* stream);
 size_t heal_bev_pool_pm_workspace(int n_agents, int channels, int nx, int ny, int nz);
+int heal_bev_pool_scatter(const float* head, int head_stride, const float* frustum, const float* cam_mats, int n_agents,
+                          int n_cams, int D, int fH, int fW, int channels, const float* dx_host, const float* bx_host,
+                          const int32_t* nx_host, void* ws, size_t ws_bytes, void* stream);
+int heal_bev_pool_emit(int n_agents, int channels, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
+                       void* stream);
+int heal_bev_stem_block(int n_agents, int channels, const int32_t* nx_host, const float* w_main, const float* b_main,
+                        const float* w_down, const float* b_down, float* out_main, float* out_identity, void* ws,
+                        size_t ws_bytes, void* stream);
 int heal_bev_pool_pm(const float* head, int head_stride, const float* frustum, const float* cam_mats, int n_agents,
                      int n_cams, int D, int fH, int fW, int channels, const float* dx_host, const float* bx_host,
                      const int32_t* nx_host, float* out, void* ws, size_t ws_bytes, void* stream);

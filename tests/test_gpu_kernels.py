@@ -853,10 +853,24 @@ def test_conv1x1_pixel_major_output_equals_nchw(n, cin, cout, H, W, act):
     assert torch.equal(nb.view(n, H, W, cout).permute(0, 3, 1, 2), ops.conv1x1(x, w, None, None, act))
 
 
+def _pm_ws_views(ws, n_cells, C):
+    """(state words, flags[2], rows[2]) views of a heal_bev_pool_pm workspace (carve_pm, csrc/bev_pool.hip)."""
+    al = lambda n: (n + 255) // 256 * 256
+    words = ws.view(torch.int32)
+    off = 256
+    flags, rows = [], []
+    for _ in range(2):
+        flags.append(ws[off:off + n_cells * 4].view(torch.int32)); off += al(n_cells * 4)
+    for _ in range(2):
+        rows.append(ws[off:off + n_cells * C * 4].view(torch.float32).view(n_cells, C)); off += al(n_cells * C * 4)
+    return words, flags, rows
+
+
 def test_bev_pool_pm_scratch_is_self_cleaning_and_repeatable():
-    """heal_bev_pool_pm never memsets: rows are zeroed behind the canvas reads and cells are tagged by generation.  Calls on
-    different inputs interleaved (dense scene, empty scene: every point out of range, dense again) must each equal a fresh
-    evaluation, and the scratch must be all-zero rows after every call."""
+    """heal_bev_pool_pm never memsets: calls alternate between the two (rows, flags) halves of the workspace, cells are tagged
+    by generation, and every scatter zeroes -- as tail work of its own launch -- the rows its predecessor tagged in the other
+    half.  Calls on different inputs interleaved (dense scene, empty scene: every point out of range, dense again) must each
+    equal a fresh evaluation; after call g the half g & 1 holds exactly the pooled rows and the other half is all zero."""
     from heal_amd import ops, synth
     rng = np.random.default_rng(5)
     final_dim, C, D, N = (96, 128), 32, 48, 4
@@ -864,8 +878,9 @@ def test_bev_pool_pm_scratch_is_self_cleaning_and_repeatable():
     frustum = O.create_frustum(list(final_dim), 8, [2, 50, 48], "LID")
     dx, bx, nx = O.gen_dx_bx([-51.2, 51.2, 0.4], [-51.2, 51.2, 0.4], [-10, 10, 20.0])
     rig = synth.camera_rig(0, N, final_dim[0], final_dim[1])
-    outs = []
-    for trial, shift in enumerate((0.0, 1e6, 0.0, 3.0)):
+    n_cells = int(nx[0] * nx[1] * nx[2])
+    gen0 = None
+    for trial, shift in enumerate((0.0, 1e6, 0.0, 3.0, 0.0)):
         cam = {k: v[None].astype(np.float32).copy() for k, v in rig.items()}
         cam["trans"][..., 0] += shift           # 1e6: the whole frustum leaves the grid -> nothing is touched
         dl = rng.standard_normal((N, D, fH, fW)).astype(np.float32)
@@ -877,15 +892,58 @@ def test_bev_pool_pm_scratch_is_self_cleaning_and_repeatable():
         _pool_close(out.cpu().numpy(), ref, max_bad_cells=0, name=f"bev_pool_pm_repeat_{trial}")
         if shift == 1e6:
             assert float(out.abs().max()) == 0.0
-        outs.append(out)
         ws = ops._ZWS[(("bev_pool_pm", 1, C, int(nx[0]), int(nx[1]), int(nx[2])), 0, torch.cuda.current_stream().cuda_stream)]
-        words = ws.view(torch.int32)
+        words, flags, rows = _pm_ws_views(ws, n_cells, C)
         gen = int(words[0].item())
-        assert gen >= trial + 1, gen                           # every call advances the generation
-        assert int(words[1].item()) == gen                     # tag published by the scatter kernel = adopted generation
-        n_cells = int(nx[0] * nx[1] * nx[2])
-        rows = ws[256 + ((n_cells * 4 + 255) // 256) * 256:].view(torch.float32)
-        assert float(rows.abs().max()) == 0.0                  # rows zeroed behind the reads
+        gen0 = gen - trial if gen0 is None else gen0
+        assert gen == gen0 + trial, (gen, gen0, trial)         # every call advances the generation by one
+        assert int(words[1].item()) == gen                     # tag published by the scatter = generation adopted by the consumer
+        assert float(rows[(gen & 1) ^ 1].abs().max()) == 0.0   # the previous call's rows were zeroed by this call's scatter
+        tagged = flags[gen & 1] == gen
+        assert float(rows[gen & 1][~tagged].abs().max() if (~tagged).any() else 0.0) == 0.0   # only tagged cells hold sums
+        want = torch.from_numpy(ref[0].reshape(C, -1).T.copy()).cuda()                       # [cells, C]
+        assert int(tagged.sum()) >= int((want.abs().sum(1) > 0).sum())
+        assert torch.allclose(rows[gen & 1], want, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_agents,C,final_dim,cam_bound", [(1, 128, (384, 512), 51.2), (2, 64, (96, 128), 25.6),
+                                                           (1, 32, (64, 96), 51.2)])
+def test_bev_stem_block_equals_dense_path(n_agents, C, final_dim, cam_bound):
+    """heal_bev_stem_block (first BasicBlock of the camera ResNetBEVBackbone read straight from K4's sparse pixel-major map)
+    against the dense hand-off: same scatter -> heal_bev_pool_emit -> plain PyTorch fp32 convolutions (3x3 stride 2 + ReLU,
+    1x1 stride 2) of the dense [C, ny, nx] canvas.  fp32 MFMA both ways: 1e-4 of the output scale."""
+    from heal_amd import ops, synth
+    g = torch.Generator().manual_seed(C + n_agents)
+    D, N = 48, 4
+    fH, fW = final_dim[0] // 8, final_dim[1] // 8
+    frustum = dev(O.create_frustum(list(final_dim), 8, [2, 50, 48], "LID"))
+    dx, bx, nx = O.gen_dx_bx([-cam_bound, cam_bound, 0.4], [-cam_bound, cam_bound, 0.4], [-10, 10, 20.0])
+    rig = synth.camera_rig(0, N, final_dim[0], final_dim[1])
+    cam = {k: np.tile(v[None], (n_agents,) + (1,) * v.ndim).astype(np.float32) for k, v in rig.items()}
+    mats = _cam_mats(cam)
+    head = torch.randn((n_agents * N, fH * fW, C + D), generator=g).cuda()
+    w1 = (torch.randn((64, C, 3, 3), generator=g) / (9 * C) ** 0.5).cuda()
+    wd = (torch.randn((64, C, 1, 1), generator=g) / C ** 0.5).cuda()
+    b1, bd = torch.randn((64,), generator=g).cuda(), torch.randn((64,), generator=g).cuda()
+    args = (head, C, D, fH, fW, frustum, mats, n_agents, N, dx.tolist(), bx.tolist(), nx.tolist())
+    dense = ops.bev_pool_pm(*args)
+    want_main = torch.relu(torch.nn.functional.conv2d(dense, w1, b1, stride=2, padding=1))
+    want_id = torch.nn.functional.conv2d(dense, wd, bd, stride=2)
+    pooled = ops.bev_pool_pm(*args, pooled=True)
+    assert isinstance(pooled, ops.PooledBEV) and pooled.shape == tuple(dense.shape)
+    assert pooled.stem_supported(64, 64)
+    wm, wdf = ops.stem_fragments(w1, wd)
+    got_main, got_id = pooled.stem_block(wm, b1, wdf, bd)
+    with pytest.raises(Exception):
+        pooled.dense()                                   # one consumer per scatter
+    assert (dense.abs().sum(1) > 0).sum() > 200
+    for got, want in ((got_main, want_main), (got_id, want_id)):
+        assert got.shape == want.shape
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 1e-4, err
+    # the same workspace keeps working for the dense consumer afterwards (generation hand-over by either consumer)
+    again = ops.bev_pool_pm(*args)
+    assert torch.allclose(again, dense, rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("n,cin,cout,H,W", [(2, 48, 24, 8, 8), (4, 96, 16, 12, 16), (1, 16, 96, 24, 32), (3, 240, 40, 6, 8),
