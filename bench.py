@@ -107,16 +107,21 @@ _PMC = None
 
 
 def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary of THIS workload
-    (profiles/r03_pmc_traffic_<workload>.json, scripts/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, bytes =
+    """HBM bytes per launch of a kernel family from the COMMITTED rocprofv3 PMC summary of THIS workload -- a file read, not a
+    measurement of this run (counters need their own rocprofv3 passes; the line says so in `traffic_source`) --
+    (profiles/r0N_pmc_traffic_<workload>.json, scripts/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, bytes =
     2 FETCH + WRITE per the guide's gfx950 correction), or None.  A family that is a SEQUENCE of kernels per launch (K4: scatter
     + canvas) sums the per-dispatch means of its kernels; a family of one kernel with many shapes takes its mean."""
     global _PMC
     if _PMC is None:
         _PMC = {}
     if workload not in _PMC:
-        path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{workload}.json")
-        _PMC[workload] = json.load(open(path))["kernels"] if os.path.exists(path) else {}
+        _PMC[workload] = {}
+        for tag in ("r04", "r03"):      # the newest committed PMC summary of this workload
+            path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{workload}.json")
+            if os.path.exists(path):
+                _PMC[workload] = json.load(open(path))["kernels"]
+                break
     ks = _PMC[workload]
     tot, hit = 0.0, False
     for pre in prefixes:
@@ -132,6 +137,7 @@ def _entry(kernel, bound, achieved, launches, launch_ms, traffic=None, **extra):
     peak = HBM_PEAK_GBS if bound == "hbm" else FP32_PEAK_TFLOPS
     d = {"kernel": kernel, "bound": bound, "achieved": round(achieved, 2), "peak": peak,
          "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+         "traffic_source": None if traffic is None else "committed rocprofv3 PMC summary (profiles/), not measured in this run",
          "launches": launches, "launch_ms": round(launch_ms, 5)}
     d.update(extra)
     return d
@@ -226,10 +232,20 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
                 per_call.append(4.0 * (n_cam * D * fhw + n_cam * C * fhw + C * nz * ny * nx))
             calls, mean_ms = timing["bev_pool"]
             bts = sum(per_call) / len(per_call)
+            extra = {}
+            if "bev_stem_block" in timing:
+                extra["consumer"] = {"kernel": "heal_bev_stem_block (first BasicBlock of the camera backbone reads the sparse map; "
+                                               "fp32 MFMA, not part of K4's duration)", "launch_ms": round(timing["bev_stem_block"][1], 5)}
+            if "bev_pool_emit" in timing:
+                extra["dense_emit"] = {"kernel": "heal_bev_pool_emit (dense canvas for consumers that want it)",
+                                       "launch_ms": round(timing["bev_pool_emit"][1], 5)}
             entries["k4"] = (calls * mean_ms, _entry(
-                "K4 heal_bev_pool_pm, one camera agent per launch (k_lss_scatter + k_lss_canvas; mean over the scene's camera agents)",
+                "K4 heal_bev_pool_scatter, one camera agent per launch (ONE kernel, k_lss_scatter: lift + splat into the sparse "
+                "pixel-major BEV map; duration = the kernel's own begin/end stamps (hipExtLaunchKernelGGL events), mean over the "
+                "scene's camera agents; bytes = SURVEY 8d: logits + features read + the dense [C,ny,nx] map the operator stands for, "
+                "which is no longer written)",
                 "hbm", bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
-                pmc_traffic(a.workload, "heal::k_lss_scatter", "heal::k_lss_canvas"), bytes_per_launch=bts))
+                pmc_traffic(a.workload, "heal::k_lss_scatter"), bytes_per_launch=bts, **extra))
     # K1: 16 N + 16 M P + 20 M bytes per agent, all LiDAR agents of a modality in one launch chain
     if "voxelize" in timing and scene.points:
         calls, mean_ms = timing["voxelize"]

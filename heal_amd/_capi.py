@@ -19,6 +19,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "heal_abi_version": (c_int, []),
     "heal_last_error": (ctypes.c_char_p, []),
+    "heal_next_launch_events": (c_int, [c_void_p, c_void_p]),
     "heal_voxelize_workspace": (c_size_t, [c_int, c_int, c_int]),
     "heal_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -407,7 +407,10 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
     constexpr int W = 4 * NDT, NTHR = 256 * NDT, MTOT = LSS_MT * NDT;
     extern __shared__ float4 smem4[];
     float* smem = reinterpret_cast<float*>(smem4);
-    const LssLds L(g.fH, g.C, NDT);
+    // blockIdx.z: channel slice [c_lo, c_lo + Cb) of the column (gridDim.z slices): with two slices two half-size blocks share a
+    // CU and run out of phase (loads of one under the atomics of the other) at the price of evaluating keys and softmax twice
+    const int Cb = g.C / gridDim.z, c_lo = blockIdx.z * Cb;
+    const LssLds L(g.fH, Cb, NDT);
     float* xs = smem + L.xs;
     float* pk_p = smem + L.pk_p;
     uint32_t* pk_key = reinterpret_cast<uint32_t*>(smem + L.pk_key);
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int LD = L.LD, fH4 = L.fH4;
     const int gen = ws.state[0] + 1;         // tag of this call: >= 1, a zero-filled flag array matches nothing
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     // HEAL_K4_DBG & 128: shader-clock stamps of block 0's first (softmax) and last (keys only) wave -> state[16..] (scripts/k4_stamps.py)
     const bool stamp_on = (dbg & 128) && bid == 0 && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64);
     int* stamp_out = ws.state + 16 + (threadIdx.x == 0 ? 0 : 16);
@@ -459,12 +462,12 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) lg[k] = *reinterpret_cast<const float4*>(lrow + min(sq + 4 * k, d4n - 1) * 4);
     }
-    const int c4n = g.C / 4, ld4 = LD / 4, nX = fH4 * c4n;
+    const int c4n = Cb / 4, ld4 = LD / 4, nX = fH4 * c4n;
     float4 xr[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = min(tid + NTHR * k, nX - 1), r = i / c4n, c4 = i - r * c4n;
-        xr[k] = *reinterpret_cast<const float4*>(hcol + (size_t)min(r, g.fH - 1) * g.fW * CT + c4 * 4);
+        xr[k] = *reinterpret_cast<const float4*>(hcol + (size_t)min(r, g.fH - 1) * g.fW * CT + c_lo + c4 * 4);
     }
 
     LSS_STAMP(0);
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
     }
     for (int i = tid + 4 * NTHR; i < nX; i += NTHR) {   // fH4 * C / 4 > 4 blockDim: the rest of the feature rows
         const int r = i / c4n, c4 = i - r * c4n;
-        smem4[r * ld4 + c4] = r < g.fH ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c4 * 4)
+        smem4[r * ld4 + c4] = r < g.fH ? *reinterpret_cast<const float4*>(hcol + (size_t)r * g.fW * CT + c_lo + c4 * 4)
                                        : float4{0.f, 0.f, 0.f, 0.f};
     }
     LSS_STAMP(3);
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
     uint32_t cell_r[4];                      // D[row = 4 lk + r][col = ln]: the main cell of bin 16 mt + 4 lk + r lives in lane 4 lk + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) cell_r[r] = __shfl(m, lk * 4 + r, 64);
-    const int n_tiles = g.C / 16;
+    const int n_tiles = Cb / 16;
     for (int nt = nq; nt < n_tiles; nt += 4) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* xb = xs + lk * LD + nt * 16 + ln;
@@ -594,8 +597,8 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
         for (int r = 0; r < 4; ++r) {
             const uint32_t cell = cell_r[r];
             if (dbg & 2) continue;
-            if (dbg & 4) { if (cell != LSS_NOKEY) rows[(size_t)cell * g.C + nt * 16 + ln] = acc[r]; continue; }
-            if (cell != LSS_NOKEY) unsafeAtomicAdd(rows + (size_t)cell * g.C + nt * 16 + ln, acc[r]);
+            if (dbg & 4) { if (cell != LSS_NOKEY) rows[(size_t)cell * g.C + c_lo + nt * 16 + ln] = acc[r]; continue; }
+            if (cell != LSS_NOKEY) unsafeAtomicAdd(rows + (size_t)cell * g.C + c_lo + nt * 16 + ln, acc[r]);
         }
     }
 
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
             todo &= todo - 1;
             const int dd = mt * LSS_MT + bl;
             const uint32_t skip = __shfl(m, bl, 64);
-            for (int c0 = 0; c0 < g.C; c0 += 64) {
+            for (int c0 = 0; c0 < Cb; c0 += 64) {
                 const int c = c0 + l;
                 float acc = 0.f;
                 uint32_t cur = LSS_NOKEY;
@@ -619,13 +622,13 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
                     if (key == skip) key = LSS_NOKEY;
                     if (key != cur) {
                         if (cur != LSS_NOKEY) {
-                            if (c < g.C) unsafeAtomicAdd(rows + (size_t)cur * g.C + c, acc);
+                            if (c < Cb) unsafeAtomicAdd(rows + (size_t)cur * g.C + c_lo + c, acc);
                             if (l == 0 && c0 == 0) flags[cur] = gen;
                         }
                         acc = 0.f;
                         cur = key;
                     }
-                    if (cur != LSS_NOKEY && c < g.C) acc += pk_p[dd * LSS_PKS + vv] * xs[vv * LD + c];
+                    if (cur != LSS_NOKEY && c < Cb) acc += pk_p[dd * LSS_PKS + vv] * xs[vv * LD + c];
                 }
             }
         }
@@ -1068,15 +1071,15 @@ static int pm_geometry(int n_agents, int channels, const float* dx_host, const f
 
 template <int NDT>
 static int launch_scatter(const float* head, int head_stride, const float* frustum, const float* cam_mats, const LssGeom& g,
-                          const LssPmWs& w, int cells_total, size_t lds, int dbg, hipStream_t s) {
+                          const LssPmWs& w, int cells_total, size_t lds, int csplit, int dbg, hipStream_t s) {
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per kernel (gfx950: 160 KB per CU)
     if (!attr_set) {
         HEAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lss_scatter<NDT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    k_lss_scatter<NDT><<<dim3(g.fW, g.n_agents * g.n_cams), 256 * NDT, lds, s>>>(
-        head, head_stride, frustum, reinterpret_cast<const CamMats*>(cam_mats), g, w, cells_total, dbg);
+    HEAL_LAUNCH_EV(k_lss_scatter<NDT>, dim3(g.fW, g.n_agents * g.n_cams, csplit), dim3(256 * NDT), lds, s, head, head_stride, frustum,
+                   reinterpret_cast<const CamMats*>(cam_mats), g, w, cells_total, dbg);
     return 0;
 }
 }  // namespace heal
@@ -1104,7 +1107,11 @@ extern "C" int heal_bev_pool_scatter(const float* head, int head_stride, const f
     if (pm_geometry(n_agents, channels, dx_host, bx_host, nx_host, g, cells_total)) return 1;
     g.n_agents = n_agents; g.n_cams = n_cams; g.D = D; g.fH = fH; g.fW = fW; g.C = channels;
     const int n_dt = ceil_div(D, LSS_MT);
-    const size_t lds = (size_t)LssLds(fH, channels, n_dt).total * sizeof(float);
+    // channel slices per column (grid.z).  Measured NEGATIVE at BASELINE size (HEAL_K4_CSPLIT=2: 14.9 vs 13.3 us for m2, 13.8 vs
+    // 12.1 for m4): the duplicated keys + softmax cost more than the two half-size blocks per CU gain by running out of phase.
+    int csplit = 1;
+    if (const char* e = getenv("HEAL_K4_CSPLIT")) csplit = atoi(e) == 2 && channels % 32 == 0 ? 2 : 1;
+    const size_t lds = (size_t)LssLds(fH, channels / csplit, n_dt).total * sizeof(float);
     HEAL_REQUIRE(lds <= 150 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS: use heal_bev_pool", lds);
     Arena a(ws, ws_bytes);
     LssPmWs w;
@@ -1113,10 +1120,10 @@ extern "C" int heal_bev_pool_scatter(const float* head, int head_stride, const f
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
     int rc = 1;
     switch (n_dt) {
-        case 1: rc = launch_scatter<1>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
-        case 2: rc = launch_scatter<2>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
-        case 3: rc = launch_scatter<3>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
-        case 4: rc = launch_scatter<4>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, dbg, s); break;
+        case 1: rc = launch_scatter<1>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, csplit, dbg, s); break;
+        case 2: rc = launch_scatter<2>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, csplit, dbg, s); break;
+        case 3: rc = launch_scatter<3>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, csplit, dbg, s); break;
+        case 4: rc = launch_scatter<4>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, csplit, dbg, s); break;
     }
     if (rc) return rc;
     HEAL_LAUNCH_CHECK();
@@ -1171,16 +1178,15 @@ extern "C" int heal_bev_stem_block(int n_agents, int channels, const int32_t* nx
     const int64_t blocks = (int64_t)n_agents * Ho * tiles_x;
     HEAL_REQUIRE(blocks < (1ll << 31), "bev_stem_block: grid too large");
     if (channels % 64 == 0)
-        k_bev_stem<64><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(w, channels, g.nx[0], g.nx[1], cells_total, w_main,
-                                                                          b_main, w_down, b_down, out_main, out_identity, Ho,
-                                                                          Wo, tiles_x, dbg);
+        HEAL_LAUNCH_EV(k_bev_stem<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, channels, g.nx[0], g.nx[1],
+                       cells_total, w_main, b_main, w_down, b_down, out_main, out_identity, Ho, Wo, tiles_x, dbg);
     else
-        k_bev_stem<32><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(w, channels, g.nx[0], g.nx[1], cells_total, w_main,
-                                                                          b_main, w_down, b_down, out_main, out_identity, Ho,
-                                                                          Wo, tiles_x, dbg);
+        HEAL_LAUNCH_EV(k_bev_stem<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, channels, g.nx[0], g.nx[1],
+                       cells_total, w_main, b_main, w_down, b_down, out_main, out_identity, Ho, Wo, tiles_x, dbg);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
+
 namespace heal {
 // ---- backward of the lift + splat (training) ----------------------------------------------------------------
 // Forward: out[cell(cam, d, v, u)][c] += p[cam, d, v, u] * f[cam, c, v, u],  p = softmax_d(logit[cam, :, v, u]).

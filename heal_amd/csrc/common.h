@@ -1,6 +1,7 @@
 // Shared host/device helpers for libheal_amd (gfx950 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -45,6 +46,21 @@ struct Arena {
     } while (0)
 
 #define HEAL_LAUNCH_CHECK() HEAL_HIP(hipGetLastError())
+
+// Measurement hook (heal_next_launch_events): a thread-local pair of events armed by the caller and consumed by the next launch
+// that supports it (HEAL_LAUNCH_EV).  hipExtLaunchKernelGGL stamps the events with the kernel's OWN begin / end, the interval a
+// rocprofv3 kernel trace reports; an event pair recorded around a launch also holds the dispatch and marker latencies (3-5 us,
+// a quarter of a 13-us kernel).
+struct LaunchEvents { hipEvent_t start, stop; };
+LaunchEvents take_launch_events();
+#define HEAL_LAUNCH_EV(kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                             \
+        const heal::LaunchEvents ev__ = heal::take_launch_events();                                                  \
+        if (ev__.start && ev__.stop)                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, ev__.start, ev__.stop, 0, __VA_ARGS__); \
+        else                                                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, __VA_ARGS__);                      \
+    } while (0)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -202,9 +202,20 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int n, int key_bits, 
     return 0;
 }
 
+static thread_local LaunchEvents g_launch_events = {nullptr, nullptr};
+LaunchEvents take_launch_events() {
+    const LaunchEvents e = g_launch_events;
+    g_launch_events = {nullptr, nullptr};
+    return e;
+}
+
 }  // namespace heal
 
 extern "C" {
+int heal_next_launch_events(void* start_event, void* stop_event) {
+    heal::g_launch_events = {(hipEvent_t)start_event, (hipEvent_t)stop_event};
+    return 0;
+}
 int heal_abi_version(void) { return HEAL_AMD_ABI_VERSION; }
 const char* heal_last_error(void) { return heal::err_buf(); }
 }

@@ -28,6 +28,11 @@ extern "C" {
 
 int heal_abi_version(void);
 const char* heal_last_error(void);
+/* Measurement hook: arm a pair of hipEvent_t (created with timing enabled) for THIS thread; the next launch of an entry point
+ * that supports it -- heal_bev_pool_scatter, heal_bev_stem_block -- stamps them with the kernel's own begin / end timestamps
+ * (hipExtLaunchKernelGGL: the interval a rocprofv3 kernel trace reports, without the dispatch / marker latencies an event pair
+ * recorded around the launch includes).  One shot; (NULL, NULL) disarms.  Not capturable in a HIP graph.                      */
+int heal_next_launch_events(void* start_event, void* stop_event);
 
 /* ------------------------------------------------------------------------------------------------
  * K1  hard voxelisation (first-come, input-order semantics of spconv's point->voxel generator).

@@ -1,5 +1,7 @@
-"""K4 timing: the production path (heal_bev_pool_pm on the pixel-major head tensor the fused image_head | depth_head convolution
-writes; 2 launches) vs the bit-reproducible sorted pipeline on the reference's NCHW tensors, standalone, HIP events.
+"""K4 timing: the production path (heal_bev_pool_scatter on the pixel-major head tensor the fused image_head | depth_head convolution
+writes, ONE launch, consumed by heal_bev_stem_block or heal_bev_pool_emit) vs the bit-reproducible sorted pipeline on the
+reference's NCHW tensors, standalone.  Kernel-attached HIP events (ops._Timed kernel_events: the kernel's own begin / end, what
+rocprofv3 reports) next to events recorded around the call and to the per-call period inside a captured graph.
 Usage: python scripts/k4_bench.py   (on the GPU box)"""
 import json
 import os
@@ -64,8 +66,24 @@ def run(final_dim, C=128, n_agents=1):
     args = (n_agents, N, dx.tolist(), bx.tolist(), nx.tolist())
     res = {}
     os.environ.pop("HEAL_LSS_PATH", None)
-    res["fused_pm_us"], res["fused_pm_min_us"], a = timed(lambda: ops.bev_pool_pm(head, C, D, fH, fW, frustum, mats, *args))
-    res["fused_pm_in_graph_us"] = timed_graph(lambda: ops.bev_pool_pm(head, C, D, fH, fW, frustum, mats, *args))
+    w1 = torch.randn((64, C, 3, 3), device="cuda") / (9 * C) ** 0.5
+    wd = torch.randn((64, C, 1, 1), device="cuda") / C ** 0.5
+    b1, bd = torch.randn(64, device="cuda"), torch.randn(64, device="cuda")
+    wm, wdf = ops.stem_fragments(w1, wd)
+    pm = lambda: ops.bev_pool_pm(head, C, D, fH, fW, frustum, mats, *args)                                     # scatter + dense emit
+    prod = lambda: ops.bev_pool_pm(head, C, D, fH, fW, frustum, mats, *args, pooled=True).stem_block(wm, b1, wdf, bd)
+    res["scatter_emit_us"], res["scatter_emit_min_us"], a = timed(pm)
+    res["scatter_emit_in_graph_us"] = timed_graph(pm)
+    res["scatter_stem_us"], _, _ = timed(prod)
+    res["scatter_stem_in_graph_us"] = timed_graph(prod)
+    ops.TIMING = {}
+    for _ in range(30):
+        prod()
+        pm()
+    torch.cuda.synchronize()
+    for name, (calls, ms) in ops.timing_summary().items():
+        res[f"kernel_events_{name}_us"] = round(ms * 1e3, 2)       # bev_pool = k_lss_scatter alone; bev_stem_block = k_bev_stem alone
+    ops.TIMING = None
     os.environ["HEAL_LSS_PATH"] = "sorted"
     res["sorted_us"], _, b = timed(lambda: ops.bev_pool(dl, ft, frustum, mats, *args))
     os.environ.pop("HEAL_LSS_PATH", None)
@@ -79,7 +97,7 @@ def run(final_dim, C=128, n_agents=1):
     res["nonzero_cells"] = int((a != 0).any(dim=1).sum())
     alg = (dl.numel() + ft.numel() + a.numel()) * 4            # logits + features read, canvas written
     res["alg_MB"] = alg / 1e6
-    res["fused_frac_hbm"] = alg / (res["fused_pm_in_graph_us"] * 1e-6) / 8e12
+    res["scatter_frac_hbm"] = alg / (res["kernel_events_bev_pool_us"] * 1e-6) / 8e12   # SURVEY 8d bytes / the scatter kernel's duration
     return res
 
 
