@@ -367,10 +367,29 @@ class ShardedCollabCompressed(ShardedCollab):
     the price is that the per-agent pyramid stages no longer shard, so this split is for links much slower than xGMI
     (`split="compressed"` / HEAL_SPLIT=compressed; the default split exchanges the warped pyramid levels)."""
 
+    _zshape = None
+
     def prepare(self, scene_input, n_agents, local_inputs):
+        """The [C / ratio, H, W] of the travelling map is what the encoder half actually produces on a rank that owns agents
+        (voxel size, backbone strides and compressor ratio all enter it); ranks without agents -- and rank 0's unpack -- learn
+        it from them once (one MAX all-reduce of three integers), so every rank packs the same size (a shape derived
+        from a hard-coded 0.8 m / pixel disagreed with the real one for any other voxel size or stride)."""
         if not self.model.compress:
             raise ValueError("split='compressed' needs a model with a `compressor` (args['compressor'])")
         self._scene_input = scene_input
+        if self._zshape is not None:
+            return
+        dev = next(self.model.parameters()).device
+        shape = torch.zeros(3, dtype=torch.int64, device=dev)
+        if owned_agents(n_agents, self.rank, self.world):
+            self.local(scene_input, n_agents, local_inputs)   # sets self._zshape
+            shape = torch.tensor(self._zshape, dtype=torch.int64, device=dev)
+        if self.world > 1:
+            dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+        got = tuple(int(v) for v in shape.tolist())
+        if self._zshape is not None and tuple(self._zshape) != got:
+            raise RuntimeError(f"compressed split: this rank's encoder output {self._zshape} differs from the job's {got}")
+        self._zshape = got
 
     @torch.no_grad()
     def local(self, scene_input, n_agents, local_inputs):
@@ -380,18 +399,14 @@ class ShardedCollabCompressed(ShardedCollab):
         x, mine = self._own_features(scene_input, n_agents, local_inputs, compress=False)
         if mine:
             z = m.compressor.encode(x)
+            if self._zshape is not None and tuple(z.shape[1:]) != tuple(self._zshape):
+                raise RuntimeError(f"compressed split: encoder output {tuple(z.shape[1:])} != agreed shape {self._zshape}")
             self._zshape = tuple(z.shape[1:])
         else:
-            z = torch.zeros((0,) + self._compressed_shape(), device=next(m.parameters()).device)
+            if self._zshape is None:
+                raise RuntimeError("compressed split: prepare() must run before local() on a rank that owns no agent")
+            z = torch.zeros((0,) + tuple(self._zshape), device=next(m.parameters()).device)
         return self._wire(pack_maps(z, n_slots))
-
-    def _compressed_shape(self):
-        c, h, w = self._level_shapes_input()
-        return (self.model.compressor.encoder[0].out_channels, h, w)
-
-    def _level_shapes_input(self):
-        m = self.model
-        return (m.compressor.encoder[0].in_channels, int(round(m.H / 0.8)), int(round(m.W / 0.8)))
 
     @torch.no_grad()
     def tail(self, gathered, n_agents):
@@ -400,7 +415,7 @@ class ShardedCollabCompressed(ShardedCollab):
         si = self._scene_input
         if gathered.dtype != torch.float32:
             gathered = gathered.float()
-        z = unpack_maps(gathered, self._compressed_shape(), n_agents, self.world)
+        z = unpack_maps(gathered, tuple(self._zshape), n_agents, self.world)
         x = m.compressor.decode(z)
         pairwise, grid_f64 = pairwise_to_host(si["pairwise_t_matrix"])
         affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)

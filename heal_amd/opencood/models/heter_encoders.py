@@ -83,6 +83,7 @@ class PointPillar(nn.Module):
             pfn0 = self.pillar_vfe.pfn_layers[0]
             if (voxels.is_cuda and ops.pfn_train_supported(voxels) and getattr(pfn0, "use_norm", True)
                     and len(self.pillar_vfe.pfn_layers) == 1 and pfn0.linear.bias is None
+                    and pfn0.linear.out_features == 64 and pfn0.linear.in_features == 10   # the kernels hard-code Linear(10 -> 64)
                     and os.environ.get("HEAL_K2_BACKWARD", "1") == "1"):
                 feats = self.pillar_vfe.pillar_features_kernels(voxels, coords, num)
             else:

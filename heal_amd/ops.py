@@ -310,7 +310,11 @@ def _pfn_inputs(voxels, coords, num_points):
     return voxels, coords, num_points
 
 
-def pfn_train_supported(voxels):
+def pfn_train_supported(voxels, weight=None):
+    """heal_pfn_features / _moments / _backward are written for Linear(10 -> 64) (PillarVFE with num_filters [64]); any other
+    width must take the torch path (the kernels would read weight / bn rows out of bounds)."""
+    if weight is not None and tuple(weight.shape) != (64, 10):
+        return False
     return voxels.is_cuda and voxels.dim() == 3 and 1 <= int(voxels.shape[1]) <= 32 and int(voxels.shape[0]) >= 1
 
 
@@ -335,6 +339,8 @@ def pfn_features(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_s
     voxels, coords, num_points = _pfn_inputs(voxels, coords, num_points)
     M, P = int(voxels.shape[0]), int(voxels.shape[1])
     out = torch.empty((M, 64), dtype=torch.float32, device=voxels.device)
+    if tuple(weight.shape) != (64, 10) or bn_scale.numel() != 64 or bn_shift.numel() != 64:
+        raise _capi.HealAmdError("pfn_features: the kernel is written for Linear(10 -> 64) (weight [64, 10], 64 BN channels)")
     _capi.call("heal_pfn_features", _ptr(voxels), _ptr(coords), _ptr(num_points), M, P, _ptr(_need(weight, torch.float32, "weight")),
                _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
                *_pfn_geom(voxel_size, lidar_range), _ptr(out), _stream())
@@ -347,6 +353,8 @@ def pfn_backward(voxels, coords, num_points, weight, bn_scale, bn_shift, mean, r
     M, P = int(voxels.shape[0]), int(voxels.shape[1])
     nb = _capi.query("heal_pfn_train_blocks", M)
     part = torch.empty((nb, 64, 12), dtype=torch.float32, device=voxels.device)
+    if tuple(weight.shape) != (64, 10) or bn_scale.numel() != 64 or bn_shift.numel() != 64:
+        raise _capi.HealAmdError("pfn_backward: the kernel is written for Linear(10 -> 64) (weight [64, 10], 64 BN channels)")
     _capi.call("heal_pfn_backward", _ptr(voxels), _ptr(coords), _ptr(num_points), M, P, _ptr(_need(weight, torch.float32, "weight")),
                _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
                _ptr(_need(mean, torch.float32, "mean")), _ptr(_need(rstd, torch.float32, "rstd")),
@@ -836,6 +844,7 @@ def sp_weight_fragments(weight):
     hit = _SP_FRAGS.get(key)
     if hit is None:
         if len(_SP_FRAGS) > 256:
+            _WS_RETIRED.extend(v[0] for v in _SP_FRAGS.values())   # retired, not freed: a captured graph may hold the address
             _SP_FRAGS.clear()
         out = torch.empty_like(weight)
         _capi.call("heal_sp_weight_fragments", _ptr(weight), K, cin, cout, _ptr(out), _stream())
@@ -1462,6 +1471,7 @@ def conv_gemm(x, w, bias=None, residual=None, relu=False, stride=1):
     hit = _TAPMAJOR_CACHE.get(key)
     if hit is None:
         if len(_TAPMAJOR_CACHE) > 256:
+            _WS_RETIRED.extend(v[0] for v in _TAPMAJOR_CACHE.values())   # retired, not freed (captured graphs)
             _TAPMAJOR_CACHE.clear()
         hit = _TAPMAJOR_CACHE[key] = (w.detach().permute(0, 2, 3, 1).reshape(cout, ks * ks, cin).contiguous(), w)
     y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
