@@ -105,6 +105,26 @@ def test_common_transformation_camera_utils_live():
     for mode in ("UD", "LID"):
         np.testing.assert_array_equal(np.asarray(cam_mine.depth_discretization(2, 50, 48, mode)),
                                       np.asarray(cam.depth_discretization(2, 50, 48, mode)))
+    # bin_depths / indices_to_depth / cumsum_trick / QuickCumsum (camera_utils.py:137-246): the names third-party code imports
+    depth = torch.from_numpy(np.concatenate([rng.uniform(-5, 80, 4000), [np.nan, np.inf, -np.inf, 2.0, 50.0]]).astype(np.float32))
+    for mode in ("UD", "LID", "SID"):
+        for target in (True, False):
+            _eq(cam_mine.bin_depths(depth.clone(), mode, 2.0, 50.0, 48, target), cam.bin_depths(depth.clone(), mode, 2.0, 50.0, 48, target))
+    idx = torch.arange(48, dtype=torch.float32)
+    for mode in ("UD", "LID"):
+        _eq(cam_mine.indices_to_depth(idx, 2.0, 50.0, 48, mode), cam.indices_to_depth(idx, 2.0, 50.0, 48, mode))
+    ranks = torch.sort(torch.from_numpy(rng.integers(0, 300, 2000)))[0]
+    x = torch.from_numpy(rng.standard_normal((2000, 8)).astype(np.float32))
+    geom = torch.from_numpy(rng.integers(0, 50, (2000, 4)))
+    _eq(cam_mine.cumsum_trick(x, geom, ranks), cam.cumsum_trick(x, geom, ranks))
+    with torch.enable_grad():      # (the reference import switches gradients off globally)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        (ya, ga), (yb, gb) = cam_mine.QuickCumsum.apply(xa, geom, ranks), cam.QuickCumsum.apply(xb, geom, ranks)
+        _eq((ya.detach(), ga), (yb.detach(), gb))
+        w = torch.from_numpy(rng.standard_normal(tuple(ya.shape)).astype(np.float32))
+        (ya * w).sum().backward()
+        (yb * w).sum().backward()
+    _eq(xa.grad, xb.grad)
 
 
 class _Captured(dict):
