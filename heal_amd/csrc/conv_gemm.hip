@@ -67,26 +67,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvGemmArgs a) {
     const size_t HW = (size_t)a.H * a.W;
     const float* x_img = a.x + (size_t)img * a.cin * HW;
 
-    float4 ra[4];
+    // staging registers: NAMED float4 values for the weights (an array of float4 written in one branch and read in another is
+    // lowered through scratch memory: 4 scratch stores + loads per chunk in the round-3 kernel), and the padding mask of the
+    // gathered activations applied at the LDS store (a select right behind the load waits for it in front of the MFMAs).
+    float4 ra0, ra1, ra2, ra3;
+    ra0 = ra1 = ra2 = ra3 = make_float4(0.f, 0.f, 0.f, 0.f);
     float rb[16];
+    bool rb_ok = false;
 #define HEAL_CG_LOAD(chunk_)                                                                                           \
     {                                                                                                                  \
         const int tap_ = (chunk_) / cpt, cc_ = (chunk_) - tap_ * cpt;                                                  \
         const int ky_ = tap_ / KS, kx_ = tap_ - ky_ * KS;                                                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (size_t)tap_ * a.cin + cc_ * CG_BK);                   \
+        const size_t wo_ = (size_t)tap_ * a.cin + cc_ * CG_BK;                                                         \
+        ra0 = *reinterpret_cast<const float4*>(a_src[0] + wo_);                                                        \
+        ra1 = *reinterpret_cast<const float4*>(a_src[1] + wo_);                                                        \
+        ra2 = *reinterpret_cast<const float4*>(a_src[2] + wo_);                                                        \
+        ra3 = *reinterpret_cast<const float4*>(a_src[3] + wo_);                                                        \
         const int iy_ = iy0 + ky_, ix_ = ix0 + kx_;                                                                    \
-        const bool ok_ = p_ok && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;                                       \
-        const float* src_ = x_img + (size_t)(cc_ * CG_BK + cb) * HW + (ok_ ? (size_t)iy_ * a.W + ix_ : 0);             \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                               \
-            const float v_ = src_[(size_t)(2 * i) * HW];                                                               \
-            rb[i] = ok_ ? v_ : 0.f;                                                                                    \
-        }                                                                                                              \
+        rb_ok = p_ok && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;                                                \
+        const float* src_ = x_img + (size_t)(cc_ * CG_BK + cb) * HW + (rb_ok ? (size_t)iy_ * a.W + ix_ : 0);           \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) rb[i] = src_[(size_t)(2 * i) * HW];                             \
     }
 #define HEAL_CG_STORE(buf_)                                                                                            \
     {                                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sA[buf_][sa_off[i]]) = ra[i];        \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) sB[buf_][(cb + 2 * i) * CG_RSB + p] = rb[i];                    \
+        *reinterpret_cast<float4*>(&sA[buf_][sa_off[0]]) = ra0;                                                        \
+        *reinterpret_cast<float4*>(&sA[buf_][sa_off[1]]) = ra1;                                                        \
+        *reinterpret_cast<float4*>(&sA[buf_][sa_off[2]]) = ra2;                                                        \
+        *reinterpret_cast<float4*>(&sA[buf_][sa_off[3]]) = ra3;                                                        \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) sB[buf_][(cb + 2 * i) * CG_RSB + p] = rb_ok ? rb[i] : 0.f;      \
     }
 
     f32x16 acc[2][2];

@@ -1266,6 +1266,28 @@ def conv1x1_ksplit(n, cin, cout, hw):
     return -(-chunks // -(-chunks // want))       # ceil(chunks / ceil(chunks / want)): no empty split
 
 
+def conv1x1_tiled_ok(n, cin, cout, hw):
+    """Shapes the 128 x 128 x 32 core (heal_conv1x1_tiled, 32x32x2 fp32 MFMA) takes over from heal_conv1x1: 32-channel K chunks,
+    64- or 128-channel M tiles, enough blocks to fill the chip, and a reduction deep enough to be MFMA- rather than HBM-bound.
+    OPT-IN (HEAL_C1_TILED=1, =force for every shape it can take): measured at the scenes' shapes (scripts/c1t_bench.py,
+    profiles/r04_c1t_bench.json) it is at parity with the 64 x 64 kernel -- 0.70-1.07x, ahead only on 256 -> 2048 and single-image
+    256 -> 128 -- because both are bound by the same thing at these sizes: 5 GFLOP launches are 1.25-2.5 rounds of resident
+    blocks, and the last partial round costs a full one."""
+    mode = os.environ.get("HEAL_C1_TILED", "0")
+    if mode == "0" or cin % 32 or cout % 64 or hw % 4 or hw < 128:
+        return False
+    bm = 128 if cout % 128 == 0 else 64
+    blocks = (cout // bm) * -(-hw // 128) * n
+    if mode == "force":
+        return True
+    return blocks >= 256 and cin >= 128
+
+
+def _w_rowmajor(w):
+    w2 = w.detach().reshape(int(w.shape[0]), int(w.shape[1]))
+    return w2 if w2.is_contiguous() else w2.contiguous()
+
+
 def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixel_major=False):
     """Pointwise convolution with fused prologue / epilogue: act(W (in_scale . x) + bias (+ residual));
     act 0 none | 1 ReLU | 2 SiLU; stride 1 | 2.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin].
@@ -1277,6 +1299,19 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
     hard_ok = stride in (1, 2) and ((Ho * Wo) % 4 == 0 if stride == 1 else Wo % 4 == 0)
     if int(w.shape[1]) != cin or not hard_ok:
         raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HxW={H}x{W} stride={stride}")
+    if (stride == 1 and not pixel_major and in_scale is None and conv1x1_tiled_ok(n, cin, cout, H * W)
+            and w.dtype == torch.float32):
+        y = torch.empty((n, cout, H, W), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            residual = _need(residual, torch.float32, "residual")
+            if tuple(residual.shape) != tuple(y.shape):
+                raise _capi.HealAmdError("conv1x1: residual shape mismatch")
+        wr = _w_rowmajor(w)
+        with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W,
+                    4.0 * n * (cin * H * W + cout * H * W * (2 if residual is not None else 1))):
+            _capi.call("heal_conv1x1_tiled", _ptr(x), _ptr(wr), _ptr(bias) if bias is not None else None,
+                       _ptr(residual) if residual is not None else None, n, cin, cout, H, W, int(act), 0, 0, 0, _ptr(y), _stream())
+        return y
     frag = conv1x1_fragments(w)
     if pixel_major:
         if residual is not None or cout % 4 != 0:
@@ -1321,8 +1356,14 @@ def conv1x1_d2s(x, w, bias, act, k, dst, channel_offset):
     if (not dst.is_contiguous() or int(dst.shape[0]) != n or int(dst.shape[2]) != H * k or int(dst.shape[3]) != W * k
             or cout % (k * k) or W % 4):
         raise _capi.HealAmdError(f"conv1x1_d2s: destination {tuple(dst.shape)} does not fit x {tuple(x.shape)} at k={k}")
-    frag = conv1x1_fragments(w)
     bias = _need(bias, torch.float32, "bias") if bias is not None else None
+    if conv1x1_tiled_ok(n, cin, cout, H * W) and w.dtype == torch.float32:
+        wr = _w_rowmajor(w)
+        with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W, 4.0 * n * H * W * (cin + cout)):
+            _capi.call("heal_conv1x1_tiled", _ptr(x), _ptr(wr), _ptr(bias) if bias is not None else None, None, n, cin, cout, H, W,
+                       int(act), int(k), int(dst.shape[1]), int(channel_offset), _ptr(dst), _stream())
+        return dst[:, channel_offset:channel_offset + cout // (k * k)]
+    frag = conv1x1_fragments(w)
     with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W, 4.0 * n * H * W * (cin + cout)):
         _capi.call("heal_conv1x1_d2s", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None, n, cin, cout, H, W,
                    int(act), int(k), int(dst.shape[1]), int(channel_offset), _ptr(dst), _stream())
@@ -1514,11 +1555,11 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
             _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
                        int(bool(relu)), waves, _ptr(y), _stream())
         return y
-    if stride == 2 and cin >= 192 and conv_gemm_supported(cin, cout, Wo) and n * Ho * Wo >= 65536:
-        # the large, deep stride-2 layers: the 128 x 128 x 32 implicit GEMM on 32x32x2 MFMA (heal_conv_gemm).  Measured
-        # (scripts/conv_gemm_bench.py, profiles/r03_conv_gemm_bench.json): 384 -> 256 @256^2 x 8: 2.82 vs 3.69 ms (MIOpen 2.64);
-        # 128 -> 256: 0.97 vs 1.02; 128 -> 128 @256^2 x 5: 0.43 vs 0.31 (the short reduction does not pay for the tile): hence
-        # the Cin bound
+    if stride == 2 and cin >= 128 and conv_gemm_supported(cin, cout, Wo) and n * Ho * Wo >= 65536:
+        # the large stride-2 layers: the 128 x 128 x 32 implicit GEMM on 32x32x2 MFMA (heal_conv_gemm).  Measured
+        # (scripts/conv_gemm_bench.py; round 4, after the kernel's weight staging stopped going through scratch memory):
+        # 384 -> 256 @256^2 x 8: 2.19 vs 3.69 ms for heal_conv3x3 (MIOpen 2.63) = 106 TFLOP/s; 128 -> 256: 0.74 vs 1.02;
+        # 128 -> 128 @256^2 x 5: 0.30 vs 0.31; 256 -> 256 @128^2 x 5 (20 480 pixels: below the bound) 0.35 vs 0.29 for MIOpen
         return conv_gemm(x, w, bias, residual, relu, stride)
     frag = conv3x3_fragments(w)
     with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * cin * cout * Ho * Wo,

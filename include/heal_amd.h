@@ -457,6 +457,14 @@ int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bia
  *   the K chunks split over `ksplit` blocks: partial sums go to the workspace [ksplit][n][Cout][HW], a second launch adds them
  *   in split order (deterministic) and applies bias / residual / activation.  ksplit in [2, ceil32(Cin)/32] with no empty
  *   split; workspace from heal_conv1x1_splitk_workspace, 16-B aligned; H*W % 4 == 0.                                  */
+/* heal_conv1x1_tiled: the same pointwise convolution on the 128 x 128 x 32 core (v_mfma_f32_32x32x2_f32, both operands through
+ *   LDS) for its MFMA-bound shapes: weight is the PLAIN [Cout, Cin] row-major matrix (nn.Conv2d's storage, no fragment
+ *   pre-layout); Cin % 32 == 0, Cout % 64 == 0, stride 1, no input gate.  d2s_k = 0: y [n, Cout, H, W]; d2s_k = k >= 1: the
+ *   depth-to-space + channel-offset write of heal_conv1x1_d2s into y [n, dst_channels, H k, W k].  bias / residual may be NULL.
+ *   heal_conv1x1_tiled_supported: 1 if the shape fills the chip with this tiling (>= 256 blocks), else 0.                    */
+int heal_conv1x1_tiled_supported(int n, int cin, int cout, int H, int W);
+int heal_conv1x1_tiled(const float* x, const float* weight, const float* bias, const float* residual, int n, int cin, int cout,
+                       int H, int W, int act, int d2s_k, int dst_channels, int dst_channel_offset, float* y, void* stream);
 size_t heal_conv1x1_splitk_workspace(int n, int cout, int H, int W, int ksplit);
 int heal_conv1x1_splitk(const float* x, const float* weight_frag, const float* bias, const float* residual,
                         const float* in_scale, int n, int cin, int cout, int H, int W, int act, int ksplit, float* y, void* ws,

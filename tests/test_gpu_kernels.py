@@ -1393,3 +1393,31 @@ def test_conv_gemm_vs_torch_fp64(n, cin, cout, H, W, ks, stride, res):
     ref = torch.relu(ref).numpy()
     got = ops.conv_gemm(dev(x), dev(w), dev(b), dev(r) if res else None, True, stride).cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,res,act", [(2, 128, 256, 64, 64, False, 1), (1, 256, 64, 96, 128, True, 0),
+                                                    (3, 64, 128, 40, 52, False, 3), (1, 512, 256, 32, 36, True, 1)])
+def test_conv1x1_tiled_equals_torch(n, cin, cout, H, W, res, act, monkeypatch):
+    """heal_conv1x1_tiled (128 x 128 x 32 core on 32x32x2 fp32 MFMA, plain [Cout, Cin] weights; opt-in: at parity with heal_conv1x1
+    at the scenes' shapes) against F.conv2d with the fused epilogues, incl. pixel counts that are not multiples of the 128-pixel
+    tile and the depth-to-space write of the deblocks."""
+    from heal_amd import ops
+    monkeypatch.setenv("HEAL_C1_TILED", "force")
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    r = torch.randn((n, cout, H, W), generator=g).cuda() if res else None
+    assert ops.conv1x1_tiled_ok(n, cin, cout, H * W)
+    got = ops.conv1x1(x, w, b, r, act)
+    ref = torch.nn.functional.conv2d(x, w, b)
+    if res:
+        ref = ref + r
+    ref = {0: lambda t: t, 1: torch.relu, 3: torch.nn.functional.gelu}[act](ref)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    if not res and cout % 4 == 0 and W % 4 == 0:
+        dst = torch.full((n, cout // 4 + 3, 2 * H, 2 * W), -7.0, device="cuda")
+        ops.conv1x1_d2s(x, w, b, 1, 2, dst, 2)
+        want = torch.nn.functional.pixel_shuffle(torch.relu(torch.nn.functional.conv2d(x, w, b)), 2)
+        assert float((dst[:, 2:2 + cout // 4] - want).abs().max() / want.abs().max()) < 1e-5
+        assert float(dst[:, :2].min()) == -7.0 and float(dst[:, 2 + cout // 4:].max()) == -7.0
