@@ -1271,8 +1271,7 @@ def conv1x1_tiled_ok(n, cin, cout, hw):
     64- or 128-channel M tiles, enough blocks to fill the chip, and a reduction deep enough to be MFMA- rather than HBM-bound.
     OPT-IN (HEAL_C1_TILED=1, =force for every shape it can take): measured at the scenes' shapes (scripts/c1t_bench.py,
     profiles/r04_c1t_bench.json) it is at parity with the 64 x 64 kernel -- 0.70-1.07x, ahead only on 256 -> 2048 and single-image
-    256 -> 128 -- because both are bound by the same thing at these sizes: 5 GFLOP launches are 1.25-2.5 rounds of resident
-    blocks, and the last partial round costs a full one."""
+    256 -> 128; neither tile shape of either kernel moves the 85-105 TFLOP/s these 5-GFLOP launches reach in isolation."""
     mode = os.environ.get("HEAL_C1_TILED", "0")
     if mode == "0" or cin % 32 or cout % 64 or hw % 4 or hw < 128:
         return False
