@@ -455,6 +455,17 @@ def main():
                     corners, scores, count = res_
                     k = int(count.item())
                     return (None, None) if k == 0 else (corners[:k], scores[:k])
+                serial_step = step
+                if a.frames_in_flight > 1:
+                    # throughput mode of the sharded step: `depth` captured copies, local stage of frame k + 1 under the fusion
+                    # tail of frame k on rank 0 (dist.ShardedFramesInFlight); exchanges stay in frame order
+                    from heal_amd.dist import ShardedFramesInFlight
+                    ring = ShardedFramesInFlight(lambda: make_sharded(pipe.model, rank, world, wire_dtype=wire), scene, n_agents,
+                                                 rank, world, depth=a.frames_in_flight, post_fn=post_fn)
+
+                    def step():  # noqa: F811
+                        r_ = ring.step(next_frame())
+                        return r_ if r_ is not None else (None, None)
 
     def fence():
         torch.cuda.synchronize()
@@ -467,14 +478,19 @@ def main():
     # `frames_in_flight` captured copies of the step overlapping on their own streams (throughput mode).
     latency_ms, serial = None, None
     if ring is not None:
+        one = (lambda: pipe.replay(next_frame())) if solo else serial_step
         for _ in range(a.warmup):
-            pipe.replay(next_frame())
+            one()
         fence()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            pipe.replay(next_frame())
+            one()
         fence()
         sdt = time.perf_counter() - t0
+        if world > 1:
+            t_ = torch.tensor([sdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            sdt = float(t_.item())
         latency_ms = sdt / a.steps * 1e3
         serial = {"value": round(a.steps / sdt, 3), "unit": "scenes/s", "ms_per_step": round(latency_ms, 3), "steps": a.steps,
                   "warmup": a.warmup, "what": "one frame at a time: hipGraph replay of the whole step, boxes read back before the "
@@ -491,7 +507,10 @@ def main():
     for _ in range(a.steps):
         res = step()
     if ring is not None:          # every one of the K frames is finished and read back inside the timed region
-        res = (ring.drain() or [res])[-1]
+        tail_ = [r_ for r_ in ring.drain() if r_ is not None]
+        res = tail_[-1] if tail_ else res
+    if res is None:
+        res = (None, None)
     fence()
     dt = time.perf_counter() - t0
     if use_graph:
@@ -526,8 +545,9 @@ def main():
     if rank == 0:
         coll_name = "n/a"
         if not solo:   # name the collective that actually ran (dist._Sharded.collective; VERDICT r3: the label said all-gather)
-            coll_name = {"gather": "RCCL gather to rank 0", "all_gather": "RCCL all-gather",
-                         "p2p": "direct point-to-point writes to rank 0"}.get(sharded.collective, sharded.collective)
+            lib_ = "RCCL" if backend == "nccl" else backend
+            coll_name = {"gather": f"{lib_} gather to rank 0", "all_gather": f"{lib_} all-gather"}.get(sharded.collective,
+                                                                                                      sharded.collective)
         ms_per_step = dt / a.steps * 1e3
         nx = ny = 512
         with torch.no_grad():

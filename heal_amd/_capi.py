@@ -41,6 +41,7 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p]),
     "heal_warp_agents_pm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "heal_fuse_warped": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "heal_fuse_warped_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_decode_nms_workspace": (c_size_t, [c_int, c_int]),
     "heal_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_float, c_int, c_void_p, c_void_p,

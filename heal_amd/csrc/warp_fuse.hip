@@ -276,8 +276,12 @@ __global__ __launch_bounds__(256) void k_warp_agents_pm(const float* __restrict_
     }
 }
 
+// Agent a's maps start at feats + off.f[a] / scores + off.s[a] (float4 units): a contiguous [n, C, HW] stack, or the rows of the
+// exchange buffer of the agent-sharded runner in place (no re-pack after the gather).
+struct FuseOffsets { long long f[WF_MAXA], s[WF_MAXA]; };
+
 __global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ feats,
-                                                    const float4* __restrict__ scores, int n, int C,
+                                                    const float4* __restrict__ scores, FuseOffsets off, int n, int C,
                                                     int HW4, float4* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW4) return;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ 
 #pragma unroll
     for (int a = 0; a < WF_MAXA; ++a) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a < n) s = scores[(size_t)a * HW4 + i];
+        if (a < n) s = scores[off.s[a] + i];
         px[a] = s.x; py[a] = s.y; pz[a] = s.z; pw[a] = s.w;
     }
     agent_softmax(px, n); agent_softmax(py, n); agent_softmax(pz, n); agent_softmax(pw, n);
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void k_fuse_warped(const float4* __restrict__ 
 #pragma unroll
         for (int a = 0; a < WF_MAXA; ++a) {
             if (a < n) {
-                const float4 v = feats[((size_t)a * C + c) * HW4 + i];
+                const float4 v = feats[off.f[a] + (size_t)c * HW4 + i];
                 acc.x += v.x * px[a]; acc.y += v.y * py[a]; acc.z += v.z * pz[a]; acc.w += v.w * pw[a];
             }
         }
@@ -452,10 +456,35 @@ extern "C" int heal_fuse_warped(const float* feats_ego, const float* scores_ego,
     HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "fuse_warped: n_agents must be in [1,%d]", WF_MAXA);
     HEAL_REQUIRE((H * W) % 4 == 0, "fuse_warped: H*W must be a multiple of 4");
     const int HW4 = H * W / 4;
+    FuseOffsets off;
+    for (int a = 0; a < WF_MAXA; ++a) {
+        off.f[a] = (long long)a * channels * HW4;
+        off.s[a] = (long long)a * HW4;
+    }
     dim3 grid(ceil_div(HW4, 256), ceil_div(channels, 16));
     k_fuse_warped<<<grid, 256, 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const float4*>(feats_ego), reinterpret_cast<const float4*>(scores_ego), n_agents,
+        reinterpret_cast<const float4*>(feats_ego), reinterpret_cast<const float4*>(scores_ego), off, n_agents,
         channels, HW4, reinterpret_cast<float4*>(out));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_fuse_warped_rows(const float* base, const int64_t* feat_offsets_host, const int64_t* score_offsets_host,
+                                     int n_agents, int channels, int H, int W, float* out, void* stream) {
+    HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "fuse_warped_rows: n_agents must be in [1,%d]", WF_MAXA);
+    HEAL_REQUIRE((H * W) % 4 == 0 && ((uintptr_t)base & 15) == 0, "fuse_warped_rows: H*W %% 4 == 0 and a 16-B aligned base");
+    const int HW4 = H * W / 4;
+    FuseOffsets off;
+    for (int a = 0; a < WF_MAXA; ++a) {
+        const int64_t fo = a < n_agents ? feat_offsets_host[a] : 0, so = a < n_agents ? score_offsets_host[a] : 0;
+        HEAL_REQUIRE(fo % 4 == 0 && so % 4 == 0 && fo >= 0 && so >= 0, "fuse_warped_rows: offsets must be multiples of 4 floats");
+        off.f[a] = fo / 4;
+        off.s[a] = so / 4;
+    }
+    dim3 grid(ceil_div(HW4, 256), ceil_div(channels, 16));
+    k_fuse_warped<<<grid, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(base),
+                                                         reinterpret_cast<const float4*>(base), off, n_agents, channels, HW4,
+                                                         reinterpret_cast<float4*>(out));
     HEAL_LAUNCH_CHECK();
     return 0;
 }

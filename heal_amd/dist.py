@@ -307,29 +307,34 @@ class ShardedCollab(_Sharded):
         mods = scene_input["agent_modality_list"]
         pb = m.pyramid_backbone
         n_slots = slots_per_rank(n_agents, self.world)
-        level_feats, level_scores = [], []
         x, mine = self._own_features(scene_input, n_agents, local_inputs)
+        shapes = self._level_shapes()
+        per_slot = sum((c + 1) * h * w for c, h, w in shapes)
+        dev = next(m.parameters()).device
+        # the exchange buffer is written IN PLACE: heal_warp_agent puts every level of an agent straight into the agent's row
+        # (no stack + pack copies of 29.7 MB per agent); only the padding slots of this rank are zeroed (a zero score is masked
+        # to -inf by the fusion kernel, so they never contribute)
+        buf = torch.empty((n_slots, per_slot), dtype=torch.float32, device=dev)
+        if len(mine) < n_slots:
+            buf[len(mine):].zero_()
         if mine:
             stages = pb.get_multiscale_feature(x)
+            off = 0
             for i, f in enumerate(stages):
+                if tuple(f.shape[1:]) != tuple(shapes[i]):
+                    raise RuntimeError(f"pyramid level {i}: stage output {tuple(f.shape[1:])} != configured {shapes[i]}")
                 occ = pb.occupancy_head(i, f)
-                fe_all, se_all = [], []
+                nf, ns = f.shape[1] * f.shape[2] * f.shape[3], f.shape[2] * f.shape[3]
                 for k, a in enumerate(mine):
                     crop = None
                     if mods[a] in m.cam_crop_info:
                         info = m.cam_crop_info[mods[a]]
                         crop = [crop_window(f.shape[2], f.shape[3], info[f"crop_ratio_H_{mods[a]}"],
                                             info[f"crop_ratio_W_{mods[a]}"])]
-                    fe, se = ops.warp_agent(f[k], occ[k], affine[0, a], grid_f64, crop)
-                    fe_all.append(fe); se_all.append(se)
-                level_feats.append(torch.stack(fe_all))
-                level_scores.append(torch.stack(se_all))
-        else:
-            dev = next(m.parameters()).device
-            shapes = self._level_shapes()
-            level_feats = [torch.zeros((0,) + s, device=dev) for s in shapes]
-            level_scores = [torch.zeros((0, 1) + s[1:], device=dev) for s in shapes]
-        return self._wire(pack_levels(level_feats, level_scores, n_slots))
+                    ops.warp_agent(f[k], occ[k], affine[0, a], grid_f64, crop,
+                                   out=(buf[k, off:off + nf], buf[k, off + nf:off + nf + ns]))
+                off += nf + ns
+        return self._wire(buf)
 
     # ---- stage 3 (rank 0): fusion and the fixed tail -------------------------------------------------------
     @torch.no_grad()
@@ -340,8 +345,16 @@ class ShardedCollab(_Sharded):
         fused = []
         if gathered.dtype != torch.float32:
             gathered = gathered.float()
-        for feats_ego, scores_ego in unpack_levels(gathered, self._level_shapes(), n_agents, self.world):
-            fused.append(ops.fuse_warped(feats_ego, scores_ego).unsqueeze(0))
+        gathered = gathered.contiguous()
+        # fuse straight from the rows of the exchange buffer (agent a = slot a // world of rank agent_owner(a)): no torch.stack /
+        # reshape / contiguous re-pack of 29.7 MB per agent between the collective and the fusion kernel
+        n_slots, per_slot = int(gathered.shape[1]), int(gathered.shape[2])
+        row0 = [(agent_owner(a, self.world) * n_slots + a // self.world) * per_slot for a in range(n_agents)]
+        off = 0
+        for (C, H, W) in self._level_shapes():
+            nf = C * H * W
+            fused.append(ops.fuse_warped_rows(gathered, [r + off for r in row0], [r + off + nf for r in row0], C, H, W).unsqueeze(0))
+            off += nf + H * W
         y = pb.decode_multiscale_feature(fused)
         cls_preds, reg_preds, dir_preds = m.heads(y)
         return {"pyramid": "collab", "cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
@@ -483,3 +496,71 @@ def make_sharded(model, rank, world, wire_dtype=None, collective=None, split=Non
     if name == "HeterModelBaseline":
         return ShardedBaseline(model, rank, world, wire_dtype, collective)
     raise NotImplementedError(f"no agent-sharded split for {name}")
+
+
+class ShardedFramesInFlight:
+    """Throughput mode of the agent-sharded step (the N > 1 counterpart of pipeline.FramesInFlight):
+    `depth` captured copies of the sharded step, each with its own static input buffers, exchange buffers, graphs and stream.
+    Frame k goes to slot k % depth: graph(local_k) -> exchange_k -> graph(tail_k) are enqueued on the slot's stream, and the host
+    moves on to frame k + 1 at once, so on rank 0 the local stage of frame k + 1 (its own agents' encoders) runs UNDER the
+    fusion tail of frame k, and the other ranks' local stages run ahead of rank 0's tail by up to `depth` frames.  The exchanges
+    are issued by every rank in frame order (the process group runs collectives in issue order), a slot's buffers are reused
+    only after its previous frame left them (same stream), and the boxes of frame k are read `depth - 1` steps later.
+
+        ring = ShardedFramesInFlight(lambda: make_sharded(model, rank, world), scene, n_agents, rank, world, post_fn=post)
+        for frame in frames:  res = ring.step(frame)     # rank 0: (corners, scores, count) tensors of the oldest frame | None
+        rest = ring.drain()
+    """
+
+    def __init__(self, make_runner, scene, n_agents, rank, world, depth=2, post_fn=None, slack=1.25):
+        from collections import deque
+        from heal_amd.pipeline import StaticInputs
+        self.rank, self.world, self.depth = rank, world, depth
+        self.slots = []
+        mine = owned_agents(n_agents, rank, world)
+        dev = scene.device
+        for _ in range(depth):
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                runner = make_runner()
+                static = StaticInputs(scene, slack, agents=mine)
+                ok = runner.capture(static.scene_meta(), n_agents, static.inputs_for(mine), post_fn)
+            stream.synchronize()
+            if not ok:
+                raise RuntimeError(f"rank {rank}: the sharded step could not be captured ({runner._capture_error})")
+            self.slots.append((runner, static, stream))
+        self._next = 0
+        self._inflight = deque()
+
+    def _collect(self):
+        runner, _static, stream, out = self._inflight.popleft()
+        if self.rank != 0:
+            stream.synchronize()          # bounds how far this rank's host runs ahead of the job
+            return None
+        with torch.cuda.stream(stream):
+            corners, scores, count = out
+            k = int(count.item())        # waits for this slot's stream only
+            res = (None, None) if k == 0 else (corners[:k].clone(), scores[:k].clone())
+        torch.cuda.current_stream(corners.device).wait_stream(stream)
+        if runner._graph_checks:
+            runner.check_sparse_capacity()
+        return res
+
+    def step(self, frame):
+        """Submit `frame`; once every slot is taken, returns the result of the oldest frame in flight (rank 0: (boxes | None,
+        scores | None); other ranks: None), else None."""
+        runner, static, stream = self.slots[self._next % self.depth]
+        self._next += 1
+        with torch.cuda.stream(stream):
+            static.load(frame)
+            out = runner.replay()
+        self._inflight.append((runner, static, stream, out))
+        if len(self._inflight) == self.depth:
+            return self._collect()
+        return None
+
+    def drain(self):
+        out = []
+        while self._inflight:
+            out.append(self._collect())
+        return out

@@ -419,13 +419,20 @@ def warp_fuse_backward(feats, occ, affine_rows, grad_out, grid_f64=True, crop=No
     return g_feats, g_occ
 
 
-def warp_agent(feat, occ, affine_row, grid_f64=True, crop=None):
-    """K5 split, rank-local half: feat [C,H,W], occ [1,H,W] -> (feat_ego [C,H,W], score_ego [1,H,W])."""
+def warp_agent(feat, occ, affine_row, grid_f64=True, crop=None, out=None):
+    """K5 split, rank-local half: feat [C,H,W], occ [1,H,W] -> (feat_ego [C,H,W], score_ego [1,H,W]).
+    out = (feat_ego, score_ego): contiguous fp32 destinations to write into (the agent's row of the exchange buffer)."""
     feat = _need(feat, torch.float32, "feat")
     occ = _need(occ, torch.float32, "occ")
     C, H, W = (int(v) for v in feat.shape[-3:])
-    feat_ego = torch.empty((C, H, W), dtype=torch.float32, device=feat.device)
-    score_ego = torch.empty((1, H, W), dtype=torch.float32, device=feat.device)
+    if out is not None:
+        feat_ego, score_ego = out
+        if not (feat_ego.is_contiguous() and score_ego.is_contiguous() and feat_ego.dtype == score_ego.dtype == torch.float32
+                and feat_ego.numel() == C * H * W and score_ego.numel() == H * W and feat_ego.is_cuda):
+            raise _capi.HealAmdError("warp_agent: `out` must be contiguous fp32 CUDA tensors of C*H*W and H*W elements")
+    else:
+        feat_ego = torch.empty((C, H, W), dtype=torch.float32, device=feat.device)
+        score_ego = torch.empty((1, H, W), dtype=torch.float32, device=feat.device)
     a, ap, adev = _affine_args(affine_row, 1)
     c, cp = _crop_host(crop, 1)
     _capi.call("heal_warp_agent", _ptr(feat), _ptr(occ), C, H, W, ap, adev, int(bool(grid_f64)), cp,
@@ -441,6 +448,17 @@ def warp_agents_pm(feats, affine_rows, grid_f64=True):
     a, ap, adev = _affine_args(affine_rows, n)
     with _Timed("warp_agents_pm", 0.0, 8.0 * n * C * H * W):
         _capi.call("heal_warp_agents_pm", _ptr(feats), n, C, H, W, ap, adev, int(bool(grid_f64)), _ptr(out), _stream())
+    return out
+
+
+def fuse_warped_rows(base, feat_offsets, score_offsets, C, H, W):
+    """K5 split, post-exchange half on the exchange buffer IN PLACE: agent a's [C,H,W] features at base.flatten()[feat_offsets[a]:],
+    scores at score_offsets[a] (element offsets, multiples of 4) -> [C,H,W].  No re-pack of the gathered rows."""
+    base = _need(base, torch.float32, "base")
+    n = len(feat_offsets)
+    out = torch.empty((C, H, W), dtype=torch.float32, device=base.device)
+    _capi.call("heal_fuse_warped_rows", _ptr(base), _host_array([int(v) for v in feat_offsets], ctypes.c_int64),
+               _host_array([int(v) for v in score_offsets], ctypes.c_int64), n, int(C), int(H), int(W), _ptr(out), _stream())
     return out
 
 

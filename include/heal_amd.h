@@ -149,6 +149,11 @@ int heal_warp_agents_pm(const float* feats, int n_agents, int channels, int H, i
 /* ... and fuse already-warped stacks (after the all-gather): -inf mask, softmax over agents, sum. */
 int heal_fuse_warped(const float* feats_ego, const float* scores_ego, int n_agents, int channels,
                      int H, int W, float* out, void* stream);
+/* heal_fuse_warped_rows: the same fusion reading every agent's maps IN PLACE from one buffer -- agent a's [C,H,W] features at
+ *   base + feat_offsets_host[a] floats, its [H,W] scores at base + score_offsets_host[a] (multiples of 4 floats).  The
+ *   agent-sharded runner points it at the rows of the exchange buffer, so nothing is re-packed after the gather. */
+int heal_fuse_warped_rows(const float* base, const int64_t* feat_offsets_host, const int64_t* score_offsets_host,
+                          int n_agents, int channels, int H, int W, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8  box decode + filters + rotated NMS.
