@@ -35,6 +35,8 @@ _SIGNATURES = {
     "heal_bev_pool_backward": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p] * 6),
     "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),
+    "heal_warp_fuse_levels": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p]),
     "heal_warp_fuse_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "heal_warp_agent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,

@@ -17,6 +17,7 @@
 // in the dtype of the affine matrix (float64 when pairwise_t_matrix comes from numpy), grid =
 // base @ M^T, rounded to fp32, unnormalise ((g+1)*size-1)/2, floor, corner weights as products of
 // fp32 differences, taps outside the image contribute zero.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/heal_amd.h"
 
@@ -209,6 +210,195 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (c + u < p.C) out[(size_t)(c + u) * HW + pix] = acc[u];
+    }
+}
+
+// ---- round 4: all pyramid levels in ONE launch, source footprints staged through LDS ------------------------------------------
+// k_warp_fuse above gathers every tap straight from global memory: one thread = one ego pixel, and for each channel the 64
+// lanes of a wave read 4 x n_agents scattered 4-byte words along a rotated line of the source map -- 16-32 cache lines per wave
+// instruction.  Its HBM traffic equals the algorithmic bytes (PMC), but the texture-address path is the limit: 35 cycles per
+// gather instruction per CU, 0.16 of the HBM roof.  Here a block is a 16 x 16 tile of ego pixels x a slice of the channels:
+//   1. every thread computes, once, its taps per agent (the reference's sampling arithmetic: make_taps), samples the occupancy
+//      score (a one-channel map: 4 words per agent), runs the masked softmax over agents and folds the probability and the
+//      "inside the image" test into four tap weights per agent;
+//   2. per agent the block reduces the bounding box of the taps it will read (LDS min / max): for a rigid pose <= 25 x 25 source
+//      pixels for 256 ego pixels;
+//   3. per agent and group of 8 channels that box goes global -> LDS as ROW SEGMENTS (a half-wave reads up to 32 consecutive
+//      floats: 2-4 cache lines per wave instruction instead of 16-32), and every thread takes its four taps from LDS;
+//   4. a box that does not fit the 32 x 32 staging tile (a zooming affine matrix) falls back to the direct gather for that
+//      agent -- any matrix gives the right answer.
+// All levels of the pyramid are one grid (level = a block-index range): one launch instead of three, no launch gaps on the
+// critical path of the scene (pyramid_fuse.py:104-168 runs the three levels back to back).
+constexpr int WL_T = 16;            // ego tile side
+constexpr int WL_BMAX = 32;         // largest staged source box side
+constexpr int WL_CC = 8;            // channels per staging round
+constexpr int WL_MAXL = 4;          // pyramid levels per launch
+
+struct WfLevel {
+    const float* feats;     // [n_agents, C, H, W]
+    const float* occ;       // [n_agents, 1, H, W]
+    float* out;             // [C, H, W]
+    int C, H, W;
+    int tiles_x, cgroups, cpb;   // tiles per row, channel slices per tile, channels per slice
+    int block0;                  // first block of this level
+    int crop[WF_MAXA][4];
+};
+struct WfLevels {
+    WfLevel lv[WL_MAXL];
+    int n_levels, n_agents, grid_f64, dbg;
+    const double* mdev;
+    double m[WF_MAXA][6];
+};
+
+template <int NA>
+__global__ __launch_bounds__(256) void k_warp_fuse_lds(const WfLevels P) {
+    __shared__ float s_box_f[WL_CC * WL_BMAX * (WL_BMAX + 1)];
+    __shared__ int s_box[WF_MAXA][4];      // min x, min y, max x, max y of the taps the block reads from agent a
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < WL_MAXL; ++i)
+        if (i < P.n_levels && (int)blockIdx.x >= P.lv[i].block0) lvl = i;
+    const WfLevel& L = P.lv[lvl];
+    const int lb = blockIdx.x - L.block0;
+    const int cg = lb % L.cgroups, tile = lb / L.cgroups;
+    const int tx0 = (tile % L.tiles_x) * WL_T, ty0 = (tile / L.tiles_x) * WL_T;
+    const int tid = threadIdx.x;
+    const int w = tx0 + (tid & (WL_T - 1)), h = ty0 + (tid >> 4);
+    const bool live = w < L.W && h < L.H;
+    const int HW = L.H * L.W;
+    if (tid < NA) { s_box[tid][0] = 1 << 30; s_box[tid][1] = 1 << 30; s_box[tid][2] = -(1 << 30); s_box[tid][3] = -(1 << 30); }
+    __syncthreads();
+
+    int tx[NA], ty[NA];          // north-west tap of agent a (clamped into [-2, W] x [-2, H]: only dereferenced under `ok`)
+    unsigned okb[NA];
+    float wt[NA][4];
+    float prob[WF_MAXA];
+#pragma unroll
+    for (int a = NA; a < WF_MAXA; ++a) prob[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        prob[a] = 0.f; okb[a] = 0u; tx[a] = 0; ty[a] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wt[a][k] = 0.f;
+        if (live) {
+            float gx, gy;
+            double m[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = P.mdev ? P.mdev[a * 6 + k] : P.m[a][k];   // wave-uniform scalar loads
+            if (P.grid_f64) grid_point<double>(m, h, w, L.H, L.W, gx, gy);
+            else grid_point<float>(m, h, w, L.H, L.W, gx, gy);
+            const Taps t = make_taps(gx, gy, L.H, L.W);
+            prob[a] = sample_score(L.occ + (size_t)a * HW, t, L.W, L.crop[a]);
+            // north-west tap coordinates: the clamps of make_taps on the coordinates themselves (t.off = y0 * W + x0)
+            const float ix = ((gx + 1.f) * (float)L.W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)L.H - 1.f) / 2.f;
+            tx[a] = (int)fminf(fmaxf(floorf(ix), -2.f), (float)L.W);
+            ty[a] = (int)fminf(fmaxf(floorf(iy), -2.f), (float)L.H);
+            okb[a] = t.ok;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wt[a][k] = ((t.ok >> k) & 1u) ? t.w[k] : 0.f;
+        }
+    }
+    agent_softmax(prob, NA);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wt[a][k] *= prob[a];
+        // taps that carry weight extend the agent's box
+        const bool any = (wt[a][0] != 0.f) | (wt[a][1] != 0.f) | (wt[a][2] != 0.f) | (wt[a][3] != 0.f);
+        if (!any) okb[a] = 0u;
+        // wave-level min / max first, then ONE LDS atomic per wave and bound: 256 threads hitting the same four words serialise
+        // (measured: the prologue alone took 200 us of the kernel's 250 with per-thread atomics)
+        int x_lo = any ? ((okb[a] & 5u) ? tx[a] : tx[a] + 1) : (1 << 30), x_hi = any ? ((okb[a] & 10u) ? tx[a] + 1 : tx[a]) : -(1 << 30);
+        int y_lo = any ? ((okb[a] & 3u) ? ty[a] : ty[a] + 1) : (1 << 30), y_hi = any ? ((okb[a] & 12u) ? ty[a] + 1 : ty[a]) : -(1 << 30);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x_lo = min(x_lo, __shfl_xor(x_lo, o, 64)); y_lo = min(y_lo, __shfl_xor(y_lo, o, 64));
+            x_hi = max(x_hi, __shfl_xor(x_hi, o, 64)); y_hi = max(y_hi, __shfl_xor(y_hi, o, 64));
+        }
+        if ((tid & 63) == 0 && x_lo <= x_hi) {
+            atomicMin(&s_box[a][0], x_lo); atomicMin(&s_box[a][1], y_lo);
+            atomicMax(&s_box[a][2], x_hi); atomicMax(&s_box[a][3], y_hi);
+        }
+    }
+    __syncthreads();
+
+    const int c_lo = cg * L.cpb, c_hi = (P.dbg & 1) ? c_lo : min(c_lo + L.cpb, L.C);
+    const int pix = h * L.W + w;
+    const int lx = tid & 31, ry = tid >> 5;      // staging role: column of a box row, one of 8 row workers
+    for (int c0 = c_lo; c0 < c_hi; c0 += WL_CC) {
+        float acc[WL_CC];
+#pragma unroll
+        for (int u = 0; u < WL_CC; ++u) acc[u] = 0.f;
+        const int nc = min(WL_CC, c_hi - c0);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int bx0 = s_box[a][0], by0 = s_box[a][1], bw = s_box[a][2] - bx0 + 1, bh = s_box[a][3] - by0 + 1;
+            if (bw <= 0 || bh <= 0) continue;                       // block-uniform: no pixel of the tile sees agent a
+            const float* __restrict__ base = L.feats + ((size_t)a * L.C + c0) * HW;
+            if (bw <= WL_BMAX && bh <= WL_BMAX) {
+                const int pitch = bw | 1;
+                // the [nc][bh][bw] box: lane lx = column, row worker ry takes rows ry, ry + 8, ry + 16, ry + 24 of every channel.
+                // ALL loads of a thread are issued (on clamped, always valid addresses) before the first LDS store: a load ->
+                // store loop with a run-time trip count waits for every load in turn (the first version of this kernel: 2.3x
+                // slower than the direct gather)
+                float st[4][WL_CC];
+                const int xs = min(lx, bw - 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* rowp = base + (size_t)(by0 + min(ry + 8 * j, bh - 1)) * L.W + bx0 + xs;
+#pragma unroll
+                    for (int u = 0; u < WL_CC; ++u) st[j][u] = (P.dbg & 2) ? 1.f : rowp[(size_t)min(u, nc - 1) * HW];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = ry + 8 * j;
+                    if (lx < bw && y < bh) {
+#pragma unroll
+                        for (int u = 0; u < WL_CC; ++u)
+                            if (u < nc) s_box_f[(u * bh + y) * pitch + lx] = st[j][u];
+                    }
+                }
+                __syncthreads();
+                if (okb[a] && !(P.dbg & 4)) {
+                    const int o = (ty[a] - by0) * pitch + (tx[a] - bx0);
+                    // taps without weight may lie outside the box: clamp their offsets to a staged word (weight 0 kills them)
+                    const int o0 = (okb[a] & 1u) ? o : 0, o1 = (okb[a] & 2u) ? o + 1 : 0;
+                    const int o2 = (okb[a] & 4u) ? o + pitch : 0, o3 = (okb[a] & 8u) ? o + pitch + 1 : 0;
+#pragma unroll
+                    for (int u = 0; u < WL_CC; ++u) {
+                        if (u < nc) {
+                            const float* s = s_box_f + u * bh * pitch;
+                            float v = s[o0] * wt[a][0];
+                            v += s[o1] * wt[a][1];
+                            v += s[o2] * wt[a][2];
+                            v += s[o3] * wt[a][3];
+                            acc[u] += v;
+                        }
+                    }
+                }
+                __syncthreads();
+            } else if (okb[a]) {                                      // a box larger than the staging tile: direct gather
+                const int o = ty[a] * L.W + tx[a];
+                const int o0 = (okb[a] & 1u) ? o : 0, o1 = (okb[a] & 2u) ? o + 1 : 0;
+                const int o2 = (okb[a] & 4u) ? o + L.W : 0, o3 = (okb[a] & 8u) ? o + L.W + 1 : 0;
+#pragma unroll
+                for (int u = 0; u < WL_CC; ++u) {
+                    if (u < nc) {
+                        const float* src = base + (size_t)u * HW;
+                        float v = src[o0] * wt[a][0];
+                        v += src[o1] * wt[a][1];
+                        v += src[o2] * wt[a][2];
+                        v += src[o3] * wt[a][3];
+                        acc[u] += v;
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < WL_CC; ++u)
+                if (u < nc) L.out[(size_t)(c0 + u) * HW + pix] = acc[u];
+        }
     }
 }
 
@@ -421,6 +611,56 @@ extern "C" int heal_warp_fuse(const float* feats, const float* occ, int n_agents
 #define HEAL_WF(N) case N: k_warp_fuse<N><<<grid, 256, 0, st>>>(feats, occ, p, cch, out); break;
         HEAL_WF(1) HEAL_WF(2) HEAL_WF(3) HEAL_WF(4) HEAL_WF(5) HEAL_WF(6) HEAL_WF(7) HEAL_WF(8)
 #undef HEAL_WF
+    }
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_warp_fuse_levels(int n_levels, const float* const* feats_host, const float* const* occ_host,
+                                     int n_agents, const int32_t* channels_host, const int32_t* h_host, const int32_t* w_host,
+                                     const double* affine_host, const double* affine_dev, int grid_f64,
+                                     const int32_t* crop_host, float* const* out_host, void* stream) {
+    HEAL_REQUIRE(n_levels >= 1 && n_levels <= WL_MAXL, "warp_fuse_levels: 1..%d levels per launch (got %d)", WL_MAXL, n_levels);
+    HEAL_REQUIRE(n_agents >= 1 && n_agents <= WF_MAXA, "warp_fuse_levels: n_agents must be in [1,%d] (got %d)", WF_MAXA, n_agents);
+    HEAL_REQUIRE(affine_host != nullptr || affine_dev != nullptr, "warp_fuse_levels: affine is NULL (host and device)");
+    WfLevels P;
+    P.n_levels = n_levels; P.n_agents = n_agents; P.grid_f64 = grid_f64; P.mdev = affine_dev;
+    { const char* e = getenv("HEAL_K5_DBG"); P.dbg = e ? atoi(e) : 0; }   // timing experiments only
+    for (int a = 0; a < WF_MAXA; ++a)
+        for (int k = 0; k < 6; ++k) P.m[a][k] = (a < n_agents && affine_host) ? affine_host[a * 6 + k] : 0.0;
+    long long blocks = 0;
+    for (int l = 0; l < WL_MAXL; ++l) {
+        WfLevel& L = P.lv[l];
+        if (l >= n_levels) { L = P.lv[0]; L.block0 = 1 << 30; continue; }
+        HEAL_REQUIRE(feats_host[l] && occ_host[l] && out_host[l] && channels_host[l] >= 1 && h_host[l] >= 1 && w_host[l] >= 1,
+                     "warp_fuse_levels: bad level %d", l);
+        L.feats = feats_host[l]; L.occ = occ_host[l]; L.out = out_host[l];
+        L.C = channels_host[l]; L.H = h_host[l]; L.W = w_host[l];
+        L.tiles_x = ceil_div(L.W, WL_T);
+        const int tiles = L.tiles_x * ceil_div(L.H, WL_T);
+        // channel slices per tile: the per-pixel prologue (fp64 grid, taps, 4 n_agents score samples with their sigmoids, softmax:
+        // half of the kernel's time at 2048 blocks per level) is recomputed by every slice, so as few slices as still give ~512
+        // blocks per level, in whole staging rounds of 8 channels.  Measured at scene5 size (scripts/k5_bench.py, HEAL_K5_BLOCKS):
+        // 2048 -> 110 us, 1024 -> 102, 768 -> 91, 512 -> 89, 384 -> 97, 256 -> 116 (three per-level launches of round 3: 135).
+        int target = 512;
+        if (const char* e = getenv("HEAL_K5_BLOCKS")) target = atoi(e) > 0 ? atoi(e) : target;
+        int cg = (int)((target + tiles - 1) / tiles);
+        cg = cg < 1 ? 1 : cg;
+        int cpb = ceil_div(ceil_div(L.C, cg), WL_CC) * WL_CC;
+        L.cpb = cpb;
+        L.cgroups = ceil_div(L.C, cpb);
+        L.block0 = (int)blocks;
+        blocks += (long long)tiles * L.cgroups;
+        for (int a = 0; a < WF_MAXA; ++a)
+            for (int k = 0; k < 4; ++k)
+                L.crop[a][k] = (a < n_agents && crop_host) ? crop_host[((size_t)l * n_agents + a) * 4 + k] : 0;
+    }
+    HEAL_REQUIRE(blocks < (1ll << 30), "warp_fuse_levels: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_agents) {
+#define HEAL_WFL(N) case N: k_warp_fuse_lds<N><<<(unsigned)blocks, 256, 0, st>>>(P); break;
+        HEAL_WFL(1) HEAL_WFL(2) HEAL_WFL(3) HEAL_WFL(4) HEAL_WFL(5) HEAL_WFL(6) HEAL_WFL(7) HEAL_WFL(8)
+#undef HEAL_WFL
     }
     HEAL_LAUNCH_CHECK();
     return 0;

@@ -119,6 +119,24 @@ class PyramidFusion(ResNetBEVBackbone):
         feature_list = self.get_multiscale_feature(spatial_features)
         use_crop = bool(cam_crop_info) and not self.training
         fused_feature_list, occ_map_list = [], []
+        import os
+        if (len(record_len) == 1 and not torch.is_grad_enabled() and feature_list[0].is_cuda and 1 <= self.num_levels <= 4
+                and int(record_len[0]) <= 8 and os.environ.get("HEAL_K5_LEVELS", "1") == "1"):
+            # inference, one scene: the three levels are independent once the stages ran -> ONE K5 launch for all of them
+            # (heal_warp_fuse_levels; HEAL_K5_LEVELS=0 keeps one heal_warp_fuse launch per level for A/B)
+            n = int(record_len[0])
+            crops_all = []
+            for i in range(self.num_levels):
+                occ_map_list.append(self.occupancy_head(i, feature_list[i]))
+                crops = None
+                if use_crop:
+                    _, _, H, W = occ_map_list[i].shape
+                    crops = [crop_window(H, W, cam_crop_info[mod][f"crop_ratio_H_{mod}"], cam_crop_info[mod][f"crop_ratio_W_{mod}"])
+                             if mod in cam_crop_info else None for mod in agent_modality_list]
+                crops_all.append(crops)
+            fused = ops.warp_fuse_levels([f[:n] for f in feature_list], [o[:n] for o in occ_map_list], affine_matrix[0][0, :n],
+                                         grid_f64, crops_all if use_crop else None)
+            return self.decode_multiscale_feature([f.unsqueeze(0) for f in fused]), occ_map_list
         for i in range(self.num_levels):
             occ_map = self.occupancy_head(i, feature_list[i])
             occ_map_list.append(occ_map)

@@ -404,6 +404,40 @@ def warp_fuse(feats, occ, affine_rows, grid_f64=True, crop=None):
     return out
 
 
+def warp_fuse_levels(feats_list, occ_list, affine_rows, grid_f64=True, crops=None):
+    """K5 for every pyramid level of one scene in ONE launch (heal_warp_fuse_levels: LDS-staged source footprints).
+    feats_list[l] [n,C_l,H_l,W_l], occ_list[l] [n,1,H_l,W_l] logits, affine_rows [n,2,3] (host array or CUDA tensor, shared by
+    the levels), crops[l] = per-agent (h0,h1,w0,w1) | None -> list of [C_l,H_l,W_l]."""
+    L = len(feats_list)
+    feats_list = [_need(f, torch.float32, "feats") for f in feats_list]
+    occ_list = [_need(o, torch.float32, "occ") for o in occ_list]
+    n = int(feats_list[0].shape[0])
+    outs, nbytes = [], 0.0
+    for f, o in zip(feats_list, occ_list):
+        if int(f.shape[0]) != n or tuple(o.shape) != (n, 1, int(f.shape[2]), int(f.shape[3])):
+            raise _capi.HealAmdError("warp_fuse_levels: inconsistent level shapes")
+        C, H, W = (int(v) for v in f.shape[1:])
+        outs.append(torch.empty((C, H, W), dtype=torch.float32, device=f.device))
+        nbytes += 4.0 * H * W * (n * (C + 1) + C)          # SURVEY 8d
+    a, ap, adev = _affine_args(affine_rows, n)
+    cp, carr = ctypes.c_void_p(0), None
+    if crops is not None and any(c is not None for c in crops):
+        carr = np.zeros((L, n, 4), dtype=np.int32)
+        for l, c in enumerate(crops):
+            if c is not None:
+                carr[l] = np.asarray([ci if ci is not None else (0, 0, 0, 0) for ci in c], dtype=np.int32).reshape(n, 4)
+        cp = carr.ctypes.data_as(ctypes.c_void_p)
+    fp = _host_array([f.data_ptr() for f in feats_list], ctypes.c_void_p)
+    op = _host_array([o.data_ptr() for o in occ_list], ctypes.c_void_p)
+    yp = _host_array([y.data_ptr() for y in outs], ctypes.c_void_p)
+    with _Timed("warp_fuse_levels", 0.0, nbytes):
+        _capi.call("heal_warp_fuse_levels", L, fp, op, n, _host_array([int(f.shape[1]) for f in feats_list], ctypes.c_int32),
+                   _host_array([int(f.shape[2]) for f in feats_list], ctypes.c_int32),
+                   _host_array([int(f.shape[3]) for f in feats_list], ctypes.c_int32), ap, adev, int(bool(grid_f64)), cp, yp,
+                   _stream())
+    return outs
+
+
 def warp_fuse_backward(feats, occ, affine_rows, grad_out, grid_f64=True, crop=None):
     """Gradient of warp_fuse with respect to (feats, occ): grad_out [C,H,W] -> ([n,C,H,W], [n,1,H,W])."""
     feats = _need(feats, torch.float32, "feats")

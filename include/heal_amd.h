@@ -127,6 +127,16 @@ int heal_warp_fuse(const float* feats, const float* occ, int n_agents, int chann
                    const double* affine_host, const double* affine_dev, int grid_f64,
                    const int32_t* crop_host, float* out, void* stream);
 
+/* heal_warp_fuse_levels: heal_warp_fuse for ALL levels of the pyramid in one launch (pyramid_fuse.py:104-168 fuses the three
+ *   levels back to back), the source footprint of every 16 x 16 ego tile staged through LDS as row segments instead of gathered
+ *   word by word.  Level l: feats_host[l] [n_agents, C_l, H_l, W_l], occ_host[l] [n_agents, 1, H_l, W_l], out_host[l] [C_l, H_l, W_l]
+ *   (HOST arrays of device pointers); the affine rows are shared by the levels (normalised coordinates); crop_host
+ *   [n_levels][n_agents][4] or NULL.  Same arithmetic, operation for operation, as heal_warp_fuse: bit-identical results.  */
+int heal_warp_fuse_levels(int n_levels, const float* const* feats_host, const float* const* occ_host, int n_agents,
+                          const int32_t* channels_host, const int32_t* h_host, const int32_t* w_host,
+                          const double* affine_host, const double* affine_dev, int grid_f64, const int32_t* crop_host,
+                          float* const* out_host, void* stream);
+
 /* heal_warp_fuse_backward: gradient of heal_warp_fuse with respect to the agents' maps and occupancy logits (training; the
  *   autograd of warp_affine_simple x 2 + masked softmax + weighted sum, pyramid_fuse.py:17-63,145-162).  Arguments as
  *   heal_warp_fuse plus grad_out [C,H,W]; grad_feats [n_agents,C,H,W] and grad_occ [n_agents,1,H,W] must be ZERO on entry

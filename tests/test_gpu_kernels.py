@@ -1421,3 +1421,38 @@ def test_conv1x1_tiled_equals_torch(n, cin, cout, H, W, res, act, monkeypatch):
         want = torch.nn.functional.pixel_shuffle(torch.relu(torch.nn.functional.conv2d(x, w, b)), 2)
         assert float((dst[:, 2:2 + cout // 4] - want).abs().max() / want.abs().max()) < 1e-5
         assert float(dst[:, :2].min()) == -7.0 and float(dst[:, 2 + cout // 4:].max()) == -7.0
+
+
+@pytest.mark.parametrize("n,dims,f64,kind", [(5, [(64, 256, 256), (128, 128, 128), (256, 64, 64)], True, "pose"),
+                                             (3, [(24, 40, 56), (12, 20, 28)], False, "pose"),
+                                             (2, [(8, 48, 48)], True, "zoom"), (8, [(16, 32, 32), (8, 16, 16), (8, 8, 8), (4, 4, 4)], True, "pose")])
+def test_warp_fuse_levels_equals_per_level(n, dims, f64, kind):
+    """heal_warp_fuse_levels (all pyramid levels in ONE launch, the source footprint of every 16 x 16 ego tile staged through LDS)
+    must be BIT-IDENTICAL to heal_warp_fuse level by level -- same sampling arithmetic, same summation order -- at the scene's
+    full size (5 agents, 64 / 128 / 256 channels), on maps that do not fill a tile, with a camera crop window, with device-resident
+    affine rows, and for a ZOOMING affine matrix whose footprint does not fit the staging tile (direct-gather fallback)."""
+    from heal_amd import ops, synth
+    from heal_amd.opencood.models.fuse_modules.pyramid_fuse import crop_window
+    rng = np.random.default_rng(n * 10 + len(dims))
+    if kind == "pose":
+        poses = synth.agent_poses(11 + n, n, r_min=2.0, r_max=30.0)
+        pw = synth.pairwise_t_matrix(poses, 8)[None].astype(np.float64 if f64 else np.float32)
+        rows = O.normalize_pairwise_tfm(pw, 204.8, 204.8, 1)[0][0, :n]
+    else:   # 3x zoom-out + rotation: a 16 x 16 ego tile reads a ~60 x 60 source box
+        th = 0.6
+        rows = np.stack([np.array([[3 * np.cos(th), -3 * np.sin(th), 0.1], [3 * np.sin(th), 3 * np.cos(th), -0.2]]),
+                         np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])]).astype(np.float64)
+    feats = [dev(rng.standard_normal((n, C, H, W)).astype(np.float32)) for C, H, W in dims]
+    occs = [dev((rng.standard_normal((n, 1, H, W)) * 2).astype(np.float32)) for C, H, W in dims]
+    crops = None
+    if n >= 3:
+        crops = [[crop_window(H, W, 2.0, 2.0) if a == 1 else None for a in range(n)] for C, H, W in dims]
+    got = ops.warp_fuse_levels(feats, occs, rows, f64, crops)
+    for l, (C, H, W) in enumerate(dims):
+        cr = None if crops is None else [c if c is not None else (0, 0, 0, 0) for c in crops[l]]
+        want = ops.warp_fuse(feats[l], occs[l], rows, f64, cr)
+        assert got[l].shape == want.shape == (C, H, W)
+        assert torch.equal(got[l], want), (l, float((got[l] - want).abs().max()))
+    again = ops.warp_fuse_levels(feats, occs, torch.from_numpy(np.asarray(rows, dtype=np.float64)).cuda(), f64, crops)
+    if f64:
+        assert all(torch.equal(a, b) for a, b in zip(again, got))
