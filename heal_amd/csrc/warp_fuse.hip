@@ -227,6 +227,9 @@ __global__ __launch_bounds__(256, 4) void k_warp_fuse(const float* __restrict__ 
 //      floats: 2-4 cache lines per wave instruction instead of 16-32), and every thread takes its four taps from LDS;
 //   4. a box that does not fit the 32 x 32 staging tile (a zooming affine matrix) falls back to the direct gather for that
 //      agent -- any matrix gives the right answer.
+// Measured and dropped: a software pipeline over the (round, agent) slots with two LDS buffers and one barrier per slot (the
+// next slot's row segments in flight under the current slot's taps): 115 vs 85 us -- two resident blocks per CU instead of four
+// lose more than the halved barrier count gains.
 // All levels of the pyramid are one grid (level = a block-index range): one launch instead of three, no launch gaps on the
 // critical path of the scene (pyramid_fuse.py:104-168 runs the three levels back to back).
 constexpr int WL_T = 16;            // ego tile side
@@ -267,6 +270,16 @@ __global__ __launch_bounds__(256) void k_warp_fuse_lds(const WfLevels P) {
     const bool live = w < L.W && h < L.H;
     const int HW = L.H * L.W;
     if (tid < NA) { s_box[tid][0] = 1 << 30; s_box[tid][1] = 1 << 30; s_box[tid][2] = -(1 << 30); s_box[tid][3] = -(1 << 30); }
+    // base grid coordinates of the tile's 16 columns and 16 rows (torch.linspace(-1, 1, n) * (n - 1) / n: two divisions each, in
+    // fp64 when the affine matrix is): evaluated once by 32 threads instead of twice by all 256
+    __shared__ double s_base_d[2][WL_T];
+    __shared__ float s_base_f[2][WL_T];
+    if (tid < 2 * WL_T) {
+        const int ax = tid >> 4, j = tid & (WL_T - 1);
+        const int idx = (ax ? ty0 : tx0) + j, nn = ax ? L.H : L.W;
+        s_base_d[ax][j] = base_coord<double>(min(idx, nn - 1), nn);
+        s_base_f[ax][j] = base_coord<float>(min(idx, nn - 1), nn);
+    }
     __syncthreads();
 
     int tx[NA], ty[NA];          // north-west tap of agent a (clamped into [-2, W] x [-2, H]: only dereferenced under `ok`)
@@ -285,8 +298,15 @@ __global__ __launch_bounds__(256) void k_warp_fuse_lds(const WfLevels P) {
             double m[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) m[k] = P.mdev ? P.mdev[a * 6 + k] : P.m[a][k];   // wave-uniform scalar loads
-            if (P.grid_f64) grid_point<double>(m, h, w, L.H, L.W, gx, gy);
-            else grid_point<float>(m, h, w, L.H, L.W, gx, gy);
+            if (P.grid_f64) {      // grid_point<T> with the base coordinates taken from LDS (same operations, same order)
+                const double xs = s_base_d[0][tid & (WL_T - 1)], ys = s_base_d[1][tid >> 4];
+                gx = (float)((m[0] * xs + m[1] * ys) + m[2]);
+                gy = (float)((m[3] * xs + m[4] * ys) + m[5]);
+            } else {
+                const float xs = s_base_f[0][tid & (WL_T - 1)], ys = s_base_f[1][tid >> 4];
+                gx = (float)(((float)m[0] * xs + (float)m[1] * ys) + (float)m[2]);
+                gy = (float)(((float)m[3] * xs + (float)m[4] * ys) + (float)m[5]);
+            }
             const Taps t = make_taps(gx, gy, L.H, L.W);
             prob[a] = sample_score(L.occ + (size_t)a * HW, t, L.W, L.crop[a]);
             // north-west tap coordinates: the clamps of make_taps on the coordinates themselves (t.off = y0 * W + x0)
