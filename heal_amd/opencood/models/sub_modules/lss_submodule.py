@@ -308,6 +308,14 @@ class CamEncode_Resnet101(_CamEncodeBase):
 
     def features(self, x):
         """lss_submodule.py:196-210: conv1 -> bn1 -> relu -> maxpool -> layer1 -> layer2 -> [BN, 512, fH, fW]."""
+        if x.is_cuda and not grad_path(x, self) and tuple(self.maxpool.kernel_size if isinstance(self.maxpool.kernel_size, tuple)
+                                                           else (self.maxpool.kernel_size,) * 2) == (3, 3):
+            # conv1 (7x7 / 2) + bn1 + relu + maxpool (3x3 / 2) in ONE kernel on the first three channels of the image tensor read
+            # in place (heal_stem7x7): no channel-slice copy, no library convolution, the 64-channel half-resolution map never
+            # reaches HBM
+            from heal_amd import ops
+            w, b = self._c.get(self.conv1, self.bn1)
+            return self.layer2(self.layer1(ops.stem7x7(x, w, b, pool=True)))
         f = ConvBN.run(x[:, :3, :, :], self.conv1, self.bn1, self._c, relu=True)
         return self.layer2(self.layer1(self.maxpool(f)))
 

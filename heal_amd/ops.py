@@ -1318,6 +1318,46 @@ def conv1x1_ksplit(n, cin, cout, hw):
     return -(-chunks // -(-chunks // want))       # ceil(chunks / ceil(chunks / want)): no empty split
 
 
+_STEM_CACHE = {}
+
+
+def stem7x7_fragments(w):
+    """[64, cin, 7, 7] -> MFMA A-fragment order [4][ceil(cin * 49 / 4)][64] of heal_stem7x7 (cached per storage + version)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _STEM_CACHE.get(key)
+    if hit is None:
+        if len(_STEM_CACHE) > 64:
+            _WS_RETIRED.extend(v[0] for v in _STEM_CACHE.values())
+            _STEM_CACHE.clear()
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        if cout != 64 or tuple(w.shape[2:]) != (7, 7) or not 1 <= cin <= 4:
+            raise _capi.HealAmdError(f"stem7x7: weight must be [64, 1..4, 7, 7], got {tuple(w.shape)}")
+        K = cin * 49
+        ks = (K + 3) // 4
+        wk = torch.nn.functional.pad(w.detach().to(torch.float32).reshape(64, K), (0, 4 * ks - K))      # [64, 4 ks]
+        frag = wk.reshape(4, 16, ks, 4).permute(0, 2, 3, 1).contiguous()                               # [mt][ks][lk][ln]
+        hit = _STEM_CACHE[key] = (frag, w)
+    return hit[0]
+
+
+def stem7x7(x, w, bias, pool=True):
+    """relu(conv7x7/2(x[:, :cin], w) + bias) (+ 3x3/2 max-pool) in one kernel; x [n, >= cin, H, W] is read in place (the first
+    cin = w.shape[1] channels of every image).  -> [n, 64, Hp, Wp]."""
+    x = _need(x, torch.float32, "x")
+    n, cx, H, W = (int(v) for v in x.shape)
+    cin = int(w.shape[1])
+    if cx < cin:
+        raise _capi.HealAmdError(f"stem7x7: input has {cx} channels, the weight wants {cin}")
+    frag = stem7x7_fragments(w)
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Ho, Wo = ((Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1) if pool else (Hc, Wc)
+    y = torch.empty((n, 64, Ho, Wo), dtype=torch.float32, device=x.device)
+    with _Timed(f"stem7x7_{cin}" + ("_pool" if pool else ""), 2.0 * n * 64 * cin * 49 * Hc * Wc, kernel_events=True):
+        _capi.call("heal_stem7x7", _ptr(x), cx * H * W, n, cin, H, W, _ptr(frag),
+                   _ptr(_need(bias, torch.float32, "bias")) if bias is not None else None, int(bool(pool)), _ptr(y), _stream())
+    return y
+
+
 def conv1x1_tiled_ok(n, cin, cout, hw):
     """Shapes the 128 x 128 x 32 core (heal_conv1x1_tiled, 32x32x2 fp32 MFMA) takes over from heal_conv1x1: 32-channel K chunks,
     64- or 128-channel M tiles, enough blocks to fill the chip, and a reduction deep enough to be MFMA- rather than HBM-bound.

@@ -472,6 +472,14 @@ int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bia
  *   the K chunks split over `ksplit` blocks: partial sums go to the workspace [ksplit][n][Cout][HW], a second launch adds them
  *   in split order (deterministic) and applies bias / residual / activation.  ksplit in [2, ceil32(Cin)/32] with no empty
  *   split; workspace from heal_conv1x1_splitk_workspace, 16-B aligned; H*W % 4 == 0.                                  */
+/* heal_stem7x7: the ResNet image stem in one kernel -- Conv2d(cin <= 4 -> 64, kernel 7, stride 2, padding 3) + bias (folded
+ *   BatchNorm) + ReLU and, with pool != 0, MaxPool2d(3, stride 2, padding 1) (lss_submodule.py:153-161,196-210; torchvision
+ *   resnet101 conv1 / bn1 / relu / maxpool).  x: images `image_stride` floats apart, the FIRST cin channels of each are read in
+ *   place ([n, >= cin, H, W]: no contiguous copy of a channel slice).  weight_frag [4][ceil(cin*49/4)][64]: the [64, cin*49]
+ *   weight matrix in 16x16x4 A-fragment order, frag[mt][ks][16 lk + ln] = W[16 mt + ln][4 ks + lk] (zero beyond cin*49).
+ *   y: [n, 64, Hp, Wp] with Hp = ((H - 1) / 2) / 2 + 1 ... (pool) or [n, 64, (H - 1) / 2 + 1, (W - 1) / 2 + 1] (no pool).          */
+int heal_stem7x7(const float* x, long long image_stride, int n, int cin, int H, int W, const float* weight_frag,
+                 const float* bias, int pool, float* y, void* stream);
 /* heal_conv1x1_tiled: the same pointwise convolution on the 128 x 128 x 32 core (v_mfma_f32_32x32x2_f32, both operands through
  *   LDS) for its MFMA-bound shapes: weight is the PLAIN [Cout, Cin] row-major matrix (nn.Conv2d's storage, no fragment
  *   pre-layout); Cin % 32 == 0, Cout % 64 == 0, stride 1, no input gate.  d2s_k = 0: y [n, Cout, H, W]; d2s_k = k >= 1: the

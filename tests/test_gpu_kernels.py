@@ -1456,3 +1456,23 @@ def test_warp_fuse_levels_equals_per_level(n, dims, f64, kind):
     again = ops.warp_fuse_levels(feats, occs, torch.from_numpy(np.asarray(rows, dtype=np.float64)).cuda(), f64, crops)
     if f64:
         assert all(torch.equal(a, b) for a, b in zip(again, got))
+
+
+@pytest.mark.parametrize("n,cx,cin,H,W,pool", [(4, 3, 3, 336, 448, True), (2, 4, 3, 96, 128, True), (1, 3, 3, 50, 70, True),
+                                               (3, 4, 4, 33, 47, False), (1, 1, 1, 64, 64, True), (2, 3, 2, 40, 36, False)])
+def test_stem7x7_equals_torch(n, cx, cin, H, W, pool):
+    """heal_stem7x7 (ResNet image stem: 7x7 / 2 convolution + folded BN + ReLU + 3x3 / 2 max-pool in one kernel, the first `cin`
+    channels of the image tensor read in place) against plain PyTorch fp32: conv2d -> relu -> max_pool2d; full camera size, odd
+    sizes whose last tiles hang over the map, a 4-channel image tensor of which 3 channels are used, and the pool-free form."""
+    import torch.nn.functional as F
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn((n, cx, H, W), generator=g).cuda()
+    w = (torch.randn((64, cin, 7, 7), generator=g) / (49 * cin) ** 0.5).cuda()
+    b = torch.randn((64,), generator=g).cuda()
+    got = ops.stem7x7(x, w, b, pool=pool)
+    ref = torch.relu(F.conv2d(x[:, :cin], w, b, stride=2, padding=3))
+    if pool:
+        ref = F.max_pool2d(ref, 3, 2, 1)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
