@@ -38,7 +38,7 @@ for n in (5, 2, 8):
     per = [timeit(lambda: ops.warp_fuse(feats[l], occs[l], rows)) for l in range(3)]
     res[f"{n} agents"] = {"per_level_three_launches_us": round(t_old, 1), "per_level_us": [round(v, 1) for v in per],
                           "levels_one_launch_us": round(t_new, 1), "alg_MB": round(byts / 1e6, 1),
-                          "frac_hbm_old": round(byts / t_old / 1e6 / 8000, 3), "frac_hbm_new": round(byts / t_new / 1e6 / 8000, 3)}
+                          "frac_hbm_old": round(byts / t_old / 1e6 / 8.0, 3), "frac_hbm_new": round(byts / t_new / 1e6 / 8.0, 3)}
     print(n, res[f"{n} agents"], flush=True)
 if "--json" in sys.argv:
     json.dump(res, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

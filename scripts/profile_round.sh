@@ -1,11 +1,11 @@
 #!/bin/bash
 # Round profile: PMC traffic passes first (bench.py reads them for `roofline.traffic`), then the bench lines of every workload and
 # the rocprofv3 kernel stats of the two BASELINE configurations.  GPU box:
-#   gpurun -- 'bash scripts/profile_round.sh r03'
+#   gpurun -- 'bash scripts/profile_round.sh r04'
 # Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries to profiles/ afterwards (the PMC json is also written straight
 # into profiles/ of the box's copy so that the bench lines of this same run carry it).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
 export TMPDIR=/tmp
@@ -23,7 +23,8 @@ done
 cp $OUT/pmc_k2_traffic_scene5.json profiles/pmc_k2_traffic.json
 timeout 600 python bench.py > $OUT/bench_n1_scene5.json 2> $OUT/bench.err
 tail -c 300 $OUT/bench_n1_scene5.json; echo
-for w in single pair scene5_lidar; do
+timeout 600 python bench.py --workload single > $OUT/bench_n1_single.json 2> $OUT/bench_single.err    # BASELINE configs 1 / 2, with cpu_baseline
+for w in pair scene5_lidar; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_n1_$w.json 2> $OUT/bench_$w.err
 done
 timeout 300 python bench.py --workload scene8_second_v2xvit --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_n1_scene8_second_v2xvit.json 2> $OUT/bench_scene8.err
@@ -34,4 +35,13 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats8 
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_scene5.csv \;
 find $OUT/stats8 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_scene8_second_v2xvit.csv \;
 rm -rf $OUT/stats $OUT/stats8
+# per-kernel micro-benchmarks of the round's kernels
+timeout 200 python scripts/k4_bench.py > $OUT/${TAG}_k4_bench.json 2> /dev/null
+timeout 200 python scripts/k5_bench.py --json $OUT/${TAG}_k5_bench.json > /dev/null 2>&1
+timeout 200 python scripts/c1t_bench.py --json $OUT/${TAG}_c1t_bench.json > /dev/null 2>&1
+timeout 200 python scripts/conv_gemm_bench.py > $OUT/${TAG}_conv_gemm_bench.txt 2> /dev/null
+timeout 100 python scripts/stem_bench.py > $OUT/${TAG}_stem_bench.txt 2> /dev/null
+for d in 0 2 16 64; do :; done
+bash scripts/k4_dbg.sh 0 2 16 64 > $OUT/${TAG}_k4_anatomy.txt 2>&1
+timeout 100 python scripts/k4_stamps.py > $OUT/${TAG}_k4_stamps.txt 2> /dev/null
 ls -la $OUT
