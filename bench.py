@@ -177,7 +177,8 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             add("linear", "K6c heal_linear (V2X-ViT token-major fp32 MFMA GEMM: LayerNorm prologue, bias / GELU / residual / "
                           "split-attention merge epilogues)", "mfma", w)
         elif name.startswith("warp_fuse"):
-            add("k5", "K5 heal_warp_fuse (warp + occupancy-softmax fusion, 3 pyramid levels)", "hbm", w)
+            add("k5", "K5 heal_warp_fuse_levels (warp + occupancy-softmax fusion, ALL pyramid levels in one launch, source footprints "
+                      "staged through LDS; heal_warp_fuse per level where the model fuses level by level)", "hbm", w)
     entries = {}
     for key, f in fam.items():
         if f["ms"] <= 0:
@@ -189,7 +190,7 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             ach = ach / 2.25
         tr = pmc_traffic(a.workload, *{"conv1x1": ("heal::k_conv1x1<",), "conv1x1s": ("heal::k_conv1x1<",),
                                        "conv3x3w": ("heal::k_conv3x3_wino<",), "conv3x3": ("heal::k_conv3x3<",),
-                                       "grouped": ("heal::k_gconv_small<",), "k5": ("heal::k_warp_fuse<",),
+                                       "grouped": ("heal::k_gconv_small<",), "k5": ("heal::k_warp_fuse",),
                                        "linear": ("heal::k_linear",)}.get(key, ()))
         entries[key] = (f["ms"], _entry(f["kernel"], f["bound"], ach, f["calls"], f["ms"] / max(f["calls"], 1), tr, **extra))
     # K2: algorithmic bytes of the collated LiDAR agents this rank encodes per launch
@@ -288,11 +289,17 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             # 64-channel layers that carry 95 % of the time, against a machine balance of 157.3 TFLOP/s : 8 TB/s = 19.7 flop/B --
             # exact-fp32 sparse convolution is bound by the fp32 matrix cores, so `frac` is the MFMA fraction (useful flops:
             # the tile padding the kernel executes is not counted); the algorithmic-byte rate is reported beside it
+            rb = timing.get("sp_rulebook", (0, 0.0))
+            rb_ms = rb[0] * rb[1] / max(a.steps, 1)                       # site sort, hash / rank structures, neighbour tables, out sites
             entries["k3"] = (tot_ms * max(a.steps, 1), _entry(
                 "K3 heal_sp_conv (pair-compacted gather-GEMM on fp32 MFMA; all sparse layers of one step, useful flops 2 R Cin Cout; "
-                "rulebook kernels not included)", "mfma",
+                "`frac` prices the convolution launches; `rulebook_ms` = the rulebook launches of the same step (site sort, hash / rank "
+                "structures, neighbour tables, output sites), `step_ms_with_rulebook` = both)", "mfma",
                 tot_f / (tot_ms * 1e-3) / 1e12, len(layers), tot_ms / len(layers), pmc_traffic(a.workload, "heal::k_sp_conv2<"),
-                step_ms=round(tot_ms, 4), hbm_gbs=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+                step_ms=round(tot_ms, 4), rulebook_ms=round(rb_ms, 4), step_ms_with_rulebook=round(tot_ms + rb_ms, 4),
+                tflops_with_rulebook=round(tot_f / ((tot_ms + rb_ms) * 1e-3) / 1e12, 2),
+                frac_with_rulebook=round(tot_f / ((tot_ms + rb_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                hbm_gbs=round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
                 hbm_frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 flop_per_byte=round(tot_f / max(tot_b, 1.0), 1), layers=layers))
     if not entries:

@@ -942,11 +942,13 @@ class SparseTensor:
         sorted_idx = torch.empty_like(indices)
         perm = torch.zeros((n,), dtype=torch.int32, device=dev)  # zeros: padding rows gather row 0, harmlessly
         ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
-        _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
-                   _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
+        with _Timed("sp_rulebook"):
+            _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
+                       _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
         C = int(features.shape[1])
         feats = torch.zeros((n, C), dtype=torch.float32, device=dev) if n_dev is not None else torch.empty((n, C), dtype=torch.float32, device=dev)
-        _capi.call("heal_sp_gather_rows", _ptr(features), _ptr(perm), n, C, _optr(n_dev), _ptr(feats), _stream())
+        with _Timed("sp_rulebook"):
+            _capi.call("heal_sp_gather_rows", _ptr(features), _ptr(perm), n, C, _optr(n_dev), _ptr(feats), _stream())
         st = SparseTensor(feats, sorted_idx, spatial_shape, batch_size, n_dev)
         st._perm = perm   # row i of the sorted set = input row perm[i] (the gradient path re-applies it differentiably)
         return st
@@ -957,8 +959,9 @@ class SparseTensor:
             dev = self.indices.device
             keys = torch.empty((cap,), dtype=torch.int32, device=dev)
             vals = torch.empty((cap,), dtype=torch.int32, device=dev)
-            _capi.call("heal_sp_hash_build", _ptr(self.indices), self.n, _i3(self.spatial_shape), self.batch_size,
-                       _ptr(keys), _ptr(vals), cap, _optr(self.n_dev), _stream())
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_hash_build", _ptr(self.indices), self.n, _i3(self.spatial_shape), self.batch_size,
+                           _ptr(keys), _ptr(vals), cap, _optr(self.n_dev), _stream())
             self._table = (keys, vals, cap)
         return self._table
 
@@ -967,14 +970,16 @@ class SparseTensor:
         K = int(ksize[0] * ksize[1] * ksize[2])
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.indices.device)
         if self._rank is not None:
-            _capi.call("heal_sp_neighbors_rank", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
-                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(self._rank), self._rank.numel(),
-                       self.n, _optr(self.n_dev), _ptr(nbr), _optr(n_out_dev), _stream())
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_neighbors_rank", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
+                           _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(self._rank), self._rank.numel(),
+                           self.n, _optr(self.n_dev), _ptr(nbr), _optr(n_out_dev), _stream())
             return nbr
         keys, vals, cap = self.table()
-        _capi.call("heal_sp_neighbors", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
-                   _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(keys), _ptr(vals), cap,
-                   _ptr(nbr), _optr(n_out_dev), _stream())
+        with _Timed("sp_rulebook"):
+            _capi.call("heal_sp_neighbors", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
+                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(keys), _ptr(vals), cap,
+                       _ptr(nbr), _optr(n_out_dev), _stream())
         return nbr
 
     def out_sites(self, ksize, stride, padding):
@@ -1000,14 +1005,16 @@ class SparseTensor:
         if os.environ.get("HEAL_SP_RULEBOOK", "rank") != "hash":
             nbytes = _capi.query("heal_sp_rank_bytes", _i3(out_shape), self.batch_size)
             rank = torch.empty((nbytes,), dtype=torch.uint8, device=dev)   # lives as long as the site set it describes
-            _capi.call("heal_sp_out_sites_rank", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
-                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
-                       _ptr(rank), nbytes, _optr(self.n_dev), _ptr(sparse_overflow_flag(dev)), _stream())
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_out_sites_rank", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
+                           _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
+                           _ptr(rank), nbytes, _optr(self.n_dev), _ptr(sparse_overflow_flag(dev)), _stream())
         else:
             ws = _workspace("sp_out_sites", _capi.query("heal_sp_out_sites_workspace", self.n, K), dev)
-            _capi.call("heal_sp_out_sites", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
-                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
-                       _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_out_sites", _ptr(self.indices), self.n, _i3(ksize), _i3(stride), _i3(padding),
+                           _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(out_idx), out_cap, _ptr(n_out),
+                           _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
         if self.n_dev is None:
             return out_idx[:int(n_out.item())], out_shape, None, rank
         self._checks.append((n_out, out_cap))
@@ -1041,8 +1048,9 @@ class SparseTensor:
         dev = self.indices.device
         out = torch.empty((self.batch_size, C * D, H, W), dtype=torch.float32, device=dev)
         ws = _workspace("sp_to_bev", _capi.query("heal_sp_to_bev_workspace", self.batch_size, D, H, W), dev)
-        _capi.call("heal_sp_to_bev", _ptr(self.features), _ptr(self.indices), self.n, C, _i3(self.spatial_shape),
-                   self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
+        with _Timed("sp_to_bev"):
+            _capi.call("heal_sp_to_bev", _ptr(self.features), _ptr(self.indices), self.n, C, _i3(self.spatial_shape),
+                       self.batch_size, _ptr(out), _ptr(ws), ws.numel(), _optr(self.n_dev), _stream())
         return out
 
 
