@@ -122,8 +122,8 @@ class SECOND(nn.Module):
     def forward(self, data_dict, modality_name):
         inp = data_dict[f"inputs_{modality_name}"]
         if torch.is_grad_enabled() and self.training:
-            # gradient path: K1 still voxelises raw clouds on the device; MeanVFE and the sparse backbone run as torch
-            # operators (dense masked evaluation of the sparse convolutions: sparse_backbone_3d.py, small grids only)
+            # gradient path: K1 still voxelises raw clouds on the device; MeanVFE as torch operators, the sparse backbone with its
+            # sparse backward on the device (dense masked evaluation off the device: sparse_backbone_3d.py)
             if "points" in inp:
                 v, c, n, offsets = ops.voxelize_collated(inp["points"], self.lidar_range, self.voxel_size,
                                                          int(inp.get("max_points_per_voxel") or self.max_points),

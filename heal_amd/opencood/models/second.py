@@ -30,7 +30,7 @@ class Second(nn.Module):
                       "voxel_num_points": lidar["voxel_num_points"],
                       "batch_size": int(coords[:, 0].max().item()) + 1}  # second.py:39
         batch_dict = self.mean_vfe(batch_dict)
-        if self.training and torch.is_grad_enabled():   # gradient path: dense masked evaluation (sparse_backbone_3d.py)
+        if self.training and torch.is_grad_enabled():   # gradient path (sparse_backbone_3d.py: sparse on the device)
             batch_dict = self.backbone_3d.forward_autograd(batch_dict)
         else:
             batch_dict = self.backbone_3d(batch_dict)

@@ -195,7 +195,7 @@ class VoxelBackBone8x(nn.Module):
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
 
     def forward_autograd(self, batch_dict):
-        """Gradient path: dense masked evaluation (module docstring).  -> batch_dict with a dense result object."""
+        """Gradient path: sparse on the device (forward_autograd_sparse), dense masked evaluation otherwise (module docstring)."""
         feats = batch_dict["voxel_features"]
         if feats.is_cuda and os.environ.get("HEAL_SP_GRAD", "sparse") != "dense":
             return self.forward_autograd_sparse(batch_dict)
@@ -208,8 +208,8 @@ class VoxelBackBone8x(nn.Module):
                 f"VoxelBackBone8x: the gradient path evaluates the sparse encoder as a dense masked conv3d; a grid of "
                 f"{B} x {D} x {H} x {W} = {cells / 1e6:.0f} M cells x >= 16 channels does not fit (limit "
                 f"{self.DENSE_GRAD_MAX_CELLS / 1e6:.0f} M cells, ~0.1 GB per channel).  Training SECOND at this range needs the "
-                "sparse backward of K3 (gather-GEMM with the transposed rulebook + per-tap weight gradient), which is not "
-                "built yet (DESIGN.md 7/8); use a smaller lidar_range / larger voxel_size, or run inference (no_grad).")
+                "sparse backward of K3, which runs on the device only (tensors on cuda:N and HEAL_SP_GRAD unset); here use a "
+                "smaller lidar_range / larger voxel_size, or run inference (no_grad).")
         site = (coords[:, 0], coords[:, 1], coords[:, 2], coords[:, 3])
         x = feats.new_zeros((B, D, H, W, feats.shape[1])).index_put(site, feats).permute(0, 4, 1, 2, 3)
         mask = feats.new_zeros((B, D, H, W)).index_put(site, feats.new_ones(coords.shape[0])).unsqueeze(1)
