@@ -76,8 +76,31 @@ def cpu_baseline(hypes, scene_cpu, cls_shift=0.0):
     args = hypes["model"]["args"]
     r = args["lidar_range"]
     mods = list(scene_cpu.modalities)
+    anchors = O.generate_anchor_box(r, 0.4, 0.4, int(round((r[3] - r[0]) / 0.4)), int(round((r[4] - r[1]) / 0.4)),
+                                    3.9, 1.6, 1.56, [0, 90],
+                                    feature_stride=hypes["postprocess"]["anchor_args"].get("feature_stride", 2))
     t0 = time.perf_counter()
     data = {"agent_modality_list": mods, "pairwise_t_matrix": np.asarray(scene_cpu.pairwise)}
+    if hypes["model"]["core_method"] == "heter_model_baseline":
+        # BASELINE config 5: C voxeliser at 0.1 m, numpy MeanVFE + the sparse SECOND encoder on its rule pairs, torch-CPU fp32
+        # BaseBEVBackbone / shrinker / V2X-ViT (oracle/v2xvit_ref.py), heads, decode + C rotated NMS
+        m = mods[0]
+        enc = args[m]["encoder_args"]
+        vs, cs, ns = [], [], []
+        for b, k in enumerate(sorted(scene_cpu.points)):
+            v, c, n = cref.voxelize(scene_cpu.points[k].numpy(), r, enc["voxel_size"], 5, 70000, batch_idx=b)
+            vs.append(v); cs.append(c); ns.append(n)
+        data[f"inputs_{m}"] = {"voxel_features": np.concatenate(vs), "voxel_coords": np.concatenate(cs),
+                               "voxel_num_points": np.concatenate(ns)}
+        out = model_ref.heter_model_baseline(sd, args, data)
+        out["cls_preds"] = out["cls_preds"] + cls_shift
+        O.post_process(out["cls_preds"], out["reg_preds"], out["dir_preds"], anchors, 0.2, 0.7853, 2, 0.15,
+                       np.eye(4, dtype=np.float32), r)
+        dt = time.perf_counter() - t0
+        return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+                "sample": f"1 scene of the same workload ({len(mods)} agents: {' '.join(mods)}) through oracle/ (C voxeliser, numpy "
+                          f"MeanVFE + sparse SECOND encoder on its rule pairs, torch-CPU fp32 BEV backbone / shrinker / V2X-ViT / "
+                          f"heads, C rotated NMS), {dt:.1f} s on {cores} threads"}
     vs, cs, ns = [], [], []
     for b, k in enumerate(sorted(scene_cpu.points)):
         v, c, n = cref.voxelize(scene_cpu.points[k].numpy(), r, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
@@ -91,8 +114,6 @@ def cpu_baseline(hypes, scene_cpu, cls_shift=0.0):
             data[f"inputs_{m}"] = {key: np.stack([scene_cpu.cameras[i][key].numpy() for i in ids])
                                    for key in ("imgs", "rots", "trans", "intrins", "post_rots", "post_trans")}
     out = model_ref.heter_pyramid_collab(sd, args, data)
-    anchors = O.generate_anchor_box(r, 0.4, 0.4, int(round((r[3] - r[0]) / 0.4)), int(round((r[4] - r[1]) / 0.4)),
-                                    3.9, 1.6, 1.56, [0, 90])
     out["cls_preds"] = out["cls_preds"] + cls_shift  # same calibrated head bias as the GPU pipeline
     O.post_process(out["cls_preds"], out["reg_preds"], out["dir_preds"], anchors, 0.2, 0.7853, 2, 0.15,
                    np.eye(4, dtype=np.float32), r)
@@ -590,7 +611,7 @@ def main():
         }
         if serial is not None:
             line["serial"] = serial
-        if not a.no_cpu_baseline and world == 1 and not baseline_model:
+        if not a.no_cpu_baseline and world == 1:
             scene_cpu = Scene(n_agents, seed=seed0, device="cpu", modalities=mods)   # the same synthetic frame, host copy
             line["cpu_baseline"] = cpu_baseline(hypes, scene_cpu, cls_shift)
         print(json.dumps(line), flush=True)

@@ -213,6 +213,8 @@ def lidar_baseline(fusion_method="v2xvit", lidar_range=FULL_RANGE, max_cav=5, mo
     elif fusion_method == "att":
         args["att"] = {"feat_dim": 256}
     h["model"] = {"core_method": "heter_model_baseline", "args": args}
+    # encoder + backbone + stride-2 shrinker leave the map at 1/4 of the 0.4 m anchor grid (lidar_v2xvit.yaml: feature_stride 4)
+    h["postprocess"]["anchor_args"]["feature_stride"] = 4
     return load_general_params(h)
 
 

@@ -522,6 +522,9 @@ def decode_nms(cls, reg, dirp, anchors, score_thr, dir_offset, num_bins, nms_thr
         cls, reg = cls[0], reg[0]
         dirp = dirp[0] if dirp is not None else None
     A, H, W = (int(v) for v in cls.shape)
+    if anchors.numel() != H * W * A * 7:
+        raise _capi.HealAmdError(f"decode_nms: anchors {tuple(anchors.shape)} do not match the {A} x {H} x {W} score map "
+                                 "(anchor_args.feature_stride of the YAML vs. the model's output stride)")
     dev = cls.device
     out_c = torch.empty((nms_top, 8, 3), dtype=torch.float32, device=dev)
     out_s = torch.empty((nms_top,), dtype=torch.float32, device=dev)

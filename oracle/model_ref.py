@@ -14,6 +14,11 @@ sub_modules/base_bev_backbone_resnet.py:88-136, resblock.py:42-122, fuse_modules
 tests/golden/hetero_small.npz -- outputs of the REFERENCE's own HeterPyramidCollab at reduced size
 (tests/test_oracle_golden.py::test_hetero_oracle_model_matches_reference).  The image trunks
 (oracle/trunks.py) are restated from the third-party packages' published architectures: PARITY UNPINNED.
+
+`heter_model_baseline` (BASELINE config 5: encoder -> BaseBEVBackbone -> shrinker -> V2X-ViT -> heads; heter_model_baseline.py:
+155-236) is pinned with PointPillars agents by tests/golden/baseline_small.npz (the REFERENCE's own HeterModelBaseline); its
+SECOND encoder (oracle_np.second_backbone_sparse) restates spconv 1.2.1, which is not in the reference tree: PARITY UNPINNED for
+that encoder (held against the dense restatement and analytic cases only).
 """
 import numpy as np
 import torch
@@ -314,3 +319,61 @@ def second_detector(sd, args, voxels, coords, num, sparse_shape, batch):
     psm = F.conv2d(x, sd["cls_head.weight"], sd["cls_head.bias"])
     rm = F.conv2d(x, sd["reg_head.weight"], sd["reg_head.bias"])
     return psm, rm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HeterModelBaseline with V2X-ViT fusion (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------------------------------
+def heter_model_baseline(sd, cfg_args, data, taps=None):
+    """One scene through HeterModelBaseline.forward (opencood/models/heter_model_baseline.py:198-236) with fusion_method
+    'v2xvit': per modality encoder (PointPillar heter_encoders.py:22-49 | SECOND :52-80) -> BaseBEVBackbone
+    (base_bev_backbone.py:96-156) -> DownsampleConv shrinker (downsample_conv.py:22-49) -> V2XViTFusion (oracle/v2xvit_ref.py)
+    -> optional shrink_conv -> the three 1x1 heads.  All agents of ONE modality (what config 5 and the golden use).
+    data: {"agent_modality_list", "pairwise_t_matrix" [1, L, L, 4, 4], "inputs_<m>": {"voxel_features", "voxel_coords",
+    "voxel_num_points"}}.  -> dict of numpy outputs."""
+    from . import v2xvit_ref
+    sd = {k: v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v)) for k, v in sd.items()}
+    sd = {k: v.float() if v.dtype.is_floating_point else v for k, v in sd.items()}
+    mods = list(data["agent_modality_list"])
+    m = mods[0]
+    assert all(mm == m for mm in mods), "one modality per scene"
+    if cfg_args["fusion_method"] != "v2xvit":
+        raise NotImplementedError(cfg_args["fusion_method"])
+    n = len(mods)
+    r = cfg_args["lidar_range"]
+    setting = cfg_args[m]
+    enc = setting["encoder_args"]
+    vs = enc["voxel_size"]
+    inp = data[f"inputs_{m}"]
+    with torch.no_grad():
+        if setting["core_method"] == "point_pillar":
+            nx, ny = int(round((r[3] - r[0]) / vs[0])), int(round((r[4] - r[1]) / vs[1]))
+            x = pointpillar_encoder(sd, f"encoder_{m}", inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"],
+                                    vs, r, n, ny, nx)
+        elif setting["core_method"] == "second":
+            grid = np.round((np.array(r[3:]) - np.array(r[:3])) / np.array(vs)).astype(np.int64)
+            sparse_shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]       # sparse_backbone_3d.py:41
+            feats = O.mean_vfe(inp["voxel_features"], inp["voxel_num_points"])
+            x = torch.from_numpy(O.second_backbone_sparse({k: v.numpy() for k, v in sd.items() if k.startswith(f"encoder_{m}.")},
+                                                          f"encoder_{m}.spconv_block.", feats, inp["voxel_coords"],
+                                                          sparse_shape, n))
+        else:
+            raise NotImplementedError(setting["core_method"])
+        if taps is not None:
+            taps["encoder"] = x.numpy()
+        x = base_bev_backbone(sd, f"backbone_{m}.", x, setting["backbone_args"])
+        sh = setting["shrink_header"]
+        x = _double_conv(x, sd, f"shrinker_{m}.layers.0", sh["stride"][0], sh["padding"][0])
+        if taps is not None:
+            taps["shrunk"] = x.numpy()
+        H, W = r[4] - r[1], r[3] - r[0]
+        aff = O.normalize_pairwise_tfm(np.asarray(data["pairwise_t_matrix"]), H, W, 1)
+        fused = v2xvit_ref.v2xvit_fusion(sd, "fusion_net.", x, [n], torch.as_tensor(np.asarray(aff)), cfg_args["v2xvit"])
+        if taps is not None:
+            taps["fused"] = fused.numpy()
+        if "shrink_header" in cfg_args:
+            fused = _double_conv(fused, sd, "shrink_conv.layers.0", cfg_args["shrink_header"]["stride"][0],
+                                 cfg_args["shrink_header"]["padding"][0])
+        return {"cls_preds": F.conv2d(fused, sd["cls_head.weight"], sd["cls_head.bias"]).numpy(),
+                "reg_preds": F.conv2d(fused, sd["reg_head.weight"], sd["reg_head.bias"]).numpy(),
+                "dir_preds": F.conv2d(fused, sd["dir_head.weight"], sd["dir_head.bias"]).numpy()}

@@ -462,6 +462,99 @@ def second_backbone(sd, prefix, vfe_features, indices, sparse_shape, batch):
     return dense.reshape(B, C * D, H, W).numpy()
 
 
+def _sp_keys(idx, shape):
+    D, H, W = shape
+    idx = np.asarray(idx).astype(np.int64)
+    return ((idx[:, 0] * D + idx[:, 1]) * H + idx[:, 2]) * W + idx[:, 3]
+
+
+def _sp_lookup(sorted_keys, query, valid):
+    """Row of every query key in the sorted key list, -1 where absent (or where `valid` is False)."""
+    pos = np.searchsorted(sorted_keys, query)
+    pos = np.minimum(pos, len(sorted_keys) - 1)
+    hit = valid & (sorted_keys[pos] == query)
+    return np.where(hit, pos, -1)
+
+
+def sparse_conv_rules(in_idx, in_shape, ksize, stride, padding, subm):
+    """spconv's indice pairs restated on sorted coordinate lists (the rules of the comment block above; same semantics as
+    `sparse_conv_dense`, without the dense grid): -> (out_idx [n_out, 4] sorted by linear coordinate, out_shape, nbr [n_out, K])
+    with nbr[o][tap] = row of the input site at o * stride - padding + tap, or -1; taps enumerated (kz, ky, kx) row-major."""
+    in_idx = np.asarray(in_idx).astype(np.int64)
+    in_keys = _sp_keys(in_idx, in_shape)
+    assert np.all(np.diff(in_keys) > 0), "input sites must be sorted and unique"
+    k, s, p = (np.asarray(v, np.int64) for v in (ksize, stride, padding))
+    if subm:
+        out_shape, out_idx = list(in_shape), in_idx
+        p = k // 2
+        s = np.ones(3, np.int64)
+    else:
+        out_shape = [int((in_shape[d] + 2 * p[d] - k[d]) // s[d] + 1) for d in range(3)]
+        cands = []
+        for kz in range(k[0]):
+            for ky in range(k[1]):
+                for kx in range(k[2]):
+                    num = in_idx[:, 1:] + p - np.array([kz, ky, kx])          # o * s = i + p - tap
+                    ok = np.all((num % s == 0) & (num >= 0), axis=1)
+                    o = num // s
+                    ok &= np.all(o < np.array(out_shape), axis=1)
+                    cands.append(np.concatenate([in_idx[ok, :1], o[ok]], 1))
+        c = np.concatenate(cands)
+        keys = np.unique(_sp_keys(c, out_shape))
+        D, H, W = out_shape
+        out_idx = np.stack([keys // (D * H * W), keys // (H * W) % D, keys // W % H, keys % W], 1)
+    K = int(k[0] * k[1] * k[2])
+    nbr = np.full((out_idx.shape[0], K), -1, np.int64)
+    t = 0
+    for kz in range(k[0]):
+        for ky in range(k[1]):
+            for kx in range(k[2]):
+                c = out_idx[:, 1:] * s - p + np.array([kz, ky, kx])
+                ok = np.all((c >= 0) & (c < np.array(in_shape)), axis=1)
+                q = _sp_keys(np.concatenate([out_idx[:, :1], np.where(ok[:, None], c, 0)], 1), in_shape)
+                nbr[:, t] = _sp_lookup(in_keys, q, ok)
+                t += 1
+    return out_idx, out_shape, nbr
+
+
+def second_backbone_sparse(sd, prefix, vfe_features, indices, sparse_shape, batch, return_sites=False):
+    """VoxelBackBone8x.forward + HeightCompression (sparse_backbone_3d.py:114-130, height_compression.py:10-26) with the sparse
+    convolutions evaluated on their rule pairs instead of a dense grid -- the same arithmetic as `second_backbone` (which the
+    tests hold it against on small grids), practical at the reference's +-102.4 m / 0.1 m grid (1.7e8 cells per agent).
+    out[o] = ReLU(BN(sum_tap W[tap]^T x[nbr[o][tap]])), taps added in (kz, ky, kx) order in fp32.  -> dense [B, C*D, H, W]."""
+    idx = np.asarray(indices).astype(np.int64)
+    order = np.argsort(_sp_keys(idx, sparse_shape), kind="stable")
+    idx, x = idx[order], np.asarray(vfe_features, F32)[order]
+    shape = list(sparse_shape)
+    cache = {}
+    for name, k, s, p, subm in SECOND_LAYERS:
+        w = np.asarray(sd[f"{prefix}{name}.0.weight"], F32)
+        w = w.reshape(-1, w.shape[3], w.shape[4])
+        key = (id(idx), tuple(k)) if subm else None
+        if subm and key in cache:
+            out_idx, out_shape, nbr = cache[key]
+        else:
+            out_idx, out_shape, nbr = sparse_conv_rules(idx, shape, k, s, p, subm)
+            if subm:
+                cache[(id(out_idx), tuple(k))] = (out_idx, out_shape, nbr)
+        y = np.zeros((out_idx.shape[0], w.shape[2]), F32)
+        for t in range(w.shape[0]):
+            rows = np.nonzero(nbr[:, t] >= 0)[0]
+            if rows.size:
+                y[rows] += x[nbr[rows, t]] @ w[t]
+        bp = f"{prefix}{name}.1."
+        g, b = np.asarray(sd[bp + "weight"], F32), np.asarray(sd[bp + "bias"], F32)
+        mu, var = np.asarray(sd[bp + "running_mean"], F32), np.asarray(sd[bp + "running_var"], F32)
+        x = np.maximum((y - mu) / np.sqrt(var + F32(1e-3)) * g + b, F32(0.0)).astype(F32)
+        idx, shape = out_idx, out_shape
+    D, H, W = shape
+    C = x.shape[1]
+    dense = np.zeros((batch, C, D, H, W), F32)
+    dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = x
+    out = dense.reshape(batch, C * D, H, W)
+    return (out, idx, x) if return_sites else out
+
+
 # ---- training-side label path (SURVEY 8f-2) -------------------------------------------------------------------------
 def bbox_overlaps(boxes, query_boxes):
     """opencood/utils/box_overlaps.pyx:17-57 (Fast R-CNN bbox_overlaps, the `+1` pixel convention), fp32 throughout:

@@ -27,7 +27,7 @@ timeout 600 python bench.py --workload single > $OUT/bench_n1_single.json 2> $OU
 for w in pair scene5_lidar; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_n1_$w.json 2> $OUT/bench_$w.err
 done
-timeout 300 python bench.py --workload scene8_second_v2xvit --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_n1_scene8_second_v2xvit.json 2> $OUT/bench_scene8.err
+timeout 420 python bench.py --workload scene8_second_v2xvit --steps 10 --warmup 3 > $OUT/bench_n1_scene8_second_v2xvit.json 2> $OUT/bench_scene8.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
     python bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats8 -- \

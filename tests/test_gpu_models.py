@@ -520,6 +520,48 @@ def test_config5_second_v2xvit_composition_vs_oracle():
         assert e2 < 1e-4, (key, e2)
 
 
+def test_config5_full_size_matches_oracle_model():
+    """BASELINE config 5 AT FULL SIZE (8 SECOND agents, +-102.4 m at 0.1 m voxels: sparse shape [41, 2048, 2048], ~3.4e5 active
+    voxels; BaseBEVBackbone, stride-2 shrinker, V2X-ViT over 8 x 128 x 128 tokens; the scene bench.py times as
+    `scene8_second_v2xvit`): the GPU model's cls / reg / dir maps against the oracle's CPU restatement of the same model
+    (oracle/model_ref.heter_model_baseline: C voxeliser, sparse SECOND encoder on its rule pairs, torch-CPU fp32 convolutions and
+    V2X-ViT -- the latter two pinned to the REFERENCE by tests/golden/{baseline_small,fusion_small}.npz) on the same synthetic
+    frame and the same weights -- north_star: within 1e-3 relative.  Also the encoder output on its own (the K1 + K3 boundary)."""
+    from heal_amd import configs
+    from heal_amd.pipeline import Scene, ScenePipeline
+    from oracle import cref, model_ref
+    mods = ["m3"] * 8
+    hypes = configs.lidar_baseline("v2xvit", max_cav=8, modality="m3")
+    pipe = ScenePipeline(hypes, "cuda:0", seed=0)
+    scene = Scene(8, seed=4, device="cuda:0", modalities=mods)
+    with torch.no_grad():
+        out = pipe.forward(scene)
+        enc_gpu = pipe.model.encoder_m3(scene.model_input(), "m3").cpu().numpy()
+    host = Scene(8, seed=4, device="cpu", modalities=mods)          # the same synthetic frame, host copy
+    args = hypes["model"]["args"]
+    r = args["lidar_range"]
+    vs, cs, ns = [], [], []
+    for b, k in enumerate(sorted(host.points)):
+        v, c, n = cref.voxelize(host.points[k].numpy(), r, [0.1, 0.1, 0.1], 5, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    data = {"agent_modality_list": mods, "pairwise_t_matrix": np.asarray(host.pairwise),
+            "inputs_m3": {"voxel_features": np.concatenate(vs), "voxel_coords": np.concatenate(cs),
+                          "voxel_num_points": np.concatenate(ns)}}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    taps = {}
+    ref = model_ref.heter_model_baseline(pipe.model.state_dict(), args, data, taps=taps)
+    from tests.report import note
+    errs = {"encoder": rel_err(enc_gpu, taps["encoder"])}
+    assert enc_gpu.shape == taps["encoder"].shape == (8, 128, 256, 256)
+    assert np.array_equal(np.abs(enc_gpu).sum(1) > 0, np.abs(taps["encoder"]).sum(1) > 0)     # the same active BEV cells
+    for key in ("cls_preds", "reg_preds", "dir_preds"):
+        got = out[key].cpu().numpy()
+        assert got.shape == ref[key].shape == (1, {"cls_preds": 2, "reg_preds": 14, "dir_preds": 4}[key], 128, 128)
+        errs[key] = rel_err(got, ref[key])
+    note("config5_full_size_vs_oracle_model", **{k: float(v) for k, v in errs.items()})
+    assert all(v < 1e-3 for v in errs.values()), errs
+
+
 def test_config5_second_v2xvit_full_scale_scene():
     """BASELINE config 5 as a whole at full size: 8 SECOND agents, +-102.4 m, V2X-ViT fusion, decode + rotated NMS; eager step,
     hipGraph replay of the same scene and replay on a DIFFERENT scene through the static input buffers."""

@@ -229,3 +229,87 @@ def test_hetero_oracle_model_from_trunk_boundary(golden):
     out = model_ref.heter_pyramid_collab(sd, hy["model"]["args"], data, boundary=boundary)
     for k, name in (("cls_preds", "cls"), ("reg_preds", "reg"), ("dir_preds", "dir")):
         assert _rel(out[k], g[name]) < 1e-4, (k, _rel(out[k], g[name]))
+
+
+# ---- BASELINE config 5: the V2X-ViT fusion operator and HeterModelBaseline ------------------------------------------------------
+def test_v2xvit_oracle_matches_reference_golden(golden):
+    """oracle/v2xvit_ref.v2xvit_fusion against the output of the REFERENCE's V2XViTFusion (tests/golden/fusion_small.npz, same
+    deterministic weights): HGT agent attention with relation matrices, three window sizes with relative position bias, split
+    attention, feed-forward, 3 blocks; 3 agents padded to max_cav 5 (the padded agents masked as keys)."""
+    import torch
+    from heal_amd import configs
+    from heal_amd.opencood.models.fuse_modules.fusion_in_one import V2XViTFusion
+    from oracle import v2xvit_ref
+    from tests.golden.detfill import fill_module
+    g = golden("fusion_small")
+    cfg = configs._v2xvit_args()
+    sd = {"f." + k: v for k, v in fill_module(V2XViTFusion(cfg)).state_dict().items()}
+    aff = O.normalize_pairwise_tfm(g["pairwise"], float(g["HW_m"][0]), float(g["HW_m"][1]), 1)
+    with torch.no_grad():
+        out = v2xvit_ref.v2xvit_fusion(sd, "f.", g["x"], [3], np.asarray(aff, np.float32), cfg).numpy()
+    assert _rel(out, g["v2xvit"]) < 1e-4, _rel(out, g["v2xvit"])
+
+
+def test_heter_model_baseline_oracle_matches_reference_golden(golden):
+    """oracle/model_ref.heter_model_baseline (PointPillar encoder -> BaseBEVBackbone -> stride-2 shrinker -> V2X-ViT -> heads)
+    against the REFERENCE's own HeterModelBaseline (tests/golden/baseline_small.npz, `v2xvit_*`)."""
+    from heal_amd import configs
+    from heal_amd.opencood.tools.train_utils import create_model
+    from oracle import model_ref
+    from tests.golden.detfill import fill_module
+    g = golden("baseline_small")
+    hy = configs.lidar_baseline("v2xvit", [-25.6, -25.6, -3, 25.6, 25.6, 1])
+    sd = fill_module(create_model(hy)).state_dict()
+    data = {"agent_modality_list": ["m1", "m1"], "pairwise_t_matrix": g["pairwise"],
+            "inputs_m1": {k: g[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+    out = model_ref.heter_model_baseline(sd, hy["model"]["args"], data)
+    for k, name in (("cls_preds", "cls"), ("reg_preds", "reg"), ("dir_preds", "dir")):
+        assert _rel(out[k], g[f"v2xvit_{name}"]) < 1e-4, (k, _rel(out[k], g[f"v2xvit_{name}"]))
+
+
+def test_sparse_second_oracle_equals_dense_restatement():
+    """oracle_np.second_backbone_sparse (rule pairs on sorted coordinate lists: what makes the reference's +-102.4 m / 0.1 m grid
+    tractable on the host) against oracle_np.second_backbone (the dense masked restatement of the same spconv rules) on a small
+    grid: same active sites after every strided layer (the output mask), values to fp32 rounding.  Includes two agents, sites on
+    the grid border and an isolated site."""
+    rng = np.random.default_rng(5)
+    shape = [41, 48, 40]
+    n = 900
+    idx = np.unique(np.stack([rng.integers(0, 2, n), rng.integers(0, 41, n), rng.integers(0, 48, n), rng.integers(0, 40, n)], 1), axis=0)
+    idx = np.concatenate([idx, [[0, 0, 0, 0], [1, 40, 47, 39], [1, 20, 5, 5]]]).astype(np.int32)
+    idx = np.unique(idx, axis=0)
+    rng.shuffle(idx)                                   # unsorted on purpose: the restatement sorts
+    feats = rng.standard_normal((idx.shape[0], 4)).astype(np.float32)
+    sd = {}
+    chans = {"conv_input": (4, 16), "conv1.0": (16, 16), "conv2.0": (16, 32), "conv2.1": (32, 32), "conv2.2": (32, 32),
+             "conv3.0": (32, 64), "conv3.1": (64, 64), "conv3.2": (64, 64), "conv4.0": (64, 64), "conv4.1": (64, 64),
+             "conv4.2": (64, 64), "conv_out": (64, 64)}
+    for name, k, s, p, subm in O.SECOND_LAYERS:
+        ci, co = chans[name]
+        sd[f"p.{name}.0.weight"] = (rng.standard_normal(tuple(k) + (ci, co)) / np.sqrt(ci * np.prod(k) / 4)).astype(np.float32)
+        sd[f"p.{name}.1.weight"] = rng.uniform(0.5, 1.5, co).astype(np.float32)
+        sd[f"p.{name}.1.bias"] = rng.uniform(-0.2, 0.2, co).astype(np.float32)
+        sd[f"p.{name}.1.running_mean"] = rng.uniform(-0.2, 0.2, co).astype(np.float32)
+        sd[f"p.{name}.1.running_var"] = rng.uniform(0.5, 1.5, co).astype(np.float32)
+    a = O.second_backbone(sd, "p.", feats, idx, shape, 2)
+    b = O.second_backbone_sparse(sd, "p.", feats, idx, shape, 2)
+    assert a.shape == b.shape == (2, 64 * 2, 6, 5)
+    assert np.abs(a).max() > 1e-3
+    np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-6 * float(np.abs(a).max()))
+
+
+def test_sparse_conv_rules_known_answers():
+    """Analytic cases of the spconv rules (the arithmetic is third-party: PARITY UNPINNED, known answers only): a single site
+    under a 3x3x3 stride-2 padding-1 convolution activates exactly the outputs whose receptive field holds it; a submanifold
+    convolution keeps the site set and links each site to itself through the centre tap."""
+    idx = np.array([[0, 4, 5, 6]])
+    out_idx, out_shape, nbr = O.sparse_conv_rules(idx, [9, 10, 12], (3, 3, 3), (2, 2, 2), (1, 1, 1), False)
+    assert out_shape == [5, 5, 6]
+    # o * 2 - 1 + tap = i  ->  z: o in {2} (tap 1) ; y: i = 5 -> o = 2 (tap 2), o = 3 (tap 0); x: i = 6 -> o = 3 (tap 1)
+    assert out_idx.tolist() == [[0, 2, 2, 3], [0, 2, 3, 3]]
+    assert nbr[0].tolist().count(0) == 1 and nbr[0][1 * 9 + 2 * 3 + 1] == 0
+    assert nbr[1].tolist().count(0) == 1 and nbr[1][1 * 9 + 0 * 3 + 1] == 0
+    idx = np.array([[0, 1, 1, 1], [0, 1, 1, 2], [0, 5, 5, 5]])
+    o2, s2, n2 = O.sparse_conv_rules(idx, [9, 10, 12], (3, 3, 3), (1, 1, 1), (1, 1, 1), True)
+    assert np.array_equal(o2, idx) and s2 == [9, 10, 12]
+    assert n2[:, 13].tolist() == [0, 1, 2] and n2[0, 14] == 1 and n2[1, 12] == 0 and (n2[2] >= 0).sum() == 1
