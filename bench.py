@@ -197,6 +197,13 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         elif name.startswith("linear_"):
             add("linear", "K6c heal_linear (V2X-ViT token-major fp32 MFMA GEMM: LayerNorm prologue, bias / GELU / residual / "
                           "split-attention merge epilogues)", "mfma", w)
+        elif name.startswith("window_attention_ws"):
+            ws = int(name[len("window_attention_ws"):])
+            # per token 4 ws^2 * 256 FLOPs against 4 KB of q | k | v | out: 16 FLOP/B at ws 4, 64 at ws 8 (below the fp32 ridge of
+            # 20-30 FLOP/B of achievable HBM: HBM-bound), 256 at ws 16 (MFMA-bound)
+            add(f"wattn{ws}", f"K6b heal_window_attention, window {ws} x {ws} (V2X-ViT PyramidWindowAttention branch: scores + relative "
+                              f"position bias + softmax + p v in one kernel; q | k | v read once, result written once)",
+                "mfma" if ws >= 16 else "hbm", w)
         elif name.startswith("warp_fuse"):
             add("k5", "K5 heal_warp_fuse_levels (warp + occupancy-softmax fusion, ALL pyramid levels in one launch, source footprints "
                       "staged through LDS; heal_warp_fuse per level where the model fuses level by level)", "hbm", w)
@@ -206,6 +213,9 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             continue
         ach = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["bound"] == "mfma" else (f["bytes"] / (f["ms"] * 1e-3) / 1e9)
         extra = {"step_ms": round(f["ms"] / max(a.steps, 1), 4)}
+        if key.startswith("wattn"):      # both roofs for the window-attention kernels
+            extra["tflops"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
+            extra["hbm_gbs"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
         if key == "conv3x3w":   # the wrapper counts the direct convolution's FLOPs; the kernel executes 16/36 of them
             extra["direct_equiv_tflops"] = round(ach, 2)
             ach = ach / 2.25

@@ -91,6 +91,11 @@ _SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "heal_sp_neighbors_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "heal_sp_neighbors_root": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "heal_sp_root_rank_bytes": (c_size_t, [c_void_p, c_int]),
+    "heal_sp_root_rank": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_size_t, c_void_p, c_void_p]),
     "heal_sp_transpose_neighbors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_weight_fragments": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_sp_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

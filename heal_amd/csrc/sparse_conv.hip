@@ -691,10 +691,12 @@ constexpr int SP_GRAN = 256;   // cells per granule (8 words)
 struct SpRank {
     const uint32_t* bm;
     const int* base;
+    const uint32_t* l1;   // root structure only: one bit per granule; granules whose bit is clear hold stale words
 };
 
 __device__ __forceinline__ int sp_rank_lookup(const SpRank& r, uint32_t key) {
     const uint32_t w = key >> 5;
+    if (r.l1 && !((r.l1[key >> 13] >> ((key >> 8) & 31u)) & 1u)) return -1;
     const uint32_t word = r.bm[w];
     const uint32_t bit = key & 31u;
     if (!((word >> bit) & 1u)) return -1;
@@ -795,6 +797,116 @@ __global__ __launch_bounds__(256) void k_sp_nbr_rank(const int4* __restrict__ ou
         const int x = x0 + kx;
         int row = (line_ok && x >= 0 && x < g.in.W) ? sp_rank_lookup(r, line + (uint32_t)x) : -1;
         dst[kx] = row < n_in ? row : -1;
+    }
+}
+
+// ---- rank structure of the ROOT site set (the voxels) ---------------------------------------------------------------------------------
+// The voxel grid of SECOND is 1.4e9 cells at 0.1 m (172 MB of bitmap) with 3e5 active sites: clearing or scanning the bitmap costs
+// more than everything else, so the root set gets a TWO-LEVEL structure: `l1` has one bit per 256-cell granule (0.7 MB, the only
+// thing cleared per frame); a granule of the big bitmap is valid only if its l1 bit is set -- the thread that sets the bit zeroes
+// the granule, a second launch then ORs the cell bits in.  Counting, the prefix sums and the per-granule bases walk l1, i.e. touch
+// only the occupied granules.  rank(key) is the site's row in linear-coordinate order: the sites are "sorted" by one scatter (no
+// radix sort: 4 x (histogram + scatter) = 200 us for 3.4e5 sites), and the neighbour queries of the first two layers use
+// k_sp_nbr_rank instead of 9e6 hash probes (135 us each).
+__global__ __launch_bounds__(256) void k_sp_root_mark1(const int4* __restrict__ idx, int cap, const int* __restrict__ n_dev,
+                                                      SpShape s, uint32_t* __restrict__ l1, uint32_t* __restrict__ bm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= live_rows(n_dev, cap)) return;
+    const int4 c = idx[i];
+    const uint32_t g = sp_key(s, c.x, c.y, c.z, c.w) >> 8;
+    // EVERY site wipes its granule (the cell bits are ORed in by the next launch, so within this one all writers write zeros) and
+    // sets the directory bit with a fire-and-forget atomic: no returning atomic, no "who was first" (39 -> see DESIGN 3)
+    uint4* gp = reinterpret_cast<uint4*>(bm + ((size_t)g << 3));
+    gp[0] = make_uint4(0u, 0u, 0u, 0u);
+    gp[1] = make_uint4(0u, 0u, 0u, 0u);
+    atomicOr(&l1[g >> 5], 1u << (g & 31u));
+}
+
+__global__ __launch_bounds__(256) void k_sp_root_mark2(const int4* __restrict__ idx, int cap, const int* __restrict__ n_dev,
+                                                      SpShape s, uint32_t* __restrict__ bm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= live_rows(n_dev, cap)) return;
+    const int4 c = idx[i];
+    const uint32_t key = sp_key(s, c.x, c.y, c.z, c.w);
+    atomicOr(&bm[key >> 5], 1u << (key & 31u));
+}
+
+__device__ __forceinline__ int sp_gran_count(const uint32_t* __restrict__ bm, uint32_t g) {
+    const uint4* gp = reinterpret_cast<const uint4*>(bm + ((size_t)g << 3));
+    const uint4 a = gp[0], b = gp[1];
+    return __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+}
+
+// One thread per directory word (32 granules; most words are empty: the loop runs over the set bits), 256 words per block.
+// Pass 0: sites below every word -> cnt[w], block totals -> blk_sum, totals of groups of SP_ROOT_GROUP blocks -> grp_sum.
+// Pass 1: base[g] = sites in front of granule g for the occupied granules: whole groups + the blocks of the own group + the words
+// in front inside the block (a block scan) + the granules in front inside the word -- no separate scan launches.
+constexpr int SP_ROOT_GROUP = 64;   // blocks per coarse sum
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sp_root_count(const uint32_t* __restrict__ l1, const uint32_t* __restrict__ bm, int l1_words,
+                                                      int* __restrict__ cnt, int* __restrict__ blk_sum, int* __restrict__ grp_sum,
+                                                      int* __restrict__ base) {
+    __shared__ int s_w[4], s_red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    uint32_t m = w < l1_words ? l1[w] : 0u;
+    if constexpr (PASS == 0) {
+        int c = 0;
+        while (m) {
+            const int j = __ffs(m) - 1;
+            m &= m - 1u;
+            c += sp_gran_count(bm, (uint32_t)w * 32u + (uint32_t)j);
+        }
+        if (w < l1_words) cnt[w] = c;
+        c = wave_sum_i(c);
+        if (lane == 0) s_w[wave] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            blk_sum[blockIdx.x] = t;
+            if (t) atomicAdd(&grp_sum[blockIdx.x / SP_ROOT_GROUP], t);     // cleared together with the directory
+        }
+    } else {
+        const int c = w < l1_words ? cnt[w] : 0;
+        const int incl = wave_incl_scan(c);
+        if (lane == 63) s_w[wave] = incl;
+        const int grp = (int)blockIdx.x / SP_ROOT_GROUP;
+        int part = 0;
+        for (int b = threadIdx.x; b < grp; b += 256) part += grp_sum[b];
+        if ((int)threadIdx.x < (int)blockIdx.x - grp * SP_ROOT_GROUP) part += blk_sum[grp * SP_ROOT_GROUP + threadIdx.x];
+        part = wave_sum_i(part);
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        int run = s_red[0] + s_red[1] + s_red[2] + s_red[3] + incl - c;
+        for (int k = 0; k < wave; ++k) run += s_w[k];
+        while (m) {
+            const int j = __ffs(m) - 1;
+            m &= m - 1u;
+            const uint32_t g = (uint32_t)w * 32u + (uint32_t)j;
+            base[g] = run;
+            run += sp_gran_count(bm, g);
+        }
+    }
+}
+
+// every site to its rank: sorted_idx[rank] = idx[i], perm[rank] = i, and (optionally) its feature row
+__global__ __launch_bounds__(256) void k_sp_root_apply(const int4* __restrict__ idx, int cap, const int* __restrict__ n_dev, SpShape s,
+                                                      SpRank r, int4* __restrict__ sorted_idx, int* __restrict__ perm,
+                                                      const float* __restrict__ feat, int channels, float* __restrict__ feat_sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= live_rows(n_dev, cap)) return;
+    const int4 c = idx[i];
+    const int row = sp_rank_lookup(r, sp_key(s, c.x, c.y, c.z, c.w));
+    if (row >= 0 && row < cap) {
+        sorted_idx[row] = c;
+        perm[row] = i;
+        if (feat) {
+            if (channels == 4) {
+                reinterpret_cast<float4*>(feat_sorted)[row] = reinterpret_cast<const float4*>(feat)[i];
+            } else {
+                for (int k = 0; k < channels; ++k) feat_sorted[(size_t)row * channels + k] = feat[(size_t)i * channels + k];
+            }
+        }
     }
 }
 
@@ -1121,11 +1233,33 @@ extern "C" int heal_sp_out_sites_rank(const int32_t* in_indices, int n_in, const
 
 // nbr [n_out, K] through the rank structure of the input site set (built by heal_sp_out_sites_rank for `in_shape`); n_in /
 // n_in_dev: rows of the input set (sites beyond its capacity were dropped when it was emitted: they are no neighbours).
-extern "C" int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
-                                      const int32_t* stride_host, const int32_t* padding_host,
-                                      const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
-                                      const void* rank, size_t rank_bytes, int n_in, const int32_t* n_in_dev,
-                                      int32_t* nbr, const int32_t* n_out_dev, void* stream) {
+// the root structure's buffer: bitmap | bases | level-1 bitmap (directory) + per-group site counts (one memset) | per-block and
+// per-directory-word counts
+struct SpRootWs {
+    uint32_t* bm; int* base; uint32_t* l1; int* grp_sum; int* blk_sum; int* cnt;
+    size_t words, gran, l1_words, clear_bytes;
+    int blocks, groups;
+};
+static bool carve_root(const SpShape& s, void* rank, size_t rank_bytes, SpRootWs& w) {
+    w.words = rank_words(s); w.gran = w.words / 8; w.l1_words = (w.gran + 31) / 32;
+    w.blocks = (int)((w.l1_words + 255) / 256);
+    Arena a(rank, rank_bytes);
+    w.bm = a.take<uint32_t>(w.words);
+    w.base = a.take<int>(w.gran);
+    w.groups = (w.blocks + SP_ROOT_GROUP - 1) / SP_ROOT_GROUP;
+    w.l1 = a.take<uint32_t>(w.l1_words);
+    w.grp_sum = a.take<int>((size_t)w.groups);
+    w.blk_sum = a.take<int>((size_t)w.blocks);
+    w.cnt = a.take<int>(w.l1_words);
+    w.clear_bytes = (size_t)((char*)w.blk_sum - (char*)w.l1);
+    return a.ok();
+}
+
+static int neighbors_rank(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
+                          const int32_t* stride_host, const int32_t* padding_host,
+                          const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
+                          const void* rank, size_t rank_bytes, int n_in, const int32_t* n_in_dev,
+                          int32_t* nbr, const int32_t* n_out_dev, void* stream, bool root) {
     SpConvGeom g;
     if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
     if (n_out <= 0) return 0;
@@ -1134,10 +1268,72 @@ extern "C" int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, con
     SpRank r;
     r.bm = a.take<uint32_t>(words);
     r.base = a.take<int>(gran);
+    r.l1 = root ? a.take<uint32_t>((gran + 31) / 32) : nullptr;
     HEAL_REQUIRE(a.ok() && ((uintptr_t)rank & 255) == 0, "sp_neighbors_rank: bad rank buffer");
     const long long total = (long long)n_out * g.k[0] * g.k[1];
     k_sp_nbr_rank<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const int4*>(out_indices), n_out, n_out_dev, g, r, n_in, n_in_dev, nbr);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
+                                      const int32_t* stride_host, const int32_t* padding_host,
+                                      const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
+                                      const void* rank, size_t rank_bytes, int n_in, const int32_t* n_in_dev,
+                                      int32_t* nbr, const int32_t* n_out_dev, void* stream) {
+    return neighbors_rank(out_indices, n_out, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch, rank,
+                          rank_bytes, n_in, n_in_dev, nbr, n_out_dev, stream, false);
+}
+
+// the same query against the two-level structure heal_sp_root_rank leaves behind
+extern "C" int heal_sp_neighbors_root(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
+                                      const int32_t* stride_host, const int32_t* padding_host,
+                                      const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
+                                      const void* rank, size_t rank_bytes, int n_in, const int32_t* n_in_dev,
+                                      int32_t* nbr, const int32_t* n_out_dev, void* stream) {
+    return neighbors_rank(out_indices, n_out, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch, rank,
+                          rank_bytes, n_in, n_in_dev, nbr, n_out_dev, stream, true);
+}
+
+extern "C" size_t heal_sp_root_rank_bytes(const int32_t* shape_host, int batch) {
+    SpShape s;
+    if (!shape_ok(shape_host, batch, s)) return 0;
+    const size_t words = rank_words(s), gran = words / 8, l1w = (gran + 31) / 32;
+    const size_t blocks = (l1w + 255) / 256, groups = (blocks + SP_ROOT_GROUP - 1) / SP_ROOT_GROUP;
+    return align_up(words * 4) + align_up(gran * 4) + 2 * align_up(l1w * 4) + align_up(groups * 4) + align_up(blocks * 4) + 256;
+}
+
+// Sort the voxel set by linear coordinate WITHOUT a sort and leave its rank structure in `rank` (heal_sp_root_rank_bytes(shape,
+// batch) bytes, 256-B aligned, caller-owned, contents on entry irrelevant): sorted_indices[r] = indices[perm[r]], r = the number
+// of sites with a smaller linear coordinate.  Same outputs as heal_sp_sort_sites (sites are unique); `features` [n, channels]
+// (optional) are re-ordered on the way: sorted_features[r] = features[perm[r]] (= heal_sp_gather_rows).  heal_sp_neighbors_root
+// then answers the neighbour queries of the layers that read this set.
+extern "C" int heal_sp_root_rank(const int32_t* indices, int n, const int32_t* shape_host, int batch, int32_t* sorted_indices,
+                                 int32_t* perm, const float* features, int channels, float* sorted_features, void* rank,
+                                 size_t rank_bytes, const int32_t* n_dev, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SpShape sh;
+    HEAL_REQUIRE(shape_ok(shape_host, batch, sh), "sp_root_rank: bad shape");
+    HEAL_REQUIRE(((uintptr_t)rank & 255) == 0, "sp_root_rank: rank buffer must be 256-B aligned");
+    HEAL_REQUIRE(features == nullptr || (channels >= 1 && sorted_features != nullptr), "sp_root_rank: bad feature arguments");
+    HEAL_REQUIRE(features == nullptr || channels != 4 || (((uintptr_t)features | (uintptr_t)sorted_features) & 15) == 0,
+                 "sp_root_rank: 4-channel feature rows must be 16-B aligned");
+    if (n <= 0) return 0;
+    SpRootWs w;
+    HEAL_REQUIRE(carve_root(sh, rank, rank_bytes, w), "sp_root_rank: rank buffer too small (%zu bytes)", rank_bytes);
+    HEAL_REQUIRE(w.gran < (1ull << 31), "sp_root_rank: grid too large");
+    const int4* idx = reinterpret_cast<const int4*>(indices);
+    const int nb = ceil_div(n, 256);
+    HEAL_HIP(hipMemsetAsync(w.l1, 0, w.clear_bytes, s));
+    k_sp_root_mark1<<<nb, 256, 0, s>>>(idx, n, n_dev, sh, w.l1, w.bm);
+    k_sp_root_mark2<<<nb, 256, 0, s>>>(idx, n, n_dev, sh, w.bm);
+    k_sp_root_count<0><<<w.blocks, 256, 0, s>>>(w.l1, w.bm, (int)w.l1_words, w.cnt, w.blk_sum, w.grp_sum, w.base);
+    k_sp_root_count<1><<<w.blocks, 256, 0, s>>>(w.l1, w.bm, (int)w.l1_words, w.cnt, w.blk_sum, w.grp_sum, w.base);
+    SpRank r;
+    r.bm = w.bm; r.base = w.base; r.l1 = w.l1;
+    k_sp_root_apply<<<nb, 256, 0, s>>>(idx, n, n_dev, sh, r, reinterpret_cast<int4*>(sorted_indices), perm, features, channels,
+                                        sorted_features);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

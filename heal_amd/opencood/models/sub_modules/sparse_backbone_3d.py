@@ -147,7 +147,7 @@ class _Block(nn.Sequential):
                 nbr_cache[conv.indice_key] = nbr
             feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=x.n_dev)
             y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.n_dev, x._checks, x._root_cap)
-            y._table, y._rank = x._table, x._rank
+            y._table, y._rank, y._rank_root = x._table, x._rank, x._rank_root
             return y
         out_idx, out_shape, n_out_dev, rank = x.out_sites_ex(conv.kernel_size, conv.stride, conv.padding)
         nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, n_out_dev=n_out_dev)

@@ -620,7 +620,9 @@ def window_attention(qkv, pos_bias, heads, dim_head, window, scale, out=None):
         out = torch.empty((L, H, W, heads * dim_head), dtype=torch.float32, device=qkv.device)
     elif not (out.is_contiguous() and out.numel() == L * H * W * heads * dim_head and out.dtype == torch.float32):
         raise _capi.HealAmdError("window_attention: `out` must be a contiguous f32 [L,H,W,heads*dim_head] buffer")
-    with _Timed(f"window_attention_ws{window}"):
+    # per token: q k^T and p v = 4 window^2 inner FLOPs; q | k | v read + the result written = 16 inner bytes
+    inner = heads * dim_head
+    with _Timed(f"window_attention_ws{window}", flops=4.0 * L * H * W * window * window * inner, nbytes=16.0 * L * H * W * inner):
         _capi.call("heal_window_attention", _ptr(qkv), _optr(pos_bias), L, H, W, int(heads), int(dim_head), int(window),
                    float(scale), _ptr(out), _stream())
     return out
@@ -966,6 +968,7 @@ class SparseTensor:
         self._root_cap = int(root_cap) if root_cap is not None else int(indices.shape[0])  # rows of the voxel set
         self._table = None
         self._rank = None   # rank structure (bitmap + prefix counts) when this site set came out of out_sites_ex()
+        self._rank_root = False   # ... or the two-level structure of the voxel set (from_unsorted)
 
     @property
     def n(self):
@@ -985,15 +988,26 @@ class SparseTensor:
         dev = indices.device
         sorted_idx = torch.empty_like(indices)
         perm = torch.zeros((n,), dtype=torch.int32, device=dev)  # zeros: padding rows gather row 0, harmlessly
-        ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
-        with _Timed("sp_rulebook"):
-            _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
-                       _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
+        rank = None
         C = int(features.shape[1])
         feats = torch.zeros((n, C), dtype=torch.float32, device=dev) if n_dev is not None else torch.empty((n, C), dtype=torch.float32, device=dev)
-        with _Timed("sp_rulebook"):
-            _capi.call("heal_sp_gather_rows", _ptr(features), _ptr(perm), n, C, _optr(n_dev), _ptr(feats), _stream())
+        if os.environ.get("HEAL_SP_RULEBOOK", "rank") == "rank" and os.environ.get("HEAL_SP_ROOT", "rank") == "rank":
+            # rank(linear coordinate) IS the sorted position: one scatter (sites, permutation and feature rows) instead of a radix
+            # sort + gather, and the structure answers the neighbour queries of the layers that read the voxel set (no hash grid)
+            nbytes = _capi.query("heal_sp_root_rank_bytes", _i3(spatial_shape), int(batch_size))
+            rank = torch.empty((nbytes,), dtype=torch.uint8, device=dev)   # lives as long as the site set it describes
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_root_rank", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
+                           _ptr(perm), _ptr(features), C, _ptr(feats), _ptr(rank), nbytes, _optr(n_dev), _stream())
+        else:
+            ws = _workspace("sp_sort", _capi.query("heal_sp_sort_workspace", n), dev)
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_sort_sites", _ptr(indices), n, _i3(spatial_shape), int(batch_size), _ptr(sorted_idx),
+                           _ptr(perm), _ptr(ws), ws.numel(), _optr(n_dev), _stream())
+            with _Timed("sp_rulebook"):
+                _capi.call("heal_sp_gather_rows", _ptr(features), _ptr(perm), n, C, _optr(n_dev), _ptr(feats), _stream())
         st = SparseTensor(feats, sorted_idx, spatial_shape, batch_size, n_dev)
+        st._rank, st._rank_root = rank, rank is not None
         st._perm = perm   # row i of the sorted set = input row perm[i] (the gradient path re-applies it differentiably)
         return st
 
@@ -1015,7 +1029,8 @@ class SparseTensor:
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.indices.device)
         if self._rank is not None:
             with _Timed("sp_rulebook"):
-                _capi.call("heal_sp_neighbors_rank", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
+                _capi.call("heal_sp_neighbors_root" if self._rank_root else "heal_sp_neighbors_rank",
+                           _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
                            _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(self._rank), self._rank.numel(),
                            self.n, _optr(self.n_dev), _ptr(nbr), _optr(n_out_dev), _stream())
             return nbr

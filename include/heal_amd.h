@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HEAL_AMD_ABI_VERSION 2
+#define HEAL_AMD_ABI_VERSION 3
 
 int heal_abi_version(void);
 const char* heal_last_error(void);
@@ -328,6 +328,21 @@ int heal_sp_out_sites_rank(const int32_t* in_indices, int n_in, const int32_t* k
                            int32_t* n_out, void* rank, size_t rank_bytes, const int32_t* n_in_dev,
                            int32_t* overflow /* optional sticky max(n_out) when n_out > out_cap */, void* stream);
 int heal_sp_neighbors_rank(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
+                           const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
+                           const int32_t* out_shape_host, int batch, const void* rank, size_t rank_bytes,
+                           int n_in, const int32_t* n_in_dev, int32_t* nbr, const int32_t* n_out_dev, void* stream);
+/* The ROOT site set (the voxels) through a two-level rank structure (round 4): heal_sp_root_rank replaces heal_sp_sort_sites +
+ * heal_sp_hash_build -- sorted_indices / perm as heal_sp_sort_sites produces them (sites are unique), by ONE scatter to
+ * row = rank(linear coordinate), no sort -- and leaves the structure in `rank` (heal_sp_root_rank_bytes(shape, batch) bytes,
+ * 256-B aligned, caller-owned, contents on entry irrelevant: only a 1-bit-per-256-cells directory is cleared per call);
+ * heal_sp_neighbors_root is heal_sp_neighbors_rank against that structure.  Replaces spconv's indice-pair generation for the first
+ * SubMConv3d / SparseConv3d of sparse_backbone_3d.py:114-118 (`ops.get_indice_pairs` on the voxel coordinates). */
+size_t heal_sp_root_rank_bytes(const int32_t* shape_host, int batch);
+int heal_sp_root_rank(const int32_t* indices, int n, const int32_t* shape_host, int batch, int32_t* sorted_indices,
+                      int32_t* perm, const float* features /* [n, channels] or NULL */, int channels,
+                      float* sorted_features /* [n, channels]: features[perm[r]], = heal_sp_gather_rows */, void* rank,
+                      size_t rank_bytes, const int32_t* n_dev, void* stream);
+int heal_sp_neighbors_root(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
                            const int32_t* stride_host, const int32_t* padding_host, const int32_t* in_shape_host,
                            const int32_t* out_shape_host, int batch, const void* rank, size_t rank_bytes,
                            int n_in, const int32_t* n_in_dev, int32_t* nbr, const int32_t* n_out_dev, void* stream);

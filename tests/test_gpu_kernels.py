@@ -1356,21 +1356,70 @@ def test_rank_rulebook_equals_hash_rulebook(monkeypatch):
     rng = np.random.default_rng(11)
     shape, batch = (21, 40, 52), 3
     idx = _random_sites(rng, 6000, shape, batch)
-    x = ops.SparseTensor.from_unsorted(dev(np.ones((len(idx), 4), np.float32)), dev(idx), shape, batch)
+    feats = rng.standard_normal((len(idx), 4)).astype(np.float32)
+    monkeypatch.setenv("HEAL_SP_RULEBOOK", "hash")
+    x_h = ops.SparseTensor.from_unsorted(dev(feats), dev(idx), shape, batch)      # radix sort + hash grid
+    assert x_h._rank is None
+    monkeypatch.setenv("HEAL_SP_RULEBOOK", "rank")
+    x = ops.SparseTensor.from_unsorted(dev(feats), dev(idx), shape, batch)        # root rank structure: one scatter, no sort
+    assert x._rank is not None and x._rank_root
+    assert torch.equal(x.indices, x_h.indices) and torch.equal(x._perm, x_h._perm) and torch.equal(x.features, x_h.features)
+    sub = (3, 3, 3)
+    assert torch.equal(x.neighbors(x.indices, shape, sub, (1, 1, 1), (1, 1, 1)),
+                       x_h.neighbors(x_h.indices, shape, sub, (1, 1, 1), (1, 1, 1)))
     for k, st, pd in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
         monkeypatch.setenv("HEAL_SP_RULEBOOK", "hash")
-        oi_h, osh, _, rk = x.out_sites_ex(k, st, pd)
+        oi_h, osh, _, rk = x_h.out_sites_ex(k, st, pd)
         assert rk is None
-        nbr_h = x.neighbors(oi_h, osh, k, st, pd)
+        nbr_h = x_h.neighbors(oi_h, osh, k, st, pd)
         monkeypatch.setenv("HEAL_SP_RULEBOOK", "rank")
         oi, osh2, _, rank = x.out_sites_ex(k, st, pd)
         assert osh == osh2 and torch.equal(oi, oi_h) and rank is not None
         y = ops.SparseTensor(torch.zeros((oi.shape[0], 4), device="cuda"), oi, osh, batch)
         y_h = ops.SparseTensor(torch.zeros((oi.shape[0], 4), device="cuda"), oi, osh, batch)
         y._rank = rank
-        sub = (3, 3, 3)
         assert torch.equal(y.neighbors(oi, osh, sub, (1, 1, 1), (1, 1, 1)), y_h.neighbors(oi, osh, sub, (1, 1, 1), (1, 1, 1)))
         assert torch.equal(x.neighbors(oi, osh, k, st, pd), nbr_h)
+
+
+def test_root_rank_structure_device_counts_and_reuse(monkeypatch):
+    """heal_sp_root_rank with a device-side row count and capacity-sized buffers (the graph-captured encoder): the live rows come out
+    sorted exactly as the radix sort leaves them; the structure is rebuilt on a DIFFERENT site set in the same (dirty) buffer --
+    only the granule directory is cleared per call, stale granule words must never leak; sites on the first / last cell of the
+    grid and in neighbouring granules."""
+    from heal_amd import _capi, ops
+    rng = np.random.default_rng(23)
+    shape, batch = (41, 64, 300), 2          # 300 cells per row: granules straddle rows
+    cap = 5000
+    nbytes = _capi.query("heal_sp_root_rank_bytes", ops._i3(shape), batch)
+    rank = torch.full((nbytes,), 0xA5, dtype=torch.uint8, device="cuda")          # garbage on entry
+    for trial, n_live in enumerate((4000, 1500, 4999)):
+        idx = _random_sites(rng, n_live - 2, shape, batch)
+        idx = np.unique(np.concatenate([idx, [[0, 0, 0, 0], [batch - 1, shape[0] - 1, shape[1] - 1, shape[2] - 1]]]).astype(np.int32), axis=0)
+        rng.shuffle(idx)
+        n_live = len(idx)
+        pad = np.concatenate([idx, np.full((cap - n_live, 4), 7, np.int32)])     # rows beyond the live count: junk
+        n_dev = torch.tensor([n_live], dtype=torch.int32, device="cuda")
+        out = torch.full((cap, 4), -1, dtype=torch.int32, device="cuda")
+        perm = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+        feats = dev(rng.standard_normal((cap, 4)).astype(np.float32))
+        fs = torch.zeros((cap, 4), device="cuda")
+        _capi.call("heal_sp_root_rank", ops._ptr(dev(pad)), cap, ops._i3(shape), batch, ops._ptr(out), ops._ptr(perm), ops._ptr(feats), 4,
+                   ops._ptr(fs), ops._ptr(rank), nbytes, ops._ptr(n_dev), ops._stream())
+        key = ((idx[:, 0].astype(np.int64) * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+        order = np.argsort(key, kind="stable")
+        np.testing.assert_array_equal(out[:n_live].cpu().numpy(), idx[order])
+        np.testing.assert_array_equal(perm[:n_live].cpu().numpy(), order)
+        assert torch.equal(fs[:n_live], feats[torch.from_numpy(order).cuda()]) and bool((fs[n_live:] == 0).all())
+        assert bool((out[n_live:] == -1).all())
+        # neighbour rows through the structure = brute force on the sorted coordinates
+        nbr = torch.empty((cap, 27), dtype=torch.int32, device="cuda")
+        _capi.call("heal_sp_neighbors_root", ops._ptr(out), cap, ops._i3((3, 3, 3)), ops._i3((1, 1, 1)), ops._i3((1, 1, 1)),
+                   ops._i3(shape), ops._i3(shape), batch, ops._ptr(rank), nbytes, cap, ops._ptr(n_dev), ops._ptr(nbr), ops._ptr(n_dev),
+                   ops._stream())
+        from oracle import oracle_np as O
+        _, _, want = O.sparse_conv_rules(idx[order], list(shape), (3, 3, 3), (1, 1, 1), (1, 1, 1), True)
+        np.testing.assert_array_equal(nbr[:n_live].cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("n,cin,cout,H,W,ks,stride,res", [(2, 64, 128, 40, 56, 3, 2, True), (1, 96, 256, 33, 24, 3, 2, False),
