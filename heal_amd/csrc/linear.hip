@@ -168,6 +168,21 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinearArgs a) {
     constexpr int CS = LIN_BN + 4;
     float* sC = s_all;       // 128 x 132 floats = 67.6 KB of the 73.7 KB the two operand rings occupy (contiguous arrays)
     static_assert(sizeof(s_all) >= (size_t)LIN_BM * CS * 4, "epilogue tile must fit the operand rings");
+    // this thread's 16-B column is fixed: 32 column pieces per row, 8 rows per pass
+    const int c4 = tid & 31, col = n0 + c4 * 4;
+    // row map (a tile never straddles an `inner` boundary: inner is a multiple of 128)
+    const long long q_ = a.map_inner > 0 ? t0 / a.map_inner : 0, rem_ = a.map_inner > 0 ? t0 - q_ * a.map_inner : t0;
+    // The residual rows are requested HERE, before the accumulators go through LDS: 16 loads in flight under the transposition
+    // instead of four exposed round trips inside the store loop (the accumulator registers are free from the LDS writes on).
+    float4 rres[16];
+    if (a.res) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = min((tid >> 5) + 8 * i, a.T - 1 - t0);     // clamped: rows past T are never stored
+            const size_t orow = a.map_inner > 0 ? (size_t)(rem_ + row) * a.map_outer + (size_t)q_ : (size_t)(t0 + row);
+            rres[i] = *reinterpret_cast<const float4*>(a.res + orow * a.ldr + col);
+        }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -177,15 +192,11 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinearArgs a) {
                 sC[(wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + wn * 64 + n * 32 + li] = acc[m][n][r];
     __syncthreads();
     const float* bias = a.bias ? a.bias + (a.bias_groups ? (size_t)group * a.N : 0) : nullptr;
-    // this thread's 16-B column is fixed: 32 column pieces per row, 8 rows per pass
-    const int c4 = tid & 31, col = n0 + c4 * 4;
     const int part = col / a.part_cols, pc = col - part * a.part_cols;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
-    // row map (a tile never straddles an `inner` boundary: inner is a multiple of 128)
-    const long long q_ = a.map_inner > 0 ? t0 / a.map_inner : 0, rem_ = a.map_inner > 0 ? t0 - q_ * a.map_inner : t0;
     float* obase = a.out + (size_t)part * a.part_stride + pc;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = (tid >> 5) + 8 * i;
         if (t0 + row >= a.T) break;
@@ -194,10 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinearArgs a) {
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (a.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         else if (a.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.res) {
-            const float4 rv = *reinterpret_cast<const float4*>(a.res + orow * a.ldr + col);
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
+        if (a.res) { v.x += rres[i].x; v.y += rres[i].y; v.z += rres[i].z; v.w += rres[i].w; }
         *reinterpret_cast<float4*>(obase + orow * a.ldo) = v;
     }
 }
