@@ -377,6 +377,28 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
     const bool even_w = (W & 1) == 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
+        // the residual values of this pass are requested BEFORE the accumulators go through LDS (unconditional loads on clamped
+        // addresses): they land under the dump, the barrier and the transform instead of costing a round trip per (channel, row)
+        // right in front of the stores
+        float rr0[16 / CPP][2], rr1[16 / CPP][2];
+        if (rin) {
+#pragma unroll
+            for (int h = 0; h < 16 / CPP; ++h) {
+                const int co = min(mb * 64 + p * 16 + ecg + CPP * h, Cout - 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int yy = min(oy + i, H - 1), xx = min(ox, W - (even_w ? 2 : 1));
+                    const size_t o0 = (size_t)co * HWo + (size_t)yy * W + xx;
+                    if (even_w) {
+                        const float2 q = *reinterpret_cast<const float2*>(rin + o0);
+                        rr0[h][i] = q.x; rr1[h][i] = q.y;
+                    } else {
+                        rr0[h][i] = rin[o0];
+                        rr1[h][i] = rin[o0 + (xx + 1 < W ? 1 : 0)];
+                    }
+                }
+            }
+        }
         lds_barrier();                            // staging buffers (first pass) / previous pass no longer read
 #pragma unroll
         for (int xi_i = 0; xi_i < XW; ++xi_i)
@@ -410,7 +432,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
                 const size_t o0 = (size_t)co * HWo + (size_t)(oy + i) * W + ox;
                 float v0 = o[i][0] + bv, v1 = o[i][1] + bv;
                 const bool two = ox + 1 < W;
-                if (rin) { v0 += rin[o0]; if (two) v1 += rin[o0 + 1]; }
+                if (rin) { v0 += rr0[h][i]; v1 += rr1[h][i]; }
                 if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                 if (two && even_w) *reinterpret_cast<float2*>(yout + o0) = make_float2(v0, v1);
                 else { yout[o0] = v0; if (two) yout[o0 + 1] = v1; }
