@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, co
     float* __restrict__ yout = y + (size_t)n * Cout * HWo;
     const float* __restrict__ rin = res ? res + (size_t)n * Cout * HWo : nullptr;
     const int ox = ox0 + ln;
+    // residual values first, all of them in flight together (unconditional loads on clamped addresses): a load inside the
+    // predicated store loop sits in its own basic block and costs one exposed round trip each
+    float rr[4][NT][4];
+    if (rin) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const size_t pix = (size_t)min(oy0 + wave * NT + nt, Ho - 1) * Wo + min(ox, Wo - 1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rr[mt][nt][r] = rin[(size_t)min(mb * 64 + mt * 16 + lk * 4 + r, Cout - 1) * HWo + pix];
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + wave * NT + nt;
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, co
                 if (co >= Cout) continue;
                 float v = acc[mt][nt][r] + (bias ? bias[co] : 0.f);
                 const size_t o = (size_t)co * HWo + pix;
-                if (rin) v += rin[o];
+                if (rin) v += rr[mt][nt][r];
                 if (relu == 1) v = fmaxf(v, 0.f);
                 else if (relu == 2) v = v / (1.f + expf(-v));
                 yout[o] = v;
