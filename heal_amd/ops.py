@@ -277,7 +277,10 @@ def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxel
         bounds = [0]
         for p in pts:
             bounds.append(bounds[-1] + int(p.shape[0]))
-        allp = pts[0] if len(pts) == 1 else torch.cat(pts, 0)
+        # clouds that already lie back to back in memory (pipeline.StaticInputs) are read in place
+        adjacent = all(p.is_contiguous() for p in pts) and all(
+            pts[i].data_ptr() + pts[i].numel() * 4 == pts[i + 1].data_ptr() for i in range(len(pts) - 1))
+        allp = pts[0] if (len(pts) == 1 or adjacent) else torch.cat(pts, 0)
         nbytes = _capi.query("heal_voxelize_batch_workspace", bounds[-1], len(pts), int(max_points), int(max_voxels))
         ws = _workspace("voxelize", nbytes, dev)
         with _Timed("voxelize"):
