@@ -41,7 +41,10 @@ timeout 200 python scripts/k5_bench.py --json $OUT/${TAG}_k5_bench.json > /dev/n
 timeout 200 python scripts/c1t_bench.py --json $OUT/${TAG}_c1t_bench.json > /dev/null 2>&1
 timeout 200 python scripts/conv_gemm_bench.py > $OUT/${TAG}_conv_gemm_bench.txt 2> /dev/null
 timeout 100 python scripts/stem_bench.py > $OUT/${TAG}_stem_bench.txt 2> /dev/null
-for d in 0 2 16 64; do :; done
+timeout 100 python scripts/k8_bench.py > $OUT/${TAG}_k8_bench.json 2> /dev/null
+bash scripts/k8_prof.sh 2> /dev/null | grep "heal::" > $OUT/${TAG}_k8_kernels.txt
+bash scripts/k3_rulebook_prof.sh > $OUT/${TAG}_k3_rulebook_kernels.txt 2> /dev/null
+timeout 100 python scripts/linear_bench.py > $OUT/${TAG}_linear_bench.txt 2> /dev/null
 bash scripts/k4_dbg.sh 0 2 16 64 > $OUT/${TAG}_k4_anatomy.txt 2>&1
 timeout 100 python scripts/k4_stamps.py > $OUT/${TAG}_k4_stamps.txt 2> /dev/null
 ls -la $OUT
