@@ -213,6 +213,10 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             continue
         ach = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["bound"] == "mfma" else (f["bytes"] / (f["ms"] * 1e-3) / 1e9)
         extra = {"step_ms": round(f["ms"] / max(a.steps, 1), 4)}
+        if key in ("conv1x1", "conv1x1s", "conv3x3w", "conv3x3", "grouped", "k5", "linear"):
+            # one kernel per launch: the events are stamped by the launch itself (heal_next_launch_events / hipExtLaunchKernelGGL)
+            # with the kernel's own begin / end -- the duration a rocprofv3 kernel trace reports for it
+            extra["duration"] = "kernel-own begin / end stamps"
         if key.startswith("wattn"):      # both roofs for the window-attention kernels
             extra["tflops"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
             extra["hbm_gbs"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)

@@ -62,6 +62,15 @@ LaunchEvents take_launch_events();
             hipLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, __VA_ARGS__);                      \
     } while (0)
 
+// the same with explicit events (either may be null): the first kernel of a two-kernel operator takes `start`, the last `stop`
+#define HEAL_LAUNCH_EV2(kernel, grid, block, lds, stream, ev_start, ev_stop, ...)                                    \
+    do {                                                                                                             \
+        if ((ev_start) || (ev_stop))                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, ev_start, ev_stop, 0, __VA_ARGS__); \
+        else                                                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, __VA_ARGS__);                      \
+    } while (0)
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ unsigned long long lanemask_lt() {

@@ -287,25 +287,28 @@ static int conv1x1_launch(const float* x, const float* weight_frag, const float*
 #define HEAL_C1(BM_, BN_, KC_, ST_)                                                                              \
     if (bm == BM_ && bn == BN_ && kc == KC_ && stride == ST_) {                                                  \
         if (ksplit > 1)                                                                                          \
-            k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n * ksplit), 256, 0, s>>>(       \
-                x, weight_frag, nullptr, nullptr, in_scale, cin, kpad, cout, HW, Wo, W, H * W, 0, 0, 1, 0, 0, n, ksplit, \
-                partials);                                                                                       \
+            HEAL_LAUNCH_EV2((k_conv1x1<BM_, BN_, KC_, ST_>), dim3(mpad / BM_, ceil_div(HW, BN_), n * ksplit), dim3(256), 0, s, \
+                            ev.start, (hipEvent_t) nullptr,                                                      \
+                            x, weight_frag, (const float*)nullptr, (const float*)nullptr, in_scale, cin, kpad, cout, HW, Wo, W, \
+                            H * W, 0, 0, 1, 0, 0, n, ksplit, partials);                                          \
         else                                                                                                     \
-            k_conv1x1<BM_, BN_, KC_, ST_><<<dim3(mpad / BM_, ceil_div(HW, BN_), n), 256, 0, s>>>(                \
-                x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, d2s_k, \
-                d2s_ctot, d2s_coff, n, 1, y);                                                                    \
+            HEAL_LAUNCH_EV2((k_conv1x1<BM_, BN_, KC_, ST_>), dim3(mpad / BM_, ceil_div(HW, BN_), n), dim3(256), 0, s, \
+                            ev.start, ev.stop,                                                                   \
+                            x, weight_frag, bias, residual, in_scale, cin, kpad, cout, HW, Wo, W, H * W, act, out_pixel_major, \
+                            d2s_k, d2s_ctot, d2s_coff, n, 1, y);                                                 \
         launched = true;                                                                                         \
     }
     bool launched = false;
+    const LaunchEvents ev = take_launch_events();   // measurement hook (heal_next_launch_events): the kernel's own begin / end
     HEAL_C1(64, 64, 32, 1) HEAL_C1(64, 64, 32, 2)
     HEAL_C1(128, 128, 32, 1) HEAL_C1(64, 128, 32, 1) HEAL_C1(128, 64, 32, 1)
 #undef HEAL_C1
     HEAL_REQUIRE(launched, "conv1x1: no kernel for tile (%d,%d,%d) stride %d", bm, bn, kc, stride);
     if (ksplit > 1) {
         const size_t total4 = (size_t)n * cout * HW / 4;
-        k_conv1x1_splitk_reduce<<<(unsigned)((total4 + 255) / 256), 256, 0, s>>>(
-            reinterpret_cast<const float4*>(partials), bias, reinterpret_cast<const float4*>(residual), ksplit, cout, HW / 4,
-            total4, act, reinterpret_cast<float4*>(y));
+        HEAL_LAUNCH_EV2(k_conv1x1_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (hipEvent_t) nullptr, ev.stop,
+                        reinterpret_cast<const float4*>(partials), bias, reinterpret_cast<const float4*>(residual), ksplit, cout,
+                        HW / 4, total4, act, reinterpret_cast<float4*>(y));
     }
     HEAL_LAUNCH_CHECK();
     return 0;

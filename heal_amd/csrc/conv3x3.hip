@@ -592,8 +592,8 @@ static int conv3x3_launch(const float* x, const float* weight_frag, const float*
     HEAL_REQUIRE((long long)tiles_x * tiles_y <= 65535 && n <= 65535, "conv3x3: map too large for the launch grid");
     const dim3 grid(mblocks, tiles_x * tiles_y, n);
 #define HEAL_C3(ST_, TH_)                                                                                          \
-    k_conv3x3<ST_, TH_><<<grid, 256, 0, s>>>(x, weight_frag, bias, residual, cin, nchunks, cout, H, W, Ho, Wo,     \
-                                             tiles_x, tiles_y, relu, pad_t, pad_l, y)
+    HEAL_LAUNCH_EV((k_conv3x3<ST_, TH_>), grid, dim3(256), 0, s, x, weight_frag, bias, residual, cin, nchunks, cout, H, W, Ho, Wo, \
+                   tiles_x, tiles_y, relu, pad_t, pad_l, y)
     if (stride == 1 && th == 16) HEAL_C3(1, 16);
     else if (stride == 1 && th == 8) HEAL_C3(1, 8);
     else if (stride == 1) HEAL_C3(1, 4);
@@ -634,9 +634,11 @@ extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const 
     const dim3 grid(tiles_x * tiles_y, n, mblocks);
     const float4* uf = reinterpret_cast<const float4*>(u_frag);
     if (waves == 8)
-        k_conv3x3_wino<8><<<grid, 512, 0, (hipStream_t)stream>>>(x, uf, bias, residual, cin, nchunks, cout, H, W, tiles_x, relu, y);
+        HEAL_LAUNCH_EV(k_conv3x3_wino<8>, grid, dim3(512), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, cout, H, W,
+                       tiles_x, relu, y);
     else
-        k_conv3x3_wino<4><<<grid, 256, 0, (hipStream_t)stream>>>(x, uf, bias, residual, cin, nchunks, cout, H, W, tiles_x, relu, y);
+        HEAL_LAUNCH_EV(k_conv3x3_wino<4>, grid, dim3(256), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, cout, H, W,
+                       tiles_x, relu, y);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

@@ -201,7 +201,7 @@ extern "C" int heal_conv_gemm(const float* x, const float* weight_tap_major, con
     const long long blocks = (long long)(cout / CG_BM) * a.tiles_x * a.tiles_y * n;
     HEAL_REQUIRE(blocks < (1ll << 31), "conv_gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
-#define HEAL_CG(KS_, ST_) k_conv_gemm<KS_, ST_><<<(unsigned)blocks, 256, 0, s>>>(a)
+#define HEAL_CG(KS_, ST_) HEAL_LAUNCH_EV((k_conv_gemm<KS_, ST_>), dim3((unsigned)blocks), dim3(256), 0, s, a)
     if (ksize == 3 && stride == 2) HEAL_CG(3, 2);
     else if (ksize == 3) HEAL_CG(3, 1);
     else if (stride == 2) HEAL_CG(1, 2);

@@ -201,7 +201,7 @@ extern "C" int heal_grouped_small_conv3x3(const float* x, const float* weight_q,
     hipStream_t s_ = (hipStream_t)stream;
 #define HEAL_GS(CG_, TH_, ST_)                                                                                        \
     if (group_channels == CG_ && th == TH_ && stride == ST_)                                                          \
-        k_gconv_small<CG_, TH_, ST_><<<grid, 256, 0, s_>>>(x, weight_q, bias, channels, H, W, Ho, Wo, tiles_x, relu, y);
+        HEAL_LAUNCH_EV((k_gconv_small<CG_, TH_, ST_>), grid, dim3(256), 0, s_, x, weight_q, bias, channels, H, W, Ho, Wo, tiles_x, relu, y);
     HEAL_GS(4, 16, 1) HEAL_GS(4, 8, 1) HEAL_GS(8, 16, 1) HEAL_GS(8, 8, 1)
     HEAL_GS(4, 8, 2) HEAL_GS(8, 8, 2) HEAL_GS(16, 8, 1) HEAL_GS(16, 8, 2)
 #undef HEAL_GS

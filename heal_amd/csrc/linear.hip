@@ -373,7 +373,7 @@ extern "C" int heal_linear(const float* x, int lda, int x_part_cols, long long x
     a.map_inner = map_inner; a.map_outer = map_outer;
     a.part_cols = part_cols > 0 ? part_cols : n_out; a.part_stride = part_stride; a.act = act;
     const int tiles = ceil_div(n_tokens, LIN_BM) * (n_out / LIN_BN);
-    k_linear<<<tiles, 256, 0, (hipStream_t)stream>>>(a);
+    HEAL_LAUNCH_EV(k_linear, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     HEAL_LAUNCH_CHECK();
     return 0;
 }

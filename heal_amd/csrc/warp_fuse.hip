@@ -678,7 +678,7 @@ extern "C" int heal_warp_fuse_levels(int n_levels, const float* const* feats_hos
     HEAL_REQUIRE(blocks < (1ll << 30), "warp_fuse_levels: grid too large");
     hipStream_t st = (hipStream_t)stream;
     switch (n_agents) {
-#define HEAL_WFL(N) case N: k_warp_fuse_lds<N><<<(unsigned)blocks, 256, 0, st>>>(P); break;
+#define HEAL_WFL(N) case N: HEAL_LAUNCH_EV(k_warp_fuse_lds<N>, dim3((unsigned)blocks), dim3(256), 0, st, P); break;
         HEAL_WFL(1) HEAL_WFL(2) HEAL_WFL(3) HEAL_WFL(4) HEAL_WFL(5) HEAL_WFL(6) HEAL_WFL(7) HEAL_WFL(8)
 #undef HEAL_WFL
     }

@@ -472,7 +472,7 @@ def warp_fuse_levels(feats_list, occ_list, affine_rows, grid_f64=True, crops=Non
     fp = _host_array([f.data_ptr() for f in feats_list], ctypes.c_void_p)
     op = _host_array([o.data_ptr() for o in occ_list], ctypes.c_void_p)
     yp = _host_array([y.data_ptr() for y in outs], ctypes.c_void_p)
-    with _Timed("warp_fuse_levels", 0.0, nbytes):
+    with _Timed("warp_fuse_levels", 0.0, nbytes, kernel_events=True):
         _capi.call("heal_warp_fuse_levels", L, fp, op, n, _host_array([int(f.shape[1]) for f in feats_list], ctypes.c_int32),
                    _host_array([int(f.shape[2]) for f in feats_list], ctypes.c_int32),
                    _host_array([int(f.shape[3]) for f in feats_list], ctypes.c_int32), ap, adev, int(bool(grid_f64)), cp, yp,
@@ -1226,7 +1226,7 @@ def linear(x, weight, bias=None, stats=None, act=None, residual=None, out=None, 
     inner, outer = (int(row_map[0]), int(row_map[1])) if row_map is not None else (0, 0)
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
-    with _Timed(f"linear_{K}_{N}", flops=2.0 * T * K * N):
+    with _Timed(f"linear_{K}_{N}", flops=2.0 * T * K * N, kernel_events=True):
         _capi.call("heal_linear", _ptr(x), xk, xk if x_parts > 1 else 0, T * xk, _optr(stats), _ptr(weight), _optr(bias),
                    int(bool(bias_per_group)),
                    _optr(colscale), int(colscale_part), int(group_rows), _optr(residual), N if residual is not None else 0,
@@ -1310,7 +1310,7 @@ def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
     if C % 16 == 0 and W % 4 == 0 and Wo % 4 == 0 and mode in ("1", "s") and cg in (4, 8, 16):
         frag = grouped_small_fragments(weight, cg)
         with _Timed(f"grouped_conv3x3_c{C}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * C * cg * Ho * Wo,
-                    4.0 * n * C * (H * W + Ho * Wo)):
+                    4.0 * n * C * (H * W + Ho * Wo), kernel_events=True):
             _capi.call("heal_grouped_small_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), n, C, cg, H, W, int(stride),
                        int(bool(relu)), _ptr(y), _stream())
         return y
@@ -1493,13 +1493,13 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
         nbytes = _capi.query("heal_conv1x1_splitk_workspace", n, cout, H, W, ksplit)
         ws = _workspace("conv1x1_splitk", nbytes, x.device)
         with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W,
-                    4.0 * n * (cin * H * W + cout * H * W * (2 if residual is not None else 1))):
+                    4.0 * n * (cin * H * W + cout * H * W * (2 if residual is not None else 1)), kernel_events=True):
             _capi.call("heal_conv1x1_splitk", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
                        _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
                        n, cin, cout, H, W, int(act), ksplit, _ptr(y), _ptr(ws), ws.numel(), _stream())
         return y
     with _Timed(f"conv1x1_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * n * cin * cout * Ho * Wo,
-                4.0 * n * (cin * Ho * Wo + cout * Ho * Wo * (2 if residual is not None else 1))):
+                4.0 * n * (cin * Ho * Wo + cout * Ho * Wo * (2 if residual is not None else 1)), kernel_events=True):
         _capi.call("heal_conv1x1", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
                    _ptr(residual) if residual is not None else None, _ptr(in_scale) if in_scale is not None else None,
                    n, cin, cout, H, W, int(stride), int(act), int(bool(pixel_major)), _ptr(y), _stream())
@@ -1525,7 +1525,7 @@ def conv1x1_d2s(x, w, bias, act, k, dst, channel_offset):
                        int(act), int(k), int(dst.shape[1]), int(channel_offset), _ptr(dst), _stream())
         return dst[:, channel_offset:channel_offset + cout // (k * k)]
     frag = conv1x1_fragments(w)
-    with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W, 4.0 * n * H * W * (cin + cout)):
+    with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W, 4.0 * n * H * W * (cin + cout), kernel_events=True):
         _capi.call("heal_conv1x1_d2s", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None, n, cin, cout, H, W,
                    int(act), int(k), int(dst.shape[1]), int(channel_offset), _ptr(dst), _stream())
     return dst[:, channel_offset:channel_offset + cout // (k * k)]
@@ -1566,7 +1566,8 @@ def conv3x3_same(x, w, bias, stride, pad, act="none"):
         raise _capi.HealAmdError(f"conv3x3_same: unsupported padding {pad} / weight {tuple(w.shape)}")
     frag = conv3x3_fragments(w)
     y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    with _Timed(f"conv3x3_{cin}_{cout}_s{stride}same", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
+    with _Timed(f"conv3x3_{cin}_{cout}_s{stride}same", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo),
+                kernel_events=True):
         _capi.call("heal_conv3x3_same", _ptr(x), _ptr(frag), _ptr(_need(bias, torch.float32, "bias")) if bias is not None else None,
                    n, cin, cout, H, W, int(stride), pt, pl, Ho, Wo, {"none": 0, "relu": 1, "silu": 2}[act], _ptr(y), _stream())
     return y
@@ -1680,7 +1681,7 @@ def conv_gemm(x, w, bias=None, residual=None, relu=False, stride=1):
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
     name = (f"conv3x3_{cin}_{cout}" if ks == 3 else f"conv1x1_{cin}_{cout}") + ("_s2" if stride == 2 else "")
-    with _Timed(name, 2.0 * ks * ks * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
+    with _Timed(name, 2.0 * ks * ks * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo), kernel_events=True):
         _capi.call("heal_conv_gemm", _ptr(x), _ptr(hit[0]), _optr(bias), _optr(residual), n, cin, cout, H, W, ks, int(stride),
                    int(bool(relu)), _ptr(y), _stream())
     return y
@@ -1712,7 +1713,8 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
     if conv3x3_algo(stride, n, cout, H, W) == "winograd":
         waves = conv3x3_winograd_waves(n, cout, H, W)
         frag = conv3x3_winograd_fragments(w, waves)
-        with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo)):
+        with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo),
+                    kernel_events=True):
             _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
                        int(bool(relu)), waves, _ptr(y), _stream())
         return y
@@ -1724,7 +1726,7 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
         return conv_gemm(x, w, bias, residual, relu, stride)
     frag = conv3x3_fragments(w)
     with _Timed(f"conv3x3_{cin}_{cout}" + ("_s2" if stride == 2 else ""), 2.0 * 9 * n * cin * cout * Ho * Wo,
-                4.0 * n * (cin * H * W + cout * Ho * Wo)):
+                4.0 * n * (cin * H * W + cout * Ho * Wo), kernel_events=True):
         _capi.call("heal_conv3x3", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W, int(stride),
                    int(bool(relu)), _ptr(y), _stream())
     return y
