@@ -96,6 +96,8 @@ _SIGNATURES = {
     "heal_sp_root_rank_bytes": (c_size_t, [c_void_p, c_int]),
     "heal_sp_root_rank": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p, c_void_p]),
+    "heal_gconv_conv3_supported": (c_int, [c_int] * 5),
+    "heal_gconv_conv3": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p, c_void_p]),
     "heal_sp_transpose_neighbors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_weight_fragments": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "heal_sp_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

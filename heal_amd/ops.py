@@ -1327,6 +1327,31 @@ def grouped_conv3x3(x, weight, bias, groups, stride=1, relu=True):
     return y
 
 
+def gconv_conv3_supported(width, cg, cout, H, W):
+    return bool(_capi.query("heal_gconv_conv3_supported", int(width), int(cg), int(cout), int(H), int(W)))
+
+
+def gconv_conv3(x, w2, b2, groups, w3, b3, residual=None, relu=True):
+    """Back half of a ResNeXt bottleneck in one kernel: y = act(conv1x1(relu(gconv3x3(x, w2) + b2), w3) + b3 (+ residual)); the 2C-wide
+    intermediate never reaches HBM.  x [n, width, H, W], w2 [width, width / groups, 3, 3], w3 [cout, width, 1, 1]."""
+    x = _need(x, torch.float32, "x")
+    n, width, H, W = (int(v) for v in x.shape)
+    cg = width // groups
+    cout = int(w3.shape[0])
+    frag2 = grouped_small_fragments(_need(w2, torch.float32, "w2"), cg)
+    key = (w3.data_ptr(), w3._version, "gc3")
+    frag3 = _FRAG_CACHE.get(key)
+    if frag3 is None:
+        frag3 = _FRAG_CACHE[key] = mfma_a_fragments(w3.detach().reshape(cout, width))
+    y = torch.empty((n, cout, H, W), dtype=torch.float32, device=x.device)
+    flops = 2.0 * n * H * W * (9 * width * cg + width * cout)
+    nbytes = 4.0 * n * H * W * (width + cout * (2 if residual is not None else 1))
+    with _Timed(f"gconv_conv3_{width}_{cout}", flops, nbytes, kernel_events=True):
+        _capi.call("heal_gconv_conv3", _ptr(x), _ptr(frag2), _ptr(_need(b2, torch.float32, "b2")), _ptr(frag3),
+                   _ptr(_need(b3, torch.float32, "b3")), _optr(residual), n, width, cg, cout, H, W, int(bool(relu)), _ptr(y), _stream())
+    return y
+
+
 def bias_act_(x, bias=None, residual=None, relu=True):
     """In place: x = act(x + bias[c] + residual).  x [n,C,H,W] contiguous f32 cuda."""
     x = _need(x, torch.float32, "x")

@@ -411,6 +411,17 @@ int heal_grouped_conv3x3(const float* x, const float* weight, const float* bias,
 int heal_bias_act(float* x, const float* bias, const float* residual, int n, int channels, int HW, int relu,
                   void* stream);
 
+/* heal_gconv_conv3 (round 4): the BACK HALF of a ResNeXt bottleneck in one kernel -- the 32-group 3x3 convolution (conv2 + bn2 + relu)
+ *   and the pointwise convolution behind it (conv3 + bn3 + identity + relu; opencood/models/sub_modules/resblock.py:110-121, stride 1,
+ *   BatchNorms folded by the caller): y = act(W3 . relu(gconv3x3(x) + b2) + b3 (+ residual)).  The 2C-wide intermediate stays in LDS.
+ *   x [n, width, H, W]; weight_q: the grouped weights in the layout heal_grouped_small_conv3x3 takes; w3_frag: W3 [cout, width] in MFMA
+ *   A-fragment order (frag[mt][ks][lane] = W3[mt*16 + (lane & 15)][ks*4 + (lane >> 4)]); residual [n, cout, H, W] or NULL.
+ *   Supported (heal_gconv_conv3_supported): 4 | 8 channels per group, width % 16 == 0, cout 64 | 128, W % 4 == 0.                        */
+int heal_gconv_conv3_supported(int width, int group_channels, int cout, int H, int W);
+int heal_gconv_conv3(const float* x, const float* weight_q, const float* b2, const float* w3_frag, const float* b3,
+                     const float* residual, int n, int width, int group_channels, int cout, int H, int W, int relu, float* y,
+                     void* stream);
+
 /* heal_resnext_bottleneck: one fused kernel for a stride-1 ResNeXt bottleneck without downsample
  *   (opencood/models/sub_modules/resblock.py:100-122; 32 groups, width = 2*C, expansion 1):
  *   y = relu(conv3(relu(gconv2(relu(conv1(x)+b1))+b2))+b3+x), BatchNorms folded by the caller.

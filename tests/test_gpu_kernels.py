@@ -1422,6 +1422,32 @@ def test_root_rank_structure_device_counts_and_reuse(monkeypatch):
         np.testing.assert_array_equal(nbr[:n_live].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n,width,cout,H,W,res", [(2, 128, 64, 24, 40, True), (1, 256, 128, 17, 36, True), (3, 128, 64, 8, 32, False),
+                                                   (1, 256, 64, 9, 12, True)])
+def test_gconv_conv3_equals_two_kernel_path(n, width, cout, H, W, res):
+    """heal_gconv_conv3 (opt-in: the grouped 3x3 + pointwise conv + identity + ReLU of a ResNeXt bottleneck in one wave-specialised
+    kernel, the 2C-wide intermediate in LDS) against float64 and against the two-kernel path: 4 and 8 channels per group, maps that
+    are not multiples of the 8 x 32 tile, with and without the identity."""
+    from heal_amd import ops
+    rng = np.random.default_rng(width + H)
+    g = 32
+    x = dev(rng.standard_normal((n, width, H, W)).astype(np.float32))
+    w2 = dev((rng.standard_normal((width, width // g, 3, 3)) / np.sqrt(9 * width // g)).astype(np.float32))
+    b2 = dev(rng.standard_normal(width).astype(np.float32) * 0.1)
+    w3 = dev((rng.standard_normal((cout, width, 1, 1)) / np.sqrt(width)).astype(np.float32))
+    b3 = dev(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    r = dev(rng.standard_normal((n, cout, H, W)).astype(np.float32)) if res else None
+    assert ops.gconv_conv3_supported(width, width // g, cout, H, W)
+    got = ops.gconv_conv3(x, w2, b2, g, w3, b3, r, True)
+    split = ops.conv1x1(ops.grouped_conv3x3(x, w2, b2, g, 1, True), w3, b3, r, 1)
+    F_ = torch.nn.functional
+    ref = F_.conv2d(torch.relu(F_.conv2d(x.double(), w2.double(), b2.double(), 1, 1, 1, g)), w3.double(), b3.double())
+    ref = torch.relu(ref + r.double() if res else ref)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 2e-6 * scale
+    assert float((got - split).abs().max()) < 4e-6 * scale
+
+
 @pytest.mark.parametrize("n,cin,cout,H,W,ks,stride,res", [(2, 64, 128, 40, 56, 3, 2, True), (1, 96, 256, 33, 24, 3, 2, False),
                                                            (2, 32, 128, 18, 20, 3, 1, True), (1, 64, 128, 16, 24, 1, 1, False),
                                                            (1, 32, 128, 15, 16, 1, 2, True)])
