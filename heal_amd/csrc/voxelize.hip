@@ -87,13 +87,20 @@ __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ 
     if (!point_cell(pts[i], g, cx, cy, cz)) { slot_of[i] = -1; return; }
     const uint32_t cell = (uint32_t)vox_agent(vb, i) * cells +
                           (((uint32_t)cz * (uint32_t)g.grid[1] + (uint32_t)cy) * (uint32_t)g.grid[0] + (uint32_t)cx);
+    // Scattered device-scope atomics run at a fixed rate (~27 G operations/s chip-wide): every one that a plain read can rule out is
+    // time saved.  A plain read may be stale, but only in the harmless direction: a key seen as the cell's own is final (keys are
+    // written once), a key seen as EMPTY / a minimum seen too large just falls through to the atomic.
     uint32_t slot = hash_u32(cell) & mask;
     for (;;) {
-        const uint32_t prev = atomicCAS(&tkey[slot], HASH_EMPTY, cell);
-        if (prev == HASH_EMPTY || prev == cell) break;
+        const uint32_t seen = tkey[slot];
+        if (seen == cell) break;                       // claimed earlier by another point of this cell: no CAS
+        if (seen == HASH_EMPTY) {
+            const uint32_t prev = atomicCAS(&tkey[slot], HASH_EMPTY, cell);
+            if (prev == HASH_EMPTY || prev == cell) break;
+        }
         slot = (slot + 1) & mask;
     }
-    atomicMin(&tmin[slot], (uint32_t)i);
+    if (tmin[slot] > (uint32_t)i) atomicMin(&tmin[slot], (uint32_t)i);   // (a stale value is >= the true one: skipping is safe)
     tick[i] = atomicAdd(&tcnt[slot], 1u) + 1u;     // the counter starts at 0xFFFFFFFF: tickets 0, 1, ...; final value = points - 1
     slot_of[i] = (int)slot;
 }
