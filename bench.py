@@ -292,9 +292,9 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         if in_graph and "voxelize" in in_graph:      # the launch chain as the timed region runs it (captured graph), not host-paced
             extra = {"eager_event_pair_ms": round(mean_ms, 5), "duration": "per-call period of the launch chain inside a captured graph"}
             mean_ms = in_graph["voxelize"]
-        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: one memset + five kernels)", "hbm",
+        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: one memset + four kernels)", "hbm",
                                                  bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
-                                                 pmc_traffic(a.workload, "heal::k_voxb_insert", "heal::k_vox_tile_sums", "heal::k_vox_assign",
+                                                 pmc_traffic(a.workload, "heal::k_voxb_insert", "heal::k_vox_assign",
                                                              "heal::k_vox_fill", "heal::k_vox_select_write"),   # (+ one memset: not a kernel)
                                                  bytes_per_launch=bts, **extra))
     if "decode_nms" in timing:

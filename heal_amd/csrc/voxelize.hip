@@ -7,15 +7,15 @@
 // first appearance, none beyond max_voxels); a point is appended to its voxel while the voxel holds
 // fewer than max_points.
 //
-// GPU formulation (order-independent, so bit-identical to the sequential scan), ONE memset + FIVE kernels for any number of
-// agents (round 3; rounds 1-2 sorted (voxel id, point index) pairs with a 3-pass radix sort: 24 launches, launch-bound):
-//   0. one memset(0xFF): hash keys | per-cell minimum point index | per-cell point counter
-//   1. k_voxb_insert: hash-grid insert, cell -> min point index, ticket   (atomicCAS claim + atomicMin + atomicAdd)
-//   2. k_vox_tile_sums: "i is the first point of its cell" flags, counted per 1024-point tile (+ the partial counts at the
-//      agent boundaries that fall inside a tile)
-//   3. k_vox_assign: every tile re-derives the prefix of all tile counts (a block-local scan of <= 4096 values: no
-//      look-back, no spin), ranks its first points -> voxel id in first-appearance order per agent, row in the collated
-//      output, coordinates; both caps applied
+// GPU formulation (order-independent, so bit-identical to the sequential scan), ONE memset + FOUR kernels for any number of
+// agents (round 4; round 3: five; rounds 1-2 sorted (voxel id, point index) pairs with a 3-pass radix sort: 24 launches):
+//   0. one memset(0xFF): hash keys | per-cell minimum point index | per-cell point counter | the tiles' publication words
+//   1. k_voxb_insert: hash-grid insert, cell -> min point index, ticket   (atomicCAS claim + atomicMin + atomicAdd, each behind a
+//      plain read that rules most of the first two out)
+//   2 + 3. k_vox_assign: per 1024-point tile the "i is the first point of its cell" flags are counted and PUBLISHED (one 64-bit word
+//      per tile), the tile looks back over the published words of the tiles below it (chained scan: tiles publish before they wait
+//      and are dispatched in order), ranks its first points -> voxel id in first-appearance order per agent, row in the collated
+//      output, coordinates; both caps applied;
 //      and a segment [seg, seg + points of the cell) of one index list (prefix sums of the cells' point counts: deterministic)
 //   4. k_vox_fill: every point drops its index at seg + ticket (the ticket it drew from its cell's counter in step 1: an
 //      arbitrary but collision-free position)
@@ -128,83 +128,31 @@ __device__ __forceinline__ int block_sum_256(int v, int* s_red) {   // all threa
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
-// 2. per-tile counts of first points and of the points of their cells; partial[a] = first points of the tile holding pt_off[a]
-//    that precede pt_off[a]
-__global__ __launch_bounds__(256) void k_vox_tile_sums(const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin,
-                                                      const uint32_t* __restrict__ tcnt, VoxBatch vb, int* __restrict__ tile_sums,
-                                                      int* __restrict__ tile_cnt, int* __restrict__ partial) {
-    __shared__ int s_red[4];
-    const int n = vb.pt_off[vb.B], tile = blockIdx.x;
-    const unsigned f = tile_flags(slot_of, tmin, tile, n);
-    int pc = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if ((f >> j) & 1u) pc += (int)(tcnt[slot_of[tile * VOX_TILE + j * 256 + (int)threadIdx.x]] + 1u);
-    const int tot = block_sum_256(__popc(f), s_red);
-    const int totc = block_sum_256(pc, s_red);
-    if (threadIdx.x == 0) { tile_sums[tile] = tot; tile_cnt[tile] = totc; }
-    for (int a = 0; a < vb.B; ++a) {      // block-uniform: a boundary inside this tile is rare
-        const int bnd = vb.pt_off[a];
-        if (bnd < tile * VOX_TILE || bnd >= (tile + 1) * VOX_TILE || bnd >= n) continue;
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (((f >> j) & 1u) && tile * VOX_TILE + j * 256 + (int)threadIdx.x < bnd) ++c;
-        c = block_sum_256(c, s_red);
-        if (threadIdx.x == 0) partial[a] = c;
-    }
+// 2 + 3. ranks -> rows and segments, ONE launch (round 4; rounds 1-3: a tile-sums launch, then every block re-scanned all tile sums).
+// Every 1024-point tile counts its first points and the points of their cells, PUBLISHES the pair as one 64-bit word
+// (tile_pub[tile] = first points << 32 | cell points; the array is part of the 0xFF memset, bit 63 set = not yet published) and then
+// looks back: thread t waits for tiles t, t + 256, ... below its own and adds them up -- tiles are dispatched in index order and
+// publish before they wait, so the chain always makes progress.  A tile that holds the first point of agent b also publishes the
+// first points in front of that boundary (part_pub[b]).  meta[0] = rows written (M), meta[1] = base row (0 without row_offset):
+// written by the LAST tile, which has seen every other.
+__device__ __forceinline__ unsigned long long vox_wait_pub(const unsigned long long* p) {
+    unsigned long long v;
+    do { v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (v >> 63);
+    return v;
 }
 
-// block-local exclusive scan of v[0..n) (n <= VOX_MAX_TILES) into s_out[0..n], s_out[n] = total; thread t owns a run of k values
-__device__ __forceinline__ void block_scan_tiles(const int* __restrict__ v, int n, int* s_out, int* s_red) {
-    const int t = threadIdx.x, k = (n + 255) / 256;
-    int run = 0;
-    for (int q = t * k; q < min((t + 1) * k, n); ++q) run += v[q];
-    const int incl = wave_incl_scan(run);
-    __syncthreads();
-    if ((t & 63) == 63) s_red[t >> 6] = incl;
-    __syncthreads();
-    int off = incl - run;
-    for (int w = 0; w < (t >> 6); ++w) off += s_red[w];
-    for (int q = t * k; q < min((t + 1) * k, n); ++q) { s_out[q] = off; off += v[q]; }
-    if (t == 255) s_out[n] = off;    // (runs beyond n are empty: thread 255 holds the total)
-    __syncthreads();
-}
-
-// 3. ranks -> rows and segments.  meta[0] = rows written (M), meta[1] = base row (0 without row_offset)
 __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
                                                    const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin,
-                                                   const uint32_t* __restrict__ tcnt, const int* __restrict__ tile_sums,
-                                                   const int* __restrict__ tile_cnt, const int* __restrict__ partial,
+                                                   const uint32_t* __restrict__ tcnt, unsigned long long* __restrict__ tile_pub,
+                                                   unsigned long long* __restrict__ part_pub,
                                                    int n_tiles, int max_voxels, const int* __restrict__ row_offset,
                                                    uint32_t* __restrict__ tvid, int* __restrict__ tseg, int* __restrict__ row_seg,
                                                    int* __restrict__ row_cnt, int* __restrict__ coords,
                                                    int* __restrict__ offsets_out, int* __restrict__ n_voxels_out,
                                                    int* __restrict__ row_offset_next, int* __restrict__ meta) {
-    __shared__ int s_pre[VOX_MAX_TILES + 1];   // exclusive prefix of the tiles' first-point counts; [n_tiles] = total
-    __shared__ int s_prc[VOX_MAX_TILES + 1];   // ... of the tiles' cell-point counts (segment starts)
-    __shared__ int s_red[4], s_w[4][4], s_wc[4][4], s_vbase[VOX_MAX_BATCH + 1], s_obase[VOX_MAX_BATCH + 1];
+    __shared__ int s_red[4], s_w[4][4], s_wc[4][4], s_vbase[VOX_MAX_BATCH + 1], s_obase[VOX_MAX_BATCH + 1], s_run[2];
+    __shared__ int s_part[VOX_MAX_BATCH + 1], s_vsum[VOX_MAX_BATCH + 1];
     const int n = vb.pt_off[vb.B], tile = blockIdx.x, t = threadIdx.x;
-    block_scan_tiles(tile_sums, n_tiles, s_pre, s_red);
-    block_scan_tiles(tile_cnt, n_tiles, s_prc, s_red);
-    if (t == 0) {
-        const int total = s_pre[n_tiles];
-        int acc = 0;
-        for (int b = 0; b <= vb.B; ++b) {
-            const int bnd = vb.pt_off[b];
-            const int v = (b == vb.B || bnd >= n) ? total : s_pre[bnd / VOX_TILE] + partial[b];
-            s_vbase[b] = v;
-            if (b > 0) acc += min(v - s_vbase[b - 1], min(max_voxels, vb.pt_off[b] - vb.pt_off[b - 1]));
-            s_obase[b] = acc;
-        }
-        if (tile == 0) {
-            const int base = row_offset ? *row_offset : 0;
-            meta[0] = acc; meta[1] = base;
-            if (offsets_out) for (int b = 0; b <= vb.B; ++b) offsets_out[b] = s_obase[b];
-            if (n_voxels_out) *n_voxels_out = acc;
-            if (row_offset_next) *row_offset_next = base + acc;
-        }
-    }
     const unsigned f = tile_flags(slot_of, tmin, tile, n);
     const int wave = t >> 6;
     const unsigned long long lt = lanemask_lt();
@@ -221,8 +169,80 @@ __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ p
         if ((t & 63) == 63) s_wc[j][wave] = incl;
     }
     __syncthreads();
+    // ---- publish this tile's sums (before any waiting) ---------------------------------------------------------------------------------
+    if (t == 0) {
+        int tot = 0, totc = 0;
+        for (int j = 0; j < 4; ++j)
+            for (int w = 0; w < 4; ++w) { tot += s_w[j][w]; totc += s_wc[j][w]; }
+        s_run[0] = tot; s_run[1] = totc;
+        __hip_atomic_store(&tile_pub[tile], ((unsigned long long)(unsigned)tot << 32) | (unsigned)totc, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int last_i = min((tile + 1) * VOX_TILE, n) - 1;
+    const bool last_tile = tile == n_tiles - 1;
+    const int a_max = last_tile ? vb.B : vox_agent(vb, last_i);      // agents whose bases this tile needs (the last tile: all, for the totals)
+    for (int b = 1; b <= min(a_max, vb.B - 1); ++b) {                 // block-uniform: a boundary inside this tile is rare
+        const int bnd = vb.pt_off[b];
+        if (bnd < tile * VOX_TILE || bnd >= (tile + 1) * VOX_TILE || bnd >= n) continue;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((f >> j) & 1u) && tile * VOX_TILE + j * 256 + t < bnd) ++c;
+        c = block_sum_256(c, s_red);
+        if (t == 0) {
+            s_part[b] = c;
+            __hip_atomic_store(&part_pub[b], (unsigned long long)(unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- look back: sums of the tiles below this one; per agent boundary the sums of the tiles below the boundary's tile ----------------
+    int P = 0, C = 0;
+    int vs[VOX_MAX_BATCH];
+#pragma unroll
+    for (int b = 0; b < VOX_MAX_BATCH; ++b) vs[b] = 0;
+    for (int q = t; q < tile; q += 256) {
+        const unsigned long long v = vox_wait_pub(&tile_pub[q]);
+        const int fp = (int)(v >> 32), cp = (int)(unsigned)v;
+        P += fp; C += cp;
+#pragma unroll
+        for (int b = 1; b < VOX_MAX_BATCH; ++b)
+            if (b <= a_max && b < vb.B && q < vb.pt_off[b] / VOX_TILE) vs[b] += fp;
+    }
+    P = block_sum_256(P, s_red);
+    C = block_sum_256(C, s_red);
+#pragma unroll
+    for (int b = 1; b < VOX_MAX_BATCH; ++b) {
+        if (b > a_max || b >= vb.B) break;                            // block-uniform
+        const int v = block_sum_256(vs[b], s_red);
+        if (t == 0) s_vsum[b] = v;
+    }
+    if (t == 0) {
+        const int total = P + s_run[0];                               // meaningful in the last tile only
+        int acc = 0;
+        for (int b = 0; b <= a_max; ++b) {
+            const int bnd = vb.pt_off[b];
+            int v;
+            if (b == 0) v = 0;
+            else if (b == vb.B || bnd >= n) v = total;                // (reached by the last tile only)
+            else {
+                const int bt = bnd / VOX_TILE;
+                const int part = bt == tile ? s_part[b] : (int)(unsigned)vox_wait_pub(&part_pub[b]);
+                v = s_vsum[b] + part;
+            }
+            s_vbase[b] = v;
+            if (b > 0) acc += min(v - s_vbase[b - 1], min(max_voxels, vb.pt_off[b] - vb.pt_off[b - 1]));
+            s_obase[b] = acc;
+        }
+        if (last_tile) {
+            const int base = row_offset ? *row_offset : 0;
+            meta[0] = acc; meta[1] = base;
+            if (offsets_out) for (int b = 0; b <= vb.B; ++b) offsets_out[b] = s_obase[b];
+            if (n_voxels_out) *n_voxels_out = acc;
+            if (row_offset_next) *row_offset_next = base + acc;
+        }
+    }
+    __syncthreads();
     const int base = row_offset ? *row_offset : 0;
-    int run = s_pre[tile], runc = s_prc[tile];
+    int run = P, runc = C;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int r = run + before[j], sg = runc + cbefore[j];
@@ -357,7 +377,8 @@ __global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pt
 
 struct VoxWs {
     uint32_t *tkey, *tmin, *tcnt, *cand, *tvid, *tick, *seg;
-    int *slot_of, *tseg, *row_seg, *row_cnt, *tile_sums, *tile_cnt, *partial, *meta;
+    int *slot_of, *tseg, *row_seg, *row_cnt, *meta;
+    unsigned long long *tile_pub, *part_pub;   // published tile sums / agent-boundary partial counts (inside the 0xFF region: unpublished)
     uint32_t tcap;
     size_t ff_bytes;     // tkey | tmin | tcnt (| cand): initialised by one memset(0xFF)
 };
@@ -374,6 +395,8 @@ static bool carve(Arena& a, int n, int cap, int P, VoxWs& w) {
     w.tmin = a.take<uint32_t>(w.tcap);
     w.tcnt = a.take<uint32_t>(w.tcap);
     w.cand = a.take<uint32_t>(P > 64 ? (size_t)cap * P : 1);
+    w.tile_pub = a.take<unsigned long long>(ceil_div(n, VOX_TILE) + 1);
+    w.part_pub = a.take<unsigned long long>(VOX_MAX_BATCH + 1);
     w.tvid = a.take<uint32_t>(w.tcap);
     w.ff_bytes = (size_t)((char*)w.tvid - (char*)w.tkey);
     w.tseg = a.take<int>(w.tcap);
@@ -382,9 +405,6 @@ static bool carve(Arena& a, int n, int cap, int P, VoxWs& w) {
     w.seg = a.take<uint32_t>(n);
     w.row_seg = a.take<int>(cap);
     w.row_cnt = a.take<int>(cap);
-    w.tile_sums = a.take<int>(ceil_div(n, VOX_TILE) + 1);
-    w.tile_cnt = a.take<int>(ceil_div(n, VOX_TILE) + 1);
-    w.partial = a.take<int>(VOX_MAX_BATCH + 1);
     w.meta = a.take<int>(64);
     return a.ok();
 }
@@ -404,8 +424,7 @@ static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& 
     const int nb = ceil_div(n, 256);
     HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, w.ff_bytes, s));
     k_voxb_insert<<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
-    k_vox_tile_sums<<<n_tiles, 256, 0, s>>>(w.slot_of, w.tmin, w.tcnt, vb, w.tile_sums, w.tile_cnt, w.partial);
-    k_vox_assign<<<n_tiles, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.tcnt, w.tile_sums, w.tile_cnt, w.partial, n_tiles,
+    k_vox_assign<<<n_tiles, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.tcnt, w.tile_pub, w.part_pub, n_tiles,
                                          max_voxels, row_offset, w.tvid, w.tseg, w.row_seg, w.row_cnt, coords, offsets_out,
                                          n_voxels_out, row_offset_next, w.meta);
     float4* vox4 = reinterpret_cast<float4*>(voxels);

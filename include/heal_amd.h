@@ -57,7 +57,7 @@ int heal_voxelize(const float* points, int n_points,
                   const int32_t* row_offset, int32_t* row_offset_next,
                   void* ws, size_t ws_bytes, void* stream);
 
-/* heal_voxelize_batch: K1 for every agent of a modality in ONE launch chain (one memset + five kernels, as the single-cloud
+/* heal_voxelize_batch: K1 for every agent of a modality in ONE launch chain (one memset + four kernels, as the single-cloud
  *   form; at most 4 M points per call): `points` holds the agents' clouds back to back, point_offsets_host [n_agents+1] (host)
  *   the boundaries.  Outputs are the collated buffers of collate_batch_list: rows of agent b at
  *   [row_offsets[b], row_offsets[b+1]) with coords (b,z,y,x); row_offsets [n_agents+1] i32 DEVICE.  Buffers need
