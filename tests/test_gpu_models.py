@@ -305,6 +305,38 @@ def test_config4_full_size_matches_oracle_model():
     assert all(v < 1e-3 for v in errs.values()), errs
 
 
+@pytest.mark.parametrize("n_agents", [1, 2])
+def test_config2_3_full_size_match_oracle_model(n_agents):
+    """BASELINE configs 2 (single agent) and 3 (two agents) AT FULL SIZE (+-102.4 m, 512 x 512 pillar grid, PointPillars + PyramidFusion;
+    the scenes bench.py times as `single` / `pair`): the GPU model's cls / reg / dir maps against the oracle's CPU restatement
+    (oracle/model_ref.heter_pyramid_collab_m1, pinned to the REFERENCE at +-25.6 m by tests/test_oracle_golden.py) on the same
+    synthetic frame and weights -- north_star: within 1e-3 relative."""
+    from heal_amd import configs
+    from heal_amd.pipeline import Scene, ScenePipeline
+    from oracle import cref, model_ref
+    mods = ["m1"] * n_agents
+    hypes = configs.lidar_pyramid(max_cav=5)
+    pipe = ScenePipeline(hypes, "cuda:0", seed=0)
+    scene = Scene(n_agents, seed=4, device="cuda:0", modalities=mods)
+    with torch.no_grad():
+        out = pipe.forward(scene)
+    host = Scene(n_agents, seed=4, device="cpu", modalities=mods)
+    args = hypes["model"]["args"]
+    r = args["lidar_range"]
+    vs, cs, ns = [], [], []
+    for b, k in enumerate(sorted(host.points)):
+        v, c, n = cref.voxelize(host.points[k].numpy(), r, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = model_ref.heter_pyramid_collab_m1(pipe.model.state_dict(), args, np.concatenate(vs), np.concatenate(cs), np.concatenate(ns),
+                                            n_agents, np.asarray(host.pairwise))
+    from tests.report import note
+    errs = {key: rel_err(out[key].cpu().numpy(), ref[key]) for key in ("cls_preds", "reg_preds", "dir_preds")}
+    assert out["cls_preds"].shape == (1, 2, 256, 256)
+    note(f"config{1 + n_agents}_full_size_vs_oracle_model", **{k: float(v) for k, v in errs.items()})
+    assert all(v < 1e-3 for v in errs.values()), errs
+
+
 def test_concurrent_modality_streams_equal_serial(monkeypatch):
     """The per-modality stems run on concurrent HIP streams (_heter_common.encode_modalities): the result must equal the
     serial order's -- eagerly and through the captured graph (where the fork / join are parallel branches), on several frames
