@@ -31,9 +31,11 @@ __global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
     int m, float scale, float* __restrict__ out /*[L,H,W,m*D]*/) {
     constexpr int T = WS * WS, KC = D / 4, NCB = T / 16, NB = D / 16, NW = wattn_waves<WS>();
     constexpr bool BIG = T == 256;                      // V in LDS, P through shuffles
+    constexpr bool VL = T >= 64;                        // V staged in LDS next to K (round 4: also the 8 x 8 window -- its P V loop read V
+                                                        // from global memory inside the MFMA loop, four exposed L2 round trips per wave)
     constexpr int KSTR = D + 4, PSTR = T + 4, VSTR = D + 16;  // VSTR % 64 == 16: k-rows of a B fragment in disjoint banks
     __shared__ __attribute__((aligned(16))) float sK[T * KSTR];
-    __shared__ __attribute__((aligned(16))) float sV[BIG ? T * VSTR : 4];
+    __shared__ __attribute__((aligned(16))) float sV[VL ? T * VSTR : 4];
     __shared__ float sP[BIG ? 1 : NW][BIG ? 4 : 16 * PSTR];
     const int nww = W / WS;
     const int ih = blockIdx.x / nww, iw = blockIdx.x - ih * nww, h = blockIdx.y, l = blockIdx.z;
@@ -45,12 +47,20 @@ __global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
         const int y = ih * WS + t / WS, x = iw * WS + t % WS;
         return ((size_t)y * W + x) * C3;
     };
+    // the first slab's Q rows are requested together with K / V (one exposed round trip instead of two)
+    const int wave0 = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    float a_first[KC];
+    {
+        const float* qp = base + tok(min(wave0, T / 16 - 1) * 16 + (lane0 & 15));
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) a_first[kc] = qp[kc * 4 + (lane0 >> 4)];
+    }
     // stage K (chunk 1 of the packed projection)
     for (int e = threadIdx.x; e < T * (D / 4); e += 64 * NW) {
         const int t = e / (D / 4), c4 = e - t * (D / 4);
         const float4 v = *reinterpret_cast<const float4*>(base + tok(t) + MD + c4 * 4);
         *reinterpret_cast<float4*>(&sK[t * KSTR + c4 * 4]) = v;
-        if constexpr (BIG)
+        if constexpr (VL)
             *reinterpret_cast<float4*>(&sV[t * VSTR + c4 * 4]) =
                 *reinterpret_cast<const float4*>(base + tok(t) + 2 * MD + c4 * 4);
     }
@@ -61,7 +71,10 @@ __global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
     for (int slab = wave; slab < T / 16; slab += NW) {
         // ---- S = Q K^T ------------------------------------------------------------------------------------------
         float a[KC];
-        {
+        if (slab == wave) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) a[kc] = a_first[kc];
+        } else {
             const float* qp = base + tok(slab * 16 + ln);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) a[kc] = qp[kc * 4 + lk];
@@ -120,10 +133,16 @@ __global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
 #pragma unroll 4
             for (int kc = 0; kc < T / 4; ++kc) {
                 const float p = sp[ln * PSTR + kc * 4 + lk];
-                const float* vp = base + tok(kc * 4 + lk) + 2 * MD;
+                if constexpr (VL) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vp[nb * 16 + ln], o[nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb)
+                        o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, sV[(kc * 4 + lk) * VSTR + nb * 16 + ln], o[nb], 0, 0, 0);
+                } else {
+                    const float* vp = base + tok(kc * 4 + lk) + 2 * MD;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vp[nb * 16 + ln], o[nb], 0, 0, 0);
+                }
             }
         } else {
             // ---- O = P V: P moves D layout -> A layout by shuffles.  A-lane (m = ln, k = lk) of k-step kc needs
