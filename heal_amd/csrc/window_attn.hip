@@ -5,13 +5,17 @@
 // re-layout of q/k/v, the [B,T,T] score tensor (0.5 GB at ws = 16), its softmax and the re-layout of the result:
 // ~2.5 GB of HBM traffic per attention against 0.54 GB compulsory.
 //
-// One block per (window, head, agent), up to 4 waves; a wave owns 16-query-row slabs.
-//   S = Q K^T on v_mfma_f32_16x16x4_f32: A = Q rows straight from global (16-B runs per token), B = K^T from an LDS copy
-//       of the window's K (row stride d+4: conflict-free fragment reads); the slab's whole score row block (16 x T) stays
-//       in registers (T/16 accumulator tiles);
-//   softmax in registers: rows live on 16-lane groups -> xor-shuffles inside the group, exp, normalise;
-//   P goes through the wave's LDS slice (MFMA D layout -> A layout), O = P V with V read from global in B-fragment order
-//       (64-B runs, L2-resident), result written as 64-B runs per token.
+// One block per (window, head, agent), up to 4 waves (8 for the 256-token window); a wave owns 16-query slabs.  Round 4: the
+// TRANSPOSED formulation -- no operand ever changes layout between the two GEMMs:
+//   S^T = K Q^T on v_mfma_f32_16x16x4_f32: A = K rows from an LDS copy of the window's K, B = Q rows straight from global; both
+//       operands use the SAME permutation of the reduction index (lane group lk takes d = lk * D/4 + step), so a lane's operand
+//       values of four consecutive steps are 16 contiguous bytes: ds_read_b128 / 16-B global loads instead of one b32 per MFMA;
+//   D layout of S^T: lane (lk, ln) holds keys cb * 16 + lk * 4 + {0..3} of QUERY ln -- a query's scores sit in ONE lane column:
+//       scale, relative-position bias (16-B loads), softmax with two xor-shuffles (across lk) per reduction;
+//   O^T = V^T P^T: reduction step (cb, r) takes key cb * 16 + lk * 4 + r from lane group lk -- exactly register r of score tile cb:
+//       the probabilities ARE the B operand (rounds 2-3 moved P through an LDS slice or 256 ds_bpermute per slab); A = V from LDS
+//       (row stride D + 4: the four lane groups, four rows apart, fall in disjoint bank groups);
+//   D layout of O^T: lane (lk, ln) holds channels nb * 16 + lk * 4 + {0..3} of query ln: one 16-B store per tile.
 #include "common.h"
 #include "../../include/heal_amd.h"
 
@@ -19,9 +23,8 @@ namespace heal {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// waves per block: one per 16-row slab up to 4; the 256-token window runs 8 waves that share K AND V in LDS (150 KB, one
-// block per CU, two waves per SIMD) and moves P from the MFMA D layout to the A layout with lane shuffles instead of an
-// LDS slice -- no global load is left inside its MFMA loops.
+// waves per block: one per 16-query slab up to 4; the 256-token window runs 8 waves (K and V of the window in LDS: 139 KB, one
+// block per CU, two waves per SIMD)
 template <int WS>
 constexpr int wattn_waves() { return WS * WS == 256 ? 8 : ((WS * WS / 16) < 4 ? (WS * WS / 16) : 4); }
 
@@ -29,14 +32,11 @@ template <int WS, int D>
 __global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
     const float* __restrict__ qkv /*[L,H,W,3,m,D]*/, const float* __restrict__ bias /*[T,T] or null*/, int H, int W,
     int m, float scale, float* __restrict__ out /*[L,H,W,m*D]*/) {
-    constexpr int T = WS * WS, KC = D / 4, NCB = T / 16, NB = D / 16, NW = wattn_waves<WS>();
-    constexpr bool BIG = T == 256;                      // V in LDS, P through shuffles
-    constexpr bool VL = T >= 64;                        // V staged in LDS next to K (round 4: also the 8 x 8 window -- its P V loop read V
-                                                        // from global memory inside the MFMA loop, four exposed L2 round trips per wave)
-    constexpr int KSTR = D + 4, PSTR = T + 4, VSTR = D + 16;  // VSTR % 64 == 16: k-rows of a B fragment in disjoint banks
+    constexpr int T = WS * WS, NCB = T / 16, NB = D / 16, NW = wattn_waves<WS>();
+    constexpr int DQ = D / 4;                            // reduction indices per lane group (d = lk * DQ + step)
+    constexpr int KSTR = D + 4, VSTR = D + 4;            // row strides (words): 16-B aligned; 4 VSTR = 16 (mod 64)
     __shared__ __attribute__((aligned(16))) float sK[T * KSTR];
-    __shared__ __attribute__((aligned(16))) float sV[VL ? T * VSTR : 4];
-    __shared__ float sP[BIG ? 1 : NW][BIG ? 4 : 16 * PSTR];
+    __shared__ __attribute__((aligned(16))) float sV[T * VSTR];
     const int nww = W / WS;
     const int ih = blockIdx.x / nww, iw = blockIdx.x - ih * nww, h = blockIdx.y, l = blockIdx.z;
     const int MD = m * D;
@@ -47,132 +47,93 @@ __global__ __launch_bounds__(64 * wattn_waves<WS>()) void k_window_attn(
         const int y = ih * WS + t / WS, x = iw * WS + t % WS;
         return ((size_t)y * W + x) * C3;
     };
-    // the first slab's Q rows are requested together with K / V (one exposed round trip instead of two)
-    const int wave0 = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
-    float a_first[KC];
-    {
-        const float* qp = base + tok(min(wave0, T / 16 - 1) * 16 + (lane0 & 15));
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) a_first[kc] = qp[kc * 4 + (lane0 >> 4)];
-    }
-    // stage K (chunk 1 of the packed projection)
-    for (int e = threadIdx.x; e < T * (D / 4); e += 64 * NW) {
-        const int t = e / (D / 4), c4 = e - t * (D / 4);
-        const float4 v = *reinterpret_cast<const float4*>(base + tok(t) + MD + c4 * 4);
-        *reinterpret_cast<float4*>(&sK[t * KSTR + c4 * 4]) = v;
-        if constexpr (VL)
-            *reinterpret_cast<float4*>(&sV[t * VSTR + c4 * 4]) =
-                *reinterpret_cast<const float4*>(base + tok(t) + 2 * MD + c4 * 4);
-    }
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lk = lane >> 4, ln = lane & 15;
-    float* sp = sP[BIG ? 0 : wave];
+    // Q rows of the first slab: requested together with K / V (one exposed round trip); lane (lk, ln): query ln, d = lk * DQ ..
+    float4 qf[DQ / 4];
+    {
+        const float* qp = base + tok(min(wave, T / 16 - 1) * 16 + ln) + lk * DQ;
+#pragma unroll
+        for (int i = 0; i < DQ / 4; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + 4 * i);
+    }
+    // stage K and V (chunks 1 and 2 of the packed projection)
+    for (int e = threadIdx.x; e < T * (D / 4); e += 64 * NW) {
+        const int t = e / (D / 4), c4 = e - t * (D / 4);
+        const float4 kv = *reinterpret_cast<const float4*>(base + tok(t) + MD + c4 * 4);
+        const float4 vv = *reinterpret_cast<const float4*>(base + tok(t) + 2 * MD + c4 * 4);
+        *reinterpret_cast<float4*>(&sK[t * KSTR + c4 * 4]) = kv;
+        *reinterpret_cast<float4*>(&sV[t * VSTR + c4 * 4]) = vv;
+    }
+    __syncthreads();
     for (int slab = wave; slab < T / 16; slab += NW) {
-        // ---- S = Q K^T ------------------------------------------------------------------------------------------
-        float a[KC];
-        if (slab == wave) {
+        if (slab != wave) {
+            const float* qp = base + tok(slab * 16 + ln) + lk * DQ;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) a[kc] = a_first[kc];
-        } else {
-            const float* qp = base + tok(slab * 16 + ln);
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) a[kc] = qp[kc * 4 + lk];
+            for (int i = 0; i < DQ / 4; ++i) qf[i] = *reinterpret_cast<const float4*>(qp + 4 * i);
         }
+        // ---- S^T = K Q^T: tile cb = keys cb * 16 .. + 15 (rows) x the slab's 16 queries (columns) -----------------------------
         f32x4 s[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             s[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* kp = &sK[(cb * 16 + ln) * KSTR + lk * DQ];
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-                s[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc], sK[(cb * 16 + ln) * KSTR + kc * 4 + lk], s[cb], 0, 0, 0);
-        }
-        // ---- scale, bias, softmax over the T keys of each row (D layout: row = lk*4 + r, col = cb*16 + ln) ----------
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[cb][r] * scale;
-                if (bias) v += bias[(size_t)(slab * 16 + lk * 4 + r) * T + cb * 16 + ln];
-                s[cb][r] = v;
-                mx[r] = fmaxf(mx[r], v);
+            for (int i = 0; i < DQ / 4; ++i) {
+                const float4 kf = *reinterpret_cast<const float4*>(kp + 4 * i);
+                s[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[i].x, s[cb], 0, 0, 0);
+                s[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[i].y, s[cb], 0, 0, 0);
+                s[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[i].z, s[cb], 0, 0, 0);
+                s[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[i].w, s[cb], 0, 0, 0);
             }
-        float sum[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
-            sum[r] = 0.f;
+            if constexpr (NCB >= 16) __builtin_amdgcn_sched_barrier(0);   // (the scheduler hoists every tile's K reads and spills)
         }
+        // ---- scale, bias, softmax over the T keys of query ln: this lane's 4 NCB values + the other three lane groups ------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + (size_t)(slab * 16 + ln) * T + cb * 16 + lk * 4);
+            s[cb][0] = s[cb][0] * scale + bv.x; s[cb][1] = s[cb][1] * scale + bv.y;
+            s[cb][2] = s[cb][2] * scale + bv.z; s[cb][3] = s[cb][3] * scale + bv.w;
+            mx = fmaxf(fmaxf(mx, fmaxf(s[cb][0], s[cb][1])), fmaxf(s[cb][2], s[cb][3]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(s[cb][r] - mx[r]);
+                const float e = expf(s[cb][r] - mx);
                 s[cb][r] = e;
-                sum[r] += e;
+                sum += e;
             }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o, 64);
-            sum[r] = 1.f / sum[r];
-        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        // ---- O^T = V^T P^T: reduction step (cb, r) = key cb * 16 + lk * 4 + r; B = the (unnormalised) probabilities as they lie ------
         f32x4 o[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) o[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (!BIG) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sp[(lk * 4 + r) * PSTR + cb * 16 + ln] = s[cb][r] * sum[r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- O = P V: A = P from the wave's LDS slice, B = V from global (64-B runs, L2-resident) --------------
-#pragma unroll 4
-            for (int kc = 0; kc < T / 4; ++kc) {
-                const float p = sp[ln * PSTR + kc * 4 + lk];
-                if constexpr (VL) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, sV[(kc * 4 + lk) * VSTR + nb * 16 + ln], o[nb], 0, 0, 0);
-                } else {
-                    const float* vp = base + tok(kc * 4 + lk) + 2 * MD;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vp[nb * 16 + ln], o[nb], 0, 0, 0);
-                }
-            }
-        } else {
-            // ---- O = P V: P moves D layout -> A layout by shuffles.  A-lane (m = ln, k = lk) of k-step kc needs
-            // P[row ln][col 4kc + lk], which sits in lane ((ln >> 2) << 4 | (4 (kc & 3) + lk)), register s[kc >> 2][ln & 3].
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[cb][r] *= sum[r];
-            const int rsel = ln & 3;
-#pragma unroll
-            for (int kc = 0; kc < T / 4; ++kc) {
-                const int srcl = ((ln >> 2) << 4) | (4 * (kc & 3) + lk);
-                const float p0 = __shfl(s[kc >> 2][0], srcl, 64), p1 = __shfl(s[kc >> 2][1], srcl, 64);
-                const float p2 = __shfl(s[kc >> 2][2], srcl, 64), p3 = __shfl(s[kc >> 2][3], srcl, 64);
-                const float p = rsel == 0 ? p0 : rsel == 1 ? p1 : rsel == 2 ? p2 : p3;
+            for (int r = 0; r < 4; ++r) {
+                const float* vp = &sV[(cb * 16 + lk * 4 + r) * VSTR + ln];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, sV[(kc * 4 + lk) * VSTR + nb * 16 + ln], o[nb], 0, 0, 0);
+                    o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[nb * 16], s[cb][r], o[nb], 0, 0, 0);
+                if constexpr (NCB >= 16) { if (r == 3) __builtin_amdgcn_sched_barrier(0); }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = slab * 16 + lk * 4 + r;
+        // ---- D layout of O^T: channels nb * 16 + lk * 4 + {0..3} of query ln -> one 16-B store per tile ------------------------------
+        {
+            const int t = slab * 16 + ln;
             const int y = ih * WS + t / WS, x = iw * WS + t % WS;
-            float* op = out + (((size_t)l * H + y) * W + x) * MD + (size_t)h * D;
+            float* op = out + (((size_t)l * H + y) * W + x) * MD + (size_t)h * D + lk * 4;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) op[nb * 16 + ln] = o[nb][r];
+            for (int nb = 0; nb < NB; ++nb)
+                *reinterpret_cast<float4*>(op + nb * 16) = make_float4(o[nb][0] * inv, o[nb][1] * inv, o[nb][2] * inv, o[nb][3] * inv);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // before the next slab overwrites the P slice
     }
 }
 
