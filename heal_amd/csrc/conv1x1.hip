@@ -10,8 +10,8 @@
 //   * B (activations): 32-channel x 128-pixel chunks staged through LDS with 512-B coalesced rows (16 B/lane),
 //     double-buffered against the MFMA loop; row stride 144 floats -> the four k-rows of a fragment read fall in
 //     disjoint bank groups (conflict-free ds_read_b32);
-//   * A (weights): pre-laid on the host in fragment order frag[mt][ks][lane] (ops.mfma_a_fragments), so a wave's
-//     A operand is ONE coalesced 256-B load per (m-tile, k-step) straight from L2 -- no LDS, no shuffles;
+//   * A (weights): pre-laid on the host in fragment order frag[mt][ks / 4][lane][ks % 4] (ops.conv1x1_fragments), so a wave's
+//     A operands of FOUR k-steps are one coalesced 1-KiB load (16 B per lane) straight from L2 -- no LDS, no shuffles;
 //   * epilogue in registers: + bias[co] (+ residual) -> ReLU | SiLU -> store (64-B segments per 16-pixel run);
 //   * XCD-contiguous block order with the Cout-chunk index fastest: the (<=4) blocks that re-read one pixel tile
 //     for different output-channel chunks share an L2.
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
         for (int mt = 0; mt < MT; ++mt) {
             const int mtg = (m0 >> 4) + wave * MT + mt;  // global m-tile
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[mt][ks] = wfrag[((size_t)mtg * ksteps + c * KS + ks) * 64 + l];
+            for (int q = 0; q < KS / 4; ++q) {     // four k-steps per 16-B load: frag[mt][ks / 4][lane][ks % 4]
+                const float4 v = *reinterpret_cast<const float4*>(wfrag + (((size_t)mtg * (ksteps / 4) + (c * KS) / 4 + q) * 64 + l) * 4);
+                a[mt][4 * q] = v.x; a[mt][4 * q + 1] = v.y; a[mt][4 * q + 2] = v.z; a[mt][4 * q + 3] = v.w;
+            }
         }
     };
 
@@ -116,15 +119,21 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             load_chunk(c + 1);
         }
         // B fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run (register double buffer)
+        // Column j of n-tile nt is PIXEL (nt / 4) * 64 + 4 j + nt % 4 of the block's tile (columns of a GEMM can be numbered freely):
+        // a lane's B operands of four n-tiles are four consecutive pixels = ONE ds_read_b128 (16 lanes x 16 B = a 256-B run per
+        // k-row, the four k-rows 16 banks apart), and its results are four consecutive pixels of a channel = one 16-B store.
         float bfr[2][NT];
+        auto read_b = [&](int ks, float (&dst)[NT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bfr[0][nt] = sB[buf][lk][nt * 16 + ln];
+            for (int gq = 0; gq < NT / 4; ++gq) {
+                const float4 v = *reinterpret_cast<const float4*>(&sB[buf][ks * 4 + lk][gq * 64 + 4 * ln]);
+                dst[4 * gq] = v.x; dst[4 * gq + 1] = v.y; dst[4 * gq + 2] = v.z; dst[4 * gq + 3] = v.w;
+            }
+        };
+        read_b(0, bfr[0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bfr[(ks + 1) & 1][nt] = sB[buf][(ks + 1) * 4 + lk][nt * 16 + ln];
-            }
+            if (ks + 1 < KS) read_b(ks + 1, bfr[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this k-step's MFMAs (the scheduler sinks it)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
             if (bias) bv = *reinterpret_cast<const float4*>(bias + co);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int p = p0 + nt * 16 + ln;
+                const int p = p0 + (nt / 4) * 64 + 4 * ln + (nt & 3);
                 if (p >= HW) continue;
                 float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z,
                                        acc[mt][nt][3] + bv.w);
@@ -168,62 +177,65 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
         }
         return;
     }
-    // Epilogue.  MFMA leaves D[row = lk*4 + r][col = ln] per (mt, nt): written directly, a store instruction covers 4 rows
-    // x 64 B.  Instead each wave transposes its 16 x BN tile through its own LDS slice (the B buffers are free after the
-    // last barrier) and streams float4 rows: BN*4-byte contiguous segments for the stores and the residual loads.
-    constexpr int LDO = BN + 4;                       // 68 | 132 floats: (lk*4*LDO + ln) % 64 distinct -> conflict-free
-    static_assert(4 * 16 * LDO <= 2 * KC * LD, "epilogue tile does not fit the B buffers");
-    float* so = &sB[0][0][0] + wave * (16 * LDO);
+    // Epilogue.  MFMA leaves D[row = lk*4 + r][col = ln] per (mt, nt); with the interleaved column numbering a lane holds, per channel
+    // row, FOUR CONSECUTIVE PIXELS in the tiles 4 gq .. 4 gq + 3: bias / residual / activation / store work on 16-B pieces straight
+    // from the accumulators (rounds 1-3 transposed every tile through LDS for that), 256-B runs per channel and instruction.
     float* __restrict__ yout = y + ((size_t)kpart * n_img + n) * Cout * HW;
     const float* __restrict__ rin = res ? res + (size_t)n * Cout * HW : nullptr;
-    constexpr int F4_PER_ROW = BN / 4, ITERS = 16 * F4_PER_ROW / 64;
+    constexpr int NG = NT / 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        // residual pieces of this m-tile first (unconditional loads on clamped addresses), all in flight together
+        float4 rq[4][NG];
+        if (rin) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) so[(lk * 4 + r) * LDO + nt * 16 + ln] = acc[mt][nt][r];
-        __builtin_amdgcn_wave_barrier();
+                for (int gq = 0; gq < NG; ++gq) {
+                    const int co = min(m0 + (wave * MT + mt) * 16 + lk * 4 + r, Cout - 1), p = min(p0 + gq * 64 + 4 * ln, HW - 4);
+                    rq[r][gq] = *reinterpret_cast<const float4*>(rin + (size_t)co * HW + p);
+                }
+        }
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int idx = i * 64 + l, row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
-            const int co = m0 + (wave * MT + mt) * 16 + row, p = p0 + c4 * 4;
-            if (co >= Cout || p >= HW) continue;
-            float4 v = *reinterpret_cast<const float4*>(&so[row * LDO + c4 * 4]);
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + (wave * MT + mt) * 16 + lk * 4 + r;
+            if (co >= Cout) continue;
             const float bv = bias ? bias[co] : 0.f;
-            const size_t o = (size_t)co * HW + p;
-            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-            if (rin) {
-                const float4 q = *reinterpret_cast<const float4*>(rin + o);
-                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            if (act == 1) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            } else if (act == 2) {
-                v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
-                v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
-            } else if (act == 3) {  // exact GELU: 0.5 x (1 + erf(x / sqrt(2)))
-                v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752f));
-                v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752f));
-                v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752f));
-                v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
-            }
-            if (out_pm != 2) {
-                *reinterpret_cast<float4*>(yout + o) = v;
-            } else {
-                const int kk = d2s_k * d2s_k, Ho = HW / Wo;
-                const int c = co / kk, r = co - c * kk, dy = r / d2s_k, dx = r - dy * d2s_k;
-                const int hh = p / Wo, ww = p - hh * Wo;      // Wo % 4 == 0 (host): the four pixels share a row
-                float* dst = y + (((size_t)n * d2s_ctot + d2s_coff + c) * ((size_t)Ho * d2s_k) + (size_t)hh * d2s_k + dy) *
-                                     ((size_t)Wo * d2s_k) + (size_t)ww * d2s_k + dx;
-                if (d2s_k == 1) {
-                    *reinterpret_cast<float4*>(dst) = v;
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                const int p = p0 + gq * 64 + 4 * ln;
+                if (p >= HW) continue;                                  // HW % 4 == 0 (host): a piece is all-in or all-out
+                float4 v = make_float4(acc[mt][4 * gq][r] + bv, acc[mt][4 * gq + 1][r] + bv, acc[mt][4 * gq + 2][r] + bv,
+                                       acc[mt][4 * gq + 3][r] + bv);
+                const size_t o = (size_t)co * HW + p;
+                if (rin) { const float4 q = rq[r][gq]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (act == 1) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                } else if (act == 2) {
+                    v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
+                    v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+                } else if (act == 3) {  // exact GELU: 0.5 x (1 + erf(x / sqrt(2)))
+                    v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752f));
+                    v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752f));
+                    v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752f));
+                    v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
+                }
+                if (out_pm != 2) {
+                    *reinterpret_cast<float4*>(yout + o) = v;
                 } else {
-                    dst[0] = v.x; dst[d2s_k] = v.y; dst[2 * d2s_k] = v.z; dst[3 * d2s_k] = v.w;
+                    const int kk = d2s_k * d2s_k, Ho = HW / Wo;
+                    const int c = co / kk, rr = co - c * kk, dy = rr / d2s_k, dx = rr - dy * d2s_k;
+                    const int hh = p / Wo, ww = p - hh * Wo;      // Wo % 4 == 0 (host): the four pixels share a row
+                    float* dst = y + (((size_t)n * d2s_ctot + d2s_coff + c) * ((size_t)Ho * d2s_k) + (size_t)hh * d2s_k + dy) *
+                                         ((size_t)Wo * d2s_k) + (size_t)ww * d2s_k + dx;
+                    if (d2s_k == 1) {
+                        *reinterpret_cast<float4*>(dst) = v;
+                    } else {
+                        dst[0] = v.x; dst[d2s_k] = v.y; dst[2 * d2s_k] = v.z; dst[3 * d2s_k] = v.w;
+                    }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -1386,7 +1386,9 @@ def conv1x1_fragments(w):
         wm = w.detach().reshape(cout, cin)
         if (mpad, kpad) != (cout, cin):
             wm = torch.nn.functional.pad(wm, (0, kpad - cin, 0, mpad - cout))
-        hit = (mfma_a_fragments(wm), w)  # keep w alive: the key is its address
+        fr = mfma_a_fragments(wm)            # [M/16, K/4, 64] -> four k-steps per lane contiguous: [M/16, K/16, 64, 4]
+        fr = fr.reshape(mpad // 16, kpad // 16, 4, 64).permute(0, 1, 3, 2).contiguous()
+        hit = (fr, w)  # keep w alive: the key is its address
         _FRAG_CACHE[key] = hit
     return hit[0]
 

@@ -477,7 +477,8 @@ int heal_se_gate(const float* mean, const float* w_reduce, const float* b_reduce
  *   second pixel); y/residual [n,Cout,Ho,Wo], Ho = (H-1)/stride+1; Ho*Wo % 4 == 0 (stride 1) or Wo % 4 == 0 (stride 2);
  *   in_scale [n,Cin] or NULL (per-image, per-input-channel gate); bias [Cout] or NULL; act 0 none | 1 ReLU | 2 SiLU | 3 GELU (erf).
  *   weight_frag = W zero-padded to [Mpad = ceil64(Cout), Kpad = ceil32(Cin)] in MFMA A-fragment order
- *   frag[mt][ks][lane] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)], mt < Mpad/16, ks < Kpad/4.
+ *   with four k-steps of a lane contiguous (ABI 3): frag[mt][ks / 4][lane][ks % 4] = W[mt*16 + (lane & 15)][ks*4 + (lane >> 4)],
+ *   mt < Mpad/16, ks < Kpad/4 (heal_amd.ops.conv1x1_fragments).
  *   out_pixel_major != 0: y is written as [n, Ho*Wo, Cout] (a pixel's channels contiguous; Cout % 4 == 0, no residual) --
  *   the layout heal_bev_pool_pm reads, produced by the fused image_head | depth_head convolution of CamEncode
  *   (lss_submodule.py:113-131) so that the lift never needs a transposition pass.                              */
