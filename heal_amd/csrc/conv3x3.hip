@@ -362,12 +362,19 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
             for (int q = 0; q < UQ; ++q) { a_[4 * q] = ua[q].x; a_[4 * q + 1] = ua[q].y; a_[4 * q + 2] = ua[q].z; a_[4 * q + 3] = ua[q].w; }
 #pragma unroll
             for (int xi_i = 0; xi_i < XW; ++xi_i) {
-                const float* __restrict__ vb = sV + ((XW * wave + xi_i) * WG_KC + lk) * VROW + ln;
+                // column ln of n-tile nt is TILE NTN * ln + nt (GEMM columns can be numbered freely): a lane's B operands of all its
+                // n-tiles are consecutive words of sV -- one ds_read_b128 (b64 for the 4-wave block) instead of NTN b32 reads
+                const float* __restrict__ vb = sV + ((XW * wave + xi_i) * WG_KC + lk) * VROW + NTN * ln;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float b[NTN];
-#pragma unroll
-                    for (int nt = 0; nt < NTN; ++nt) b[nt] = vb[ks * 4 * VROW + nt * 16];
+                    if constexpr (NTN == 4) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(vb + ks * 4 * VROW);
+                        b[0] = q4.x; b[1] = q4.y; b[2] = q4.z; b[3] = q4.w;
+                    } else {
+                        const float2 q2 = *reinterpret_cast<const float2*>(vb + ks * 4 * VROW);
+                        b[0] = q2.x; b[NTN - 1] = q2.y;
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
             const int co = mb * 64 + p * 16 + col;
             float m[16];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 16 + col) * MROW + etile];
+            for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 16 + col) * MROW + (etile % NTN) * 16 + etile / NTN];   // GEMM column of tile etile
             if (co >= Cout || oy >= H || ox >= W) continue;
             // Y = A^T M A,  A^T = [[1,1,1,0],[0,1,-1,-1]]
             float t0[4], t1[4];
