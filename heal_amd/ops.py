@@ -138,6 +138,16 @@ def _need(t, dtype, name):
 _WS_RETIRED = []
 
 
+def _retire_cache(cache):
+    """Evict a weight-layout cache WITHOUT freeing its device tensors: a captured HIP graph may have their addresses baked in
+    (same policy as `_workspace`); every tensor found in the cached values moves to the keep-alive list."""
+    for v in cache.values():
+        for t in (v if isinstance(v, (tuple, list)) else (v,)):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                _WS_RETIRED.append(t)
+    cache.clear()
+
+
 def _workspace(key, nbytes, device):
     """Grow-only per-(op, device) scratch buffer (256-B aligned by the caching allocator).  A buffer that is outgrown is
     RETIRED, not freed: a captured HIP graph may have its address baked in, and handing the memory back to the caching
@@ -1259,7 +1269,7 @@ def grouped16_fragments(weight, cg):
     hit = _FRAGG_CACHE.get(key)
     if hit is None:
         if len(_FRAGG_CACHE) > 512:
-            _FRAGG_CACHE.clear()
+            _retire_cache(_FRAGG_CACHE)
         C = int(weight.shape[0])
         w = weight.detach().reshape(C // 16, 16, cg, 9)                   # [sg, co, ci_in_group, tap]
         if cg == 16:
@@ -1285,7 +1295,7 @@ def grouped_small_fragments(weight, cg):
     hit = _FRAGQ_CACHE.get(key)
     if hit is None:
         if len(_FRAGQ_CACHE) > 512:
-            _FRAGQ_CACHE.clear()
+            _retire_cache(_FRAGQ_CACHE)
         C = int(weight.shape[0])
         f = weight.detach().reshape(C // 16, 16, cg, 9).permute(0, 3, 2, 1).contiguous()   # [sg, tap, ci, co]
         hit = (f, weight)
@@ -1380,7 +1390,7 @@ def conv1x1_fragments(w):
     hit = _FRAG_CACHE.get(key)
     if hit is None:
         if len(_FRAG_CACHE) > 1024:
-            _FRAG_CACHE.clear()
+            _retire_cache(_FRAG_CACHE)
         cout, cin = int(w.shape[0]), int(w.shape[1])
         mpad, kpad = (cout + 63) // 64 * 64, (cin + 31) // 32 * 32
         wm = w.detach().reshape(cout, cin)
@@ -1568,7 +1578,7 @@ def conv3x3_fragments(w):
     hit = _FRAG3_CACHE.get(key)
     if hit is None:
         if len(_FRAG3_CACHE) > 512:
-            _FRAG3_CACHE.clear()
+            _retire_cache(_FRAG3_CACHE)
         cout, cin = int(w.shape[0]), int(w.shape[1])
         mpad, kpad = (cout + 63) // 64 * 64, (cin + 7) // 8 * 8
         wm = w.detach().reshape(cout, cin, 9)
@@ -1622,7 +1632,7 @@ def conv3x3_winograd_fragments(w, waves=8):
     hit = _FRAGW_CACHE.get(key)
     if hit is None:
         if len(_FRAGW_CACHE) > 512:
-            _FRAGW_CACHE.clear()
+            _retire_cache(_FRAGW_CACHE)
         cout, cin = int(w.shape[0]), int(w.shape[1])
         mpad, kpad = (cout + 63) // 64 * 64, (cin + 7) // 8 * 8
         G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
@@ -1645,7 +1655,7 @@ def conv3x3_winograd4_fragments(w):
     hit = _FRAGW_CACHE.get(key)
     if hit is None:
         if len(_FRAGW_CACHE) > 512:
-            _FRAGW_CACHE.clear()
+            _retire_cache(_FRAGW_CACHE)
         cout, cin = int(w.shape[0]), int(w.shape[1])
         mpad, kpad = (cout + 31) // 32 * 32, (cin + 15) // 16 * 16
         G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
