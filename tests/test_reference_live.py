@@ -297,3 +297,22 @@ def test_checkpoint_optimizer_scheduler_helpers_match_live_reference(tmp_path, c
             s1 = mine.setup_lr_schedular(h, mine.setup_optimizer(h, net(3)), 9)
             s2 = theirs.setup_lr_schedular(h, theirs.setup_optimizer(h, net(3)), 9)
             assert type(s1) is type(s2) and s1.get_last_lr() == s2.get_last_lr()
+
+
+@pytest.mark.parametrize("shift", [1000, 2000])
+def test_v2xvit_and_baseline_oracles_against_live_reference_with_other_seeds(shift, monkeypatch):
+    """oracle/v2xvit_ref.py and oracle/model_ref.heter_model_baseline are pinned by ONE committed sample each (fusion_small,
+    baseline_small); here the same generators run against the LIVE reference with other seeds (other inputs, other agent poses) and
+    the oracle checks of tests/test_oracle_golden.py are applied to what they produce."""
+    from tests import test_oracle_golden as checks
+    from tests.golden import gen_golden as G
+    captured = {}
+    monkeypatch.setattr(G, "SEED_SHIFT", shift)
+    monkeypatch.setattr(G, "CAPTURE", captured)
+    for name in ("fusion_small", "baseline_small"):
+        G.GENS[name]()
+
+    def golden(name):
+        return _Captured(captured[name])
+    checks.test_v2xvit_oracle_matches_reference_golden(golden)
+    checks.test_heter_model_baseline_oracle_matches_reference_golden(golden)
