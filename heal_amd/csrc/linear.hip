@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinearArgs a) {
     }
 }
 
-// ---- LayerNorm statistics: one wave per token --------------------------------------------------------------------------
+// ---- LayerNorm statistics: one wave per token (C <= 512), four tokens per wave at C == 256 ------------------------------------
 __global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ x, int T, int C, float eps,
                                                  float2* __restrict__ stats) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
@@ -231,61 +231,132 @@ __global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ x, i
     if (l == 0) stats[t] = make_float2(mean, 1.0f / sqrtf(var + eps));
 }
 
+// C == 256: a wave takes FOUR tokens (its four 1-KB rows requested together; the same per-token arithmetic order as above, so
+// the statistics are bit-identical) -- one row per wave left the loads of a CU too shallow for HBM (2.9 TB/s).
+__global__ __launch_bounds__(256) void k_ln_stats256(const float* __restrict__ x, int T, float eps, float2* __restrict__ stats) {
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4, l = threadIdx.x & 63;
+    if (t0 >= T) return;
+    float4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const float4*>(x + (size_t)min(t0 + i, T - 1) * 256 + l * 4);
+    float mean[4], var[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mean[i] = wave_sum((q[i].x + q[i].y) + (q[i].z + q[i].w)) / 256.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float d = 0.f;
+        d += (q[i].x - mean[i]) * (q[i].x - mean[i]);
+        d += (q[i].y - mean[i]) * (q[i].y - mean[i]);
+        d += (q[i].z - mean[i]) * (q[i].z - mean[i]);
+        d += (q[i].w - mean[i]) * (q[i].w - mean[i]);
+        var[i] = wave_sum(d) / 256.0f;
+    }
+    if (l < 4 && t0 + l < T) {
+        const float m = l == 0 ? mean[0] : l == 1 ? mean[1] : l == 2 ? mean[2] : mean[3];
+        const float vv = l == 0 ? var[0] : l == 1 ? var[1] : l == 2 ? var[2] : var[3];
+        stats[t0 + l] = make_float2(m, 1.0f / sqrtf(vv + eps));
+    }
+}
+
 // ---- split attention weights (split_attn.py:43-62) ------------------------------------------------------------------------
 // colsum[g][part][c]: sums over the group's tokens of the three window-attention outputs (BEFORE their to_out projections;
 // the projections are linear, so the average of the projected branches is the projection of the averages).
 //   gap = sum_part (mean_part W_out[part]^T + b_out[part]);  a = fc2(relu(LN(fc1(gap))));  softmax over the 3 parts per channel
 // -> scale [g][3][C] (the column scales of the merged to_out GEMM) and bias [g][C] = sum_part scale * b_out[part].
+// A row is read as C / 4 lanes x 16 B; the block's 256 threads cover 256 / (C / 4) rows per step and keep four steps in flight
+// (one float per thread and four rows in flight left this 400-MB read at 4.3 TB/s); the row groups are then summed through LDS in
+// a fixed order, so the sums do not depend on the execution order.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long long part_stride, int rows_per_group, int C,
                                                int chunk, float* __restrict__ out /*[g][parts][chunks][C]*/) {
+    __shared__ float4 s_part[256];
     const int g = blockIdx.z, part = blockIdx.y;
     const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, rows_per_group);
-    const int c = threadIdx.x;   // C <= 256
-    if (c >= C) return;
-    const float* p = x + (size_t)part * part_stride + ((size_t)g * rows_per_group + r0) * C + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = r0;
-    for (; r + 3 < r1; r += 4, p += 4 * (size_t)C) { s0 += p[0]; s1 += p[C]; s2 += p[2 * (size_t)C]; s3 += p[3 * (size_t)C]; }
-    for (; r < r1; ++r, p += C) s0 += *p;
-    out[(((size_t)g * gridDim.y + part) * gridDim.x + blockIdx.x) * C + c] = (s0 + s1) + (s2 + s3);   // summed in chunk order below
+    const int lpr = C >> 2, rpg = 256 / lpr;           // lanes per row (16 / 32 / 48 / 64), rows per step (16 / 8 / 5 / 4; at C = 192 sixteen threads idle)
+    const int c4 = threadIdx.x % lpr, rg = threadIdx.x / lpr;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (rg < rpg) {
+        const float* base = x + (size_t)part * part_stride + (size_t)g * rows_per_group * C + c4 * 4;
+        int r = r0 + rg;
+        for (; r + 3 * rpg < r1; r += 4 * rpg) {
+            const float4 a = *reinterpret_cast<const float4*>(base + (size_t)r * C);
+            const float4 b = *reinterpret_cast<const float4*>(base + (size_t)(r + rpg) * C);
+            const float4 c = *reinterpret_cast<const float4*>(base + (size_t)(r + 2 * rpg) * C);
+            const float4 d = *reinterpret_cast<const float4*>(base + (size_t)(r + 3 * rpg) * C);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+            s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+        }
+        for (; r < r1; r += rpg) {
+            const float4 a = *reinterpret_cast<const float4*>(base + (size_t)r * C);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    s_part[threadIdx.x] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                                      (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (threadIdx.x < lpr) {
+        float4 t = s_part[threadIdx.x];
+        for (int k = 1; k < rpg; ++k) {
+            const float4 u = s_part[k * lpr + threadIdx.x];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(out + (((size_t)g * gridDim.y + part) * gridDim.x + blockIdx.x) * C + threadIdx.x * 4) = t;
+    }
 }
 
-// out[row] = (bias ? bias[row] : 0) + w[row][0..C) . vec, rows strided over the block's waves: a wave reads a weight row as 64 x 16 B
-// (coalesced; one thread per row would stride the lanes by a whole row) and reduces across lanes.  C <= 256, C % 64 == 0.
+// out[row] = (bias ? bias[row] : 0) + w[row][0..C) . vec[(row / C) * vstride ..], rows strided over the block's 16 waves: a wave
+// reads a weight row as 64 x 16 B (coalesced; one thread per row would stride the lanes by a whole row) and reduces across
+// lanes.  C <= 256, C % 64 == 0, rows % 4 == 0.  The kernel runs on ONE block per group and is pure latency: a wave requests 16
+// rows (four steps of four) with unconditional, clamped loads BEFORE it reduces any of them -- the round-3 version (4 waves, one
+// step in flight, predicated loads) spent 145 us on seven 256 x 256 matrix-vector products.
 __device__ __forceinline__ void block_matvec(const float* __restrict__ w, const float* __restrict__ bias,
-                                             const float* __restrict__ vec /*LDS*/, float* __restrict__ out /*LDS*/, int C) {
+                                             const float* __restrict__ vec /*LDS*/, int vstride, float* __restrict__ out /*LDS*/,
+                                             int rows, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const bool on = lane * 4 < C;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (on) v = *reinterpret_cast<const float4*>(vec + lane * 4);
-    for (int r0 = wave * 4; r0 < C; r0 += nw * 4) {
-        float d[4];
+    const int lc = on ? lane * 4 : 0;
+    for (int rb = 0; rb < rows; rb += nw * 16) {
+        float4 q[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (on && r0 + j < C) q = *reinterpret_cast<const float4*>(w + (size_t)(r0 + j) * C + lane * 4);
-            d[j] = fmaf(q.w, v.w, fmaf(q.z, v.z, fmaf(q.y, v.y, q.x * v.x)));
-        }
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = wave_sum(d[j]);
-        if (lane < 4 && r0 + lane < C) {
-            const float t = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
-            out[r0 + lane] = t + (bias ? bias[r0 + lane] : 0.f);
+            for (int jj = 0; jj < 4; ++jj) {
+                const int r = min(rb + (it * nw + wave) * 4 + jj, rows - 1);
+                q[it][jj] = *reinterpret_cast<const float4*>(w + (size_t)r * C + lc);
+            }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r0 = rb + (it * nw + wave) * 4;
+            if (r0 >= rows) break;                          // wave-uniform
+            float4 v = *reinterpret_cast<const float4*>(vec + (r0 / C) * vstride + lc);
+            if (!on) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float d[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 x = q[it][jj];
+                d[jj] = wave_sum(fmaf(x.w, v.w, fmaf(x.z, v.z, fmaf(x.y, v.y, x.x * v.x))));
+            }
+            if (lane < 4) {
+                const float t = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
+                out[r0 + lane] = t + (bias ? bias[r0 + lane] : 0.f);
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ colsum, int chunks, float inv_rows,
-                                                      const float* __restrict__ w_out /*[3][C][C] (nn.Linear [N][K])*/,
-                                                      const float* __restrict__ b_out /*[3][C]*/,
-                                                      const float* __restrict__ fc1 /*[C][C]*/, const float* __restrict__ ln_g,
-                                                      const float* __restrict__ ln_b, float eps,
-                                                      const float* __restrict__ fc2 /*[3C][C]*/, int C,
-                                                      float* __restrict__ scale /*[g][3][C]*/, float* __restrict__ bias /*[g][C]*/) {
+__global__ __launch_bounds__(1024) void k_split_weights(const float* __restrict__ colsum, int chunks, float inv_rows,
+                                                       const float* __restrict__ w_out /*[3][C][C] (nn.Linear [N][K])*/,
+                                                       const float* __restrict__ b_out /*[3][C]*/,
+                                                       const float* __restrict__ fc1 /*[C][C]*/, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, float eps,
+                                                       const float* __restrict__ fc2 /*[3C][C]*/, int C,
+                                                       float* __restrict__ scale /*[g][3][C]*/, float* __restrict__ bias /*[g][C]*/) {
     __shared__ __attribute__((aligned(16))) float s_mean[3 * 256], s_gap[256], s_h[256], s_t[3 * 256];
     __shared__ float s_red[8];
-    const int g = blockIdx.x, c = threadIdx.x;   // C == blockDim.x <= 256
-    for (int i = c; i < 3 * C; i += C) {
+    const int g = blockIdx.x, c = threadIdx.x;   // 1024 threads; channel-indexed steps use the first C <= 256 of them
+    const bool ch = c < C;
+    for (int i = c; i < 3 * C; i += blockDim.x) {
         const float* q = colsum + ((size_t)g * 3 + i / C) * chunks * C + (i % C);
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;     // four interleaved partial sums: a fixed order, loads in flight together
         int k = 0;
@@ -296,16 +367,16 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
         s_mean[i] = ((t0 + t1) + (t2 + t3)) * inv_rows;
     }
     __syncthreads();
-    for (int p = 0; p < 3; ++p) block_matvec(w_out + (size_t)p * C * C, b_out + p * C, s_mean + p * C, s_t + p * C, C);
+    block_matvec(w_out, b_out, s_mean, C, s_t, 3 * C, C);       // the three to_out projections: row block p reads mean p
     __syncthreads();
-    s_gap[c] = (s_t[c] + s_t[C + c]) + s_t[2 * C + c];
+    if (ch) s_gap[c] = (s_t[c] + s_t[C + c]) + s_t[2 * C + c];
     __syncthreads();
-    block_matvec(fc1, nullptr, s_gap, s_t, C);
+    block_matvec(fc1, nullptr, s_gap, 0, s_t, C, C);
     __syncthreads();
-    const float hval = s_t[c];
-    // LayerNorm over the C values of the block
+    const float hval = ch ? s_t[c] : 0.f;
+    // LayerNorm over the C values of the block (the waves past C hold zeros and are not summed)
     float sm = wave_sum(hval);
-    if ((c & 63) == 0) s_red[c >> 6] = sm;
+    if (ch && (c & 63) == 0) s_red[c >> 6] = sm;
     __syncthreads();
     float tot = 0.f;
     for (int i = 0; i < (C + 63) / 64; ++i) tot += s_red[i];
@@ -313,15 +384,16 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
     __syncthreads();
     const float dv = (hval - mean) * (hval - mean);
     sm = wave_sum(dv);
-    if ((c & 63) == 0) s_red[c >> 6] = sm;
+    if (ch && (c & 63) == 0) s_red[c >> 6] = sm;
     __syncthreads();
     tot = 0.f;
     for (int i = 0; i < (C + 63) / 64; ++i) tot += s_red[i];
     const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
-    s_h[c] = fmaxf((hval - mean) * rstd * ln_g[c] + ln_b[c], 0.f);
+    if (ch) s_h[c] = fmaxf((hval - mean) * rstd * ln_g[c] + ln_b[c], 0.f);
     __syncthreads();
-    for (int p = 0; p < 3; ++p) block_matvec(fc2 + (size_t)p * C * C, nullptr, s_h, s_t + p * C, C);
+    block_matvec(fc2, nullptr, s_h, 0, s_t, 3 * C, C);
     __syncthreads();
+    if (!ch) return;
     const float lg[3] = {s_t[c], s_t[C + c], s_t[2 * C + c]};
     const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
     const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx), e2 = expf(lg[2] - mx);
@@ -340,8 +412,11 @@ using namespace heal;
 extern "C" int heal_ln_stats(const float* x, int n_tokens, int channels, float eps, float* stats, void* stream) {
     HEAL_REQUIRE(channels % 4 == 0 && channels <= 512, "ln_stats: channels must be a multiple of 4, <= 512");
     if (n_tokens <= 0) return 0;
-    k_ln_stats<<<ceil_div(n_tokens, 4), 256, 0, (hipStream_t)stream>>>(x, n_tokens, channels, eps,
-                                                                      reinterpret_cast<float2*>(stats));
+    if (channels == 256)
+        k_ln_stats256<<<ceil_div(n_tokens, 16), 256, 0, (hipStream_t)stream>>>(x, n_tokens, eps, reinterpret_cast<float2*>(stats));
+    else
+        k_ln_stats<<<ceil_div(n_tokens, 4), 256, 0, (hipStream_t)stream>>>(x, n_tokens, channels, eps,
+                                                                          reinterpret_cast<float2*>(stats));
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -388,10 +463,12 @@ extern "C" int heal_split_attn_weights(const float* branches, long long part_str
                                        float* colsum_ws, float* scale, float* bias, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(channels <= 256 && channels % 64 == 0, "split_attn_weights: channels must be 64, 128, 192 or 256");
+    HEAL_REQUIRE(part_stride % 4 == 0 && ((uintptr_t)branches & 15) == 0 && ((uintptr_t)colsum_ws & 15) == 0,
+                 "split_attn_weights: 16-B alignment");
     const int chunk = 512, chunks = ceil_div(rows_per_group, chunk);
     dim3 grid(chunks, 3, groups);
     k_colsum<<<grid, 256, 0, s>>>(branches, part_stride, rows_per_group, channels, chunk, colsum_ws);
-    k_split_weights<<<groups, channels, 0, s>>>(colsum_ws, chunks, 1.0f / (float)rows_per_group, w_out, b_out, fc1, ln_gamma, ln_beta,
+    k_split_weights<<<groups, 1024, 0, s>>>(colsum_ws, chunks, 1.0f / (float)rows_per_group, w_out, b_out, fc1, ln_gamma, ln_beta,
                                                eps, fc2, channels, scale, bias);
     HEAL_LAUNCH_CHECK();
     return 0;
