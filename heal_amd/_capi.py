@@ -86,6 +86,9 @@ _SIGNATURES = {
     "heal_split_attn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "heal_split_attn_weights": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_int] + [c_void_p] * 5 + [c_float] +
                                 [c_void_p] * 5),
+    "heal_split_attn_colsum": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "heal_split_attn_weights_from_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_float] +
+                                            [c_void_p] * 4),
     "heal_sp_rank_bytes": (c_size_t, [c_void_p, c_int]),
     "heal_sp_out_sites_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

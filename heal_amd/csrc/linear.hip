@@ -345,7 +345,8 @@ __device__ __forceinline__ void block_matvec(const float* __restrict__ w, const 
     }
 }
 
-__global__ __launch_bounds__(1024) void k_split_weights(const float* __restrict__ colsum, int chunks, float inv_rows,
+__global__ __launch_bounds__(1024) void k_split_weights(const float* __restrict__ colsum /*[parts][g][3][chunks][C]*/, int chunks,
+                                                       int n_parts, float inv_rows,
                                                        const float* __restrict__ w_out /*[3][C][C] (nn.Linear [N][K])*/,
                                                        const float* __restrict__ b_out /*[3][C]*/,
                                                        const float* __restrict__ fc1 /*[C][C]*/, const float* __restrict__ ln_g,
@@ -356,14 +357,18 @@ __global__ __launch_bounds__(1024) void k_split_weights(const float* __restrict_
     __shared__ float s_red[8];
     const int g = blockIdx.x, c = threadIdx.x;   // 1024 threads; channel-indexed steps use the first C <= 256 of them
     const bool ch = c < C;
+    // the partial sums of a (group, branch, channel) are added in the order of the token chunks they cover: part-major (a part
+    // = the stripe of one rank when the tokens of a group are spread over ranks, dist.py), then chunk -- with whole 512-token
+    // chunks per stripe this is the order of the unsharded call, whatever the number of parts
+    const size_t part_stride = (size_t)gridDim.x * 3 * chunks * C;
+    const int n_sums = n_parts * chunks;
     for (int i = c; i < 3 * C; i += blockDim.x) {
-        const float* q = colsum + ((size_t)g * 3 + i / C) * chunks * C + (i % C);
+        const float* q0 = colsum + ((size_t)g * 3 + i / C) * chunks * C + (i % C);
+        auto q = [&](int k) { return q0[(size_t)(k / chunks) * part_stride + (size_t)(k % chunks) * C]; };
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;     // four interleaved partial sums: a fixed order, loads in flight together
         int k = 0;
-        for (; k + 3 < chunks; k += 4) {
-            t0 += q[(size_t)k * C]; t1 += q[(size_t)(k + 1) * C]; t2 += q[(size_t)(k + 2) * C]; t3 += q[(size_t)(k + 3) * C];
-        }
-        for (; k < chunks; ++k) t0 += q[(size_t)k * C];
+        for (; k + 3 < n_sums; k += 4) { t0 += q(k); t1 += q(k + 1); t2 += q(k + 2); t3 += q(k + 3); }
+        for (; k < n_sums; ++k) t0 += q(k);
         s_mean[i] = ((t0 + t1) + (t2 + t3)) * inv_rows;
     }
     __syncthreads();
@@ -457,19 +462,41 @@ extern "C" size_t heal_split_attn_workspace(int groups, int rows_per_group, int 
     return (size_t)groups * 3 * ceil_div(rows_per_group, 512) * channels * sizeof(float) + 256;
 }
 
+static int split_attn_colsum(const float* branches, long long part_stride, int groups, int rows_per_group, int channels,
+                            float* colsum, hipStream_t s) {
+    HEAL_REQUIRE(channels <= 256 && channels % 64 == 0, "split_attn_weights: channels must be 64, 128, 192 or 256");
+    HEAL_REQUIRE(part_stride % 4 == 0 && ((uintptr_t)branches & 15) == 0 && ((uintptr_t)colsum & 15) == 0,
+                 "split_attn_weights: 16-B alignment");
+    const int chunk = 512, chunks = ceil_div(rows_per_group, chunk);
+    dim3 grid(chunks, 3, groups);
+    k_colsum<<<grid, 256, 0, s>>>(branches, part_stride, rows_per_group, channels, chunk, colsum);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int heal_split_attn_colsum(const float* branches, long long part_stride, int groups, int rows_per_group, int channels,
+                                      float* colsum, void* stream) {
+    return split_attn_colsum(branches, part_stride, groups, rows_per_group, channels, colsum, (hipStream_t)stream);
+}
+
+extern "C" int heal_split_attn_weights_from_colsum(const float* colsum, int n_parts, int groups, int rows_per_part, int channels,
+                                                   const float* w_out, const float* b_out, const float* fc1,
+                                                   const float* ln_gamma, const float* ln_beta, float eps, const float* fc2,
+                                                   float* scale, float* bias, void* stream) {
+    HEAL_REQUIRE(channels <= 256 && channels % 64 == 0, "split_attn_weights: channels must be 64, 128, 192 or 256");
+    HEAL_REQUIRE(n_parts >= 1 && rows_per_part >= 1, "split_attn_weights: n_parts, rows_per_part >= 1");
+    const int chunks = ceil_div(rows_per_part, 512);
+    k_split_weights<<<groups, 1024, 0, (hipStream_t)stream>>>(colsum, chunks, n_parts, 1.0f / ((float)rows_per_part * (float)n_parts),
+                                                            w_out, b_out, fc1, ln_gamma, ln_beta, eps, fc2, channels, scale, bias);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int heal_split_attn_weights(const float* branches, long long part_stride, int groups, int rows_per_group,
                                        int channels, const float* w_out, const float* b_out, const float* fc1,
                                        const float* ln_gamma, const float* ln_beta, float eps, const float* fc2,
                                        float* colsum_ws, float* scale, float* bias, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    HEAL_REQUIRE(channels <= 256 && channels % 64 == 0, "split_attn_weights: channels must be 64, 128, 192 or 256");
-    HEAL_REQUIRE(part_stride % 4 == 0 && ((uintptr_t)branches & 15) == 0 && ((uintptr_t)colsum_ws & 15) == 0,
-                 "split_attn_weights: 16-B alignment");
-    const int chunk = 512, chunks = ceil_div(rows_per_group, chunk);
-    dim3 grid(chunks, 3, groups);
-    k_colsum<<<grid, 256, 0, s>>>(branches, part_stride, rows_per_group, channels, chunk, colsum_ws);
-    k_split_weights<<<groups, 1024, 0, s>>>(colsum_ws, chunks, 1.0f / (float)rows_per_group, w_out, b_out, fc1, ln_gamma, ln_beta,
-                                               eps, fc2, channels, scale, bias);
-    HEAL_LAUNCH_CHECK();
-    return 0;
+    if (int rc = split_attn_colsum(branches, part_stride, groups, rows_per_group, channels, colsum_ws, (hipStream_t)stream)) return rc;
+    return heal_split_attn_weights_from_colsum(colsum_ws, 1, groups, rows_per_group, channels, w_out, b_out, fc1, ln_gamma, ln_beta,
+                                               eps, fc2, scale, bias, stream);
 }

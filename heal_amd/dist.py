@@ -487,13 +487,251 @@ class ShardedBaseline(_Sharded):
         return {"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
 
 
+class _StripeComm:
+    """The collectives of the striped tail (ShardedBaselineStriped).  Eager mode: each call just runs.  Capture mode
+    (`begin_capture`): the step is recorded as a PROGRAM -- a call closes the HIP graph under capture, runs the collective on
+    buffers that stay alive (its input lives in the graphs' shared pool, its output is allocated outside the capture), and opens
+    the next graph; `replay()` then alternates graph launches and collectives in the recorded order.  The collectives stay
+    ordinary stream operations of the process group (RCCL on the GPU box), as in _Sharded.replay."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.program = None          # None: eager
+        self._g = None
+        self._pool = None
+        self._keep = []
+
+    # ---- capture plumbing
+    def begin_capture(self, open_graph=True):
+        self.program, self._keep, self._pool, self._g = [], [], None, None
+        if open_graph:
+            self._open()
+
+    def _open(self):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: the process-group watchdog thread may query events while we capture
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()     # one pool for the program's graphs: tensors cross the cuts
+        g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+        self._g = g
+
+    def _cut(self):
+        if self._g is not None:
+            self._g.capture_end()
+            self.program.append(("graph", self._g))
+            self._g = None
+
+    def end_capture(self):
+        self._cut()
+
+    def abort_capture(self):
+        if self._g is not None:
+            try:
+                self._g.capture_end()
+            except Exception:  # noqa: BLE001 - already failing
+                pass
+            self._g = None
+        self.program = None
+
+    def replay(self):
+        for kind, item in self.program:
+            if kind == "graph":
+                item.replay()
+            else:
+                item()
+
+    def _run(self, fn, keep, reopen=True):
+        if self.program is None:
+            fn()
+            return
+        self._cut()
+        fn()
+        self.program.append(("coll", fn))
+        self._keep.append(keep)
+        if reopen:
+            self._open()
+
+    # ---- the three exchanges
+    def all_gather(self, t):
+        """-> [world, *t.shape] on every rank."""
+        t = t.detach()
+        assert t.is_contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self._run(lambda: dist.all_gather_into_tensor(out.view(-1), t.view(-1)), (t, out))
+        return out
+
+    def all_to_all(self, send):
+        """send [world, ...]: slice d goes to rank d -> recv [world, ...]: slice s came from rank s."""
+        assert send.is_contiguous() and send.shape[0] == self.world
+        recv = torch.empty_like(send)
+        if dist.get_backend() == "gloo" and send.is_cuda:
+            # two ranks on one device in the tests: gloo has no device all-to-all; `world` gathers move the same slices
+            def fn():
+                for d in range(self.world):
+                    dist.gather(send[d], [recv[s_] for s_ in range(self.world)] if self.rank == d else None, dst=d)
+        else:
+            def fn():
+                dist.all_to_all_single(recv, send)
+        self._run(fn, (send, recv))
+        return recv
+
+    def gather0(self, t):
+        """-> [world, *t.shape] on rank 0, None elsewhere (no graph is opened after it on the other ranks: their step ends here)."""
+        assert t.is_contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == 0 else None
+        self._run(lambda: dist.gather(t, [out[r] for r in range(self.world)] if self.rank == 0 else None, dst=0), (t, out),
+                  reopen=self.rank == 0)
+        return out
+
+
+class ShardedBaselineStriped(ShardedBaseline):
+    """HeterModelBaseline with the V2X-ViT fusion (BASELINE config 5), tail striped over the ranks instead of serial on rank 0
+    (VERDICT r3 gap 1).  The transformer is per pixel (agent attention, LayerNorm, feed-forward, RTE) or per window
+    (mswin.py:46-80, windows of 4 / 8 / 16 rows), so with H a multiple of world x the largest window rank r can run the WHOLE
+    encoder on rows [r H / world, (r + 1) H / world) of every agent's map:
+
+        local      encode own agents, warp into the ego frame, token-major                       (as ShardedBaseline)
+        all-to-all stripe d of my agents -> rank d            ((world - 1) / world of one map leaves each rank, all links busy;
+                                                               the gather moved world - 1 whole maps INTO rank 0)
+        encoder    on [L, H / world, W, C]; the one global step -- split attention's average pool (split_attn.py:43-62) --
+                   all-gathers per-chunk column sums (12 KB per agent and rank) and reduces them in the unsharded order
+        gather     the ego agent's fused stripe -> rank 0 (1 / world of a map per rank), which runs the heads.
+
+    Same values as the unsharded model: every stripe computes exactly the rows the serial tail computes (bit for bit when a
+    stripe is whole 512-token chunks).  Falls back to ShardedBaseline's gather + serial tail when H does not divide.  Opt out:
+    HEAL_V2XVIT_STRIPES=0."""
+
+    _striped = None
+
+    def __init__(self, model, rank, world, wire_dtype=None, collective=None):
+        super().__init__(model, rank, world, wire_dtype, collective)
+        self._comm = _StripeComm(rank, world)
+        self._zero_send = None
+
+    def _encoder(self):
+        return self.model.fusion_net.fusion_net.encoder
+
+    def _stripe_modules(self):
+        from heal_amd.opencood.models.sub_modules.v2xvit_basic import PyramidWindowAttention, SplitAttn
+        return [mod for mod in self._encoder().modules() if isinstance(mod, (PyramidWindowAttention, SplitAttn))]
+
+    def prepare(self, scene_input, n_agents, local_inputs):
+        super().prepare(scene_input, n_agents, local_inputs)
+        if self._striped is None:
+            from heal_amd.opencood.models.sub_modules.v2xvit_basic import BaseWindowAttention
+            ws = max([mod.window_size for mod in self._encoder().modules() if isinstance(mod, BaseWindowAttention)] or [1])
+            H = self._shape[1]
+            self._striped = self.world > 1 and H % (self.world * ws) == 0
+
+    def _step(self, scene_input, n_agents, local_inputs, comm, post_fn=None):
+        from heal_amd.opencood.models.fuse_modules.fusion_in_one import warp_to_ego
+        from heal_amd.opencood.utils.transformation_utils import normalize_pairwise_tfm, pairwise_to_host
+        from heal_amd import ops
+        m, world = self.model, self.world
+        C, H, W = self._shape
+        Hs = H // world
+        n_slots = slots_per_rank(n_agents, world)
+        dev = next(m.parameters()).device
+        mine = owned_agents(n_agents, self.rank, world)
+        if mine:
+            pairwise, _ = pairwise_to_host(scene_input["pairwise_t_matrix"])
+            affine = normalize_pairwise_tfm(pairwise, m.H, m.W, m.fake_voxel_size)
+            f64 = str(affine.dtype).endswith("float64")
+            x, _ = self._own_features(scene_input, n_agents, local_inputs)
+            if isinstance(affine, torch.Tensor) and affine.is_cuda:      # poses on the device (StaticInputs): read at replay time
+                rows = torch.stack([affine[0][0, a] for a in mine])     # views + one cat kernel: nothing uploaded under capture
+            else:
+                rows = [affine[0][0, a] for a in mine]
+            if x.is_cuda and x.shape[1] % 4 == 0:
+                pm = ops.warp_agents_pm(x, rows, f64)                                   # [n_mine, H, W, C]
+            else:
+                pm = warp_to_ego(x, rows, f64).permute(0, 2, 3, 1)
+            send = torch.zeros((world, n_slots, Hs, W, C), dtype=torch.float32, device=dev)
+            send[:, :len(mine)] = pm.reshape(len(mine), world, Hs, W, C).transpose(0, 1)
+        else:
+            if self._zero_send is None:      # a rank without agents sends constant zero stripes (never read: not a real agent)
+                self._zero_send = torch.zeros((world, n_slots, Hs, W, C), dtype=torch.float32, device=dev)
+            send = self._zero_send
+        recv = comm.all_to_all(self._wire(send))
+        if recv.dtype != torch.float32:
+            recv = recv.float()
+        x = torch.stack([recv[agent_owner(a, world), a // world] for a in range(n_agents)])   # [L, Hs, W, C], ego first
+        mods = self._stripe_modules()
+        for mod in mods:
+            mod._stripe = comm
+        try:
+            y = self._encoder()(x)[0].contiguous()                                       # the ego agent's fused stripe [Hs, W, C]
+        finally:
+            for mod in mods:
+                mod._stripe = None
+        g = comm.gather0(y)
+        if self.rank != 0:
+            return None
+        fused = g.view(H, W, C).permute(2, 0, 1).unsqueeze(0)
+        cls_preds, reg_preds, dir_preds = m.heads(fused)
+        out = {"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
+        return post_fn(out) if post_fn is not None else out
+
+    @torch.no_grad()
+    def forward(self, scene_input, n_agents, local_inputs):
+        self.prepare(scene_input, n_agents, local_inputs)
+        if not self._striped:
+            return super().forward(scene_input, n_agents, local_inputs)
+        return self._step(scene_input, n_agents, local_inputs, _StripeComm(self.rank, self.world))
+
+    @torch.no_grad()
+    def capture(self, scene_input, n_agents, local_inputs, post_fn=None, warmup=2):
+        """The striped step as a program of HIP graphs and collectives (_StripeComm).  A rank that fails to capture raises: the
+        other ranks are inside the same collective sequence and cannot be told to fall back."""
+        self.prepare(scene_input, n_agents, local_inputs)
+        if not self._striped:
+            return super().capture(scene_input, n_agents, local_inputs, post_fn, warmup)
+        dev = next(self.model.parameters()).device
+        cur = torch.cuda.current_stream(dev)
+        if cur == torch.cuda.default_stream(dev):
+            raise RuntimeError("capture() must be called under a non-default stream")
+        from heal_amd import ops
+        for _ in range(warmup):
+            out = self.forward(scene_input, n_agents, local_inputs)
+            if post_fn is not None and self.rank == 0:
+                post_fn(out)
+        cur.synchronize()
+        ops.verify_sparse_capacity()
+        self._graph_checks, self._replays = [], 0
+        self._capture_error = None
+        comm = self._comm
+        comm.begin_capture(open_graph=bool(owned_agents(n_agents, self.rank, self.world)))
+        try:
+            self._static_post = self._step(scene_input, n_agents, local_inputs, comm, post_fn)
+            comm.end_capture()
+        except Exception as e:  # noqa: BLE001
+            comm.abort_capture()
+            self._capture_error = e
+            raise
+        self._graph_checks = ops.take_sparse_checks()
+        return True
+
+    def replay(self):
+        if not self._striped:
+            return super().replay()
+        self._comm.replay()
+        self._replays += 1
+        if self._graph_checks and self._replays % 32 == 0:
+            self.check_sparse_capacity()
+        return self._static_post if self.rank == 0 else None
+
+
 def make_sharded(model, rank, world, wire_dtype=None, collective=None, split=None):
     """The agent-sharded runner that matches the model class.  split: "levels" (default: warped pyramid levels travel) |
     "compressed" (HeterPyramidCollab with a compressor: the compressor's encoder output travels)."""
+    import os
     name = type(model).__name__
     if name == "HeterPyramidCollab":
         return ShardedCollab(model, rank, world, wire_dtype, collective, split)
     if name == "HeterModelBaseline":
+        if (world > 1 and type(model.fusion_net).__name__ == "V2XViTFusion"
+                and os.environ.get("HEAL_V2XVIT_STRIPES", "1") != "0"):
+            return ShardedBaselineStriped(model, rank, world, wire_dtype, collective)
         return ShardedBaseline(model, rank, world, wire_dtype, collective)
     raise NotImplementedError(f"no agent-sharded split for {name}")
 

@@ -288,12 +288,18 @@ class SplitAttn(nn.Module):
         self.bn1 = nn.LayerNorm(input_dim)
         self.act1 = nn.ReLU()
         self.fc2 = nn.Linear(input_dim, input_dim * 3, bias=False)
+        self._stripe = None     # set by heal_amd.dist (row stripes of one scene on several ranks): see PyramidWindowAttention
 
     def forward(self, window_list):
         """split_attn.py:43-62 on [L,H,W,C] tensors."""
         sw, mw, bw = window_list
         L = sw.shape[0]
-        gap = (sw + mw + bw).mean((1, 2), keepdim=True)                  # [L,1,1,C]
+        if self._stripe is not None:
+            # the global average pool is the one step of the encoder that looks beyond a window: sum of the ranks' stripe sums
+            part = (sw + mw + bw).sum((1, 2))                            # [L,C] over this rank's rows
+            gap = (self._stripe.all_gather(part).sum(0) / float(self._stripe.world * sw.shape[1] * sw.shape[2]))[:, None, None, :]
+        else:
+            gap = (sw + mw + bw).mean((1, 2), keepdim=True)              # [L,1,1,C]
         a = self.fc2(F.relu(self.bn1(self.fc1(gap))))                    # [L,1,1,3C]
         a = F.softmax(a.view(L, 1, 3, -1), dim=2).reshape(L, 1, 1, -1)   # radix softmax over the 3 windows
         c = self.input_dim
@@ -308,6 +314,10 @@ class PyramidWindowAttention(nn.Module):
                                     for h, d, w in zip(heads, dim_heads, window_size)])
         self.fuse_mehod = fuse_method
         self._f, self._fo, self._fc = _Folded(), _Folded(), _Folded()
+        # Row stripes (heal_amd/dist.py, ShardedBaselineStriped): x is rows [r Hs, (r + 1) Hs) of every agent's map, Hs a multiple
+        # of the largest window.  Windows never cross a stripe, so everything here is local EXCEPT split attention's global
+        # average: `_stripe.all_gather(t)` -> [world, *t.shape] is the only exchange (the per-chunk column sums, 12 KB per agent).
+        self._stripe = None
         if fuse_method.startswith("split_attn"):
             self.split_attn = SplitAttn({"split_attn": 256, "split_attn128": 128, "split_attn64": 64}[fuse_method])
 
@@ -344,8 +354,13 @@ class PyramidWindowAttention(nn.Module):
             bias = (bo.sum(0) / 3.0).expand(L, C).contiguous()
         else:
             sa = self.split_attn
-            scale, bias = ops.split_attn_weights(branches, L, H * W, wo, bo, sa.fc1.weight, sa.bn1.weight, sa.bn1.bias,
-                                                 sa.bn1.eps, sa.fc2.weight)
+            if self._stripe is not None:
+                sums = self._stripe.all_gather(ops.split_attn_colsum(branches, L, H * W))     # [world, L, 3, chunks, C]
+                scale, bias = ops.split_attn_weights_from_colsum(sums, H * W, wo, bo, sa.fc1.weight, sa.bn1.weight, sa.bn1.bias,
+                                                                 sa.bn1.eps, sa.fc2.weight)
+            else:
+                scale, bias = ops.split_attn_weights(branches, L, H * W, wo, bo, sa.fc1.weight, sa.bn1.weight, sa.bn1.bias,
+                                                     sa.bn1.eps, sa.fc2.weight)
         return ops.linear(branches, wo_cat, bias, residual=x.reshape(-1, C), colscale=scale, colscale_part=C,
                           group_rows=H * W, bias_per_group=True, x_parts=3).view(L, H, W, C)
 

@@ -1258,6 +1258,30 @@ def split_attn_weights(branches, groups, rows_per_group, w_out, b_out, fc1, ln_g
     return scale, bias
 
 
+def split_attn_colsum(branches, groups, rows_per_group):
+    """First half of split_attn_weights for tokens spread over ranks: [groups, 3, ceil(rows / 512), C] per-chunk column sums of
+    the local tokens of branches [3, groups * rows_per_group, C] (a fresh tensor: it is handed to a collective)."""
+    branches = _need(branches, torch.float32, "branches")
+    C = int(branches.shape[-1])
+    out = torch.empty((groups, 3, (rows_per_group + 511) // 512, C), dtype=torch.float32, device=branches.device)
+    _capi.call("heal_split_attn_colsum", _ptr(branches), int(branches.stride(0)), groups, rows_per_group, C, _ptr(out), _stream())
+    return out
+
+
+def split_attn_weights_from_colsum(colsum, rows_per_part, w_out, b_out, fc1, ln_g, ln_b, eps, fc2):
+    """Second half: colsum [n_parts, groups, 3, chunks, C] (the all-gathered halves) -> (scale [groups,3,C], bias [groups,C])."""
+    colsum = _need(colsum, torch.float32, "colsum")
+    n_parts, groups, _three, chunks, C = (int(v) for v in colsum.shape)
+    if chunks != (rows_per_part + 511) // 512:
+        raise ValueError(f"split_attn_weights_from_colsum: {chunks} chunks do not match {rows_per_part} rows per part")
+    dev = colsum.device
+    scale = torch.empty((groups, 3, C), dtype=torch.float32, device=dev)
+    bias = torch.empty((groups, C), dtype=torch.float32, device=dev)
+    _capi.call("heal_split_attn_weights_from_colsum", _ptr(colsum), n_parts, groups, int(rows_per_part), C, _ptr(w_out),
+               _ptr(b_out), _ptr(fc1), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(fc2), _ptr(scale), _ptr(bias), _stream())
+    return scale, bias
+
+
 # ------------------------------------------------------------------------------------------------ K7
 _FRAGG_CACHE = {}
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HEAL_AMD_ABI_VERSION 3
+#define HEAL_AMD_ABI_VERSION 4
 
 int heal_abi_version(void);
 const char* heal_last_error(void);
@@ -648,6 +648,18 @@ int heal_split_attn_weights(const float* branches, long long part_stride, int gr
                             const float* w_out, const float* b_out, const float* fc1, const float* ln_gamma,
                             const float* ln_beta, float eps, const float* fc2, float* colsum_ws, float* scale,
                             float* bias, void* stream);
+/* The same operator in its two halves, for a scene whose tokens are spread over ranks as row stripes (heal_amd/dist.py,
+ * ShardedBaselineStriped; the only step of the V2X-ViT encoder that looks beyond a window, mswin.py:118-122 -> split_attn.py:43-62):
+ * heal_split_attn_colsum: colsum [groups, 3, ceil(rows_per_group / 512), channels] <- per-chunk column sums of the LOCAL tokens;
+ * the ranks all-gather these (12 KB per group and rank), and heal_split_attn_weights_from_colsum reduces colsum [n_parts, groups,
+ * 3, chunks, channels] part-major, chunk by chunk -- the order of the unsharded call when rows_per_part is a multiple of 512 --
+ * over n_parts * rows_per_part tokens per group.                                                                               */
+int heal_split_attn_colsum(const float* branches, long long part_stride, int groups, int rows_per_group, int channels,
+                           float* colsum, void* stream);
+int heal_split_attn_weights_from_colsum(const float* colsum, int n_parts, int groups, int rows_per_part, int channels,
+                                        const float* w_out, const float* b_out, const float* fc1, const float* ln_gamma,
+                                        const float* ln_beta, float eps, const float* fc2, float* scale, float* bias,
+                                        void* stream);
 
 /* ---- training-side anchor labelling --------------------------------------------------------
  * heal_label_assign: the IoU / assignment core of VoxelPostprocessor.generate_label

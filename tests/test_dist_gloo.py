@@ -123,3 +123,56 @@ def test_all_gather_of_single_scale_maps_world2(tmp_path, n_agents):
     mp.spawn(_map_worker, args=(2, n_agents, _free_port(), out), nprocs=2, join=True)
     want = torch.stack([_agent_maps(a)[0][0] for a in range(n_agents)])
     assert torch.equal(torch.load(out), want)
+
+
+def _stripe_args():
+    return {"num_blocks": 1, "depth": 2, "use_roi_mask": True, "use_RTE": False, "RTE_ratio": 0,
+            "cav_att_config": {"dim": 64, "use_hetero": True, "use_RTE": False, "RTE_ratio": 0, "heads": 4, "dim_head": 16, "dropout": 0.0},
+            "pwindow_att_config": {"dim": 64, "heads": [4, 2, 1], "dim_head": [16, 32, 64], "dropout": 0.0, "window_size": [2, 4, 8],
+                                   "relative_pos_embedding": True, "fusion_method": "split_attn64"},
+            "feed_forward": {"mlp_dim": 64, "dropout": 0.0},
+            "sttf": {"voxel_size": [0.4, 0.4, 4], "downsample_rate": 4}}
+
+
+def _stripe_worker(rank, world, port, tmp):
+    """The exchanges of dist.ShardedBaselineStriped on CPU: all-to-all of row stripes, the V2X-ViT encoder on a stripe with split
+    attention's average pool all-gathered (v2xvit_basic.SplitAttn._stripe), gather of the ego stripe."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heal_amd.opencood.models.sub_modules.v2xvit_basic import PyramidWindowAttention, SplitAttn, V2XTEncoder
+    torch.manual_seed(3)
+    enc = V2XTEncoder(_stripe_args())      # training mode with zero dropout: the torch path of every operator (CPU)
+    L, H, W, C = 3, 16, 8, 64
+    Hs = H // world
+    x = torch.randn(L, H, W, C, generator=torch.Generator().manual_seed(4))
+    n_slots = hd.slots_per_rank(L, world)
+    comm = hd._StripeComm(rank, world)
+    mine = hd.owned_agents(L, rank, world)
+    send = torch.zeros((world, n_slots, Hs, W, C))
+    send[:, :len(mine)] = x[mine].reshape(len(mine), world, Hs, W, C).transpose(0, 1)
+    recv = comm.all_to_all(send)
+    xs = torch.stack([recv[hd.agent_owner(a, world), a // world] for a in range(L)])
+    assert torch.equal(xs, x[:, rank * Hs:(rank + 1) * Hs])
+    mods = [m for m in enc.modules() if isinstance(m, (PyramidWindowAttention, SplitAttn))]
+    for m in mods:
+        m._stripe = comm
+    y = enc(xs)[0].detach().contiguous()
+    for m in mods:
+        m._stripe = None
+    g = comm.gather0(y)
+    assert (g is None) == (rank != 0)
+    if rank == 0:
+        torch.save((g.reshape(H, W, C), enc(x)[0].detach(), enc(xs)[0].detach()), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_v2xvit_encoder_on_row_stripes_world2(tmp_path):
+    out = str(tmp_path / "stripes.pt")
+    mp.spawn(_stripe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got, want, local_only = torch.load(out)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 1e-5 * scale
+    # without the exchange a stripe pools only its own rows: the split-attention weights differ -> the test would see it
+    assert float((local_only - want[:8]).abs().max()) > 1e-4 * scale

@@ -19,10 +19,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=None):
+def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=None, stripes=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if stripes is not None:
+        os.environ["HEAL_V2XVIT_STRIPES"] = "1" if stripes else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from heal_amd import configs
@@ -58,6 +60,15 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=Non
             rep = sharded.replay()
             rep = sharded.replay()
         torch.cuda.synchronize()
+        if stripes is not None:
+            from heal_amd.dist import ShardedBaselineStriped
+            assert isinstance(sharded, ShardedBaselineStriped) == bool(stripes)
+            if stripes:   # the 32 x 32 map of this scene splits into two 16-row stripes (the largest window)
+                assert sharded._striped and sharded._comm.program is not None
+                kinds = [k for k, _ in sharded._comm.program]
+                # local | all-to-all | encoder up to each split attention | all-gather | ... | gather | heads (rank 0)
+                assert kinds.count("coll") == 2 + 3 and kinds[0] == ("graph" if mine else "coll"), kinds
+                assert kinds[-1] == ("graph" if rank == 0 else "coll"), kinds
         if rank == 0:
             ref = pipe.model(scene.model_input())
             torch.save({k: (out[k].cpu(), ref[k].cpu(), rep[k].cpu()) for k in ("cls_preds", "reg_preds", "dir_preds")},
@@ -96,6 +107,23 @@ def test_sharded_baseline_equals_single_process(tmp_path, fusion, n_agents):
         assert err < 1e-4, ("graph replay", k, err)
 
 
+@pytest.mark.parametrize("stripes,n_agents", [(True, 3), (True, 1), (False, 3)])
+def test_sharded_v2xvit_tail_striped_over_ranks_equals_single_process(tmp_path, stripes, n_agents):
+    """dist.ShardedBaselineStriped (VERDICT r3 gap 1): the V2X-ViT encoder on row stripes -- all-to-all of the ego-frame maps,
+    one all-gather of column sums per split attention, gather of the ego stripe -- eager and as a program of HIP graphs and
+    collectives; the stripes compute the rows of the serial tail, so the heads agree to rounding of the shared sums (a stripe of
+    this map is one 512-token chunk: the sums are added in the unsharded order).  n_agents = 1: rank 0 owns no agent.
+    stripes = False: HEAL_V2XVIT_STRIPES=0 keeps the gather + serial tail."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_worker, args=(2, _free_port(), ["m1"] * n_agents, out, None, "v2xvit", None, stripes), nprocs=2, join=True)
+    res = torch.load(out)
+    for k, (got, ref, rep) in res.items():
+        assert float(ref.abs().max()) > 0
+        assert float((got - ref).abs().max() / (ref.abs().max() + 1e-12)) < 1e-5, k
+        assert float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)) < 1e-5, ("program replay", k)
+
+
 def test_sharded_forward_fp16_wire_stays_inside_the_parity_budget(tmp_path):
     """half-size exchange buffer.  fp16 rounding of the shared maps (~5e-4 relative) must keep the head
     outputs within the 1e-3 north-star tolerance of the fp32 single-process result."""
@@ -124,7 +152,7 @@ def test_sharded_compressed_wire_equals_single_process(tmp_path):
         assert float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)) < 1e-4, ("graph replay", k)
 
 
-def _ring_worker(rank, world, port, mods, out_path):
+def _ring_worker(rank, world, port, mods, out_path, fusion=None):
     """Two frames in flight through the agent-sharded step (dist.ShardedFramesInFlight): the boxes of a SEQUENCE of different
     frames must equal the single-process pipeline's, frame by frame."""
     import numpy as np
@@ -137,7 +165,7 @@ def _ring_worker(rank, world, port, mods, out_path):
     from heal_amd.dist import ShardedFramesInFlight, make_sharded
     from heal_amd.pipeline import Scene, ScenePipeline
     small = [-25.6, -25.6, -3, 25.6, 25.6, 1]
-    hypes = configs.lidar_pyramid(small)
+    hypes = configs.lidar_pyramid(small) if fusion is None else configs.lidar_baseline(fusion, small)
     pipe = ScenePipeline(hypes, "cuda:0", seed=5)
     frames = []
     for i in range(5):
@@ -175,11 +203,12 @@ def _ring_worker(rank, world, port, mods, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_agents", [3, 2])
-def test_sharded_frames_in_flight_equal_single_process(tmp_path, n_agents):
+@pytest.mark.parametrize("n_agents,fusion", [(3, None), (2, None), (3, "v2xvit")])
+def test_sharded_frames_in_flight_equal_single_process(tmp_path, n_agents, fusion):
+    """fusion = "v2xvit": the striped tail (programs of graphs and collectives) with two frames in flight."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "ring.pt")
-    mp.spawn(_ring_worker, args=(2, _free_port(), ["m1"] * n_agents, out), nprocs=2, join=True)
+    mp.spawn(_ring_worker, args=(2, _free_port(), ["m1"] * n_agents, out, fusion), nprocs=2, join=True)
     pairs = torch.load(out)
     assert len(pairs) == 5
     seen = 0
