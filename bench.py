@@ -606,11 +606,15 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        coll_name = "n/a"
+        coll_name, striped = "n/a", False
         if not solo:   # name the collective that actually ran (dist._Sharded.collective; VERDICT r3: the label said all-gather)
             lib_ = "RCCL" if backend == "nccl" else backend
             coll_name = {"gather": f"{lib_} gather to rank 0", "all_gather": f"{lib_} all-gather"}.get(sharded.collective,
                                                                                                       sharded.collective)
+            striped = bool(getattr(sharded, "_striped", False))
+            if striped:   # dist.ShardedBaselineStriped: the V2X-ViT tail runs on row stripes of every rank
+                coll_name = (f"{lib_} all-to-all of ego-frame stripes + all-gathered split-attention sums + gather of the ego "
+                             f"stripe")
         ms_per_step = dt / a.steps * 1e3
         nx = ny = 512
         with torch.no_grad():
@@ -638,6 +642,8 @@ def main():
                        else (f"agent-sharded over {world} ranks, 1 {coll_name}"
                                                                    + (" (fp16 wire)" if os.environ.get("HEAL_WIRE") == "fp16" else "")),
                        "launch": ("eager launches" if not use_graph else "hipGraph replay of the whole step" if solo
+                                  else "program of hipGraphs cut at the collectives: local | all-to-all | encoder stripe (cut at each "
+                                       "split attention) | gather | heads + decode/NMS" if striped
                                   else f"hipGraph(local stage) -> {coll_name} -> hipGraph(fusion tail + decode/NMS)"),
                        "frames_in_flight": (ring.depth if ring is not None else 1),
                        "frame_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),

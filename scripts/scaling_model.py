@@ -9,6 +9,13 @@ exactly as `_Sharded.capture` does and replayed ALONE on this GPU (HIP events), 
     period(N)   = max( max_r local_r + exchange,  local_0 + exchange + tail )           (rank 0 runs the tail; the other
                   ranks' next local stage overlaps it, the next exchange waits for rank 0)
 
+Config 5 (HeterModelBaseline + V2X-ViT), N > 1: the tail is STRIPED over the ranks (dist.ShardedBaselineStriped).  Its stages are
+timed the same way -- the encoder on one [L, H / N, W, C] stripe with the all-gather replaced by a local copy, the heads + decode
+on rank 0 -- and its exchanges priced from their bytes: the all-to-all sends (N - 1) / N of a rank's maps over N - 1 links in
+parallel, the three all-gathers of column sums are latency (30 us each assumed), the gather brings 1 / N of one map per link:
+
+    period(N) = max_r local_r + all_to_all + encoder_stripe + 3 x all_gather + gather + heads       (`striped_*` fields)
+
 This is a MODEL, not a measurement: no multi-GPU hardware was available to the builder (SCALE_r01/r02: skipped).  It is what
 the first hardware run is to be checked against.
 
@@ -103,10 +110,44 @@ def main():
             senders = [r for r in range(1, N)]
             exch_ms = (slots_per_rank(n_agents, N) * shard_bytes / (LINK_GBS * 1e9) * 1e3) if senders else 0.0
             period = max(max(local_ms) + exch_ms, local_ms[0] + exch_ms + tail_ms)
+            striped = None
+            if baseline and N > 1 and getattr(runners[0], "_encoder", None) is not None and shape[1] % (N * 16) == 0:
+                from heal_amd.dist import unpack_maps
+                C_, H_, W_ = shape
+                Hs = H_ // N
+                ego = unpack_maps(gathered, shape, n_agents, N)                               # [L, C, H, W]
+                xs = ego[:, :, :Hs].permute(0, 2, 3, 1).contiguous()                          # stripe 0, token-major
+
+                class _Local:   # timing stand-in: every rank's column sums are this stripe's
+                    world = N
+
+                    def all_gather(self, t):
+                        return t.unsqueeze(0).repeat(N, *([1] * t.dim()))
+                enc = runners[0]._encoder()
+                mods_ = runners[0]._stripe_modules()
+                for m_ in mods_:
+                    m_._stripe = _Local()
+                y, enc_ms, g = timed_graph(lambda: enc(xs)[0].contiguous(), stream)
+                for m_ in mods_:
+                    m_._stripe = None
+                keep.append((g, xs, y))
+                fused = y.repeat(N, 1, 1).permute(2, 0, 1).unsqueeze(0).contiguous()
+                _, heads_ms, g = timed_graph(lambda: post_fn(dict(zip(("cls_preds", "reg_preds", "dir_preds"),
+                                                                     pipe.model.heads(fused)))), stream)
+                keep.append((g, fused))
+                map_bytes = C_ * H_ * W_ * 4
+                a2a_ms = slots_per_rank(n_agents, N) * map_bytes / N / (LINK_GBS * 1e9) * 1e3     # per link: one stripe per slot
+                ag_ms, gat_ms = 3 * 0.03, map_bytes / N / (LINK_GBS * 1e9) * 1e3
+                sp = max(local_ms) + a2a_ms + enc_ms + ag_ms + gat_ms + heads_ms
+                striped = {"encoder_stripe_ms": round(enc_ms, 3), "heads_ms": round(heads_ms, 3), "all_to_all_ms_model": round(a2a_ms, 3),
+                           "all_gathers_ms_assumed": ag_ms, "gather_ms_model": round(gat_ms, 3), "period_ms_model": round(sp, 3)}
+                period = sp
             rows.append({"n_gpus": N, "owned": [owned_agents(n_agents, r, N) for r in range(N)],
                          "local_ms": [round(v, 3) for v in local_ms], "tail_ms": round(tail_ms, 3),
                          "shard_MB": round(shard_bytes / 1e6, 2), "exchange_ms_model": round(exch_ms, 3),
-                         "period_ms_model": round(period, 3), "scenes_per_s_model": round(1e3 / period, 1)})
+                         "period_ms_model": round(period, 3), "scenes_per_s_model": round(1e3 / period, 1),
+                         "serial_tail_period_ms_model": round(max(max(local_ms) + exch_ms, local_ms[0] + exch_ms + tail_ms), 3),
+                         "striped": striped})
             print(json.dumps(rows[-1]), flush=True)
     base = rows[0]["period_ms_model"]
     for r in rows:
