@@ -110,6 +110,8 @@ _SIGNATURES = {
                                c_void_p, c_void_p]),
     "heal_agent_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                      c_int, c_void_p, c_int, c_void_p]),
+    "heal_agent_attention_backward": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_float, c_int] + [c_void_p] * 3 +
+                                      [c_int, c_void_p]),
     "heal_grouped_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
     "heal_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1,6 +1,8 @@
 """Single-scale fusion operators used by HeterModelBaseline (reference: opencood/models/fuse_modules/
 fusion_in_one.py): MaxFusion (:87-124), AttFusion (:126-151, :14-45), V2XViTFusion (:320-372).
 Warping to the ego frame is K5's heal_warp_agent; the per-pixel attention is K6."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -66,6 +68,9 @@ class AttFusion(_WarpThenFuse):
         x = ego.reshape(n, C, H * W).permute(2, 0, 1).contiguous()      # [HW, n, C]
         if torch.is_grad_enabled() and ego.requires_grad:
             # gradient path (fusion_in_one.py:14-45,126-151): softmax(x x^T / sqrt(C)) x per pixel, the ego row
+            if n <= 8 and ops.agent_attention_train_supported(x, 1) and os.environ.get("HEAL_ATTN_GRAD", "kernel") != "torch":
+                # K6 forward (ego row) + heal_agent_attention_backward; x enters as q, k and v: autograd sums the three gradients
+                return ops.AgentAttention.apply(x, x, x, 1, 1.0 / self.sqrt_dim, 1, False)[:, 0, :].t().reshape(C, H, W)
             attn = torch.softmax(torch.bmm(x, x.transpose(1, 2)) / self.sqrt_dim, dim=-1)
             return torch.bmm(attn, x)[:, 0, :].t().reshape(C, H, W)
         h = ops.agent_attention(x, x, x, heads=1, scale=1.0 / self.sqrt_dim, out_rows=1)  # ego row only

@@ -161,8 +161,15 @@ class HGTCavAttention(nn.Module):
             v = self.v_linears[0](flat).view(L, H * W, m, d)
             qa = torch.einsum("lphd,hde->lphe", q, self.relation_att[0])
             vm = torch.einsum("lphd,hde->lphe", v, self.relation_msg[0])
-            att = torch.einsum("iphd,jphd->phij", qa, k) * self.scale            # [HW, m, L, L]
-            out = torch.einsum("phij,jphd->iphd", att.softmax(dim=-1), vm)       # [L, HW, m, d]
+            if (L <= 8 and m * d == 256 and ops.agent_attention_train_supported(flat, m)
+                    and os.environ.get("HEAL_ATTN_GRAD", "kernel") != "torch"):
+                # on the device: K6 forward + heal_agent_attention_backward (no [HW, m, L, L] score / [L, HW, m, d] message tensors
+                # kept for the backward: q, k, v are saved and the probabilities recomputed per pixel)
+                out = ops.AgentAttention.apply(qa.reshape(L, H * W, m * d), k.reshape(L, H * W, m * d),
+                                               vm.reshape(L, H * W, m * d), m, self.scale, L, True).view(L, H * W, m, d)
+            else:
+                att = torch.einsum("iphd,jphd->phij", qa, k) * self.scale        # [HW, m, L, L]
+                out = torch.einsum("phij,jphd->iphd", att.softmax(dim=-1), vm)   # [L, HW, m, d]
             return self.drop_out(self.a_linears[0](out.reshape(L, H * W, m * d))).reshape(L, H, W, C)
         w, b = self._folded_qkv()
         qkv = torch.addmm(b, x.reshape(-1, C), w)                       # [L*H*W, 3*inner]

@@ -1195,6 +1195,50 @@ def agent_attention(q, k, v, heads, scale, key_mask=None, out_rows=None, agent_m
     return out
 
 
+def agent_attention_backward(q, k, v, grad_out, heads, scale, key_mask=None, agent_major=False):
+    """Backward of agent_attention: grad_out [n_pix, out_rows, 256] (or [out_rows, n_pix, 256]) -> (grad_q, grad_k, grad_v), each
+    shaped like q.  Rows >= out_rows of the forward output were not produced and carry no gradient."""
+    q = _need(q, torch.float32, "q"); k = _need(k, torch.float32, "k"); v = _need(v, torch.float32, "v")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    if agent_major:
+        L, n_pix, C = (int(x) for x in q.shape)
+        rows = int(grad_out.shape[0])
+    else:
+        n_pix, L, C = (int(x) for x in q.shape)
+        rows = int(grad_out.shape[1])
+    if key_mask is not None:
+        key_mask = _need(key_mask, torch.int32, "key_mask")
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    with _Timed(f"agent_attention_bwd_h{heads}"):
+        _capi.call("heal_agent_attention_backward", _ptr(q), _ptr(k), _ptr(v), _optr(key_mask), _ptr(grad_out), n_pix, L, C,
+                   int(heads), float(scale), rows, _ptr(gq), _ptr(gk), _ptr(gv), int(bool(agent_major)), _stream())
+    return gq, gk, gv
+
+
+class AgentAttention(torch.autograd.Function):
+    """agent_attention under autograd (the gradient path of HGTCavAttention and AttFusion on the device): forward = K6, backward =
+    heal_agent_attention_backward; saves q, k, v only (the L x L probabilities are recomputed per pixel)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, out_rows, agent_major):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (int(heads), float(scale), bool(agent_major))
+        return agent_attention(q, k, v, heads, scale, out_rows=out_rows, agent_major=agent_major)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v = ctx.saved_tensors
+        heads, scale, am = ctx.cfg
+        gq, gk, gv = agent_attention_backward(q, k, v, grad_out.contiguous(), heads, scale, agent_major=am)
+        return gq, gk, gv, None, None, None, None
+
+
+def agent_attention_train_supported(q, heads):
+    """The device gradient path: fp32 CUDA tensors, 256 channels, at most 8 agents, heads in {1, 4, 8, 16}."""
+    return bool(q.is_cuda and q.dtype == torch.float32 and q.shape[-1] == 256 and heads in (1, 4, 8, 16))
+
+
 # ------------------------------------------------------------------------------------------------ K6c
 def ln_stats(x, eps):
     """(mean, rstd) of every token of x [..., C] -> [T, 2] f32: the statistics half of a LayerNorm whose application is

@@ -396,6 +396,12 @@ int heal_agent_attention(const float* q, const float* k, const float* v, const i
                          int n_agents, int channels, int heads, float scale, int out_rows, float* out,
                          int agent_major /* 1: q, k, v, out are [n_agents, n_pix, 256] (the token order of the transformer) */,
                          void* stream);
+/* Backward of the same operator (training; the reference differentiates its einsum / bmm formulation through autograd:
+ * hmsa.py:131-146, fusion_in_one.py:37-44): grad_out [n_pix, out_rows, 256] (rows >= out_rows carry no gradient) ->
+ * grad_q, grad_k, grad_v [n_pix, n_agents, 256], every element written.  The probabilities are recomputed from q and k.       */
+int heal_agent_attention_backward(const float* q, const float* k, const float* v, const int32_t* key_mask,
+                                  const float* grad_out, int n_pix, int n_agents, int channels, int heads, float scale,
+                                  int out_rows, float* grad_q, float* grad_k, float* grad_v, int agent_major, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7 helpers for the dense BEV stacks.

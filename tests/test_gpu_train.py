@@ -338,3 +338,78 @@ def test_inference_operator_refuses_autograd_activations():
         ops.conv1x1(x, w)
     with torch.no_grad():
         ops.conv1x1(x, w)   # fine without a graph
+
+
+@pytest.mark.parametrize("heads,L,agent_major,out_rows,masked", [(8, 5, True, 5, False), (1, 3, False, 1, False),
+                                                                  (16, 8, True, 8, True), (4, 2, False, 2, False),
+                                                                  (8, 1, True, 1, False)])
+def test_agent_attention_backward_kernel_vs_float64_autograd(heads, L, agent_major, out_rows, masked):
+    """K6 backward (heal_agent_attention_backward behind ops.AgentAttention) against autograd of the reference's composition
+    (hmsa.py:131-146: scores -> masked softmax over agents -> weighted sum; fusion_in_one.py:37-44 for one head and the ego row)
+    differentiated on the CPU in FLOAT64: output and the three gradients within 1e-5 of their scale."""
+    from heal_amd import ops
+    g = np.random.default_rng(7 * heads + L)
+    P, C = 203, 256
+    d = C // heads
+    scale = d ** -0.5
+    shape = (L, P, C) if agent_major else (P, L, C)
+    q, k, v = (torch.from_numpy((g.standard_normal(shape) * 1.5).astype(np.float32)).cuda().requires_grad_(True) for _ in range(3))
+    mask = None
+    if masked:
+        mask_np = np.ones(L, np.int32)
+        mask_np[-2:] = 0
+        mask = torch.from_numpy(mask_np).cuda()
+    oshape = (out_rows, P, C) if agent_major else (P, out_rows, C)
+    wgt = torch.from_numpy(g.standard_normal(oshape).astype(np.float32)).cuda()
+    if mask is None:
+        out = ops.AgentAttention.apply(q, k, v, heads, scale, out_rows, agent_major)
+        assert out.requires_grad
+        (out * wgt).sum().backward()
+        got = (out.detach(), q.grad, k.grad, v.grad)
+    else:   # the masked form has no autograd wrapper (HEAL never pads under training): forward + backward entry points directly
+        with torch.no_grad():
+            out = ops.agent_attention(q.detach(), k.detach(), v.detach(), heads, scale, key_mask=mask, out_rows=out_rows,
+                                      agent_major=agent_major)
+            got = (out,) + ops.agent_attention_backward(q.detach(), k.detach(), v.detach(), wgt, heads, scale, key_mask=mask,
+                                                        agent_major=agent_major)
+
+    def pm(t):     # -> [P, L, heads, d] float64 on the host
+        t = t.detach().double().cpu()
+        return (t.permute(1, 0, 2) if agent_major else t).reshape(P, -1, heads, d)
+    q64, k64, v64 = (pm(t).requires_grad_(True) for t in (q, k, v))
+    att = torch.einsum("pihd,pjhd->phij", q64, k64) * scale
+    if masked:
+        att = att.masked_fill(torch.from_numpy(mask_np == 0)[None, None, None, :], float("-inf"))
+    ref = torch.einsum("phij,pjhd->pihd", att.softmax(-1), v64)[:, :out_rows]
+    (ref * pm(wgt)).sum().backward()
+    for name, a, b in zip(("out", "grad_q", "grad_k", "grad_v"), got, (ref, q64.grad, k64.grad, v64.grad)):
+        b = b.detach()
+        # one agent: the softmax is constant, q and k get no gradient at all (0 against 0)
+        err = float((pm(a) - b).abs().max() / max(float(b.abs().max()), 1e-30))
+        assert err < 1e-5, (name, err)
+    if out_rows < L:
+        assert float(got[1].reshape(shape)[(slice(out_rows, None),) if agent_major else (slice(None), slice(out_rows, None))].abs().max()) == 0.0
+
+
+def test_attention_modules_gradient_path_kernel_equals_torch(monkeypatch):
+    """HGTCavAttention and AttFusion under autograd: the device path (K6 forward + backward kernels) and the torch composition
+    (HEAL_ATTN_GRAD=torch) give the same outputs and parameter / input gradients."""
+    from heal_amd.opencood.models.fuse_modules.fusion_in_one import AttFusion
+    from heal_amd.opencood.models.sub_modules.v2xvit_basic import HGTCavAttention
+    torch.manual_seed(11)
+    att = HGTCavAttention(256, heads=8, dim_head=32, dropout=0.0).cuda().train()
+    x = torch.randn(3, 12, 16, 256, device="cuda", requires_grad=True)
+    fus = AttFusion(256).cuda()
+    e = torch.randn(4, 256, 10, 12, device="cuda", requires_grad=True)
+    res = {}
+    for mode in ("kernel", "torch"):
+        monkeypatch.setenv("HEAL_ATTN_GRAD", mode)
+        att.zero_grad(); x.grad = None; e.grad = None
+        y = att(x)
+        (y * y).sum().backward()
+        z = fus.fuse_warped(e)
+        z.square().sum().backward()
+        res[mode] = [y.detach(), x.grad.clone(), att.relation_att.grad.clone(), att.q_linears[0].weight.grad.clone(),
+                     att.v_linears[0].weight.grad.clone(), z.detach(), e.grad.clone()]
+    for a, b in zip(res["kernel"], res["torch"]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-4
