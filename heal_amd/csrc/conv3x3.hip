@@ -238,7 +238,12 @@ struct WgGeom {
     static constexpr int UQ = XW * 2;                    // float4 of U per lane per chunk (XW xi x 2 k-steps x 4 m-tiles floats)
 };
 
-template <int NW>
+// EXACT (Cin % 8 == 0: every shape of the two BASELINE scenes): the addresses of the loop are a UNIFORM base that advances by one
+// chunk plus per-thread byte offsets fixed before the loop -- `global_load v, v_off, s[base]` with no vector ALU work per load.
+// Round 3 recomputed, per chunk and element, the clamped channel, a 64-bit `channel * HW + offset` and the in-range predicate of
+// the store: ~60 of the 150 non-MFMA instructions of an iteration, all in the transform phase the matrix pipe waits for.
+// The zero padding is written ONCE (slots outside the image keep their zero: their loads land in the dummy zone).
+template <int NW, bool EXACT>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restrict__ x, const float4* __restrict__ ufrag,
                                                          const float* __restrict__ bias, const float* __restrict__ res,
                                                          int Cin, int nchunks, int Cout, int H, int W, int tiles_x, int relu,
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
     // predicated loads put every load in its own basic block, and the compiler's waitcnt insertion then falls back to
     // `s_waitcnt vmcnt(0)` at each of them -- which drains the U loads issued just before and serialises one L2 round trip per
     // chunk (visible in the ISA of the first version of this loop; scripts/wg_dbg.py: 125 + 76 us of 654 us).
-    int p_off[NP];      // offset inside the image plane (clamped to 0 when outside)
+    int p_off[NP];      // offset inside the image plane (clamped to 0 when outside); EXACT: BYTE offset from the chunk's base
     int p_lds[NP];      // LDS word (slots beyond the patch land in the dummy zone: no branch around the store -- a conditional
                         // store lets the compiler sink the LOAD into the branch, right in front of its wait)
     unsigned p_ok = 0;  // bit j: element j lies inside the image and the patch
@@ -281,29 +286,50 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
         p_off[j] = ok ? gy * W + gx : 0;
         p_ok |= ok ? (1u << j) : 0u;
         p_lds[j] = e < WG_KC * PE ? ci * PCI + py * WG_PROW + px : WG_KC * PCI + (e - WG_KC * PE) % WG_PDUMMY;
+        if constexpr (EXACT) {
+            if (!ok && e < WG_KC * PE) {      // padding: zero once, then send this slot's (clamped) loads to the dummy zone
+                sP[p_lds[j]] = 0.f;
+                p_lds[j] = WG_KC * PCI + e % WG_PDUMMY;
+            }
+            p_off[j] = (int)(((size_t)min(ci, WG_KC - 1) * HW + (size_t)p_off[j]) * sizeof(float));   // < 8 HW 4 B: fits (host check)
+        }
     }
     float pst[NP];
+    const size_t chunk_bytes = (size_t)WG_KC * HW * sizeof(float);
     auto load_patch = [&](int c) {
+        if constexpr (EXACT) {
+            const char* __restrict__ cb = reinterpret_cast<const char*>(xin) + (size_t)c * chunk_bytes;   // uniform
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int ch = min(c * WG_KC + (int)(threadIdx.x + NT * j) / PE, Cin - 1);
-            pst[j] = xin[(size_t)ch * HW + p_off[j]];
+            for (int j = 0; j < NP; ++j) pst[j] = *reinterpret_cast<const float*>(cb + (unsigned)p_off[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int ch = min(c * WG_KC + (int)(threadIdx.x + NT * j) / PE, Cin - 1);
+                pst[j] = xin[(size_t)ch * HW + p_off[j]];
+            }
         }
     };
     auto store_patch = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int ci = (int)(threadIdx.x + NT * j) / PE;
-            const bool ok = ((p_ok >> j) & 1u) && c * WG_KC + ci < Cin;
-            sP[p_lds[j]] = ok ? pst[j] : 0.f;
+            if constexpr (EXACT) {
+                sP[p_lds[j]] = pst[j];
+            } else {
+                const int ci = (int)(threadIdx.x + NT * j) / PE;
+                const bool ok = ((p_ok >> j) & 1u) && c * WG_KC + ci < Cin;
+                sP[p_lds[j]] = ok ? pst[j] : 0.f;
+            }
         }
     };
     // U fragments of this wave: XW*8 floats per lane per chunk, lane-major: [mb][chunk][wave][lane][(xi_i*2 + ks)*4 + mt]
-    const float4* __restrict__ ubase = ufrag + (((size_t)mb * nchunks * NW + wave) * 64 + l) * UQ;
+    // (uniform chunk base + a per-lane byte offset: no vector address arithmetic per load)
+    const char* __restrict__ ublock = reinterpret_cast<const char*>(ufrag + (size_t)mb * nchunks * NW * 64 * UQ);
+    const unsigned u_off = (unsigned)((wave * 64 + l) * UQ * sizeof(float4));
     float4 ua[UQ];
     auto load_u = [&](int c) {
+        const char* __restrict__ ub = ublock + (size_t)c * (NW * 64 * UQ * sizeof(float4));
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) ua[q] = ubase[(size_t)c * NW * 64 * UQ + q];
+        for (int q = 0; q < UQ; ++q) ua[q] = *reinterpret_cast<const float4*>(ub + u_off + q * sizeof(float4));
     };
 
     f32x4 acc[XW][4][NTN];
@@ -640,12 +666,14 @@ extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const 
                  "conv3x3_winograd: map too large for the launch grid");
     const dim3 grid(tiles_x * tiles_y, n, mblocks);
     const float4* uf = reinterpret_cast<const float4*>(u_frag);
-    if (waves == 8)
-        HEAL_LAUNCH_EV(k_conv3x3_wino<8>, grid, dim3(512), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, cout, H, W,
-                       tiles_x, relu, y);
-    else
-        HEAL_LAUNCH_EV(k_conv3x3_wino<4>, grid, dim3(256), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, cout, H, W,
-                       tiles_x, relu, y);
+    // uniform-base addressing (see the kernel): whole chunks and byte offsets inside a chunk that fit 32 bits
+    const bool exact = cin % WG_KC == 0 && (long long)WG_KC * H * W * 4 < 2147483647ll;
+#define HEAL_WINO_LAUNCH(NW_, EX_)                                                                                              \
+    HEAL_LAUNCH_EV((k_conv3x3_wino<NW_, EX_>), grid, dim3(64 * NW_), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, \
+                   cout, H, W, tiles_x, relu, y)
+    if (waves == 8) { if (exact) HEAL_WINO_LAUNCH(8, true); else HEAL_WINO_LAUNCH(8, false); }
+    else { if (exact) HEAL_WINO_LAUNCH(4, true); else HEAL_WINO_LAUNCH(4, false); }
+#undef HEAL_WINO_LAUNCH
     HEAL_LAUNCH_CHECK();
     return 0;
 }
