@@ -77,6 +77,9 @@ __device__ __forceinline__ int vox_agent(const VoxBatch& vb, int i) {
 // 1. insert: table_key[slot] = (agent, cell), table_min[slot] = min point index, ticket; slot_of[i] = slot or -1.
 // (Grouping the lanes of a wave by cell first -- ballot matching, one set of atomics per group leader -- was measured on three
 // 64-line sweeps: 35 us against 26 us for this form; the matching loop costs more than the same-address atomics it saves.)
+// DENSE (round 4, pillar grids): when agents x cells fits the table the cell IS the slot -- no key array, no probe, no CAS claim
+// (131 072 cells x 3 agents against 524 288 slots in scene 5); what follows only uses slots as ids, so the output is unchanged.
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
                                                     uint32_t cells, uint32_t* __restrict__ tkey,
                                                     uint32_t* __restrict__ tmin, uint32_t* __restrict__ tcnt, uint32_t mask,
@@ -90,15 +93,18 @@ __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ 
     // Scattered device-scope atomics run at a fixed rate (~27 G operations/s chip-wide): every one that a plain read can rule out is
     // time saved.  A plain read may be stale, but only in the harmless direction: a key seen as the cell's own is final (keys are
     // written once), a key seen as EMPTY / a minimum seen too large just falls through to the atomic.
-    uint32_t slot = hash_u32(cell) & mask;
-    for (;;) {
-        const uint32_t seen = tkey[slot];
-        if (seen == cell) break;                       // claimed earlier by another point of this cell: no CAS
-        if (seen == HASH_EMPTY) {
-            const uint32_t prev = atomicCAS(&tkey[slot], HASH_EMPTY, cell);
-            if (prev == HASH_EMPTY || prev == cell) break;
+    uint32_t slot = cell;
+    if constexpr (!DENSE) {
+        slot = hash_u32(cell) & mask;
+        for (;;) {
+            const uint32_t seen = tkey[slot];
+            if (seen == cell) break;                       // claimed earlier by another point of this cell: no CAS
+            if (seen == HASH_EMPTY) {
+                const uint32_t prev = atomicCAS(&tkey[slot], HASH_EMPTY, cell);
+                if (prev == HASH_EMPTY || prev == cell) break;
+            }
+            slot = (slot + 1) & mask;
         }
-        slot = (slot + 1) & mask;
     }
     if (tmin[slot] > (uint32_t)i) atomicMin(&tmin[slot], (uint32_t)i);   // (a stale value is >= the true one: skipping is safe)
     tick[i] = atomicAdd(&tcnt[slot], 1u) + 1u;     // the counter starts at 0xFFFFFFFF: tickets 0, 1, ...; final value = points - 1
@@ -423,7 +429,11 @@ static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& 
     HEAL_REQUIRE(carve(a, n, cap, P, w), "%s: workspace too small (%zu < %zu)", who, ws_bytes, a.off);
     const int nb = ceil_div(n, 256);
     HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, w.ff_bytes, s));
-    k_voxb_insert<<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
+    static const bool dense_ok = [] { const char* e = getenv("HEAL_VOX_DENSE"); return !(e && e[0] == '0'); }();
+    if (dense_ok && (unsigned long long)vb.B * cells <= (unsigned long long)w.tcap)
+        k_voxb_insert<true><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
+    else
+        k_voxb_insert<false><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
     k_vox_assign<<<n_tiles, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.tcnt, w.tile_pub, w.part_pub, n_tiles,
                                          max_voxels, row_offset, w.tvid, w.tseg, w.row_seg, w.row_cnt, coords, offsets_out,
                                          n_voxels_out, row_offset_next, w.meta);
