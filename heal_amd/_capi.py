@@ -139,6 +139,9 @@ _SIGNATURES = {
     "heal_nms_quads": (c_int, [c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "heal_window_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p]),
+    "heal_window_attention_backward_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "heal_window_attention_backward": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                c_void_p]),
     "heal_label_assign_workspace": (c_size_t, [c_int]),
     "heal_label_assign": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

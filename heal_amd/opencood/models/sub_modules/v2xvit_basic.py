@@ -257,6 +257,10 @@ class BaseWindowAttention(nn.Module):
             # the [windows, T, T] score tensor (heal_window_attention): 16x (ws 4), 4x (ws 8) and 1.7x (ws 16) faster
             # than the library sequence at 8 agents x 128 x 128
             return self.to_out[0](ops.window_attention(qkv, bias, m, d, ws, self.scale))
+        if (x.is_cuda and _grad_path(x, self) and os.environ.get("HEAL_WATTN_GRAD", "torch") == "kernel"
+                and ops.window_attention_supported(ws, d, H, W) and qkv.dtype == torch.float32):
+            # opt-in (unmeasured): K6b forward + heal_window_attention_backward instead of the library composition below
+            return self.to_out(ops.WindowAttention.apply(qkv, bias, m, d, ws, self.scale))
         qkv = qkv.view(L, nh, ws, nw, ws, 3, m, d)
         qkv = qkv.permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, L * m * nh * nw, ws * ws, d)
         dots = torch.baddbmm(bias.unsqueeze(0).expand(qkv.shape[1], -1, -1), qkv[0], qkv[1].transpose(1, 2),

@@ -641,6 +641,45 @@ def window_attention(qkv, pos_bias, heads, dim_head, window, scale, out=None):
     return out
 
 
+def window_attention_backward(qkv, pos_bias, out, grad_out, heads, dim_head, window, scale):
+    """Backward of window_attention -> (grad_qkv like qkv, grad_bias [T,T] | None).  Unmeasured so far: the modules use it only
+    under HEAL_WATTN_GRAD=kernel."""
+    qkv = _need(qkv, torch.float32, "qkv"); out = _need(out, torch.float32, "out"); grad_out = _need(grad_out, torch.float32, "grad_out")
+    L, H, W, C3 = (int(v) for v in qkv.shape)
+    if C3 != 3 * heads * dim_head or not window_attention_supported(window, dim_head, H, W):
+        raise _capi.HealAmdError(f"window_attention_backward: unsupported shape (window {window}, dim_head {dim_head}, map {H}x{W})")
+    grad_qkv = torch.empty_like(qkv)
+    grad_bias = None
+    if pos_bias is not None:
+        pos_bias = _need(pos_bias, torch.float32, "pos_bias")
+        grad_bias = torch.zeros_like(pos_bias)
+    need = _capi.query("heal_window_attention_backward_workspace", L, H, W, int(heads))
+    ws = _workspace("window_attention_bwd", need, qkv.device)
+    _capi.call("heal_window_attention_backward", _ptr(qkv), _optr(pos_bias), _ptr(out), _ptr(grad_out), L, H, W, int(heads),
+               int(dim_head), int(window), float(scale), _ptr(grad_qkv), _optr(grad_bias), _ptr(ws), need, _stream())
+    return grad_qkv, grad_bias
+
+
+class WindowAttention(torch.autograd.Function):
+    """window_attention under autograd: forward = K6b, backward = heal_window_attention_backward (saves qkv, the bias table and
+    the output; the T x T probabilities are recomputed per window)."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos_bias, heads, dim_head, window, scale):
+        qkv = qkv.contiguous()
+        out = window_attention(qkv, pos_bias, heads, dim_head, window, scale)
+        ctx.save_for_backward(qkv, pos_bias, out)
+        ctx.cfg = (int(heads), int(dim_head), int(window), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        qkv, pos_bias, out = ctx.saved_tensors
+        heads, dim_head, window, scale = ctx.cfg
+        gq, gb = window_attention_backward(qkv, pos_bias, out, grad_out.contiguous(), heads, dim_head, window, scale)
+        return gq, gb, None, None, None, None
+
+
 def label_assign(anchor_boxes, gt_boxes, pos_threshold, neg_threshold):
     """Anchor labelling core of generate_label: stand-up boxes [N,4] / [G,4] f32 cuda -> (assigned [N] i32: gt index of a
     positive anchor or -1, neg [N] u8)."""

@@ -625,6 +625,14 @@ int heal_nms_quads(const float* quads_sorted, int n, float thresh, void* workspa
  *   (window, dim_head) in {(4,16),(8,32),(16,64),(4,32),(8,16),(8,64),(4,64)}; H, W multiples of window.          */
 int heal_window_attention(const float* qkv, const float* pos_bias, int n_agents, int H, int W, int heads,
                           int dim_head, int window, float scale, float* out, void* stream);
+/* Backward of heal_window_attention (training; the reference differentiates mswin.py:64-78 through autograd).  OPT-IN in the host
+ * mirror until measured (HEAL_WATTN_GRAD=kernel).  out = the forward's result, grad_out its gradient, both [L,H,W,heads*dim_head];
+ * grad_qkv [L,H,W,3*heads*dim_head] is written completely; grad_bias [T,T] (or NULL) is ACCUMULATED with atomics into a buffer the
+ * caller zeroes (the sum over agents, windows and heads).  Workspace: (max, 1/sum, dO.O) per query and head.                      */
+size_t heal_window_attention_backward_workspace(int n_agents, int H, int W, int heads);
+int heal_window_attention_backward(const float* qkv, const float* pos_bias, const float* out, const float* grad_out, int n_agents,
+                                   int H, int W, int heads, int dim_head, int window, float scale, float* grad_qkv,
+                                   float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- V2X-ViT linear algebra (opencood/models/sub_modules/base_transformer.py:7-40, hmsa.py:38-151, mswin.py:46-122,
  * split_attn.py:6-62, v2xvit_basic.py:158-192): token-major fp32 GEMM on v_mfma_f32_32x32x2_f32 with the LayerNorm of PreNorm

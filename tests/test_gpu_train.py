@@ -413,3 +413,37 @@ def test_attention_modules_gradient_path_kernel_equals_torch(monkeypatch):
                      att.v_linears[0].weight.grad.clone(), z.detach(), e.grad.clone()]
     for a, b in zip(res["kernel"], res["torch"]):
         assert float((a - b).abs().max() / b.abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("ws,d,m,use_bias", [(4, 16, 16, True), (8, 32, 8, True), (16, 64, 4, True), (8, 32, 8, False)])
+def test_window_attention_backward_kernel_vs_float64_autograd(ws, d, m, use_bias):
+    """K6b backward (heal_window_attention_backward behind ops.WindowAttention; opt-in in the modules, HEAL_WATTN_GRAD=kernel)
+    against autograd of the reference's composition (mswin.py:64-78: window re-layout, scores + position bias, softmax, weighted
+    sum) differentiated on the CPU in FLOAT64: output, grad_qkv and grad_bias within 2e-5 of their scale."""
+    from heal_amd import ops
+    g = np.random.default_rng(100 + ws)
+    L, H, W = 2, 16, 32
+    C = m * d
+    T = ws * ws
+    scale = d ** -0.5
+    qkv = torch.from_numpy((g.standard_normal((L, H, W, 3 * C)) * 0.8).astype(np.float32)).cuda().requires_grad_(True)
+    bias = torch.from_numpy(g.standard_normal((T, T)).astype(np.float32)).cuda().requires_grad_(True) if use_bias else None
+    wgt = torch.from_numpy(g.standard_normal((L, H, W, C)).astype(np.float32)).cuda()
+    out = ops.WindowAttention.apply(qkv, bias, m, d, ws, scale)
+    (out * wgt).sum().backward()
+
+    q64 = qkv.detach().double().cpu().requires_grad_(True)
+    b64 = bias.detach().double().cpu().requires_grad_(True) if use_bias else None
+    nh, nw = H // ws, W // ws
+    t = q64.view(L, nh, ws, nw, ws, 3, m, d).permute(5, 0, 6, 1, 3, 2, 4, 7).reshape(3, L * m * nh * nw, T, d)
+    dots = torch.matmul(t[0], t[1].transpose(1, 2)) * scale
+    if use_bias:
+        dots = dots + b64[None]
+    ref = torch.matmul(dots.softmax(-1), t[2]).view(L, m, nh, nw, ws, ws, d).permute(0, 2, 4, 3, 5, 1, 6).reshape(L, H, W, C)
+    (ref * wgt.double().cpu()).sum().backward()
+    pairs = [("out", out.detach(), ref.detach()), ("grad_qkv", qkv.grad, q64.grad)]
+    if use_bias:
+        pairs.append(("grad_bias", bias.grad, b64.grad))
+    for name, a, b in pairs:
+        err = float((a.double().cpu() - b).abs().max() / b.abs().max())
+        assert err < 2e-5, (name, err)
