@@ -447,3 +447,22 @@ def test_window_attention_backward_kernel_vs_float64_autograd(ws, d, m, use_bias
     for name, a, b in pairs:
         err = float((a.double().cpu() - b).abs().max() / b.abs().max())
         assert err < 2e-5, (name, err)
+
+
+def test_window_attention_module_gradient_path_kernel_equals_torch(monkeypatch):
+    """BaseWindowAttention under autograd: the opt-in device path (HEAL_WATTN_GRAD=kernel) and the library composition give the
+    same output and the same gradients of the input, the projections and the relative-position table."""
+    from heal_amd.opencood.models.sub_modules.v2xvit_basic import BaseWindowAttention
+    torch.manual_seed(13)
+    att = BaseWindowAttention(256, heads=8, dim_head=32, drop_out=0.0, window_size=8, relative_pos_embedding=True).cuda().train()
+    x = torch.randn(2, 16, 24, 256, device="cuda", requires_grad=True)
+    res = {}
+    for mode in ("kernel", "torch"):
+        monkeypatch.setenv("HEAL_WATTN_GRAD", mode)
+        att.zero_grad(); x.grad = None
+        y = att(x)
+        (y * y).sum().backward()
+        res[mode] = [y.detach(), x.grad.clone(), att.to_qkv.weight.grad.clone(), att.pos_embedding.grad.clone(),
+                     att.to_out[0].weight.grad.clone()]
+    for a, b in zip(res["kernel"], res["torch"]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-4
