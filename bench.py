@@ -544,8 +544,10 @@ def main():
             sdt = float(t_.item())
         latency_ms = sdt / a.steps * 1e3
         serial = {"value": round(a.steps / sdt, 3), "unit": "scenes/s", "ms_per_step": round(latency_ms, 3), "steps": a.steps,
-                  "warmup": a.warmup, "what": "one frame at a time: hipGraph replay of the whole step, boxes read back before the "
-                                              "next frame is submitted (frames_in_flight = 1)"}
+                  "warmup": a.warmup,
+                  "what": ("one frame at a time: " + ("hipGraph replay of the whole step" if solo else
+                                                     "hipGraph replays of the rank-local stages around the exchange(s)")
+                           + ", boxes read back before the next frame is submitted (frames_in_flight = 1)")}
     for _ in range(a.warmup):
         step()
     if ring is not None:
