@@ -19,6 +19,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "heal_abi_version": (c_int, []),
     "heal_last_error": (ctypes.c_char_p, []),
+    "heal_fill_bytes": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "heal_next_launch_events": (c_int, [c_void_p, c_void_p]),
     "heal_voxelize_workspace": (c_size_t, [c_int, c_int, c_int]),
     "heal_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -199,14 +200,43 @@ def lib():
     return _lib
 
 
+# HEAL_TRACE_CALLS=1: debugging aid for GPU memory faults (a fault kills the process without a Python traceback).  Every C-ABI call
+# is announced on stderr BEFORE it is issued and the device is synchronised AFTER it (outside stream captures), so the last line
+# printed names the faulting operator.  =2 also prints the pointer / integer arguments.
+_TRACE = int(os.environ.get("HEAL_TRACE_CALLS", "0") or 0)
+
+
+def _trace_call(name, args):
+    import sys
+    import torch
+    cap = torch.cuda.is_current_stream_capturing()
+    extra = ""
+    if _TRACE >= 2:
+        extra = " " + " ".join(hex(a.value or 0) if isinstance(a, ctypes.c_void_p) else str(a) for a in args
+                               if isinstance(a, (int, float, ctypes.c_void_p)))
+    print(f"[heal pid {os.getpid()}] {'capture ' if cap else ''}{name}{extra}", file=sys.stderr, flush=True)
+
+
+def _trace_done(name):
+    import sys
+    import torch
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        print(f"[heal pid {os.getpid()}]   ok {name}", file=sys.stderr, flush=True)
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise HealAmdError with heal_last_error() on failure."""
     L = lib()
     if not hasattr(L, name):
         raise HealAmdError(f"libheal_amd.so does not export {name}")
+    if _TRACE:
+        _trace_call(name, args)
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise HealAmdError(f"{name} failed: {L.heal_last_error().decode(errors='replace')}")
+    if _TRACE:
+        _trace_done(name)
 
 
 def query(name, *args):

@@ -1013,7 +1013,7 @@ extern "C" int heal_bev_pool(const float* depth_logit, const float* feat, const 
     HEAL_REQUIRE(carve(a, n_agents, n_cams, D, HW, channels, cells_total, w),
                  "bev_pool: workspace too small (%zu < %zu)", ws_bytes, a.off);
 
-    HEAL_HIP(hipMemsetAsync(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s));  // -1 = empty cell
+    HEAL_FILL(w.cell_map, 0xFF, (size_t)cells_total * sizeof(int), s);  // -1 = empty cell
     const uint32_t invalid_key = (uint32_t)cells_total;
     k_lss_keys<<<ceil_div(n_agents * n_cams * HW, 64), 256, 0, s>>>(
         depth_logit, frustum, reinterpret_cast<const CamMats*>(cam_mats), g,

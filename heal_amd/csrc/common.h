@@ -47,6 +47,19 @@ struct Arena {
 
 #define HEAL_LAUNCH_CHECK() HEAL_HIP(hipGetLastError())
 
+// fill_bytes: the library's ONLY way of initialising device memory (a kernel, prims.hip).  hipMemsetAsync is not used anywhere: captured
+// into a HIP graph it becomes a memset NODE, and in round 4 K1's 0xFF table fill came back from such a node with byte 0 of every
+// 16 B cleared (workspace dump in profiles/r05_k1_memset_node_dump.txt; DESIGN 5 "memory fault") -- the runtime's fill goes through
+// a pattern buffer that is not private to the node.  A kernel node carries its pattern in its own arguments.
+// dst and bytes must be multiples of 4; `byte` is replicated.  Returns 0 / sets the error text.
+int fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s);
+// 4-byte device-to-device copy as a kernel (dst <- *src, or 0 when src is null); same reason
+int copy_word(int* dst, const int* src, hipStream_t s);
+#define HEAL_FILL(dst, byte, bytes, s)                      \
+    do {                                                    \
+        if (heal::fill_bytes((dst), (byte), (bytes), (s))) return 1; \
+    } while (0)
+
 // Measurement hook (heal_next_launch_events): a thread-local pair of events armed by the caller and consumed by the next launch
 // that supports it (HEAL_LAUNCH_EV).  hipExtLaunchKernelGGL stamps the events with the kernel's OWN begin / end, the interval a
 // rocprofv3 kernel trace reports; an event pair recorded around a launch also holds the dispatch and marker latencies (3-5 us,

@@ -614,7 +614,7 @@ extern "C" int heal_decode_nms(const float* cls, const float* reg, const float* 
     (void)max_key;
     HEAL_REQUIRE(nms_top <= TOPK_CAP, "decode_nms: nms_top exceeds the top-k capacity");
 
-    HEAL_HIP(hipMemsetAsync(w.nb.n_cand, 0, sizeof(int), s));
+    HEAL_FILL(w.nb.n_cand, 0, sizeof(int), s);
     k_decode_key<<<ceil_div(n, 256), 256, 0, s>>>(cls, reg, dir, anchors, p, n, w.cand, w.nb.n_cand);
     const int words = ceil_div(nms_top, 64);
     k_rank_prepare<<<TOPK_CAP / RANK_PER_BLOCK, TOPK_THREADS, 0, s>>>(cls, reg, dir, anchors, p, n, w.cand, nms_top, w.nb);
@@ -663,7 +663,7 @@ extern "C" int heal_nms_quads(const float* quads_sorted, int n, float thresh, vo
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(n >= 0 && num_keep != nullptr, "nms_quads: bad arguments");
     if (n == 0) {
-        HEAL_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), s));
+        HEAL_FILL(num_keep, 0, sizeof(int), s);
         return 0;
     }
     HEAL_REQUIRE(quads_sorted && keep && workspace, "nms_quads: null pointer");

@@ -321,7 +321,7 @@ extern "C" int heal_gconv_conv3(const float* x, const float* weight_q, const flo
     static long long* dbg = nullptr;
     static const bool want_dbg = getenv("HEAL_GC3_DBG") != nullptr;
     if (want_dbg && !dbg) { HEAL_HIP(hipMalloc(&dbg, 128 * 8)); }
-    if (want_dbg) HEAL_HIP(hipMemsetAsync(dbg, 0, 128 * 8, s));
+    if (want_dbg) HEAL_FILL(dbg, 0, 128 * 8, s);
     HEAL_GC3(4, 64) HEAL_GC3(8, 128) HEAL_GC3(4, 128) HEAL_GC3(8, 64)
 #undef HEAL_GC3
     HEAL_LAUNCH_CHECK();

@@ -249,7 +249,7 @@ extern "C" int heal_nms_bev(const float* boxes_sorted, int n, float thresh, int 
     HEAL_REQUIRE(num_keep != nullptr, "heal_nms_bev: null num_keep");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        HEAL_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), st));
+        HEAL_FILL(num_keep, 0, sizeof(int), st);
         return 0;
     }
     HEAL_REQUIRE(boxes_sorted && keep && workspace, "heal_nms_bev: null pointer");

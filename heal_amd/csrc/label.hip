@@ -90,7 +90,7 @@ extern "C" int heal_label_assign(const float* anchor_boxes, int n_anchors, const
     HEAL_REQUIRE(ws_bytes >= heal_label_assign_workspace(n_gt) && ((uintptr_t)ws & 7) == 0,
                  "label_assign: workspace too small or misaligned");
     unsigned long long* best = (unsigned long long*)ws;
-    HEAL_HIP(hipMemsetAsync(best, 0, sizeof(unsigned long long) * (size_t)(n_gt < 1 ? 1 : n_gt), s));
+    HEAL_FILL(best, 0, sizeof(unsigned long long) * (size_t)(n_gt < 1 ? 1 : n_gt), s);
     k_label_iou<<<ceil_div(n_anchors, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(anchor_boxes), n_anchors,
                                                         reinterpret_cast<const float4*>(gt_boxes), n_gt, pos_threshold,
                                                         neg_threshold, assigned, neg, best);

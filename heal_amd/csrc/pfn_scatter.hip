@@ -476,7 +476,7 @@ extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, cons
     if (pf == nullptr) pf = a.take<float>((size_t)(n_voxels < 1 ? 1 : n_voxels) * channels);
     HEAL_REQUIRE(a.ok(), "pfn_scatter: workspace too small (%zu < %zu)", ws_bytes, a.off);
 
-    HEAL_HIP(hipMemsetAsync(cell_map, 0xFF, (size_t)n_agents * ny * nx * sizeof(int), s));
+    HEAL_FILL(cell_map, 0xFF, (size_t)n_agents * ny * nx * sizeof(int), s);
     if (n_voxels > 0) {
         PfnGeom g{vx, vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx};
         // one pillar per wave up to 32768 waves (a collated 3-agent launch is ~33 k pillars), beyond that a

@@ -93,9 +93,51 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const int* in, int*
         *total = tile_offset + lds[16];
 }
 
+// ------------------------------------------------------------------------------------------------
+// fill / one-word copy (see common.h: no hipMemsetAsync in this library)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_words(uint32_t* __restrict__ dst, uint32_t v, size_t words) {
+    // 16-B stores over the aligned body, words one by one at the ragged ends
+    const size_t head = (size_t)((16 - ((uintptr_t)dst & 15)) & 15) / 4;          // words in front of the first 16-B boundary
+    const size_t h = head < words ? head : words;
+    const size_t body = (words - h) / 4;
+    uint4* d4 = reinterpret_cast<uint4*>(dst + h);
+    const uint4 v4 = make_uint4(v, v, v, v);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < body; i += stride) d4[i] = v4;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h) dst[threadIdx.x] = v;
+        const size_t done = h + body * 4;
+        if (threadIdx.x < words - done) dst[done + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_copy_word(int* __restrict__ dst, const int* __restrict__ src) { *dst = src ? *src : 0; }
+
+int fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (dst == nullptr || (((uintptr_t)dst | bytes) & 3) != 0)
+        return set_error("fill_bytes: destination / size must be non-null multiples of 4 (%p, %zu)", dst, bytes);
+    const uint32_t b = (uint32_t)(byte & 0xFF), v = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t words = bytes / 4;
+    size_t blocks = (words / 4 + 255) / 256;                       // one 16-B store per thread up to 2048 blocks, then grid-stride
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    k_fill_words<<<(unsigned)blocks, 256, 0, s>>>(reinterpret_cast<uint32_t*>(dst), v, words);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+int copy_word(int* dst, const int* src, hipStream_t s) {
+    if (dst == nullptr) return set_error("copy_word: null destination");
+    k_copy_word<<<1, 1, 0, s>>>(dst, src);
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
 int scan_exclusive(const int* in, int* out, int n, int* total, int* scratch, hipStream_t s) {
     if (n <= 0) {
-        if (total) HEAL_HIP(hipMemsetAsync(total, 0, sizeof(int), s));
+        if (total) HEAL_FILL(total, 0, sizeof(int), s);
         return 0;
     }
     const int nb = ceil_div(n, SCAN_TILE);
@@ -218,4 +260,5 @@ int heal_next_launch_events(void* start_event, void* stop_event) {
 }
 int heal_abi_version(void) { return HEAL_AMD_ABI_VERSION; }
 const char* heal_last_error(void) { return heal::err_buf(); }
+int heal_fill_bytes(void* dst, int byte, size_t bytes, void* stream) { return heal::fill_bytes(dst, byte, bytes, (hipStream_t)stream); }
 }

@@ -1095,7 +1095,7 @@ extern "C" int heal_sp_hash_build(const int32_t* indices, int n, const int32_t* 
     SpShape sh;
     HEAL_REQUIRE(shape_ok(shape_host, batch, sh), "sp_hash_build: bad shape");
     HEAL_REQUIRE(table_cap >= pow2_cap(n) && (table_cap & (table_cap - 1)) == 0, "sp_hash_build: bad table capacity");
-    HEAL_HIP(hipMemsetAsync(table_keys, 0xFF, table_cap * sizeof(uint32_t), s));
+    HEAL_FILL(table_keys, 0xFF, table_cap * sizeof(uint32_t), s);
     if (n > 0) {
         k_sp_hash_insert<<<ceil_div(n, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(indices), n, n_dev, sh,
                                                           table_keys, table_vals, (uint32_t)table_cap - 1);
@@ -1151,7 +1151,7 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
     SpConvGeom g;
     if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
     HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "sp_out_sites: workspace must be 256-B aligned");
-    if (n_in <= 0) { HEAL_HIP(hipMemsetAsync(n_out, 0, sizeof(int), s)); return 0; }
+    if (n_in <= 0) { HEAL_FILL(n_out, 0, sizeof(int), s); return 0; }
     const int K = g.k[0] * g.k[1] * g.k[2];
     const uint32_t cap = pow2_cap((int64_t)n_in * (K < 8 ? K : 8));
     Arena a(ws, ws_bytes);
@@ -1162,14 +1162,14 @@ extern "C" int heal_sp_out_sites(const int32_t* in_indices, int n_in, const int3
     int* sscratch = a.take<int>(sort_scratch_words(cap));
     int* cscratch = a.take<int>(scan_scratch_words(cap));
     HEAL_REQUIRE(a.ok(), "sp_out_sites: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    HEAL_HIP(hipMemsetAsync(okey, 0xFF, (size_t)cap * 4, s));
+    HEAL_FILL(okey, 0xFF, (size_t)cap * 4, s);
     const long long total = (long long)n_in * K;
     k_sp_candidates<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(reinterpret_cast<const int4*>(in_indices), n_in,
                                                                     n_in_dev, g, okey, cap - 1);
     k_sp_slot_flags<<<ceil_div((int)cap, 256), 256, 0, s>>>(okey, (int)cap, flag);
     if (scan_exclusive(flag, flag, (int)cap, n_out, cscratch, s)) return 1;
     // unique keys -> compact; pad the tail with 0xFFFFFFFF so that a fixed-size sort puts them last
-    HEAL_HIP(hipMemsetAsync(keys[0], 0xFF, (size_t)out_cap * 4, s));
+    HEAL_FILL(keys[0], 0xFF, (size_t)out_cap * 4, s);
     HEAL_REQUIRE((uint32_t)out_cap <= cap, "sp_out_sites: out_cap larger than the candidate table");
     k_sp_compact<<<ceil_div((int)cap, 256), 256, 0, s>>>(okey, flag, (int)cap, out_cap, keys[0], vals[0]);
     // sort on the bits a real key can occupy; the 0xFF.. padding has all of them set and, the sort
@@ -1220,7 +1220,7 @@ extern "C" int heal_sp_out_sites_rank(const int32_t* in_indices, int n_in, const
     int* base = a.take<int>(gran);
     int* scratch = a.take<int>(scan_scratch_words((int64_t)gran));
     HEAL_REQUIRE(a.ok(), "sp_out_sites_rank: rank buffer too small (%zu < %zu)", rank_bytes, a.off);
-    HEAL_HIP(hipMemsetAsync(bm, 0, words * 4, s));
+    HEAL_FILL(bm, 0, words * 4, s);
     if (n_in > 0)
         k_sp_bm_mark<<<ceil_div(n_in, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(in_indices), n_in, n_in_dev, g, bm);
     k_sp_bm_count<<<(unsigned)((gran + 255) / 256), 256, 0, s>>>(reinterpret_cast<const uint4*>(bm), (int)gran, base);
@@ -1325,7 +1325,7 @@ extern "C" int heal_sp_root_rank(const int32_t* indices, int n, const int32_t* s
     HEAL_REQUIRE(w.gran < (1ull << 31), "sp_root_rank: grid too large");
     const int4* idx = reinterpret_cast<const int4*>(indices);
     const int nb = ceil_div(n, 256);
-    HEAL_HIP(hipMemsetAsync(w.l1, 0, w.clear_bytes, s));
+    HEAL_FILL(w.l1, 0, w.clear_bytes, s);
     k_sp_root_mark1<<<nb, 256, 0, s>>>(idx, n, n_dev, sh, w.l1, w.bm);
     k_sp_root_mark2<<<nb, 256, 0, s>>>(idx, n, n_dev, sh, w.bm);
     k_sp_root_count<0><<<w.blocks, 256, 0, s>>>(w.l1, w.bm, (int)w.l1_words, w.cnt, w.blk_sum, w.grp_sum, w.base);
@@ -1345,7 +1345,7 @@ extern "C" int heal_sp_transpose_neighbors(const int32_t* nbr, int n_out, int ke
                                            const int32_t* n_out_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(kernel_volume >= 1 && kernel_volume <= 27 && n_in >= 0, "sp_transpose_neighbors: bad arguments");
-    if (n_in > 0) HEAL_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * kernel_volume * sizeof(int32_t), s));
+    if (n_in > 0) HEAL_FILL(nbr_t, 0xFF, (size_t)n_in * kernel_volume * sizeof(int32_t), s);
     if (n_out <= 0 || n_in <= 0) return 0;
     const long long total = (long long)n_out * kernel_volume;
     k_sp_nbr_transpose<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(nbr, n_out, n_out_dev, kernel_volume, n_in, nbr_t);
@@ -1484,7 +1484,7 @@ extern "C" int heal_sp_to_bev(const float* features, const int32_t* indices, int
     const size_t cells = (size_t)batch * sh.D * sh.H * sh.W;
     int* cell_map = a.take<int>(cells);
     HEAL_REQUIRE(a.ok(), "sp_to_bev: workspace too small");
-    HEAL_HIP(hipMemsetAsync(cell_map, 0xFF, cells * 4, s));
+    HEAL_FILL(cell_map, 0xFF, cells * 4, s);
     if (n > 0)
         k_sp_fill_map<<<ceil_div(n, 256), 256, 0, s>>>(reinterpret_cast<const int4*>(indices), n, n_dev, sh, cell_map);
     const int cells4 = sh.H * sh.W / 4;

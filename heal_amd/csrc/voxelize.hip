@@ -7,9 +7,9 @@
 // first appearance, none beyond max_voxels); a point is appended to its voxel while the voxel holds
 // fewer than max_points.
 //
-// GPU formulation (order-independent, so bit-identical to the sequential scan), ONE memset + FOUR kernels for any number of
+// GPU formulation (order-independent, so bit-identical to the sequential scan), ONE fill + FOUR kernels for any number of
 // agents (round 4; round 3: five; rounds 1-2 sorted (voxel id, point index) pairs with a 3-pass radix sort: 24 launches):
-//   0. one memset(0xFF): hash keys | per-cell minimum point index | per-cell point counter | the tiles' publication words
+//   0. one fill(0xFF) (a KERNEL, heal::fill_bytes -- not hipMemsetAsync, see common.h): hash keys | per-cell minimum point index | per-cell point counter | the tiles' publication words
 //   1. k_voxb_insert: hash-grid insert, cell -> min point index, ticket   (atomicCAS claim + atomicMin + atomicAdd, each behind a
 //      plain read that rules most of the first two out)
 //   2 + 3. k_vox_assign: per 1024-point tile the "i is the first point of its cell" flags are counted and PUBLISHED (one 64-bit word
@@ -136,7 +136,7 @@ __device__ __forceinline__ int block_sum_256(int v, int* s_red) {   // all threa
 
 // 2 + 3. ranks -> rows and segments, ONE launch (round 4; rounds 1-3: a tile-sums launch, then every block re-scanned all tile sums).
 // Every 1024-point tile counts its first points and the points of their cells, PUBLISHES the pair as one 64-bit word
-// (tile_pub[tile] = first points << 32 | cell points; the array is part of the 0xFF memset, bit 63 set = not yet published) and then
+// (tile_pub[tile] = first points << 32 | cell points; the array is part of the 0xFF fill, bit 63 set = not yet published) and then
 // looks back: thread t waits for tiles t, t + 256, ... below its own and adds them up -- tiles are dispatched in index order and
 // publish before they wait, so the chain always makes progress.  A tile that holds the first point of agent b also publishes the
 // first points in front of that boundary (part_pub[b]).  meta[0] = rows written (M), meta[1] = base row (0 without row_offset):
@@ -314,8 +314,8 @@ __device__ __forceinline__ uint32_t group_merge(uint32_t v, int l) {   // v bito
 template <int G>
 __global__ __launch_bounds__(256) void k_vox_select_write(const float4* __restrict__ pts, const uint32_t* __restrict__ seg,
                                                          const int* __restrict__ row_seg, const int* __restrict__ row_cnt,
-                                                         const int* __restrict__ meta, int P, float4* __restrict__ voxels,
-                                                         int* __restrict__ num_points) {
+                                                         int* __restrict__ meta, int P, float4* __restrict__ voxels,
+                                                         int* __restrict__ num_points, int n_pts) {
     const int row = blockIdx.x * (256 / G) + (int)threadIdx.x / G, l = (int)threadIdx.x & (G - 1);
     const int M = meta[0];
     if ((int)blockIdx.x * (256 / G) >= M) return;     // block-uniform: the grid is sized by capacity
@@ -334,7 +334,14 @@ __global__ __launch_bounds__(256) void k_vox_select_write(const float4* __restri
     }
     if (!live || l >= P) return;
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (best != HASH_EMPTY) val = pts[best];
+    if (best != HASH_EMPTY) {
+        // An index that is no point of this call can only come from a corrupted table (round 4: the runtime's memset node, see
+        // common.h fill_bytes).  It is recorded -- meta[8] = hits (never reset), meta[9..14] = index, row, count, segment, M, lane of
+        // the first -- instead of being dereferenced; scripts/ring_dbg.py prints the words.
+        if (best >= (uint32_t)n_pts) {
+            if (atomicAdd(&meta[8], 1) == 0) { meta[9] = (int)best; meta[10] = row; meta[11] = cnt; meta[12] = st; meta[13] = M; meta[14] = l; }
+        } else val = pts[best];
+    }
     const int base = meta[1];
     voxels[(size_t)(base + row) * P + l] = val;
     if (l == 0) num_points[base + row] = min(cnt, P);
@@ -386,7 +393,7 @@ struct VoxWs {
     int *slot_of, *tseg, *row_seg, *row_cnt, *meta;
     unsigned long long *tile_pub, *part_pub;   // published tile sums / agent-boundary partial counts (inside the 0xFF region: unpublished)
     uint32_t tcap;
-    size_t ff_bytes;     // tkey | tmin | tcnt (| cand): initialised by one memset(0xFF)
+    size_t ff_bytes;     // tkey | tmin | tcnt (| cand): initialised by one fill(0xFF)
 };
 
 static uint32_t table_cap(int n) {
@@ -428,7 +435,7 @@ static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& 
     VoxWs w;
     HEAL_REQUIRE(carve(a, n, cap, P, w), "%s: workspace too small (%zu < %zu)", who, ws_bytes, a.off);
     const int nb = ceil_div(n, 256);
-    HEAL_HIP(hipMemsetAsync(w.tkey, 0xFF, w.ff_bytes, s));
+    HEAL_FILL(w.tkey, 0xFF, w.ff_bytes, s);
     static const bool dense_ok = [] { const char* e = getenv("HEAL_VOX_DENSE"); return !(e && e[0] == '0'); }();
     if (dense_ok && (unsigned long long)vb.B * cells <= (unsigned long long)w.tcap)
         k_voxb_insert<true><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
@@ -443,7 +450,7 @@ static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& 
         k_vox_write<<<(unsigned)(((long long)cap * P + 255) / 256), 256, 0, s>>>(pts, w.cand, w.meta, P, vox4, num_points);
     } else {
         k_vox_fill<<<nb, 256, 0, s>>>(w.slot_of, w.tick, w.tseg, n, w.seg);
-#define HEAL_VSW(G_) k_vox_select_write<G_><<<ceil_div(cap, 256 / G_), 256, 0, s>>>(pts, w.seg, w.row_seg, w.row_cnt, w.meta, P, vox4, num_points)
+#define HEAL_VSW(G_) k_vox_select_write<G_><<<ceil_div(cap, 256 / G_), 256, 0, s>>>(pts, w.seg, w.row_seg, w.row_cnt, w.meta, P, vox4, num_points, n)
         if (P > 32) HEAL_VSW(64);
         else if (P > 16) HEAL_VSW(32);
         else if (P > 8) HEAL_VSW(16);
@@ -535,10 +542,10 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
     HEAL_REQUIRE(n_points >= 0 && max_points >= 1 && max_voxels >= 1, "voxelize: bad sizes");
     HEAL_REQUIRE(n_voxels != nullptr, "voxelize: n_voxels is NULL");
     if (n_points == 0) {
-        HEAL_HIP(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
+        HEAL_FILL(n_voxels, 0, sizeof(int), s);
         if (row_offset_next) {
-            if (row_offset) HEAL_HIP(hipMemcpyAsync(row_offset_next, row_offset, sizeof(int), hipMemcpyDeviceToDevice, s));
-            else HEAL_HIP(hipMemsetAsync(row_offset_next, 0, sizeof(int), s));
+            if (row_offset) { if (heal::copy_word(row_offset_next, row_offset, s)) return 1; }
+            else HEAL_FILL(row_offset_next, 0, sizeof(int), s);
         }
         return 0;
     }
@@ -581,7 +588,7 @@ extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_off
     }
     const int n = vb.pt_off[n_agents];
     if (n == 0) {
-        HEAL_HIP(hipMemsetAsync(row_offsets, 0, sizeof(int) * (size_t)(n_agents + 1), s));
+        HEAL_FILL(row_offsets, 0, sizeof(int) * (size_t)(n_agents + 1), s);
         return 0;
     }
     VoxGrid g;

@@ -1969,3 +1969,12 @@ def depthwise_conv(x, weight, bias, stride, pad, act="none", channel_sums=None):
     _capi.call("heal_depthwise_conv", _ptr(x), _ptr(weight), _ptr(bias), n, C, H, W, k, int(stride), pt, pl, Ho, Wo,
                {"none": 0, "relu": 1, "silu": 2}[act], _ptr(y), _ptr(sums) if sums is not None else None, _stream())
     return (y, sums) if channel_sums else y
+
+
+def fill_bytes(t, byte):
+    """t (contiguous CUDA tensor, size a multiple of 4 bytes) <- `byte` in every byte, by the library's fill KERNEL (heal_fill_bytes;
+    include/heal_amd.h explains why not a memset)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+        raise _capi.HealAmdError("fill_bytes: a contiguous CUDA tensor is required")
+    _capi.call("heal_fill_bytes", _ptr(t), int(byte), t.numel() * t.element_size(), _stream())
+    return t

@@ -24,10 +24,17 @@
 extern "C" {
 #endif
 
-#define HEAL_AMD_ABI_VERSION 4
+#define HEAL_AMD_ABI_VERSION 5
 
 int heal_abi_version(void);
 const char* heal_last_error(void);
+
+/* heal_fill_bytes: dst[0 .. bytes) <- byte, as a KERNEL (dst and bytes multiples of 4).  Every table / counter initialisation inside this
+ * library goes through it; hipMemsetAsync is not used: captured into a HIP graph it becomes a memset node, and the round-4 memory fault
+ * was such a node writing 00 FF FF .. FF for every 16 bytes of a 0xFF fill (profiles/r05_k1_memset_node_dump.txt).  Exported so that
+ * callers that prepare buffers for this library inside a captured region (and the tests) can use the same primitive.  No reference
+ * counterpart: torch's `x.fill_()` / `torch.zeros` play this role around opencood's CUDA extensions.                                     */
+int heal_fill_bytes(void* dst, int byte, size_t bytes, void* stream);
 /* Measurement hook: arm a pair of hipEvent_t (created with timing enabled) for THIS thread; the next launch of an entry point
  * that supports it -- heal_bev_pool_scatter, heal_bev_stem_block -- stamps them with the kernel's own begin / end timestamps
  * (hipExtLaunchKernelGGL: the interval a rocprofv3 kernel trace reports, without the dispatch / marker latencies an event pair

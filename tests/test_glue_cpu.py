@@ -137,3 +137,21 @@ def test_oldstyle_pointpillar_glue(monkeypatch):
                                      "args": dict(configs.oldstyle_pointpillar("max")["model"]["args"], backbone_fix=True)}})
     assert not any(p.requires_grad for p in frozen.backbone.parameters())
     assert not any(p.requires_grad for p in frozen.cls_head.parameters())
+
+
+def test_no_runtime_memset_or_d2d_copy_in_the_library():
+    """Round-5 rule (include/heal_amd.h, heal_fill_bytes): the library initialises device memory with its own fill KERNEL.  A
+    hipMemsetAsync / hipMemcpyAsync captured into a HIP graph becomes a runtime-executed node, and the r4 memory fault was such a node
+    writing a wrong pattern (profiles/r05_k1_memset_node_dump.txt).  No source file may call either."""
+    import glob
+    import os
+    import re
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "heal_amd", "csrc")
+    hits = []
+    for path in sorted(glob.glob(os.path.join(src, "*"))):
+        text = open(path).read()
+        text = re.sub(r"//.*", "", text)
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b(hipMemset\w*|hipMemcpy\w*Async)\s*\(", text):     # (a blocking D2H read in a debug branch is no graph node)
+            hits.append((os.path.basename(path), m.group(0)))
+    assert not hits, hits
