@@ -1116,8 +1116,7 @@ extern "C" int heal_bev_pool_scatter(const float* head, int head_stride, const f
     Arena a(ws, ws_bytes);
     LssPmWs w;
     HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_pool_pm: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    const char* dbg_env = getenv("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const int dbg = HEAL_DEBUG_ENV("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
     int rc = 1;
     switch (n_dt) {
         case 1: rc = launch_scatter<1>(head, head_stride, frustum, cam_mats, g, w, cells_total, lds, csplit, dbg, s); break;
@@ -1172,8 +1171,7 @@ extern "C" int heal_bev_stem_block(int n_agents, int channels, const int32_t* nx
     Arena a(ws, ws_bytes);
     LssPmWs w;
     HEAL_REQUIRE(carve_pm(a, channels, cells_total, w), "bev_stem_block: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    const char* dbg_env = getenv("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const int dbg = HEAL_DEBUG_ENV("HEAL_K4_DBG");   // timing experiments only (bits skip parts of the work: results invalid)
     const int tiles_x = ceil_div(Wo, 64);
     const int64_t blocks = (int64_t)n_agents * Ho * tiles_x;
     HEAL_REQUIRE(blocks < (1ll << 31), "bev_stem_block: grid too large");

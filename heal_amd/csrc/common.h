@@ -47,6 +47,11 @@ struct Arena {
 
 #define HEAL_LAUNCH_CHECK() HEAL_HIP(hipGetLastError())
 
+// Debug switches that SKIP WORK (HEAL_K4_DBG, HEAL_K5_DBG, HEAL_SP_DBG: timing anatomy only, outputs invalid) are read ONCE per process and
+// announced on stderr when set, so that a stray variable cannot corrupt results silently and costs nothing per launch.
+int debug_env_once(const char* name);
+#define HEAL_DEBUG_ENV(name) ([]() -> int { static const int v__ = heal::debug_env_once(name); return v__; }())
+
 // fill_bytes: the library's ONLY way of initialising device memory (a kernel, prims.hip).  hipMemsetAsync is not used anywhere: captured
 // into a HIP graph it becomes a memset NODE, and in round 4 K1's 0xFF table fill came back from such a node with byte 0 of every
 // 16 B cleared (workspace dump in profiles/r05_k1_memset_node_dump.txt; DESIGN 5 "memory fault") -- the runtime's fill goes through

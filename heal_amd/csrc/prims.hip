@@ -1,4 +1,5 @@
 // Device-wide scan and stable radix sort (see prims.h).  gfx950, wave = 64.
+#include <stdlib.h>
 #include "prims.h"
 #include "../../include/heal_amd.h"
 
@@ -113,6 +114,15 @@ __global__ __launch_bounds__(256) void k_fill_words(uint32_t* __restrict__ dst, 
 }
 
 __global__ void k_copy_word(int* __restrict__ dst, const int* __restrict__ src) { *dst = src ? *src : 0; }
+
+int debug_env_once(const char* name) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    if (v != 0)
+        fprintf(stderr, "[heal_amd] WARNING: %s=%d is set -- a DEBUG switch that skips parts of the kernel's work; "
+                        "outputs of the affected operator are INVALID in this process\n", name, v);
+    return v;
+}
 
 int fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s) {
     if (bytes == 0) return 0;

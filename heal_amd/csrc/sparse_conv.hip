@@ -1366,7 +1366,7 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
     if (weight_frag && !(mode && mode[0] == 'v' && mode[1] == '1') && kernel_volume <= 27) {
         const int env_tx = getenv("HEAL_SP_TPSX") ? atoi(getenv("HEAL_SP_TPSX")) : 0;
         const int env_db = getenv("HEAL_SP_DB") ? atoi(getenv("HEAL_SP_DB")) : -1;
-        const int dbg = getenv("HEAL_SP_DBG") ? atoi(getenv("HEAL_SP_DBG")) : 0;
+        const int dbg = HEAL_DEBUG_ENV("HEAL_SP_DBG");
 #define HEAL_SP2(CI, CO, MM, TT, DD, GG)                                                                                 \
     {                                                                                                                    \
         k_sp_conv2<CI, CO, MM, TT, DD, GG><<<ceil_div(n_out, MM), 256, 0, s>>>(feat_in, nbr, n_out, n_out_dev,           \

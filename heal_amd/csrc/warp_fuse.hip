@@ -645,7 +645,7 @@ extern "C" int heal_warp_fuse_levels(int n_levels, const float* const* feats_hos
     HEAL_REQUIRE(affine_host != nullptr || affine_dev != nullptr, "warp_fuse_levels: affine is NULL (host and device)");
     WfLevels P;
     P.n_levels = n_levels; P.n_agents = n_agents; P.grid_f64 = grid_f64; P.mdev = affine_dev;
-    { const char* e = getenv("HEAL_K5_DBG"); P.dbg = e ? atoi(e) : 0; }   // timing experiments only
+    P.dbg = HEAL_DEBUG_ENV("HEAL_K5_DBG");   // timing experiments only (read once, announced on stderr)
     for (int a = 0; a < WF_MAXA; ++a)
         for (int k = 0; k < 6; ++k) P.m[a][k] = (a < n_agents && affine_host) ? affine_host[a * 6 + k] : 0.0;
     long long blocks = 0;
@@ -663,7 +663,8 @@ extern "C" int heal_warp_fuse_levels(int n_levels, const float* const* feats_hos
         // blocks per level, in whole staging rounds of 8 channels.  Measured at scene5 size (scripts/k5_bench.py, HEAL_K5_BLOCKS):
         // 2048 -> 110 us, 1024 -> 102, 768 -> 91, 512 -> 89, 384 -> 97, 256 -> 116 (three per-level launches of round 3: 135).
         int target = 512;
-        if (const char* e = getenv("HEAL_K5_BLOCKS")) target = atoi(e) > 0 ? atoi(e) : target;
+        static const int env_blocks = [] { const char* e = getenv("HEAL_K5_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning knob, read once
+        if (env_blocks > 0) target = env_blocks;
         int cg = (int)((target + tiles - 1) / tiles);
         cg = cg < 1 ? 1 : cg;
         int cpb = ceil_div(ceil_div(L.C, cg), WL_CC) * WL_CC;

@@ -308,6 +308,11 @@ class ShardedCollab(_Sharded):
         pb = m.pyramid_backbone
         n_slots = slots_per_rank(n_agents, self.world)
         x, mine = self._own_features(scene_input, n_agents, local_inputs)
+        stages = pb.get_multiscale_feature(x) if mine else None
+        if self._shapes is None:
+            if not mine:
+                raise RuntimeError("ShardedCollab: prepare() must run before local() on a rank that owns no agent")
+            self._shapes = [tuple(int(v) for v in f.shape[1:]) for f in stages]
         shapes = self._level_shapes()
         per_slot = sum((c + 1) * h * w for c, h, w in shapes)
         dev = next(m.parameters()).device
@@ -318,11 +323,10 @@ class ShardedCollab(_Sharded):
         if len(mine) < n_slots:
             buf[len(mine):].zero_()
         if mine:
-            stages = pb.get_multiscale_feature(x)
             off = 0
             for i, f in enumerate(stages):
                 if tuple(f.shape[1:]) != tuple(shapes[i]):
-                    raise RuntimeError(f"pyramid level {i}: stage output {tuple(f.shape[1:])} != configured {shapes[i]}")
+                    raise RuntimeError(f"pyramid level {i}: stage output {tuple(f.shape[1:])} != agreed {shapes[i]}")
                 occ = pb.occupancy_head(i, f)
                 nf, ns = f.shape[1] * f.shape[2] * f.shape[3], f.shape[2] * f.shape[3]
                 for k, a in enumerate(mine):
@@ -359,17 +363,35 @@ class ShardedCollab(_Sharded):
         cls_preds, reg_preds, dir_preds = m.heads(y)
         return {"pyramid": "collab", "cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds}
 
+    _shapes = None      # [(C, H, W)] of the pyramid levels, from the stage outputs of a rank that owns agents
+    _agreed = False     # set by prepare() only, AFTER its collective: every rank enters that collective exactly once
+
+    def prepare(self, scene_input, n_agents, local_inputs):
+        """The (C, H, W) of every pyramid level is what the model's stages actually produce on a rank that owns agents (voxel size,
+        encoder strides and `layer_strides` all enter it; rounds 3-4 derived it from a hard-coded 0.8 m / pixel, ADVICE r3 / VERDICT
+        r4 item 15); ranks without agents -- and rank 0's fusion -- learn it from them once: one MAX all-reduce of 3 x levels
+        integers.  Whether a rank joins that all-reduce depends on `_agreed` alone, never on what an earlier local() call cached."""
+        if self._agreed:
+            return
+        dev = next(self.model.parameters()).device
+        n_lev = len(self.model.args["fusion_backbone"]["num_filters"])
+        t = torch.zeros(3 * n_lev, dtype=torch.int64, device=dev)
+        if owned_agents(n_agents, self.rank, self.world):
+            if self._shapes is None:
+                self.local(scene_input, n_agents, local_inputs)   # sets self._shapes
+            t = torch.tensor([v for shp in self._shapes for v in shp], dtype=torch.int64, device=dev)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        got = [tuple(int(v) for v in t[3 * i:3 * i + 3].tolist()) for i in range(n_lev)]
+        if self._shapes is not None and [tuple(x) for x in self._shapes] != got:
+            raise RuntimeError(f"ShardedCollab: this rank's pyramid levels {self._shapes} differ from the job's {got}")
+        self._shapes = got
+        self._agreed = True
+
     def _level_shapes(self):
-        m = self.model
-        fb = m.args["fusion_backbone"]
-        # BEV size entering the pyramid: lidar grid / 2 (all HEAL encoders+backbones end at 0.8 m/px)
-        H = int(round(m.H / 0.8))
-        W = int(round(m.W / 0.8))
-        shapes = []
-        for c, s in zip(fb["num_filters"], fb["layer_strides"]):
-            H, W = H // s, W // s
-            shapes.append((c, H, W))
-        return shapes
+        if self._shapes is None:
+            raise RuntimeError("ShardedCollab: level shapes unknown -- prepare() (or local() on a rank that owns agents) runs first")
+        return self._shapes
 
 
 class ShardedCollabCompressed(ShardedCollab):
@@ -390,12 +412,13 @@ class ShardedCollabCompressed(ShardedCollab):
         if not self.model.compress:
             raise ValueError("split='compressed' needs a model with a `compressor` (args['compressor'])")
         self._scene_input = scene_input
-        if self._zshape is not None:
-            return
+        if self._agreed:         # (not `_zshape is not None`: local() sets that too, and a rank that had called local() before would
+            return               #  skip the all-reduce another rank is waiting in -- ADVICE r4)
         dev = next(self.model.parameters()).device
         shape = torch.zeros(3, dtype=torch.int64, device=dev)
         if owned_agents(n_agents, self.rank, self.world):
-            self.local(scene_input, n_agents, local_inputs)   # sets self._zshape
+            if self._zshape is None:
+                self.local(scene_input, n_agents, local_inputs)   # sets self._zshape
             shape = torch.tensor(self._zshape, dtype=torch.int64, device=dev)
         if self.world > 1:
             dist.all_reduce(shape, op=dist.ReduceOp.MAX)
@@ -403,6 +426,7 @@ class ShardedCollabCompressed(ShardedCollab):
         if self._zshape is not None and tuple(self._zshape) != got:
             raise RuntimeError(f"compressed split: this rank's encoder output {self._zshape} differs from the job's {got}")
         self._zshape = got
+        self._agreed = True
 
     @torch.no_grad()
     def local(self, scene_input, n_agents, local_inputs):
@@ -443,20 +467,23 @@ class ShardedBaseline(_Sharded):
     rank 0 reduces the gathered ego-frame stack with the model's fusion operator (max / att / V2XTransformer)."""
 
     _shape = None
+    _agreed = False
 
     def prepare(self, scene_input, n_agents, local_inputs):
         """Ranks that own no agent (world > n_agents) still contribute a zero slot of the right size: the [C, H, W] of
         the shared map is learnt once from the ranks that do own agents (one MAX all-reduce of three integers)."""
-        if self._shape is not None:
+        if self._agreed:         # (set after the collective only; local() caching `_shape` must not decide who joins it)
             return
         dev = next(self.model.parameters()).device
         shape = torch.zeros(3, dtype=torch.int64, device=dev)
         if owned_agents(n_agents, self.rank, self.world):
-            self.local(scene_input, n_agents, local_inputs)   # sets self._shape
+            if self._shape is None:
+                self.local(scene_input, n_agents, local_inputs)   # sets self._shape
             shape = torch.tensor(self._shape, dtype=torch.int64, device=dev)
         if self.world > 1:
             dist.all_reduce(shape, op=dist.ReduceOp.MAX)
         self._shape = tuple(int(v) for v in shape.tolist())
+        self._agreed = True
 
     @torch.no_grad()
     def local(self, scene_input, n_agents, local_inputs):
@@ -490,7 +517,7 @@ class ShardedBaseline(_Sharded):
 class _StripeComm:
     """The collectives of the striped tail (ShardedBaselineStriped).  Eager mode: each call just runs.  Capture mode
     (`begin_capture`): the step is recorded as a PROGRAM -- a call closes the HIP graph under capture, runs the collective on
-    buffers that stay alive (its input lives in the graphs' shared pool, its output is allocated outside the capture), and opens
+    buffers that stay alive (its input lives in the graphs' shared pool, its output is allocated AFTER the cut, i.e. outside any capture), and opens
     the next graph; `replay()` then alternates graph launches and collectives in the recorded order.  The collectives stay
     ordinary stream operations of the process group (RCCL on the GPU box), as in _Sharded.replay."""
 
@@ -540,48 +567,60 @@ class _StripeComm:
             else:
                 item()
 
-    def _run(self, fn, keep, reopen=True):
+    def _run(self, make, reopen=True):
+        """make() -> (fn, keep, result): allocates the collective's OUTPUT and returns the call.  In capture mode the open graph is cut
+        FIRST, so the output comes from the ordinary allocator -- not from the graphs' pool, where an eager collective would write into
+        memory the pool may hand to a later node -- and `keep` pins input and output for the life of the program."""
         if self.program is None:
+            fn, _keep, res = make()
             fn()
-            return
+            return res
         self._cut()
+        assert not torch.cuda.is_current_stream_capturing()
+        fn, keep, res = make()
         fn()
         self.program.append(("coll", fn))
         self._keep.append(keep)
         if reopen:
             self._open()
+        return res
 
     # ---- the three exchanges
     def all_gather(self, t):
         """-> [world, *t.shape] on every rank."""
         t = t.detach()
         assert t.is_contiguous()
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self._run(lambda: dist.all_gather_into_tensor(out.view(-1), t.view(-1)), (t, out))
-        return out
+
+        def make():
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            return (lambda: dist.all_gather_into_tensor(out.view(-1), t.view(-1))), (t, out), out
+        return self._run(make)
 
     def all_to_all(self, send):
         """send [world, ...]: slice d goes to rank d -> recv [world, ...]: slice s came from rank s."""
         assert send.is_contiguous() and send.shape[0] == self.world
-        recv = torch.empty_like(send)
-        if dist.get_backend() == "gloo" and send.is_cuda:
-            # two ranks on one device in the tests: gloo has no device all-to-all; `world` gathers move the same slices
-            def fn():
-                for d in range(self.world):
-                    dist.gather(send[d], [recv[s_] for s_ in range(self.world)] if self.rank == d else None, dst=d)
-        else:
-            def fn():
-                dist.all_to_all_single(recv, send)
-        self._run(fn, (send, recv))
-        return recv
+
+        def make():
+            recv = torch.empty_like(send)
+            if dist.get_backend() == "gloo" and send.is_cuda:
+                # two ranks on one device in the tests: gloo has no device all-to-all; `world` gathers move the same slices
+                def fn():
+                    for d in range(self.world):
+                        dist.gather(send[d], [recv[s_] for s_ in range(self.world)] if self.rank == d else None, dst=d)
+            else:
+                def fn():
+                    dist.all_to_all_single(recv, send)
+            return fn, (send, recv), recv
+        return self._run(make)
 
     def gather0(self, t):
         """-> [world, *t.shape] on rank 0, None elsewhere (no graph is opened after it on the other ranks: their step ends here)."""
         assert t.is_contiguous()
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == 0 else None
-        self._run(lambda: dist.gather(t, [out[r] for r in range(self.world)] if self.rank == 0 else None, dst=0), (t, out),
-                  reopen=self.rank == 0)
-        return out
+
+        def make():
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == 0 else None
+            return (lambda: dist.gather(t, [out[r] for r in range(self.world)] if self.rank == 0 else None, dst=0)), (t, out), out
+        return self._run(make, reopen=self.rank == 0)
 
 
 class ShardedBaselineStriped(ShardedBaseline):
@@ -619,9 +658,11 @@ class ShardedBaselineStriped(ShardedBaseline):
         super().prepare(scene_input, n_agents, local_inputs)
         if self._striped is None:
             from heal_amd.opencood.models.sub_modules.v2xvit_basic import BaseWindowAttention
-            ws = max([mod.window_size for mod in self._encoder().modules() if isinstance(mod, BaseWindowAttention)] or [1])
+            import math
+            sizes = [int(mod.window_size) for mod in self._encoder().modules() if isinstance(mod, BaseWindowAttention)] or [1]
             H = self._shape[1]
-            self._striped = self.world > 1 and H % (self.world * ws) == 0
+            # a stripe must hold WHOLE windows of every configured size (lcm, not the largest: [3, 5] does not divide by 5 alone)
+            self._striped = self.world > 1 and H % self.world == 0 and (H // self.world) % math.lcm(*sizes) == 0
 
     def _step(self, scene_input, n_agents, local_inputs, comm, post_fn=None):
         from heal_amd.opencood.models.fuse_modules.fusion_in_one import warp_to_ego
