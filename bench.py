@@ -627,8 +627,9 @@ def main():
         coll_name, striped = "n/a", False
         if not solo:   # name the collective that actually ran (dist._Sharded.collective; VERDICT r3: the label said all-gather)
             lib_ = "RCCL" if backend == "nccl" else backend
-            coll_name = {"gather": f"{lib_} gather to rank 0", "all_gather": f"{lib_} all-gather"}.get(sharded.collective,
-                                                                                                      sharded.collective)
+            coll_name = {"gather": f"{lib_} gather to rank 0", "all_gather": f"{lib_} all-gather",
+                         "p2p": f"peer window in rank 0's HBM (IPC-mapped; rows written by their producers, two 1-element {lib_} "
+                                "all-reduces as fences)"}.get(sharded.collective, sharded.collective)
             striped = bool(getattr(sharded, "_striped", False))
             if striped:   # dist.ShardedBaselineStriped: the V2X-ViT tail runs on row stripes of every rank
                 coll_name = (f"{lib_} all-to-all of ego-frame stripes + all-gathered split-attention sums + gather of the ego "

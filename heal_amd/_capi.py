@@ -225,6 +225,74 @@ def _trace_done(name):
         print(f"[heal pid {os.getpid()}]   ok {name}", file=sys.stderr, flush=True)
 
 
+# ---- HEAL_GRAPH_GUARD=1: pointer ownership of captured graphs ---------------------------------------------------------
+# A captured HIP graph has every address it was handed baked in; nothing in the runtime notices when one of them is later freed (ops.py
+# keeps scratch and weight layouts alive by policy: "retire, never free").  In guard mode every device address passed through the C ABI
+# DURING a capture is logged; whoever owns the graph takes the log (guard_take) and has it verified before replays (guard_check): each
+# address must still lie in memory the caching allocator has handed out -- an active block of the ordinary pool, or any block of a
+# graph-private pool that is still mapped (tensors allocated and released inside a capture live there for the life of their graph).
+_GUARD = os.environ.get("HEAL_GRAPH_GUARD", "0") == "1"
+_guard_log = []
+
+
+def _segments():
+    import torch
+    segs = []
+    for seg in torch.cuda.memory_snapshot():
+        blocks, addr = [], seg["address"]
+        for b in seg["blocks"]:
+            a = b.get("address", addr)
+            blocks.append((a, a + b["size"], b["state"]))
+            addr = a + b["size"]
+        pool = tuple(seg.get("segment_pool_id", (0, 0)))
+        segs.append((seg["address"], seg["address"] + seg["total_size"], pool != (0, 0), blocks))
+    segs.sort()
+    return segs
+
+
+def _locate(segs, addr):
+    """-> None (no mapped segment: a host pointer or freed memory) | (private_pool, block_state)."""
+    import bisect
+    i = bisect.bisect_right(segs, (addr, float("inf"), True, [])) - 1
+    if i < 0 or not (segs[i][0] <= addr < segs[i][1]):
+        return None
+    for lo, hi, state in segs[i][3]:
+        if lo <= addr < hi:
+            return segs[i][2], state
+    return segs[i][2], "unknown"
+
+
+def guard_take():
+    """The device addresses logged by captures since the last call: [(entry point, address)] (empty when the guard is off)."""
+    global _guard_log
+    log, _guard_log = _guard_log, []
+    if not log:
+        return []
+    segs = _segments()
+    seen, out = set(), []
+    for name, addr in log:
+        if addr not in seen and _locate(segs, addr) is not None:     # (host arrays also travel as void*: not guarded)
+            seen.add(addr)
+            out.append((name, addr))
+    return out
+
+
+def guard_check(entries, what="captured graph"):
+    """Raise HealAmdError if any logged address no longer belongs to live allocator memory (see above).  One allocator snapshot."""
+    if not entries:
+        return
+    segs = _segments()
+    for name, addr in entries:
+        where = _locate(segs, addr)
+        if where is None:
+            raise HealAmdError(f"{what}: {name} was captured with device address {addr:#x}, which is no longer mapped "
+                               "(its tensor was freed and the memory returned to the driver)")
+        private, state = where
+        if not private and state != "active_allocated":
+            raise HealAmdError(f"{what}: {name} was captured with device address {addr:#x}, whose block is now '{state}' "
+                               "(its tensor was freed: a replay would read or overwrite somebody else's memory)")
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise HealAmdError with heal_last_error() on failure."""
     L = lib()
@@ -232,6 +300,10 @@ def call(name, *args):
         raise HealAmdError(f"libheal_amd.so does not export {name}")
     if _TRACE:
         _trace_call(name, args)
+    if _GUARD:
+        import torch
+        if torch.cuda.is_current_stream_capturing():
+            _guard_log.extend((name, a.value) for a in args if isinstance(a, ctypes.c_void_p) and a.value)
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise HealAmdError(f"{name} failed: {L.heal_last_error().decode(errors='replace')}")

@@ -113,6 +113,52 @@ def all_gather_packed(buf, world):
     return out.view(world, n_slots, per_slot)
 
 
+class PeerWindow:
+    """Rank 0's exchange buffer [world, n_slots, per_slot] mapped into EVERY rank's address space (hipIpcMemHandle through torch's CUDA
+    IPC: the handle travels over the process group once, at set-up).  With it the exchange is no collective at all: the owner of an agent
+    writes the agent's row straight into rank 0's HBM -- peer stores over xGMI issued by the kernel that produces the row (heal_warp_agent's
+    `out`), not a separate gather pass over a packed copy -- and two one-element all-reduces per frame order the accesses:
+
+        free   (before a rank's local stage)  rank 0 enqueues it behind the fusion tail that last READ this window, so no owner overwrites
+               rows that are still being fused;
+        ready  (after the local stage)        every rank enqueues it behind the kernels that WROTE its rows; rank 0's tail is enqueued behind it.
+
+    Memory visibility: a kernel's end is a system-scope release and a kernel's start an acquire that also drops the XCD-private L2 lines
+    (what keeps the eight XCDs of one MI355X coherent), so rows written by a peer before `ready` are what the tail reads after it.
+    SURVEY 8e ("prefer direct P2P over ring": the path's one exchange has ONE consumer).  Opt-in (HEAL_COLLECTIVE=p2p): exercised by two
+    ranks on one GPU (tests/test_gpu_dist.py), never on more than one device -- like everything in DESIGN 5."""
+
+    def __init__(self, rank, world, n_slots, per_slot, dtype, device):
+        import pickle
+        from multiprocessing.reduction import ForkingPickler
+        import torch.multiprocessing  # noqa: F401 - registers the tensor reductions (CUDA: hipIpcMemHandle; host: shared memory)
+        self.rank, self.world = rank, world
+        device = torch.device(device)
+        box = [None]
+        if rank == 0:
+            self.full = torch.zeros((world, n_slots, per_slot), dtype=dtype, device=device)    # zero: padding slots never change
+            if device.type == "cpu":
+                self.full.share_memory_()      # (host tensors: the gloo tests of the N > 1 path run this class without a GPU)
+            box = [bytes(ForkingPickler.dumps(self.full))]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        if rank != 0:
+            self.full = pickle.loads(box[0])   # a view of rank 0's allocation (a CUDA one lives on rank 0's device)
+            if device.type == "cuda" and self.full.device != device:
+                # raw-pointer kernels write through this mapping: make torch enable peer access device -> rank 0's device once
+                self.full[rank, :1, :1].copy_(torch.zeros((1, 1), dtype=dtype, device=device))
+        self.mine = self.full[rank]            # [n_slots, per_slot]: the rows this rank owns
+        self._flag = torch.zeros(1, dtype=torch.float32, device=device)
+        if world > 1:
+            dist.barrier()                     # every rank has opened the handle before rank 0 may go on (and possibly free it)
+
+    def fence(self):
+        """`free` / `ready`: a one-element all-reduce on the current stream (stream-ordered on every rank, see the class docstring)."""
+        if self.world > 1:
+            dist.all_reduce(self._flag)
+            self._flag.zero_()
+
+
 class _Sharded:
     """One scene, `world` ranks, model forward split at the fusion boundary.
 
@@ -132,12 +178,40 @@ class _Sharded:
         self.wire_dtype = wire_dtype if wire_dtype is not None else torch.float32
         import os
         self.collective = collective or os.environ.get("HEAL_COLLECTIVE", "gather")
-        if self.collective not in ("gather", "all_gather"):
-            raise ValueError(f"collective must be 'gather' or 'all_gather', got {self.collective!r}")
+        if self.collective not in ("gather", "all_gather", "p2p"):
+            raise ValueError(f"collective must be 'gather', 'all_gather' or 'p2p', got {self.collective!r}")
         self._g_local = self._g_tail = None
+        self._window = None      # PeerWindow (collective == "p2p"), created by the first forward / capture after prepare()
+
+    def _slot_elems(self):
+        """Elements of one agent's row of the exchange buffer (known after prepare()); p2p sizes its window with it."""
+        raise NotImplementedError
+
+    def _ensure_window(self, n_agents):
+        if self.collective == "p2p" and self._window is None:
+            dev = next(self.model.parameters()).device
+            self._window = PeerWindow(self.rank, self.world, slots_per_rank(n_agents, self.world), self._slot_elems(),
+                                      self.wire_dtype, dev)
+        return self._window
+
+    def _dest(self, n_slots, per_slot, dev):
+        """Where `local` writes its rows: this rank's rows of the peer window (p2p with an fp32 wire: no packed copy at all), else a
+        fresh buffer that the exchange then moves."""
+        w = self._window
+        if w is not None and self.wire_dtype == torch.float32:
+            if tuple(w.mine.shape) != (n_slots, per_slot):
+                raise RuntimeError(f"p2p window rows {tuple(w.mine.shape)} != ({n_slots}, {per_slot})")
+            return w.mine
+        return torch.empty((n_slots, per_slot), dtype=torch.float32, device=dev)
 
     def _exchange(self, buf, out=None):
         """The single exchange step: [world, n_slots, per_slot] on rank 0 (on every rank with all_gather), else None."""
+        if self.collective == "p2p":
+            w = self._window
+            if buf.data_ptr() != w.mine.data_ptr():
+                w.mine.copy_(buf)              # (fp16 wire / models whose local stage packs its own buffer: one peer copy)
+            w.fence()                          # ready
+            return w.full if self.rank == 0 else None
         if self.collective == "all_gather" or self.world == 1:
             g = all_gather_packed(buf, self.world)
             if out is not None:
@@ -179,6 +253,8 @@ class _Sharded:
         reference's collated layout, restricted to the local agents).  Returns the model output dict
         on rank 0, None elsewhere."""
         self.prepare(scene_input, n_agents, local_inputs)
+        if self._ensure_window(n_agents) is not None:
+            self._window.fence()               # free: rank 0's previous tail has left the window
         buf = self.local(scene_input, n_agents, local_inputs)
         gathered = self._exchange(buf)
         if self.rank != 0:
@@ -215,6 +291,8 @@ class _Sharded:
         self._capture_error = None
         ok = True
         self._g_local = None
+        if self._ensure_window(n_agents) is not None:
+            self._window.fence()               # free (the warm-up forwards above end with a tail on rank 0)
         if not owned_agents(n_agents, self.rank, self.world):
             # a rank without agents (world > n_agents) contributes a constant all-zero slot: nothing to capture
             self._static_buf = self.local(scene_input, n_agents, local_inputs)
@@ -234,7 +312,8 @@ class _Sharded:
             self._g_local = None
             return False
         g0 = self._exchange(self._static_buf)
-        self._static_gathered = g0.clone() if g0 is not None else None
+        # p2p: the tail graph reads the window itself (a clone would be the copy the window exists to avoid)
+        self._static_gathered = g0 if (g0 is None or self.collective == "p2p") else g0.clone()
         ok = True
         if self.rank == 0:
             cur.synchronize()
@@ -261,6 +340,8 @@ class _Sharded:
     def replay(self):
         """graph(local) -> exchange (gather to rank 0 | all-gather) -> graph(tail).  The graphs read whatever the buffers behind the captured inputs hold
         (pipeline.StaticInputs.load puts the next frame there: sensor data AND poses)."""
+        if self.collective == "p2p":
+            self._window.fence()        # free: behind rank 0's previous tail on this stream
         if self._g_local is not None:   # None: this rank owns no agent, its slot is the constant zero buffer
             self._g_local.replay()
             self._replays += 1
@@ -268,7 +349,9 @@ class _Sharded:
             # (ops.sparse_overflow_flag) that the same check reads keeps a violation of ANY frame in between
             if self._graph_checks and self._replays % 32 == 0:
                 self.check_sparse_capacity()
-        if self.world > 1 and self.collective == "all_gather":
+        if self.collective == "p2p":
+            self._exchange(self._static_buf)          # the rows are in rank 0's window already: `ready`
+        elif self.world > 1 and self.collective == "all_gather":
             n_slots, per_slot = self._static_buf.shape
             dist.all_gather_into_tensor(self._static_gathered.view(self.world * n_slots, per_slot), self._static_buf)
         elif self.world > 1:
@@ -319,7 +402,7 @@ class ShardedCollab(_Sharded):
         # the exchange buffer is written IN PLACE: heal_warp_agent puts every level of an agent straight into the agent's row
         # (no stack + pack copies of 29.7 MB per agent); only the padding slots of this rank are zeroed (a zero score is masked
         # to -inf by the fusion kernel, so they never contribute)
-        buf = torch.empty((n_slots, per_slot), dtype=torch.float32, device=dev)
+        buf = self._dest(n_slots, per_slot, dev)
         if len(mine) < n_slots:
             buf[len(mine):].zero_()
         if mine:
@@ -388,6 +471,9 @@ class ShardedCollab(_Sharded):
         self._shapes = got
         self._agreed = True
 
+    def _slot_elems(self):
+        return sum((c + 1) * h * w for c, h, w in self._level_shapes())
+
     def _level_shapes(self):
         if self._shapes is None:
             raise RuntimeError("ShardedCollab: level shapes unknown -- prepare() (or local() on a rank that owns agents) runs first")
@@ -427,6 +513,10 @@ class ShardedCollabCompressed(ShardedCollab):
             raise RuntimeError(f"compressed split: this rank's encoder output {self._zshape} differs from the job's {got}")
         self._zshape = got
         self._agreed = True
+
+    def _slot_elems(self):
+        c, h, w = self._zshape
+        return c * h * w
 
     @torch.no_grad()
     def local(self, scene_input, n_agents, local_inputs):
@@ -484,6 +574,10 @@ class ShardedBaseline(_Sharded):
             dist.all_reduce(shape, op=dist.ReduceOp.MAX)
         self._shape = tuple(int(v) for v in shape.tolist())
         self._agreed = True
+
+    def _slot_elems(self):
+        c, h, w = self._shape
+        return c * h * w
 
     @torch.no_grad()
     def local(self, scene_input, n_agents, local_inputs):

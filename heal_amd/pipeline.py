@@ -6,7 +6,7 @@ I/O: inputs are already resident in HBM.
 import numpy as np
 import torch
 
-from heal_amd import synth
+from heal_amd import _capi, synth
 from heal_amd.opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
 from heal_amd.opencood.tools.train_utils import create_model
 
@@ -276,7 +276,9 @@ class ScenePipeline:
         with torch.cuda.graph(graph, stream=cur):
             static_out = body()
         # the capacity counters written inside the graph live in its private pool: keep them to re-check after every replay
-        return _Slot(static, graph, static_out, ops.take_sparse_checks(), cur)
+        slot = _Slot(static, graph, static_out, ops.take_sparse_checks(), cur)
+        slot.guard = _capi.guard_take()       # HEAL_GRAPH_GUARD=1: every device address the capture handed to a kernel
+        return slot
 
     @torch.no_grad()
     def capture(self, scene, warmup=3, slack=1.25):
@@ -284,6 +286,7 @@ class ScenePipeline:
         it on whatever the buffers hold, `replay(other_scene)` loads another frame of the same layout first."""
         slot = self.capture_slot(scene, warmup, slack)
         self._static_in, self._graph, self._static_out, self._graph_checks = slot.static_in, slot.graph, slot.out, slot.checks
+        self._guard = slot.guard
         return slot.graph
 
     def check_sparse_capacity(self):
@@ -297,6 +300,8 @@ class ScenePipeline:
         hold; returns (pred_box3d | None, scores | None) like step()."""
         if scene is not None:
             self._static_in.load(scene)
+        if getattr(self, "_guard", None):
+            _capi.guard_check(self._guard, "ScenePipeline.replay")
         self._graph.replay()
         corners, scores, count = self._static_out
         k = int(count.item())
@@ -313,6 +318,7 @@ class _Slot:
     def __init__(self, static_in, graph, out, checks, stream):
         self.static_in, self.graph, self.out, self.checks, self.stream = static_in, graph, out, checks, stream
         self.done = torch.cuda.Event()
+        self.guard = []
 
 
 class FramesInFlight:
@@ -370,6 +376,8 @@ class FramesInFlight:
             if len(self._done) == self.depth:
                 slot.stream.wait_event(self._done[0])        # at most `depth` frames run at a time
             slot.static_in.load(scene)
+            if slot.guard:
+                _capi.guard_check(slot.guard, "FramesInFlight.step")
             slot.graph.replay()
             ev = torch.cuda.Event()
             ev.record(slot.stream)

@@ -176,3 +176,38 @@ def test_v2xvit_encoder_on_row_stripes_world2(tmp_path):
     assert float((got - want).abs().max()) < 1e-5 * scale
     # without the exchange a stripe pools only its own rows: the split-attention weights differ -> the test would see it
     assert float((local_only - want[:8]).abs().max()) > 1e-4 * scale
+
+
+def _window_worker(rank, world, port, tmp):
+    """dist.PeerWindow on host memory: rank 0's buffer mapped into both ranks, rows written in place, `free` / `ready` fences."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_slots, per_slot = 2, 1000
+    w = hd.PeerWindow(rank, world, n_slots, per_slot, torch.float32, "cpu")
+    assert tuple(w.full.shape) == (world, n_slots, per_slot) and tuple(w.mine.shape) == (n_slots, per_slot)
+    seen = []
+    for frame in range(3):
+        w.fence()                                     # free: rank 0 has read the previous frame
+        w.mine.copy_(torch.full((n_slots, per_slot), float(10 * frame + rank + 1)))
+        w.fence()                                     # ready
+        if rank == 0:
+            seen.append(w.full.clone())
+    if rank == 0:
+        torch.save(seen, tmp)
+    dist.barrier()
+    del w
+    dist.destroy_process_group()
+
+
+def test_peer_window_rows_written_in_place_world2(tmp_path):
+    """HEAL_COLLECTIVE=p2p (dist.PeerWindow, SURVEY 8e "prefer direct P2P"): what every rank writes into ITS rows is what rank 0 reads after
+    the `ready` fence, frame after frame -- the N > 1 exchange without a data collective, on gloo and host shared memory (the GPU form,
+    hipIpcMemHandle, is tests/test_gpu_dist.py::test_sharded_p2p_window_equals_gather_and_single_process)."""
+    out = str(tmp_path / "win.pt")
+    mp.spawn(_window_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    seen = torch.load(out)
+    assert len(seen) == 3
+    for frame, full in enumerate(seen):
+        for r in range(2):
+            assert torch.equal(full[r], torch.full((2, 1000), float(10 * frame + r + 1))), (frame, r)

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=None, stripes=None):
+def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=None, stripes=None, collective=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -40,7 +40,8 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=Non
                     for k, p in scene.points.items()}
     from heal_amd import synth
     scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
-    sharded = make_sharded(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None, split=split)
+    sharded = make_sharded(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None, split=split,
+                           collective=collective)
     assert isinstance(sharded, ShardedCollab if fusion is None else ShardedBaseline)
     if split == "compressed":
         from heal_amd.dist import ShardedCollabCompressed
@@ -69,11 +70,24 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=Non
                 # local | all-to-all | encoder up to each split attention | all-gather | ... | gather | heads (rank 0)
                 assert kinds.count("coll") == 2 + 3 and kinds[0] == ("graph" if mine else "coll"), kinds
                 assert kinds[-1] == ("graph" if rank == 0 else "coll"), kinds
+        if collective == "p2p":
+            # the exchange really is the peer window: every rank's rows alias rank 0's allocation, and (fp32 wire, pyramid levels) the
+            # local stage wrote them in place -- no packed copy exists
+            w = sharded._window
+            assert w is not None and tuple(w.full.shape[:1]) == (world,)
+            if fusion is None and wire is None and mine:
+                assert sharded._static_buf.data_ptr() == w.mine.data_ptr()
+            gather_ref = make_sharded(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None, split=split)
+            via_gather = gather_ref.forward(scene.model_input(), len(mods), scene.inputs_for(mine))
+            if rank == 0:   # same kernels, same values: the window path equals the gather path BIT FOR BIT
+                for k in ("cls_preds", "reg_preds", "dir_preds"):
+                    assert torch.equal(out[k], via_gather[k]) and torch.equal(rep[k], via_gather[k]), k
         if rank == 0:
             ref = pipe.model(scene.model_input())
             torch.save({k: (out[k].cpu(), ref[k].cpu(), rep[k].cpu()) for k in ("cls_preds", "reg_preds", "dir_preds")},
                        out_path)
     dist.barrier()
+    del sharded
     dist.destroy_process_group()
 
 
@@ -152,7 +166,7 @@ def test_sharded_compressed_wire_equals_single_process(tmp_path):
         assert float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)) < 1e-4, ("graph replay", k)
 
 
-def _ring_worker(rank, world, port, mods, out_path, fusion=None, rounds=1):
+def _ring_worker(rank, world, port, mods, out_path, fusion=None, rounds=1, collective=None):
     """Two frames in flight through the agent-sharded step (dist.ShardedFramesInFlight): the boxes of a SEQUENCE of different
     frames must equal the single-process pipeline's, frame by frame."""
     import numpy as np
@@ -184,8 +198,8 @@ def _ring_worker(rank, world, port, mods, out_path, fusion=None, rounds=1):
     work = torch.cuda.Stream()
     torch.cuda.set_stream(work)
     with torch.no_grad():
-        ring = ShardedFramesInFlight(lambda: make_sharded(pipe.model, rank, world), frames[0], len(mods), rank, world, depth=2,
-                                     post_fn=post_fn)
+        ring = ShardedFramesInFlight(lambda: make_sharded(pipe.model, rank, world, collective=collective), frames[0], len(mods), rank,
+                                     world, depth=2, post_fn=post_fn)
         got = []
         for _round in range(rounds):
             for f in frames:
@@ -211,12 +225,13 @@ def _ring_worker(rank, world, port, mods, out_path, fusion=None, rounds=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_agents,fusion", [(3, None), (2, None), (3, "v2xvit")])
-def test_sharded_frames_in_flight_equal_single_process(tmp_path, n_agents, fusion):
-    """fusion = "v2xvit": the striped tail (programs of graphs and collectives) with two frames in flight."""
+@pytest.mark.parametrize("n_agents,fusion,collective", [(3, None, None), (2, None, None), (3, "v2xvit", None), (3, None, "p2p")])
+def test_sharded_frames_in_flight_equal_single_process(tmp_path, n_agents, fusion, collective):
+    """fusion = "v2xvit": the striped tail (programs of graphs and collectives) with two frames in flight.  collective = "p2p": two peer
+    windows (one per slot), `free` / `ready` fences instead of the gather."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "ring.pt")
-    mp.spawn(_ring_worker, args=(2, _free_port(), ["m1"] * n_agents, out, fusion), nprocs=2, join=True)
+    mp.spawn(_ring_worker, args=(2, _free_port(), ["m1"] * n_agents, out, fusion, 1, collective), nprocs=2, join=True)
     pairs = torch.load(out)
     assert len(pairs) == 5
     seen = 0
@@ -248,3 +263,21 @@ def test_sharded_ring_200_frames(tmp_path):
         assert (gb is None) == (wb is None)
         if wb is not None:
             assert abs(gb.shape[0] - wb.shape[0]) <= 3
+
+
+@pytest.mark.parametrize("n_agents,fusion,wire", [(3, None, None), (1, None, None), (3, None, "float16"), (3, "att", None)])
+def test_sharded_p2p_window_equals_gather_and_single_process(tmp_path, n_agents, fusion, wire):
+    """SURVEY 8e "prefer direct P2P over ring" (VERDICT r4 missing 3): HEAL_COLLECTIVE=p2p -- rank 0's exchange buffer is mapped into
+    every rank (hipIpcMemHandle; here two processes on one device), the owners write their rows into it from the producing kernel, two
+    one-element all-reduces per frame order the accesses.  Same heads as the gather path bit for bit (asserted in the worker), eager and
+    as graph(local) -> ready -> graph(tail), and the single-process model to rounding.  n_agents = 1: one rank owns nothing; fp16: the
+    wire conversion is the one peer copy; att: HeterModelBaseline packs its own buffer (one peer copy)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "p2p.pt")
+    mp.spawn(_worker, args=(2, _free_port(), ["m1"] * n_agents, out, wire, fusion, None, None, "p2p"), nprocs=2, join=True)
+    res = torch.load(out)
+    tol = 1e-3 if wire else 1e-4
+    for k, (got, ref, rep) in res.items():
+        assert float(ref.abs().max()) > 0
+        assert float((got - ref).abs().max() / (ref.abs().max() + 1e-12)) < tol, k
+        assert float((rep - ref).abs().max() / (ref.abs().max() + 1e-12)) < tol, ("graph replay", k)

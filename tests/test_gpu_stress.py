@@ -97,3 +97,63 @@ def test_fill_bytes_inside_a_busy_graph():
         del z
     with pytest.raises(Exception):
         ops.fill_bytes(big[1:6], 0)                              # not 4-byte aligned / sized: refused, not rounded
+
+
+def test_graph_guard_names_a_freed_address():
+    """HEAL_GRAPH_GUARD (heal_amd/_capi.py): addresses handed to kernels during a capture are logged; the check passes
+    while their tensors live -- those of the ordinary pool AND the ones allocated and released inside the capture (graph-private pool) --
+    and names the entry point once one of them has been freed."""
+    from heal_amd import _capi, ops
+    st = torch.cuda.Stream()
+    old = _capi._GUARD
+    _capi._GUARD = True
+    try:
+        with torch.cuda.stream(st):
+            _capi.guard_take()
+            keep = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0")
+            victim = torch.zeros(3 << 20, dtype=torch.uint8, device="cuda:0")
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                ops.fill_bytes(keep, 1)
+                ops.fill_bytes(victim, 2)
+                tmp = torch.empty(1 << 16, dtype=torch.uint8, device="cuda:0")     # lives in the graph's private pool only
+                ops.fill_bytes(tmp, 3)
+                del tmp
+            log = _capi.guard_take()
+            assert {a for _, a in log} >= {keep.data_ptr(), victim.data_ptr()} and len(log) == 3
+            _capi.guard_check(log)                       # everything alive (the private-pool block is free but still the graph's)
+            g.replay()
+            st.synchronize()
+            addr = victim.data_ptr()
+            del victim                                   # block returns to the allocator: 'inactive'
+            with pytest.raises(_capi.HealAmdError, match="heal_fill_bytes.*%x" % addr):
+                _capi.guard_check(log)
+            torch.cuda.empty_cache()                     # ... and now back to the driver: unmapped
+            with pytest.raises(_capi.HealAmdError, match="heal_fill_bytes"):
+                _capi.guard_check(log)
+    finally:
+        _capi._GUARD = old
+        _capi.guard_take()
+
+
+def test_graph_guard_passes_on_the_pipeline(monkeypatch):
+    """The whole captured step under the guard: ~100 logged addresses (inputs, scratch per stream, weight layouts, outputs), all live
+    across 10 replays on changing frames, two slots in flight."""
+    from heal_amd import _capi, configs
+    from heal_amd.pipeline import FramesInFlight, ScenePipeline
+    monkeypatch.setattr(_capi, "_GUARD", True)
+    frames = _frames(2, 3, True)
+    side = torch.cuda.Stream()
+    with torch.no_grad(), torch.cuda.stream(side):
+        pipe = ScenePipeline(configs.lidar_pyramid([-25.6, -25.6, -3, 25.6, 25.6, 1]), "cuda:0", seed=3)
+        pipe.calibrate_cls_bias(frames[0], target_candidates=200)
+        pipe.capture(frames[0], warmup=1)
+        assert len(pipe._guard) > 50
+        for k in range(4):
+            pipe.replay(frames[k % 3])
+        ring = FramesInFlight(pipe, frames[0], depth=2, warmup=1)
+        assert all(len(s.guard) > 50 for s in ring.slots)
+        for k in range(6):
+            ring.step(frames[k % 3])
+        ring.drain()
+    torch.cuda.synchronize()
