@@ -147,7 +147,7 @@ def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
         _PMC = {}
     if workload not in _PMC:
         _PMC[workload] = {}
-        for tag in ("r04", "r03"):      # the newest committed PMC summary of this workload
+        for tag in ("r05", "r04", "r03"):      # the newest committed PMC summary of this workload
             path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{workload}.json")
             if os.path.exists(path):
                 _PMC[workload] = json.load(open(path))["kernels"]
@@ -169,6 +169,11 @@ def _entry(kernel, bound, achieved, launches, launch_ms, traffic=None, **extra):
          "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
          "traffic_source": None if traffic is None else "committed rocprofv3 PMC summary (profiles/), not measured in this run",
          "launches": launches, "launch_ms": round(launch_ms, 5)}
+    if bound == "hbm" and traffic is not None and launch_ms > 0:
+        # `frac` prices the kernel at SURVEY 8d's ALGORITHMIC bytes, which for a fused kernel include traffic it no
+        # longer performs (K4: the dense cell map it stopped writing).  This is the same launch duration with the bytes the counters saw
+        # cross the HBM interface: what the kernel actually sustains.  Both are printed; neither replaces the other.
+        d["frac_counter_bytes"] = round(traffic / (launch_ms * 1e-3) / 1e9 / peak, 4)
     d.update(extra)
     return d
 
@@ -301,10 +306,10 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         if in_graph and "voxelize" in in_graph:      # the launch chain as the timed region runs it (captured graph), not host-paced
             extra = {"eager_event_pair_ms": round(mean_ms, 5), "duration": "per-call period of the launch chain inside a captured graph"}
             mean_ms = in_graph["voxelize"]
-        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: one memset + four kernels)", "hbm",
+        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: the table fill + four kernels)", "hbm",
                                                  bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
                                                  pmc_traffic(a.workload, "heal::k_voxb_insert", "heal::k_vox_assign",
-                                                             "heal::k_vox_fill", "heal::k_vox_select_write"),   # (+ one memset: not a kernel)
+                                                             "heal::k_vox_fill", "heal::k_vox_select_write"),   # (+ the table fill, k_fill_words: shared by all operators, not in the sum)
                                                  bytes_per_launch=bts, **extra))
     if "decode_nms" in timing:
         calls, mean_ms = timing["decode_nms"]
@@ -314,7 +319,7 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         if in_graph and "decode_nms" in in_graph:
             extra = {"eager_event_pair_ms": round(mean_ms, 5), "duration": "per-call period of the launch chain inside a captured graph"}
             mean_ms = in_graph["decode_nms"]
-        entries["k8"] = (calls * mean_ms, _entry("K8 heal_decode_nms (decode + filters + rotated NMS: one memset + four kernels; "
+        entries["k8"] = (calls * mean_ms, _entry("K8 heal_decode_nms (decode + filters + rotated NMS: a 4-byte fill + four kernels; "
                                                  "latency-bound)", "hbm",
                                                  bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
                                                  pmc_traffic(a.workload, "heal::k_decode_key", "heal::k_rank_prepare",
