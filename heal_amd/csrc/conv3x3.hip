@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ x, co
 //     (co, tile) gathers its 16 transform-domain sums, applies A^T . A, bias (+ residual) (+ ReLU) and stores 2x2 pixels.
 // Arithmetic: fp32 throughout; the transform changes the rounding sequence (like the library's F(2,3) kernel): ~1e-6
 // relative to the direct evaluation, inside the 1e-3 feature tolerance and tested at 1e-4.
-constexpr int WG_KC = 8;                         // input channels per chunk
+constexpr int WG_KC = 8;                         // input channels per chunk (default); KC = 16: round 5, half the barriers per MFMA
 constexpr int WG_PROW = 24;                      // patch row stride (words): 2*24 = 48 -> the 4 tile rows of a 32-lane ds_read_b64 phase fall in disjoint bank ranges
 constexpr int WG_PDUMMY = 512;                   // landing zone of the staging slots beyond the patch (keeps the stores unconditional)
 
 // NW = waves per block: 8 -> 16x16 output pixels (64 tiles), two transform positions per wave, one block per CU;
 //                       4 -> 8x16 output pixels (32 tiles), four transform positions per wave, TWO independent blocks per CU
 //                            (same 8 waves per CU), so one block's transform phase overlaps the other's MFMA phase.
-template <int NW>
+template <int NW, int KC = WG_KC>
 struct WgGeom {
     static constexpr int TR = 2 * NW;                    // output rows of the block's tile
     static constexpr int NTL = 8 * NW;                   // 2x2 tiles per block (TR/2 rows x 8)
@@ -232,10 +232,11 @@ struct WgGeom {
     static constexpr int PCI = PR * WG_PROW;             // LDS words per patch channel
     static constexpr int VROW = NTL + 16;                // sV row stride: k-rows lk, lk+1 of a B fragment hit disjoint banks
     static constexpr int MROW = NTL + 4;                 // sM row stride: 4*MROW = 16 (mod 32) -> conflict-free accumulator dump
-    static constexpr int STAGE = WG_KC * PCI + WG_PDUMMY + 16 * WG_KC * VROW;
+    static constexpr int STAGE = KC * PCI + WG_PDUMMY + 16 * KC * VROW;
     static constexpr int SMEM = STAGE > 16 * 16 * MROW ? STAGE : 16 * 16 * MROW;   // staging buffers alias the epilogue buffer
-    static constexpr int NP = (WG_KC * PE + 64 * NW - 1) / (64 * NW);              // patch elements staged per thread
-    static constexpr int UQ = XW * 2;                    // float4 of U per lane per chunk (XW xi x 2 k-steps x 4 m-tiles floats)
+    static constexpr int NP = (KC * PE + 64 * NW - 1) / (64 * NW);                 // patch elements staged per thread
+    static constexpr int KS = KC / 4;                    // MFMA k-steps per chunk
+    static constexpr int UQ = XW * KS;                   // float4 of U per lane per chunk (XW xi x KS k-steps x 4 m-tiles floats)
 };
 
 // EXACT (Cin % 8 == 0: every shape of the two BASELINE scenes): the addresses of the loop are a UNIFORM base that advances by one
@@ -243,17 +244,19 @@ struct WgGeom {
 // Round 3 recomputed, per chunk and element, the clamped channel, a 64-bit `channel * HW + offset` and the in-range predicate of
 // the store: ~60 of the 150 non-MFMA instructions of an iteration, all in the transform phase the matrix pipe waits for.
 // The zero padding is written ONCE (slots outside the image keep their zero: their loads land in the dummy zone).
-template <int NW, bool EXACT>
+template <int NW, bool EXACT, int KC = WG_KC>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restrict__ x, const float4* __restrict__ ufrag,
                                                          const float* __restrict__ bias, const float* __restrict__ res,
                                                          int Cin, int nchunks, int Cout, int H, int W, int tiles_x, int relu,
                                                          float* __restrict__ y) {
-    using G = WgGeom<NW>;
+    using G = WgGeom<NW, KC>;
     constexpr int NT = 64 * NW, TR = G::TR, NTL = G::NTL, XW = G::XW, NTN = G::NTN, PE = G::PE, PCI = G::PCI;
-    constexpr int VROW = G::VROW, MROW = G::MROW, NP = G::NP, UQ = G::UQ;
+    constexpr int VROW = G::VROW, MROW = G::MROW, NP = G::NP, UQ = G::UQ, KS = G::KS;
+    constexpr int TCH = KC / (NT / NTL);          // channels a thread transforms per chunk (NT / NTL = 8 per sweep)
+    static_assert(KC == 8 || KC == 16, "chunk of 8 or 16 input channels");
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
     float* sP = smem;
-    float* sV = smem + WG_KC * PCI + WG_PDUMMY;
+    float* sV = smem + KC * PCI + WG_PDUMMY;
     float* sM = smem;
 
     // Block order: tile fastest, image next, Cout block SLOWEST -- the Winograd weights are the big stream (16 x Cin x 64
@@ -282,20 +285,20 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
         const int e = threadIdx.x + NT * j;
         const int ci = e / PE, rem = e - ci * PE, py = rem / 18, px = rem - py * 18;
         const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-        const bool ok = e < WG_KC * PE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool ok = e < KC * PE && gy >= 0 && gy < H && gx >= 0 && gx < W;
         p_off[j] = ok ? gy * W + gx : 0;
         p_ok |= ok ? (1u << j) : 0u;
-        p_lds[j] = e < WG_KC * PE ? ci * PCI + py * WG_PROW + px : WG_KC * PCI + (e - WG_KC * PE) % WG_PDUMMY;
+        p_lds[j] = e < KC * PE ? ci * PCI + py * WG_PROW + px : KC * PCI + (e - KC * PE) % WG_PDUMMY;
         if constexpr (EXACT) {
-            if (!ok && e < WG_KC * PE) {      // padding: zero once, then send this slot's (clamped) loads to the dummy zone
+            if (!ok && e < KC * PE) {      // padding: zero once, then send this slot's (clamped) loads to the dummy zone
                 sP[p_lds[j]] = 0.f;
-                p_lds[j] = WG_KC * PCI + e % WG_PDUMMY;
+                p_lds[j] = KC * PCI + e % WG_PDUMMY;
             }
-            p_off[j] = (int)(((size_t)min(ci, WG_KC - 1) * HW + (size_t)p_off[j]) * sizeof(float));   // < 8 HW 4 B: fits (host check)
+            p_off[j] = (int)(((size_t)min(ci, KC - 1) * HW + (size_t)p_off[j]) * sizeof(float));   // < 8 HW 4 B: fits (host check)
         }
     }
     float pst[NP];
-    const size_t chunk_bytes = (size_t)WG_KC * HW * sizeof(float);
+    const size_t chunk_bytes = (size_t)KC * HW * sizeof(float);
     auto load_patch = [&](int c) {
         if constexpr (EXACT) {
             const char* __restrict__ cb = reinterpret_cast<const char*>(xin) + (size_t)c * chunk_bytes;   // uniform
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
         } else {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int ch = min(c * WG_KC + (int)(threadIdx.x + NT * j) / PE, Cin - 1);
+                const int ch = min(c * KC + (int)(threadIdx.x + NT * j) / PE, Cin - 1);
                 pst[j] = xin[(size_t)ch * HW + p_off[j]];
             }
         }
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
                 sP[p_lds[j]] = pst[j];
             } else {
                 const int ci = (int)(threadIdx.x + NT * j) / PE;
-                const bool ok = ((p_ok >> j) & 1u) && c * WG_KC + ci < Cin;
+                const bool ok = ((p_ok >> j) & 1u) && c * KC + ci < Cin;
                 sP[p_lds[j]] = ok ? pst[j] : 0.f;
             }
         }
@@ -357,12 +360,15 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
         const int cn = min(c + 1, nchunks - 1);
         lds_barrier();                            // patch(c) is in LDS; every wave is done with sV of chunk c-1
         load_patch(cn);
-        {   // V = B^T d B for (tci, ttile)
+#pragma unroll
+        for (int h = 0; h < TCH; ++h) {   // V = B^T d B for (tci + 8 h, ttile)
+            const float* __restrict__ ds_ = dsrc + h * (NT / NTL) * PCI;
+            float* __restrict__ vd_ = vdst + h * (NT / NTL) * VROW;
             float d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float2 lo = *reinterpret_cast<const float2*>(dsrc + i * WG_PROW);
-                const float2 hi = *reinterpret_cast<const float2*>(dsrc + i * WG_PROW + 2);
+                const float2 lo = *reinterpret_cast<const float2*>(ds_ + i * WG_PROW);
+                const float2 hi = *reinterpret_cast<const float2*>(ds_ + i * WG_PROW + 2);
                 d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
             }
             float t[4][4];
@@ -375,10 +381,10 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vdst[((4 * i + 0) * WG_KC) * VROW] = t[i][0] - t[i][2];
-                vdst[((4 * i + 1) * WG_KC) * VROW] = t[i][1] + t[i][2];
-                vdst[((4 * i + 2) * WG_KC) * VROW] = t[i][2] - t[i][1];
-                vdst[((4 * i + 3) * WG_KC) * VROW] = t[i][1] - t[i][3];
+                vd_[((4 * i + 0) * KC) * VROW] = t[i][0] - t[i][2];
+                vd_[((4 * i + 1) * KC) * VROW] = t[i][1] + t[i][2];
+                vd_[((4 * i + 2) * KC) * VROW] = t[i][2] - t[i][1];
+                vd_[((4 * i + 3) * KC) * VROW] = t[i][1] - t[i][3];
             }
         }
         lds_barrier();                            // sV(c) complete; sP free (global loads stay in flight)
@@ -390,9 +396,9 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
             for (int xi_i = 0; xi_i < XW; ++xi_i) {
                 // column ln of n-tile nt is TILE NTN * ln + nt (GEMM columns can be numbered freely): a lane's B operands of all its
                 // n-tiles are consecutive words of sV -- one ds_read_b128 (b64 for the 4-wave block) instead of NTN b32 reads
-                const float* __restrict__ vb = sV + ((XW * wave + xi_i) * WG_KC + lk) * VROW + NTN * ln;
+                const float* __restrict__ vb = sV + ((XW * wave + xi_i) * KC + lk) * VROW + NTN * ln;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     float b[NTN];
                     if constexpr (NTN == 4) {
                         const float4 q4 = *reinterpret_cast<const float4*>(vb + ks * 4 * VROW);
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
                     for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            acc[xi_i][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[(xi_i * 2 + ks) * 4 + mt], b[nt],
+                            acc[xi_i][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[(xi_i * KS + ks) * 4 + mt], b[nt],
                                                                                      acc[xi_i][mt][nt], 0, 0, 0);
                 }
             }
@@ -656,10 +662,17 @@ extern "C" int heal_conv3x3_same(const float* x, const float* weight_frag, const
 
 extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
                                      int cin, int cout, int H, int W, int relu, int waves, float* y, void* stream) {
+    return heal_conv3x3_winograd_kc(x, u_frag, bias, residual, n, cin, cout, H, W, relu, waves, WG_KC, y, stream);
+}
+
+extern "C" int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
+                                        int cin, int cout, int H, int W, int relu, int waves, int kc, float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv3x3_winograd: bad shape");
     HEAL_REQUIRE(x && u_frag && y, "conv3x3_winograd: null pointer");
     HEAL_REQUIRE(((uintptr_t)u_frag & 15) == 0, "conv3x3_winograd: weight fragments must be 16-B aligned");
-    const int nchunks = (cin + WG_KC - 1) / WG_KC, mblocks = (cout + 63) / 64;
+    HEAL_REQUIRE(kc == 8 || (kc == 16 && waves == 8 && cin % 16 == 0),
+                 "conv3x3_winograd: chunks of 16 input channels need 8 waves per block and cin %% 16 == 0 (kc=%d waves=%d cin=%d)", kc, waves, cin);
+    const int nchunks = (cin + kc - 1) / kc, mblocks = (cout + 63) / 64;
     HEAL_REQUIRE(waves == 8 || waves == 4, "conv3x3_winograd: waves per block must be 8 (16x16-pixel tiles) or 4 (8x16)");
     const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 2 * waves);
     HEAL_REQUIRE((long long)tiles_x * tiles_y <= 2147483647ll / 4 && n <= 65535 && mblocks <= 65535,
@@ -667,12 +680,21 @@ extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const 
     const dim3 grid(tiles_x * tiles_y, n, mblocks);
     const float4* uf = reinterpret_cast<const float4*>(u_frag);
     // uniform-base addressing (see the kernel): whole chunks and byte offsets inside a chunk that fit 32 bits
-    const bool exact = cin % WG_KC == 0 && (long long)WG_KC * H * W * 4 < 2147483647ll;
-#define HEAL_WINO_LAUNCH(NW_, EX_)                                                                                              \
-    HEAL_LAUNCH_EV((k_conv3x3_wino<NW_, EX_>), grid, dim3(64 * NW_), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, \
+    const bool exact = cin % kc == 0 && (long long)kc * H * W * 4 < 2147483647ll;
+#define HEAL_WINO_LAUNCH(NW_, EX_, KC_)                                                                                              \
+    HEAL_LAUNCH_EV((k_conv3x3_wino<NW_, EX_, KC_>), grid, dim3(64 * NW_), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, \
                    cout, H, W, tiles_x, relu, y)
-    if (waves == 8) { if (exact) HEAL_WINO_LAUNCH(8, true); else HEAL_WINO_LAUNCH(8, false); }
-    else { if (exact) HEAL_WINO_LAUNCH(4, true); else HEAL_WINO_LAUNCH(4, false); }
+    if (kc == 16) {
+        HEAL_REQUIRE(exact, "conv3x3_winograd: kc = 16 needs a map of less than 2^31 / 64 bytes per channel");
+        // 111.6 KB of LDS per block: above the 64 KB a kernel gets without asking
+        static bool attr16 = false;
+        if (!attr16) {
+            HEAL_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino<8, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+            attr16 = true;
+        }
+        HEAL_WINO_LAUNCH(8, true, 16);
+    } else if (waves == 8) { if (exact) HEAL_WINO_LAUNCH(8, true, 8); else HEAL_WINO_LAUNCH(8, false, 8); }
+    else { if (exact) HEAL_WINO_LAUNCH(4, true, 8); else HEAL_WINO_LAUNCH(4, false, 8); }
 #undef HEAL_WINO_LAUNCH
     HEAL_LAUNCH_CHECK();
     return 0;

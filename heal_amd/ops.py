@@ -1732,23 +1732,35 @@ def conv3x3_winograd_waves(n=1, cout=64, H=256, W=256):
     return 8 if blocks8 >= 512 else 4
 
 
-def conv3x3_winograd_fragments(w, waves=8):
+def conv3x3_winograd_kc(cin, waves):
+    """Input channels per chunk of the Winograd K loop: 16 where the kernel has it (8-wave blocks, cin % 16 == 0) and HEAL_WG_KC
+    allows, else 8.  Measured in round 5 (profiles/r05_wino_kc16.txt)."""
+    import os
+    want = os.environ.get("HEAL_WG_KC", _WG_KC_DEFAULT)
+    return 16 if (want == "16" and waves == 8 and cin % 16 == 0) else 8
+
+
+_WG_KC_DEFAULT = "8"
+
+
+def conv3x3_winograd_fragments(w, waves=8, kc=8):
     """Cached Winograd-domain weights U = G g G^T of a [Cout,Cin,3,3] filter bank in the lane-major fragment order
-    heal_conv3x3_winograd reads for `waves` waves per block (include/heal_amd.h); keyed by storage + version."""
-    key = (w.data_ptr(), w._version, tuple(w.shape), waves)
+    heal_conv3x3_winograd[_kc] reads for `waves` waves per block and `kc` channels per chunk (include/heal_amd.h); keyed by storage +
+    version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), waves, kc)
     hit = _FRAGW_CACHE.get(key)
     if hit is None:
         if len(_FRAGW_CACHE) > 512:
             _retire_cache(_FRAGW_CACHE)
         cout, cin = int(w.shape[0]), int(w.shape[1])
-        mpad, kpad = (cout + 63) // 64 * 64, (cin + 7) // 8 * 8
+        mpad, kpad = (cout + 63) // 64 * 64, (cin + kc - 1) // kc * kc
         G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
                          device=w.device)
         U = (G @ w.detach().double() @ G.t()).float().reshape(cout, cin, 16)      # xi = 4a + b
         if (mpad, kpad) != (cout, cin):
             U = torch.nn.functional.pad(U, (0, 0, 0, kpad - cin, 0, mpad - cout))
         # [mb, mt, ln, chunk, ks, lk, w, xi_i] -> [mb, chunk, w, lk, ln, xi_i, ks, mt]
-        f = U.reshape(mpad // 64, 4, 16, kpad // 8, 2, 4, waves, 16 // waves).permute(0, 3, 6, 5, 2, 7, 4, 1).contiguous()
+        f = U.reshape(mpad // 64, 4, 16, kpad // kc, kc // 4, 4, waves, 16 // waves).permute(0, 3, 6, 5, 2, 7, 4, 1).contiguous()
         hit = (f, w)
         _FRAGW_CACHE[key] = hit
     return hit[0]
@@ -1856,11 +1868,12 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
         return y
     if conv3x3_algo(stride, n, cout, H, W) == "winograd":
         waves = conv3x3_winograd_waves(n, cout, H, W)
-        frag = conv3x3_winograd_fragments(w, waves)
+        kc = conv3x3_winograd_kc(cin, waves)
+        frag = conv3x3_winograd_fragments(w, waves, kc)
         with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo),
                     kernel_events=True):
-            _capi.call("heal_conv3x3_winograd", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
-                       int(bool(relu)), waves, _ptr(y), _stream())
+            _capi.call("heal_conv3x3_winograd_kc", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
+                       int(bool(relu)), waves, kc, _ptr(y), _stream())
         return y
     if stride == 2 and cin >= 128 and conv_gemm_supported(cin, cout, Wo) and n * Ho * Wo >= 65536:
         # the large stride-2 layers: the 128 x 128 x 32 implicit GEMM on 32x32x2 MFMA (heal_conv_gemm).  Measured

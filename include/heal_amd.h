@@ -591,6 +591,11 @@ int heal_grouped_small_conv3x3(const float* x, const float* weight_q, const floa
  *   w < waves, xi_i < XW, xi = 4a + b indexes the 4x4 transform domain (16-B aligned).  The fragment order depends on `waves`. */
 int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
                           int cout, int H, int W, int relu, int waves, float* y, void* stream);
+/* heal_conv3x3_winograd_kc: the same with `kc` input channels per chunk of the K loop: 8 (= heal_conv3x3_winograd) or 16 (round 5: half
+ *   the barriers and operand waits per MFMA, 112 KB of LDS; waves = 8 and cin %% 16 == 0 only).  Fragment order with KS = kc / 4:
+ *   frag[mb][chunk][w][lane][(xi_i*KS + ks)*4 + mt] = U[mb*64 + mt*16 + (lane & 15)][chunk*kc + ks*4 + (lane >> 4)][xi = XW*w + xi_i]. */
+int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
+                             int cout, int H, int W, int relu, int waves, int kc, float* y, void* stream);
 
 /* heal_conv3x3_winograd4: the same operator with the F(4x4,3x3) transform (36 positions, 6x6 input windows, 4x4 output tiles:
  *   1/4 of the direct multiplications; csrc/conv3x3_wino4.hip).  u_frag: U = G g G^T in the lane-major order

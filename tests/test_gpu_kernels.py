@@ -775,6 +775,8 @@ _C3_SHAPES = [
 ]
 # Winograd F(2x2,3x3) is the stride-1 formulation (8- and 4-wave blocks); the implicit GEMM takes every shape
 _C3_CASES = [sh + (algo,) for sh in _C3_SHAPES for algo in ("winograd", "winograd8", "winograd4", "direct") if algo == "direct" or sh[5] == 1]
+# round 5: chunks of 16 input channels (heal_conv3x3_winograd_kc; measured 4-13 % slower, opt-in HEAL_WG_KC=16) where it applies
+_C3_CASES += [sh + ("winograd8kc16",) for sh in _C3_SHAPES if sh[5] == 1 and sh[1] % 16 == 0]
 
 
 @pytest.mark.parametrize("n,cin,cout,H,W,stride,res,relu,algo", _C3_CASES)
@@ -783,6 +785,9 @@ def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu, algo, monk
     ReLU against torch's fp64 convolution: 1e-4 relative to the output scale (fp32 accumulation order and, for Winograd, the
     transform's rounding sequence differ; the north-star tolerance for features is 1e-3)."""
     from heal_amd import ops
+    kc16 = algo.endswith("kc16")
+    algo = algo[:-4] if kc16 else algo
+    monkeypatch.setenv("HEAL_WG_KC", "16" if kc16 else "8")
     monkeypatch.setenv("HEAL_C3_ALGO", algo if algo == "winograd4" else algo.rstrip("8"))   # winograd4: F(4x4,3x3)
     monkeypatch.setenv("HEAL_WG_WAVES", "8" if algo.endswith("8") else "4")   # 16x16- or 8x16-pixel Winograd blocks
     g = torch.Generator().manual_seed(cin * 31 + cout + H)
