@@ -24,7 +24,7 @@ cp $OUT/pmc_k2_traffic_scene5.json profiles/pmc_k2_traffic.json
 timeout 600 python bench.py > $OUT/bench_n1_scene5.json 2> $OUT/bench.err
 tail -c 300 $OUT/bench_n1_scene5.json; echo
 timeout 600 python bench.py --workload single > $OUT/bench_n1_single.json 2> $OUT/bench_single.err    # BASELINE configs 1 / 2, with cpu_baseline
-for w in pair scene5_lidar; do
+for w in pair scene5_lidar single_native pair_native; do     # (the *_native workloads: round 5, the YAMLs' 480 x 240 range)
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_n1_$w.json 2> $OUT/bench_$w.err
 done
 timeout 420 python bench.py --workload scene8_second_v2xvit --steps 10 --warmup 3 > $OUT/bench_n1_scene8_second_v2xvit.json 2> $OUT/bench_scene8.err
@@ -35,6 +35,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats8 
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_scene5.csv \;
 find $OUT/stats8 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_scene8_second_v2xvit.csv \;
 rm -rf $OUT/stats $OUT/stats8
+[ "${FAST:-0}" = "1" ] && { ls -la $OUT; exit 0; }      # FAST=1: the round's lines and stats only (the micro-benchmarks below are unchanged kernels)
 # per-kernel micro-benchmarks of the round's kernels
 timeout 200 python scripts/k4_bench.py > $OUT/${TAG}_k4_bench.json 2> /dev/null
 timeout 200 python scripts/k5_bench.py --json $OUT/${TAG}_k5_bench.json > /dev/null 2>&1
