@@ -330,6 +330,8 @@ class _Sharded:
         if not self._agree(ok, dev):
             self._g_local = self._g_tail = None
             return False
+        from heal_amd import _capi
+        self._guard = _capi.guard_take()      # HEAL_GRAPH_GUARD=1: the device addresses both captures handed to kernels
         return True
 
     def check_sparse_capacity(self):
@@ -340,6 +342,9 @@ class _Sharded:
     def replay(self):
         """graph(local) -> exchange (gather to rank 0 | all-gather) -> graph(tail).  The graphs read whatever the buffers behind the captured inputs hold
         (pipeline.StaticInputs.load puts the next frame there: sensor data AND poses)."""
+        if getattr(self, "_guard", None):
+            from heal_amd import _capi
+            _capi.guard_check(self._guard, f"{type(self).__name__}.replay (rank {self.rank})")
         if self.collective == "p2p":
             self._window.fence()        # free: behind rank 0's previous tail on this stream
         if self._g_local is not None:   # None: this rank owns no agent, its slot is the constant zero buffer
@@ -844,11 +849,16 @@ class ShardedBaselineStriped(ShardedBaseline):
             self._capture_error = e
             raise
         self._graph_checks = ops.take_sparse_checks()
+        from heal_amd import _capi
+        self._guard = _capi.guard_take()
         return True
 
     def replay(self):
         if not self._striped:
             return super().replay()
+        if getattr(self, "_guard", None):
+            from heal_amd import _capi
+            _capi.guard_check(self._guard, f"ShardedBaselineStriped.replay (rank {self.rank})")
         self._comm.replay()
         self._replays += 1
         if self._graph_checks and self._replays % 32 == 0:
