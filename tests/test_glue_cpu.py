@@ -155,3 +155,22 @@ def test_no_runtime_memset_or_d2d_copy_in_the_library():
         for m in re.finditer(r"\b(hipMemset\w*|hipMemcpy\w*Async)\s*\(", text):     # (a blocking D2H read in a debug branch is no graph node)
             hits.append((os.path.basename(path), m.group(0)))
     assert not hits, hits
+
+
+def test_collection_order_names_exist():
+    """tests/conftest.py runs one parity test per BASELINE config FIRST (by name) and the rank-spawning file LAST: a renamed test or file
+    would silently fall out of that order.  Every name in `_FIRST` must be a collected test, and they must lead the GPU collection."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--collect-only", "-q"], cwd=root,
+                         capture_output=True, text=True, timeout=600).stdout
+    ids = [line.strip() for line in out.splitlines() if "::" in line]
+    from tests import conftest
+    want = ["tests/" + name for name in conftest._FIRST]
+    assert ids[:len(want)] == want, ids[:len(want)]
+    files = [i.split("::")[0] for i in ids]
+    assert files[-1] == "tests/test_gpu_dist.py" and "tests/test_gpu_dist.py" not in files[:files.index("tests/test_gpu_dist.py")]
+    for f in conftest._FILE_RANK:
+        assert os.path.exists(os.path.join(root, "tests", f)), f
