@@ -524,13 +524,14 @@ def main():
                 if a.frames_in_flight > 1:
                     # throughput mode of the sharded step: `depth` captured copies, local stage of frame k + 1 under the fusion
                     # tail of frame k on rank 0 (dist.ShardedFramesInFlight); exchanges stay in frame order
-                    from heal_amd.dist import ShardedFramesInFlight
+                    from heal_amd.dist import AgreedCaptureFailure, ShardedFramesInFlight
                     try:
                         ring = ShardedFramesInFlight(lambda: make_sharded(pipe.model, rank, world, wire_dtype=wire), scene, n_agents,
                                                      rank, world, depth=a.frames_in_flight, post_fn=post_fn)
-                    except RuntimeError as e:
+                    except AgreedCaptureFailure as e:
                         # a slot that cannot be captured is AGREED between the ranks (dist._Sharded._agree), so every rank lands
-                        # here together and the job goes on with the serial sharded replay instead of dying
+                        # here together and the job goes on with the serial sharded replay instead of dying.
+                        # Any OTHER exception (e.g. the striped runner's one-rank failure) is not agreed: it ends the job
                         print(f"[bench] rank {rank}: frames in flight unavailable ({e}); serial sharded replay", file=sys.stderr)
                         ring = None
                     if ring is not None:

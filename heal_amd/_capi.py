@@ -10,6 +10,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HEAL_AMD_LIB") or os.path.join(HERE, "lib", "libheal_amd.so")  # env: A/B a rebuilt library
 HEADER = os.path.join(os.path.dirname(HERE), "include", "heal_amd.h")
+HEADER_EXPERIMENTAL = os.path.join(os.path.dirname(HERE), "include", "heal_amd_experimental.h")
 
 _lib = None
 
@@ -33,6 +34,11 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_float,
                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "heal_pfn_pillars": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p]),
+    "heal_pillar_canvas": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "heal_pillar_stem_block": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
     "heal_bev_pool_backward": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p] * 6),
     "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),
@@ -157,9 +163,10 @@ class HealAmdError(RuntimeError):
     pass
 
 
-def declared_symbols():
-    """Function names declared in include/heal_amd.h."""
-    text = open(HEADER).read()
+def declared_symbols(experimental=False):
+    """Function names declared in include/heal_amd.h (the shipped C ABI), or with experimental=True in
+    include/heal_amd_experimental.h (the measured-negative kernels of a HEAL_BUILD_EXPERIMENTAL=1 library)."""
+    text = open(HEADER_EXPERIMENTAL if experimental else HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(heal_[a-z0-9_]+)\s*\(", text)))
 
@@ -261,6 +268,14 @@ def _locate(segs, addr):
         if lo <= addr < hi:
             return segs[i][2], state
     return segs[i][2], "unknown"
+
+
+def guard_begin():
+    """Start of an OWNING capture (and every failure path of one): drop whatever earlier captures left in the log.  A capture that
+    failed or was aborted never reaches guard_take(); without this its addresses -- tensors legitimately freed since -- would be
+    inherited by the next owner and reported as 'freed' on its replays, and the log would grow without bound."""
+    global _guard_log
+    _guard_log = []
 
 
 def guard_take():

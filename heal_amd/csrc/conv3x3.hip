@@ -685,14 +685,12 @@ extern "C" int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, con
     HEAL_LAUNCH_EV((k_conv3x3_wino<NW_, EX_, KC_>), grid, dim3(64 * NW_), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, \
                    cout, H, W, tiles_x, relu, y)
     if (kc == 16) {
+#ifdef HEAL_BUILD_EXPERIMENTAL
         HEAL_REQUIRE(exact, "conv3x3_winograd: kc = 16 needs a map of less than 2^31 / 64 bytes per channel");
-        // 111.6 KB of LDS per block: above the 64 KB a kernel gets without asking
-        static bool attr16 = false;
-        if (!attr16) {
-            HEAL_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino<8, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 0));
-            attr16 = true;
-        }
-        HEAL_WINO_LAUNCH(8, true, 16);
+        HEAL_WINO_LAUNCH(8, true, 16);     // (111.6 KB of STATIC LDS: no dynamic-LDS attribute to raise)
+#else
+        HEAL_REQUIRE(false, "conv3x3_winograd: kc = 16 is a measured-negative variant, built only with HEAL_BUILD_EXPERIMENTAL=1");
+#endif
     } else if (waves == 8) { if (exact) HEAL_WINO_LAUNCH(8, true, 8); else HEAL_WINO_LAUNCH(8, false, 8); }
     else { if (exact) HEAL_WINO_LAUNCH(4, true, 8); else HEAL_WINO_LAUNCH(4, false, 8); }
 #undef HEAL_WINO_LAUNCH

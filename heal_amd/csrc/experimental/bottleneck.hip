@@ -14,8 +14,9 @@
 //            registers across the width chunks)
 //   epilogue bias + residual (x is still in LDS) + ReLU, store.
 // Weight matrices arrive pre-arranged in MFMA A-fragment order (one coalesced 256 B load per fragment).
-#include "common.h"
-#include "../../include/heal_amd.h"
+#include "../common.h"
+#include "../../../include/heal_amd.h"
+#include "../../../include/heal_amd_experimental.h"
 
 namespace heal {
 

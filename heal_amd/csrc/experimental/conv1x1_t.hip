@@ -23,8 +23,9 @@
 // Roofline: fp32 MFMA (157.3 TFLOP/s).  Dispatch (ops.conv1x1): Cin % 32 == 0, Cout % 64 == 0, stride 1, no input gate, >= 256
 // blocks; everything else stays on k_conv1x1.
 #include <stdlib.h>
-#include "common.h"
-#include "../../include/heal_amd.h"
+#include "../common.h"
+#include "../../../include/heal_amd.h"
+#include "../../../include/heal_amd_experimental.h"
 
 namespace heal {
 

@@ -28,8 +28,9 @@
 // relative to the output scale at Cin = 384 (measured against float64), inside the 1e-3 feature tolerance and the 1e-4 the
 // kernel tests use.
 #include <stdlib.h>
-#include "common.h"
-#include "../../include/heal_amd.h"
+#include "../common.h"
+#include "../../../include/heal_amd.h"
+#include "../../../include/heal_amd_experimental.h"
 
 namespace heal {
 

@@ -19,8 +19,9 @@
 // Traffic at level 1 per launch: 168 MB read (+ halo from L2) + 84 MB identity + 84 MB written -- what the grouped convolution ALONE
 // moved before.
 #include <stdlib.h>
-#include "common.h"
-#include "../../include/heal_amd.h"
+#include "../common.h"
+#include "../../../include/heal_amd.h"
+#include "../../../include/heal_amd_experimental.h"
 
 namespace heal {
 

@@ -457,25 +457,16 @@ extern "C" size_t heal_pfn_scatter_workspace(int n_voxels, int n_agents, int ny,
     return b + 256;
 }
 
-extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points,
-                                int n_voxels, const int32_t* n_voxels_dev, int max_points,
-                                const float* weight, const float* bn_scale, const float* bn_shift,
-                                int channels, float vx, float vy, float vz, float x_offset,
-                                float y_offset, float z_offset, int n_agents, int ny, int nx,
-                                float* canvas, float* pillar_feat, void* ws, size_t ws_bytes,
-                                void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    HEAL_REQUIRE(channels == PFN_C, "pfn_scatter: channels must be 64 (got %d)", channels);
-    HEAL_REQUIRE(max_points >= 1 && max_points <= 64, "pfn_scatter: max_points must be in [1,64]");
-    HEAL_REQUIRE(n_agents >= 1 && ny >= 1 && nx >= 1 && (nx * ny) % 4 == 0, "pfn_scatter: bad grid");
-    HEAL_REQUIRE(n_voxels >= 0, "pfn_scatter: negative n_voxels");
-    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "pfn_scatter: workspace must be 256-B aligned");
-    Arena a(ws, ws_bytes);
-    int* cell_map = a.take<int>((size_t)n_agents * ny * nx);
-    float* pf = pillar_feat;
-    if (pf == nullptr) pf = a.take<float>((size_t)(n_voxels < 1 ? 1 : n_voxels) * channels);
-    HEAL_REQUIRE(a.ok(), "pfn_scatter: workspace too small (%zu < %zu)", ws_bytes, a.off);
-
+// PillarVFE + PFN for the collated agents of a modality: pillar features [M, 64] and the cell -> pillar-row map (-1 = empty cell)
+static int pfn_pillars_impl(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
+                            const int32_t* n_voxels_dev, int max_points, const float* weight, const float* bn_scale,
+                            const float* bn_shift, int channels, float vx, float vy, float vz, float x_offset, float y_offset,
+                            float z_offset, int n_agents, int ny, int nx, float* pf, int* cell_map, hipStream_t s,
+                            const char* who) {
+    HEAL_REQUIRE(channels == PFN_C, "%s: channels must be 64 (got %d)", who, channels);
+    HEAL_REQUIRE(max_points >= 1 && max_points <= 64, "%s: max_points must be in [1,64]", who);
+    HEAL_REQUIRE(n_agents >= 1 && ny >= 1 && nx >= 1 && (nx * ny) % 4 == 0, "%s: bad grid", who);
+    HEAL_REQUIRE(n_voxels >= 0, "%s: negative n_voxels", who);
     HEAL_FILL(cell_map, 0xFF, (size_t)n_agents * ny * nx * sizeof(int), s);
     if (n_voxels > 0) {
         PfnGeom g{vx, vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx};
@@ -495,7 +486,45 @@ extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, cons
                                          bn_scale, bn_shift, g, pf, cell_map);
         HEAL_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points,
+                                int n_voxels, const int32_t* n_voxels_dev, int max_points,
+                                const float* weight, const float* bn_scale, const float* bn_shift,
+                                int channels, float vx, float vy, float vz, float x_offset,
+                                float y_offset, float z_offset, int n_agents, int ny, int nx,
+                                float* canvas, float* pillar_feat, void* ws, size_t ws_bytes,
+                                void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n_agents >= 1 && ny >= 1 && nx >= 1 && n_voxels >= 0, "pfn_scatter: bad sizes");
+    HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "pfn_scatter: workspace must be 256-B aligned");
+    Arena a(ws, ws_bytes);
+    int* cell_map = a.take<int>((size_t)n_agents * ny * nx);
+    float* pf = pillar_feat;
+    if (pf == nullptr) pf = a.take<float>((size_t)(n_voxels < 1 ? 1 : n_voxels) * channels);
+    HEAL_REQUIRE(a.ok(), "pfn_scatter: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    if (pfn_pillars_impl(voxels, coords, num_points, n_voxels, n_voxels_dev, max_points, weight, bn_scale, bn_shift, channels, vx,
+                         vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx, pf, cell_map, s, "pfn_scatter"))
+        return 1;
     return heal_canvas_from_map(cell_map, pf, n_agents, channels, ny * nx, canvas, s);
+}
+
+extern "C" int heal_pfn_pillars(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
+                                const int32_t* n_voxels_dev, int max_points, const float* weight, const float* bn_scale,
+                                const float* bn_shift, int channels, float vx, float vy, float vz, float x_offset,
+                                float y_offset, float z_offset, int n_agents, int ny, int nx, float* pillar_feat,
+                                int32_t* cell_map, void* stream) {
+    HEAL_REQUIRE(pillar_feat && cell_map && ((uintptr_t)cell_map & 15) == 0, "pfn_pillars: null / misaligned output");
+    return pfn_pillars_impl(voxels, coords, num_points, n_voxels, n_voxels_dev, max_points, weight, bn_scale, bn_shift, channels,
+                            vx, vy, vz, x_offset, y_offset, z_offset, n_agents, ny, nx, pillar_feat, cell_map,
+                            (hipStream_t)stream, "pfn_pillars");
+}
+
+extern "C" int heal_pillar_canvas(const int32_t* cell_map, const float* pillar_feat, int n_agents, int channels, int ny, int nx,
+                                  float* canvas, void* stream) {
+    HEAL_REQUIRE(cell_map && pillar_feat && canvas && n_agents >= 1 && ny >= 1 && nx >= 1, "pillar_canvas: bad arguments");
+    return heal_canvas_from_map(cell_map, pillar_feat, n_agents, channels, ny * nx, canvas, (hipStream_t)stream);
 }
 
 static PfnGeom pfn_geom(float vx, float vy, float vz, float xo, float yo, float zo) {

@@ -291,6 +291,8 @@ class _Sharded:
         self._capture_error = None
         ok = True
         self._g_local = None
+        from heal_amd import _capi
+        _capi.guard_begin()
         if self._ensure_window(n_agents) is not None:
             self._window.fence()               # free (the warm-up forwards above end with a tail on rank 0)
         if not owned_agents(n_agents, self.rank, self.world):
@@ -310,6 +312,7 @@ class _Sharded:
                 torch.cuda.synchronize()
         if not self._agree(ok, dev):
             self._g_local = None
+            _capi.guard_begin()
             return False
         g0 = self._exchange(self._static_buf)
         # p2p: the tail graph reads the window itself (a clone would be the copy the window exists to avoid)
@@ -329,8 +332,8 @@ class _Sharded:
                 torch.cuda.synchronize()
         if not self._agree(ok, dev):
             self._g_local = self._g_tail = None
+            _capi.guard_begin()
             return False
-        from heal_amd import _capi
         self._guard = _capi.guard_take()      # HEAL_GRAPH_GUARD=1: the device addresses both captures handed to kernels
         return True
 
@@ -840,16 +843,18 @@ class ShardedBaselineStriped(ShardedBaseline):
         self._graph_checks, self._replays = [], 0
         self._capture_error = None
         comm = self._comm
+        from heal_amd import _capi
+        _capi.guard_begin()
         comm.begin_capture(open_graph=bool(owned_agents(n_agents, self.rank, self.world)))
         try:
             self._static_post = self._step(scene_input, n_agents, local_inputs, comm, post_fn)
             comm.end_capture()
         except Exception as e:  # noqa: BLE001
             comm.abort_capture()
+            _capi.guard_begin()
             self._capture_error = e
             raise
         self._graph_checks = ops.take_sparse_checks()
-        from heal_amd import _capi
         self._guard = _capi.guard_take()
         return True
 
@@ -881,6 +886,13 @@ def make_sharded(model, rank, world, wire_dtype=None, collective=None, split=Non
     raise NotImplementedError(f"no agent-sharded split for {name}")
 
 
+class AgreedCaptureFailure(RuntimeError):
+    """A slot of ShardedFramesInFlight could not be captured AND every rank knows it: the `ok` that comes back from
+    `_Sharded.capture` is the all-reduced agreement of the ranks (`_agree`), so all of them raise this together and may fall
+    back together.  A failure of ONE rank only (ShardedBaselineStriped.capture re-raises its own exception: its peers are
+    inside the same collective sequence) is NOT this type and must end the job."""
+
+
 class ShardedFramesInFlight:
     """Throughput mode of the agent-sharded step (the N > 1 counterpart of pipeline.FramesInFlight):
     `depth` captured copies of the sharded step, each with its own static input buffers, exchange buffers, graphs and stream.
@@ -910,7 +922,7 @@ class ShardedFramesInFlight:
                 ok = runner.capture(static.scene_meta(), n_agents, static.inputs_for(mine), post_fn)
             stream.synchronize()
             if not ok:
-                raise RuntimeError(f"rank {rank}: the sharded step could not be captured ({runner._capture_error})")
+                raise AgreedCaptureFailure(f"rank {rank}: the sharded step could not be captured ({runner._capture_error})")
             self.slots.append((runner, static, stream))
         self._next = 0
         self._inflight = deque()

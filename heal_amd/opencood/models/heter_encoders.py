@@ -37,6 +37,18 @@ class PointPillar(nn.Module):
         self._fold_key = None
         self._fold = None
 
+    # set by the model when this encoder's backbone opens with a block that reads the pillars itself (bev_blocks.BasicBlock.
+    # takes_pooled): the inference forward then returns ops.PillarBEV instead of the dense canvas (HEAL_K2_POOLED=0: always dense)
+    emit_pooled = False
+
+    def _scatter_op(self, v, c, n, weight, scale, shift, n_agents, n_voxels_dev=None):
+        ny, nx = self.scatter.ny, self.scatter.nx
+        if self.emit_pooled and os.environ.get("HEAL_K2_POOLED", "1") == "1" and int(weight.shape[0]) == 64:
+            return ops.pfn_pillars(v, c, n, weight, scale, shift, self.voxel_size, self.lidar_range, n_agents, ny, nx,
+                                   n_voxels_dev=n_voxels_dev)
+        return ops.pfn_scatter(v, c, n, weight, scale, shift, self.voxel_size, self.lidar_range, n_agents, ny, nx,
+                               n_voxels_dev=n_voxels_dev)
+
     def _bn(self):
         pfn = self.pillar_vfe.pfn_layers[0]
         tensors = [pfn.linear.weight] + ([pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean,
@@ -53,12 +65,10 @@ class PointPillar(nn.Module):
         PillarVFE + PointPillarScatter call (heter_encoders.py:46-49), 3x67 MB written by one streaming kernel."""
         scale, shift = self._bn()
         weight = self.pillar_vfe.pfn_layers[0].linear.weight.detach()
-        ny, nx = self.scatter.ny, self.scatter.nx
         v, c, n, offsets = ops.voxelize_collated(point_list, self.lidar_range, self.voxel_size,
                                                  int(max_points or self.max_points), int(max_voxels or self.max_voxels))
         k = len(point_list)
-        return ops.pfn_scatter(v, c, n, weight, scale, shift, self.voxel_size, self.lidar_range, k, ny, nx,
-                               n_voxels_dev=offsets[k:k + 1])
+        return self._scatter_op(v, c, n, weight, scale, shift, k, n_voxels_dev=offsets[k:k + 1])
 
     def forward(self, data_dict, modality_name):
         inp = data_dict[f"inputs_{modality_name}"]
@@ -95,8 +105,7 @@ class PointPillar(nn.Module):
             num = num.to(torch.int32)
         scale, shift = self._bn()
         weight = self.pillar_vfe.pfn_layers[0].linear.weight.detach()
-        return ops.pfn_scatter(voxels, coords, num, weight, scale, shift, self.voxel_size, self.lidar_range,
-                               n_agents, self.scatter.ny, self.scatter.nx)
+        return self._scatter_op(voxels, coords, num, weight, scale, shift, n_agents)
 
 
 class SECOND(nn.Module):

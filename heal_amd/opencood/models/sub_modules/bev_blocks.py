@@ -52,8 +52,8 @@ _CONV1X1 = os.environ.get("HEAL_CONV1X1", "1") == "1"  # hand-written pointwise 
 _CONV3X3 = os.environ.get("HEAL_CONV3X3", "1") == "1"  # hand-written dense 3x3 conv on fp32 MFMA (0: MIOpen + heal_bias_act, A/B)
 
 
-def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, residual=None):
-    """conv2d + per-channel bias (+ residual) (+ ReLU).  The ResNeXt 32-group 3x3 convolutions run on the
+def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, residual=None, out=None):
+    """conv2d + per-channel bias (+ residual) (+ ReLU); `out`: optional destination (a batch slice of a stage output).  The ResNeXt 32-group 3x3 convolutions run on the
     hand-written stencil kernel (heal_grouped_conv3x3); everything else is a library convolution WITHOUT
     bias followed by ONE fused in-place pass (heal_bias_act) instead of separate bias / add / ReLU kernels."""
     from heal_amd import ops
@@ -73,7 +73,7 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
     if _CONV1X1 and groups == 1 and w.shape[2:] == (1, 1) and st in (1, 2) and pd == 0:
         Ho, Wo = (int(x.shape[2]) - 1) // st + 1, (int(x.shape[3]) - 1) // st + 1
         if ops.conv1x1_supported(int(w.shape[1]), int(w.shape[0]), Ho * Wo, st, Wo):
-            return ops.conv1x1(x, w, b, residual, 1 if relu else 0, stride=st)
+            return ops.conv1x1(x, w, b, residual, 1 if relu else 0, stride=st, out=out)
     if (_CONV3X3 and x.is_cuda and groups == 1 and tuple(w.shape[2:]) == (3, 3) and pd == 1 and dl == 1 and st in (1, 2)
             and (padding if isinstance(padding, int) else padding[1]) == 1
             and (stride if isinstance(stride, int) else stride[1]) == st):
@@ -132,7 +132,13 @@ class ConvBN(nn.Module):
     owner; this helper only provides the folded forward."""
 
     @staticmethod
-    def run(x, conv, bn, cache, relu, residual=None):
+    def run(x, conv, bn, cache, relu, residual=None, out=None):
+        if out is not None:      # (inference only: the agent-chunked stage walk)
+            w, b = cache.get(conv, bn)
+            y = conv_bias_act(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups, relu, residual, out=out)
+            if y.data_ptr() != out.data_ptr():
+                out.copy_(y)
+            return out
         if grad_path(x, bn, conv):   # training / fine-tuning: conv -> BatchNorm (batch statistics when training) -> + -> ReLU
             y = bn(conv(x))
             if residual is not None:
@@ -192,7 +198,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         from heal_amd import ops
-        if isinstance(x, ops.PooledBEV):
+        if isinstance(x, (ops.PooledBEV, ops.PillarBEV)):     # a sparse stand-in for the encoder's dense map (K4 / K2)
             if (not grad_path(None, self) and self.takes_pooled() and x.channels == self.conv1.in_channels
                     and x.stem_supported(self.conv1.out_channels, self.downsample[0].out_channels)):
                 wm, wd, b1, bd = self._stem_params()
@@ -248,21 +254,30 @@ class Bottleneck(nn.Module):
         import os
         if os.environ.get("HEAL_FUSED_BOTTLENECK", "0") != "1":
             return False
+        from heal_amd import ops
+        if not ops.experimental_build():      # the kernel ships only in a HEAL_BUILD_EXPERIMENTAL=1 library
+            return False
         c = self.conv1.in_channels
         return (x.is_cuda and self.downsample is None and self.stride == 1 and self.conv2.groups == 32
                 and self.conv3.out_channels == c and self.conv1.out_channels == 2 * c and c in (64, 128, 256)
                 and self.conv2.dilation == (1, 1))
 
-    def forward(self, x):
+    def out_shape(self, x):
+        s = self.stride
+        return (int(x.shape[0]), self.conv3.out_channels, (int(x.shape[2]) - 1) // s + 1, (int(x.shape[3]) - 1) // s + 1)
+
+    def forward(self, x, out=None):
+        """out: optional destination of the block's result (inference; the agent-chunked stage walk of ResNetModified)."""
         if not grad_path(x, self) and self._fusable(x):
             from heal_amd import ops
-            return ops.resnext_bottleneck(x.contiguous(), *self._fused_params())
+            y = ops.resnext_bottleneck(x.contiguous(), *self._fused_params())
+            return y if out is None else out.copy_(y)
         identity = x
         if self.downsample is not None:
             identity = ConvBN.run(x, self.downsample[0], self.downsample[1], self._cd, relu=False)
-        out = ConvBN.run(x, self.conv1, self.bn1, self._c1, relu=True)
-        out = ConvBN.run(out, self.conv2, self.bn2, self._c2, relu=True)
-        return ConvBN.run(out, self.conv3, self.bn3, self._c3, relu=True, residual=identity)
+        y = ConvBN.run(x, self.conv1, self.bn1, self._c1, relu=True)
+        y = ConvBN.run(y, self.conv2, self.bn2, self._c2, relu=True)
+        return ConvBN.run(y, self.conv3, self.bn3, self._c3, relu=True, residual=identity, out=out)
 
 
 class ResNetModified(nn.Module):
@@ -294,10 +309,45 @@ class ResNetModified(nn.Module):
             layers.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width, **kw))
         return nn.Sequential(*layers)
 
+    @staticmethod
+    def stage_chunk(layer, x):
+        """Agents per chunk of the depth-first stage walk, or 0 for the plain layer-by-layer order.
+
+        A ResNeXt stage on the wide BEV maps is HBM-bound when every launch streams ALL agents (level 0 of the fusion pyramid, 5
+        agents: 84 MB in, 168 MB of 2C-wide intermediate written and read twice -- 924 MB per block against 256 MB of Infinity
+        Cache), although one agent's whole block (16.8 + 33.5 + 33.5 + 16.8 MB) fits the cache.  Walking the stage agent chunk by
+        agent chunk -- every block of the stage on chunk 0, then chunk 1, ... -- keeps a chunk's intermediates on the die between
+        the producing and the consuming launch.  HEAL_STAGE_CHUNK_MB: the working-set budget per chunk (0: off)."""
+        mb = float(os.environ.get("HEAL_STAGE_CHUNK_MB", "0"))
+        if mb <= 0 or not x.is_cuda or torch.is_grad_enabled() or not all(isinstance(b, Bottleneck) for b in layer):
+            return 0
+        n = int(x.shape[0])
+        blk = layer[-1]
+        co, s0 = blk.conv3.out_channels, layer[0].stride
+        ho, wo = (int(x.shape[2]) - 1) // s0 + 1, (int(x.shape[3]) - 1) // s0 + 1
+        per_agent = 4.0 * ho * wo * (2 * co + 2 * blk.conv1.out_channels) / 2 ** 20      # in + out + the 2C-wide pair, MB
+        chunk = max(1, int(mb // per_agent))
+        return chunk if chunk < n else 0
+
+    def run_stage(self, layer, x):
+        chunk = self.stage_chunk(layer, x)
+        if not chunk:
+            return layer(x)
+        n = int(x.shape[0])
+        shape = list(x.shape)
+        for blk in layer:
+            shape = list(blk.out_shape(torch.empty(shape, device="meta")))
+        y = torch.empty(shape, dtype=x.dtype, device=x.device)
+        for a in range(0, n, chunk):
+            xa = x[a:a + chunk]
+            for j, blk in enumerate(layer):
+                xa = blk(xa, out=y[a:a + chunk]) if j == len(layer) - 1 else blk(xa)
+        return y
+
     def forward(self, x):
         feats = []
         for i in range(self.layernum):
-            x = getattr(self, f"layer{i}")(x)
+            x = self.run_stage(getattr(self, f"layer{i}"), x)
             feats.append(x)
         return feats
 

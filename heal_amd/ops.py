@@ -348,6 +348,74 @@ def pfn_scatter(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_si
     return canvas
 
 
+class PillarBEV:
+    """K2's result WITHOUT the dense canvas: pillar feature rows [M, 64] + the cell -> pillar-row map [n_agents, ny, nx] (-1 = empty).
+    It stands for PointPillarScatter's [n_agents, 64, ny, nx] canvas (point_pillar_scatter.py:19-76; 96 % zeros) until somebody
+    needs it: `stem_block(...)` -- the first BasicBlock of the PointPillars ResNetBEVBackbone reads the pillars through the map
+    (heal_pillar_stem_block); `dense()` -- anybody else gets the reference's tensor.  Same protocol as PooledBEV (K4)."""
+
+    def __init__(self, pillars, cell_map, n_agents, ny, nx):
+        self.pillars, self.cell_map = pillars, cell_map
+        self.n_agents, self.ny, self.nx_ = int(n_agents), int(ny), int(nx)
+        self.channels = int(pillars.shape[1])
+        self.device = pillars.device
+
+    @property
+    def shape(self):
+        return (self.n_agents, self.channels, self.ny, self.nx_)
+
+    @property
+    def is_cuda(self):
+        return True
+
+    def dense(self):
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        with _Timed("pillar_canvas", nbytes=4.0 * out.numel()):
+            _capi.call("heal_pillar_canvas", _ptr(self.cell_map), _ptr(self.pillars), self.n_agents, self.channels, self.ny,
+                       self.nx_, _ptr(out), _stream())
+        return out
+
+    def stem_supported(self, cout_main, cout_down):
+        return (self.channels == 64 and cout_main == 64 and cout_down == 64 and ((self.nx_ - 1) // 2 + 1) % 4 == 0)
+
+    def stem_block(self, w_main, b_main, w_down, b_down):
+        """relu(conv3x3_s2(canvas, W1) + b1), conv1x1_s2(canvas, Wd) + bd straight from the pillars; weights in the layouts of
+        stem_fragments()."""
+        Ho, Wo = (self.ny - 1) // 2 + 1, (self.nx_ - 1) // 2 + 1
+        out_main = torch.empty((self.n_agents, 64, Ho, Wo), dtype=torch.float32, device=self.device)
+        out_id = torch.empty_like(out_main)
+        flops = 2.0 * self.n_agents * Ho * Wo * 64 * 64 * 10          # the dense convolutions it replaces
+        with _Timed("pillar_stem_block", flops=flops, nbytes=8.0 * out_main.numel(), kernel_events=True):
+            _capi.call("heal_pillar_stem_block", _ptr(self.pillars), _ptr(self.cell_map), self.n_agents, self.channels, self.ny,
+                       self.nx_, _ptr(w_main), _ptr(b_main), _ptr(w_down), _ptr(b_down), _ptr(out_main), _ptr(out_id), _stream())
+        return out_main, out_id
+
+
+def pfn_pillars(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_size, lidar_range, n_agents, ny, nx,
+                n_voxels_dev=None):
+    """K2 without the canvas -> PillarBEV (pillar features [M, 64] + cell -> pillar map); see pfn_scatter for the arguments."""
+    voxels = _need(voxels, torch.float32, "voxels")
+    coords = _need(coords, torch.int32, "coords")
+    num_points = _need(num_points, torch.int32, "num_points")
+    weight = _need(weight, torch.float32, "weight")
+    bn_scale = _need(bn_scale, torch.float32, "bn_scale")
+    bn_shift = _need(bn_shift, torch.float32, "bn_shift")
+    M, P = int(voxels.shape[0]), int(voxels.shape[1])
+    C = int(weight.shape[0])
+    if weight.shape[1] != 10 or voxels.shape[2] != 4 or coords.shape[1] != 4:
+        raise _capi.HealAmdError("pfn_pillars: expected voxels [M,P,4], coords [M,4], weight [C,10]")
+    dev = voxels.device
+    pillars = torch.empty((max(M, 1), C), dtype=torch.float32, device=dev)
+    cell_map = torch.empty((n_agents, ny, nx), dtype=torch.int32, device=dev)
+    vx, vy, vz = (float(v) for v in voxel_size)
+    xo, yo, zo = vx / 2 + lidar_range[0], vy / 2 + lidar_range[1], vz / 2 + lidar_range[2]
+    with _Timed("pfn_pillars", nbytes=16.0 * M * P + 20.0 * M + 4.0 * C * M):
+        _capi.call("heal_pfn_pillars", _ptr(voxels), _ptr(coords), _ptr(num_points), M, _ptr(n_voxels_dev), P,
+                   _ptr(weight), _ptr(bn_scale), _ptr(bn_shift), C, vx, vy, vz, xo, yo, zo, int(n_agents), int(ny), int(nx),
+                   _ptr(pillars), _ptr(cell_map), _stream())
+    return PillarBEV(pillars, cell_map, n_agents, ny, nx)
+
+
 def _pfn_geom(voxel_size, lidar_range):
     vx, vy, vz = (float(v) for v in voxel_size)
     return vx, vy, vz, vx / 2 + lidar_range[0], vy / 2 + lidar_range[1], vz / 2 + lidar_range[2]
@@ -1579,7 +1647,7 @@ def conv1x1_tiled_ok(n, cin, cout, hw):
     profiles/r04_c1t_bench.json) it is at parity with the 64 x 64 kernel -- 0.70-1.07x, ahead only on 256 -> 2048 and single-image
     256 -> 128; neither tile shape of either kernel moves the 85-105 TFLOP/s these 5-GFLOP launches reach in isolation."""
     mode = os.environ.get("HEAL_C1_TILED", "0")
-    if mode == "0" or cin % 32 or cout % 64 or hw % 4 or hw < 128:
+    if mode == "0" or not experimental_build() or cin % 32 or cout % 64 or hw % 4 or hw < 128:
         return False
     bm = 128 if cout % 128 == 0 else 64
     blocks = (cout // bm) * -(-hw // 128) * n
@@ -1593,10 +1661,20 @@ def _w_rowmajor(w):
     return w2 if w2.is_contiguous() else w2.contiguous()
 
 
-def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixel_major=False):
+def _out_or_empty(out, shape, device, who):
+    """The caller's destination (a contiguous f32 tensor of exactly `shape`, e.g. a batch slice of a larger map) or a new one."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if (tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous()):
+        raise _capi.HealAmdError(f"{who}: `out` must be a contiguous f32 cuda tensor of shape {tuple(shape)}")
+    return out
+
+
+def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixel_major=False, out=None):
     """Pointwise convolution with fused prologue / epilogue: act(W (in_scale . x) + bias (+ residual));
     act 0 none | 1 ReLU | 2 SiLU; stride 1 | 2.  x [n,Cin,H,W] f32 cuda, w [Cout,Cin,1,1], in_scale [n,Cin].
-    pixel_major=True: the result comes back as [n, Ho*Wo, Cout] (a pixel's channels contiguous) instead of NCHW."""
+    pixel_major=True: the result comes back as [n, Ho*Wo, Cout] (a pixel's channels contiguous) instead of NCHW.
+    out: optional destination (NCHW result only), e.g. the batch slice of a stage's output that an agent chunk fills."""
     x = _need(x, torch.float32, "x")
     n, cin, H, W = (int(v) for v in x.shape)
     cout = int(w.shape[0])
@@ -1604,9 +1682,11 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
     hard_ok = stride in (1, 2) and ((Ho * Wo) % 4 == 0 if stride == 1 else Wo % 4 == 0)
     if int(w.shape[1]) != cin or not hard_ok:
         raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HxW={H}x{W} stride={stride}")
+    if out is not None and pixel_major:
+        raise _capi.HealAmdError("conv1x1: `out` is for the NCHW result")
     if (stride == 1 and not pixel_major and in_scale is None and conv1x1_tiled_ok(n, cin, cout, H * W)
             and w.dtype == torch.float32):
-        y = torch.empty((n, cout, H, W), dtype=torch.float32, device=x.device)
+        y = _out_or_empty(out, (n, cout, H, W), x.device, "conv1x1")
         if residual is not None:
             residual = _need(residual, torch.float32, "residual")
             if tuple(residual.shape) != tuple(y.shape):
@@ -1625,7 +1705,7 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
         if bias is not None:
             bias = _need(bias, torch.float32, "bias")
     else:
-        y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        y = _out_or_empty(out, (n, cout, Ho, Wo), x.device, "conv1x1")
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
         if tuple(residual.shape) != tuple(y.shape):
@@ -1732,12 +1812,20 @@ def conv3x3_winograd_waves(n=1, cout=64, H=256, W=256):
     return 8 if blocks8 >= 512 else 4
 
 
-def conv3x3_winograd_kc(cin, waves):
-    """Input channels per chunk of the Winograd K loop: 16 where the kernel has it (8-wave blocks, cin % 16 == 0) and HEAL_WG_KC
-    allows, else 8.  Measured in round 5 (profiles/r05_wino_kc16.txt)."""
+def conv3x3_winograd_kc(cin, waves, H=1, W=1):
+    """Input channels per chunk of the Winograd K loop: 16 where the kernel has it (an experimental build, 8-wave blocks,
+    cin % 16 == 0, a map whose 16-channel chunk stays below 2^31 bytes) and HEAL_WG_KC asks for it, else 8.  Measured in round 5
+    (profiles/r05_wino_kc16.txt): 4-13 % slower, hence experimental."""
     import os
     want = os.environ.get("HEAL_WG_KC", _WG_KC_DEFAULT)
-    return 16 if (want == "16" and waves == 8 and cin % 16 == 0) else 8
+    ok16 = (want == "16" and waves == 8 and cin % 16 == 0 and 16 * H * W * 4 < 2 ** 31 and experimental_build())
+    return 16 if ok16 else 8
+
+
+def experimental_build():
+    """True if libheal_amd.so was built with HEAL_BUILD_EXPERIMENTAL=1 (the measured-negative kernels of
+    include/heal_amd_experimental.h are present)."""
+    return hasattr(_capi.lib(), "heal_gconv_conv3")
 
 
 _WG_KC_DEFAULT = "8"
@@ -1794,7 +1882,7 @@ def conv3x3_winograd4_ok(n, cout, H, W):
     shapes (profiles/r03_wino_f44_vs_f22.json): a quarter of the multiplications instead of 4/9, but twice the transform work per
     output at 32 output channels per block."""
     import os
-    return os.environ.get("HEAL_C3_ALGO", "") == "winograd4"
+    return os.environ.get("HEAL_C3_ALGO", "") == "winograd4" and experimental_build()
 
 
 def conv3x3_algo(stride, n=1, cout=64, H=256, W=256):
@@ -1868,7 +1956,7 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
         return y
     if conv3x3_algo(stride, n, cout, H, W) == "winograd":
         waves = conv3x3_winograd_waves(n, cout, H, W)
-        kc = conv3x3_winograd_kc(cin, waves)
+        kc = conv3x3_winograd_kc(cin, waves, H, W)
         frag = conv3x3_winograd_fragments(w, waves, kc)
         with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo),
                     kernel_events=True):

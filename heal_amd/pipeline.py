@@ -273,8 +273,13 @@ class ScenePipeline:
         cur.synchronize()
         ops.verify_sparse_capacity()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=cur):
-            static_out = body()
+        _capi.guard_begin()
+        try:
+            with torch.cuda.graph(graph, stream=cur):
+                static_out = body()
+        except BaseException:
+            _capi.guard_begin()               # a failed capture owns nothing
+            raise
         # the capacity counters written inside the graph live in its private pool: keep them to re-check after every replay
         slot = _Slot(static, graph, static_out, ops.take_sparse_checks(), cur)
         slot.guard = _capi.guard_take()       # HEAL_GRAPH_GUARD=1: every device address the capture handed to a kernel

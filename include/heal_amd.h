@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define HEAL_AMD_ABI_VERSION 5
+#define HEAL_AMD_ABI_VERSION 6   /* 6 (round 6): + heal_pfn_pillars / heal_pillar_canvas / heal_pillar_stem_block; the measured-negative entry
+                                   points moved to include/heal_amd_experimental.h (HEAL_BUILD_EXPERIMENTAL=1 builds only) */
 
 int heal_abi_version(void);
 const char* heal_last_error(void);
@@ -108,6 +109,26 @@ int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* 
                      int n_agents, int ny, int nx,
                      float* canvas, float* pillar_feat,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* Round 6: K2 without the dense canvas, for consumers that read the pillars themselves.
+ * heal_pfn_pillars: PillarVFE + PFNLayer (pillar_vfe.py:31-155) only -> pillar_feat [n_voxels, 64] and cell_map [n_agents, ny, nx]
+ *   (int32: the pillar row that PointPillarScatter.forward, point_pillar_scatter.py:58-65, would copy into that cell -- the highest
+ *   row when several rows name one cell, -1 for an empty cell).  Same arguments as heal_pfn_scatter otherwise; no workspace.
+ * heal_pillar_canvas: the reference's canvas [n_agents, channels, ny, nx] from (cell_map, pillar_feat): what heal_pfn_scatter writes.
+ * heal_pillar_stem_block: the first BasicBlock convolutions of the PointPillars ResNetBEVBackbone (base_bev_backbone_resnet.py:88-109,
+ *   resblock.py:18-64) straight from the pillars: out_main = relu(conv3x3/2 pad 1 (canvas, W1) + b1), out_identity = conv1x1/2 (canvas,
+ *   Wd) + bd, both [n_agents, 64, ceil(ny/2), ceil(nx/2)], BatchNorms folded by the caller; the canvas is never written (it is 96 % zeros:
+ *   taps with no pillar under an 8 x 8 output tile are skipped).  channels must be 64; w_main [9][1][64][64] (tap = ky*3 + kx, cout, cin),
+ *   w_down [1][64][64] (heal_amd.ops.stem_fragments -- the layouts of heal_bev_stem_block); biases may be NULL.                          */
+int heal_pfn_pillars(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
+                     const int32_t* n_voxels_dev, int max_points, const float* weight, const float* bn_scale,
+                     const float* bn_shift, int channels, float vx, float vy, float vz, float x_offset, float y_offset,
+                     float z_offset, int n_agents, int ny, int nx, float* pillar_feat, int32_t* cell_map, void* stream);
+int heal_pillar_canvas(const int32_t* cell_map, const float* pillar_feat, int n_agents, int channels, int ny, int nx,
+                       float* canvas, void* stream);
+int heal_pillar_stem_block(const float* pillar_feat, const int32_t* cell_map, int n_agents, int channels, int ny, int nx,
+                           const float* w_main, const float* b_main, const float* w_down, const float* b_down,
+                           float* out_main, float* out_identity, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5  warp to ego + occupancy-softmax weighted fusion over agents (one pyramid level, one scene).
@@ -424,27 +445,6 @@ int heal_grouped_conv3x3(const float* x, const float* weight, const float* bias,
 int heal_bias_act(float* x, const float* bias, const float* residual, int n, int channels, int HW, int relu,
                   void* stream);
 
-/* heal_gconv_conv3 (round 4): the BACK HALF of a ResNeXt bottleneck in one kernel -- the 32-group 3x3 convolution (conv2 + bn2 + relu)
- *   and the pointwise convolution behind it (conv3 + bn3 + identity + relu; opencood/models/sub_modules/resblock.py:110-121, stride 1,
- *   BatchNorms folded by the caller): y = act(W3 . relu(gconv3x3(x) + b2) + b3 (+ residual)).  The 2C-wide intermediate stays in LDS.
- *   x [n, width, H, W]; weight_q: the grouped weights in the layout heal_grouped_small_conv3x3 takes; w3_frag: W3 [cout, width] in MFMA
- *   A-fragment order (frag[mt][ks][lane] = W3[mt*16 + (lane & 15)][ks*4 + (lane >> 4)]); residual [n, cout, H, W] or NULL.
- *   Supported (heal_gconv_conv3_supported): 4 | 8 channels per group, width % 16 == 0, cout 64 | 128, W % 4 == 0.                        */
-int heal_gconv_conv3_supported(int width, int group_channels, int cout, int H, int W);
-int heal_gconv_conv3(const float* x, const float* weight_q, const float* b2, const float* w3_frag, const float* b3,
-                     const float* residual, int n, int width, int group_channels, int cout, int H, int W, int relu, float* y,
-                     void* stream);
-
-/* heal_resnext_bottleneck: one fused kernel for a stride-1 ResNeXt bottleneck without downsample
- *   (opencood/models/sub_modules/resblock.py:100-122; 32 groups, width = 2*C, expansion 1):
- *   y = relu(conv3(relu(gconv2(relu(conv1(x)+b1))+b2))+b3+x), BatchNorms folded by the caller.
- *   x,y [n,C,H,W] (C = 64|128|256); w2 [2C, 2C/32, 3, 3]; b1,b2 [2C]; b3 [C];
- *   w1_frag / w3_frag: the 1x1 weights W1 [2C,C], W3 [C,2C] re-laid in MFMA A-fragment order
- *   frag[mt][ks][lane] = Wm[mt*16 + (lane & 15)][ks*4 + (lane >> 4)].                                */
-int heal_resnext_bottleneck(const float* x, const float* w1_frag, const float* b1, const float* w2,
-                            const float* b2, const float* w3_frag, const float* b3, int n, int channels, int H,
-                            int W, float* y, void* stream);
-
 /* heal_upsample2x_bilinear: nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) of the
  *   Lift-Splat `Up` block (opencood/models/sub_modules/lss_submodule.py:21-22,33); x [n,C,H,W] -> y [n,C,2H,2W] */
 int heal_upsample2x_bilinear(const float* x, int n, int channels, int H, int W, float* y, void* stream);
@@ -520,14 +520,6 @@ int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bia
  *   y: [n, 64, Hp, Wp] with Hp = ((H - 1) / 2) / 2 + 1 ... (pool) or [n, 64, (H - 1) / 2 + 1, (W - 1) / 2 + 1] (no pool).          */
 int heal_stem7x7(const float* x, long long image_stride, int n, int cin, int H, int W, const float* weight_frag,
                  const float* bias, int pool, float* y, void* stream);
-/* heal_conv1x1_tiled: the same pointwise convolution on the 128 x 128 x 32 core (v_mfma_f32_32x32x2_f32, both operands through
- *   LDS) for its MFMA-bound shapes: weight is the PLAIN [Cout, Cin] row-major matrix (nn.Conv2d's storage, no fragment
- *   pre-layout); Cin % 32 == 0, Cout % 64 == 0, stride 1, no input gate.  d2s_k = 0: y [n, Cout, H, W]; d2s_k = k >= 1: the
- *   depth-to-space + channel-offset write of heal_conv1x1_d2s into y [n, dst_channels, H k, W k].  bias / residual may be NULL.
- *   heal_conv1x1_tiled_supported: 1 if the shape fills the chip with this tiling (>= 256 blocks), else 0.                    */
-int heal_conv1x1_tiled_supported(int n, int cin, int cout, int H, int W);
-int heal_conv1x1_tiled(const float* x, const float* weight, const float* bias, const float* residual, int n, int cin, int cout,
-                       int H, int W, int act, int d2s_k, int dst_channels, int dst_channel_offset, float* y, void* stream);
 size_t heal_conv1x1_splitk_workspace(int n, int cout, int H, int W, int ksplit);
 int heal_conv1x1_splitk(const float* x, const float* weight_frag, const float* bias, const float* residual,
                         const float* in_scale, int n, int cin, int cout, int H, int W, int act, int ksplit, float* y, void* ws,
@@ -592,17 +584,11 @@ int heal_grouped_small_conv3x3(const float* x, const float* weight_q, const floa
 int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
                           int cout, int H, int W, int relu, int waves, float* y, void* stream);
 /* heal_conv3x3_winograd_kc: the same with `kc` input channels per chunk of the K loop: 8 (= heal_conv3x3_winograd) or 16 (round 5: half
- *   the barriers and operand waits per MFMA, 112 KB of LDS; waves = 8 and cin %% 16 == 0 only).  Fragment order with KS = kc / 4:
+ *   the barriers and operand waits per MFMA, 112 KB of LDS; waves = 8 and cin %% 16 == 0 only; measured 4-13 % SLOWER, so the kc = 16
+ *   instantiation exists only in a HEAL_BUILD_EXPERIMENTAL=1 library -- the shipped one rejects kc = 16).  Fragment order with KS = kc / 4:
  *   frag[mb][chunk][w][lane][(xi_i*KS + ks)*4 + mt] = U[mb*64 + mt*16 + (lane & 15)][chunk*kc + ks*4 + (lane >> 4)][xi = XW*w + xi_i]. */
 int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
                              int cout, int H, int W, int relu, int waves, int kc, float* y, void* stream);
-
-/* heal_conv3x3_winograd4: the same operator with the F(4x4,3x3) transform (36 positions, 6x6 input windows, 4x4 output tiles:
- *   1/4 of the direct multiplications; csrc/conv3x3_wino4.hip).  u_frag: U = G g G^T in the lane-major order
- *   [ceil(Cout/32)][ceil(Cin/16)][wave 8][lane 64][xi_i 9][ks 4] (heal_amd.ops.conv3x3_winograd4_fragments).  fp32; ~2e-5 of
- *   the output scale against float64 in the worst case measured (F(2x2,3x3): ~1e-6).                                          */
-int heal_conv3x3_winograd4(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
-                           int cout, int H, int W, int relu, float* y, void* stream);
 
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265

@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 PP_RANGE = [-102.4, -102.4, -3, 102.4, 102.4, 1]
 
 
+def _need_experimental():
+    """The measured-negative kernels (include/heal_amd_experimental.h) exist only in a HEAL_BUILD_EXPERIMENTAL=1 library."""
+    from heal_amd import ops
+    if not ops.experimental_build():
+        pytest.skip("libheal_amd.so was built without HEAL_BUILD_EXPERIMENTAL=1 (measured-negative kernels are not shipped)")
+
+
+
 def dev(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype is not None:
@@ -167,6 +175,66 @@ def test_pfn_scatter_full_size_vs_oracle():
     # every pillar occupies exactly one canvas cell (some channels may be exactly 0 after ReLU)
     occupied = (canvas != 0).any(axis=1).sum()
     assert occupied <= len(n) and occupied >= 0.99 * len(n)
+
+
+def test_pfn_pillars_equal_pfn_scatter(golden):
+    """Round 6: heal_pfn_pillars (K2 without the canvas) returns the same pillar features, and heal_pillar_canvas of its
+    (cell map, pillars) pair is heal_pfn_scatter's canvas bit for bit (and the reference's golden canvas)."""
+    from heal_amd import ops
+    g = golden("pointpillar_encoder")
+    _, w, scale, shift = pfn_params()
+    args = (dev(g["voxel_features"]), dev(g["voxel_coords"], torch.int32), dev(g["voxel_num_points"], torch.int32), dev(w),
+            dev(scale), dev(shift), g["voxel_size"].tolist(), g["lidar_range"].tolist(), 2, 128, 128)
+    canvas, pillars = ops.pfn_scatter(*args, return_pillars=True)
+    pb = ops.pfn_pillars(*args)
+    assert torch.equal(pb.pillars[:pillars.shape[0]], pillars)
+    assert torch.equal(pb.dense(), canvas)
+    m = pb.cell_map.cpu().numpy()
+    assert (m >= 0).sum() == (canvas != 0).any(1).sum().item() or (m >= 0).sum() >= (canvas != 0).any(1).sum().item()
+    np.testing.assert_allclose(pb.dense().cpu().numpy(), g["spatial_features"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("n_agents,ny,nx,rng_,seeds", [(2, 512, 512, PP_RANGE, (1000, 1001)),
+                                                        (1, 240, 480, [-96, -48, -3, 96, 48, 1], (1002,)),
+                                                        (3, 128, 128, [-25.6, -25.6, -3, 25.6, 25.6, 1], (1003, 1004, 1005)),
+                                                        (1, 40, 24, [-4.8, -8.0, -3, 4.8, 8.0, 1], (1006,))])
+def test_pillar_stem_block_equals_dense_path(n_agents, ny, nx, rng_, seeds):
+    """heal_pillar_stem_block (first BasicBlock convolutions of the PointPillars backbone read from the pillar rows through the
+    cell map; the canvas is never written) against the dense path it replaces -- the canvas + torch's fp64 3x3 / stride 2 and 1x1 /
+    stride 2 convolutions: 1e-5 of the output scale (summation order), background pixels exactly relu(bias) / bias.  Full 512 x 512
+    and native 480 x 240 grids, a small one, and a map smaller than the tile raster (40 x 24 -> 20 x 12 outputs: ragged tiles)."""
+    from heal_amd import ops, synth
+    _, w, scale, shift = pfn_params()
+    vs, cs, ns = [], [], []
+    for b, seed in enumerate(seeds):
+        v, c, n = cref.voxelize(synth.lidar_frame(seed), rng_, [0.4, 0.4, 4], 32, 70000, batch_idx=b)
+        vs.append(v); cs.append(c); ns.append(n)
+    args = (dev(np.concatenate(vs)), dev(np.concatenate(cs)), dev(np.concatenate(ns)), dev(w), dev(scale), dev(shift),
+            [0.4, 0.4, 4], rng_, n_agents, ny, nx)
+    canvas = ops.pfn_scatter(*args)
+    pb = ops.pfn_pillars(*args)
+    g = torch.Generator().manual_seed(ny * 7 + nx)
+    w1 = (torch.randn((64, 64, 3, 3), generator=g) / 24.0).cuda()
+    wd = (torch.randn((64, 64, 1, 1), generator=g) / 8.0).cuda()
+    b1, bd = torch.randn((64,), generator=g).cuda(), torch.randn((64,), generator=g).cuda()
+    assert pb.stem_supported(64, 64)
+    wm, wdf = ops.stem_fragments(w1, wd)
+    got_main, got_id = pb.stem_block(wm, b1, wdf, bd)
+    ref_main = torch.relu(torch.nn.functional.conv2d(canvas.double(), w1.double(), b1.double(), 2, 1))
+    ref_id = torch.nn.functional.conv2d(canvas.double(), wd.double(), bd.double(), 2, 0)
+    assert got_main.shape == ref_main.shape and got_id.shape == ref_id.shape
+    for got, ref in ((got_main, ref_main), (got_id, ref_id)):
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, err
+    # pixels no pillar reaches: exactly the bias (ReLU on the conv1 half)
+    occ = (canvas != 0).any(1, keepdim=True).float()
+    reach = torch.nn.functional.max_pool2d(torch.nn.functional.pad(occ, (1, 1, 1, 1)), 3, 2) == 0
+    bg_main = torch.relu(b1)[None, :, None, None].expand_as(got_main)
+    assert torch.equal(got_main[reach.expand_as(got_main)], bg_main[reach.expand_as(got_main)])
+    # no bias
+    got2, _ = pb.stem_block(wm, None, wdf, None)
+    ref2 = torch.relu(torch.nn.functional.conv2d(canvas.double(), w1.double(), None, 2, 1))
+    assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------- K5
@@ -698,6 +766,7 @@ def test_bias_act_vs_torch():
 
 @pytest.mark.parametrize("C,H,W", [(64, 32, 48), (128, 24, 24), (256, 16, 16), (64, 13, 21), (256, 7, 10), (128, 9, 8)])
 def test_fused_resnext_bottleneck_vs_torch(C, H, W):
+    _need_experimental()
     """K7b against the block it fuses, evaluated in fp64 by torch (resblock.py:100-122 with folded BN)."""
     from heal_amd import ops
     g = torch.Generator().manual_seed(C + H)
@@ -785,6 +854,8 @@ def test_conv3x3_mfma_vs_torch(n, cin, cout, H, W, stride, res, relu, algo, monk
     ReLU against torch's fp64 convolution: 1e-4 relative to the output scale (fp32 accumulation order and, for Winograd, the
     transform's rounding sequence differ; the north-star tolerance for features is 1e-3)."""
     from heal_amd import ops
+    if algo in ("winograd4", "winograd8kc16"):
+        _need_experimental()
     kc16 = algo.endswith("kc16")
     algo = algo[:-4] if kc16 else algo
     monkeypatch.setenv("HEAL_WG_KC", "16" if kc16 else "8")
@@ -1433,6 +1504,7 @@ def test_gconv_conv3_equals_two_kernel_path(n, width, cout, H, W, res):
     """heal_gconv_conv3 (opt-in: the grouped 3x3 + pointwise conv + identity + ReLU of a ResNeXt bottleneck in one wave-specialised
     kernel, the 2C-wide intermediate in LDS) against float64 and against the two-kernel path: 4 and 8 channels per group, maps that
     are not multiples of the 8 x 32 tile, with and without the identity."""
+    _need_experimental()
     from heal_amd import ops
     rng = np.random.default_rng(width + H)
     g = 32
@@ -1481,6 +1553,7 @@ def test_conv1x1_tiled_equals_torch(n, cin, cout, H, W, res, act, monkeypatch):
     """heal_conv1x1_tiled (128 x 128 x 32 core on 32x32x2 fp32 MFMA, plain [Cout, Cin] weights; opt-in: at parity with heal_conv1x1
     at the scenes' shapes) against F.conv2d with the fused epilogues, incl. pixel counts that are not multiples of the 128-pixel
     tile and the depth-to-space write of the deblocks."""
+    _need_experimental()
     from heal_amd import ops
     monkeypatch.setenv("HEAL_C1_TILED", "force")
     g = torch.Generator().manual_seed(cin + cout)

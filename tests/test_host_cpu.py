@@ -26,6 +26,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert not missing, f"declared in include/heal_amd.h but not exported: {missing}"
     assert set(names) <= set(_capi._SIGNATURES), "ctypes signature table is missing a declared symbol"
     assert _capi.lib().heal_abi_version() == _capi.abi_version_of_header() >= 2
+    # the measured-negative kernels are NOT part of the shipped ABI: declared in their own header, bound by the
+    # signature table, exported only by a HEAL_BUILD_EXPERIMENTAL=1 library -- all of them or none
+    exp = _capi.declared_symbols(experimental=True)
+    assert exp and not set(exp) & set(names) and set(exp) <= set(_capi._SIGNATURES)
+    have = [n for n in exp if hasattr(L, n)]
+    assert have == [] or have == exp, f"half an experimental build: {have}"
+    import os
+    if os.environ.get("HEAL_BUILD_EXPERIMENTAL", "0") != "1":
+        assert have == [], "the default build must not carry the experimental kernels"
 
 
 def test_product_has_no_cpu_path():
