@@ -38,7 +38,7 @@ _SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
     "heal_pillar_canvas": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "heal_pillar_stem_block": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
+    "heal_pillar_stem_block": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3),
     "heal_bev_pool_backward": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p] * 6),
     "heal_warp_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),

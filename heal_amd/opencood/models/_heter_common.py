@@ -48,8 +48,16 @@ def crop_camera_feature(model, m, feature):
     """Camera BEV maps cover the camera grid; keep the centre that corresponds to the LiDAR range (no-op for LiDAR)."""
     if model.sensor_type_dict[m] != "camera":
         return feature
-    H, W = feature.shape[-2:]
-    return center_crop(feature, int(H * getattr(model, f"crop_ratio_H_{m}")), int(W * getattr(model, f"crop_ratio_W_{m}")))
+    H, W = (int(v) for v in feature.shape[-2:])
+    th, tw = int(H * getattr(model, f"crop_ratio_H_{m}")), int(W * getattr(model, f"crop_ratio_W_{m}"))
+    # where the map's content lies after the call when BOTH axes are zero-padded (center_crop's pad rule): everything outside this
+    # box is exactly zero -- PyramidFusion's camera-crop walk (pyramid_fuse.py) skips the work whose result that fixes in advance
+    boxes = model.__dict__.setdefault("_heal_cam_boxes", {})
+    if th > H and tw > W:
+        boxes[m] = ((th - H) // 2, (th - H) // 2 + H, (tw - W) // 2, (tw - W) // 2 + W)
+    else:
+        boxes.pop(m, None)
+    return center_crop(feature, th, tw)
 
 
 def wants_depth_items(model, m):

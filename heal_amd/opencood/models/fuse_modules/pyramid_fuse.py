@@ -86,6 +86,27 @@ def weighted_fuse(x, occ, record_len, affine_matrix, grid_f64=True, crops=None):
     return out[0].unsqueeze(0) if len(out) == 1 else torch.stack(out)   # (one scene: no copy)
 
 
+def _stage_influence(lo, hi, layer, size_in):
+    """[lo, hi) of the stage INPUT that differs from the all-zero input -> ([lo', hi') of the stage output that can differ from the
+    zero-input output, output size).  Every Bottleneck is 1x1 -> 3x3 (stride s, padding 1) -> 1x1 (+ a 1x1 stride-s downsample):
+    output o reads inputs s o - 1 .. s o + 1."""
+    size = size_in
+    for blk in layer:
+        s_ = blk.stride
+        size = (size - 1) // s_ + 1
+        lo = max(0, -((1 - lo) // s_))         # ceil((lo - 1) / s)
+        hi = min(size, hi // s_ + 1)           # floor((hi - 1 + 1) / s) + 1, exclusive
+    return lo, hi, size
+
+
+def _stage_needs(olo, ohi, layer, size_in):
+    """[olo, ohi) of the stage OUTPUT -> the [ilo, ihi) of its INPUT those outputs read (the receptive field, clipped to the map)."""
+    for blk in reversed(list(layer)):
+        s_ = blk.stride
+        olo, ohi = s_ * olo - 1, s_ * (ohi - 1) + 2
+    return max(0, olo), min(size_in, ohi)
+
+
 class PyramidFusion(ResNetBEVBackbone):
     def __init__(self, model_cfg, input_channels=64):
         super().__init__(model_cfg, input_channels)
@@ -112,11 +133,116 @@ class PyramidFusion(ResNetBEVBackbone):
         occ_map_list = [self.occupancy_head(i, feature_list[i]) for i in range(self.num_levels)]
         return self.decode_multiscale_feature(feature_list), occ_map_list
 
+    # ---- camera agents: their padded maps are ZERO outside the centre box (round 6) ------------------------------------------------
+    # The camera modalities' BEV maps cover the camera grid (+-51.2 m) and are zero-padded to the LiDAR range before the fusion
+    # pyramid (heter_pyramid_collab.py:153-167, torchvision CenterCrop: 128^2 -> 256^2), so 75 % of a camera agent's pyramid input is
+    # exactly zero -- and the reference still pushes it through every ResNeXt block (pyramid_fuse.py:71-79,139).  A convolution stack
+    # is local: an output pixel whose receptive field holds only zero input equals the stack's output for an ALL-ZERO map at that
+    # position.  So for the camera agents each stage runs on a CROP (the box its content can influence + the receptive-field halo,
+    # aligned to 8 pixels) and the rest of the stage output is the zero-input response `BG`, computed once per weight version
+    # (a frame-independent constant).  Exact: the pasted box is computed by the same kernels from the same values; only work whose
+    # result is known in advance is skipped.  Level 0: 144^2 of 256^2 pixels, level 1: 88^2 of 128^2; the last level's content box
+    # already reaches the borders and runs in full.  HEAL_PYRAMID_CAMCROP=0 switches it off.
+    def _zero_response(self, like):
+        """Stage outputs of the pyramid for an all-zero [1, C, H, W] input (cached per parameter version and map size)."""
+        key = (tuple((p.data_ptr(), p._version) for p in self.resnet.parameters()) +
+               tuple((b.data_ptr(), b._version) for b in self.resnet.buffers()), tuple(like.shape[1:]), str(like.device))
+        if getattr(self, "_bg_key", None) != key:
+            with torch.no_grad():
+                z = torch.zeros((1,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+                self._bg = [f.clone() for f in self.resnet(z)]
+            self._bg_key = key
+        return self._bg
+
+    def _camcrop_plan(self, x, cam_slice, box):
+        """Per stage: None (run the stage in full) or (crop of the stage input (y0, y1, x0, x1), output box to paste (global), the same
+        box in the crop's output coordinates).  box = (y0, y1, x0, x1) of the non-zero region of the camera agents' input."""
+        H, W = int(x.shape[2]), int(x.shape[3])
+        ly, hy, lx, hx = box
+        plan = []
+        for i in range(self.layernum_):
+            layer = getattr(self.resnet, f"layer{i}")
+            s_tot = 1
+            for blk in layer:
+                s_tot *= blk.stride
+            oly, ohy, Ho = _stage_influence(ly, hy, layer, H)
+            olx, ohx, Wo = _stage_influence(lx, hx, layer, W)
+            iy0, iy1 = _stage_needs(oly, ohy, layer, H)
+            ix0, ix1 = _stage_needs(olx, ohx, layer, W)
+            a = 8 * s_tot                      # crop origin / size: multiples of 8 output pixels (kernel tile and 16-B row constraints)
+            cy0, cy1, cx0, cx1 = iy0 // a * a, min(H, -(-iy1 // a) * a), ix0 // a * a, min(W, -(-ix1 // a) * a)
+            if (cy1 - cy0) * (cx1 - cx0) > 0.7 * H * W:
+                plan.append(None)              # the content reaches (nearly) everywhere: no saving in cropping this stage
+            else:
+                plan.append(((cy0, cy1, cx0, cx1), (oly, ohy, olx, ohx),
+                             (oly - cy0 // s_tot, ohy - cy0 // s_tot, olx - cx0 // s_tot, ohx - cx0 // s_tot)))
+            ly, hy, lx, hx, H, W = oly, ohy, olx, ohx, Ho, Wo
+        return plan
+
+    def get_multiscale_feature_camcrop(self, x, cam_slice, box):
+        """get_multiscale_feature for a scene whose agents [cam_slice] are camera agents with non-zero input inside `box` only (and
+        whose other agents form ONE contiguous range)."""
+        n = int(x.shape[0])
+        c0, c1 = cam_slice
+        other = (0, c0) if c0 > 0 else (c1, n)
+        bg = self._zero_response(x)
+        plan = self._camcrop_plan(x, cam_slice, box)
+        feats = []
+        for i in range(self.layernum_):
+            layer = getattr(self.resnet, f"layer{i}")
+            if plan[i] is None:
+                x = self.resnet.run_stage(layer, x)
+                feats.append(x)
+                continue
+            (cy0, cy1, cx0, cx1), (gy0, gy1, gx0, gx1), (py0, py1, px0, px1) = plan[i]
+            full = torch.empty((n,) + tuple(bg[i].shape[1:]), dtype=x.dtype, device=x.device)
+            if other[1] > other[0]:            # the LiDAR agents: the whole map, written straight into their slice
+                xa = x[other[0]:other[1]]
+                for j, blk in enumerate(layer):
+                    xa = blk(xa, out=full[other[0]:other[1]]) if j == len(layer) - 1 else blk(xa)
+            yc = layer(x[c0:c1, :, cy0:cy1, cx0:cx1].contiguous())
+            full[c0:c1] = bg[i]                # (broadcast copy) the zero-input response everywhere ...
+            full[c0:c1, :, gy0:gy1, gx0:gx1] = yc[:, :, py0:py1, px0:px1]   # ... and the box the content reaches
+            x = full
+            feats.append(x)
+        return feats
+
+    @property
+    def layernum_(self):
+        return self.resnet.layernum
+
+    def _camcrop_args(self, spatial_features, agent_modality_list, cam_boxes):
+        """(cam_slice, box) when the camera-crop walk applies: inference on a HIP device, ResNeXt stages, the camera agents form one
+        contiguous range at an end of the scene and share one valid box."""
+        import os
+        if (not cam_boxes or agent_modality_list is None or torch.is_grad_enabled() or not spatial_features.is_cuda
+                or os.environ.get("HEAL_PYRAMID_CAMCROP", "1") != "1"):
+            return None
+        cams = [k for k, m in enumerate(agent_modality_list) if m in cam_boxes]
+        n = len(agent_modality_list)
+        if not cams or len(cams) == n or cams != list(range(cams[0], cams[-1] + 1)) or (cams[0] != 0 and cams[-1] != n - 1):
+            return None
+        from heal_amd.opencood.models.sub_modules.bev_blocks import Bottleneck
+        if not all(isinstance(b, Bottleneck) and b.conv2.kernel_size == (3, 3) and b.conv2.padding == (1, 1)
+                   for i in range(self.layernum_) for b in getattr(self.resnet, f"layer{i}")):
+            return None
+        boxes = [cam_boxes[agent_modality_list[k]] for k in cams]
+        box = (min(b[0] for b in boxes), max(b[1] for b in boxes), min(b[2] for b in boxes), max(b[3] for b in boxes))
+        H, W = int(spatial_features.shape[2]), int(spatial_features.shape[3])
+        if H % 32 or W % 32 or not (0 <= box[0] < box[1] <= H and 0 <= box[2] < box[3] <= W):
+            return None
+        return (cams[0], cams[-1] + 1), box
+
     def forward_collab(self, spatial_features, record_len, affine_matrix, agent_modality_list=None,
-                       cam_crop_info=None, grid_f64=True):
+                       cam_crop_info=None, grid_f64=True, cam_boxes=None):
         """affine_matrix: host numpy [B,L,L,2,3] (normalize_pairwise_tfm of the host pairwise matrix);
-        record_len: list of ints."""
-        feature_list = self.get_multiscale_feature(spatial_features)
+        record_len: list of ints.  cam_boxes: {modality: (y0, y1, x0, x1)} -- the caller's promise that the maps of those (camera)
+        modalities are exactly zero outside the box (it zero-padded them itself): enables the camera-crop stage walk."""
+        cc = self._camcrop_args(spatial_features, agent_modality_list, cam_boxes) if len(record_len) == 1 else None
+        if cc is not None:
+            feature_list = self.get_multiscale_feature_camcrop(spatial_features, *cc)
+        else:
+            feature_list = self.get_multiscale_feature(spatial_features)
         use_crop = bool(cam_crop_info) and not self.training
         fused_feature_list, occ_map_list = [], []
         import os

@@ -81,10 +81,13 @@ class HeterPyramidCollab(nn.Module):
                 parts.append(feats[m][cursor[m]])
                 cursor[m] += 1
             heter_feature_2d = torch.stack(parts)
+        cam_boxes = None
         if self.compress:
             heter_feature_2d = self.compressor(heter_feature_2d)
+        else:   # the padded camera maps reach the pyramid untouched: it may rely on their zero border (crop_camera_feature)
+            cam_boxes = {m: b for m, b in self.__dict__.get("_heal_cam_boxes", {}).items() if m in feats}
         fused, occ_outputs = self.pyramid_backbone.forward_collab(
-            heter_feature_2d, record_len, affine_matrix, agent_modality_list, self.cam_crop_info, grid_f64)
+            heter_feature_2d, record_len, affine_matrix, agent_modality_list, self.cam_crop_info, grid_f64, cam_boxes=cam_boxes)
         cls_preds, reg_preds, dir_preds = self.heads(fused)
         output_dict.update({"cls_preds": cls_preds, "reg_preds": reg_preds, "dir_preds": dir_preds,
                             "occ_single_list": occ_outputs})

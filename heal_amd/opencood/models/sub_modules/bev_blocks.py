@@ -186,13 +186,14 @@ class BasicBlock(nn.Module):
                 and self.conv1.stride == (2, 2) and self.conv1.out_channels == 64 and self.conv1.in_channels % 32 == 0
                 and isinstance(self.bn1, nn.BatchNorm2d) and isinstance(d[1], nn.BatchNorm2d))
 
-    def _stem_params(self):
+    def _stem_params(self, x):
         from heal_amd import ops
         w1, b1 = self._c1.get(self.conv1, self.bn1)
         wd, bd = self._cd.get(self.downsample[0], self.downsample[1])
-        key = (self._c1.key, self._cd.key)
+        frag = getattr(x, "fragments", ops.stem_fragments)     # the weight layout the sparse input's kernel reads
+        key = (self._c1.key, self._cd.key, getattr(x, "weight_layout", "tiles"))
         if getattr(self, "_stem_key", None) != key:
-            self._stem = ops.stem_fragments(w1, wd) + (b1, bd)
+            self._stem = frag(w1, wd) + (b1, bd)
             self._stem_key = key
         return self._stem
 
@@ -201,7 +202,7 @@ class BasicBlock(nn.Module):
         if isinstance(x, (ops.PooledBEV, ops.PillarBEV)):     # a sparse stand-in for the encoder's dense map (K4 / K2)
             if (not grad_path(None, self) and self.takes_pooled() and x.channels == self.conv1.in_channels
                     and x.stem_supported(self.conv1.out_channels, self.downsample[0].out_channels)):
-                wm, wd, b1, bd = self._stem_params()
+                wm, wd, b1, bd = self._stem_params(x)
                 out, identity = x.stem_block(wm, b1, wd, bd)
                 return ConvBN.run(out, self.conv2, self.bn2, self._c2, relu=True, residual=identity)
             x = x.dense()

@@ -378,17 +378,36 @@ class PillarBEV:
     def stem_supported(self, cout_main, cout_down):
         return (self.channels == 64 and cout_main == 64 and cout_down == 64 and ((self.nx_ - 1) // 2 + 1) % 4 == 0)
 
+    # weight layout of stem_block: "lanes" (pillar_stem_fragments, the pixel-compacted kernel) | "tiles" (stem_fragments, v1: A/B)
+    weight_layout = "tiles" if os.environ.get("HEAL_PILLAR_STEM", "2") == "1" else "lanes"
+
+    def fragments(self, w_main, w_down):
+        return pillar_stem_fragments(w_main, w_down) if self.weight_layout == "lanes" else stem_fragments(w_main, w_down)
+
     def stem_block(self, w_main, b_main, w_down, b_down):
-        """relu(conv3x3_s2(canvas, W1) + b1), conv1x1_s2(canvas, Wd) + bd straight from the pillars; weights in the layouts of
-        stem_fragments()."""
+        """relu(conv3x3_s2(canvas, W1) + b1), conv1x1_s2(canvas, Wd) + bd straight from the pillars; weights from
+        self.fragments(...)."""
         Ho, Wo = (self.ny - 1) // 2 + 1, (self.nx_ - 1) // 2 + 1
         out_main = torch.empty((self.n_agents, 64, Ho, Wo), dtype=torch.float32, device=self.device)
         out_id = torch.empty_like(out_main)
         flops = 2.0 * self.n_agents * Ho * Wo * 64 * 64 * 10          # the dense convolutions it replaces
         with _Timed("pillar_stem_block", flops=flops, nbytes=8.0 * out_main.numel(), kernel_events=True):
             _capi.call("heal_pillar_stem_block", _ptr(self.pillars), _ptr(self.cell_map), self.n_agents, self.channels, self.ny,
-                       self.nx_, _ptr(w_main), _ptr(b_main), _ptr(w_down), _ptr(b_down), _ptr(out_main), _ptr(out_id), _stream())
+                       self.nx_, _ptr(w_main), _ptr(b_main), _ptr(w_down), _ptr(b_down), 1 if self.weight_layout == "tiles" else 0,
+                       _ptr(out_main), _ptr(out_id), _stream())
         return out_main, out_id
+
+
+def pillar_stem_fragments(w_main, w_down):
+    """Weights of heal_pillar_stem_block (layout 0): w_main [64, 64, 3, 3] -> [9][4][64][16] with frag[tap][w][16 lk + ln][ks] =
+    W[16 w + ln][16 lk + ks][tap]; w_down [64, 64, 1, 1] -> [4][64][16] likewise (the 16x16x4 A operand of wave w with the
+    reduction index permuted so that a lane's 16 k-steps are 16 consecutive input channels)."""
+    if tuple(w_main.shape) != (64, 64, 3, 3) or tuple(w_down.shape) != (64, 64, 1, 1):
+        raise _capi.HealAmdError("pillar_stem_fragments: expected [64, 64, 3, 3] and [64, 64, 1, 1]")
+    # [co = (w, ln), ci = (lk, ks), tap] -> [tap, w, lk, ln, ks]
+    wm = w_main.detach().to(torch.float32).reshape(4, 16, 4, 16, 9).permute(4, 0, 2, 1, 3).contiguous()
+    wd = w_down.detach().to(torch.float32).reshape(4, 16, 4, 16).permute(0, 2, 1, 3).contiguous()
+    return wm, wd
 
 
 def pfn_pillars(voxels, coords, num_points, weight, bn_scale, bn_shift, voxel_size, lidar_range, n_agents, ny, nx,

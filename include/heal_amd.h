@@ -118,8 +118,10 @@ int heal_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* 
  * heal_pillar_stem_block: the first BasicBlock convolutions of the PointPillars ResNetBEVBackbone (base_bev_backbone_resnet.py:88-109,
  *   resblock.py:18-64) straight from the pillars: out_main = relu(conv3x3/2 pad 1 (canvas, W1) + b1), out_identity = conv1x1/2 (canvas,
  *   Wd) + bd, both [n_agents, 64, ceil(ny/2), ceil(nx/2)], BatchNorms folded by the caller; the canvas is never written (it is 96 % zeros:
- *   taps with no pillar under an 8 x 8 output tile are skipped).  channels must be 64; w_main [9][1][64][64] (tap = ky*3 + kx, cout, cin),
- *   w_down [1][64][64] (heal_amd.ops.stem_fragments -- the layouts of heal_bev_stem_block); biases may be NULL.                          */
+ *   only the output pixels that see a pillar are multiplied, in groups of 16 on the 16x16x4 fp32 MFMA).  channels must be 64; biases may be NULL.
+ *   weight_layout 0 (production): lane fragments w_main [9][4][64][16], w_down [4][64][16] with frag[tap][w][16 lk + ln][ks] =
+ *   W[16 w + ln][16 lk + ks][tap] (heal_amd.ops.pillar_stem_fragments); weight_layout 1 (the round's first version, 8 x 8 tile x tap
+ *   skipping on 32x32x2 MFMA, kept for A/B): w_main [9][1][64][64] (tap = ky*3 + kx, cout, cin), w_down [1][64][64] (ops.stem_fragments). */
 int heal_pfn_pillars(const float* voxels, const int32_t* coords, const int32_t* num_points, int n_voxels,
                      const int32_t* n_voxels_dev, int max_points, const float* weight, const float* bn_scale,
                      const float* bn_shift, int channels, float vx, float vy, float vz, float x_offset, float y_offset,
@@ -128,7 +130,7 @@ int heal_pillar_canvas(const int32_t* cell_map, const float* pillar_feat, int n_
                        float* canvas, void* stream);
 int heal_pillar_stem_block(const float* pillar_feat, const int32_t* cell_map, int n_agents, int channels, int ny, int nx,
                            const float* w_main, const float* b_main, const float* w_down, const float* b_down,
-                           float* out_main, float* out_identity, void* stream);
+                           int weight_layout, float* out_main, float* out_identity, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5  warp to ego + occupancy-softmax weighted fusion over agents (one pyramid level, one scene).

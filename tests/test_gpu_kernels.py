@@ -194,11 +194,12 @@ def test_pfn_pillars_equal_pfn_scatter(golden):
     np.testing.assert_allclose(pb.dense().cpu().numpy(), g["spatial_features"], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("layout", ["lanes", "tiles"])
 @pytest.mark.parametrize("n_agents,ny,nx,rng_,seeds", [(2, 512, 512, PP_RANGE, (1000, 1001)),
                                                         (1, 240, 480, [-96, -48, -3, 96, 48, 1], (1002,)),
                                                         (3, 128, 128, [-25.6, -25.6, -3, 25.6, 25.6, 1], (1003, 1004, 1005)),
                                                         (1, 40, 24, [-4.8, -8.0, -3, 4.8, 8.0, 1], (1006,))])
-def test_pillar_stem_block_equals_dense_path(n_agents, ny, nx, rng_, seeds):
+def test_pillar_stem_block_equals_dense_path(n_agents, ny, nx, rng_, seeds, layout):
     """heal_pillar_stem_block (first BasicBlock convolutions of the PointPillars backbone read from the pillar rows through the
     cell map; the canvas is never written) against the dense path it replaces -- the canvas + torch's fp64 3x3 / stride 2 and 1x1 /
     stride 2 convolutions: 1e-5 of the output scale (summation order), background pixels exactly relu(bias) / bias.  Full 512 x 512
@@ -218,7 +219,8 @@ def test_pillar_stem_block_equals_dense_path(n_agents, ny, nx, rng_, seeds):
     wd = (torch.randn((64, 64, 1, 1), generator=g) / 8.0).cuda()
     b1, bd = torch.randn((64,), generator=g).cuda(), torch.randn((64,), generator=g).cuda()
     assert pb.stem_supported(64, 64)
-    wm, wdf = ops.stem_fragments(w1, wd)
+    pb.weight_layout = layout       # "lanes": the pixel-compacted production kernel; "tiles": the round's first version (A/B)
+    wm, wdf = pb.fragments(w1, wd)
     got_main, got_id = pb.stem_block(wm, b1, wdf, bd)
     ref_main = torch.relu(torch.nn.functional.conv2d(canvas.double(), w1.double(), b1.double(), 2, 1))
     ref_id = torch.nn.functional.conv2d(canvas.double(), wd.double(), bd.double(), 2, 0)

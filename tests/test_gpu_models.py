@@ -315,6 +315,35 @@ def test_config4_full_size_matches_oracle_model():
     assert all(v < 1e-3 for v in loc.values()), loc
 
 
+@pytest.mark.parametrize("mods", [["m1", "m1", "m1", "m2", "m4"], ["m2", "m4", "m1"], ["m1", "m2", "m1"]])
+def test_round6_work_skipping_paths_equal_the_plain_walk(mods, monkeypatch):
+    """Round 6 removed work whose result is known in advance, at FULL size: (a) the LiDAR backbone's first block reads the pillars
+    (heal_pillar_stem_block; HEAL_K2_POOLED=0: the dense canvas path), (b) the fusion pyramid runs the camera agents' stages on the
+    crop their zero-padded maps can influence and pastes it into the cached zero-input response (HEAL_PYRAMID_CAMCROP=0: the full
+    walk).  Both must reproduce the plain walk: heads to 1e-5 of their scale (a: summation order of the skipped zero taps), every
+    occupancy map of every agent to 1e-5 as well -- i.e. also OUTSIDE the pasted boxes, where the zero-input response stands in.
+    The third order (a camera agent between two LiDAR agents) has no contiguous split: the model must take the plain walk by itself."""
+    from heal_amd import configs
+    from heal_amd.pipeline import Scene, ScenePipeline
+    hypes = configs.heal_heter(tuple(sorted(set(mods))), max_cav=5)
+    pipe = ScenePipeline(hypes, "cuda:0", seed=0)
+    scene = Scene(len(mods), seed=11, device="cuda:0", modalities=mods)
+    outs = {}
+    for tag, pooled, camcrop in (("plain", "0", "0"), ("skip", "1", "1")):
+        monkeypatch.setenv("HEAL_K2_POOLED", pooled)
+        monkeypatch.setenv("HEAL_PYRAMID_CAMCROP", camcrop)
+        with torch.no_grad():
+            out = pipe.forward(scene)
+        outs[tag] = {k: out[k].clone() for k in ("cls_preds", "reg_preds", "dir_preds")}
+        outs[tag]["occ"] = [o.clone() for o in out["occ_single_list"]]
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        a, b = outs["plain"][k], outs["skip"][k]
+        assert float((a - b).abs().max() / a.abs().max()) < 1e-5, k
+    for a, b in zip(outs["plain"]["occ"], outs["skip"]["occ"]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max() / a.abs().max()) < 1e-5
+
+
 NATIVE_RANGE = [-96, -48, -3, 96, 48, 1]      # hypes_yaml/opv2v/Single/m1_pointpillar_pretrain.yaml:17 (tools/inference.py:34 widens it)
 
 
