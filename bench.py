@@ -134,23 +134,42 @@ def cpu_baseline(hypes, scene_cpu, cls_shift=0.0):
 
 
 _PMC = None
+_PMC_NOTE = {}
+
+
+def lib_stamp():
+    """Identity of the loaded libheal_amd.so: the build stamp (SHA-256 of csrc + headers + flags) heal_amd.build wrote beside it."""
+    try:
+        from heal_amd import build
+        return open(os.path.join(build.LIBDIR, "libheal_amd.stamp")).read().strip()
+    except OSError:
+        return None
 
 
 def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
-    """HBM bytes per launch of a kernel family from the COMMITTED rocprofv3 PMC summary of THIS workload -- a file read, not a
-    measurement of this run (counters need their own rocprofv3 passes; the line says so in `traffic_source`) --
-    (profiles/r0N_pmc_traffic_<workload>.json, scripts/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, bytes =
-    2 FETCH + WRITE per the guide's gfx950 correction), or None.  A family that is a SEQUENCE of kernels per launch (K4: scatter
-    + canvas) sums the per-dispatch means of its kernels; a family of one kernel with many shapes takes its mean."""
+    """HBM bytes per launch of a kernel family from the newest COMMITTED rocprofv3 PMC summary of THIS workload
+    (profiles/r0N_pmc_traffic_<workload>.json, scripts/runs/r06_profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, bytes =
+    2 FETCH + WRITE per the guide's gfx950 correction).  A file read, not a measurement of this run -- so it is REFUSED (None, the
+    reason in `traffic_source`) unless the summary records the build stamp of the library that is loaded now: counters of other
+    kernels say nothing about these.  A family that is a SEQUENCE of kernels per launch sums the per-dispatch
+    means of its kernels; a family of one kernel with many shapes takes its mean."""
     global _PMC
     if _PMC is None:
         _PMC = {}
     if workload not in _PMC:
         _PMC[workload] = {}
-        for tag in ("r05", "r04", "r03"):      # the newest committed PMC summary of this workload
+        _PMC_NOTE[workload] = "no committed PMC summary for this workload"
+        for tag in ("r06", "r05", "r04", "r03"):      # the newest committed PMC summary of this workload
             path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{workload}.json")
             if os.path.exists(path):
-                _PMC[workload] = json.load(open(path))["kernels"]
+                j = json.load(open(path))
+                if j.get("lib_stamp") and j.get("lib_stamp") == lib_stamp():
+                    _PMC[workload] = j["kernels"]
+                    _PMC_NOTE[workload] = (f"committed rocprofv3 PMC summary profiles/{tag}_pmc_traffic_{workload}.json of THIS library "
+                                           f"build (stamp {j['lib_stamp'][:12]}), not measured in this run")
+                else:
+                    _PMC_NOTE[workload] = (f"refused: profiles/{tag}_pmc_traffic_{workload}.json was recorded for library build "
+                                           f"{str(j.get('lib_stamp'))[:12]}, the loaded one is {str(lib_stamp())[:12]}")
                 break
     ks = _PMC[workload]
     tot, hit = 0.0, False
@@ -163,11 +182,41 @@ def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
     return round(tot, 1) if hit else None
 
 
+_KSTATS = {}
+
+
+def rocprof_mean_us(workload, prefix):
+    """Mean duration (us) of the kernels whose name starts with `prefix` in the newest committed `rocprofv3 --kernel-trace --stats`
+    summary of this workload's bench run (profiles/r0N_kernel_stats_<workload>.csv) -- the IN-GRAPH duration: the kernel as the
+    timed region runs it, sharing the chip with the other modality streams and the second frame in flight -- or None.  Accepted only
+    from a summary whose sidecar (.stamp) names the loaded library build."""
+    if workload not in _KSTATS:
+        _KSTATS[workload] = None
+        for tag in ("r06",):
+            path = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{workload}.csv")
+            side = path[:-4] + ".stamp"
+            if os.path.exists(path) and os.path.exists(side) and open(side).read().strip() == lib_stamp():
+                import csv
+                _KSTATS[workload] = (tag, list(csv.DictReader(open(path))))
+                break
+    if not _KSTATS[workload]:
+        return None
+    tag, rows = _KSTATS[workload]
+    calls = tot = 0.0
+    for r in rows:
+        name = r.get("Name") or r.get("KernelName") or ""
+        if name.startswith(prefix):
+            c = float(r.get("Calls") or 0)
+            calls += c
+            tot += float(r.get("TotalDurationNs") or 0)
+    return round(tot / calls / 1e3, 2) if calls else None
+
+
 def _entry(kernel, bound, achieved, launches, launch_ms, traffic=None, **extra):
     peak = HBM_PEAK_GBS if bound == "hbm" else FP32_PEAK_TFLOPS
     d = {"kernel": kernel, "bound": bound, "achieved": round(achieved, 2), "peak": peak,
          "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-         "traffic_source": None if traffic is None else "committed rocprofv3 PMC summary (profiles/), not measured in this run",
+         "traffic_source": _PMC_NOTE.get(_entry.workload, "no committed PMC summary for this workload"),
          "launches": launches, "launch_ms": round(launch_ms, 5)}
     if bound == "hbm" and traffic is not None and launch_ms > 0:
         # VERDICT r4 item 5: `frac` prices the kernel at SURVEY 8d's ALGORITHMIC bytes, which for a fused kernel include traffic it no
@@ -178,12 +227,16 @@ def _entry(kernel, bound, achieved, launches, launch_ms, traffic=None, **extra):
     return d
 
 
+_entry.workload = None
+
+
 def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, world, n_agents, sp_trace, ny, nx, in_graph=None):
     """`roofline` = the hand-written kernel family that takes the most time in this workload; `roofline_other` = every other
     north-star kernel present.  achieved = algorithmic bytes (HBM-bound kernels) or FLOPs (MFMA-bound kernels)
     of the recorded launches / their summed HIP-event durations, i.e. per-launch work / average launch duration."""
     from heal_amd.dist import owned_agents
     from heal_amd.pipeline import Scene
+    _entry.workload = a.workload
     fam = {}
 
     def add(name, kernel, bound, w):
@@ -191,14 +244,13 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         f["calls"] += w["calls"]; f["ms"] += w["total_ms"]; f["flops"] += w["flops"]; f["bytes"] += w["bytes"]
     for name, w in work.items():
         if name.startswith("conv1x1_"):
-            # two populations: the fusion-backbone / trunk convolutions with >= 1 GFLOP per launch (MFMA-bound; most of the
-            # family's time) and the small ones (image trunks at 1/16 .. 1/32 resolution, heads: launch / latency-bound)
-            if w["flops"] >= 1e9 * max(w["calls"], 1):
-                add("conv1x1", "K7 heal_conv1x1, launches of >= 1 GFLOP (pointwise convolutions of the fusion backbone and the "
-                               "trunks, fp32 MFMA, fused epilogues)", "mfma", w)
-            else:
-                add("conv1x1s", "K7 heal_conv1x1, launches below 1 GFLOP (image trunks at 1/16..1/32 resolution, heads: "
-                                "latency-bound)", "mfma", w)
+            # ONE family entry: every launch of the kernel (the >= 1 GFLOP population alone flattered the headline).
+            # The two populations -- fusion-backbone / trunk convolutions with >= 1 GFLOP per launch (MFMA-bound; most of the family's
+            # time) and the small ones (image trunks at 1/16 .. 1/32 resolution, heads: launch / latency-bound) -- stay as sub-fields.
+            add("conv1x1", "K7 heal_conv1x1, ALL launches (pointwise convolutions of the fusion backbone, the image trunks at 1/8..1/32 "
+                           "resolution, the ConvNeXt aligners, deblocks and heads; fp32 MFMA, fused epilogues); `split` = the launches of "
+                           ">= 1 GFLOP and those below", "mfma", w)
+            add("conv1x1_big" if w["flops"] >= 1e9 * max(w["calls"], 1) else "conv1x1_small", "", "mfma", w)
         elif name.startswith("conv3x3w_"):
             add("conv3x3w", "K7 heal_conv3x3_winograd (dense 3x3 stride 1, F(2x2,3x3) on fp32 MFMA; achieved = EXECUTED matrix "
                             "FLOPs 2*16*Cin*Cout*tiles = direct/2.25, `direct_equiv_tflops` = the direct convolution's count)",
@@ -222,22 +274,34 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             add("k5", "K5 heal_warp_fuse_levels (warp + occupancy-softmax fusion, ALL pyramid levels in one launch, source footprints "
                       "staged through LDS; heal_warp_fuse per level where the model fuses level by level)", "hbm", w)
     entries = {}
+    split1 = {}
+    for key in ("conv1x1_big", "conv1x1_small"):
+        f = fam.pop(key, None)
+        if f and f["ms"] > 0:
+            t_ = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            split1["ge_1_gflop" if key.endswith("big") else "lt_1_gflop"] = {
+                "launches": f["calls"], "launch_ms": round(f["ms"] / max(f["calls"], 1), 5), "step_ms": round(f["ms"] / max(a.steps, 1), 4),
+                "tflops": round(t_, 2), "frac": round(t_ / FP32_PEAK_TFLOPS, 4)}
     for key, f in fam.items():
         if f["ms"] <= 0:
             continue
         ach = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["bound"] == "mfma" else (f["bytes"] / (f["ms"] * 1e-3) / 1e9)
         extra = {"step_ms": round(f["ms"] / max(a.steps, 1), 4)}
-        if key in ("conv1x1", "conv1x1s", "conv3x3w", "conv3x3", "grouped", "k5", "linear"):
+        if key in ("conv1x1", "conv3x3w", "conv3x3", "grouped", "k5", "linear"):
             # one kernel per launch: the events are stamped by the launch itself (heal_next_launch_events / hipExtLaunchKernelGGL)
             # with the kernel's own begin / end -- the duration a rocprofv3 kernel trace reports for it
             extra["duration"] = "kernel-own begin / end stamps"
         if key.startswith("wattn"):      # both roofs for the window-attention kernels
             extra["tflops"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
             extra["hbm_gbs"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
+        if key == "conv1x1":
+            extra["split"] = split1
+            # the same kernel inside the replayed graphs (two frames in flight, concurrent modality streams): rocprofv3's mean
+            extra["rocprof_in_graph_mean_us"] = rocprof_mean_us(a.workload, "void heal::k_conv1x1<") or rocprof_mean_us(a.workload, "heal::k_conv1x1<")
         if key == "conv3x3w":   # the wrapper counts the direct convolution's FLOPs; the kernel executes 16/36 of them
             extra["direct_equiv_tflops"] = round(ach, 2)
             ach = ach / 2.25
-        tr = pmc_traffic(a.workload, *{"conv1x1": ("heal::k_conv1x1<",), "conv1x1s": ("heal::k_conv1x1<",),
+        tr = pmc_traffic(a.workload, *{"conv1x1": ("heal::k_conv1x1<",),
                                        "conv3x3w": ("heal::k_conv3x3_wino<",), "conv3x3": ("heal::k_conv3x3<",),
                                        "grouped": ("heal::k_gconv_small<",), "k5": ("heal::k_warp_fuse",),
                                        "linear": ("heal::k_linear",)}.get(key, ()))
@@ -260,6 +324,27 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         entries["k2"] = (calls * mean_ms, _entry(
             f"K2 heal_pfn_scatter, {len(m_launch)} collated LiDAR agents per launch (k_pfn + k_canvas)", "hbm",
             bytes_per_launch / (mean_ms * 1e-3) / 1e9, calls, mean_ms, traffic, bytes_per_launch=bytes_per_launch))
+    if "pfn_pillars" in timing:
+        # round 6: K2 WITHOUT the dense canvas (heal_pfn_pillars: pillar features + cell -> pillar map); its consumer, the first block of
+        # the LiDAR backbone, reads the pillars (heal_pillar_stem_block).  `frac` prices the bytes this operator really has to move
+        # (voxels + coords + counts read, pillar features + map written); SURVEY 8d's K2 formula -- which includes the 4*64*ny*nx canvas
+        # this path no longer writes -- is printed beside it, as is the consumer.
+        calls, mean_ms = timing["pfn_pillars"]
+        lidar_ids = [i for i, m in enumerate(mods) if m == "m1"]
+        if not solo:
+            lidar_ids = [i for i in lidar_ids if i in owned_agents(n_agents, 0, world)]
+        order = sorted(scene.points)
+        m_launch = [m_per_agent[order.index(i)] for i in lidar_ids if i in order]
+        moved = float(sum(16 * 32 * m + 20 * m + 256 * m for m in m_launch) + 4 * ny * nx * len(m_launch))
+        survey = float(sum(k2_algorithmic_bytes(32, m, ny, nx) for m in m_launch))
+        extra = {"bytes_per_launch": moved, "survey_8d_bytes_with_canvas": survey, "canvas_written": False}
+        if "pillar_stem_block" in timing:
+            extra["consumer"] = {"kernel": "heal_pillar_stem_block (3x3/2 conv1 + 1x1/2 downsample of the first LiDAR BasicBlock straight from "
+                                           "the pillars: only output pixels that see a pillar are multiplied; replaces k_canvas + heal_conv3x3 "
+                                           "stride 2 + heal_conv1x1 stride 2)", "launch_ms": round(timing["pillar_stem_block"][1], 5)}
+        entries["k2"] = (calls * mean_ms, _entry(
+            f"K2 heal_pfn_pillars, {len(m_launch)} collated LiDAR agents per launch (k_pfn4 + the cell map fill; no canvas)", "hbm",
+            moved / (mean_ms * 1e-3) / 1e9, calls, mean_ms, pmc_traffic(a.workload, "heal::k_pfn"), **extra))
     # K4: one camera agent per launch (logits + features read, canvas written)
     if "bev_pool" in timing:
         cam_ids = [i for i, m in enumerate(mods) if m in Scene.CAMERA_DIMS and (solo or i in owned_agents(n_agents, 0, world))]
@@ -366,6 +451,51 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
     return entries[order[0]][1], [entries[k][1] for k in order[1:]]
 
 
+def preflight(dist, rank, world, dev, backend, limit_s=30.0):
+    """First contact of the N > 1 path with the hardware: one all-reduce, one gather and one all-to-all of 1 KB each,
+    bounded by a timer that ends the job with a clear message instead of a silent watchdog exit; every rank announces itself on stderr
+    and rank 0 keeps who-runs-where for the JSON line, so the driver's record shows N ranks on N devices."""
+    import threading
+
+    def _expire():
+        print(f"[bench] rank {rank}: PREFLIGHT FAILED -- the {backend} process group of {world} ranks did not complete a 1-KB all_reduce / "
+              f"gather / all_to_all_single within {limit_s:.0f} s (device {dev}; check HSA_ENABLE_IPC_MODE_LEGACY=0, one rank per GPU, "
+              "MASTER_ADDR=127.0.0.1)", file=sys.stderr, flush=True)
+        os._exit(4)
+    timer = threading.Timer(limit_s, _expire)
+    timer.daemon = True
+    timer.start()
+    t0 = time.perf_counter()
+    x = torch.full((256,), float(rank + 1), device=dev)
+    dist.all_reduce(x)
+    assert float(x[0].item()) == world * (world + 1) / 2, "preflight: all_reduce returned a wrong sum"
+    parts = [torch.empty(256, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(torch.full((256,), float(rank), device=dev), parts, dst=0)
+    if rank == 0:
+        assert [float(p_[0].item()) for p_ in parts] == [float(r) for r in range(world)], "preflight: gather returned wrong rows"
+    a2a_in = torch.arange(world * 64, device=dev, dtype=torch.float32) + 1000.0 * rank
+    a2a_out = torch.empty_like(a2a_in)
+    try:
+        dist.all_to_all_single(a2a_out, a2a_in)
+        a2a = bool(float(a2a_out[0].item()) == 64.0 * rank)
+    except Exception as e:  # noqa: BLE001 - gloo has no all_to_all on device tensors: the striped tail then uses gathers
+        a2a = f"unavailable on this backend ({type(e).__name__})"
+    torch.cuda.synchronize()
+    timer.cancel()
+    me = {"rank": rank, "device_index": dev.index, "device": torch.cuda.get_device_name(dev), "pid": os.getpid()}
+    print(f"[bench] rank {rank}/{world} on cuda:{dev.index} ({me['device']}), backend {backend}, preflight "
+          f"{(time.perf_counter() - t0) * 1e3:.0f} ms", file=sys.stderr, flush=True)
+    who = [None] * world
+    dist.all_gather_object(who, me)
+    out = {"ranks": who, "preflight": {"all_reduce": True, "gather": True, "all_to_all_single": a2a}}
+    if backend == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            out["rccl_version"] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,12 +542,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
+    job = {"world_size": world, "backend": "none" if world == 1 else ("nccl (RCCL)" if backend == "nccl" else backend)}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        job.update(preflight(dist, rank, world, dev, backend))
 
     if os.environ.get("HEAL_MIOPEN_BENCHMARK", "0") == "1":
         torch.backends.cudnn.benchmark = True  # MIOpen find mode: time the applicable solvers once per shape
@@ -492,6 +624,29 @@ def main():
                 return pipe.post.post_process(batch, {"ego": out})
             return None, None
         eager_step = step
+
+        # Self-proof of the sharded step BEFORE anything is timed: frame 0 through the agent-sharded forward of
+        # the whole job, and the same frame as ONE process on rank 0's GPU (every rank holds the whole model and the synthetic scene);
+        # the boxes must agree -- same survivors, corners / scores to 1e-5 -- or the job ends here, on every rank.
+        static.load(frames[0])
+        out0 = sharded.forward(inp, n_agents, local_inputs)
+        verdict = torch.ones(1, device=dev)
+        if rank == 0:
+            b_sh, s_sh = pipe.post.post_process(batch, {"ego": out0})
+            b_1, s_1 = pipe.step(frames[0])
+            same = (b_sh is None) == (b_1 is None)
+            if same and b_1 is not None:
+                same = (tuple(b_sh.shape) == tuple(b_1.shape) and bool(torch.allclose(b_sh, b_1, rtol=1e-5, atol=1e-5))
+                        and bool(torch.allclose(s_sh, s_1, rtol=1e-5, atol=1e-5)))
+            job["sharded_equals_single"] = bool(same)
+            job["sharded_check"] = {"frame": 0, "boxes_sharded": 0 if b_sh is None else int(b_sh.shape[0]),
+                                    "boxes_single_process": 0 if b_1 is None else int(b_1.shape[0]),
+                                    "bit_equal": bool(same and (b_1 is None or (torch.equal(b_sh, b_1) and torch.equal(s_sh, s_1))))}
+            verdict.fill_(1.0 if same else 0.0)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        if float(verdict.item()) != 1.0:
+            raise SystemExit(f"[bench] rank {rank}: the agent-sharded step does NOT reproduce the single-process step on frame 0 "
+                             f"({job.get('sharded_check')}): refusing to time it")
 
         if not a.eager:
             # graph(local stage) -> RCCL all-gather -> graph(fusion tail + decode/NMS on rank 0)
@@ -673,7 +828,10 @@ def main():
                                   else f"hipGraph(local stage) -> {coll_name} -> hipGraph(fusion tail + decode/NMS)"),
                        "frames_in_flight": (ring.depth if ring is not None else 1),
                        "frame_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
-                       "boxes_out": 0 if res[0] is None else int(res[0].shape[0])},
+                       "boxes_out": 0 if res[0] is None else int(res[0].shape[0]),
+                       "inputs": "sensor frames resident in HBM before the timed region (4 distinct frames cycled); H2D not timed",
+                       "job": job, "collective": coll_name,
+                       "sharded_equals_single": job.get("sharded_equals_single")},
             "roofline": roof, "roofline_other": roof_other, "op_timing_ms": kernels,
         }
         if serial is not None:

@@ -399,7 +399,9 @@ class ShardedCollab(_Sharded):
         pb = m.pyramid_backbone
         n_slots = slots_per_rank(n_agents, self.world)
         x, mine = self._own_features(scene_input, n_agents, local_inputs)
-        stages = pb.get_multiscale_feature(x) if mine else None
+        # (a rank whose agents are cameras walks the stages on the crop their zero-padded maps can influence: pyramid_fuse.multiscale)
+        stages = pb.multiscale(x, [mods[a] for a in mine], None if getattr(m, "compress", False)
+                               else m.__dict__.get("_heal_cam_boxes")) if mine else None
         if self._shapes is None:
             if not mine:
                 raise RuntimeError("ShardedCollab: prepare() must run before local() on a rank that owns no agent")

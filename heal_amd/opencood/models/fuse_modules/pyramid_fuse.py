@@ -220,7 +220,7 @@ class PyramidFusion(ResNetBEVBackbone):
             return None
         cams = [k for k, m in enumerate(agent_modality_list) if m in cam_boxes]
         n = len(agent_modality_list)
-        if not cams or len(cams) == n or cams != list(range(cams[0], cams[-1] + 1)) or (cams[0] != 0 and cams[-1] != n - 1):
+        if not cams or cams != list(range(cams[0], cams[-1] + 1)) or (cams[0] != 0 and cams[-1] != n - 1):
             return None
         from heal_amd.opencood.models.sub_modules.bev_blocks import Bottleneck
         if not all(isinstance(b, Bottleneck) and b.conv2.kernel_size == (3, 3) and b.conv2.padding == (1, 1)
@@ -233,16 +233,19 @@ class PyramidFusion(ResNetBEVBackbone):
             return None
         return (cams[0], cams[-1] + 1), box
 
+    def multiscale(self, spatial_features, agent_modality_list=None, cam_boxes=None):
+        """get_multiscale_feature, by the camera-crop walk where it applies (cam_boxes: see forward_collab)."""
+        cc = self._camcrop_args(spatial_features, agent_modality_list, cam_boxes)
+        if cc is not None:
+            return self.get_multiscale_feature_camcrop(spatial_features, *cc)
+        return self.get_multiscale_feature(spatial_features)
+
     def forward_collab(self, spatial_features, record_len, affine_matrix, agent_modality_list=None,
                        cam_crop_info=None, grid_f64=True, cam_boxes=None):
         """affine_matrix: host numpy [B,L,L,2,3] (normalize_pairwise_tfm of the host pairwise matrix);
         record_len: list of ints.  cam_boxes: {modality: (y0, y1, x0, x1)} -- the caller's promise that the maps of those (camera)
         modalities are exactly zero outside the box (it zero-padded them itself): enables the camera-crop stage walk."""
-        cc = self._camcrop_args(spatial_features, agent_modality_list, cam_boxes) if len(record_len) == 1 else None
-        if cc is not None:
-            feature_list = self.get_multiscale_feature_camcrop(spatial_features, *cc)
-        else:
-            feature_list = self.get_multiscale_feature(spatial_features)
+        feature_list = self.multiscale(spatial_features, agent_modality_list, cam_boxes if len(record_len) == 1 else None)
         use_crop = bool(cam_crop_info) and not self.training
         fused_feature_list, occ_map_list = [], []
         import os

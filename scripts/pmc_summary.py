@@ -73,8 +73,11 @@ def main():
             allk[name] = {"dispatches": n, "fetch_KB": round(fetch.get(k, (0, 0.0))[1], 1),
                           "write_KB": round(write.get(k, (0, 0.0))[1], 1),
                           "bytes_per_dispatch": (2.0 * fetch.get(k, (0, 0.0))[1] + write.get(k, (0, 0.0))[1]) * 1024.0}
+        # the build stamp of the library whose kernels were counted: bench.py refuses the summary for any other build
+        stamp_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "heal_amd", "lib", "libheal_amd.stamp")
+        stamp = open(stamp_path).read().strip() if os.path.exists(stamp_path) else None
         json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; bytes = (2 FETCH + WRITE) KB",
-                   "kernels": allk}, open(sys.argv[sys.argv.index("--json-all") + 1], "w"), indent=1)
+                   "lib_stamp": stamp, "kernels": allk}, open(sys.argv[sys.argv.index("--json-all") + 1], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ class _Pyramid(nn.Module):
     def forward_single(self, x):
         return x.repeat(1, 4, 1, 1)[:, :256], [x[:, :1], x[:, :1, ::2, ::2], x[:, :1, ::4, ::4]]
 
-    def forward_collab(self, x, record_len, affine_matrix, agent_modality_list=None, cam_crop_info=None, grid_f64=True):
+    def forward_collab(self, x, record_len, affine_matrix, agent_modality_list=None, cam_crop_info=None, grid_f64=True, cam_boxes=None):
         assert x.shape[0] == sum(record_len) and affine_matrix.shape[-2:] == (2, 3)
         return x[:1].repeat(1, 4, 1, 1)[:, :256], [x[:, :1], x[:, :1, ::2, ::2], x[:, :1, ::4, ::4]]
 
@@ -148,7 +148,9 @@ def test_no_runtime_memset_or_d2d_copy_in_the_library():
     import re
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "heal_amd", "csrc")
     hits = []
-    for path in sorted(glob.glob(os.path.join(src, "*"))):
+    for path in sorted(glob.glob(os.path.join(src, "*")) + glob.glob(os.path.join(src, "experimental", "*"))):
+        if os.path.isdir(path):
+            continue
         text = open(path).read()
         text = re.sub(r"//.*", "", text)
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
