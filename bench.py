@@ -635,12 +635,23 @@ def main():
             b_sh, s_sh = pipe.post.post_process(batch, {"ego": out0})
             b_1, s_1 = pipe.step(frames[0])
             same = (b_sh is None) == (b_1 is None)
+            dev_box = dev_score = 0.0
             if same and b_1 is not None:
-                same = (tuple(b_sh.shape) == tuple(b_1.shape) and bool(torch.allclose(b_sh, b_1, rtol=1e-5, atol=1e-5))
-                        and bool(torch.allclose(s_sh, s_1, rtol=1e-5, atol=1e-5)))
+                # same survivors: equal count, every sharded box has its twin (nearest centre) within 5 mm with a score within 1e-3 --
+                # the tolerance of tests/test_gpu_dist.py: the two paths sum the agents' contributions in different orders (warp per agent
+                # + fuse vs one fused kernel; camera lift atomics), so the head maps agree to ~1e-5 of their scale, not bit for bit
+                same = tuple(b_sh.shape) == tuple(b_1.shape)
+                if same:
+                    d_ = torch.cdist(b_sh.mean(1), b_1.mean(1))
+                    twin = d_.argmin(1)
+                    dev_box = float((b_sh - b_1[twin]).abs().max())
+                    dev_score = float((s_sh - s_1[twin]).abs().max())
+                    same = bool(len(set(twin.tolist())) == int(b_1.shape[0]) and dev_box < 5e-3 and dev_score < 1e-3)
             job["sharded_equals_single"] = bool(same)
             job["sharded_check"] = {"frame": 0, "boxes_sharded": 0 if b_sh is None else int(b_sh.shape[0]),
                                     "boxes_single_process": 0 if b_1 is None else int(b_1.shape[0]),
+                                    "max_corner_deviation_m": dev_box, "max_score_deviation": dev_score,
+                                    "tolerance": "same survivor set; corners 5e-3 m, scores 1e-3 (tests/test_gpu_dist.py)",
                                     "bit_equal": bool(same and (b_1 is None or (torch.equal(b_sh, b_1) and torch.equal(s_sh, s_1))))}
             verdict.fill_(1.0 if same else 0.0)
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN)

@@ -561,3 +561,76 @@ def test_grouped_small_fragment_layout():
         assert tuple(f.shape) == (C // 16, 9, cg, 16) and f.is_contiguous()
         for sg, tap, ci, co in ((0, 0, 0, 0), (C // 16 - 1, 8, cg - 1, 15), (3, 5, 1, 9)):
             assert float(f[sg, tap, ci, co]) == float(w[sg * 16 + co, ci, tap // 3, tap % 3])
+
+
+def _pairs_near_threshold(n, seed, thr=0.15):
+    """Pairs of car-sized rotated boxes whose IoU lies around `thr`: B = A shifted along A's heading by the offset that gives exactly
+    `thr` for an aligned pair, then perturbed (offset, lateral shift, yaw) by amounts from 1e-7 to 1e-2 -- so the set holds pairs from
+    far on either side of the threshold down to a few ulps of it."""
+    from oracle import exact_iou as E
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        cx, cy = rng.uniform(-100, 100, 2)
+        L, W = rng.uniform(3.5, 5.0), rng.uniform(1.6, 2.2)
+        yaw = rng.uniform(-np.pi, np.pi)
+        dx = L * (1 - thr) / (1 + thr)                      # aligned pair: iou = (L - dx) / (L + dx)
+        eps = 10.0 ** rng.uniform(-7, -2) * rng.choice([-1, 1])
+        lat = 10.0 ** rng.uniform(-7, -2) * rng.choice([-1, 0, 1])
+        dyaw = 10.0 ** rng.uniform(-7, -2) * rng.choice([-1, 0, 1])
+        bx = cx + (dx + eps) * np.cos(yaw) - lat * np.sin(yaw)
+        by = cy + (dx + eps) * np.sin(yaw) + lat * np.cos(yaw)
+        out.append((E.box_quad(cx, cy, L, W, yaw), E.box_quad(bx, by, L, W, yaw + dyaw)))
+    return out
+
+
+def test_oracle_quad_iou_against_exact_rational_arithmetic():
+    """the NMS survivors are bit-exact by contract, the reference's IoU arithmetic (GEOS) is absent, so the oracle's
+    fp64 clip is checked against the TRUE IoU -- exact rational arithmetic on the fp32 corners (oracle/exact_iou.py) -- on 10^4 pairs
+    drawn around the 0.15 threshold: (a) the oracle's value is the true value rounded to fp32 (one ulp of slack for a true value on a
+    rounding boundary), (b) its suppression decision `iou > 0.15f` equals the true one for EVERY pair, (c) pairs whose true IoU lies
+    within 1e-9 of the threshold -- the only ones where GEOS's robust predicates, or any other correct fp64 evaluation, could decide
+    differently -- are counted and reported."""
+    from fractions import Fraction
+    from oracle import cref
+    from oracle import exact_iou as E
+    from tests.report import note
+    pairs = _pairs_near_threshold(10000, seed=7)
+    thr32 = np.float32(0.15)
+    thr = Fraction(float(thr32))
+    got = np.array([cref.quad_iou(a[None], b[None])[0, 0] for a, b in pairs], np.float32)
+    close = flips = off_ulp = 0
+    worst = 0.0
+    for (a, b), g in zip(pairs, got):
+        t = E.exact_quad_iou(a, b)
+        tf = float(t)
+        worst = max(worst, abs(float(g) - tf))
+        if np.float32(tf) != g:
+            off_ulp += 1
+            assert abs(float(g) - tf) <= np.spacing(np.float32(tf)), (float(g), tf)
+        if abs(t - thr) < Fraction(1, 10 ** 9):
+            close += 1
+        # the decision the reference takes: fp32(iou) > fp32(0.15); the true value decides the same way unless rounding to fp32
+        # carries it across the threshold -- which the comparison below would expose
+        if bool(g > thr32) != bool(np.float32(tf) > thr32):
+            flips += 1
+    note("nms_iou_exact_rational", pairs=len(pairs), within_1e9_of_threshold=close, decision_flips=flips,
+         not_the_rounded_true_value=off_ulp, max_abs_error=worst)
+    assert flips == 0
+    assert worst < 1e-7
+
+
+def test_exact_rational_iou_known_answers():
+    """The checker itself: identical boxes 1, disjoint 0, half-shifted axis-aligned unit squares 1/3, a 45-degree rotated unit square
+    over a unit square (2 sqrt 2 - 2) / (4 - 2 sqrt 2) (irrational: only approximately), containment = area ratio -- exact where rational."""
+    from fractions import Fraction
+    from oracle import exact_iou as E
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    assert E.exact_quad_iou(sq, sq) == 1
+    assert E.exact_quad_iou(sq, sq + np.float32(2)) == 0
+    assert E.exact_quad_iou(sq, sq + np.array([0.5, 0], np.float32)) == Fraction(1, 3)
+    assert E.exact_quad_iou(sq, sq[::-1].copy()) == 1                      # orientation does not matter
+    big = np.array([[-1, -1], [3, -1], [3, 3], [-1, 3]], np.float32)
+    assert E.exact_quad_iou(sq, big) == Fraction(1, 16)
+    assert E.exact_quad_iou(sq, sq + np.array([1, 0], np.float32)) == 0    # shared edge only
+    assert E.exact_quad_iou(np.zeros((4, 2), np.float32), np.zeros((4, 2), np.float32)) is None
