@@ -826,7 +826,10 @@ def main():
             "metric": "scenes/sec (5-agent OPV2V-H, PointPillars+PyramidFusion)",
             "value": round((world if replicas else 1) * a.steps / dt, 3), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if replicas else "strong", "vs_baseline": None,
+            "dtype": ("f32" if not os.environ.get("HEAL_ARITH") else
+                      f"f32 via {os.environ['HEAL_ARITH']} split (OPT-IN: pointwise convolutions with cin % 32 == 0, cout % 128 == 0 on the "
+                      "bf16 matrix cores, fp32 in / out / accumulate; everything else exact-fp32 MFMA)"), "data": "synthetic",
             "config": {"workload": f"{a.workload}: {desc}", "agents": n_agents,
                        "pillars_per_agent": m_per_agent, "modalities": mods,
                        "points_per_agent": [int(scene.points[k].shape[0]) for k in sorted(scene.points)],

@@ -131,6 +131,8 @@ _SIGNATURES = {
     "heal_se_gate": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_int, c_void_p, c_void_p]),
     "heal_conv1x1": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p]),
     "heal_stem7x7": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "heal_conv1x1_split_supported": (c_int, [c_int] * 4),
+    "heal_conv1x1_split": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_void_p]),
     "heal_conv1x1_tiled_supported": (c_int, [c_int] * 5),
     "heal_conv1x1_tiled": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_void_p]),
     "heal_conv1x1_splitk_workspace": (c_size_t, [c_int] * 5),

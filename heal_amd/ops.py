@@ -1675,6 +1675,39 @@ def conv1x1_tiled_ok(n, cin, cout, hw):
     return blocks >= 256 and cin >= 128
 
 
+_FRAGS_CACHE = {}
+
+
+def arith_products():
+    """HEAL_ARITH: "" / "f32" (default: exact-fp32 MFMA everywhere) | "bf16x6" | "bf16x9" -- the OPT-IN split-bf16 evaluation of the
+    pointwise convolutions (heal_conv1x1_split; fp32 in / out / accumulate, 6 or 9 bf16 partial products per fp32 product)."""
+    a = os.environ.get("HEAL_ARITH", "")
+    return {"bf16x6": 6, "bf16x9": 9}.get(a, 0)
+
+
+def conv1x1_split_fragments(w):
+    """[Cout, Cin(,1,1)] fp32 -> the three bf16 planes (w = h + m + l, round to nearest) in the fragment order of heal_conv1x1_split:
+    [Cout/128][Cin/32][k16 step 2][row block 4][plane 3][lane 64][8] with element = W_p[128 ct + 32 rb + lane % 32][32 c + 16 s +
+    8 (lane / 32) + e]; cached per storage + version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _FRAGS_CACHE.get(key)
+    if hit is None:
+        if len(_FRAGS_CACHE) > 512:
+            _retire_cache(_FRAGS_CACHE)
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        wm = w.detach().reshape(cout, cin).to(torch.float32)
+        h = wm.to(torch.bfloat16)
+        r1 = wm - h.float()
+        m = r1.to(torch.bfloat16)
+        lo = (r1 - m.float()).to(torch.bfloat16)
+        planes = torch.stack([h, m, lo], 0)                                    # [3, cout, cin]
+        f = planes.reshape(3, cout // 128, 4, 32, cin // 32, 2, 2, 8)          # [p, ct, rb, li, c, s, kb, e]
+        f = f.permute(1, 4, 5, 2, 0, 6, 3, 7).contiguous()                     # [ct, c, s, rb, p, kb, li, e]
+        hit = (f, w)
+        _FRAGS_CACHE[key] = hit
+    return hit[0]
+
+
 def _w_rowmajor(w):
     w2 = w.detach().reshape(int(w.shape[0]), int(w.shape[1]))
     return w2 if w2.is_contiguous() else w2.contiguous()
@@ -1703,6 +1736,20 @@ def conv1x1(x, w, bias=None, residual=None, act=0, in_scale=None, stride=1, pixe
         raise _capi.HealAmdError(f"conv1x1: unsupported shape Cin={cin} Cout={cout} HxW={H}x{W} stride={stride}")
     if out is not None and pixel_major:
         raise _capi.HealAmdError("conv1x1: `out` is for the NCHW result")
+    nprod = arith_products()
+    if (nprod and stride == 1 and not pixel_major and in_scale is None and w.dtype == torch.float32
+            and _capi.query("heal_conv1x1_split_supported", cin, cout, H, W)):
+        y = _out_or_empty(out, (n, cout, H, W), x.device, "conv1x1")
+        if residual is not None:
+            residual = _need(residual, torch.float32, "residual")
+            if tuple(residual.shape) != tuple(y.shape):
+                raise _capi.HealAmdError("conv1x1: residual shape mismatch")
+        frag = conv1x1_split_fragments(w)
+        with _Timed(f"conv1x1_{cin}_{cout}", 2.0 * n * cin * cout * H * W,
+                    4.0 * n * (cin * H * W + cout * H * W * (2 if residual is not None else 1)), kernel_events=True):
+            _capi.call("heal_conv1x1_split", _ptr(x), _ptr(frag), _ptr(bias) if bias is not None else None,
+                       _ptr(residual) if residual is not None else None, n, cin, cout, H, W, int(act), nprod, _ptr(y), _stream())
+        return y
     if (stride == 1 and not pixel_major and in_scale is None and conv1x1_tiled_ok(n, cin, cout, H * W)
             and w.dtype == torch.float32):
         y = _out_or_empty(out, (n, cout, H, W), x.device, "conv1x1")

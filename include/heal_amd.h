@@ -522,6 +522,15 @@ int heal_conv3x3_same(const float* x, const float* weight_frag, const float* bia
  *   y: [n, 64, Hp, Wp] with Hp = ((H - 1) / 2) / 2 + 1 ... (pool) or [n, 64, (H - 1) / 2 + 1, (W - 1) / 2 + 1] (no pool).          */
 int heal_stem7x7(const float* x, long long image_stride, int n, int cin, int H, int W, const float* weight_frag,
                  const float* bias, int pool, float* y, void* stream);
+/* heal_conv1x1_split (round 6, OPT-IN prototype: HEAL_ARITH=bf16x6 | bf16x9 in the host mirror; never the default): the same pointwise
+ *   convolution with fp32 inputs / outputs and fp32 accumulation, evaluated on the BF16 matrix cores by splitting both operands into three
+ *   bf16 numbers (a = a_h + a_m + a_l exactly) and summing n_products = 6 (terms down to 2^-16 of the product) or 9 (all: exact products)
+ *   partial products.  weight_frag: the three bf16 planes of W [Cout, Cin] in fragment order (heal_amd.ops.conv1x1_split_fragments:
+ *   [Cout/128][Cin/32][2][4][3][64 lanes][8 bf16]); stride 1, NCHW in and out; cin % 32 == 0, cout % 128 == 0; act 0 none | 1 ReLU |
+ *   2 SiLU | 3 GELU (erf).  Error against fp64 and the exact-fp32 kernel: tests/test_gpu_kernels.py::test_conv1x1_split_*.          */
+int heal_conv1x1_split_supported(int cin, int cout, int H, int W);
+int heal_conv1x1_split(const float* x, const void* weight_frag, const float* bias, const float* residual, int n, int cin, int cout,
+                       int H, int W, int act, int n_products, float* y, void* stream);
 size_t heal_conv1x1_splitk_workspace(int n, int cout, int H, int W, int ksplit);
 int heal_conv1x1_splitk(const float* x, const float* weight_frag, const float* bias, const float* residual,
                         const float* in_scale, int n, int cin, int cout, int H, int W, int act, int ksplit, float* y, void* ws,

@@ -310,7 +310,9 @@ def test_config4_full_size_matches_oracle_model():
         assert got.shape == ref[key].shape == (1, {"cls_preds": 2, "reg_preds": 14, "dir_preds": 4}[key], 256, 256)
         errs[key] = rel_err(got, ref[key])
     loc = {key: local_err(out[key].cpu().numpy(), ref[key]) for key in errs}
-    note("config4_full_size_vs_oracle_model", **{k: float(v) for k, v in errs.items()}, **{f"local_{k}": v for k, v in loc.items()})
+    # (HEAL_ARITH=bf16x6 | bf16x9, opt-in: the same test is the end-to-end parity number of the split-bf16 pointwise convolutions)
+    note("config4_full_size_vs_oracle_model" + ("_" + os.environ["HEAL_ARITH"] if os.environ.get("HEAL_ARITH") else ""),
+         **{k: float(v) for k, v in errs.items()}, **{f"local_{k}": v for k, v in loc.items()})
     assert all(v < 1e-3 for v in errs.values()), errs
     assert all(v < 1e-3 for v in loc.values()), loc
 
