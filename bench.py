@@ -366,7 +366,9 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
                 n_cam = len(ca["data_aug_conf"].get("cams", [0, 1, 2, 3])) if isinstance(ca["data_aug_conf"].get("cams"), (list, tuple)) else 4
                 per_call.append(4.0 * (n_cam * D * fhw + n_cam * C * fhw + C * nz * ny * nx))
             calls, mean_ms = timing["bev_pool"]
-            bts = sum(per_call) / len(per_call)
+            # bytes per LAUNCH: one camera agent per launch, or (round 6, heal_bev_pool_scatter_multi) every camera agent of the scene in one
+            launches_per_step = max(1, round(calls / max(a.steps, 1)))
+            bts = sum(per_call) / launches_per_step
             extra = {}
             if "bev_stem_block" in timing:
                 extra["consumer"] = {"kernel": "heal_bev_stem_block (first BasicBlock of the camera backbone reads the sparse map; "
@@ -375,7 +377,7 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
                 extra["dense_emit"] = {"kernel": "heal_bev_pool_emit (dense canvas for consumers that want it)",
                                        "launch_ms": round(timing["bev_pool_emit"][1], 5)}
             entries["k4"] = (calls * mean_ms, _entry(
-                "K4 heal_bev_pool_scatter, one camera agent per launch (ONE kernel, k_lss_scatter: lift + splat into the sparse "
+                f"K4 heal_bev_pool_scatter{'_multi' if launches_per_step < len(per_call) else ''}, {len(per_call) // launches_per_step} camera agent(s) per launch (ONE kernel, k_lss_scatter: lift + splat into the sparse "
                 "pixel-major BEV map; duration = the kernel's own begin/end stamps (hipExtLaunchKernelGGL events), mean over the "
                 "scene's camera agents; bytes = SURVEY 8d: logits + features read + the dense [C,ny,nx] map the operator stands for, "
                 "which is no longer written)",

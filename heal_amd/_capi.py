@@ -62,6 +62,7 @@ _SIGNATURES = {
     "heal_bev_pool_pm_workspace": (c_size_t, [c_int] * 5),
     "heal_bev_pool_pm": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "heal_bev_pool_scatter": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "heal_bev_pool_scatter_multi": (c_int, [c_int] + [c_void_p] * 16),
     "heal_bev_pool_emit": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "heal_bev_stem_block": (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "heal_pfn_train_blocks": (c_int, [c_int]),

@@ -24,6 +24,9 @@
 #include <string.h>
 #include "prims.h"
 #include "../../include/heal_amd.h"
+#ifdef HEAL_BUILD_EXPERIMENTAL
+#include "../../include/heal_amd_experimental.h"
+#endif
 
 int heal_canvas_from_map(const int* cell_map, const float* rows, int n_agents, int channels, int cells,
                          float* canvas, hipStream_t s);
@@ -399,30 +402,29 @@ struct LssLds {
 // The frustum of create_frustum (heter_encoders.py:110-123) is separable -- frustum[d][v][u] = (xs[u], ys[v], ds[d]) --
 // and is read as such (three short axes instead of D*fH*fW strided triples); the host wrapper verifies the property once
 // per frustum tensor and takes the sorted pipeline for anything else.
+// The block's work: column u of camera bn (channel slice zs of nz); `first` = the block that publishes the tag (one per problem).
 template <int NDT>
-__global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
-                                                          const float* __restrict__ frustum,
-                                                          const CamMats* __restrict__ cams, LssGeom g, LssPmWs ws,
-                                                          int cells_total, int dbg) {
+__device__ __forceinline__ void lss_scatter_body(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
+                                                 const float* __restrict__ frustum, const CamMats* __restrict__ cams,
+                                                 const LssGeom& g, const LssPmWs& ws, int cells_total, int dbg, int u, int bn, int zs,
+                                                 int nz, bool first) {
     constexpr int W = 4 * NDT, NTHR = 256 * NDT, MTOT = LSS_MT * NDT;
     extern __shared__ float4 smem4[];
     float* smem = reinterpret_cast<float*>(smem4);
-    // blockIdx.z: channel slice [c_lo, c_lo + Cb) of the column (gridDim.z slices): with two slices two half-size blocks share a
+    // zs: channel slice [c_lo, c_lo + Cb) of the column (nz slices): with two slices two half-size blocks share a
     // CU and run out of phase (loads of one under the atomics of the other) at the price of evaluating keys and softmax twice
-    const int Cb = g.C / gridDim.z, c_lo = blockIdx.z * Cb;
+    const int Cb = g.C / nz, c_lo = zs * Cb;
     const LssLds L(g.fH, Cb, NDT);
     float* xs = smem + L.xs;
     float* pk_p = smem + L.pk_p;
     uint32_t* pk_key = reinterpret_cast<uint32_t*>(smem + L.pk_key);
 
     const int HW = g.fH * g.fW;
-    const int u = blockIdx.x, bn = blockIdx.y;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int LD = L.LD, fH4 = L.fH4;
     const int gen = ws.state[0] + 1;         // tag of this call: >= 1, a zero-filled flag array matches nothing
-    const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    // HEAL_K4_DBG & 128: shader-clock stamps of block 0's first (softmax) and last (keys only) wave -> state[16..] (scripts/k4_stamps.py)
-    const bool stamp_on = (dbg & 128) && bid == 0 && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64);
+    // HEAL_K4_DBG & 128: shader-clock stamps of the first block's first (softmax) and last (keys only) wave -> state[16..] (scripts/k4_stamps.py)
+    const bool stamp_on = (dbg & 128) && first && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64);
     int* stamp_out = ws.state + 16 + (threadIdx.x == 0 ? 0 : 16);
     const unsigned long long stamp0 = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
 #define LSS_STAMP(i) do { if (stamp_on) { __builtin_amdgcn_s_waitcnt(0); stamp_out[i] = (int)(__builtin_amdgcn_s_memtime() - stamp0); } } while (0)
@@ -637,9 +639,46 @@ __global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restri
     LSS_STAMP(7);
     // Publish the tag for the consumer in state[1] -- a word nobody READS in this kernel (every block derives the tag from
     // state[0]); the consumer reads state[1] and writes it back to state[0], which nobody reads there.
-    if (bid == 0 && tid == 0) ws.state[1] = gen;
+    if (first && tid == 0) ws.state[1] = gen;
 #undef LSS_STAMP
 }
+
+template <int NDT>
+__global__ __launch_bounds__(256 * NDT) void k_lss_scatter(const float* __restrict__ head /*[BN, HW, CT]*/, int CT,
+                                                          const float* __restrict__ frustum,
+                                                          const CamMats* __restrict__ cams, LssGeom g, LssPmWs ws,
+                                                          int cells_total, int dbg) {
+    lss_scatter_body<NDT>(head, CT, frustum, cams, g, ws, cells_total, dbg, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z,
+                          blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+}
+
+// Round 6: the camera agents of ALL camera modalities of a scene in ONE launch (m2 and m4 of the heterogeneous scene have different image
+// sizes, heads, frustums and workspaces but the same kernel): a block finds its problem by its index range.  One launch ramp / tail
+// instead of one per modality, and the blocks of the second problem fill the CUs the first leaves idle (256 + 224 columns: one round of
+// two resident blocks per CU) -- the per-agent fraction of VERDICT r5 item 3a.
+#ifdef HEAL_BUILD_EXPERIMENTAL
+constexpr int LSS_MAX_PROBLEMS = 4;
+struct LssProblem {
+    const float* head; const float* frustum; const CamMats* cams;
+    LssGeom g; LssPmWs ws;
+    int CT, cells_total, blocks;              // blocks = columns x cameras of this problem
+};
+
+// TWO problems per launch, each with its own inlined copy of the body: the problem descriptors stay kernel ARGUMENTS read with scalar loads.
+// (A first version took an array of descriptors and selected one by the block's index: the compiler copied the selected struct into vector
+// registers and scratch -- 123 registers + 160 B of scratch against 85 + 0 -- and the launch took 46.7 us against 2 x 14 for two launches.)
+template <int NDT>
+__global__ __launch_bounds__(256 * NDT) void k_lss_scatter_pair(LssProblem p0, LssProblem p1, int dbg) {
+    const int b = blockIdx.x;
+    if (b < p0.blocks) {
+        lss_scatter_body<NDT>(p0.head, p0.CT, p0.frustum, p0.cams, p0.g, p0.ws, p0.cells_total, dbg, b % p0.g.fW, b / p0.g.fW, 0, 1, b == 0);
+    } else {
+        const int c = b - p0.blocks;
+        lss_scatter_body<NDT>(p1.head, p1.CT, p1.frustum, p1.cams, p1.g, p1.ws, p1.cells_total, dbg, c % p1.g.fW, c / p1.g.fW, 0, 1, c == 0);
+    }
+}
+
+#endif
 
 // Zero the rows that generation gen - 1 tagged in the half the call in flight does NOT use; `part` of `nparts` equal cell ranges
 // per block.  Called by the consumer kernels (every block, all threads; blockDim a multiple of 64).
@@ -1128,6 +1167,75 @@ extern "C" int heal_bev_pool_scatter(const float* head, int head_stride, const f
     HEAL_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef HEAL_BUILD_EXPERIMENTAL   // measured negative at the scene level (profiles/r06_k4_shared_launch.json): not in the shipped library
+extern "C" int heal_bev_pool_scatter_multi(int n_problems, const float* const* heads, const int32_t* head_strides,
+                                           const float* const* frustums, const float* const* cam_mats, const int32_t* n_agents,
+                                           const int32_t* n_cams, const int32_t* D, const int32_t* fH, const int32_t* fW,
+                                           const int32_t* channels, const float* dx_host, const float* bx_host,
+                                           const int32_t* nx_host, void* const* ws, const size_t* ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HEAL_REQUIRE(n_problems >= 1 && n_problems <= LSS_MAX_PROBLEMS, "bev_pool_scatter_multi: 1..%d problems per launch", LSS_MAX_PROBLEMS);
+    LssProblem pr[LSS_MAX_PROBLEMS];
+    size_t lds = 0;
+    const int n_dt = ceil_div(D[0], LSS_MT);
+    for (int i = 0; i < n_problems; ++i) {
+        HEAL_REQUIRE(n_agents[i] >= 1 && n_cams[i] >= 1 && D[i] >= 1 && fH[i] >= 1 && fW[i] >= 1, "bev_pool_pm: bad shape");
+        HEAL_REQUIRE(fH[i] <= 64 && D[i] <= 64 && D[i] % 4 == 0, "bev_pool_pm: fH, D <= 64 and D %% 4 == 0 (got %d, %d)", fH[i], D[i]);
+        HEAL_REQUIRE(ceil_div(D[i], LSS_MT) == n_dt, "bev_pool_scatter_multi: the problems of one launch must share ceil(D / 16)");
+        HEAL_REQUIRE(head_strides[i] >= channels[i] + D[i] && head_strides[i] % 4 == 0 && ((uintptr_t)heads[i] & 15) == 0,
+                     "bev_pool_pm: head rows must hold C + D floats, 16-B aligned (stride %d)", head_strides[i]);
+        HEAL_REQUIRE(((uintptr_t)ws[i] & 255) == 0, "bev_pool_pm: workspace must be 256-B aligned");
+        LssProblem& p = pr[i];
+        if (pm_geometry(n_agents[i], channels[i], dx_host + 3 * i, bx_host + 3 * i, nx_host + 3 * i, p.g, p.cells_total)) return 1;
+        p.g.n_agents = n_agents[i]; p.g.n_cams = n_cams[i]; p.g.D = D[i]; p.g.fH = fH[i]; p.g.fW = fW[i]; p.g.C = channels[i];
+        const size_t l = (size_t)LssLds(fH[i], channels[i], n_dt).total * sizeof(float);
+        HEAL_REQUIRE(l <= 150 * 1024, "bev_pool_pm: feature column of %zu B does not fit the LDS: use heal_bev_pool", l);
+        lds = l > lds ? l : lds;
+        Arena a(ws[i], ws_bytes[i]);
+        HEAL_REQUIRE(carve_pm(a, channels[i], p.cells_total, p.ws), "bev_pool_pm: workspace too small (%zu < %zu)", ws_bytes[i], a.off);
+        for (int j = 0; j < i; ++j) HEAL_REQUIRE(ws[j] != ws[i], "bev_pool_scatter_multi: every problem needs its own workspace");
+        p.head = heads[i]; p.frustum = frustums[i]; p.cams = reinterpret_cast<const CamMats*>(cam_mats[i]); p.CT = head_strides[i];
+        p.blocks = fW[i] * n_agents[i] * n_cams[i];
+    }
+    const int dbg = HEAL_DEBUG_ENV("HEAL_K4_DBG");
+#define HEAL_LSS_PAIR(NDT_, P0, P1)                                                                                               \
+    {                                                                                                                              \
+        static bool attr_set = false;                                                                                              \
+        if (!attr_set) {                                                                                                           \
+            HEAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lss_scatter_pair<NDT_>),                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                \
+            attr_set = true;                                                                                                       \
+        }                                                                                                                          \
+        HEAL_LAUNCH_EV(k_lss_scatter_pair<NDT_>, dim3((P0).blocks + (P1).blocks), dim3(256 * NDT_), lds, s, P0, P1, dbg);         \
+    }
+    for (int i = 0; i + 1 < n_problems; i += 2) {
+        switch (n_dt) {
+            case 1: HEAL_LSS_PAIR(1, pr[i], pr[i + 1]) break;
+            case 2: HEAL_LSS_PAIR(2, pr[i], pr[i + 1]) break;
+            case 3: HEAL_LSS_PAIR(3, pr[i], pr[i + 1]) break;
+            case 4: HEAL_LSS_PAIR(4, pr[i], pr[i + 1]) break;
+            default: HEAL_REQUIRE(false, "bev_pool_pm: D must be <= 64");
+        }
+    }
+#undef HEAL_LSS_PAIR
+    if (n_problems & 1) {                        // an odd one out: the single-problem kernel
+        const LssProblem& p = pr[n_problems - 1];
+        int rc = 1;
+        const size_t l1 = (size_t)LssLds(p.g.fH, p.g.C, n_dt).total * sizeof(float);
+        switch (n_dt) {
+            case 1: rc = launch_scatter<1>(p.head, p.CT, p.frustum, reinterpret_cast<const float*>(p.cams), p.g, p.ws, p.cells_total, l1, 1, dbg, s); break;
+            case 2: rc = launch_scatter<2>(p.head, p.CT, p.frustum, reinterpret_cast<const float*>(p.cams), p.g, p.ws, p.cells_total, l1, 1, dbg, s); break;
+            case 3: rc = launch_scatter<3>(p.head, p.CT, p.frustum, reinterpret_cast<const float*>(p.cams), p.g, p.ws, p.cells_total, l1, 1, dbg, s); break;
+            case 4: rc = launch_scatter<4>(p.head, p.CT, p.frustum, reinterpret_cast<const float*>(p.cams), p.g, p.ws, p.cells_total, l1, 1, dbg, s); break;
+        }
+        if (rc) return rc;
+    }
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+
+#endif
 
 extern "C" int heal_bev_pool_emit(int n_agents, int channels, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
                                   void* stream) {

@@ -335,12 +335,17 @@ __global__ __launch_bounds__(256) void k_vox_select_write(const float4* __restri
     if (!live || l >= P) return;
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
     if (best != HASH_EMPTY) {
-        // An index that is no point of this call can only come from a corrupted table (round 4: the runtime's memset node, see
-        // common.h fill_bytes).  It is recorded -- meta[8] = hits (never reset), meta[9..14] = index, row, count, segment, M, lane of
-        // the first -- instead of being dereferenced; scripts/ring_dbg.py prints the words.
+#ifdef HEAL_VOX_RECORDER
+        // DEBUG BUILDS ONLY (-DHEAL_VOX_RECORDER; scripts/ring_dbg.py zeroes and prints meta[8..14]): an index that is no point of this call can
+        // only come from a corrupted table (round 4: the runtime's memset node, see common.h fill_bytes); it is recorded -- meta[8] = hits,
+        // meta[9..14] = index, row, count, segment, M, lane of the first -- instead of being dereferenced.  The production kernel has NO such
+        // guard (round 6): it would turn a memory fault into silently wrong voxels with no host-visible signal; the cause it was
+        // written for is removed by construction (no runtime memset / copy node anywhere in the library), and a corrupted table must fault loudly.
         if (best >= (uint32_t)n_pts) {
             if (atomicAdd(&meta[8], 1) == 0) { meta[9] = (int)best; meta[10] = row; meta[11] = cnt; meta[12] = st; meta[13] = M; meta[14] = l; }
-        } else val = pts[best];
+        } else
+#endif
+        val = pts[best];
     }
     const int base = meta[1];
     voxels[(size_t)(base + row) * P + l] = val;

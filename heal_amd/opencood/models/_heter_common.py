@@ -131,24 +131,85 @@ def encode_modalities(model, data_dict, present, encode):
     and only its OUTPUT crosses to the caller's stream after the join; every forward starts with the fork's wait, so a block
     the side stream reuses is never still read by the caller's previous work.  `HEAL_PARALLEL_MODALITIES=0` serialises."""
     import os
+    from heal_amd import ops
     mods = [m for m in model.modality_name_list if m in present]
     dev = next(model.parameters()).device
+    # Round 6: camera modalities whose lift + splat (K4) can share ONE launch: their encoders run up to the heads (forward_head ->
+    # PendingPool), then ops.bev_pool_pm_multi, then each modality's backbone / aligner (encode_modality_tail).  HEAL_K4_MULTI=0: off.
+    # MEASURED NEGATIVE at the scene level (profiles/r06_k4_shared_launch.json): the streams have to meet for the launch, and the extra
+    # branches stop the two frames in flight from overlapping (6.15 -> 7.4 ms per step) -- opt-in, and only in an experimental build.
+    two = (dev.type == "cuda" and not torch.is_grad_enabled() and os.environ.get("HEAL_K4_MULTI", "0") == "1" and ops.experimental_build()
+           and hasattr(model, "encode_modality_tail") and getattr(encode, "__func__", None) is getattr(model.encode_modality, "__func__", 0))
+    cams = [m for m in mods if two and hasattr(getattr(model, f"encoder_{m}"), "forward_head")]
+    if len(cams) < 2:
+        cams = []
+    pend = {}
+
+    def first_half(m):
+        if m in cams:
+            pend[m] = model.encode_modality_head(data_dict, m)
+            return None
+        return encode(data_dict, m)
+
+    def pool_all():
+        items = [pend[m] for m in cams]
+        deferred = [p for p in items if hasattr(p, "finish")]
+        pooled = iter(ops.bev_pool_pm_multi([p.args for p in deferred]) if len(deferred) >= 2 else [p.finish() for p in deferred])
+        return [next(pooled) if hasattr(p, "finish") else p for p in items]
+
     if (len(mods) < 2 or dev.type != "cuda" or os.environ.get("HEAL_PARALLEL_MODALITIES", "1") != "1"
             or torch.is_grad_enabled()):   # (a gradient path stays on one stream)
-        return {m: encode(data_dict, m) for m in mods}
+        feats = {m: first_half(m) for m in mods}
+        if cams:
+            for m, r in zip(cams, pool_all()):
+                feats[m] = model.encode_modality_tail(m, r)
+        return feats
     main = torch.cuda.current_stream(dev)
     streams = model.__dict__.setdefault("_heal_side_streams", {})
     feats = {}
     # side streams per CALLER stream: two captured copies of the step that run concurrently (pipeline.FramesInFlight) must
     # not share them -- the operators' scratch buffers are per stream
+    st = {mods[0]: main}
     for m in mods[1:]:
         s = streams.get((m, dev.index, main.cuda_stream))
         if s is None:
             s = streams[(m, dev.index, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+        st[m] = s
         s.wait_stream(main)
         with torch.cuda.stream(s):
-            feats[m] = encode(data_dict, m)
-    feats[mods[0]] = encode(data_dict, mods[0])       # the first modality stays on the caller's stream
+            feats[m] = first_half(m)
+    feats[mods[0]] = first_half(mods[0])       # the first modality stays on the caller's stream
+    if cams:
+        # the shared launch runs on its OWN stream once every camera head is there; the camera modalities' streams then wait for it and
+        # carry on with their backbones.  (A head tensor allocated on stream A and read on the pool stream is safe: A waits for the pool
+        # stream before it allocates again.  HEAL_K4_MULTI_TAIL=serial runs the tails on the pool stream instead, one after the other.)
+        key = ("k4pool", dev.index, main.cuda_stream)
+        P = streams.get(key)
+        if P is None:
+            P = streams[key] = torch.cuda.Stream(device=dev)
+        for m in cams:
+            P.wait_stream(st[m])
+        with torch.cuda.stream(P):
+            results = pool_all()
+        # The tails run on FRESH streams forked from the pool stream (the first on the pool stream itself), never on the head streams: a
+        # stream that another capturing stream has already waited for and that then waits back and carries on made hipStreamEndCapture
+        # segfault (ROCm 7.2; eager execution was fine) -- measured with the tails on the head streams and on the pool stream.
+        tails = []
+        for k, (m, r) in enumerate(zip(cams, results)):
+            if k == 0:
+                T = P
+            else:
+                tk = ("k4tail", m, dev.index, main.cuda_stream)
+                T = streams.get(tk)
+                if T is None:
+                    T = streams[tk] = torch.cuda.Stream(device=dev)
+                T.wait_stream(P)
+                tails.append(T)
+            with torch.cuda.stream(T):
+                feats[m] = model.encode_modality_tail(m, r)
+        for T in tails:
+            main.wait_stream(T)
+        main.wait_stream(P)
     for m in mods[1:]:
-        main.wait_stream(streams[(m, dev.index, main.cuda_stream)])
+        main.wait_stream(st[m])
     return {m: feats[m] for m in mods}

@@ -185,6 +185,17 @@ class _LiftPool(torch.autograd.Function):
         return g_logit, g_feat, None, None, None, None, None, None, None
 
 
+class PendingPool:
+    """What LiftSplatShoot.forward_head hands back instead of the pooled map: the arguments of ops.bev_pool_pm, so that the lift + splat
+    of SEVERAL camera modalities can go into one launch (ops.bev_pool_pm_multi; _heter_common.encode_modalities)."""
+
+    def __init__(self, **args):
+        self.args = args
+
+    def finish(self):
+        return ops.bev_pool_pm(**self.args)
+
+
 class LiftSplatShoot(nn.Module):
     """Camera agents: image trunk -> (depth logits, image features) -> fused lift + BEV pool (K4).
 
@@ -247,10 +258,15 @@ class LiftSplatShoot(nn.Module):
         return ops.bev_pool(depth_logit, x_img, self.frustum(x_img.device), cam_mats, B, N, self.dx_host,
                             self.bx_host, self.nx_host)
 
-    def pool_pixel_major(self, head, cam_mats, B, N, fH, fW):
+    def pool_pixel_major(self, head, cam_mats, B, N, fH, fW, defer=False):
         pooled = self.emit_pooled and self.nx_host[2] == 1 and os.environ.get("HEAL_K4_POOLED", "1") == "1"
-        return ops.bev_pool_pm(head, self.camC, self.D, fH, fW, self.frustum(head.device), cam_mats, B, N, self.dx_host,
-                               self.bx_host, self.nx_host, pooled=pooled)
+        pend = PendingPool(head=head, C=self.camC, D=self.D, fH=fH, fW=fW, frustum=self.frustum(head.device), cam_mats=cam_mats,
+                           n_agents=B, n_cams=N, dx=self.dx_host, bx=self.bx_host, nx=self.nx_host, pooled=pooled)
+        return pend if defer else pend.finish()
+
+    def forward_head(self, data_dict, modality_name):
+        """forward() up to the lift + splat: -> PendingPool (inference on the fused pixel-major path), else forward()'s result."""
+        return self.forward(data_dict, modality_name, defer_pool=True)
 
     def lift_pool_autograd(self, depth_logit, x_img, inp, B, N):
         """Gradient path of get_geometry + voxel_pooling (heter_encoders.py:125-217) with torch operators: ego coordinates of
@@ -276,7 +292,7 @@ class LiftSplatShoot(nn.Module):
         out = lifted.new_zeros((B * nz * ny * nx, C)).index_add(0, flat[ok], lifted[ok])
         return out.view(B, nz, ny, nx, C).permute(0, 1, 4, 2, 3).reshape(B, nz * C, ny, nx)
 
-    def forward(self, data_dict, modality_name):
+    def forward(self, data_dict, modality_name, defer_pool=False):
         inp = data_dict[f"inputs_{modality_name}"]
         x = inp["imgs"]
         B, N, C, imH, imW = x.shape
@@ -303,7 +319,7 @@ class LiftSplatShoot(nn.Module):
             # feature-map size from the trunk's own output: the trunks round UP (7x7 s2 p3, max-pool p1, TF-same padding), so
             # an image size not divisible by the downsample factor is not imH // downsample
             fH, fW = self.camencode.last_feature_hw
-            return self.pool_pixel_major(res[1], cam, B, N, fH, fW)
+            return self.pool_pixel_major(res[1], cam, B, N, fH, fW, defer=defer_pool)
         return self.pool(res[1].contiguous(), res[2].contiguous(), cam, B, N)
 
 

@@ -52,7 +52,14 @@ class HeterPyramidCollab(nn.Module):
 
     def encode_modality(self, data_dict, m):
         """encoder -> light backbone -> aligner (-> camera pad) for all agents of modality m."""
-        feature = getattr(self, f"encoder_{m}")(data_dict, m)
+        return self.encode_modality_tail(m, getattr(self, f"encoder_{m}")(data_dict, m))
+
+    # the same in two halves, so that the lift + splat of several camera modalities can share one launch (encode_modalities)
+    def encode_modality_head(self, data_dict, m):
+        enc = getattr(self, f"encoder_{m}")
+        return enc.forward_head(data_dict, m) if hasattr(enc, "forward_head") else enc(data_dict, m)
+
+    def encode_modality_tail(self, m, feature):
         feature = getattr(self, f"backbone_{m}")({"spatial_features": feature})["spatial_features_2d"]
         return crop_camera_feature(self, m, getattr(self, f"aligner_{m}")(feature))
 

@@ -991,6 +991,54 @@ def bev_pool_pm(head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx,
     return handle if pooled else handle.dense()
 
 
+def bev_pool_pm_multi(problems):
+    """K4 for several independent problems in ONE launch (heal_bev_pool_scatter_multi): the camera agents of every camera modality of a
+    scene.  problems: list of dicts with the arguments of bev_pool_pm (head, C, D, fH, fW, frustum, cam_mats, n_agents, n_cams, dx, bx,
+    nx, pooled) -> list of PooledBEV | dense tensors in the same order."""
+    if len(problems) == 1:
+        return [bev_pool_pm(**problems[0])]
+    dev = problems[0]["head"].device
+    keep, wss, nbytes_alg = [], [], 0.0
+    for i, q in enumerate(problems):
+        head = _need(q["head"], torch.float32, "head")
+        fr = _need(q["frustum"], torch.float32, "frustum")
+        cm = _need(q["cam_mats"], torch.float32, "cam_mats")
+        BN, HW, CT = (int(v) for v in head.shape)
+        C, D, fH, fW = int(q["C"]), int(q["D"]), int(q["fH"]), int(q["fW"])
+        if (BN != q["n_agents"] * q["n_cams"] or HW != fH * fW or CT < C + D or tuple(fr.shape) != (D, fH, fW, 3)
+                or tuple(cm.shape) != (BN, 27)):
+            raise _capi.HealAmdError("bev_pool_pm_multi: inconsistent shapes")
+        if not bev_pool_pm_supported(D, fH, C) or not _frustum_separable(fr):
+            raise _capi.HealAmdError("bev_pool_pm_multi: shape / frustum outside the fused path")
+        nxi = [int(v) for v in q["nx"]]
+        nb = _capi.query("heal_bev_pool_pm_workspace", int(q["n_agents"]), C, nxi[0], nxi[1], nxi[2])
+        # one scratch per problem SLOT and shape: two problems of equal shape in one launch must not share rows / flags
+        wss.append(_workspace_zeroed(("bev_pool_pm", i, int(q["n_agents"]), C, nxi[0], nxi[1], nxi[2]), nb, dev))
+        keep.append((head, fr, cm, CT, nxi))
+        nbytes_alg += 4.0 * (BN * HW * (C + D)) + 4.0 * q["n_agents"] * C * nxi[0] * nxi[1] * nxi[2]
+    n = len(problems)
+    PP = ctypes.c_void_p * n
+    I32 = ctypes.c_int32 * n
+    arr = lambda vals: I32(*[int(v) for v in vals])
+    f3 = lambda key: (ctypes.c_float * (3 * n))(*[float(v) for q in problems for v in q[key]])
+    with _Timed("bev_pool", nbytes=nbytes_alg, kernel_events=True):
+        _capi.call("heal_bev_pool_scatter_multi", n,
+                   ctypes.cast(PP(*[k[0].data_ptr() for k in keep]), ctypes.c_void_p), ctypes.cast(arr(k[3] for k in keep), ctypes.c_void_p),
+                   ctypes.cast(PP(*[k[1].data_ptr() for k in keep]), ctypes.c_void_p), ctypes.cast(PP(*[k[2].data_ptr() for k in keep]), ctypes.c_void_p),
+                   ctypes.cast(arr(q["n_agents"] for q in problems), ctypes.c_void_p), ctypes.cast(arr(q["n_cams"] for q in problems), ctypes.c_void_p),
+                   ctypes.cast(arr(q["D"] for q in problems), ctypes.c_void_p), ctypes.cast(arr(q["fH"] for q in problems), ctypes.c_void_p),
+                   ctypes.cast(arr(q["fW"] for q in problems), ctypes.c_void_p), ctypes.cast(arr(q["C"] for q in problems), ctypes.c_void_p),
+                   ctypes.cast(f3("dx"), ctypes.c_void_p), ctypes.cast(f3("bx"), ctypes.c_void_p),
+                   ctypes.cast((ctypes.c_int32 * (3 * n))(*[v for k in keep for v in k[4]]), ctypes.c_void_p),
+                   ctypes.cast(PP(*[w.data_ptr() for w in wss]), ctypes.c_void_p),
+                   ctypes.cast((ctypes.c_size_t * n)(*[w.numel() for w in wss]), ctypes.c_void_p), _stream())
+    out = []
+    for q, w, k in zip(problems, wss, keep):
+        h = PooledBEV(w, q["n_agents"], q["C"], k[4])
+        out.append(h if q.get("pooled") else h.dense())
+    return out
+
+
 def bev_pool(depth_logit, feat, frustum, cam_mats, n_agents, n_cams, dx, bx, nx):
     """K4 on the reference's NCHW tensors.  depth_logit [n_agents*n_cams,D,fH,fW], feat [n_agents*n_cams,C,fH,fW], frustum
     [D,fH,fW,3] (f32 cuda); cam_mats: f32 cuda [n_agents*n_cams,27] (combine 9, inv(post_rots) 9, post_trans 3,

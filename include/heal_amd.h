@@ -272,6 +272,7 @@ size_t heal_bev_pool_pm_workspace(int n_agents, int channels, int nx, int ny, in
 int heal_bev_pool_scatter(const float* head, int head_stride, const float* frustum, const float* cam_mats, int n_agents,
                           int n_cams, int D, int fH, int fW, int channels, const float* dx_host, const float* bx_host,
                           const int32_t* nx_host, void* ws, size_t ws_bytes, void* stream);
+
 int heal_bev_pool_emit(int n_agents, int channels, const int32_t* nx_host, float* out, void* ws, size_t ws_bytes,
                        void* stream);
 int heal_bev_stem_block(int n_agents, int channels, const int32_t* nx_host, const float* w_main, const float* b_main,

@@ -53,6 +53,15 @@ int heal_conv3x3_winograd4(const float* x, const float* u_frag, const float* bia
                            int cout, int H, int W, int relu, float* y, void* stream);
 
 
+/* heal_bev_pool_scatter_multi (round 6): heal_bev_pool_scatter for up to 4 independent problems in ONE launch (measured: the launch reaches 0.41 of the HBM roof, the stream join it needs costs the step 1.2 ms: profiles/r06_k4_shared_launch.json) -- the camera agents of every
+ *   camera modality of a scene (different heads, image sizes, frustums, workspaces; the same ceil(D / 16)).  Arrays of n_problems entries;
+ *   dx_host / bx_host / nx_host hold 3 values per problem; every problem has its own workspace (heal_bev_pool_pm_workspace) and its own
+ *   consumer (heal_bev_stem_block / heal_bev_pool_emit) afterwards.  Same arithmetic per problem as the single launch.                  */
+int heal_bev_pool_scatter_multi(int n_problems, const float* const* heads, const int32_t* head_strides, const float* const* frustums,
+                                const float* const* cam_mats, const int32_t* n_agents, const int32_t* n_cams, const int32_t* D,
+                                const int32_t* fH, const int32_t* fW, const int32_t* channels, const float* dx_host,
+                                const float* bx_host, const int32_t* nx_host, void* const* ws, const size_t* ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

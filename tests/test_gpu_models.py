@@ -346,6 +346,41 @@ def test_round6_work_skipping_paths_equal_the_plain_walk(mods, monkeypatch):
         assert float((a - b).abs().max() / a.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("parallel", ["1", "0"])
+def test_shared_k4_launch_equals_one_launch_per_modality(parallel, monkeypatch):
+    """Round 6: the lift + splat of the camera modalities m2 and m4 in ONE launch (heal_bev_pool_scatter_multi; the encoders stop at the
+    heads, the modalities' streams meet for the launch and part again) against one launch per modality (HEAL_K4_MULTI=0), with the
+    modality stems on concurrent streams and serially: the heads agree to the lift's atomics tolerance, eagerly and replayed from a
+    captured graph on another frame."""
+    from heal_amd import configs, ops
+    from heal_amd.pipeline import Scene, ScenePipeline
+    if not ops.experimental_build():
+        pytest.skip("heal_bev_pool_scatter_multi is measured negative (profiles/r06_k4_shared_launch.json): HEAL_BUILD_EXPERIMENTAL=1 builds only")
+    mods = ["m1", "m2", "m4"]
+    monkeypatch.setenv("HEAL_PARALLEL_MODALITIES", parallel)
+    hypes = configs.heal_heter(("m1", "m2", "m4"), max_cav=5)
+    pipe = ScenePipeline(hypes, "cuda:0", seed=0)
+    scene, other = Scene(3, seed=21, device="cuda:0", modalities=mods), Scene(3, seed=22, device="cuda:0", modalities=mods)
+    outs = {}
+    for multi in ("0", "1"):
+        monkeypatch.setenv("HEAL_K4_MULTI", multi)
+        with torch.no_grad():
+            out = pipe.forward(scene)
+        outs[multi] = {k: out[k].clone() for k in ("cls_preds", "reg_preds", "dir_preds")}
+    for k, a in outs["0"].items():
+        assert float((a - outs["1"][k]).abs().max() / a.abs().max()) < 1e-5, k
+    side = torch.cuda.Stream()
+    with torch.no_grad(), torch.cuda.stream(side):
+        pipe.capture(scene, warmup=1)
+        pipe.replay(other)
+        gb, gs = pipe.replay(other)
+        eb, es = pipe.step(other)
+    torch.cuda.synchronize()
+    assert (gb is None) == (eb is None)
+    if eb is not None:
+        assert gb.shape == eb.shape and torch.allclose(gb, eb, atol=1e-3) and torch.allclose(gs, es, atol=1e-4)
+
+
 NATIVE_RANGE = [-96, -48, -3, 96, 48, 1]      # hypes_yaml/opv2v/Single/m1_pointpillar_pretrain.yaml:17 (tools/inference.py:34 widens it)
 
 
@@ -489,7 +524,7 @@ def _hetero_small_model_and_data(g):
 
 
 @pytest.mark.parametrize("pooled", [False, True])
-def test_heterogeneous_collab_matches_reference(golden, pooled):
+def test_heterogeneous_collab_matches_reference(golden, pooled, monkeypatch):
     """pooled = True is what the models run: K4 hands its sparse pixel-major map (ops.PooledBEV) to the first block of the camera
     backbone (heal_bev_stem_block) and the dense BEV canvas is never written; pooled = False keeps the dense hand-off so that the
     encoder's output can be compared with the reference's `voxel_pooling` tensor itself.
@@ -500,6 +535,9 @@ def test_heterogeneous_collab_matches_reference(golden, pooled):
     and the camera crop / crop-mask path against the reference, stage by stage."""
     g = golden("hetero_small")
     from heal_amd import ops
+    # the stage-by-stage taps below hook each ENCODER's output: one K4 launch per modality (the shared launch of the camera modalities,
+    # round 6, hands a PendingPool across instead; test_shared_k4_launch_equals_one_launch_per_modality covers it)
+    monkeypatch.setenv("HEAL_K4_MULTI", "0")
     model, data, agents = _hetero_small_model_and_data(g)
     taps = {}
     hooks = []
