@@ -22,12 +22,12 @@ _SIGNATURES = {
     "heal_last_error": (ctypes.c_char_p, []),
     "heal_fill_bytes": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "heal_next_launch_events": (c_int, [c_void_p, c_void_p]),
-    "heal_voxelize_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "heal_voxelize_workspace": (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong]),
     "heal_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "heal_voxelize_batch_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "heal_voxelize_batch_workspace": (c_size_t, [c_int, c_int, c_int, c_int, ctypes.c_longlong]),
     "heal_voxelize_batch": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "heal_mask_points": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "heal_pfn_scatter_workspace": (c_size_t, [c_int] * 5),
     "heal_pfn_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,

@@ -7,6 +7,10 @@
 // first appearance, none beyond max_voxels); a point is appended to its voxel while the voxel holds
 // fewer than max_points.
 //
+// Round 6: THREE kernels and no fill -- the per-cell table is one 16-B record {key, min point index, counter, segment}, SELF-CLEANING (the
+// last kernel resets every record it used, so a workspace that entered clean leaves clean: `tables_clean`), and the index-list fill is
+// folded into k_vox_assign (a point waits for its cell's segment start, which a tile at or below its own publishes).  The description
+// below is the round-4 chain these two changes start from.
 // GPU formulation (order-independent, so bit-identical to the sequential scan), ONE fill + FOUR kernels for any number of
 // agents (round 4; round 3: five; rounds 1-2 sorted (voxel id, point index) pairs with a 3-pass radix sort: 24 launches):
 //   0. one fill(0xFF) (a KERNEL, heal::fill_bytes -- not hipMemsetAsync, see common.h): hash keys | per-cell minimum point index | per-cell point counter | the tiles' publication words
@@ -79,15 +83,25 @@ __device__ __forceinline__ int vox_agent(const VoxBatch& vb, int i) {
 // 64-line sweeps: 35 us against 26 us for this form; the matching loop costs more than the same-address atomics it saves.)
 // DENSE (round 4, pillar grids): when agents x cells fits the table the cell IS the slot -- no key array, no probe, no CAS claim
 // (131 072 cells x 3 agents against 524 288 slots in scene 5); what follows only uses slots as ids, so the output is unchanged.
+// per-cell words, one ARRAY each: tkey = hash key (the cell; no array for the dense map), tmin = minimum point index, tcnt = point counter
+// (starts at 0xFFFFFFFF: the ticket of the first arrival is 0), tseg = start of the cell's segment in the index list (bit 31: the cell's voxel
+// was dropped by max_voxels); all-ones = free.  (Measured and dropped in round 6: ONE 16-B record per cell -- a point's atomicMin and atomicAdd
+// then hit the same line and SERIALISE at the memory side: k_voxb_insert 21.6 -> 32.7 us for the dense map, 27.3 for the hash grid.)
+constexpr uint32_t VOX_DROP_BIT = 0x80000000u;
+// meta words (ints): 0 rows written, 1 base row, 2 generation of the last finished chain, 3 generation of the chain in flight,
+// 4 generation of the last chain that dropped a voxel
+constexpr int VM_ROWS = 0, VM_BASE = 1, VM_GEN = 2, VM_GEN_NEXT = 3, VM_DROPGEN = 4;
+
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
-                                                    uint32_t cells, uint32_t* __restrict__ tkey,
-                                                    uint32_t* __restrict__ tmin, uint32_t* __restrict__ tcnt, uint32_t mask,
-                                                    int* __restrict__ slot_of, uint32_t* __restrict__ tick) {
+                                                    uint32_t cells, uint32_t* __restrict__ tkey, uint32_t* __restrict__ tmin,
+                                                    uint32_t* __restrict__ tcnt, uint32_t mask, int2* __restrict__ st,
+                                                    int* __restrict__ meta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) meta[VM_GEN_NEXT] = meta[VM_GEN] + 1;      // (nobody reads VM_GEN_NEXT in this kernel, nobody writes VM_GEN)
     if (i >= vb.pt_off[vb.B]) return;
     int cx, cy, cz;
-    if (!point_cell(pts[i], g, cx, cy, cz)) { slot_of[i] = -1; return; }
+    if (!point_cell(pts[i], g, cx, cy, cz)) { st[i] = make_int2(-1, 0); return; }
     const uint32_t cell = (uint32_t)vox_agent(vb, i) * cells +
                           (((uint32_t)cz * (uint32_t)g.grid[1] + (uint32_t)cy) * (uint32_t)g.grid[0] + (uint32_t)cx);
     // Scattered device-scope atomics run at a fixed rate (~27 G operations/s chip-wide): every one that a plain read can rule out is
@@ -107,20 +121,25 @@ __global__ __launch_bounds__(256) void k_voxb_insert(const float4* __restrict__ 
         }
     }
     if (tmin[slot] > (uint32_t)i) atomicMin(&tmin[slot], (uint32_t)i);   // (a stale value is >= the true one: skipping is safe)
-    tick[i] = atomicAdd(&tcnt[slot], 1u) + 1u;     // the counter starts at 0xFFFFFFFF: tickets 0, 1, ...; final value = points - 1
-    slot_of[i] = (int)slot;
+    const uint32_t tick = atomicAdd(&tcnt[slot], 1u) + 1u;     // the counter starts at 0xFFFFFFFF: tickets 0, 1, ...; final value = points - 1
+    st[i] = make_int2((int)slot, (int)tick);
 }
 
 // first-point flags of a tile: point j * 256 + t of tile `tile` (j = 0..3); bit j of the result
-__device__ __forceinline__ unsigned tile_flags(const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin, int tile,
-                                               int n) {
+// (also returns the points' slots / tickets and, for first points, their cells' point counts)
+__device__ __forceinline__ unsigned tile_flags(const int2* __restrict__ st, const uint32_t* __restrict__ tmin,
+                                               const uint32_t* __restrict__ tcnt, int tile, int n, int2 (&my)[4], int (&cnt)[4]) {
     unsigned f = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = tile * VOX_TILE + j * 256 + (int)threadIdx.x;
+        my[j] = make_int2(-1, 0);
+        cnt[j] = 0;
         if (i < n) {
-            const int s = slot_of[i];
-            if (s >= 0 && tmin[s] == (uint32_t)i) f |= 1u << j;
+            my[j] = st[i];
+            if (my[j].x >= 0) {
+                if (tmin[my[j].x] == (uint32_t)i) { f |= 1u << j; cnt[j] = (int)(tcnt[my[j].x] + 1u); }
+            }
         }
     }
     return f;
@@ -148,27 +167,30 @@ __device__ __forceinline__ unsigned long long vox_wait_pub(const unsigned long l
 }
 
 __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ pts, VoxBatch vb, VoxGrid g,
-                                                   const int* __restrict__ slot_of, const uint32_t* __restrict__ tmin,
-                                                   const uint32_t* __restrict__ tcnt, unsigned long long* __restrict__ tile_pub,
+                                                   const int2* __restrict__ st, const uint32_t* __restrict__ tmin,
+                                                   const uint32_t* __restrict__ tcnt, uint32_t* __restrict__ tseg,
+                                                   unsigned long long* __restrict__ tile_pub,
                                                    unsigned long long* __restrict__ part_pub,
                                                    int n_tiles, int max_voxels, const int* __restrict__ row_offset,
-                                                   uint32_t* __restrict__ tvid, int* __restrict__ tseg, int* __restrict__ row_seg,
-                                                   int* __restrict__ row_cnt, int* __restrict__ coords,
+                                                   uint32_t* __restrict__ tvid /* P > 64 only, else null */, int* __restrict__ row_seg,
+                                                   int* __restrict__ row_cnt, int* __restrict__ row_slot, int* __restrict__ coords,
                                                    int* __restrict__ offsets_out, int* __restrict__ n_voxels_out,
-                                                   int* __restrict__ row_offset_next, int* __restrict__ meta) {
+                                                   int* __restrict__ row_offset_next, int* __restrict__ meta,
+                                                   uint32_t* __restrict__ seg /* null: no index list (P > 64) */) {
     __shared__ int s_red[4], s_w[4][4], s_wc[4][4], s_vbase[VOX_MAX_BATCH + 1], s_obase[VOX_MAX_BATCH + 1], s_run[2];
     __shared__ int s_part[VOX_MAX_BATCH + 1], s_vsum[VOX_MAX_BATCH + 1];
     const int n = vb.pt_off[vb.B], tile = blockIdx.x, t = threadIdx.x;
-    const unsigned f = tile_flags(slot_of, tmin, tile, n);
+    int2 my[4];
+    int cnt[4];
+    const unsigned f = tile_flags(st, tmin, tcnt, tile, n, my, cnt);
     const int wave = t >> 6;
     const unsigned long long lt = lanemask_lt();
-    int before[4], cnt[4], cbefore[4];     // first points (and their cells' points) of this wave that precede point (j, t)
+    int before[4], cbefore[4];     // first points (and their cells' points) of this wave that precede point (j, t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool first = (f >> j) & 1u;
         const unsigned long long bal = __ballot(first);
         before[j] = __popcll(bal & lt);
-        cnt[j] = first ? (int)(tcnt[slot_of[tile * VOX_TILE + j * 256 + t]] + 1u) : 0;
         const int incl = wave_incl_scan(cnt[j]);
         cbefore[j] = incl - cnt[j];
         if ((t & 63) == 0) s_w[j][wave] = __popcll(bal);
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ p
         }
         if (last_tile) {
             const int base = row_offset ? *row_offset : 0;
-            meta[0] = acc; meta[1] = base;
+            meta[VM_ROWS] = acc; meta[VM_BASE] = base;
             if (offsets_out) for (int b = 0; b <= vb.B; ++b) offsets_out[b] = s_obase[b];
             if (n_voxels_out) *n_voxels_out = acc;
             if (row_offset_next) *row_offset_next = base + acc;
@@ -261,29 +283,73 @@ __global__ __launch_bounds__(256) void k_vox_assign(const float4* __restrict__ p
         const int i = tile * VOX_TILE + j * 256 + t;
         const int a = vox_agent(vb, i);
         const int vl = r - s_vbase[a];                 // first-appearance rank inside the agent
-        const int s = slot_of[i];
-        tseg[s] = sg;
+        const int s = my[j].x;
+        uint32_t segw = (uint32_t)sg;
         if (vl < max_voxels) {
             const int row = s_obase[a] + vl;           // row in this call's outputs (the caller's base row is added on write)
-            tvid[s] = (uint32_t)row;
+            if (tvid) tvid[s] = (uint32_t)row;
             row_seg[row] = sg;
             row_cnt[row] = cnt[j];
+            row_slot[row] = s;
             int cx, cy, cz;
             point_cell(pts[i], g, cx, cy, cz);
             reinterpret_cast<int4*>(coords)[base + row] = make_int4(vb.label0 + a, cz, cy, cx);
         } else {
-            tvid[s] = VOX_DROPPED;                     // voxels past max_voxels are dropped
+            if (tvid) tvid[s] = VOX_DROPPED;           // voxels past max_voxels are dropped
+            segw |= VOX_DROP_BIT;
+            meta[VM_DROPGEN] = meta[VM_GEN_NEXT];      // (every writer stores the same value; read by the last kernel of the chain)
         }
+        // publish the segment start: every point of the cell is waiting for it (below, in this or a later tile)
+        __hip_atomic_store(&tseg[s], segw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!seg) return;
+    // ---- index list (round 6: was its own launch): the points of a cell occupy [segment, segment + count) in ticket order.  A point's
+    // cell is ranked by the cell's FIRST point, which lies in this tile or in a lower one -- tiles are dispatched in index order and a
+    // tile publishes its segments without waiting for anybody above it, so the wait always ends.
+    __syncthreads();                                   // the segments this tile itself published: visible before its own points look
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (my[j].x < 0) continue;
+        uint32_t w;
+        do { w = __hip_atomic_load(&tseg[my[j].x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (w == 0xFFFFFFFFu);
+        if (!(w & VOX_DROP_BIT)) seg[w + (uint32_t)my[j].y] = (uint32_t)(tile * VOX_TILE + j * 256 + t);
     }
 }
 
-// 4. index list: the points of a cell occupy [tseg[slot], tseg[slot] + count) in ticket order
-__global__ __launch_bounds__(256) void k_vox_fill(const int* __restrict__ slot_of, const uint32_t* __restrict__ tick,
-                                                 const int* __restrict__ tseg, int n, uint32_t* __restrict__ seg) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int s = slot_of[i];
-    if (s >= 0) seg[tseg[s] + (int)tick[i]] = (uint32_t)i;
+// Table hygiene, by the LAST kernel of a chain: every record the call used goes back to all-ones (rows: through row_slot; dropped cells,
+// which have no row: their first point finds them, only on calls that dropped one), the tiles' publication words too.  All threads of
+// the grid call it with their global index.
+struct VoxTab { uint32_t *tkey /* null: dense map */, *tmin, *tcnt, *tseg; };
+
+__device__ __forceinline__ void vox_free_slot(const VoxTab& tb, int s) {
+    if (tb.tkey) tb.tkey[s] = 0xFFFFFFFFu;
+    tb.tmin[s] = 0xFFFFFFFFu; tb.tcnt[s] = 0xFFFFFFFFu; tb.tseg[s] = 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ void vox_clean(long long gid, long long gsize, VoxTab tb, const int2* __restrict__ st,
+                                          const int* __restrict__ row_slot, unsigned long long* __restrict__ tile_pub,
+                                          unsigned long long* __restrict__ part_pub, int n_tiles, int n, int* __restrict__ meta) {
+    const int M = meta[VM_ROWS], gen = meta[VM_GEN_NEXT];
+    for (long long r = gid; r < M; r += gsize) vox_free_slot(tb, row_slot[r]);
+    for (long long q = gid; q < n_tiles + 1 + VOX_MAX_BATCH + 1; q += gsize) {
+        if (q <= n_tiles) tile_pub[q] = ~0ull;
+        else part_pub[q - n_tiles - 1] = ~0ull;
+    }
+    if (meta[VM_DROPGEN] == gen) {
+        for (long long i = gid; i < n; i += gsize) {
+            const int s = st[i].x;
+            if (s < 0) continue;
+            const uint32_t sg = tb.tseg[s];
+            if (tb.tmin[s] == (uint32_t)i && (sg & VOX_DROP_BIT) && sg != 0xFFFFFFFFu) vox_free_slot(tb, s);
+        }
+    }
+    if (gid == 0) meta[VM_GEN] = gen;                  // (read by the NEXT chain's first kernel only)
+}
+
+__global__ __launch_bounds__(256) void k_vox_clean(VoxTab tb, const int2* __restrict__ st, const int* __restrict__ row_slot,
+                                                  unsigned long long* __restrict__ tile_pub, unsigned long long* __restrict__ part_pub,
+                                                  int n_tiles, int n, int* __restrict__ meta) {
+    vox_clean((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, tb, st, row_slot, tile_pub, part_pub, n_tiles, n, meta);
 }
 
 // bitonic network over the G lanes of a group (G a power of two <= 64, groups aligned in the wave): ascending
@@ -315,9 +381,14 @@ template <int G>
 __global__ __launch_bounds__(256) void k_vox_select_write(const float4* __restrict__ pts, const uint32_t* __restrict__ seg,
                                                          const int* __restrict__ row_seg, const int* __restrict__ row_cnt,
                                                          int* __restrict__ meta, int P, float4* __restrict__ voxels,
-                                                         int* __restrict__ num_points, int n_pts) {
+                                                         int* __restrict__ num_points, int n_pts, VoxTab tb,
+                                                         const int2* __restrict__ slot_tick, const int* __restrict__ row_slot,
+                                                         unsigned long long* __restrict__ tile_pub,
+                                                         unsigned long long* __restrict__ part_pub, int n_tiles) {
+    // table hygiene first (nothing below reads the records): this is the chain's last kernel
+    vox_clean((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, tb, slot_tick, row_slot, tile_pub, part_pub, n_tiles, n_pts, meta);
     const int row = blockIdx.x * (256 / G) + (int)threadIdx.x / G, l = (int)threadIdx.x & (G - 1);
-    const int M = meta[0];
+    const int M = meta[VM_ROWS];
     if ((int)blockIdx.x * (256 / G) >= M) return;     // block-uniform: the grid is sized by capacity
     // (a group past the last row idles through the shuffles with an empty segment: whole waves take the same path)
     const bool live = row < M;
@@ -347,17 +418,17 @@ __global__ __launch_bounds__(256) void k_vox_select_write(const float4* __restri
 #endif
         val = pts[best];
     }
-    const int base = meta[1];
+    const int base = meta[VM_BASE];
     voxels[(size_t)(base + row) * P + l] = val;
     if (l == 0) num_points[base + row] = min(cnt, P);
 }
 
 // 4'. (max_points > 64) candidate slots: cand[row][0..P) ascending, 0xFFFFFFFF = empty
-__global__ __launch_bounds__(256) void k_vox_candidates(const int* __restrict__ slot_of, const uint32_t* __restrict__ tvid,
+__global__ __launch_bounds__(256) void k_vox_candidates(const int2* __restrict__ st, const uint32_t* __restrict__ tvid,
                                                        int n, int P, uint32_t* __restrict__ cand) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int s = slot_of[i];
+    const int s = st[i].x;
     if (s < 0) return;
     const uint32_t row = tvid[s];
     if (row == VOX_DROPPED) return;
@@ -380,8 +451,8 @@ __global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pt
                                                   int* __restrict__ num_points) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(e / P), p = (int)(e - (long long)row * P);
-    if (row >= meta[0]) return;
-    const int base = meta[1];
+    if (row >= meta[VM_ROWS]) return;
+    const int base = meta[VM_BASE];
     const uint32_t idx = cand[e];
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx != HASH_EMPTY) val = pts[idx];
@@ -394,11 +465,13 @@ __global__ __launch_bounds__(256) void k_vox_write(const float4* __restrict__ pt
 }
 
 struct VoxWs {
-    uint32_t *tkey, *tmin, *tcnt, *cand, *tvid, *tick, *seg;
-    int *slot_of, *tseg, *row_seg, *row_cnt, *meta;
-    unsigned long long *tile_pub, *part_pub;   // published tile sums / agent-boundary partial counts (inside the 0xFF region: unpublished)
+    uint32_t *tkey, *tmin, *tcnt, *tseg;         // [tcap] per-cell words (tkey: hash grid only)
+    uint32_t *cand, *tvid, *seg;
+    int2* st;                                    // [n] (slot, ticket) of every point
+    int *row_seg, *row_cnt, *row_slot, *meta;
+    unsigned long long *tile_pub, *part_pub;     // published tile sums / agent-boundary partial counts (all-ones: unpublished)
     uint32_t tcap;
-    size_t ff_bytes;     // tkey | tmin | tcnt (| cand): initialised by one fill(0xFF)
+    size_t clean_bytes;     // tmin | tcnt | tseg | tkey | tile_pub | part_pub: all-ones between calls (self-cleaning); meta follows (zero-initialised)
 };
 
 static uint32_t table_cap(int n) {
@@ -407,30 +480,42 @@ static uint32_t table_cap(int n) {
     return c;
 }
 
-static bool carve(Arena& a, int n, int cap, int P, VoxWs& w) {
-    w.tcap = table_cap(n);
-    w.tkey = a.take<uint32_t>(w.tcap);
+// Table slots: pillar grids whose agents x cells stay below 2^21 use the CELL as the slot (no key, no probe, no CAS): with the self-cleaning
+// records a large sparse table costs nothing per call (nothing is filled, only used records are reset), so the table is simply made as
+// large as the grid -- 786 432 cells for three agents at 512 x 512, 12.6 MB -- instead of 2 n hash slots; anything bigger hashes.
+constexpr long long VOX_DENSE_MAX = 1ll << 21;
+static bool table_dense(long long agents_x_cells) {
+    static const bool dense_ok = [] { const char* e = getenv("HEAL_VOX_DENSE"); return !(e && e[0] == '0'); }();
+    return dense_ok && agents_x_cells > 0 && agents_x_cells <= VOX_DENSE_MAX;
+}
+static uint32_t table_slots(int n, long long agents_x_cells) {
+    return table_dense(agents_x_cells) ? (uint32_t)agents_x_cells : table_cap(n);
+}
+
+static bool carve(Arena& a, int n, int cap, int P, long long agents_x_cells, VoxWs& w) {
+    w.tcap = table_slots(n, agents_x_cells);
     w.tmin = a.take<uint32_t>(w.tcap);
     w.tcnt = a.take<uint32_t>(w.tcap);
-    w.cand = a.take<uint32_t>(P > 64 ? (size_t)cap * P : 1);
+    w.tseg = a.take<uint32_t>(w.tcap);
+    w.tkey = a.take<uint32_t>(table_dense(agents_x_cells) ? 1 : w.tcap);
     w.tile_pub = a.take<unsigned long long>(ceil_div(n, VOX_TILE) + 1);
     w.part_pub = a.take<unsigned long long>(VOX_MAX_BATCH + 1);
-    w.tvid = a.take<uint32_t>(w.tcap);
-    w.ff_bytes = (size_t)((char*)w.tvid - (char*)w.tkey);
-    w.tseg = a.take<int>(w.tcap);
-    w.slot_of = a.take<int>(n);
-    w.tick = a.take<uint32_t>(n);
+    w.meta = a.take<int>(64);
+    w.clean_bytes = (size_t)((char*)w.meta - (char*)w.tmin);
+    w.cand = a.take<uint32_t>(P > 64 ? (size_t)cap * P : 1);
+    w.tvid = a.take<uint32_t>(P > 64 ? w.tcap : 1);
+    w.st = a.take<int2>(n);
     w.seg = a.take<uint32_t>(n);
     w.row_seg = a.take<int>(cap);
     w.row_cnt = a.take<int>(cap);
-    w.meta = a.take<int>(64);
+    w.row_slot = a.take<int>(cap);
     return a.ok();
 }
 
 // the whole chain; outputs as documented in include/heal_amd.h
 static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& g, uint32_t cells, int P, int max_voxels, int cap,
                           const int32_t* row_offset, float* voxels, int32_t* coords, int32_t* num_points, int32_t* offsets_out,
-                          int32_t* n_voxels_out, int32_t* row_offset_next, void* ws, size_t ws_bytes, hipStream_t s,
+                          int32_t* n_voxels_out, int32_t* row_offset_next, void* ws, size_t ws_bytes, int tables_clean, hipStream_t s,
                           const char* who) {
     const int n = vb.pt_off[vb.B];
     const int n_tiles = ceil_div(n, VOX_TILE);
@@ -438,24 +523,35 @@ static int voxelize_chain(const float4* pts, const VoxBatch& vb, const VoxGrid& 
     HEAL_REQUIRE(((uintptr_t)ws & 255) == 0, "%s: workspace must be 256-B aligned", who);
     Arena a(ws, ws_bytes);
     VoxWs w;
-    HEAL_REQUIRE(carve(a, n, cap, P, w), "%s: workspace too small (%zu < %zu)", who, ws_bytes, a.off);
+    // the cell map if the grid qualifies AND the caller sized the workspace for it (agents_x_cells of the size query), else the hash grid
+    long long axc = (long long)vb.B * cells;
+    if (table_dense(axc) && !carve(a, n, cap, P, axc, w)) { axc = 0; a = Arena(ws, ws_bytes); }
+    if (!table_dense(axc)) {
+        axc = 0;
+        HEAL_REQUIRE(carve(a, n, cap, P, 0, w), "%s: workspace too small (%zu < %zu)", who, ws_bytes, a.off);
+    }
     const int nb = ceil_div(n, 256);
-    HEAL_FILL(w.tkey, 0xFF, w.ff_bytes, s);
-    static const bool dense_ok = [] { const char* e = getenv("HEAL_VOX_DENSE"); return !(e && e[0] == '0'); }();
-    if (dense_ok && (unsigned long long)vb.B * cells <= (unsigned long long)w.tcap)
-        k_voxb_insert<true><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
+    if (!tables_clean) {       // a workspace of unknown contents: records / publication words all-ones, meta zero (one fill launch each)
+        HEAL_FILL(w.tmin, 0xFF, w.clean_bytes, s);
+        HEAL_FILL(w.meta, 0, 64 * sizeof(int), s);
+    }
+    if (table_dense(axc))
+        k_voxb_insert<true><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.st, w.meta);
     else
-        k_voxb_insert<false><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.slot_of, w.tick);
-    k_vox_assign<<<n_tiles, 256, 0, s>>>(pts, vb, g, w.slot_of, w.tmin, w.tcnt, w.tile_pub, w.part_pub, n_tiles,
-                                         max_voxels, row_offset, w.tvid, w.tseg, w.row_seg, w.row_cnt, coords, offsets_out,
-                                         n_voxels_out, row_offset_next, w.meta);
+        k_voxb_insert<false><<<nb, 256, 0, s>>>(pts, vb, g, cells, w.tkey, w.tmin, w.tcnt, w.tcap - 1, w.st, w.meta);
+    const VoxTab tb{table_dense(axc) ? nullptr : w.tkey, w.tmin, w.tcnt, w.tseg};
+    k_vox_assign<<<n_tiles, 256, 0, s>>>(pts, vb, g, w.st, w.tmin, w.tcnt, w.tseg, w.tile_pub, w.part_pub, n_tiles, max_voxels, row_offset,
+                                         P > 64 ? w.tvid : nullptr, w.row_seg, w.row_cnt, w.row_slot, coords, offsets_out, n_voxels_out,
+                                         row_offset_next, w.meta, P > 64 ? nullptr : w.seg);
     float4* vox4 = reinterpret_cast<float4*>(voxels);
     if (P > 64) {
-        k_vox_candidates<<<nb, 256, 0, s>>>(w.slot_of, w.tvid, n, P, w.cand);
+        HEAL_FILL(w.cand, 0xFF, (size_t)cap * P * sizeof(uint32_t), s);
+        k_vox_candidates<<<nb, 256, 0, s>>>(w.st, w.tvid, n, P, w.cand);
         k_vox_write<<<(unsigned)(((long long)cap * P + 255) / 256), 256, 0, s>>>(pts, w.cand, w.meta, P, vox4, num_points);
+        k_vox_clean<<<ceil_div(n, 256), 256, 0, s>>>(tb, w.st, w.row_slot, w.tile_pub, w.part_pub, n_tiles, n, w.meta);
     } else {
-        k_vox_fill<<<nb, 256, 0, s>>>(w.slot_of, w.tick, w.tseg, n, w.seg);
-#define HEAL_VSW(G_) k_vox_select_write<G_><<<ceil_div(cap, 256 / G_), 256, 0, s>>>(pts, w.seg, w.row_seg, w.row_cnt, w.meta, P, vox4, num_points, n)
+#define HEAL_VSW(G_) k_vox_select_write<G_><<<ceil_div(cap, 256 / G_), 256, 0, s>>>(pts, w.seg, w.row_seg, w.row_cnt, w.meta, P, vox4, num_points, n, \
+                                                                                  tb, w.st, w.row_slot, w.tile_pub, w.part_pub, n_tiles)
         if (P > 32) HEAL_VSW(64);
         else if (P > 16) HEAL_VSW(32);
         else if (P > 8) HEAL_VSW(16);
@@ -487,13 +583,13 @@ static bool vox_grid(const float* range_host, const float* voxel_size_host, VoxG
 
 using namespace heal;
 
-extern "C" size_t heal_voxelize_workspace(int n_points, int max_points, int max_voxels) {
+extern "C" size_t heal_voxelize_workspace(int n_points, int max_points, int max_voxels, long long agents_x_cells) {
     if (n_points < 1) n_points = 1;
     int cap = n_points < max_voxels ? n_points : max_voxels;
     if (cap < 1) cap = 1;
     Arena a(nullptr, 0);
     VoxWs w;
-    carve(a, n_points, cap, max_points < 1 ? 1 : max_points, w);
+    carve(a, n_points, cap, max_points < 1 ? 1 : max_points, agents_x_cells, w);
     return a.off + 256;
 }
 
@@ -542,7 +638,7 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
                              const float* voxel_size_host, int max_points, int max_voxels,
                              int batch_idx, float* voxels, int32_t* coords, int32_t* num_points,
                              int32_t* n_voxels, const int32_t* row_offset, int32_t* row_offset_next, void* ws,
-                             size_t ws_bytes, void* stream) {
+                             size_t ws_bytes, int tables_clean, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(n_points >= 0 && max_points >= 1 && max_voxels >= 1, "voxelize: bad sizes");
     HEAL_REQUIRE(n_voxels != nullptr, "voxelize: n_voxels is NULL");
@@ -563,10 +659,11 @@ extern "C" int heal_voxelize(const float* points, int n_points, const float* ran
     for (int b = 2; b <= VOX_MAX_BATCH; ++b) vb.pt_off[b] = n_points;
     const int cap = n_points < max_voxels ? n_points : max_voxels;
     return voxelize_chain(reinterpret_cast<const float4*>(points), vb, g, (uint32_t)cells, max_points, max_voxels, cap, row_offset,
-                          voxels, coords, num_points, nullptr, n_voxels, row_offset_next, ws, ws_bytes, s, "voxelize");
+                          voxels, coords, num_points, nullptr, n_voxels, row_offset_next, ws, ws_bytes, tables_clean, s, "voxelize");
 }
 
-extern "C" size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents, int max_points, int max_voxels) {
+extern "C" size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents, int max_points, int max_voxels,
+                                                long long agents_x_cells) {
     if (n_points_total < 1) n_points_total = 1;
     (void)n_agents;
     Arena a(nullptr, 0);
@@ -574,14 +671,14 @@ extern "C" size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents
     // rows: sum_b min(n_b, max_voxels) <= min(n_total, n_agents * max_voxels)
     long long cap = (long long)(n_agents < 1 ? 1 : n_agents) * (max_voxels < 1 ? 1 : max_voxels);
     if (cap > n_points_total) cap = n_points_total;
-    carve(a, n_points_total, (int)cap, max_points < 1 ? 1 : max_points, w);
+    carve(a, n_points_total, (int)cap, max_points < 1 ? 1 : max_points, agents_x_cells, w);
     return a.off + 256;
 }
 
 extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_offsets_host, int n_agents,
                                    const float* range_host, const float* voxel_size_host, int max_points,
                                    int max_voxels, float* voxels, int32_t* coords, int32_t* num_points,
-                                   int32_t* row_offsets, void* ws, size_t ws_bytes, void* stream) {
+                                   int32_t* row_offsets, void* ws, size_t ws_bytes, int tables_clean, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HEAL_REQUIRE(n_agents >= 1 && n_agents <= VOX_MAX_BATCH, "voxelize_batch: 1..%d agents per call", VOX_MAX_BATCH);
     HEAL_REQUIRE(max_points >= 1 && max_voxels >= 1 && row_offsets != nullptr, "voxelize_batch: bad arguments");
@@ -603,5 +700,5 @@ extern "C" int heal_voxelize_batch(const float* points, const int32_t* point_off
     int cap = 0;  // rows of the collated outputs: sum of min(n_b, max_voxels)
     for (int b = 0; b < n_agents; ++b) cap += (vb.pt_off[b + 1] - vb.pt_off[b]) < max_voxels ? (vb.pt_off[b + 1] - vb.pt_off[b]) : max_voxels;
     return voxelize_chain(reinterpret_cast<const float4*>(points), vb, g, (uint32_t)cells, max_points, max_voxels, cap, nullptr,
-                          voxels, coords, num_points, row_offsets, nullptr, nullptr, ws, ws_bytes, s, "voxelize_batch");
+                          voxels, coords, num_points, row_offsets, nullptr, nullptr, ws, ws_bytes, tables_clean, s, "voxelize_batch");
 }

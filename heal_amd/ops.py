@@ -222,6 +222,32 @@ def _host_array(values, ctype):
 
 
 # ------------------------------------------------------------------------------------------------
+# K1's per-cell table is self-cleaning (round 6): a workspace that a finished call left behind needs no fill.  One workspace per
+# (stream, layout) -- a call with other sizes carves the buffer differently -- and the set of buffers known to be clean.
+_VOX_CLEAN = set()
+
+
+def _vox_cells(lidar_range, voxel_size):
+    """Cells of the voxel grid, as the library counts them (round((max - min) / size) per axis in fp64)."""
+    c = 1
+    for j in range(3):
+        c *= int(round((float(np.float32(lidar_range[3 + j])) - float(np.float32(lidar_range[j]))) / float(np.float32(voxel_size[j]))))
+    return max(c, 0)
+
+
+def _vox_workspace(kind, nbytes, dev, layout):
+    ws = _workspace(("voxelize", kind) + tuple(layout), nbytes, dev)
+    return ws, (ws.data_ptr(), ws.numel(), kind) + tuple(layout)
+
+
+def _vox_call(name, key, *args):
+    """Call a voxelize entry point with tables_clean from the bookkeeping; any failure leaves the workspace 'unknown'."""
+    clean = key in _VOX_CLEAN
+    _VOX_CLEAN.discard(key)
+    _capi.call(name, *args[:-1], 1 if clean else 0, args[-1])
+    _VOX_CLEAN.add(key)
+
+
 def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=0, sync=True):
     """K1.  points [N,4] f32 cuda -> (voxels [M,P,4], coords [M,4] (b,z,y,x) i32, num_points [M] i32).
 
@@ -238,13 +264,14 @@ def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
-    nbytes = _capi.query("heal_voxelize_workspace", n, int(max_points), int(max_voxels))
-    ws = _workspace("voxelize", nbytes, dev)
+    cells = _vox_cells(lidar_range, voxel_size)
+    nbytes = _capi.query("heal_voxelize_workspace", n, int(max_points), int(max_voxels), cells)
+    ws, key = _vox_workspace("one", nbytes, dev, (n, int(max_points), int(max_voxels), cells))
     rng = _host_array([float(v) for v in lidar_range], ctypes.c_float)
     vs = _host_array([float(v) for v in voxel_size], ctypes.c_float)
     with _Timed("voxelize"):
-        _capi.call("heal_voxelize", _ptr(points), n, rng, vs, int(max_points), int(max_voxels), int(batch_idx),
-                   _ptr(voxels), _ptr(coords), _ptr(num), _ptr(count), None, None, _ptr(ws), ws.numel(), _stream())
+        _vox_call("heal_voxelize", key, _ptr(points), n, rng, vs, int(max_points), int(max_voxels), int(batch_idx),
+                  _ptr(voxels), _ptr(coords), _ptr(num), _ptr(count), None, None, _ptr(ws), ws.numel(), _stream())
     if not sync:
         return voxels, coords, num, count
     m = int(count.item())
@@ -291,23 +318,26 @@ def voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxel
         adjacent = all(p.is_contiguous() for p in pts) and all(
             pts[i].data_ptr() + pts[i].numel() * 4 == pts[i + 1].data_ptr() for i in range(len(pts) - 1))
         allp = pts[0] if (len(pts) == 1 or adjacent) else torch.cat(pts, 0)
-        nbytes = _capi.query("heal_voxelize_batch_workspace", bounds[-1], len(pts), int(max_points), int(max_voxels))
-        ws = _workspace("voxelize", nbytes, dev)
+        axc = len(pts) * _vox_cells(lidar_range, voxel_size)
+        nbytes = _capi.query("heal_voxelize_batch_workspace", bounds[-1], len(pts), int(max_points), int(max_voxels), axc)
+        # (the carve depends on the total point count, the row capacity = sum of min(n_b, max_voxels), max_points and the table kind)
+        ws, key = _vox_workspace("batch", nbytes, dev, (bounds[-1], cap, int(max_points), axc))
         with _Timed("voxelize"):
-            _capi.call("heal_voxelize_batch", _ptr(allp), _host_array(bounds, ctypes.c_int32), len(pts), rng, vs,
-                       int(max_points), int(max_voxels), _ptr(voxels), _ptr(coords), _ptr(num), _ptr(offsets), _ptr(ws),
-                       ws.numel(), _stream())
+            _vox_call("heal_voxelize_batch", key, _ptr(allp), _host_array(bounds, ctypes.c_int32), len(pts), rng, vs,
+                      int(max_points), int(max_voxels), _ptr(voxels), _ptr(coords), _ptr(num), _ptr(offsets), _ptr(ws),
+                      ws.numel(), _stream())
         _remember("voxelize", lambda: voxelize_collated(point_list, lidar_range, voxel_size, max_points, max_voxels))
         return voxels, coords, num, offsets
     counts = torch.zeros((len(pts),), dtype=torch.int32, device=dev)
     for b, p in enumerate(pts):
         n = int(p.shape[0])
-        nbytes = _capi.query("heal_voxelize_workspace", n, int(max_points), int(max_voxels))
-        ws = _workspace("voxelize", nbytes, dev)
+        cells = _vox_cells(lidar_range, voxel_size)
+        nbytes = _capi.query("heal_voxelize_workspace", n, int(max_points), int(max_voxels), cells)
+        ws, key = _vox_workspace("one", nbytes, dev, (n, int(max_points), int(max_voxels), cells))
         with _Timed("voxelize"):
-            _capi.call("heal_voxelize", _ptr(p), n, rng, vs, int(max_points), int(max_voxels), b, _ptr(voxels),
-                       _ptr(coords), _ptr(num), _ptr(counts[b:b + 1]), _ptr(offsets[b:b + 1]),
-                       _ptr(offsets[b + 1:b + 2]), _ptr(ws), ws.numel(), _stream())
+            _vox_call("heal_voxelize", key, _ptr(p), n, rng, vs, int(max_points), int(max_voxels), b, _ptr(voxels),
+                      _ptr(coords), _ptr(num), _ptr(counts[b:b + 1]), _ptr(offsets[b:b + 1]),
+                      _ptr(offsets[b + 1:b + 2]), _ptr(ws), ws.numel(), _stream())
     return voxels, coords, num, offsets
 
 

@@ -56,26 +56,32 @@ int heal_next_launch_events(void* start_event, void* stop_event);
  *   row_offset / row_offset_next  device i32 or NULL: collate_batch_list without a host round trip -- this agent's
  *               rows go to [*row_offset, *row_offset + M) of voxels/coords/num_points (buffers shared by the agents
  *               of a modality) and *row_offset_next <- *row_offset + M feeds the next agent's call.
+ *   ws / tables_clean  round 6: the per-cell table inside the workspace is SELF-CLEANING -- the chain's last kernel resets every record it
+ *               used -- so only the FIRST call on a workspace has to initialise it: tables_clean = 0 "contents unknown" (the call fills the
+ *               tables first: two more launches), 1 "the previous call on this workspace used the same (n_points, max_points, max_voxels)
+ *               and ran to completion" (no fill; three kernels).  A call with other sizes carves the workspace differently: pass 0 again.
  * -----------------------------------------------------------------------------------------------*/
-size_t heal_voxelize_workspace(int n_points, int max_points, int max_voxels);
+/* agents_x_cells (size queries): agents x grid cells of the call, or 0.  Grids of up to 2^21 cells in total (every PointPillars grid: 3 agents
+ *   at 512 x 512 = 786 432) then get a per-cell table instead of a hash grid -- no key, no probe; free per call because the table cleans itself. */
+size_t heal_voxelize_workspace(int n_points, int max_points, int max_voxels, long long agents_x_cells);
 int heal_voxelize(const float* points, int n_points,
                   const float* range_host, const float* voxel_size_host,
                   int max_points, int max_voxels, int batch_idx,
                   float* voxels, int32_t* coords, int32_t* num_points, int32_t* n_voxels,
                   const int32_t* row_offset, int32_t* row_offset_next,
-                  void* ws, size_t ws_bytes, void* stream);
+                  void* ws, size_t ws_bytes, int tables_clean, void* stream);
 
-/* heal_voxelize_batch: K1 for every agent of a modality in ONE launch chain (one memset + four kernels, as the single-cloud
+/* heal_voxelize_batch: K1 for every agent of a modality in ONE launch chain (three kernels on a clean workspace, as the single-cloud
  *   form; at most 4 M points per call): `points` holds the agents' clouds back to back, point_offsets_host [n_agents+1] (host)
  *   the boundaries.  Outputs are the collated buffers of collate_batch_list: rows of agent b at
  *   [row_offsets[b], row_offsets[b+1]) with coords (b,z,y,x); row_offsets [n_agents+1] i32 DEVICE.  Buffers need
  *   sum_b min(n_b, max_voxels) rows.  Same semantics per agent as heal_voxelize (first-come order, both caps).  <= 16
  *   agents per call.                                                                                              */
-size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents, int max_points, int max_voxels);
+size_t heal_voxelize_batch_workspace(int n_points_total, int n_agents, int max_points, int max_voxels, long long agents_x_cells);
 int heal_voxelize_batch(const float* points, const int32_t* point_offsets_host, int n_agents,
                         const float* range_host, const float* voxel_size_host, int max_points, int max_voxels,
                         float* voxels, int32_t* coords, int32_t* num_points, int32_t* row_offsets,
-                        void* ws, size_t ws_bytes, void* stream);
+                        void* ws, size_t ws_bytes, int tables_clean, void* stream);
 
 /* heal_mask_points: the point filters the dataset applies right before the voxeliser, on the device.
  * Replaces: opencood/utils/pcd_utils.py:41-67 (mask_points_by_range: strict > / < on x, y, z) and :70-88
