@@ -93,7 +93,9 @@ def test_points_fast_path_equals_voxel_input(golden):
         in_a = {"inputs_m1": {"voxel_features": dev(v), "voxel_coords": dev(c), "voxel_num_points": dev(n)}}
         in_b = {"inputs_m1": {"points": [dev(pts)]}}
         # the encoder (K1 + K2, our kernels) is bit-identical on both routes ...
-        assert torch.equal(model.encoder_m1(in_a, "m1"), model.encoder_m1(in_b, "m1"))
+        # (round 6: the inference encoder hands over ops.PillarBEV -- pillar rows + cell map; .dense() is the reference's canvas)
+        ea, eb = (t.dense() if hasattr(t, "dense") else t for t in (model.encoder_m1(in_a, "m1"), model.encoder_m1(in_b, "m1")))
+        assert torch.equal(ea, eb)
         a, b = model(in_a), model(in_b)
     # ... the dense tail goes through MIOpen, which may pick another algorithm on a later call
     for key in ("cls_preds", "reg_preds", "dir_preds"):

@@ -89,7 +89,8 @@ def test_training_from_raw_point_clouds():
     enc = model.encoder_m1
     canvas_g = enc(data, "m1")                      # gradient path (parameters require grad)
     with torch.no_grad():
-        canvas_i = enc(data, "m1")                  # K1 + K2
+        canvas_i = enc(data, "m1")                  # K1 + K2 (round 6: ops.PillarBEV when the backbone reads the pillars itself)
+        canvas_i = canvas_i.dense() if hasattr(canvas_i, "dense") else canvas_i
     assert canvas_g.requires_grad and not canvas_i.requires_grad
     assert float((canvas_g - canvas_i).abs().max() / canvas_i.abs().max()) < 1e-4
     model.train()
