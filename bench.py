@@ -159,7 +159,7 @@ def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
     if workload not in _PMC:
         _PMC[workload] = {}
         _PMC_NOTE[workload] = "no committed PMC summary for this workload"
-        for tag in ("r06", "r05", "r04", "r03"):      # the newest committed PMC summary of this workload
+        for tag in ("r06", "r05", "r04", "r03"):      # the newest committed PMC summary of this workload (the box-local copy profile_round.sh writes counts too)
             path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{workload}.json")
             if os.path.exists(path):
                 j = json.load(open(path))
@@ -642,18 +642,22 @@ def main():
                 # same survivors: equal count, every sharded box has its twin (nearest centre) within 5 mm with a score within 1e-3 --
                 # the tolerance of tests/test_gpu_dist.py: the two paths sum the agents' contributions in different orders (warp per agent
                 # + fuse vs one fused kernel; camera lift atomics), so the head maps agree to ~1e-5 of their scale, not bit for bit
-                same = tuple(b_sh.shape) == tuple(b_1.shape)
-                if same:
-                    d_ = torch.cdist(b_sh.mean(1), b_1.mean(1))
-                    twin = d_.argmin(1)
-                    dev_box = float((b_sh - b_1[twin]).abs().max())
-                    dev_score = float((s_sh - s_1[twin]).abs().max())
-                    same = bool(len(set(twin.tolist())) == int(b_1.shape[0]) and dev_box < 5e-3 and dev_score < 1e-3)
+                # (a candidate within rounding of the score threshold or of the 0.15 IoU may appear on one side only: up to 3 boxes without a
+                #  twin are tolerated, as in tests/test_gpu_dist.py; every other box must have its twin)
+                d_ = torch.cdist(b_sh.mean(1), b_1.mean(1))
+                twin = d_.argmin(1)
+                close = (d_.min(1).values < 5e-3) & ((s_sh - s_1[twin]).abs() < 1e-3)
+                lone = int((~close).sum()) + max(0, int(b_1.shape[0]) - int(close.sum()))
+                if bool(close.any()):
+                    dev_box = float((b_sh[close] - b_1[twin[close]]).abs().max())
+                    dev_score = float((s_sh[close] - s_1[twin[close]]).abs().max())
+                same = bool(abs(int(b_sh.shape[0]) - int(b_1.shape[0])) <= 3 and lone <= 3
+                            and len(set(twin[close].tolist())) == int(close.sum()))
             job["sharded_equals_single"] = bool(same)
             job["sharded_check"] = {"frame": 0, "boxes_sharded": 0 if b_sh is None else int(b_sh.shape[0]),
                                     "boxes_single_process": 0 if b_1 is None else int(b_1.shape[0]),
                                     "max_corner_deviation_m": dev_box, "max_score_deviation": dev_score,
-                                    "tolerance": "same survivor set; corners 5e-3 m, scores 1e-3 (tests/test_gpu_dist.py)",
+                                    "tolerance": "twins within 5e-3 m / 1e-3 score; at most 3 boxes without a twin (tests/test_gpu_dist.py)",
                                     "bit_equal": bool(same and (b_1 is None or (torch.equal(b_sh, b_1) and torch.equal(s_sh, s_1))))}
             verdict.fill_(1.0 if same else 0.0)
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN)

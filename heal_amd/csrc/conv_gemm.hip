@@ -1,4 +1,4 @@
-// Dense NCHW convolution (3x3 padding 1, or 1x1; stride 1 | 2) as an implicit GEMM on the 128 x 128 x 32 core of linear.hip:
+// Dense NCHW convolution (3x3 padding 1, or 1x1; stride 1 | 2; round 6: also 7x7 padding 3 stride 2) as an implicit GEMM on the 128 x 128 x 32 core of linear.hip:
 // v_mfma_f32_32x32x2_f32, 4 waves x (64 x 64), double-buffered LDS chunks, epilogue through LDS.
 //
 // Reference call sites: the stride-2 3x3 convolutions of the dense BEV stacks -- BaseBEVBackbone's stage heads
@@ -183,7 +183,8 @@ using namespace heal;
 // Wo % 4 == 0.  y = act(conv(x) + bias (+ residual)).
 extern "C" int heal_conv_gemm(const float* x, const float* weight_tap_major, const float* bias, const float* residual, int n,
                               int cin, int cout, int H, int W, int ksize, int stride, int relu, float* y, void* stream) {
-    HEAL_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv_gemm: ksize 1 | 3, stride 1 | 2");
+    HEAL_REQUIRE(((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2)) || (ksize == 7 && stride == 2),
+                 "conv_gemm: ksize 1 | 3 with stride 1 | 2, or the 7x7 / 2 stem (padding = ksize / 2)");
     HEAL_REQUIRE(cout % CG_BM == 0 && cin % CG_BK == 0 && n >= 1 && H >= 1 && W >= 1,
                  "conv_gemm: Cout must be a multiple of 128 and Cin of 32 (got %d -> %d)", cin, cout);
     ConvGemmArgs a;
@@ -202,7 +203,8 @@ extern "C" int heal_conv_gemm(const float* x, const float* weight_tap_major, con
     HEAL_REQUIRE(blocks < (1ll << 31), "conv_gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
 #define HEAL_CG(KS_, ST_) HEAL_LAUNCH_EV((k_conv_gemm<KS_, ST_>), dim3((unsigned)blocks), dim3(256), 0, s, a)
-    if (ksize == 3 && stride == 2) HEAL_CG(3, 2);
+    if (ksize == 7) HEAL_CG(7, 2);               // BevEncode's stem (lss_submodule.py:242: Conv2d(inC, 64, 7, stride 2, padding 3)), round 6
+    else if (ksize == 3 && stride == 2) HEAL_CG(3, 2);
     else if (ksize == 3) HEAL_CG(3, 1);
     else if (stride == 2) HEAL_CG(1, 2);
     else HEAL_CG(1, 1);

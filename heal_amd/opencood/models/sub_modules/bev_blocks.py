@@ -78,6 +78,9 @@ def conv_bias_act(x, w, b, stride, padding, dilation=1, groups=1, relu=True, res
             and (padding if isinstance(padding, int) else padding[1]) == 1
             and (stride if isinstance(stride, int) else stride[1]) == st):
         return ops.conv3x3(x, w, b, residual, relu, st)
+    if (x.is_cuda and groups == 1 and tuple(w.shape[2:]) == (7, 7) and st == 2 and pd == 3 and dl == 1 and residual is None
+            and ops.conv7x7_s2_supported(int(w.shape[1]), int(w.shape[0]), int(x.shape[3]))):
+        return ops.conv7x7_s2(x, w, b, relu)      # BevEncode's stem (lss_submodule.py:242): the last library convolution of any mirrored model
     _library_fallthrough(x, w, stride, padding, dilation, groups)
     y = F.conv2d(x, w, None, stride, padding, dilation, groups)
     if b is None and residual is None and not relu:

@@ -2068,11 +2068,39 @@ def conv_gemm(x, w, bias=None, residual=None, relu=False, stride=1):
     y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _need(residual, torch.float32, "residual")
-    name = (f"conv3x3_{cin}_{cout}" if ks == 3 else f"conv1x1_{cin}_{cout}") + ("_s2" if stride == 2 else "")
+    name = (f"conv3x3_{cin}_{cout}" if ks == 3 else f"conv{ks}x{ks}_{cin}_{cout}") + ("_s2" if stride == 2 else "")
     with _Timed(name, 2.0 * ks * ks * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo), kernel_events=True):
         _capi.call("heal_conv_gemm", _ptr(x), _ptr(hit[0]), _optr(bias), _optr(residual), n, cin, cout, H, W, ks, int(stride),
                    int(bool(relu)), _ptr(y), _stream())
     return y
+
+
+_PAD128_CACHE = {}
+
+
+def conv7x7_s2_supported(cin, cout, W):
+    return cin % 32 == 0 and cout <= 128 and ((W - 1) // 2 + 1) % 4 == 0 and os.environ.get("HEAL_CONV_GEMM", "1") == "1"
+
+
+def conv7x7_s2(x, w, bias=None, relu=False):
+    """Conv2d(Cin, Cout <= 128, kernel 7, stride 2, padding 3) (+ bias) (+ ReLU) on heal_conv_gemm's 128 x 128 x 32 implicit GEMM: BevEncode's
+    stem of the old-style Lift-Splat model (lss_submodule.py:242).  The kernel wants 128-channel output tiles: the weight (and bias) are
+    padded with zero rows once (cached), the first Cout channels of the result are returned."""
+    cout = int(w.shape[0])
+    key = (w.data_ptr(), w._version, None if bias is None else (bias.data_ptr(), bias._version))
+    hit = _PAD128_CACHE.get(key)
+    if hit is None:
+        if len(_PAD128_CACHE) > 32:
+            _retire_cache(_PAD128_CACHE)
+        wp = torch.zeros((128,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+        wp[:cout] = w.detach()
+        bp = None
+        if bias is not None:
+            bp = torch.zeros((128,), dtype=torch.float32, device=w.device)
+            bp[:cout] = bias.detach()
+        hit = _PAD128_CACHE[key] = (wp, bp, w)
+    y = conv_gemm(x, hit[0], hit[1], None, relu, 2)
+    return y[:, :cout].contiguous() if cout < 128 else y
 
 
 def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):

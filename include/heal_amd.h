@@ -570,7 +570,9 @@ int heal_conv3x3(const float* x, const float* weight_frag, const float* bias, co
  *   implicit GEMM on 128 x 128 x 32 tiles of v_mfma_f32_32x32x2_f32 -- the formulation for the LARGE stride-2 layers
  *   (BaseBEVBackbone stage heads, base_bev_backbone.py:49-74; the 384 -> 256 shrink_header of HeterModelBaseline,
  *   downsample_conv.py:7-49), where the long reduction (9 Cin) amortises its 128 x 128 tiles.  weight_tap_major = W re-laid
- *   [Cout, k*k, Cin] (tap = k ky + kx); Cout % 128 == 0, Cin % 32 == 0, output width % 4 == 0.                              */
+ *   [Cout, k*k, Cin] (tap = k ky + kx); Cout % 128 == 0, Cin % 32 == 0, output width % 4 == 0.  Round 6: ksize 7 with stride 2
+ *   (padding 3) as well -- BevEncode's stem Conv2d(inC, 64, 7, 2, 3) of the old-style Lift-Splat model (lss_submodule.py:242), the last
+ *   convolution any mirrored model left to the library (the caller pads its 64 output channels to 128 zero rows).                    */
 int heal_conv_gemm(const float* x, const float* weight_tap_major, const float* bias, const float* residual, int n, int cin,
                    int cout, int H, int W, int ksize, int stride, int relu, float* y, void* stream);
 

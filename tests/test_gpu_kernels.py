@@ -1720,3 +1720,23 @@ def test_conv1x1_split_bf16_error_vs_exact_fp32_kernel(n, cin, cout, H, W, res, 
     note("conv1x1_split_error", shape=[n, cin, cout, H, W], products=nprod, err_exact_fp32_kernel=e_exact, err_split=e_split)
     assert e_split <= 2.0 * e_exact + 1e-9, (e_split, e_exact)
     assert e_split < 2e-6
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,relu", [(1, 128, 64, 64, 64, True), (2, 32, 64, 40, 56, False), (1, 64, 128, 30, 24, True)])
+def test_conv7x7_stride2_vs_torch(n, cin, cout, H, W, relu):
+    """Round 6: the 7x7 / stride 2 / padding 3 stem of BevEncode (lss_submodule.py:242; the last convolution a mirrored model left to the
+    library) on heal_conv_gemm's implicit GEMM (Cout padded to a 128-channel tile) against torch's fp64 convolution."""
+    from heal_amd import ops
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 7, 7), generator=g) / (49 * cin) ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    assert ops.conv7x7_s2_supported(cin, cout, W)
+    got = ops.conv7x7_s2(x, w, b, relu)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 2, 3)
+    ref = torch.relu(ref) if relu else ref
+    assert got.shape == ref.shape and got.is_contiguous()
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    got2 = ops.conv7x7_s2(x, w, None, False)
+    ref2 = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 3)
+    assert float((got2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-5
