@@ -27,10 +27,8 @@ namespace heal {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16s;
 
-constexpr int CS_BM = 128, CS_BN = 128, CS_BK = 32;
+constexpr int CS_BM = 128, CS_BK = 32;
 constexpr int CS_ROWB = 80;                       // bytes per pixel row of a B plane (32 bf16 = 64 B + 16 B pad)
-constexpr int CS_PLANE = CS_BN * CS_ROWB;         // 10 240 B
-constexpr int CS_BUF = 3 * CS_PLANE;              // 30 720 B per buffer
 
 struct Split3 { bf16x8 h, m, l; };
 
@@ -50,24 +48,25 @@ __device__ __forceinline__ Split3 split8(const float* v) {
 // Epilogue of a wave's 64 x 64 tile: the 32x32 D blocks go through a wave-private LDS slice [32 channels][64 pixels] so that bias / residual /
 // activation and the stores work on 16-B pieces (128-B runs per channel).  The first version stored one dword per lane and register -- 64
 // scalar stores per lane: the anatomy (HEAL_SPLIT_DBG=15: no loads, no splitting, no MFMAs) still took 32 of the kernel's 64 us.
-constexpr int CS_ES = 68;                          // row stride (floats) of the epilogue slice
-__device__ __forceinline__ void split_epilogue(float* __restrict__ se /* this wave's [32][CS_ES] floats */, const f32x16s (&acc)[2][2],
-                                               const f32x16s (&cor)[2][2], const float* __restrict__ bias,
+template <int NA, int NB>                          // row blocks / pixel blocks (32 x 32 each) of a wave's tile; slice row stride 32 NB + 4 floats
+__device__ __forceinline__ void split_epilogue(float* __restrict__ se /* this wave's [32][32 NB + 4] floats */, const f32x16s (&acc)[NA][NB],
+                                               const f32x16s (&cor)[NA][NB], const float* __restrict__ bias,
                                                const float* __restrict__ residual, float* __restrict__ y, int img, int cout, int HW,
                                                int co0 /* first channel of the wave tile */, int px_base /* first pixel */, int act) {
+    constexpr int CS_ES = 32 * NB + 4, P4 = 8 * NB;    // float4 pieces per slice row
     const int l = threadIdx.x & 63, lj = l & 31, kb = l >> 5;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < NA; ++a) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 se[((r & 3) + 8 * (r >> 2) + 4 * kb) * CS_ES + 32 * b + lj] = acc[a][b][r] + cor[a][b][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = l + 64 * i, cl = idx >> 4, p4 = idx & 15;
+        for (int i = 0; i < 4 * NB; ++i) {
+            const int idx = l + 64 * i, cl = idx / P4, p4 = idx % P4;
             const int co = co0 + 32 * a + cl, px = px_base + 4 * p4;
             if (px >= HW) continue;                // HW % 4 == 0 (host): a 16-B piece is inside or outside
             float4 v = *reinterpret_cast<const float4*>(&se[cl * CS_ES + 4 * p4]);
@@ -87,48 +86,51 @@ __device__ __forceinline__ void split_epilogue(float* __restrict__ se /* this wa
     }
 }
 
-template <int NPROD>
-__global__ __launch_bounds__(256, 2) void k_conv1x1_split(const float* __restrict__ x, const uint4* __restrict__ wfrag,
+template <int NPROD, int NA, int NB>      // NA row blocks x NB pixel blocks per wave: the block is 64 NA channels x 64 NB pixels
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void k_conv1x1_split(const float* __restrict__ x, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const float* __restrict__ residual,
                                                          int cin, int cout, int HW, int act, float* __restrict__ y, int dbg) {
     // dbg (HEAL_SPLIT_DBG, timing anatomy only): 1 no MFMAs, 2 no splitting (hi plane only computed), 4 no activation loads, 8 no weight loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int wr = w >> 1, wc = w & 1, lj = l & 31, kb = l >> 5;
-    const int px0 = blockIdx.x * CS_BN, ct = blockIdx.y, img = blockIdx.z;
+    constexpr int BN = 64 * NB, PLANE = BN * CS_ROWB, BUF = 3 * PLANE, NS = 8 * NB;   // NS staged values per thread and chunk
+    const int px0 = blockIdx.x * BN, img = blockIdx.z;
+    const int co0 = blockIdx.y * 64 * NA;         // first output channel of the block; the fragments are laid out per 128 channels
+    const int ct = co0 >> 7, rb0 = (co0 & 127) >> 5;
     const int nchunks = cin / CS_BK;
     const float* __restrict__ xi = x + (size_t)img * cin * HW;
 
-    // staging role: pixel spx, channel groups 2 sh and 2 sh + 1 (8 channels each) of the chunk
-    const int spx = tid & 127, sh = tid >> 7;
+    // staging role: pixel spx, NB groups of 8 channels of the chunk starting at channel NS sh
+    const int spx = tid & (BN - 1), sh = tid / BN;
     const int gpx = min(px0 + spx, HW - 1);       // clamped: loads are unconditional, stores masked
-    float stage[16];
+    float stage[NS];
     auto load = [&](int c) {
         if (dbg & 4) return;
-        const float* p = xi + (size_t)(c * CS_BK + 16 * sh) * HW + gpx;
+        const float* p = xi + (size_t)(c * CS_BK + NS * sh) * HW + gpx;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) stage[i] = p[(size_t)i * HW];
+        for (int i = 0; i < NS; ++i) stage[i] = p[(size_t)i * HW];
     };
     auto store = [&](int buf) {
-        unsigned char* base = smem + buf * CS_BUF + spx * CS_ROWB + 32 * sh;   // k = 16 sh .. 16 sh + 15 -> byte offset 32 sh
+        unsigned char* base = smem + buf * BUF + spx * CS_ROWB + 2 * NS * sh;   // k = NS sh .. -> byte offset 2 NS sh
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < NB; ++g) {
             Split3 s;
             if (dbg & 2) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s.h[i] = (__bf16)stage[8 * g + i]; s.m[i] = s.h[i]; s.l[i] = s.h[i]; }
             } else s = split8(stage + 8 * g);
             *reinterpret_cast<bf16x8*>(base + 16 * g) = s.h;
-            *reinterpret_cast<bf16x8*>(base + CS_PLANE + 16 * g) = s.m;
-            *reinterpret_cast<bf16x8*>(base + 2 * CS_PLANE + 16 * g) = s.l;
+            *reinterpret_cast<bf16x8*>(base + PLANE + 16 * g) = s.m;
+            *reinterpret_cast<bf16x8*>(base + 2 * PLANE + 16 * g) = s.l;
         }
     };
 
-    f32x16s acc[2][2], cor[2][2];                 // [row block][pixel block]: leading products / corrections
+    f32x16s acc[NA][NB], cor[NA][NB];             // [row block][pixel block]: leading products / corrections
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; cor[a][b][r] = 0.f; }
 
@@ -138,14 +140,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_split(const float* __restric
         return *reinterpret_cast<const bf16x8*>(&v);
     };
 #pragma unroll
-    for (int i = 0; i < 16; ++i) stage[i] = 1.f;
+    for (int i = 0; i < NS; ++i) stage[i] = 1.f;
     load(0);
     store(0);
-    bf16x8 A[2][3], An[2][3];                     // this k16-step's weight fragments / the next step's, requested one step ahead
+    bf16x8 A[NA][3], An[NA][3];                   // this k16-step's weight fragments / the next step's, requested one step ahead
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { A[a][p] = afrag(0, 0, 2 * wr + a, p); An[a][p] = A[a][p]; }
+        for (int p = 0; p < 3; ++p) { A[a][p] = afrag(0, 0, rb0 + NA * wr + a, p); An[a][p] = A[a][p]; }
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -157,22 +159,22 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_split(const float* __restric
             const int cn = s ? c + 1 : c, sn = s ^ 1;
             if (cn < nchunks) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < NA; ++a)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) An[a][p] = afrag(cn, sn, 2 * wr + a, p);
+                    for (int p = 0; p < 3; ++p) An[a][p] = afrag(cn, sn, rb0 + NA * wr + a, p);
             }
-            bf16x8 B[2][3];
+            bf16x8 B[NB][3];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    B[b][p] = *reinterpret_cast<const bf16x8*>(smem + buf * CS_BUF + p * CS_PLANE +
-                                                               (64 * wc + 32 * b + lj) * CS_ROWB + (16 * s + 8 * kb) * 2);
+                    B[b][p] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + p * PLANE +
+                                                               (32 * NB * wc + 32 * b + lj) * CS_ROWB + (16 * s + 8 * kb) * 2);
             __builtin_amdgcn_sched_barrier(0);
             // term by term over the four output blocks (consecutive MFMAs hit different accumulators); smallest terms first
 #define CS_TERM(DST, PA, PB)                                                                                        \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                   \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                  \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                              \
             DST[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][PA], B[b][PB], DST[a][b], 0, 0, 0);
             if (!(dbg & 1)) {
             if (NPROD == 9) {
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_split(const float* __restric
 #undef CS_TERM
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) A[a][p] = An[a][p];
         }
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1_split(const float* __restric
     }
 
     // epilogue through LDS (the plane buffers are free after the loop's last barrier): 16-B stores
-    split_epilogue(reinterpret_cast<float*>(smem) + w * 32 * CS_ES, acc, cor, bias, residual, y, img, cout, HW, ct * CS_BM + 64 * wr,
-                   px0 + 64 * wc, act);
+    split_epilogue<NA, NB>(reinterpret_cast<float*>(smem) + w * 32 * (32 * NB + 4), acc, cor, bias, residual, y, img, cout, HW,
+                           co0 + 32 * NA * wr, px0 + 32 * NB * wc, act);
 }
 
 
@@ -220,14 +222,22 @@ extern "C" int heal_conv1x1_split(const float* x, const void* weight_frag, const
     HEAL_REQUIRE(((uintptr_t)weight_frag & 15) == 0, "conv1x1_split: weight fragments must be 16-B aligned");
     const int HW = H * W;
     HEAL_REQUIRE(n >= 1 && n <= 65535 && cout / CS_BM <= 65535, "conv1x1_split: grid limit");
-    const dim3 grid(ceil_div(HW, CS_BN), cout / CS_BM, n);
     const uint4* wf = reinterpret_cast<const uint4*>(weight_frag);
-    const size_t lds = 2 * CS_BUF;               // 61 440 B: two blocks per CU
     const int dbg = HEAL_DEBUG_ENV("HEAL_SPLIT_DBG");
-    if (n_products == 6)
-        HEAL_LAUNCH_EV(k_conv1x1_split<6>, grid, dim3(256), lds, (hipStream_t)stream, x, wf, bias, residual, cin, cout, HW, act, y, dbg);
-    else
-        HEAL_LAUNCH_EV(k_conv1x1_split<9>, grid, dim3(256), lds, (hipStream_t)stream, x, wf, bias, residual, cin, cout, HW, act, y, dbg);
+    // pixels per block: 128 when that still gives every CU two or more blocks and a half, else 64 (twice the blocks, three resident per CU:
+    // the 64^2 levels of the fusion pyramid give 320 blocks of 128 pixels for 256 CUs -- two rounds on a quarter of the chip)
+    // block shape (channels x pixels): 128 x 64 (default) | 64 x 128 | 128 x 128.  Measured at the scene's shapes (scripts/split_gemm_bench.py,
+    // bf16x6, 512 -> 256 at 5 x 64^2): 50.6 | 58.4 | 57.1 us (exact-fp32 kernel 55.6) -- the 128 x 128 block leaves the 64^2 pyramid levels with
+    // 320 blocks for 256 CUs; the 64 x 128 block reads half the weight fragments per MFMA but needs 61 KB of LDS (two blocks per CU instead of
+    // three) and loses; 128 x 64 wins at every shape.
+    static const int shape = []() { const char* e = getenv("HEAL_SPLIT_TILE"); return e ? atoi(e) : 1; }();   // 1 128x64 | 2 64x128 | 3 128x128
+    const int na = (shape == 2) ? 1 : 2, nb = (shape == 2 || shape == 3) ? 2 : 1;
+    const dim3 grid(ceil_div(HW, 64 * nb), cout / (64 * na), n);
+    const size_t lds = (size_t)2 * 3 * 64 * nb * CS_ROWB;      // 61 440 B (two blocks per CU) | 30 720 B
+#define HEAL_CS(NP_, NA_, NB_) HEAL_LAUNCH_EV((k_conv1x1_split<NP_, NA_, NB_>), grid, dim3(256), lds, (hipStream_t)stream, x, wf, bias, residual, cin, cout, HW, act, y, dbg)
+    if (n_products == 6) { if (na == 2 && nb == 2) HEAL_CS(6, 2, 2); else if (na == 2) HEAL_CS(6, 2, 1); else HEAL_CS(6, 1, 2); }
+    else { if (na == 2 && nb == 2) HEAL_CS(9, 2, 2); else if (na == 2) HEAL_CS(9, 2, 1); else HEAL_CS(9, 1, 2); }
+#undef HEAL_CS
     HEAL_LAUNCH_CHECK();
     return 0;
 }
