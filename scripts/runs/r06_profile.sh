@@ -25,3 +25,6 @@ except Exception as e:
     print(sys.argv[1], 'unreadable', e)
 PY
 done
+timeout 400 python scripts/scaling_model.py --workload scene5 --json $OUT/r06_scaling_model_scene5.json > $OUT/scaling_scene5.log 2>&1
+timeout 400 python scripts/scaling_model.py --workload scene8_second_v2xvit --json $OUT/r06_scaling_model_scene8_second_v2xvit.json > $OUT/scaling_scene8.log 2>&1
+tail -3 $OUT/scaling_scene5.log
