@@ -644,9 +644,10 @@ def main():
                 # + fuse vs one fused kernel; camera lift atomics), so the head maps agree to ~1e-5 of their scale, not bit for bit
                 # (a candidate within rounding of the score threshold or of the 0.15 IoU may appear on one side only: up to 3 boxes without a
                 #  twin are tolerated, as in tests/test_gpu_dist.py; every other box must have its twin)
-                d_ = torch.cdist(b_sh.mean(1), b_1.mean(1))
-                twin = d_.argmin(1)
-                close = (d_.min(1).values < 5e-3) & ((s_sh - s_1[twin]).abs() < 1e-3)
+                c_sh, c_1 = b_sh.mean(1), b_1.mean(1)
+                twin = torch.cdist(c_sh, c_1, compute_mode="donot_use_mm_for_euclid_dist").argmin(1)
+                # (the distance to the twin from the coordinates themselves: cdist's matrix-product form loses ~1e-2 m at |x| ~ 100 m)
+                close = ((c_sh - c_1[twin]).norm(dim=1) < 5e-3) & ((s_sh - s_1[twin]).abs() < 1e-3)
                 lone = int((~close).sum()) + max(0, int(b_1.shape[0]) - int(close.sum()))
                 if bool(close.any()):
                     dev_box = float((b_sh[close] - b_1[twin[close]]).abs().max())

@@ -143,10 +143,13 @@ class PyramidFusion(ResNetBEVBackbone):
     # (a frame-independent constant).  Exact: the pasted box is computed by the same kernels from the same values; only work whose
     # result is known in advance is skipped.  Level 0: 144^2 of 256^2 pixels, level 1: 88^2 of 128^2; the last level's content box
     # already reaches the borders and runs in full.  HEAL_PYRAMID_CAMCROP=0 switches it off.
+    def _zero_response_key(self, like):
+        return (tuple((p.data_ptr(), p._version) for p in self.resnet.parameters()) +
+                tuple((b.data_ptr(), b._version) for b in self.resnet.buffers()), tuple(like.shape[1:]), str(like.device))
+
     def _zero_response(self, like):
         """Stage outputs of the pyramid for an all-zero [1, C, H, W] input (cached per parameter version and map size)."""
-        key = (tuple((p.data_ptr(), p._version) for p in self.resnet.parameters()) +
-               tuple((b.data_ptr(), b._version) for b in self.resnet.buffers()), tuple(like.shape[1:]), str(like.device))
+        key = self._zero_response_key(like)
         if getattr(self, "_bg_key", None) != key:
             with torch.no_grad():
                 z = torch.zeros((1,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
@@ -231,6 +234,9 @@ class PyramidFusion(ResNetBEVBackbone):
         H, W = int(spatial_features.shape[2]), int(spatial_features.shape[3])
         if H % 32 or W % 32 or not (0 <= box[0] < box[1] <= H and 0 <= box[2] < box[3] <= W):
             return None
+        if (torch.cuda.is_current_stream_capturing()
+                and getattr(self, "_bg_key", None) != self._zero_response_key(spatial_features[:1])):
+            return None     # the zero response would be computed INSIDE the capture (valid only after a replay): plain walk for this graph
         return (cams[0], cams[-1] + 1), box
 
     def multiscale(self, spatial_features, agent_modality_list=None, cam_boxes=None):

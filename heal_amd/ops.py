@@ -245,7 +245,11 @@ def _vox_call(name, key, *args):
     clean = key in _VOX_CLEAN
     _VOX_CLEAN.discard(key)
     _capi.call(name, *args[:-1], 1 if clean else 0, args[-1])
-    _VOX_CLEAN.add(key)
+    # A call RECORDED into a graph has not run: if it carries the initial fill (workspace first seen inside a capture), the tables are
+    # clean only once that graph has been replayed -- later calls must not rely on it, so the workspace stays 'unknown' (every capture
+    # then carries its own fill; the first eager call settles it).
+    if clean or not torch.cuda.is_current_stream_capturing():
+        _VOX_CLEAN.add(key)
 
 
 def voxelize(points, lidar_range, voxel_size, max_points, max_voxels, batch_idx=0, sync=True):

@@ -98,11 +98,15 @@ def main():
                 local_ms.append(ms)
                 bufs[r] = buf
                 shape = getattr(runners[r], "_shape", None) or shape
+            # what dist.prepare()'s all-reduce agrees between the ranks of a real job: the level shapes a rank WITH agents produced
+            shapes = next((getattr(rr, "_shapes", None) for rr in runners if getattr(rr, "_shapes", None)), None)
             for r in range(N):   # ranks without agents contribute a zero slot
                 if bufs[r] is None:
                     bufs[r] = torch.zeros_like(next(b for b in bufs if b is not None))
                 if shape is not None:
                     runners[r]._shape = shape
+                if shapes is not None and hasattr(runners[r], "_shapes"):
+                    runners[r]._shapes = shapes
             gathered = torch.stack(bufs)
             _, tail_ms, g = timed_graph(lambda: post_fn(runners[0].tail(gathered, n_agents)), stream)
             keep.append((g, gathered))
