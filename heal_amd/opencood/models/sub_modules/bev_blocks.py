@@ -136,12 +136,14 @@ class ConvBN(nn.Module):
 
     @staticmethod
     def run(x, conv, bn, cache, relu, residual=None, out=None):
-        if out is not None:      # (inference only: the agent-chunked stage walk)
+        if out is not None and not grad_path(x, bn, conv):      # (inference: the agent-chunked / camera-crop stage walks)
             w, b = cache.get(conv, bn)
             y = conv_bias_act(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups, relu, residual, out=out)
             if y.data_ptr() != out.data_ptr():
                 out.copy_(y)
             return out
+        if out is not None:      # gradient path with a destination (CPU tests of the stage walks): compute, then copy
+            return out.copy_(ConvBN.run(x, conv, bn, cache, relu, residual))
         if grad_path(x, bn, conv):   # training / fine-tuning: conv -> BatchNorm (batch statistics when training) -> + -> ReLU
             y = bn(conv(x))
             if residual is not None:

@@ -634,3 +634,74 @@ def test_exact_rational_iou_known_answers():
     assert E.exact_quad_iou(sq, big) == Fraction(1, 16)
     assert E.exact_quad_iou(sq, sq + np.array([1, 0], np.float32)) == 0    # shared edge only
     assert E.exact_quad_iou(np.zeros((4, 2), np.float32), np.zeros((4, 2), np.float32)) is None
+
+
+def test_camera_crop_walk_is_exact_on_the_torch_path():
+    """Round 6 (fuse_modules/pyramid_fuse.py): camera agents' zero-padded maps go through the pyramid stages on the crop their content can
+    influence, the rest of every stage output is the stack's response to an all-zero map.  The claim is about LOCALITY, not about
+    kernels, so it is checked here on the CPU with the modules' torch path (parameters require grad -> conv / BatchNorm as torch operators):
+    random weights and BatchNorm statistics, two LiDAR-like agents with dense maps + two camera agents that are zero outside a box,
+    both agent orders; every level must equal the plain walk EVERYWHERE (inside and outside the pasted box) to fp32 rounding.  Also the
+    interval arithmetic the crop is planned with."""
+    from heal_amd.opencood.models.fuse_modules.pyramid_fuse import PyramidFusion, _stage_influence, _stage_needs
+    cfg = {"layer_nums": [3, 5, 8], "num_filters": [16, 32, 64], "layer_strides": [1, 2, 2], "upsample_strides": [1, 2, 4],
+           "num_upsample_filter": [32, 32, 32], "resnext": True, "inplanes": 16}
+    torch.manual_seed(0)
+    pf = PyramidFusion(cfg).eval()
+    for m in pf.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.5)
+    H = W = 128
+    box = (48, 80, 52, 84)
+    for cams_first in (False, True):
+        x = torch.randn(4, 16, H, W)
+        cam = (0, 2) if cams_first else (2, 4)
+        keep = torch.zeros(1, 1, H, W)
+        keep[..., box[0]:box[1], box[2]:box[3]] = 1
+        x[cam[0]:cam[1]] *= keep
+        with torch.enable_grad():                       # (the torch path; no autograd graph is needed afterwards)
+            # the cached zero-input response, computed here on the torch path (the model computes it under no_grad on the device)
+            pf._bg = [f.detach() for f in pf.resnet(torch.zeros(1, 16, H, W))]
+            pf._bg_key = pf._zero_response_key(x)
+            plain = [f.detach() for f in pf.get_multiscale_feature(x)]
+            plan = pf._camcrop_plan(x, cam, box)
+            crop = [f.detach() for f in pf.get_multiscale_feature_camcrop(x, cam, box)]
+        assert plan[0] is not None and plan[1] is not None          # levels 0 and 1 are cropped at this size
+        for i, (a, b) in enumerate(zip(plain, crop)):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (cams_first, i)
+    l0, l1 = [type("B", (), {"stride": 1})()] * 3, [type("B", (), {"stride": 2})()] + [type("B", (), {"stride": 1})()] * 4
+    assert _stage_influence(64, 192, l0, 256) == (61, 195, 256) and _stage_needs(61, 195, l0, 256) == (58, 198)
+    assert _stage_influence(61, 195, l1, 256) == (26, 102, 128) and _stage_needs(26, 102, l1, 256) == (43, 212)
+    assert _stage_influence(0, 10, l0, 256)[0] == 0 and _stage_needs(0, 5, l0, 256)[0] == 0      # clipped at the map's border
+
+
+def test_bench_refuses_profile_files_of_another_library_build(tmp_path, monkeypatch):
+    """bench.py quotes `roofline.traffic` / the in-graph rocprof duration only from committed profile files that carry the build stamp of
+    the library that is loaded: a summary of another build is refused with the reason in `traffic_source`."""
+    import importlib
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    stamp = bench.lib_stamp()
+    assert stamp and len(stamp) == 64
+    body = {"kernels": {"heal::k_conv1x1<64, 64, 32, 1>": {"dispatches": 4, "bytes_per_dispatch": 1000.0}}}
+    for tag, recorded, want in (("other", "0" * 64, None), ("mine", stamp, 1000.0)):
+        bench._PMC, bench._PMC_NOTE = None, {}
+        json.dump(dict(body, lib_stamp=recorded), open(tmp_path / "profiles" / "r06_pmc_traffic_scene5.json", "w"))
+        assert bench.pmc_traffic("scene5", "heal::k_conv1x1<") == want, tag
+        note = bench._PMC_NOTE["scene5"]
+        assert ("refused" in note) == (want is None), note
+    bench._KSTATS.clear()
+    open(tmp_path / "profiles" / "r06_kernel_stats_scene5.csv", "w").write(
+        '"Name","Calls","TotalDurationNs","AverageNs"\n"void heal::k_conv1x1<64, 64, 32, 1>(float const*)",10,300000,30000\n')
+    open(tmp_path / "profiles" / "r06_kernel_stats_scene5.stamp", "w").write("0" * 64)
+    assert bench.rocprof_mean_us("scene5", "void heal::k_conv1x1<") is None
+    bench._KSTATS.clear()
+    open(tmp_path / "profiles" / "r06_kernel_stats_scene5.stamp", "w").write(stamp)
+    assert bench.rocprof_mean_us("scene5", "void heal::k_conv1x1<") == 30.0
