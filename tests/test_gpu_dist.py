@@ -31,15 +31,20 @@ def _worker(rank, world, port, mods, out_path, wire=None, fusion=None, split=Non
     from heal_amd.dist import ShardedBaseline, ShardedCollab, make_sharded, owned_agents
     from heal_amd.pipeline import Scene, ScenePipeline
     small = [-25.6, -25.6, -3, 25.6, 25.6, 1]
-    hypes = configs.lidar_pyramid(small) if fusion is None else configs.lidar_baseline(fusion, small)
+    heter = fusion == "heter"   # the heterogeneous pyramid model at full range (cameras need their real frustum): fusion stays PyramidFusion
+    if heter:
+        fusion = None
+    hypes = (configs.heal_heter(tuple(sorted(set(mods))), max_cav=5) if heter
+             else configs.lidar_pyramid(small) if fusion is None else configs.lidar_baseline(fusion, small))
     if split == "compressed":   # the reference's compressor option (heter_pyramid_collab.py:176-178): 64 -> 16 channels on the wire
         hypes["model"]["args"]["compressor"] = {"input_dim": 64, "compress_ratio": 4}
     pipe = ScenePipeline(hypes, "cuda:0", seed=5)
     scene = Scene(len(mods), seed=6, device="cuda:0", modalities=mods)
-    scene.points = {k: p[(p[:, 0].abs() < 28) & (p[:, 1].abs() < 28)][:6000].contiguous()
-                    for k, p in scene.points.items()}
     from heal_amd import synth
-    scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
+    if not heter:
+        scene.points = {k: p[(p[:, 0].abs() < 28) & (p[:, 1].abs() < 28)][:6000].contiguous()
+                        for k, p in scene.points.items()}
+        scene.pairwise = synth.pairwise_t_matrix(synth.agent_poses(6, len(mods), r_min=3.0, r_max=10.0), 5)[None]
     sharded = make_sharded(pipe.model, rank, world, wire_dtype=getattr(torch, wire) if wire else None, split=split,
                            collective=collective)
     assert isinstance(sharded, ShardedCollab if fusion is None else ShardedBaseline)
@@ -102,6 +107,23 @@ def test_sharded_forward_equals_single_process(tmp_path, n_agents):
         assert err < 1e-4, (k, err)
         err = float((rep - ref).abs().max() / (ref.abs().max() + 1e-12))
         assert err < 1e-4, ("graph replay", k, err)
+
+
+@pytest.mark.parametrize("mods", [["m1", "m2", "m4"], ["m2", "m1"]])
+def test_sharded_heterogeneous_scene_with_a_camera_only_rank(tmp_path, mods):
+    """The headline model class sharded: with (a + 1) % world ownership the first list gives rank 0 the m2 camera ALONE (its stage
+    walk runs on the camera crop with an empty 'other' range, pyramid_fuse.multiscale) and rank 1 a LiDAR + the m4 camera (mixed
+    walk); the second is a camera-EGO scene whose camera sits alone on rank 1.  Eager and graph replay must equal the single-process
+    model, which itself equals the plain walk (test_round6_work_skipping_paths_equal_the_plain_walk)."""
+    import torch.multiprocessing as mp
+    from heal_amd.dist import owned_agents
+    assert any(all(mods[a] != "m1" for a in owned_agents(len(mods), r, 2)) for r in range(2))
+    out = str(tmp_path / "o.pt")
+    mp.spawn(_worker, args=(2, _free_port(), mods, out, None, "heter"), nprocs=2, join=True)
+    for k, (got, ref, rep) in torch.load(out).items():
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((got - ref).abs().max()) / scale < 1e-4, (k, "eager")
+        assert float((rep - ref).abs().max()) / scale < 1e-4, (k, "graph replay")
 
 
 @pytest.mark.parametrize("fusion,n_agents", [("v2xvit", 3), ("att", 2), ("max", 1)])
@@ -179,7 +201,11 @@ def _ring_worker(rank, world, port, mods, out_path, fusion=None, rounds=1, colle
     from heal_amd.dist import ShardedFramesInFlight, make_sharded
     from heal_amd.pipeline import Scene, ScenePipeline
     small = [-25.6, -25.6, -3, 25.6, 25.6, 1]
-    hypes = configs.lidar_pyramid(small) if fusion is None else configs.lidar_baseline(fusion, small)
+    heter = fusion == "heter"   # the heterogeneous pyramid model at full range (cameras need their real frustum): fusion stays PyramidFusion
+    if heter:
+        fusion = None
+    hypes = (configs.heal_heter(tuple(sorted(set(mods))), max_cav=5) if heter
+             else configs.lidar_pyramid(small) if fusion is None else configs.lidar_baseline(fusion, small))
     pipe = ScenePipeline(hypes, "cuda:0", seed=5)
     frames = []
     for i in range(5):
