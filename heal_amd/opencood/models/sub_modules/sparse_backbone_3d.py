@@ -140,17 +140,21 @@ class _Block(nn.Sequential):
         conv = self[0]
         scale, shift = self.bn()
         if conv.subm:
-            nbr = nbr_cache.get(conv.indice_key)
+            # the rulebook of an indice_key comes in the form its layer's kernel reads (ops.SparseTensor.rulebook: pair tiles for the
+            # c_in <= 16 layers, the neighbour table otherwise); layers that share a key but not the form each get their own
+            key = (conv.indice_key, x.tiles_ok(conv.kernel_size, conv.in_channels, conv.out_channels))
+            nbr = nbr_cache.get(key)
             if nbr is None:
-                nbr = x.neighbors(x.indices, x.spatial_shape, conv.kernel_size, (1, 1, 1),
-                                  tuple(k // 2 for k in conv.kernel_size), n_out_dev=x.n_dev)
-                nbr_cache[conv.indice_key] = nbr
+                nbr = x.rulebook(x.indices, x.spatial_shape, conv.kernel_size, (1, 1, 1), tuple(k // 2 for k in conv.kernel_size),
+                                 conv.in_channels, conv.out_channels, n_out_dev=x.n_dev)
+                nbr_cache[key] = nbr
             feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=x.n_dev)
             y = SparseTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.n_dev, x._checks, x._root_cap)
             y._table, y._rank, y._rank_root = x._table, x._rank, x._rank_root
             return y
         out_idx, out_shape, n_out_dev, rank = x.out_sites_ex(conv.kernel_size, conv.stride, conv.padding)
-        nbr = x.neighbors(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, n_out_dev=n_out_dev)
+        nbr = x.rulebook(out_idx, out_shape, conv.kernel_size, conv.stride, conv.padding, conv.in_channels, conv.out_channels,
+                         n_out_dev=n_out_dev)
         feats = x.conv(nbr, conv.flat_weight(), scale, shift, relu=True, n_out_dev=n_out_dev)
         y = SparseTensor(feats, out_idx, out_shape, x.batch_size, n_out_dev, x._checks, x._root_cap)
         y._rank = rank   # occupancy bitmap + prefix counts of the new site set: the later layers' neighbour queries

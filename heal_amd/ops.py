@@ -1171,6 +1171,30 @@ def sp_weight_fragments(weight):
     return hit[0]
 
 
+class PairTiles:
+    """The rulebook of a thin sparse layer as pair tiles (include/heal_amd.h, heal_sp_neighbor_tiles): one fixed-stride slot per 64
+    output sites, only the used prefix written.  Stands where the [n_out, 27] neighbour table stands in SparseTensor.conv for
+    c_in <= 16; `.to_neighbors()` decodes it into that table (bit for bit what heal_sp_neighbors_rank gives)."""
+
+    def __init__(self, buf, n_out, n_out_dev=None):
+        self.buf, self.n_out, self.n_out_dev = buf, int(n_out), n_out_dev
+        self.shape = (self.n_out, 27)
+        self.device = buf.device
+
+    def to_neighbors(self):
+        nbr = torch.full((self.n_out, 27), -1, dtype=torch.int32, device=self.buf.device)
+        _capi.call("heal_sp_tiles_to_neighbors", _ptr(self.buf), self.n_out, _optr(self.n_out_dev), _ptr(nbr), _stream())
+        return nbr
+
+    def __getitem__(self, key):     # bench.py counts the live pairs of a traced layer through the table
+        return self.to_neighbors()[key]
+
+
+def sp_tiles_enabled():
+    """HEAL_SP_TILES=0: every sparse layer through the [n_out, K] neighbour table (A/B, and what training uses)."""
+    return os.environ.get("HEAL_SP_TILES", "1") != "0"
+
+
 class SparseTensor:
     """features [n,C] f32 + indices [n,4] i32 (b,z,y,x) sorted by linear coordinate + shape (D,H,W).
 
@@ -1262,6 +1286,23 @@ class SparseTensor:
                        _ptr(nbr), _optr(n_out_dev), _stream())
         return nbr
 
+    def rulebook(self, out_indices, out_shape, ksize, stride, padding, cin, cout, n_out_dev=None):
+        """What SparseTensor.conv needs for a (cin -> cout) layer on these output sites: pair tiles when the thin-layer kernel
+        takes the layer (3 x 3 x 3, c_in <= 16, rank-structure path), the neighbour table otherwise."""
+        if not self.tiles_ok(ksize, cin, cout):
+            return self.neighbors(out_indices, out_shape, ksize, stride, padding, n_out_dev=n_out_dev)
+        n_out = int(out_indices.shape[0])
+        buf = torch.empty((_capi.query("heal_sp_pair_tiles_words", n_out),), dtype=torch.int32, device=self.indices.device)
+        with _Timed("sp_rulebook"):
+            _capi.call("heal_sp_neighbor_tiles", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
+                       _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(self._rank), self._rank.numel(),
+                       int(bool(self._rank_root)), self.n, _optr(self.n_dev), _ptr(buf), _optr(n_out_dev), _stream())
+        return PairTiles(buf, n_out, n_out_dev)
+
+    def tiles_ok(self, ksize, cin, cout):
+        return (sp_tiles_enabled() and self._rank is not None and tuple(int(k) for k in ksize) == (3, 3, 3)
+                and self.n < (1 << 26) and bool(_capi.query("heal_sp_conv_tiles_supported", int(cin), int(cout))))
+
     def out_sites(self, ksize, stride, padding):
         """Active output sites of a strided conv: (indices sorted, out_shape, n_out_dev).  Exact-size indices and
         n_out_dev None when this tensor carries host counts; capacity-size indices plus the device count otherwise."""
@@ -1313,9 +1354,17 @@ class SparseTensor:
         # SURVEY 8d, K3 per layer: 4 (N_in C_in + N_out C_out) + 4 K C_in C_out + 8 R bytes, 2 R C_in C_out flops; with device
         # row counts the host only knows capacities: bench.py fills in the live N_in / N_out / R of its instrumented pass
         with _Timed(f"sp_conv_{cin}_{cout}") as tm:
-            _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight), _optr(frag),
-                       _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
-                       int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
+            if isinstance(nbr, PairTiles):
+                if K != 27 or not _capi.query("heal_sp_conv_tiles_supported", cin, cout):
+                    raise ValueError(f"SparseTensor.conv: pair tiles do not serve a {K}-tap {cin} -> {cout} layer "
+                                     "(SparseTensor.rulebook decides per layer)")
+                _capi.call("heal_sp_conv_tiles", _ptr(self.features), _ptr(nbr.buf), n_out, cin, cout, _ptr(frag),
+                           _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
+                           int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
+            else:
+                _capi.call("heal_sp_conv", _ptr(self.features), _ptr(nbr), n_out, K, cin, cout, _ptr(weight), _optr(frag),
+                           _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
+                           int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
         if SP_TRACE is not None and TIMING is not None:
             SP_TRACE.append({"cin": cin, "cout": cout, "K": K, "n_in": self.n_dev if self.n_dev is not None else self.n,
                              "n_out": n_out_dev if n_out_dev is not None else n_out, "nbr": nbr, "events": (tm.e0, tm.e1)})
