@@ -105,13 +105,13 @@ _SIGNATURES = {
     "heal_sp_neighbors_root": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "heal_sp_root_rank_bytes": (c_size_t, [c_void_p, c_int]),
-    "heal_sp_pair_tiles_words": (c_size_t, [c_int]),
+    "heal_sp_pair_tiles_words": (c_size_t, [c_int, c_int]),
     "heal_sp_neighbor_tiles": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                       c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "heal_sp_tiles_to_neighbors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_size_t, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "heal_sp_tiles_to_neighbors": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "heal_sp_conv_tiles_supported": (c_int, [c_int, c_int]),
-    "heal_sp_conv_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                   c_void_p, c_void_p]),
+    "heal_sp_conv_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
     "heal_sp_root_rank": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p, c_void_p]),
     "heal_gconv_conv3_supported": (c_int, [c_int] * 5),

@@ -643,151 +643,129 @@ __global__ __launch_bounds__(256) void k_sp_conv2(const float* __restrict__ feat
 #undef HEAL_SP_W_WAIT
 }
 
-// ---- gather-GEMM, round 6: the thin layers (CIN <= 16) --------------------------------------------------------------------
-// On the 4 -> 16, 16 -> 16 and 16 -> 32 layers of VoxelBackBone8x (sparse_backbone_3d.py:48-62) a tile of 16 pairs is ONE to
-// EIGHT matrix instructions: k_sp_conv2's block-wide stages (barrier + drain per 128-256 gathered rows, 4 blocks per CU) leave
-// the layer waiting on memory latency -- 0.14 of the HBM roof.  Here ONE WAVE owns 64 consecutive output sites and never meets
-// a barrier:
-//   * the 64 x K neighbour words are read as 16-B chunks (the [site][tap] table is contiguous per wave: 6.9 KB) into LDS and
-//     come back transposed, lane = site (stride K = 27 words: conflict-free) -- the tap-strided dword loads of the same words
-//     cost 54 cache lines per instruction;
-//   * every tap's live pairs are compacted by ballot into the SAME LDS words, each tap padded to whole 16-pair tiles (a tap has
-//     <= 64 pairs = 4 tiles, so the list never outgrows the staging area);
-//   * the tiles then stream through a register pipeline D tiles deep: pair word -> input row straight from global memory into
-//     the B fragment (lane (pair, g) reads channels 4g..4g+3: one 16-B load; CIN = 4: one dword), the tap's weight fragment from
-//     heal_sp_weight_fragments' layout (L1 / L2 hits), KC x NC MFMAs, and one 16-B read-modify-write per slice of the wave's
-//     private [64][COUT] accumulator in LDS.  The loads of group i+1 are in flight while group i multiplies; 9-13 such waves
-//     per CU overlap their neighbour-table, gather and store phases;
-//   * LDS operations of one wave execute in order and nothing is shared between waves: a fixed summation order (taps ascending,
-//     pairs in site order), bit-reproducible, no atomics.
-//
-// TILES: the rulebook already IS the list (heal_sp_neighbor_tiles: one fixed-stride slot per 64 output sites holding the tile count,
-// the tap of every tile and the pair tiles, written and read only as far as they are used) -- `nbr` then points at those slots, the
-// staging copies T x 64 B instead of 64 x K x 4 B and nothing is compacted here.
-constexpr int SPT_HDR_WORDS = 32;                            // word 0: tiles T; bytes 4 .. 4 + T: tap of tile i (T <= 108)
-constexpr int SPT_SLOT_WORDS = SPT_HDR_WORDS + 27 * 64;      // 7040 B per 64 output sites
-constexpr uint32_t SPT_PAD = 0xFFFFFFFFu;
+// ---- gather-GEMM, round 6: the thin layers (CIN <= 16) on the pair-tile rulebook ------------------------------------------------
+// On the 4 -> 16, 16 -> 16 and 16 -> 32 layers of VoxelBackBone8x (sparse_backbone_3d.py:48-62) a tile of 16 pairs is ONE to EIGHT
+// matrix instructions: k_sp_conv2's block-wide stages (compaction of the [site][tap] table, barrier + drain per 128-256 gathered
+// rows, 4 blocks per CU) leave such a layer waiting -- 0.14 of the HBM roof.  Here the rulebook already IS the list of pair tiles
+// (k_sp_nbr_tiles below: one fixed-stride slot per S output sites, only its used prefix written and read), ONE WAVE owns a slot
+// and never meets a barrier, and three pipeline stages run straight from global memory: while group i (4 tiles) multiplies, the
+// input rows and weight fragments of group i+1 and the pair words of group i+2 are in flight.
+//   * pair word = input row << SPT_LB(S) | accumulator row; padding pairs read input row 0 and add into a trash row (S) of the
+//     accumulator: no predicate, no branch anywhere in the loop; the slot's tile count is a multiple of 4 (all-padding tiles);
+//   * lane (pair, g) reads channels 4g..4g+3 of its pair's input row (one 16-B load; CIN = 4: one dword, channel g): the B
+//     fragment as it lies; the tap's weight fragment comes from heal_sp_weight_fragments' layout (L1 / L2 hits); KC x NC MFMAs;
+//   * a tile's 16 x 16 result rows belong to 16 different output sites: one 16-B read-modify-write per lane and slice of the
+//     wave's private [S + 1][COUT] accumulator in LDS.  LDS operations of one wave execute in order and nothing is shared
+//     between waves: a fixed summation order (taps ascending per site), bit-reproducible, no atomics;
+//   * LDS holds the accumulator and the tap bytes only (5-19 KB), the register file sets the occupancy (4-8 waves per SIMD).
+// S = 64 or 128 output sites per slot: the first strided layer has 2.5 live taps of 27 per site -- 6 pairs per tap and 64 sites fill
+// 37 % of a 16-pair tile, 128 sites 75 %.
+constexpr int SPT_HDR_WORDS = 64;                            // word 0: tiles T (multiple of 4); bytes 4 .. 4 + T + 4: tap of tile i
+//   (behind the T tiles one more group of 4 all-padding tiles, not counted: what the consumer's pipeline reads past the end)
+__host__ __device__ constexpr int spt_lb(int S) { return S == 64 ? 7 : 8; }
+__host__ __device__ constexpr int spt_slot_words(int S) { return SPT_HDR_WORDS + 27 * S + 128; }   // + padding to 4 tiles + one all-padding group
 
-template <int CIN, int COUT, int D, int DBG = 0, bool TILES = false>
-__global__ __launch_bounds__(64) void k_sp_thin(const float* __restrict__ feat_in, const int* __restrict__ nbr, int out_cap,
-                                                const int* __restrict__ n_dev, int K, const float* __restrict__ wfrag,
-                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                float* __restrict__ feat_out) {
-    static_assert((CIN == 4 || CIN == 16) && COUT % 16 == 0, "shape");
-    constexpr int S = 64;                        // output sites per wave
+template <int CIN, int COUT, int S, int DBG = 0>
+__global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_in, const uint32_t* __restrict__ tiles, int out_cap,
+                                                 const int* __restrict__ n_dev, const float* __restrict__ wfrag,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                 float* __restrict__ feat_out) {
+    static_assert((CIN == 4 || CIN == 16) && COUT % 16 == 0 && (S == 64 || S == 128), "shape");
+    constexpr int D = 4;                         // tiles per pipeline group
+    constexpr int LB = spt_lb(S);
     constexpr int NC = COUT / 16;
     constexpr int RSA = COUT + 4;                // accumulator row stride (words)
-    constexpr int MAXT = 27 * 4;                 // tiles, worst case
-    constexpr uint32_t PAD = 0xFFFFFFFFu;
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[(MAXT + 3 * D) * 16];   // neighbour words, then the pair tiles
-    __shared__ __attribute__((aligned(16))) float s_acc[S * RSA];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tap[MAXT + 3 * D + 4];   // tap of every tile
+    constexpr int MAXT = 27 * S / 16 + 4;
+    constexpr int SLOT = spt_slot_words(S);
+    __shared__ __attribute__((aligned(16))) float s_acc[(S + 1) * RSA];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tap[MAXT / 4 + 2];   // 4 tap bytes per word = one pipeline group
 
     const int n_out = live_rows(n_dev, out_cap);
     const unsigned nb_ = (unsigned)(n_out + S - 1) / S;
     if (blockIdx.x >= nb_) return;
-    // XCD-contiguous site ranges over the LIVE blocks (see k_sp_conv2)
+    // XCD-contiguous site ranges over the LIVE slots (see k_sp_conv2)
     const unsigned q_ = nb_ >> 3, r_ = nb_ & 7u, x_ = blockIdx.x & 7u;
     const int blk = (int)((x_ < r_ ? x_ * (q_ + 1) : r_ * (q_ + 1) + (x_ - r_) * q_) + (blockIdx.x >> 3));
     const int site0 = blk * S;
     const int l = threadIdx.x, g = l >> 4, ln = l & 15;
+    const uint32_t* slot = tiles + (size_t)blk * SLOT;
+    const uint32_t* list = slot + SPT_HDR_WORDS + ln;
+    const int T = min((int)slot[0], MAXT) & ~3;
+    for (int i = l; i < T / 4 + 1; i += 64) s_tap[i] = slot[1 + i];   // + the all-padding group behind the last tile
+    for (int i = l; i < (S + 1) * RSA / 4; i += 64) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    int T = 0;
-    if constexpr (TILES) {
-        const uint32_t* slot = reinterpret_cast<const uint32_t*>(nbr) + (size_t)blk * SPT_SLOT_WORDS;
-        const uint32_t hdr = l < 28 ? slot[l] : 0u;
-        T = (int)__shfl(hdr, 0, 64);
-        if (l >= 1 && l < 28) reinterpret_cast<uint32_t*>(s_tap)[l - 1] = hdr;   // the 108 tap bytes behind word 0
-        const int4* src = reinterpret_cast<const int4*>(slot + SPT_HDR_WORDS);
-        for (int i = l; i < 4 * T; i += 64) reinterpret_cast<int4*>(s_list)[i] = src[i];
-        for (int i = l; i < S * RSA / 4; i += 64) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-        // ---- neighbour words of the wave's sites: 16-B chunks -> LDS -> lane = site ------------------------------------------------
-        {
-            const int words = min(S, out_cap - site0) * K;            // words of this wave that exist in the table
-            const int* src = nbr + (size_t)site0 * K;                 // 256 K bytes per wave: 16-B aligned
-            for (int i = l; i < (S * K + 3) / 4; i += 64) {
-                int4 q;
-                if (4 * i + 3 < words) q = *reinterpret_cast<const int4*>(src + 4 * i);
-                else {
-                    q.x = 4 * i < words ? src[4 * i] : -1;
-                    q.y = 4 * i + 1 < words ? src[4 * i + 1] : -1;
-                    q.z = 4 * i + 2 < words ? src[4 * i + 2] : -1;
-                    q.w = -1;
-                }
-                reinterpret_cast<int4*>(s_list)[i] = q;
-            }
-        }
-        for (int i = l; i < S * RSA / 4; i += 64) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int v[27];
-        const bool live = site0 + l < n_out;
-#pragma unroll
-        for (int t = 0; t < 27; ++t) v[t] = (t < K && live) ? (int)s_list[l * K + t] : -1;
-        // ---- the pair tiles, tap after tap (the reads above precede these writes in the wave's LDS queue) -----------------------------
-#pragma unroll
-        for (int t = 0; t < ((DBG & 16) ? 1 : 27); ++t) {
-            const bool h = v[t] >= 0;
-            const unsigned long long have = __ballot(h);
-            const int cnt = __popcll(have), nt = (cnt + 15) >> 4;
-            if (h) s_list[16 * T + __popcll(have & lanemask_lt())] = ((uint32_t)v[t] << 6) | (uint32_t)l;
-            if (l < 16 * nt - cnt) s_list[16 * T + cnt + l] = PAD;
-            if (l < nt) s_tap[T + l] = (uint8_t)t;
-            T += nt;
-        }
-    }
-    for (int i = l; i < 3 * D * 16; i += 64) s_list[16 * T + i] = PAD;   // what the pipeline reads past the end
-    if (l < 3 * D) s_tap[T + l] = 0;
-
-    // ---- the pipeline ----------------------------------------------------------------------------------------------------------
-    struct Group {
-        uint32_t e[D];
+    const char* fin = reinterpret_cast<const char*>(feat_in) + (CIN == 16 ? 16 * g : 4 * g);
+    const char* wf = reinterpret_cast<const char*>(wfrag) + (CIN == 16 ? 16 * l : 4 * l);
+    constexpr uint32_t WTAP = NC * (CIN == 16 ? 1024u : 256u);   // bytes of one tap's fragments
+    struct Xw {
         f32x4 x[D];                 // CIN = 16: channels 4g..4g+3 of the pair's input row; CIN = 4: .x = channel g
         f32x4 w[D][NC];             // CIN = 16: the four k-steps of (tap, slice); CIN = 4: .x
     };
-    auto fetch = [&](Group& G, int base) {
+    auto load_e = [&](uint32_t (&e)[D], int base) {           // stage 1: pair words (past the end: the all-padding group)
+        const uint32_t* p = list + min(base, T) * 16;
+#pragma unroll
+        for (int q = 0; q < D; ++q) e[q] = p[q * 16];
+    };
+    auto load_xw = [&](const uint32_t (&e)[D], Xw& G, int base) {   // stage 2: input rows + weight fragments
+        const uint32_t taps = (DBG & 2) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tap[min(base, T) >> 2]);
 #pragma unroll
         for (int q = 0; q < D; ++q) {
-            G.e[q] = s_list[(base + q) * 16 + ln];
-            const int tap = (DBG & 2) ? 0 : __builtin_amdgcn_readfirstlane((int)s_tap[base + q]);
-            const size_t row = (G.e[q] == PAD || (DBG & 1)) ? 0 : (size_t)(G.e[q] >> 6);
+            const uint32_t row = (DBG & 1) ? 0u : e[q] >> LB;
+            const char* wt = wf + ((taps >> (8 * q)) & 0xFFu) * WTAP;
             if constexpr (CIN == 16) {
-                G.x[q] = *reinterpret_cast<const f32x4*>(feat_in + row * 16 + 4 * g);
+                G.x[q] = *reinterpret_cast<const f32x4*>(fin + row * 64u);
 #pragma unroll
-                for (int nb = 0; nb < NC; ++nb)
-                    G.w[q][nb] = *reinterpret_cast<const f32x4*>(wfrag + ((size_t)tap * NC + nb) * 256 + l * 4);
+                for (int nb = 0; nb < NC; ++nb) G.w[q][nb] = *reinterpret_cast<const f32x4*>(wt + nb * 1024);
             } else {
-                G.x[q][0] = feat_in[row * 4 + g];
+                G.x[q][0] = *reinterpret_cast<const float*>(fin + row * 16u);
 #pragma unroll
-                for (int nb = 0; nb < NC; ++nb) G.w[q][nb][0] = wfrag[((size_t)tap * NC + nb) * 64 + l];
+                for (int nb = 0; nb < NC; ++nb) G.w[q][nb][0] = *reinterpret_cast<const float*>(wt + nb * 256);
             }
         }
     };
-    auto multiply = [&](const Group& G) {
+    auto multiply = [&](const uint32_t (&e)[D], const Xw& G) {   // stage 3
 #pragma unroll
         for (int q = 0; q < D; ++q) {
+            float* p = &s_acc[(e[q] & (uint32_t)((1 << LB) - 1)) * RSA + 4 * g];
 #pragma unroll
             for (int nb = 0; nb < NC; ++nb) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kc = 0; kc < CIN / 4; ++kc)
                     a = __builtin_amdgcn_mfma_f32_16x16x4f32(G.w[q][nb][kc], G.x[q][kc], a, 0, 0, 0);
-                if ((DBG & 4) ? a[0] == 12345.678f : G.e[q] != PAD) {
-                    float4* p = reinterpret_cast<float4*>(&s_acc[(G.e[q] & 63u) * RSA + nb * 16 + 4 * g]);
-                    float4 o = *p;
+                if constexpr (!(DBG & 4)) {
+                    float4* p4 = reinterpret_cast<float4*>(p + nb * 16);   // (per-dword ds_add_f32 measured 8x slower: 8-way bank conflicts)
+                    float4 o = *p4;
                     o.x += a[0]; o.y += a[1]; o.z += a[2]; o.w += a[3];
-                    *p = o;
-                }
+                    *p4 = o;
+                } else if (a[0] == 12345.678f) p[0] = 1.f;
             }
         }
     };
-    Group A, B;
-    if constexpr (DBG & 8) T = 0;
-    fetch(A, 0);
-    for (int base = 0; base < T; base += 2 * D) {
-        fetch(B, base + D);
-        multiply(A);
-        fetch(A, base + 2 * D);
-        if (base + D < T) multiply(B);
+    if (T > 0 && !(DBG & 8)) {
+        // two register sets for the rows / weights, used alternately by the two halves of the loop body: a copy "C = B" would make
+        // the compiler wait for the loads it has just issued
+        uint32_t eA[D], eB[D], eC[D];
+        Xw X0, X1;
+        load_e(eB, 0);
+        load_e(eA, D);
+        load_xw(eB, X0, 0);
+        for (int base = 0; base < T; base += 2 * D) {
+#pragma unroll
+            for (int q = 0; q < D; ++q) { eC[q] = eB[q]; eB[q] = eA[q]; }
+            load_e(eA, base + 2 * D);
+            load_xw(eB, X1, base + D);
+            __builtin_amdgcn_sched_barrier(0);   // the loads are issued BEFORE the group that hides them multiplies
+            multiply(eC, X0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < D; ++q) { eC[q] = eB[q]; eB[q] = eA[q]; }
+            load_e(eA, base + 3 * D);
+            load_xw(eB, X0, base + 2 * D);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(eC, X1);   // T / 4 odd: the all-padding group (input row 0 into the trash row)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- epilogue: BatchNorm1d (eval) + ReLU, 16-B row stores (the wave's rows are contiguous) -----------------------------------
@@ -1174,71 +1152,91 @@ __global__ __launch_bounds__(256) void k_sp_nbr_transpose(const int* __restrict_
     if (i >= 0 && i < n_in) nbr_t[(size_t)i * K + (int)(t % K)] = (int)(t / K);
 }
 
-// ---- the rulebook as pair tiles (round 6): what k_sp_thin consumes, written directly -----------------------------------------------
-// One wave per 64 output sites, lane = site: the 27 neighbour rows come from the rank structure (the same lookups as k_sp_nbr_rank),
-// every tap's live (input row, site) pairs are compacted by ballot and stored as whole 16-pair tiles into the wave's fixed-stride
-// slot, the tile count and the tap of every tile into its header.  Against the [n_out][27] table: 6.2 of 27 taps are live on the
-// full-resolution submanifold layers (2.5 of 27 on the first strided layer), so the rulebook WRITES ~2.6 KB instead of 6.9 KB per
-// 64 sites, each convolution that uses it READS as much, and none of them compacts anything.
+// ---- the rulebook as pair tiles (round 6): what k_sp_tiles consumes, written directly --------------------------------------------------
+// One wave per S output sites (lane = site, S / 64 sites per lane): the 27 neighbour rows come from the rank structure (the same
+// lookups as k_sp_nbr_rank), every tap's live (input row, site) pairs are compacted by ballot and stored as whole 16-pair tiles into
+// the wave's fixed-stride slot, the tile count and the tap of every tile into its header.  Against the [n_out][27] table: 6.2 of
+// 27 taps are live on the full-resolution submanifold layers (2.5 of 27 on the first strided layer), so the rulebook WRITES
+// ~2.6 KB instead of 6.9 KB per 64 sites, each convolution that uses it READS as much, and none of them compacts anything.
+template <int S>
 __global__ __launch_bounds__(256) void k_sp_nbr_tiles(const int4* __restrict__ out_idx, int out_cap,
                                                      const int* __restrict__ n_dev, SpConvGeom g, SpRank r, int in_cap,
                                                      const int* __restrict__ n_in_dev, uint32_t* __restrict__ tiles) {
+    constexpr int CH = S / 64, LB = spt_lb(S);
+    constexpr uint32_t PADW = (uint32_t)S;       // input row 0 -> the accumulator's trash row
     const int n_out = live_rows(n_dev, out_cap), n_in = live_rows(n_in_dev, in_cap);
     const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), l = threadIdx.x & 63;
-    const int site0 = wave * 64;
+    const int site0 = wave * S;
     if (site0 >= n_out) return;
-    const bool live = site0 + l < n_out;
-    const int4 c = out_idx[live ? site0 + l : site0];
-    const int z0 = c.y * g.s[0] - g.p[0], y0 = c.z * g.s[1] - g.p[1], x0 = c.w * g.s[2] - g.p[2];
-    int v[27];
+    int v[CH][27];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz)
+    for (int c = 0; c < CH; ++c) {
+        const int o = site0 + c * 64 + l;
+        const bool live = o < n_out;
+        const int4 cd = out_idx[live ? o : site0];
+        const int z0 = cd.y * g.s[0] - g.p[0], y0 = cd.z * g.s[1] - g.p[1], x0 = cd.w * g.s[2] - g.p[2];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int z = z0 + kz, y = y0 + ky;
-            const bool line_ok = live && z >= 0 && z < g.in.D && y >= 0 && y < g.in.H;
-            const uint32_t line = line_ok ? sp_key(g.in, c.x, z, y, 0) : 0u;
+        for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int x = x0 + kx;
-                const int row = (line_ok && x >= 0 && x < g.in.W) ? sp_rank_lookup(r, line + (uint32_t)x) : -1;
-                v[(kz * 3 + ky) * 3 + kx] = row < n_in ? row : -1;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int z = z0 + kz, y = y0 + ky;
+                const bool line_ok = live && z >= 0 && z < g.in.D && y >= 0 && y < g.in.H;
+                const uint32_t line = line_ok ? sp_key(g.in, cd.x, z, y, 0) : 0u;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int x = x0 + kx;
+                    const int row = (line_ok && x >= 0 && x < g.in.W) ? sp_rank_lookup(r, line + (uint32_t)x) : -1;
+                    v[c][(kz * 3 + ky) * 3 + kx] = row < n_in ? row : -1;
+                }
             }
-        }
-    uint32_t* slot = tiles + (size_t)wave * SPT_SLOT_WORDS;
+    }
+    uint32_t* slot = tiles + (size_t)wave * spt_slot_words(S);
     uint32_t* list = slot + SPT_HDR_WORDS;
     uint8_t* taps = reinterpret_cast<uint8_t*>(slot + 1);
     int T = 0;
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
-        const bool h = v[t] >= 0;
-        const unsigned long long have = __ballot(h);
-        const int cnt = __popcll(have), nt = (cnt + 15) >> 4;
-        if (h) list[16 * T + __popcll(have & lanemask_lt())] = ((uint32_t)v[t] << 6) | (uint32_t)l;
-        if (l < 16 * nt - cnt) list[16 * T + cnt + l] = SPT_PAD;
+        int n = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const bool h = v[c][t] >= 0;
+            const unsigned long long have = __ballot(h);
+            if (h) list[16 * T + n + __popcll(have & lanemask_lt())] = ((uint32_t)v[c][t] << LB) | (uint32_t)(c * 64 + l);
+            n += __popcll(have);
+        }
+        const int nt = (n + 15) >> 4;
+        if (l < 16 * nt - n) list[16 * T + n + l] = PADW;
         if (l < nt) taps[T + l] = (uint8_t)t;
         T += nt;
     }
-    if (l == 0) slot[0] = (uint32_t)T;
+    // whole groups of 4 tiles for the consumer's pipeline (all-padding tiles of tap 0), and one all-padding group behind them
+    const int Tp = (T + 3) & ~3;
+    for (int i = l; i < 16 * (Tp + 4 - T); i += 64) list[16 * T + i] = PADW;
+    if (l < Tp + 4 - T) taps[T + l] = 0;
+    if (l == 0) slot[0] = (uint32_t)Tp;
 }
 
-// pair tiles -> the [n_out][27] table (tests, the training path, bench's pair counts)
+// pair tiles -> the [n_out][27] table (tests, bench's pair counts)
+template <int S>
 __global__ __launch_bounds__(256) void k_sp_tiles_to_nbr(const uint32_t* __restrict__ tiles, int out_cap,
                                                         const int* __restrict__ n_dev, int* __restrict__ nbr) {
+    constexpr int LB = spt_lb(S);
     const int n_out = live_rows(n_dev, out_cap);
-    const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), l = threadIdx.x & 63;
-    const int site0 = wave * 64;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wave = (int)(blockIdx.x * (256 / 64) + w);
+    const int site0 = wave * S;
     if (site0 >= n_out) return;
-    __shared__ int s_tab[4][64 * 27];
-    int* tab = s_tab[threadIdx.x >> 6];           // wave-private: LDS operations of one wave execute in order
-    const int rows = min(64, n_out - site0);
-    for (int i = l; i < 64 * 27; i += 64) tab[i] = -1;
-    const uint32_t* slot = tiles + (size_t)wave * SPT_SLOT_WORDS;
+    __shared__ int s_tab[4][(S + 1) * 27];
+    int* tab = s_tab[w];                          // wave-private: LDS operations of one wave execute in order
+    const int rows = min(S, n_out - site0);
+    for (int i = l; i < (S + 1) * 27; i += 64) tab[i] = -1;
+    const uint32_t* slot = tiles + (size_t)wave * spt_slot_words(S);
     const int T = (int)slot[0];
     const uint8_t* taps = reinterpret_cast<const uint8_t*>(slot + 1);
     for (int i = l; i < 16 * T; i += 64) {
         const uint32_t e = slot[SPT_HDR_WORDS + i];
-        if (e != SPT_PAD) tab[(int)(e & 63u) * 27 + taps[i >> 4]] = (int)(e >> 6);
+        const int m = (int)(e & (uint32_t)((1 << LB) - 1));
+        if (m < S) tab[m * 27 + taps[i >> 4]] = (int)(e >> LB);
     }
     for (int i = l; i < rows * 27; i += 64) nbr[(size_t)site0 * 27 + i] = tab[i];
 }
@@ -1528,17 +1526,23 @@ extern "C" int heal_sp_neighbors_root(const int32_t* out_indices, int n_out, con
                           rank_bytes, n_in, n_in_dev, nbr, n_out_dev, stream, true);
 }
 
-extern "C" size_t heal_sp_pair_tiles_words(int n_out) { return (size_t)ceil_div(n_out < 1 ? 1 : n_out, 64) * SPT_SLOT_WORDS; }
+static bool slot_sites_ok(int S) { return S == 64 || S == 128; }
+
+extern "C" size_t heal_sp_pair_tiles_words(int n_out, int slot_sites) {
+    if (!slot_sites_ok(slot_sites)) return 0;
+    return (size_t)ceil_div(n_out < 1 ? 1 : n_out, slot_sites) * spt_slot_words(slot_sites);
+}
 
 extern "C" int heal_sp_neighbor_tiles(const int32_t* out_indices, int n_out, const int32_t* ksize_host,
                                       const int32_t* stride_host, const int32_t* padding_host,
                                       const int32_t* in_shape_host, const int32_t* out_shape_host, int batch,
                                       const void* rank, size_t rank_bytes, int root, int n_in, const int32_t* n_in_dev,
-                                      uint32_t* tiles, const int32_t* n_out_dev, void* stream) {
+                                      int slot_sites, uint32_t* tiles, const int32_t* n_out_dev, void* stream) {
     SpConvGeom g;
     if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
     HEAL_REQUIRE(g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3, "sp_neighbor_tiles: 3 x 3 x 3 kernels only");
-    HEAL_REQUIRE(n_in < (1 << 26), "sp_neighbor_tiles: %d input rows do not fit the pair word", n_in);
+    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_neighbor_tiles: %d sites per slot (64 or 128)", slot_sites);
+    HEAL_REQUIRE(n_in < (1 << 24), "sp_neighbor_tiles: %d input rows do not fit the pair word", n_in);
     if (n_out <= 0) return 0;
     const size_t words = rank_words(g.in), gran = words / 8;
     Arena a(const_cast<void*>(rank), rank_bytes);
@@ -1547,15 +1551,21 @@ extern "C" int heal_sp_neighbor_tiles(const int32_t* out_indices, int n_out, con
     r.base = a.take<int>(gran);
     r.l1 = root ? a.take<uint32_t>((gran + 31) / 32) : nullptr;
     HEAL_REQUIRE(a.ok() && ((uintptr_t)rank & 255) == 0 && ((uintptr_t)tiles & 15) == 0, "sp_neighbor_tiles: bad rank / tile buffer");
-    k_sp_nbr_tiles<<<ceil_div(n_out, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const int4*>(out_indices), n_out,
-                                                                         n_out_dev, g, r, n_in, n_in_dev, tiles);
+    const int4* oi = reinterpret_cast<const int4*>(out_indices);
+    if (slot_sites == 64)
+        k_sp_nbr_tiles<64><<<ceil_div(n_out, 256), 256, 0, (hipStream_t)stream>>>(oi, n_out, n_out_dev, g, r, n_in, n_in_dev, tiles);
+    else
+        k_sp_nbr_tiles<128><<<ceil_div(n_out, 512), 256, 0, (hipStream_t)stream>>>(oi, n_out, n_out_dev, g, r, n_in, n_in_dev, tiles);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int heal_sp_tiles_to_neighbors(const uint32_t* tiles, int n_out, const int32_t* n_out_dev, int32_t* nbr, void* stream) {
+extern "C" int heal_sp_tiles_to_neighbors(const uint32_t* tiles, int n_out, int slot_sites, const int32_t* n_out_dev, int32_t* nbr,
+                                          void* stream) {
+    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_tiles_to_neighbors: %d sites per slot (64 or 128)", slot_sites);
     if (n_out <= 0) return 0;
-    k_sp_tiles_to_nbr<<<ceil_div(n_out, 256), 256, 0, (hipStream_t)stream>>>(tiles, n_out, n_out_dev, nbr);
+    if (slot_sites == 64) k_sp_tiles_to_nbr<64><<<ceil_div(n_out, 256), 256, 0, (hipStream_t)stream>>>(tiles, n_out, n_out_dev, nbr);
+    else k_sp_tiles_to_nbr<128><<<ceil_div(n_out, 512), 256, 0, (hipStream_t)stream>>>(tiles, n_out, n_out_dev, nbr);
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -1631,38 +1641,6 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
         const int env_tx = getenv("HEAL_SP_TPSX") ? atoi(getenv("HEAL_SP_TPSX")) : 0;
         const int env_db = getenv("HEAL_SP_DB") ? atoi(getenv("HEAL_SP_DB")) : -1;
         const int dbg = HEAL_DEBUG_ENV("HEAL_SP_DBG");
-        // round 6: the thin layers on the barrier-free one-wave-per-64-sites kernel (HEAL_SP_THIN=0: k_sp_conv2 as before;
-        // HEAL_SP_THIN_D = pipeline depth, tuning only)
-        {
-            const char* thin = getenv("HEAL_SP_THIN");
-            const int depth = getenv("HEAL_SP_THIN_D") ? atoi(getenv("HEAL_SP_THIN_D")) : 0;
-            const int tdbg = HEAL_DEBUG_ENV("HEAL_SP_THIN_DBG");
-            if (!(thin && thin[0] == '0') && c_in <= 16 && kernel_volume <= 27) {
-#define HEAL_SPT_DBG(CI, CO, G)                                                                                          \
-    if (tdbg == G) {                                                                                                     \
-        k_sp_thin<CI, CO, 4, G><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, nbr, n_out, n_out_dev, kernel_volume,        \
-                                                                   weight_frag, bn_scale, bn_shift, relu, feat_out);     \
-        HEAL_LAUNCH_CHECK();                                                                                             \
-        return 0;                                                                                                        \
-    }
-#define HEAL_SPT(CI, CO, DEF_D)                                                                                          \
-    if (c_in == CI && c_out == CO) {                                                                                     \
-        const int d_ = depth ? depth : DEF_D;                                                                            \
-        HEAL_SPT_DBG(CI, CO, 1) HEAL_SPT_DBG(CI, CO, 2) HEAL_SPT_DBG(CI, CO, 4) HEAL_SPT_DBG(CI, CO, 8) HEAL_SPT_DBG(CI, CO, 16) HEAL_SPT_DBG(CI, CO, 7) \
-        if (d_ == 2) k_sp_thin<CI, CO, 2><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, nbr, n_out, n_out_dev, kernel_volume, \
-                                                                            weight_frag, bn_scale, bn_shift, relu, feat_out); \
-        else if (d_ == 8) k_sp_thin<CI, CO, 8><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, nbr, n_out, n_out_dev, kernel_volume, \
-                                                                            weight_frag, bn_scale, bn_shift, relu, feat_out); \
-        else k_sp_thin<CI, CO, 4><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, nbr, n_out, n_out_dev, kernel_volume,      \
-                                                                     weight_frag, bn_scale, bn_shift, relu, feat_out);   \
-        HEAL_LAUNCH_CHECK();                                                                                             \
-        return 0;                                                                                                        \
-    }
-                HEAL_SPT(4, 16, 4) HEAL_SPT(16, 16, 4) HEAL_SPT(16, 32, 4)
-#undef HEAL_SPT
-#undef HEAL_SPT_DBG
-            }
-        }
 #define HEAL_SP2(CI, CO, MM, TT, DD, GG)                                                                                 \
     {                                                                                                                    \
         k_sp_conv2<CI, CO, MM, TT, DD, GG><<<ceil_div(n_out, MM), 256, 0, s>>>(feat_in, nbr, n_out, n_out_dev,           \
@@ -1718,28 +1696,34 @@ extern "C" int heal_sp_conv_tiles_supported(int c_in, int c_out) {
     return (c_in == 4 && c_out == 16) || (c_in == 16 && (c_out == 16 || c_out == 32));
 }
 
-extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, int n_out, int c_in, int c_out,
+extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, int n_out, int slot_sites, int c_in, int c_out,
                                   const float* weight_frag, const float* bn_scale, const float* bn_shift, int relu,
                                   float* feat_out, const int32_t* n_out_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n_out <= 0) return 0;
     HEAL_REQUIRE(weight_frag != nullptr, "sp_conv_tiles: weight fragments (heal_sp_weight_fragments) are required");
-    const int depth = getenv("HEAL_SP_THIN_D") ? atoi(getenv("HEAL_SP_THIN_D")) : 0;
-    const int* tl = reinterpret_cast<const int*>(tiles);
-#define HEAL_SPTT(CI, CO, DEF_D)                                                                                         \
-    if (c_in == CI && c_out == CO) {                                                                                     \
-        const int d_ = depth ? depth : DEF_D;                                                                            \
-        if (d_ == 2) k_sp_thin<CI, CO, 2, 0, true><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, tl, n_out, n_out_dev, 27,  \
-                                                                                    weight_frag, bn_scale, bn_shift, relu, feat_out); \
-        else if (d_ == 8) k_sp_thin<CI, CO, 8, 0, true><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, tl, n_out, n_out_dev, 27, \
-                                                                                    weight_frag, bn_scale, bn_shift, relu, feat_out); \
-        else k_sp_thin<CI, CO, 4, 0, true><<<ceil_div(n_out, 64), 64, 0, s>>>(feat_in, tl, n_out, n_out_dev, 27,          \
-                                                                             weight_frag, bn_scale, bn_shift, relu, feat_out); \
+    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_conv_tiles: %d sites per slot (64 or 128)", slot_sites);
+    const int dbg = HEAL_DEBUG_ENV("HEAL_SP_TILES_DBG");
+#define HEAL_SPTL(CI, CO, SS, GG)                                                                                        \
+    {                                                                                                                    \
+        k_sp_tiles<CI, CO, SS, GG><<<ceil_div(n_out, SS), 64, 0, s>>>(feat_in, tiles, n_out, n_out_dev, weight_frag,      \
+                                                                      bn_scale, bn_shift, relu, feat_out);               \
         HEAL_LAUNCH_CHECK();                                                                                             \
         return 0;                                                                                                        \
     }
-    HEAL_SPTT(4, 16, 4) HEAL_SPTT(16, 16, 4) HEAL_SPTT(16, 32, 4)
+#define HEAL_SPTT(CI, CO)                                                                                                \
+    if (c_in == CI && c_out == CO) {                                                                                     \
+        if (slot_sites == 128) HEAL_SPTL(CI, CO, 128, 0)                                                                 \
+        if (dbg == 1) HEAL_SPTL(CI, CO, 64, 1)                                                                           \
+        if (dbg == 2) HEAL_SPTL(CI, CO, 64, 2)                                                                           \
+        if (dbg == 4) HEAL_SPTL(CI, CO, 64, 4)                                                                           \
+        if (dbg == 7) HEAL_SPTL(CI, CO, 64, 7)                                                                           \
+        if (dbg == 8) HEAL_SPTL(CI, CO, 64, 8)                                                                           \
+        HEAL_SPTL(CI, CO, 64, 0)                                                                                         \
+    }
+    HEAL_SPTT(4, 16) HEAL_SPTT(16, 16) HEAL_SPTT(16, 32)
 #undef HEAL_SPTT
+#undef HEAL_SPTL
     return set_error("sp_conv_tiles: channel combination %d -> %d is not instantiated", c_in, c_out);
 }
 

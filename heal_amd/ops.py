@@ -1176,14 +1176,15 @@ class PairTiles:
     output sites, only the used prefix written.  Stands where the [n_out, 27] neighbour table stands in SparseTensor.conv for
     c_in <= 16; `.to_neighbors()` decodes it into that table (bit for bit what heal_sp_neighbors_rank gives)."""
 
-    def __init__(self, buf, n_out, n_out_dev=None):
-        self.buf, self.n_out, self.n_out_dev = buf, int(n_out), n_out_dev
+    def __init__(self, buf, n_out, n_out_dev=None, slot_sites=64):
+        self.buf, self.n_out, self.n_out_dev, self.slot_sites = buf, int(n_out), n_out_dev, int(slot_sites)
         self.shape = (self.n_out, 27)
         self.device = buf.device
 
     def to_neighbors(self):
         nbr = torch.full((self.n_out, 27), -1, dtype=torch.int32, device=self.buf.device)
-        _capi.call("heal_sp_tiles_to_neighbors", _ptr(self.buf), self.n_out, _optr(self.n_out_dev), _ptr(nbr), _stream())
+        _capi.call("heal_sp_tiles_to_neighbors", _ptr(self.buf), self.n_out, self.slot_sites, _optr(self.n_out_dev), _ptr(nbr),
+                   _stream())
         return nbr
 
     def __getitem__(self, key):     # bench.py counts the live pairs of a traced layer through the table
@@ -1292,16 +1293,19 @@ class SparseTensor:
         if not self.tiles_ok(ksize, cin, cout):
             return self.neighbors(out_indices, out_shape, ksize, stride, padding, n_out_dev=n_out_dev)
         n_out = int(out_indices.shape[0])
-        buf = torch.empty((_capi.query("heal_sp_pair_tiles_words", n_out),), dtype=torch.int32, device=self.indices.device)
+        # sites per slot: a strided layer has few live taps per site (2.5 of 27 on conv2's SparseConv3d) -- 128 sites fill its 16-pair
+        # tiles twice as well as 64
+        sites = int(os.environ.get("HEAL_SP_SLOT_SITES", 0)) or (64 if tuple(int(v) for v in stride) == (1, 1, 1) else 128)
+        buf = torch.empty((_capi.query("heal_sp_pair_tiles_words", n_out, sites),), dtype=torch.int32, device=self.indices.device)
         with _Timed("sp_rulebook"):
             _capi.call("heal_sp_neighbor_tiles", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
                        _i3(self.spatial_shape), _i3(out_shape), self.batch_size, _ptr(self._rank), self._rank.numel(),
-                       int(bool(self._rank_root)), self.n, _optr(self.n_dev), _ptr(buf), _optr(n_out_dev), _stream())
-        return PairTiles(buf, n_out, n_out_dev)
+                       int(bool(self._rank_root)), self.n, _optr(self.n_dev), sites, _ptr(buf), _optr(n_out_dev), _stream())
+        return PairTiles(buf, n_out, n_out_dev, sites)
 
     def tiles_ok(self, ksize, cin, cout):
         return (sp_tiles_enabled() and self._rank is not None and tuple(int(k) for k in ksize) == (3, 3, 3)
-                and self.n < (1 << 26) and bool(_capi.query("heal_sp_conv_tiles_supported", int(cin), int(cout))))
+                and self.n < (1 << 24) and bool(_capi.query("heal_sp_conv_tiles_supported", int(cin), int(cout))))
 
     def out_sites(self, ksize, stride, padding):
         """Active output sites of a strided conv: (indices sorted, out_shape, n_out_dev).  Exact-size indices and
@@ -1358,7 +1362,7 @@ class SparseTensor:
                 if K != 27 or not _capi.query("heal_sp_conv_tiles_supported", cin, cout):
                     raise ValueError(f"SparseTensor.conv: pair tiles do not serve a {K}-tap {cin} -> {cout} layer "
                                      "(SparseTensor.rulebook decides per layer)")
-                _capi.call("heal_sp_conv_tiles", _ptr(self.features), _ptr(nbr.buf), n_out, cin, cout, _ptr(frag),
+                _capi.call("heal_sp_conv_tiles", _ptr(self.features), _ptr(nbr.buf), n_out, nbr.slot_sites, cin, cout, _ptr(frag),
                            _ptr(_need(bn_scale, torch.float32, "bn_scale")), _ptr(_need(bn_shift, torch.float32, "bn_shift")),
                            int(bool(relu)), _ptr(out), _optr(n_out_dev), _stream())
             else:

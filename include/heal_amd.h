@@ -384,23 +384,25 @@ int heal_sp_neighbors_root(const int32_t* out_indices, int n_out, const int32_t*
                            const int32_t* out_shape_host, int batch, const void* rank, size_t rank_bytes,
                            int n_in, const int32_t* n_in_dev, int32_t* nbr, const int32_t* n_out_dev, void* stream);
 /* The rulebook as PAIR TILES (round 6), for the layers with c_in <= 16 (sparse_backbone_3d.py:48-62: conv_input, conv1, the first
- * SparseConv3d of conv2): instead of the [n_out][27] table, every 64 consecutive output sites own one fixed-stride slot of
- * heal_sp_pair_tiles_words(64) words -- word 0: tile count T; bytes 4 .. 4+T: the tap of tile i; from word 32: T tiles of 16 pair
- * words (input row << 6 | site - site0; 0xFFFFFFFF = padding), taps ascending, pairs in site order.  Only the used prefix of a slot
- * is written and read (6.2 of 27 taps are live at full resolution).  3 x 3 x 3 kernels, rank-structure path (`root` selects the
- * two-level structure of heal_sp_root_rank), n_in < 2^26.  heal_sp_conv_tiles = heal_sp_conv on such a rulebook (same result up to
- * the order of the fp32 sums: taps ascending per site in both); heal_sp_tiles_to_neighbors decodes the slots into the
- * [n_out][27] table heal_sp_neighbors_rank / _root would have produced, bit for bit (tests, the training path). */
-size_t heal_sp_pair_tiles_words(int n_out);
+ * SparseConv3d of conv2): instead of the [n_out][27] table, every `slot_sites` (64 or 128) consecutive output sites own one
+ * fixed-stride slot of 64 + 27 slot_sites + 128 words -- word 0: tile count T (a multiple of 4); bytes 4 .. 4+T: the tap of tile i;
+ * from word 64: T tiles of 16 pair words, taps ascending, pairs in site order (+ 4 uncounted all-padding tiles).  Pair word = input row << (7 | 8) | site - site0;
+ * a padding pair is input row 0 with site = slot_sites.  Only the used prefix of a slot is written and read (6.2 of 27 taps are
+ * live at full resolution).  3 x 3 x 3 kernels, rank-structure path (`root` selects the two-level structure of
+ * heal_sp_root_rank), n_in < 2^24.  heal_sp_conv_tiles = heal_sp_conv on such a rulebook (fp32 MFMA, fixed summation order: taps
+ * ascending per site); heal_sp_tiles_to_neighbors decodes the slots into the [n_out][27] table heal_sp_neighbors_rank / _root
+ * would have produced, bit for bit (tests). */
+size_t heal_sp_pair_tiles_words(int n_out, int slot_sites);
 int heal_sp_neighbor_tiles(const int32_t* out_indices, int n_out, const int32_t* ksize_host, const int32_t* stride_host,
                            const int32_t* padding_host, const int32_t* in_shape_host, const int32_t* out_shape_host,
                            int batch, const void* rank, size_t rank_bytes, int root, int n_in, const int32_t* n_in_dev,
-                           uint32_t* tiles, const int32_t* n_out_dev, void* stream);
-int heal_sp_tiles_to_neighbors(const uint32_t* tiles, int n_out, const int32_t* n_out_dev, int32_t* nbr, void* stream);
+                           int slot_sites, uint32_t* tiles, const int32_t* n_out_dev, void* stream);
+int heal_sp_tiles_to_neighbors(const uint32_t* tiles, int n_out, int slot_sites, const int32_t* n_out_dev, int32_t* nbr,
+                               void* stream);
 int heal_sp_conv_tiles_supported(int c_in, int c_out);
-int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, int n_out, int c_in, int c_out, const float* weight_frag,
-                       const float* bn_scale, const float* bn_shift, int relu, float* feat_out, const int32_t* n_out_dev,
-                       void* stream);
+int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, int n_out, int slot_sites, int c_in, int c_out,
+                       const float* weight_frag, const float* bn_scale, const float* bn_shift, int relu, float* feat_out,
+                       const int32_t* n_out_dev, void* stream);
 /* Training: nbr_t [n_in, K] i32 <- the transposed rulebook (nbr_t[i][tap] = o where nbr[o][tap] = i, else -1).  The gradient of
  * heal_sp_conv with respect to its input features is heal_sp_conv itself on (grad_out, nbr_t, weight[tap]^T, scale 1, shift 0,
  * no ReLU): a sparse backward -- no dense grid anywhere.                                                    */

@@ -20,10 +20,29 @@ LAYERS = [  # (cin, cout, ksize, stride, padding, subm, key)
     (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, "subm4"), (64, 64, (3, 1, 1), (2, 1, 1), (0, 0, 0), False, None)]
 
 
+GRAPH = False
+
+
 def timed(fn, iters):
     for _ in range(2):
-        fn()
+        out = fn()
     torch.cuda.synchronize()
+    if GRAPH:   # the launches of `iters` calls replayed from a captured graph: no host time between the kernels
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                for _ in range(iters):
+                    out = fn()
+            gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(3):
+                gr.replay()
+            e1.record(st)
+            torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1) * 1e3 / (3 * iters)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -59,7 +78,9 @@ def main():
     ap.add_argument("--brief", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="timing anatomy runs (HEAL_SP_THIN_DBG / HEAL_SP_DBG): outputs are invalid")
     ap.add_argument("--layers", type=int, default=len(LAYERS), help="only the first N layers")
+    ap.add_argument("--graph", action="store_true", help="time the conv launches as replays of a captured graph")
     a = ap.parse_args()
+    global GRAPH
     modes = a.modes.split(",")
     dev = torch.device("cuda:0")
     R = configs.FULL_RANGE
@@ -133,7 +154,9 @@ def main():
         for m in modes:
             set_mode(m)
             rule = tiles if (m.startswith("tiles") and tiles is not None) else nbr
+            GRAPH = a.graph
             out, us = timed(lambda: x.conv(rule, w, sc, sh), a.iters)
+            GRAPH = False
             outs[m] = out
             total[m] += us
             row[m] = {"us": round(us, 1), "TFLOP/s": round(flops / us * 1e-6, 2), "GB/s": round(nbytes / us * 1e-3, 1)}
