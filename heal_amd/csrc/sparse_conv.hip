@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_sp_conv2(const float* __restrict__ feat
 // matrix instructions: k_sp_conv2's block-wide stages (compaction of the [site][tap] table, barrier + drain per 128-256 gathered
 // rows, 4 blocks per CU) leave such a layer waiting -- 0.14 of the HBM roof.  Here the rulebook already IS the list of pair tiles
 // (k_sp_nbr_tiles below: one fixed-stride slot per S output sites, only its used prefix written and read), ONE WAVE owns a slot
-// and never meets a barrier, and three pipeline stages run straight from global memory: while group i (4 tiles) multiplies, the
+// and never meets a barrier, and three pipeline stages run straight from global memory: while group i (2 tiles) multiplies, the
 // input rows and weight fragments of group i+1 and the pair words of group i+2 are in flight.
 //   * pair word = input row << SPT_LB(S) | accumulator row; padding pairs read input row 0 and add into a trash row (S) of the
 //     accumulator: no predicate, no branch anywhere in the loop; the slot's tile count is a multiple of 4 (all-padding tiles);
@@ -658,20 +658,24 @@ __global__ __launch_bounds__(256) void k_sp_conv2(const float* __restrict__ feat
 //     wave's private [S + 1][COUT] accumulator in LDS.  LDS operations of one wave execute in order and nothing is shared
 //     between waves: a fixed summation order (taps ascending per site), bit-reproducible, no atomics;
 //   * LDS holds the accumulator and the tap bytes only (5-19 KB), the register file sets the occupancy (4-8 waves per SIMD).
-// S = 64 or 128 output sites per slot: the first strided layer has 2.5 live taps of 27 per site -- 6 pairs per tap and 64 sites fill
-// 37 % of a 16-pair tile, 128 sites 75 %.
+// S = 64 or 128 output sites per slot (the caller's choice; measured, profiles/r06_k3_thin.json): 128 sites fill the 16-pair tiles
+// better (0.73 -> 0.84 on the submanifold layers, 0.5 -> 0.68 on the first strided layer with its 2.5 live taps of 27 per site) and
+// save 5 us on that layer, but k_sp_nbr_tiles<128> has half the waves for the same lookups and loses 22 us: 64 is the default.
+// What bounds the kernel (PMC, profiles/r06_k3_tiles_pmc.txt): a 20-50 us kernel of 5 300 one-wave blocks whose waves live 12-15 us
+// each -- launch ramp, a chain of three dependent round trips before the first MFMA, and the matrix pipe itself (24 M busy cycles =
+// 10 us per SIMD on 16 -> 16: a 16-pair fp32 tile is 4 x 32 cycles whether 6 or 16 of its rows are real).
 constexpr int SPT_HDR_WORDS = 64;                            // word 0: tiles T (multiple of 4); bytes 4 .. 4 + T + 4: tap of tile i
 //   (behind the T tiles one more group of 4 all-padding tiles, not counted: what the consumer's pipeline reads past the end)
 __host__ __device__ constexpr int spt_lb(int S) { return S == 64 ? 7 : 8; }
 __host__ __device__ constexpr int spt_slot_words(int S) { return SPT_HDR_WORDS + 27 * S + 128; }   // + padding to 4 tiles + one all-padding group
 
-template <int CIN, int COUT, int S, int DBG = 0>
+template <int CIN, int COUT, int S, int DBG = 0, int D = 2>
 __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_in, const uint32_t* __restrict__ tiles, int out_cap,
                                                  const int* __restrict__ n_dev, const float* __restrict__ wfrag,
                                                  const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                  float* __restrict__ feat_out) {
     static_assert((CIN == 4 || CIN == 16) && COUT % 16 == 0 && (S == 64 || S == 128), "shape");
-    constexpr int D = 4;                         // tiles per pipeline group
+    static_assert(D == 4 || D == 2, "tiles per pipeline group");
     constexpr int LB = spt_lb(S);
     constexpr int NC = COUT / 16;
     constexpr int RSA = COUT + 4;                // accumulator row stride (words)
@@ -707,7 +711,8 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
         for (int q = 0; q < D; ++q) e[q] = p[q * 16];
     };
     auto load_xw = [&](const uint32_t (&e)[D], Xw& G, int base) {   // stage 2: input rows + weight fragments
-        const uint32_t taps = (DBG & 2) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tap[min(base, T) >> 2]);
+        const int b_ = min(base, T);
+        const uint32_t taps = (DBG & 2) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tap[b_ >> 2]) >> (8 * (b_ & 3));
 #pragma unroll
         for (int q = 0; q < D; ++q) {
             const uint32_t row = (DBG & 1) ? 0u : e[q] >> LB;
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
 
     // ---- epilogue: BatchNorm1d (eval) + ReLU, 16-B row stores (the wave's rows are contiguous) -----------------------------------
     constexpr int C4 = COUT / 4;
-#pragma unroll
+#pragma unroll 2
     for (int i0 = 0; i0 < S * C4; i0 += 64) {
         const int i = i0 + l, m = i / C4, c4 = i - m * C4;
         if (site0 + m < n_out) {
@@ -1704,12 +1709,20 @@ extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, i
     HEAL_REQUIRE(weight_frag != nullptr, "sp_conv_tiles: weight fragments (heal_sp_weight_fragments) are required");
     HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_conv_tiles: %d sites per slot (64 or 128)", slot_sites);
     const int dbg = HEAL_DEBUG_ENV("HEAL_SP_TILES_DBG");
-#define HEAL_SPTL(CI, CO, SS, GG)                                                                                        \
+    // tiles per pipeline group (HEAL_SP_TILES_D=4: A/B).  Measured on the three layers of config 5 (profiles/r06_k3_thin.json):
+    // groups of 2 tiles 21.7 / 32.7 / 48.4 us on 36 / 64 / 88 VGPRs, groups of 4 22.2 / 34.9 / 52.5 us on 52 / 104 / 148
+    const int four = getenv("HEAL_SP_TILES_D") && atoi(getenv("HEAL_SP_TILES_D")) == 4;
+#define HEAL_SPTL2(CI, CO, SS, GG, DD)                                                                                   \
     {                                                                                                                    \
-        k_sp_tiles<CI, CO, SS, GG><<<ceil_div(n_out, SS), 64, 0, s>>>(feat_in, tiles, n_out, n_out_dev, weight_frag,      \
-                                                                      bn_scale, bn_shift, relu, feat_out);               \
+        k_sp_tiles<CI, CO, SS, GG, DD><<<ceil_div(n_out, SS), 64, 0, s>>>(feat_in, tiles, n_out, n_out_dev, weight_frag,  \
+                                                                          bn_scale, bn_shift, relu, feat_out);           \
         HEAL_LAUNCH_CHECK();                                                                                             \
         return 0;                                                                                                        \
+    }
+#define HEAL_SPTL(CI, CO, SS, GG)                                                                                        \
+    {                                                                                                                    \
+        if (GG == 0 && four) HEAL_SPTL2(CI, CO, SS, 0, 4)                                                                \
+        HEAL_SPTL2(CI, CO, SS, GG, 2)                                                                                    \
     }
 #define HEAL_SPTT(CI, CO)                                                                                                \
     if (c_in == CI && c_out == CO) {                                                                                     \
@@ -1724,6 +1737,7 @@ extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, i
     HEAL_SPTT(4, 16) HEAL_SPTT(16, 16) HEAL_SPTT(16, 32)
 #undef HEAL_SPTT
 #undef HEAL_SPTL
+#undef HEAL_SPTL2
     return set_error("sp_conv_tiles: channel combination %d -> %d is not instantiated", c_in, c_out);
 }
 

@@ -149,6 +149,11 @@ def main():
                 tiles, t = timed(lambda: x.rulebook(oi, oshape, k, st_, pd_, cin, cout), 5)
                 rb["nbr_tiles"] = rb.get("nbr_tiles", 0.0) + t
                 assert torch.equal(tiles.to_neighbors(), nbr), "pair tiles do not decode to the neighbour table"
+                sw = tiles.buf.numel() // ((n_out_ := int(oi.shape[0])) + tiles.slot_sites - 1) * 1
+                slots = (n_out_ + tiles.slot_sites - 1) // tiles.slot_sites
+                T_sum = int(tiles.buf.view(slots, -1)[:, 0].sum().item())
+                rb.setdefault("tile_fill", {})[f"L{li}"] = {"slot_sites": tiles.slot_sites, "tiles": T_sum,
+                                                           "fill": round(int((nbr >= 0).sum().item()) / (16.0 * T_sum), 3)}
                 if tkey is not None:
                     cache[("tiles", tkey)] = tiles
         for m in modes:
@@ -186,7 +191,7 @@ def main():
         x_rank = x._rank if subm else rank
         x = ops.SparseTensor(outs[modes[-1]], oi, oshape, a.agents)
         x._rank = x_rank
-    summ = {"total_conv_us": {m: round(t, 1) for m, t in total.items()}, "rulebook_us": {k: round(t, 1) for k, t in rb.items()}}
+    summ = {"total_conv_us": {m: round(t, 1) for m, t in total.items()}, "rulebook_us": {k: (round(t, 1) if not isinstance(t, dict) else t) for k, t in rb.items()}}
     print(json.dumps(summ))
     if a.json:
         with open(a.json, "w") as f:

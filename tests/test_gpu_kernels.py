@@ -637,6 +637,63 @@ def test_sparse_conv_layer_vs_dense_oracle(cin, cout, ksize, stride, padding, su
     np.testing.assert_allclose(got, ref.numpy(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("slot_sites", [64, 128])
+@pytest.mark.parametrize("cin,cout,stride,padding,subm", [
+    (4, 16, (1, 1, 1), (1, 1, 1), True), (16, 16, (1, 1, 1), (1, 1, 1), True), (16, 32, (2, 2, 2), (1, 1, 1), False)])
+def test_sparse_conv_on_pair_tiles_vs_dense_oracle(cin, cout, stride, padding, subm, slot_sites, monkeypatch):
+    """Round 6, the c_in <= 16 layers of VoxelBackBone8x (sparse_backbone_3d.py:48-62) on the pair-tile rulebook
+    (heal_sp_neighbor_tiles + heal_sp_conv_tiles): the tiles decode to the neighbour table BIT FOR BIT (an index computation), the
+    convolution matches the dense restatement, two runs are bit-identical (fixed summation order), and the device-count mode
+    (capacity-sized buffers, live rows on the device) gives the same rows."""
+    from heal_amd import ops
+    monkeypatch.setenv("HEAL_SP_SLOT_SITES", str(slot_sites))
+    rng = np.random.default_rng(cin * 11 + cout + slot_sites)
+    shape, batch, ksize = (11, 24, 20), 2, (3, 3, 3)
+    idx = _random_sites(rng, 1500, shape, batch)
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    w = (rng.standard_normal(ksize + (cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.uniform(0.8, 1.2, cout).astype(np.float32); b = rng.normal(0, 0.1, cout).astype(np.float32)
+    mu = rng.normal(0, 0.1, cout).astype(np.float32); var = rng.uniform(0.7, 1.3, cout).astype(np.float32)
+    scale = (g / np.sqrt(var + np.float32(1e-3))).astype(np.float32); shift = (b - mu * scale).astype(np.float32)
+    wd, sc, sh = dev(w.reshape(27, cin, cout)), dev(scale), dev(shift)
+
+    def layer(x):
+        if subm:
+            oi, oshape, n_dev = x.indices, list(shape), x.n_dev
+            st, pd = (1, 1, 1), (1, 1, 1)
+        else:
+            oi, oshape, n_dev, rank = x.out_sites_ex(ksize, stride, padding)
+            st, pd = stride, padding
+        assert x.tiles_ok(ksize, cin, cout)
+        tiles = x.rulebook(oi, oshape, ksize, st, pd, cin, cout, n_out_dev=n_dev)
+        assert isinstance(tiles, ops.PairTiles) and tiles.slot_sites == slot_sites
+        nbr = x.neighbors(oi, oshape, ksize, st, pd, n_out_dev=n_dev)
+        out = x.conv(tiles, wd, sc, sh, n_out_dev=n_dev)
+        rows = int(n_dev.item()) if n_dev is not None else int(out.shape[0])   # rows behind the live count are never written
+        assert torch.equal(out[:rows], x.conv(tiles, wd, sc, sh, n_out_dev=n_dev)[:rows])
+        via_table = x.conv(nbr, wd, sc, sh, n_out_dev=n_dev)
+        return oi, oshape, n_dev, tiles, nbr, out, via_table
+
+    x = ops.SparseTensor.from_unsorted(dev(feats), dev(idx), shape, batch)
+    oi, oshape, _, tiles, nbr, out, via_table = layer(x)
+    assert torch.equal(tiles.to_neighbors(), nbr)
+    dense, mask = O.densify(feats, idx, shape, batch)
+    ref, rmask = O.sparse_conv_dense(dense, mask, w, ksize, stride if not subm else (1, 1, 1), padding, subm, g, b, mu, var)
+    got = _dense_from(ops.SparseTensor(out, oi, oshape, batch))
+    np.testing.assert_allclose(got, ref.numpy(), rtol=1e-3, atol=1e-4)
+    # against the neighbour-table kernel: the same products, another order of the fp32 sums
+    assert float((out - via_table).abs().max()) < 1e-5 * float(via_table.abs().max() + 1)
+    # device-count mode: capacity 2 x the rows, the live count on the device
+    n = len(idx)
+    fpad = np.concatenate([feats, np.full((77, cin), 7.0, np.float32)])    # padding rows behind the live ones
+    ipad = np.concatenate([idx, np.full((77, 4), 3, np.int32)]); ipad[n:, 0] = 0
+    xd = ops.SparseTensor.from_unsorted(dev(fpad), dev(ipad), shape, batch, n_dev=torch.tensor([n], dtype=torch.int32).cuda())
+    oi_d, _, n_dev, tiles_d, nbr_d, out_d, _ = layer(xd)
+    live = int(out.shape[0])
+    assert n_dev is None or int(n_dev.item()) == live
+    assert torch.equal(tiles_d.to_neighbors()[:live], nbr[:live]) and torch.equal(out_d[:live], out)
+
+
 def test_second_encoder_vs_dense_oracle():
     """The whole VoxelBackBone8x + HeightCompression on a reduced grid against the dense restatement."""
     from heal_amd.opencood.models.heter_encoders import SECOND
