@@ -1293,9 +1293,10 @@ class SparseTensor:
         if not self.tiles_ok(ksize, cin, cout):
             return self.neighbors(out_indices, out_shape, ksize, stride, padding, n_out_dev=n_out_dev)
         n_out = int(out_indices.shape[0])
-        # sites per slot: a strided layer has few live taps per site (2.5 of 27 on conv2's SparseConv3d) -- 128 sites fill its 16-pair
-        # tiles twice as well as 64
-        sites = int(os.environ.get("HEAL_SP_SLOT_SITES", 0)) or (64 if tuple(int(v) for v in stride) == (1, 1, 1) else 128)
+        # sites per slot: 64.  128 fill the 16-pair tiles of a strided layer better (2.5 live taps of 27 per site on conv2's
+        # SparseConv3d: -5 us on that convolution) but the rulebook kernel then has half the waves for the same lookups (+22 us):
+        # HEAL_SP_SLOT_SITES=128 is the A/B switch (profiles/r06_k3_thin.json)
+        sites = int(os.environ.get("HEAL_SP_SLOT_SITES", 0)) or 64
         buf = torch.empty((_capi.query("heal_sp_pair_tiles_words", n_out, sites),), dtype=torch.int32, device=self.indices.device)
         with _Timed("sp_rulebook"):
             _capi.call("heal_sp_neighbor_tiles", _ptr(out_indices), n_out, _i3(ksize), _i3(stride), _i3(padding),
