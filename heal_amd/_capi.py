@@ -153,6 +153,8 @@ _SIGNATURES = {
     "heal_conv3x3_winograd4": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_void_p]),
     "heal_conv3x3_winograd": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_void_p]),
     "heal_conv3x3_winograd_kc": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_void_p]),
+    "heal_conv3x3_winograd_splitk_workspace": (c_size_t, [c_int] * 5),
+    "heal_conv3x3_winograd_splitk": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "heal_nms_quads_workspace": (c_size_t, [c_int]),
     "heal_nms_quads": (c_int, [c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "heal_window_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,

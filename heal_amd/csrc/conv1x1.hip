@@ -269,6 +269,19 @@ __global__ __launch_bounds__(256) void k_conv1x1_splitk_reduce(const float4* __r
 
 using namespace heal;
 
+namespace heal {
+// shared with the Winograd split-K path (conv3x3.hip)
+int splitk_reduce_launch(const float* partials, const float* bias, const float* residual, int ksplit, int n, int cout, int HW,
+                         int act, float* y, hipStream_t s, hipEvent_t ev_stop) {
+    const size_t total4 = (size_t)n * cout * HW / 4;
+    HEAL_LAUNCH_EV2(k_conv1x1_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (hipEvent_t) nullptr, ev_stop,
+                    reinterpret_cast<const float4*>(partials), bias, reinterpret_cast<const float4*>(residual), ksplit, cout,
+                    HW / 4, total4, act, reinterpret_cast<float4*>(y));
+    HEAL_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace heal
+
 static int conv1x1_launch(const float* x, const float* weight_frag, const float* bias, const float* residual,
                           const float* in_scale, int n, int cin, int cout, int H, int W, int stride, int act,
                           int out_pixel_major, int d2s_k, int d2s_ctot, int d2s_coff, float* y, void* stream,

@@ -248,7 +248,7 @@ template <int NW, bool EXACT, int KC = WG_KC>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restrict__ x, const float4* __restrict__ ufrag,
                                                          const float* __restrict__ bias, const float* __restrict__ res,
                                                          int Cin, int nchunks, int Cout, int H, int W, int tiles_x, int relu,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, int n_img, int ksplit) {
     using G = WgGeom<NW, KC>;
     constexpr int NT = 64 * NW, TR = G::TR, NTL = G::NTL, XW = G::XW, NTN = G::NTN, PE = G::PE, PCI = G::PCI;
     constexpr int VROW = G::VROW, MROW = G::MROW, NP = G::NP, UQ = G::UQ, KS = G::KS;
@@ -262,8 +262,13 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
     // Block order: tile fastest, image next, Cout block SLOWEST -- the Winograd weights are the big stream (16 x Cin x 64
     // floats per Cout block: 1.6 MB at Cin = 384, re-read by every tile) and have to stay in the XCDs' 4 MB L2s, so the
     // blocks in flight at any time share one Cout block; the input map is then read once per Cout block.
+    // ksplit > 1 (small maps with a deep reduction: 192 blocks of 64 chunks each for the 512 -> 512 layers of the camera trunk at
+    // 4 x 24 x 32 pixels): grid.y = ksplit * n_img, block y reduces chunk range kpart of image n and writes its PARTIAL output --
+    // the output transform is linear, so partial sums may leave the transform domain -- to y[kpart][n][Cout][HW] without bias /
+    // residual / ReLU; k_conv1x1_splitk_reduce adds the partials in split order (deterministic) and applies them.
     const Block3 bk = xcd_block();
-    const int mb = bk.z, n = bk.y;
+    const int mb = bk.z, n = (int)bk.y % n_img, kpart = (int)bk.y / n_img;
+    const int cps = (nchunks + ksplit - 1) / ksplit, cbeg = kpart * cps, cend = min(cbeg + cps, nchunks);
     const int tyb = bk.x / tiles_x, txb = bk.x - tyb * tiles_x;
     const int oy0 = tyb * TR, ox0 = txb * 16;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -353,11 +358,11 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
     // been issued and land during the next barrier + transform.  This requires barriers that do not drain VMEM
     // (lds_barrier, common.h) and a loop body that is ONE basic block (no predicated loads; the last iteration reloads
     // chunk nchunks-1 instead of branching).
-    load_patch(0);
-    load_u(0);
-    store_patch(0);
-    for (int c = 0; c < nchunks; ++c) {
-        const int cn = min(c + 1, nchunks - 1);
+    load_patch(cbeg);
+    load_u(cbeg);
+    store_patch(cbeg);
+    for (int c = cbeg; c < cend; ++c) {
+        const int cn = min(c + 1, cend - 1);
         lds_barrier();                            // patch(c) is in LDS; every wave is done with sV of chunk c-1
         load_patch(cn);
 #pragma unroll
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_wino(const float* __restric
 
     // Epilogue: four passes of 16 output channels (m-tile p) through sM[xi][co][tile]
     const size_t HWo = HW;                        // stride 1, padding 1: same map size
-    float* __restrict__ yout = y + (size_t)n * Cout * HWo;
+    float* __restrict__ yout = y + ((size_t)kpart * n_img + n) * Cout * HWo;
     const float* __restrict__ rin = res ? res + (size_t)n * Cout * HWo : nullptr;
     constexpr int CPP = NT / NTL;                 // channels handled per sweep of the block (8)
     const int ecg = threadIdx.x / NTL, etile = threadIdx.x - ecg * NTL, ety = etile >> 3, etx = etile & 7;
@@ -665,8 +670,14 @@ extern "C" int heal_conv3x3_winograd(const float* x, const float* u_frag, const 
     return heal_conv3x3_winograd_kc(x, u_frag, bias, residual, n, cin, cout, H, W, relu, waves, WG_KC, y, stream);
 }
 
-extern "C" int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
-                                        int cin, int cout, int H, int W, int relu, int waves, int kc, float* y, void* stream) {
+namespace heal {
+// conv1x1.hip: out = act(sum_ks part[ks] + bias (+ residual)), the partials [ksplit][n][Cout][HW] added in split order
+int splitk_reduce_launch(const float* partials, const float* bias, const float* residual, int ksplit, int n, int cout, int HW,
+                         int act, float* y, hipStream_t s, hipEvent_t ev_stop);
+}
+
+static int winograd_launch(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin, int cout,
+                           int H, int W, int relu, int waves, int kc, int ksplit, float* partials, float* y, void* stream) {
     HEAL_REQUIRE(n >= 1 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv3x3_winograd: bad shape");
     HEAL_REQUIRE(x && u_frag && y, "conv3x3_winograd: null pointer");
     HEAL_REQUIRE(((uintptr_t)u_frag & 15) == 0, "conv3x3_winograd: weight fragments must be 16-B aligned");
@@ -675,15 +686,22 @@ extern "C" int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, con
     const int nchunks = (cin + kc - 1) / kc, mblocks = (cout + 63) / 64;
     HEAL_REQUIRE(waves == 8 || waves == 4, "conv3x3_winograd: waves per block must be 8 (16x16-pixel tiles) or 4 (8x16)");
     const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 2 * waves);
-    HEAL_REQUIRE((long long)tiles_x * tiles_y <= 2147483647ll / 4 && n <= 65535 && mblocks <= 65535,
+    HEAL_REQUIRE((long long)tiles_x * tiles_y <= 2147483647ll / 4 && (long long)n * ksplit <= 65535 && mblocks <= 65535,
                  "conv3x3_winograd: map too large for the launch grid");
-    const dim3 grid(tiles_x * tiles_y, n, mblocks);
+    const dim3 grid(tiles_x * tiles_y, n * ksplit, mblocks);
     const float4* uf = reinterpret_cast<const float4*>(u_frag);
     // uniform-base addressing (see the kernel): whole chunks and byte offsets inside a chunk that fit 32 bits
     const bool exact = cin % kc == 0 && (long long)kc * H * W * 4 < 2147483647ll;
+    // split K: the blocks write partial outputs, the reduce launch applies bias / residual / ReLU
+    const float* kb = ksplit > 1 ? nullptr : bias;
+    const float* kr = ksplit > 1 ? nullptr : residual;
+    const int krelu = ksplit > 1 ? 0 : relu;
+    float* ky = ksplit > 1 ? partials : y;
+    LaunchEvents ev = take_launch_events();
+    hipEvent_t ev_mid = ksplit > 1 ? (hipEvent_t) nullptr : ev.stop;
 #define HEAL_WINO_LAUNCH(NW_, EX_, KC_)                                                                                              \
-    HEAL_LAUNCH_EV((k_conv3x3_wino<NW_, EX_, KC_>), grid, dim3(64 * NW_), 0, (hipStream_t)stream, x, uf, bias, residual, cin, nchunks, \
-                   cout, H, W, tiles_x, relu, y)
+    HEAL_LAUNCH_EV2((k_conv3x3_wino<NW_, EX_, KC_>), grid, dim3(64 * NW_), 0, (hipStream_t)stream, ev.start, ev_mid, x, uf, kb, kr, cin, \
+                    nchunks, cout, H, W, tiles_x, krelu, ky, n, ksplit)
     if (kc == 16) {
 #ifdef HEAL_BUILD_EXPERIMENTAL
         HEAL_REQUIRE(exact, "conv3x3_winograd: kc = 16 needs a map of less than 2^31 / 64 bytes per channel");
@@ -695,7 +713,31 @@ extern "C" int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, con
     else { if (exact) HEAL_WINO_LAUNCH(4, true, 8); else HEAL_WINO_LAUNCH(4, false, 8); }
 #undef HEAL_WINO_LAUNCH
     HEAL_LAUNCH_CHECK();
+    if (ksplit > 1) return splitk_reduce_launch(partials, bias, residual, ksplit, n, cout, H * W, relu ? 1 : 0, y, (hipStream_t)stream, ev.stop);
     return 0;
+}
+
+extern "C" int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
+                                        int cin, int cout, int H, int W, int relu, int waves, int kc, float* y, void* stream) {
+    return winograd_launch(x, u_frag, bias, residual, n, cin, cout, H, W, relu, waves, kc, 1, nullptr, y, stream);
+}
+
+extern "C" size_t heal_conv3x3_winograd_splitk_workspace(int n, int cout, int H, int W, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * n * cout * H * W * sizeof(float) : 0;
+}
+
+extern "C" int heal_conv3x3_winograd_splitk(const float* x, const float* u_frag, const float* bias, const float* residual, int n,
+                                            int cin, int cout, int H, int W, int relu, int waves, int ksplit, float* y, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    const int nchunks = (cin + WG_KC - 1) / WG_KC;
+    HEAL_REQUIRE(ksplit >= 2 && ksplit <= nchunks, "conv3x3_winograd_splitk: ksplit must be in [2, %d] (got %d)", nchunks, ksplit);
+    HEAL_REQUIRE((ksplit - 1) * ceil_div(nchunks, ksplit) < nchunks,
+                 "conv3x3_winograd_splitk: %d splits of %d chunks leave an empty split (use ceil(chunks / ceil(chunks / ksplit)))",
+                 ksplit, nchunks);
+    HEAL_REQUIRE((H * W) % 4 == 0, "conv3x3_winograd_splitk: H*W must be a multiple of 4");
+    HEAL_REQUIRE(ws && ws_bytes >= heal_conv3x3_winograd_splitk_workspace(n, cout, H, W, ksplit) && ((uintptr_t)ws & 15) == 0,
+                 "conv3x3_winograd_splitk: workspace too small or misaligned");
+    return winograd_launch(x, u_frag, bias, residual, n, cin, cout, H, W, relu, waves, WG_KC, ksplit, (float*)ws, y, stream);
 }
 
 

@@ -2161,6 +2161,21 @@ def conv7x7_s2(x, w, bias=None, relu=False):
     return y[:, :cout].contiguous() if cout < 128 else y
 
 
+def conv3x3_winograd_ksplit(n, cin, cout, H, W, waves):
+    """K splits of a Winograd launch: 1 unless the grid is small (< 256 blocks: less than one per CU) and the reduction deep
+    (>= 32 chunks of 8 input channels); then enough splits for ~768 blocks (three per CU: two resident 4-wave blocks + one queued),
+    at least 8 chunks each, none empty.  The camera trunk's Up block (lss_submodule.py:33-50: 432 -> 512 and 512 -> 512 at
+    4 x 24 x 32 pixels = 192 blocks of 54 / 64 chunks) is what this is for.  HEAL_C3_KSPLIT forces a value (0 / 1: off)."""
+    chunks = (cin + 7) // 8
+    blocks = -(-W // 16) * -(-H // (2 * waves)) * n * -(-cout // 64)
+    env = os.environ.get("HEAL_C3_KSPLIT")
+    want = int(env) if env is not None else (min(chunks // 8, max(2, -(-768 // blocks))) if blocks < 256 and chunks >= 32 else 1)
+    if want < 2 or chunks < 2 or (H * W) % 4 or n * want > 65535:
+        return 1
+    want = min(want, chunks)
+    return -(-chunks // -(-chunks // want))       # ceil(chunks / ceil(chunks / want)): no empty split
+
+
 def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
     """Dense 3x3 convolution, padding 1, stride 1 | 2, on the fp32 matrix cores with fused bias (+ residual) (+ ReLU).
     x [n,Cin,H,W] f32 cuda, w [Cout,Cin,3,3] -> [n,Cout,Ho,Wo].  Stride 1 runs the Winograd F(2x2,3x3) formulation
@@ -2188,10 +2203,17 @@ def conv3x3(x, w, bias=None, residual=None, relu=False, stride=1):
         waves = conv3x3_winograd_waves(n, cout, H, W)
         kc = conv3x3_winograd_kc(cin, waves, H, W)
         frag = conv3x3_winograd_fragments(w, waves, kc)
+        ksplit = conv3x3_winograd_ksplit(n, cin, cout, H, W, waves) if kc == 8 else 1
         with _Timed(f"conv3x3w_{cin}_{cout}", 2.0 * 9 * n * cin * cout * Ho * Wo, 4.0 * n * (cin * H * W + cout * Ho * Wo),
                     kernel_events=True):
-            _capi.call("heal_conv3x3_winograd_kc", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
-                       int(bool(relu)), waves, kc, _ptr(y), _stream())
+            if ksplit > 1:
+                ws = _workspace("conv3x3w_splitk", _capi.query("heal_conv3x3_winograd_splitk_workspace", n, cout, H, W, ksplit),
+                                x.device)
+                _capi.call("heal_conv3x3_winograd_splitk", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
+                           int(bool(relu)), waves, ksplit, _ptr(y), _ptr(ws), ws.numel(), _stream())
+            else:
+                _capi.call("heal_conv3x3_winograd_kc", _ptr(x), _ptr(frag), _ptr(bias), _ptr(residual), n, cin, cout, H, W,
+                           int(bool(relu)), waves, kc, _ptr(y), _stream())
         return y
     if stride == 2 and cin >= 128 and conv_gemm_supported(cin, cout, Wo) and n * Ho * Wo >= 65536:
         # the large stride-2 layers: the 128 x 128 x 32 implicit GEMM on 32x32x2 MFMA (heal_conv_gemm).  Measured

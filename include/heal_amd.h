@@ -629,6 +629,16 @@ int heal_conv3x3_winograd(const float* x, const float* u_frag, const float* bias
  *   frag[mb][chunk][w][lane][(xi_i*KS + ks)*4 + mt] = U[mb*64 + mt*16 + (lane & 15)][chunk*kc + ks*4 + (lane >> 4)][xi = XW*w + xi_i]. */
 int heal_conv3x3_winograd_kc(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
                              int cout, int H, int W, int relu, int waves, int kc, float* y, void* stream);
+/* heal_conv3x3_winograd_splitk (round 6): heal_conv3x3_winograd for SMALL maps with a DEEP reduction -- the 432 -> 512 and 512 -> 512
+ *   layers of the camera trunk's Up block (lss_submodule.py:33-50) at 4 x 24 x 32 pixels are 192 blocks of 54 / 64 K-chunks each --
+ *   with the chunks of 8 input channels split over `ksplit` blocks.  The output transform is linear: every block writes its PARTIAL
+ *   output to the workspace [ksplit][n][Cout][H W], a second launch adds the partials in split order (deterministic) and applies
+ *   bias / residual / ReLU.  ksplit in [2, ceil(cin / 8)] with no empty split; H*W % 4 == 0; workspace from
+ *   heal_conv3x3_winograd_splitk_workspace, 16-B aligned.                                                                */
+size_t heal_conv3x3_winograd_splitk_workspace(int n, int cout, int H, int W, int ksplit);
+int heal_conv3x3_winograd_splitk(const float* x, const float* u_frag, const float* bias, const float* residual, int n, int cin,
+                                 int cout, int H, int W, int relu, int waves, int ksplit, float* y, void* ws, size_t ws_bytes,
+                                 void* stream);
 
 /* ---- pcdet rotated-BEV box ops ------------------------------------------------------------
  * Replace opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (box_overlap, iou_bev), :236-265

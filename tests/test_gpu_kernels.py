@@ -637,6 +637,37 @@ def test_sparse_conv_layer_vs_dense_oracle(cin, cout, ksize, stride, padding, su
     np.testing.assert_allclose(got, ref.numpy(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,cin,cout,H,W,ksplit", [(4, 432, 512, 24, 32, None), (2, 128, 64, 16, 32, 4), (1, 72, 64, 10, 14, 3),
+                                                  (3, 256, 128, 8, 16, 32)])
+def test_conv3x3_winograd_split_k_equals_one_launch(n, cin, cout, H, W, ksplit, monkeypatch):
+    """heal_conv3x3_winograd_splitk (round 6: small maps with a deep reduction, the camera trunk's Up block, lss_submodule.py:33-50): K
+    chunks split over blocks, partial OUTPUTS (the output transform is linear) added in split order, then bias + residual + ReLU.
+    Against the single launch (another order of the fp32 sums: 1e-5) and fp64 torch; two runs bit-identical; the default policy picks a
+    split for the 4 x 24 x 32 layer and none for a grid that already fills the chip."""
+    from heal_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + cin)
+    x = torch.randn((n, cin, H, W), generator=g).cuda()
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    r = torch.randn((n, cout, H, W), generator=g).cuda()
+    monkeypatch.setenv("HEAL_C3_ALGO", "winograd")
+    monkeypatch.setenv("HEAL_C3_KSPLIT", "1")
+    one = ops.conv3x3(x, w, b, r, True, 1)
+    if ksplit is None:
+        monkeypatch.delenv("HEAL_C3_KSPLIT")
+        waves = ops.conv3x3_winograd_waves(n, cout, H, W)
+        assert ops.conv3x3_winograd_ksplit(n, cin, cout, H, W, waves) >= 2
+        assert ops.conv3x3_winograd_ksplit(4, 512, 512, 48, 64, ops.conv3x3_winograd_waves(4, 512, 48, 64)) == 1
+    else:
+        monkeypatch.setenv("HEAL_C3_KSPLIT", str(ksplit))
+    got = ops.conv3x3(x, w, b, r, True, 1)
+    assert torch.equal(got, ops.conv3x3(x, w, b, r, True, 1))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1) + r.double())
+    scale = float(ref.abs().max())
+    assert float((got - one).abs().max()) < 1e-5 * scale
+    assert float((got.double() - ref).abs().max()) < 1e-4 * scale
+
+
 @pytest.mark.parametrize("slot_sites", [64, 128])
 @pytest.mark.parametrize("cin,cout,stride,padding,subm", [
     (4, 16, (1, 1, 1), (1, 1, 1), True), (16, 16, (1, 1, 1), (1, 1, 1), True), (16, 32, (2, 2, 2), (1, 1, 1), False)])
