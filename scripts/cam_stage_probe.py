@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--agent", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--depth", type=int, default=1, help="copies of the stage in flight (own stream, own static inputs and graph each)")
     a = ap.parse_args()
     from bench import WORKLOADS
     from heal_amd import configs
@@ -30,12 +31,29 @@ def main():
     mine = owned_agents(n_agents, r, N)
     assert mine == [a.agent], mine
     with torch.no_grad():
-        runner = make_sharded(pipe.model, r, N, collective="gather")
-        static = StaticInputs(scene, agents=mine)
-        static.load(scene)
-        li, inp = static.inputs_for(mine), static.scene_meta()
-        buf, ms, g = timed_graph(lambda: runner.local(inp, n_agents, li), stream, iters=a.iters)
-    print(f"agent {a.agent} ({mods[a.agent]}): local stage {ms:.3f} ms per replay", flush=True)
+        slots = []
+        for d in range(a.depth):
+            st = stream if d == 0 else torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                runner = make_sharded(pipe.model, r, N, collective="gather")
+                static = StaticInputs(scene, agents=mine)
+                static.load(scene)
+                li, inp = static.inputs_for(mine), static.scene_meta()
+                buf, ms, g = timed_graph(lambda: runner.local(inp, n_agents, li), st, iters=a.iters)
+            slots.append((g, st, buf, static, runner))
+        print(f"agent {a.agent} ({mods[a.agent]}): local stage {ms:.3f} ms per replay (alone)", flush=True)
+        if a.depth > 1:
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            total = a.iters * a.depth
+            for k in range(total):
+                g, st = slots[k % a.depth][:2]
+                with torch.cuda.stream(st):
+                    g.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3 / total
+            print(f"agent {a.agent} ({mods[a.agent]}): {a.depth} frames in flight: {dt:.3f} ms per frame", flush=True)
 
 
 if __name__ == "__main__":
