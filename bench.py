@@ -182,6 +182,14 @@ def pmc_traffic(workload, *prefixes, per_launch_kernels=None):
     return round(tot, 1) if hit else None
 
 
+def k3_traffic(workload):
+    """Mean HBM bytes per sparse-convolution launch over BOTH kernels of the family (k_sp_conv2: the table path, k_sp_tiles: the thin layers)."""
+    pmc_traffic(workload, "heal::k_sp_conv2<")
+    ks = [v for k, v in (_PMC.get(workload) or {}).items() if k.startswith("heal::k_sp_conv2<") or k.startswith("heal::k_sp_tiles<")]
+    d = sum(v["dispatches"] for v in ks)
+    return round(sum(v["bytes_per_dispatch"] * v["dispatches"] for v in ks) / d, 1) if d else None
+
+
 _KSTATS = {}
 
 
@@ -393,10 +401,9 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
         if in_graph and "voxelize" in in_graph:      # the launch chain as the timed region runs it (captured graph), not host-paced
             extra = {"eager_event_pair_ms": round(mean_ms, 5), "duration": "per-call period of the launch chain inside a captured graph"}
             mean_ms = in_graph["voxelize"]
-        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: the table fill + four kernels)", "hbm",
+        entries["k1"] = (calls * mean_ms, _entry("K1 heal_voxelize_batch (all LiDAR agents of the scene: insert / assign + fill / select + write, self-cleaning tables)", "hbm",
                                                  bts / (mean_ms * 1e-3) / 1e9, calls, mean_ms,
-                                                 pmc_traffic(a.workload, "heal::k_voxb_insert", "heal::k_vox_assign",
-                                                             "heal::k_vox_fill", "heal::k_vox_select_write"),   # (+ the table fill, k_fill_words: shared by all operators, not in the sum)
+                                                 pmc_traffic(a.workload, "heal::k_voxb_insert", "heal::k_vox_assign", "heal::k_vox_select_write"),
                                                  bytes_per_launch=bts, **extra))
     if "decode_nms" in timing:
         calls, mean_ms = timing["decode_nms"]
@@ -437,10 +444,11 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
             rb = timing.get("sp_rulebook", (0, 0.0))
             rb_ms = rb[0] * rb[1] / max(a.steps, 1)                       # site sort, hash / rank structures, neighbour tables, out sites
             entries["k3"] = (tot_ms * max(a.steps, 1), _entry(
-                "K3 heal_sp_conv (pair-compacted gather-GEMM on fp32 MFMA; all sparse layers of one step, useful flops 2 R Cin Cout; "
+                "K3 heal_sp_conv / heal_sp_conv_tiles (pair-compacted gather-GEMM on fp32 MFMA; the c_in <= 16 layers on the pair-tile rulebook; "
+                "all sparse layers of one step, useful flops 2 R Cin Cout; `traffic` = mean HBM bytes per convolution launch over both kernels; "
                 "`frac` prices the convolution launches; `rulebook_ms` = the rulebook launches of the same step (site sort, hash / rank "
                 "structures, neighbour tables, output sites), `step_ms_with_rulebook` = both)", "mfma",
-                tot_f / (tot_ms * 1e-3) / 1e12, len(layers), tot_ms / len(layers), pmc_traffic(a.workload, "heal::k_sp_conv2<"),
+                tot_f / (tot_ms * 1e-3) / 1e12, len(layers), tot_ms / len(layers), k3_traffic(a.workload),
                 step_ms=round(tot_ms, 4), rulebook_ms=round(rb_ms, 4), step_ms_with_rulebook=round(tot_ms + rb_ms, 4),
                 tflops_with_rulebook=round(tot_f / ((tot_ms + rb_ms) * 1e-3) / 1e12, 2),
                 frac_with_rulebook=round(tot_f / ((tot_ms + rb_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
