@@ -674,7 +674,8 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
                                                  const int* __restrict__ n_dev, const float* __restrict__ wfrag,
                                                  const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                  float* __restrict__ feat_out) {
-    static_assert((CIN == 4 || CIN == 16) && COUT % 16 == 0 && (S == 64 || S == 128), "shape");
+    static_assert((CIN == 4 || CIN == 16 || CIN == 32) && COUT % 16 == 0 && (S == 64 || S == 128), "shape");
+    constexpr int J = CIN >= 16 ? CIN / 16 : 1;   // 16-B pieces of an input row per lane (= of a weight fragment per slice)
     static_assert(D == 4 || D == 2, "tiles per pipeline group");
     constexpr int LB = spt_lb(S);
     constexpr int NC = COUT / 16;
@@ -698,12 +699,12 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
     for (int i = l; i < T / 4 + 1; i += 64) s_tap[i] = slot[1 + i];   // + the all-padding group behind the last tile
     for (int i = l; i < (S + 1) * RSA / 4; i += 64) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const char* fin = reinterpret_cast<const char*>(feat_in) + (CIN == 16 ? 16 * g : 4 * g);
-    const char* wf = reinterpret_cast<const char*>(wfrag) + (CIN == 16 ? 16 * l : 4 * l);
-    constexpr uint32_t WTAP = NC * (CIN == 16 ? 1024u : 256u);   // bytes of one tap's fragments
+    const char* fin = reinterpret_cast<const char*>(feat_in) + (CIN >= 16 ? 16 * g : 4 * g);
+    const char* wf = reinterpret_cast<const char*>(wfrag) + (CIN >= 16 ? 16 * l : 4 * l);
+    constexpr uint32_t WTAP = NC * (CIN >= 16 ? J * 1024u : 256u);   // bytes of one tap's fragments
     struct Xw {
-        f32x4 x[D];                 // CIN = 16: channels 4g..4g+3 of the pair's input row; CIN = 4: .x = channel g
-        f32x4 w[D][NC];             // CIN = 16: the four k-steps of (tap, slice); CIN = 4: .x
+        f32x4 x[D][J];              // CIN >= 16: channels 16j+4g..+3 of the pair's input row; CIN = 4: .x = channel g
+        f32x4 w[D][NC][J];          // CIN >= 16: the four k-steps (16j+4g+i) of (tap, slice); CIN = 4: .x
     };
     auto load_e = [&](uint32_t (&e)[D], int base) {           // stage 1: pair words (past the end: the all-padding group)
         const uint32_t* p = list + min(base, T) * 16;
@@ -717,14 +718,17 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
         for (int q = 0; q < D; ++q) {
             const uint32_t row = (DBG & 1) ? 0u : e[q] >> LB;
             const char* wt = wf + ((taps >> (8 * q)) & 0xFFu) * WTAP;
-            if constexpr (CIN == 16) {
-                G.x[q] = *reinterpret_cast<const f32x4*>(fin + row * 64u);
+            if constexpr (CIN >= 16) {
 #pragma unroll
-                for (int nb = 0; nb < NC; ++nb) G.w[q][nb] = *reinterpret_cast<const f32x4*>(wt + nb * 1024);
+                for (int j = 0; j < J; ++j) G.x[q][j] = *reinterpret_cast<const f32x4*>(fin + row * (4u * CIN) + 64 * j);
+#pragma unroll
+                for (int nb = 0; nb < NC; ++nb)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) G.w[q][nb][j] = *reinterpret_cast<const f32x4*>(wt + (nb * J + j) * 1024);
             } else {
-                G.x[q][0] = *reinterpret_cast<const float*>(fin + row * 16u);
+                G.x[q][0][0] = *reinterpret_cast<const float*>(fin + row * 16u);
 #pragma unroll
-                for (int nb = 0; nb < NC; ++nb) G.w[q][nb][0] = *reinterpret_cast<const float*>(wt + nb * 256);
+                for (int nb = 0; nb < NC; ++nb) G.w[q][nb][0][0] = *reinterpret_cast<const float*>(wt + nb * 256);
             }
         }
     };
@@ -736,8 +740,10 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
             for (int nb = 0; nb < NC; ++nb) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kc = 0; kc < CIN / 4; ++kc)
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(G.w[q][nb][kc], G.x[q][kc], a, 0, 0, 0);
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int i = 0; i < (CIN >= 16 ? 4 : 1); ++i)
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(G.w[q][nb][j][i], G.x[q][j][i], a, 0, 0, 0);
                 if constexpr (!(DBG & 4)) {
                     float4* p4 = reinterpret_cast<float4*>(p + nb * 16);   // (per-dword ds_add_f32 measured 8x slower: 8-way bank conflicts)
                     float4 o = *p4;
@@ -1698,7 +1704,8 @@ extern "C" int heal_sp_conv(const float* feat_in, const int32_t* nbr, int n_out,
 }
 
 extern "C" int heal_sp_conv_tiles_supported(int c_in, int c_out) {
-    return (c_in == 4 && c_out == 16) || (c_in == 16 && (c_out == 16 || c_out == 32));
+    // (32 -> 32: 173 -> 166 us, and its rulebook launch is 18 us cheaper as tiles; 32 -> 64 measured no gain on 212 VGPRs: not built)
+    return (c_in == 4 && c_out == 16) || (c_in == 16 && (c_out == 16 || c_out == 32)) || (c_in == 32 && c_out == 32);
 }
 
 extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, int n_out, int slot_sites, int c_in, int c_out,
@@ -1734,7 +1741,7 @@ extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, i
         if (dbg == 8) HEAL_SPTL(CI, CO, 64, 8)                                                                           \
         HEAL_SPTL(CI, CO, 64, 0)                                                                                         \
     }
-    HEAL_SPTT(4, 16) HEAL_SPTT(16, 16) HEAL_SPTT(16, 32)
+    HEAL_SPTT(4, 16) HEAL_SPTT(16, 16) HEAL_SPTT(16, 32) HEAL_SPTT(32, 32)
 #undef HEAL_SPTT
 #undef HEAL_SPTL
 #undef HEAL_SPTL2

@@ -670,7 +670,8 @@ def test_conv3x3_winograd_split_k_equals_one_launch(n, cin, cout, H, W, ksplit, 
 
 @pytest.mark.parametrize("slot_sites", [64, 128])
 @pytest.mark.parametrize("cin,cout,stride,padding,subm", [
-    (4, 16, (1, 1, 1), (1, 1, 1), True), (16, 16, (1, 1, 1), (1, 1, 1), True), (16, 32, (2, 2, 2), (1, 1, 1), False)])
+    (4, 16, (1, 1, 1), (1, 1, 1), True), (16, 16, (1, 1, 1), (1, 1, 1), True), (16, 32, (2, 2, 2), (1, 1, 1), False),
+    (32, 32, (1, 1, 1), (1, 1, 1), True)])
 def test_sparse_conv_on_pair_tiles_vs_dense_oracle(cin, cout, stride, padding, subm, slot_sites, monkeypatch):
     """Round 6, the c_in <= 16 layers of VoxelBackBone8x (sparse_backbone_3d.py:48-62) on the pair-tile rulebook
     (heal_sp_neighbor_tiles + heal_sp_conv_tiles): the tiles decode to the neighbour table BIT FOR BIT (an index computation), the
