@@ -1537,7 +1537,13 @@ extern "C" int heal_sp_neighbors_root(const int32_t* out_indices, int n_out, con
                           rank_bytes, n_in, n_in_dev, nbr, n_out_dev, stream, true);
 }
 
+// 128-site slots, groups of 4 tiles and the timing-anatomy variants are measured alternatives (profiles/r06_k3_thin.json): they are built
+// only into a HEAL_BUILD_EXPERIMENTAL=1 library, the shipped one carries what runs
+#ifdef HEAL_BUILD_EXPERIMENTAL
 static bool slot_sites_ok(int S) { return S == 64 || S == 128; }
+#else
+static bool slot_sites_ok(int S) { return S == 64; }
+#endif
 
 extern "C" size_t heal_sp_pair_tiles_words(int n_out, int slot_sites) {
     if (!slot_sites_ok(slot_sites)) return 0;
@@ -1552,7 +1558,7 @@ extern "C" int heal_sp_neighbor_tiles(const int32_t* out_indices, int n_out, con
     SpConvGeom g;
     if (fill_geom(g, ksize_host, stride_host, padding_host, in_shape_host, out_shape_host, batch)) return 1;
     HEAL_REQUIRE(g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3, "sp_neighbor_tiles: 3 x 3 x 3 kernels only");
-    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_neighbor_tiles: %d sites per slot (64 or 128)", slot_sites);
+    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_neighbor_tiles: %d sites per slot (64; 128 in experimental builds)", slot_sites);
     HEAL_REQUIRE(n_in < (1 << 24), "sp_neighbor_tiles: %d input rows do not fit the pair word", n_in);
     if (n_out <= 0) return 0;
     const size_t words = rank_words(g.in), gran = words / 8;
@@ -1565,18 +1571,22 @@ extern "C" int heal_sp_neighbor_tiles(const int32_t* out_indices, int n_out, con
     const int4* oi = reinterpret_cast<const int4*>(out_indices);
     if (slot_sites == 64)
         k_sp_nbr_tiles<64><<<ceil_div(n_out, 256), 256, 0, (hipStream_t)stream>>>(oi, n_out, n_out_dev, g, r, n_in, n_in_dev, tiles);
+#ifdef HEAL_BUILD_EXPERIMENTAL
     else
         k_sp_nbr_tiles<128><<<ceil_div(n_out, 512), 256, 0, (hipStream_t)stream>>>(oi, n_out, n_out_dev, g, r, n_in, n_in_dev, tiles);
+#endif
     HEAL_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int heal_sp_tiles_to_neighbors(const uint32_t* tiles, int n_out, int slot_sites, const int32_t* n_out_dev, int32_t* nbr,
                                           void* stream) {
-    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_tiles_to_neighbors: %d sites per slot (64 or 128)", slot_sites);
+    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_tiles_to_neighbors: %d sites per slot (64; 128 in experimental builds)", slot_sites);
     if (n_out <= 0) return 0;
     if (slot_sites == 64) k_sp_tiles_to_nbr<64><<<ceil_div(n_out, 256), 256, 0, (hipStream_t)stream>>>(tiles, n_out, n_out_dev, nbr);
+#ifdef HEAL_BUILD_EXPERIMENTAL
     else k_sp_tiles_to_nbr<128><<<ceil_div(n_out, 512), 256, 0, (hipStream_t)stream>>>(tiles, n_out, n_out_dev, nbr);
+#endif
     HEAL_LAUNCH_CHECK();
     return 0;
 }
@@ -1714,11 +1724,13 @@ extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, i
     hipStream_t s = (hipStream_t)stream;
     if (n_out <= 0) return 0;
     HEAL_REQUIRE(weight_frag != nullptr, "sp_conv_tiles: weight fragments (heal_sp_weight_fragments) are required");
-    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_conv_tiles: %d sites per slot (64 or 128)", slot_sites);
+    HEAL_REQUIRE(slot_sites_ok(slot_sites), "sp_conv_tiles: %d sites per slot (64; 128 in experimental builds)", slot_sites);
+#ifdef HEAL_BUILD_EXPERIMENTAL
     const int dbg = HEAL_DEBUG_ENV("HEAL_SP_TILES_DBG");
     // tiles per pipeline group (HEAL_SP_TILES_D=4: A/B).  Measured on the three layers of config 5 (profiles/r06_k3_thin.json):
     // groups of 2 tiles 21.7 / 32.7 / 48.4 us on 36 / 64 / 88 VGPRs, groups of 4 22.2 / 34.9 / 52.5 us on 52 / 104 / 148
     const int four = getenv("HEAL_SP_TILES_D") && atoi(getenv("HEAL_SP_TILES_D")) == 4;
+#endif
 #define HEAL_SPTL2(CI, CO, SS, GG, DD)                                                                                   \
     {                                                                                                                    \
         k_sp_tiles<CI, CO, SS, GG, DD><<<ceil_div(n_out, SS), 64, 0, s>>>(feat_in, tiles, n_out, n_out_dev, weight_frag,  \
@@ -1726,6 +1738,7 @@ extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, i
         HEAL_LAUNCH_CHECK();                                                                                             \
         return 0;                                                                                                        \
     }
+#ifdef HEAL_BUILD_EXPERIMENTAL
 #define HEAL_SPTL(CI, CO, SS, GG)                                                                                        \
     {                                                                                                                    \
         if (GG == 0 && four) HEAL_SPTL2(CI, CO, SS, 0, 4)                                                                \
@@ -1741,6 +1754,10 @@ extern "C" int heal_sp_conv_tiles(const float* feat_in, const uint32_t* tiles, i
         if (dbg == 8) HEAL_SPTL(CI, CO, 64, 8)                                                                           \
         HEAL_SPTL(CI, CO, 64, 0)                                                                                         \
     }
+#else
+#define HEAL_SPTL(CI, CO, SS, GG) HEAL_SPTL2(CI, CO, SS, GG, 2)
+#define HEAL_SPTT(CI, CO) if (c_in == CI && c_out == CO) HEAL_SPTL(CI, CO, 64, 0)
+#endif
     HEAL_SPTT(4, 16) HEAL_SPTT(16, 16) HEAL_SPTT(16, 32) HEAL_SPTT(32, 32)
 #undef HEAL_SPTT
 #undef HEAL_SPTL

@@ -1295,7 +1295,7 @@ class SparseTensor:
         n_out = int(out_indices.shape[0])
         # sites per slot: 64.  128 fill the 16-pair tiles of a strided layer better (2.5 live taps of 27 per site on conv2's
         # SparseConv3d: -5 us on that convolution) but the rulebook kernel then has half the waves for the same lookups (+22 us):
-        # HEAL_SP_SLOT_SITES=128 is the A/B switch (profiles/r06_k3_thin.json)
+        # HEAL_SP_SLOT_SITES=128 is the A/B switch of a HEAL_BUILD_EXPERIMENTAL=1 library (profiles/r06_k3_thin.json)
         sites = int(os.environ.get("HEAL_SP_SLOT_SITES", 0)) or 64
         buf = torch.empty((_capi.query("heal_sp_pair_tiles_words", n_out, sites),), dtype=torch.int32, device=self.indices.device)
         with _Timed("sp_rulebook"):

@@ -384,7 +384,7 @@ int heal_sp_neighbors_root(const int32_t* out_indices, int n_out, const int32_t*
                            const int32_t* out_shape_host, int batch, const void* rank, size_t rank_bytes,
                            int n_in, const int32_t* n_in_dev, int32_t* nbr, const int32_t* n_out_dev, void* stream);
 /* The rulebook as PAIR TILES (round 6), for the layers with c_in <= 16 (sparse_backbone_3d.py:48-62: conv_input, conv1, the first
- * SparseConv3d of conv2) and the 32 -> 32 submanifold layers of conv2 (heal_sp_conv_tiles_supported): instead of the [n_out][27] table, every `slot_sites` (64 or 128) consecutive output sites own one
+ * SparseConv3d of conv2) and the 32 -> 32 submanifold layers of conv2 (heal_sp_conv_tiles_supported): instead of the [n_out][27] table, every `slot_sites` (64; 128 only in a HEAL_BUILD_EXPERIMENTAL=1 library) consecutive output sites own one
  * fixed-stride slot of 64 + 27 slot_sites + 128 words -- word 0: tile count T (a multiple of 4); bytes 4 .. 4+T: the tap of tile i;
  * from word 64: T tiles of 16 pair words, taps ascending, pairs in site order (+ 4 uncounted all-padding tiles).  Pair word = input row << (7 | 8) | site - site0;
  * a padding pair is input row 0 with site = slot_sites.  Only the used prefix of a slot is written and read (6.2 of 27 taps are

@@ -3,7 +3,7 @@ layer by layer, with HIP events.  For every layer: live N_in / N_out / rule pair
 algorithmic GB/s, and the result compared with the round-2 kernel (HEAL_SP_CONV=v1) on the same inputs.
 Also times the rulebook entry points (sort, hash, out_sites, neighbors).
 
-    python scripts/k3_bench.py [--agents 8] [--iters 20] [--json out.json] [--modes v1,v2,v2m64]
+    python scripts/k3_bench.py [--agents 8] [--iters 20] [--json out.json] [--modes v1,v2,v2:m128,tiles] [--graph] [--layers N]
 """
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -54,13 +54,13 @@ def timed(fn, iters):
 
 def set_mode(mode):
     """v1 | v2 | v2:m64,t2,d0 (block sites M, stage-size multiplier, double-buffered gather tile)"""
-    for k in ("HEAL_SP_CONV", "HEAL_SP_M", "HEAL_SP_TPSX", "HEAL_SP_DB", "HEAL_SP_THIN_D"):
+    for k in ("HEAL_SP_CONV", "HEAL_SP_M", "HEAL_SP_TPSX", "HEAL_SP_DB", "HEAL_SP_TILES_D"):
         os.environ.pop(k, None)
-    # thin | thin:d8 -- round-6 kernel for the CIN <= 16 layers on the neighbour table; tiles | tiles:d8 -- on the pair-tile rulebook
-    os.environ["HEAL_SP_THIN"] = "1" if mode.startswith(("thin", "tiles")) else "0"
-    if mode.startswith(("thin", "tiles")):
-        if ":" in mode:
-            os.environ["HEAL_SP_THIN_D"] = mode.split(":d")[1]
+    # tiles | tiles:d4 -- the round-6 kernel for the thin layers on the pair-tile rulebook (main() builds the tiles); :d4 = groups of 4
+    # tiles (HEAL_BUILD_EXPERIMENTAL=1 libraries only)
+    if mode.startswith("tiles"):
+        if ":d" in mode:
+            os.environ["HEAL_SP_TILES_D"] = mode.split(":d")[1]
         return
     if mode == "v1":
         os.environ["HEAL_SP_CONV"] = "v1"
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--modes", default="v1,v2")
     ap.add_argument("--json", default=None)
     ap.add_argument("--brief", action="store_true")
-    ap.add_argument("--no-check", action="store_true", help="timing anatomy runs (HEAL_SP_THIN_DBG / HEAL_SP_DBG): outputs are invalid")
+    ap.add_argument("--no-check", action="store_true", help="timing anatomy runs (HEAL_SP_TILES_DBG / HEAL_SP_DBG): outputs are invalid")
     ap.add_argument("--layers", type=int, default=len(LAYERS), help="only the first N layers")
     ap.add_argument("--graph", action="store_true", help="time the conv launches as replays of a captured graph")
     a = ap.parse_args()

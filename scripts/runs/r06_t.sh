@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: K3 thin-layer kernels (k_sp_thin / k_sp_tiles) against k_sp_conv2 on the three CIN <= 16 layers of config 5
+# round 6: the K3 pair-tile kernel (k_sp_tiles) against k_sp_conv2 on the first layers of config 5; ANATOMY="0 7 8" (HEAL_SP_TILES_DBG) needs
+# a HEAL_BUILD_EXPERIMENTAL=1 library
 mkdir -p gpurun_out/r06
 if [ -n "$ANATOMY" ]; then
   for d in ${ANATOMY}; do
