@@ -705,3 +705,25 @@ def test_bench_refuses_profile_files_of_another_library_build(tmp_path, monkeypa
     bench._KSTATS.clear()
     open(tmp_path / "profiles" / "r06_kernel_stats_scene5.stamp", "w").write(stamp)
     assert bench.rocprof_mean_us("scene5", "void heal::k_conv1x1<") == 30.0
+
+
+def test_winograd_split_k_policy_never_leaves_an_empty_split(monkeypatch):
+    """ops.conv3x3_winograd_ksplit (host logic of heal_conv3x3_winograd_splitk): splits only small grids with a deep reduction, and what it
+    returns always satisfies the C entry point's contract -- 2 <= ksplit <= chunks and (ksplit - 1) * ceil(chunks / ksplit) < chunks."""
+    from heal_amd import ops
+    monkeypatch.delenv("HEAL_C3_KSPLIT", raising=False)
+    assert ops.conv3x3_winograd_ksplit(4, 432, 512, 24, 32, 4) == 4      # the camera Up block: 192 blocks of 54 chunks
+    assert ops.conv3x3_winograd_ksplit(4, 512, 512, 48, 64, 4) == 1      # 768 blocks: the grid fills the chip
+    assert ops.conv3x3_winograd_ksplit(1, 64, 64, 16, 16, 4) == 1        # 8 chunks: too shallow
+    assert ops.conv3x3_winograd_ksplit(1, 512, 64, 15, 15, 4) == 1       # H * W % 4 != 0: the float4 reduce does not apply
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n, cin, cout = int(rng.integers(1, 9)), int(rng.integers(1, 130)) * 8, int(rng.integers(1, 9)) * 64
+        H, W, waves = int(rng.integers(1, 40)) * 2, int(rng.integers(1, 40)) * 2, int(rng.choice([4, 8]))
+        for env in (None, "2", "3", "5", "64", "1000"):
+            if env is None:
+                monkeypatch.delenv("HEAL_C3_KSPLIT", raising=False)
+            else:
+                monkeypatch.setenv("HEAL_C3_KSPLIT", env)
+            ks, chunks = ops.conv3x3_winograd_ksplit(n, cin, cout, H, W, waves), (cin + 7) // 8
+            assert ks == 1 or (2 <= ks <= chunks and (ks - 1) * -(-chunks // ks) < chunks), (n, cin, cout, H, W, waves, env, ks)
