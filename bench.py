@@ -461,10 +461,12 @@ def roofline_report(a, work, timing, scene, mods, m_per_agent, hypes, solo, worl
     return entries[order[0]][1], [entries[k][1] for k in order[1:]]
 
 
-def preflight(dist, rank, world, dev, backend, limit_s=30.0):
+def preflight(dist, rank, world, dev, backend, limit_s=float(os.environ.get("HEAL_PREFLIGHT_S", "120"))):
     """First contact of the N > 1 path with the hardware: one all-reduce, one gather and one all-to-all of 1 KB each,
     bounded by a timer that ends the job with a clear message instead of a silent watchdog exit; every rank announces itself on stderr
-    and rank 0 keeps who-runs-where for the JSON line, so the driver's record shows N ranks on N devices."""
+    and rank 0 keeps who-runs-where for the JSON line, so the driver's record shows N ranks on N devices.  The limit (120 s, HEAL_PREFLIGHT_S)
+    is generous on purpose: the ranks leave init_process_group together, but the first gather / all-to-all of a process group still set up
+    their peer-to-peer channels lazily -- the timer is there to turn a dead job into a message, not to police a slow first contact."""
     import threading
 
     def _expire():
