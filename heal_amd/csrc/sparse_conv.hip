@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void k_sp_conv2(const float* __restrict__ feat
 //   * a tile's 16 x 16 result rows belong to 16 different output sites: one 16-B read-modify-write per lane and slice of the
 //     wave's private [S + 1][COUT] accumulator in LDS.  LDS operations of one wave execute in order and nothing is shared
 //     between waves: a fixed summation order (taps ascending per site), bit-reproducible, no atomics;
-//   * LDS holds the accumulator and the tap bytes only (5-19 KB), the register file sets the occupancy (4-8 waves per SIMD).
+//   * LDS holds the accumulator only (5-18 KB; the tap bytes travel with the pair words), the register file sets the occupancy.
 // S = 64 or 128 output sites per slot (the caller's choice; measured, profiles/r06_k3_thin.json): 128 sites fill the 16-pair tiles
 // better (0.73 -> 0.84 on the submanifold layers, 0.5 -> 0.68 on the first strided layer with its 2.5 live taps of 27 per site) and
 // save 5 us on that layer, but k_sp_nbr_tiles<128> has half the waves for the same lookups and loses 22 us: 64 is the default.
@@ -683,7 +683,6 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
     constexpr int MAXT = 27 * S / 16 + 4;
     constexpr int SLOT = spt_slot_words(S);
     __shared__ __attribute__((aligned(16))) float s_acc[(S + 1) * RSA];
-    __shared__ __attribute__((aligned(16))) uint32_t s_tap[MAXT / 4 + 2];   // 4 tap bytes per word = one pipeline group
 
     const int n_out = live_rows(n_dev, out_cap);
     const unsigned nb_ = (unsigned)(n_out + S - 1) / S;
@@ -695,8 +694,13 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
     const int l = threadIdx.x, g = l >> 4, ln = l & 15;
     const uint32_t* slot = tiles + (size_t)blk * SLOT;
     const uint32_t* list = slot + SPT_HDR_WORDS + ln;
+    // the first group's pair words and tap bytes do not depend on the tile count (an empty slot still holds its all-padding group):
+    // they are requested TOGETHER with it -- two dependent round trips in front of the first MFMA instead of three
+    uint32_t e0[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) e0[q] = list[q * 16];
+    uint32_t tw0 = slot[1];
     const int T = min((int)slot[0], MAXT) & ~3;
-    for (int i = l; i < T / 4 + 1; i += 64) s_tap[i] = slot[1 + i];   // + the all-padding group behind the last tile
     for (int i = l; i < (S + 1) * RSA / 4; i += 64) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const char* fin = reinterpret_cast<const char*>(feat_in) + (CIN >= 16 ? 16 * g : 4 * g);
@@ -706,14 +710,17 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
         f32x4 x[D][J];              // CIN >= 16: channels 16j+4g..+3 of the pair's input row; CIN = 4: .x = channel g
         f32x4 w[D][NC][J];          // CIN >= 16: the four k-steps (16j+4g+i) of (tap, slice); CIN = 4: .x
     };
-    auto load_e = [&](uint32_t (&e)[D], int base) {           // stage 1: pair words (past the end: the all-padding group)
-        const uint32_t* p = list + min(base, T) * 16;
+    // stage 1: pair words + the header word with the group's tap bytes (4 per word; past the end: the all-padding group)
+    auto load_e = [&](uint32_t (&e)[D], uint32_t& tw, int base) {
+        const int b_ = min(base, T);
+        const uint32_t* p = list + b_ * 16;
 #pragma unroll
         for (int q = 0; q < D; ++q) e[q] = p[q * 16];
+        tw = slot[1 + (b_ >> 2)];
     };
-    auto load_xw = [&](const uint32_t (&e)[D], Xw& G, int base) {   // stage 2: input rows + weight fragments
+    auto load_xw = [&](const uint32_t (&e)[D], uint32_t tw, Xw& G, int base) {   // stage 2: input rows + weight fragments
         const int b_ = min(base, T);
-        const uint32_t taps = (DBG & 2) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tap[b_ >> 2]) >> (8 * (b_ & 3));
+        const uint32_t taps = (DBG & 2) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)tw) >> (8 * (b_ & 3));
 #pragma unroll
         for (int q = 0; q < D; ++q) {
             const uint32_t row = (DBG & 1) ? 0u : e[q] >> LB;
@@ -756,23 +763,27 @@ __global__ __launch_bounds__(64) void k_sp_tiles(const float* __restrict__ feat_
     if (T > 0 && !(DBG & 8)) {
         // two register sets for the rows / weights, used alternately by the two halves of the loop body: a copy "C = B" would make
         // the compiler wait for the loads it has just issued
-        uint32_t eA[D], eB[D], eC[D];
+        uint32_t eA[D], eB[D], eC[D], twA, twB;
         Xw X0, X1;
-        load_e(eB, 0);
-        load_e(eA, D);
-        load_xw(eB, X0, 0);
+#pragma unroll
+        for (int q = 0; q < D; ++q) eB[q] = e0[q];
+        twB = tw0;
+        load_e(eA, twA, D);
+        load_xw(eB, twB, X0, 0);
         for (int base = 0; base < T; base += 2 * D) {
 #pragma unroll
             for (int q = 0; q < D; ++q) { eC[q] = eB[q]; eB[q] = eA[q]; }
-            load_e(eA, base + 2 * D);
-            load_xw(eB, X1, base + D);
+            twB = twA;
+            load_e(eA, twA, base + 2 * D);
+            load_xw(eB, twB, X1, base + D);
             __builtin_amdgcn_sched_barrier(0);   // the loads are issued BEFORE the group that hides them multiplies
             multiply(eC, X0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < D; ++q) { eC[q] = eB[q]; eB[q] = eA[q]; }
-            load_e(eA, base + 3 * D);
-            load_xw(eB, X0, base + 2 * D);
+            twB = twA;
+            load_e(eA, twA, base + 3 * D);
+            load_xw(eB, twB, X0, base + 2 * D);
             __builtin_amdgcn_sched_barrier(0);
             multiply(eC, X1);   // T / 4 odd: the all-padding group (input row 0 into the trash row)
             __builtin_amdgcn_sched_barrier(0);
